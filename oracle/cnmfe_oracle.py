@@ -1,0 +1,629 @@
+"""CPU oracle for the CNMF-E factor-update hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a float64 NumPy/SciPy *restatement* of the reference's algorithm
+(zhoupc/CNMF_E @ 2024_08_07, MATLAB) for the background -> spatial -> temporal
+update loop.  Every function cites the reference file:line it follows.  It is
+the checker for the HIP engine: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  The product package
+(``cnmf_e_amd``) never imports it and has no CPU fallback.
+
+PARITY UNPINNED: the reference is MATLAB, there is no MATLAB/Octave in the build
+container, and the reference ships no tests / golden vectors for this path
+(SURVEY.md section 4, 8(c)).  The oracle is therefore pinned only by algebraic
+self-checks (tests/test_oracle_*.py): normal equations vs ``numpy.linalg``,
+HALS monotone objective, NNLS KKT conditions, planted-model recovery.
+
+Conventions: everything is column-major like MATLAB.  A "frame image" of an
+``nr x nc`` region is flattened with the row index fastest, so the pixel linear
+index is ``c*nr + r`` (0-based).  ``Y`` is ``d x T`` (pixels x frames).
+Positions ``[r0, r1, c0, c1]`` are 1-based and inclusive exactly as in
+``distribute_data.m`` so that they can be compared against the reference by eye.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+__all__ = [
+    "get_nhood", "distribute_geometry", "build_ring_W", "fit_ring_model",
+    "residual_ysig", "HALS_spatial", "HALS_spatial_thresh", "nnls", "nnls_spatial",
+    "HALS_temporal", "com", "determine_search_location", "connectivity_constraint",
+    "post_process_spatial", "OracleSources2D",
+]
+
+
+# --------------------------------------------------------------------------- #
+# geometry
+# --------------------------------------------------------------------------- #
+def _matlab_round(x):
+    """MATLAB round(): half away from zero."""
+    x = np.asarray(x, dtype=np.float64)
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
+
+
+def get_nhood(radius, k=None):
+    """Ring offsets (r_shift, c_shift).  endoscope/get_nhood.m:1-25."""
+    rsub = np.arange(-radius, radius + 1)
+    cind, rind = np.meshgrid(rsub, rsub)                     # get_nhood.m:9
+    R = np.sqrt(cind.astype(np.float64) ** 2 + rind ** 2)    # :10
+    kernel = (R >= radius) & (R < radius + 1)                # :11
+    # MATLAB find() walks column-major: column index slow, row index fast (:13)
+    c_idx, r_idx = np.nonzero(kernel.T)
+    r_shift = r_idx - radius
+    c_shift = c_idx - radius
+    if k is None or k > r_shift.size:                        # :17
+        return r_shift.astype(np.int64), c_shift.astype(np.int64)
+    temp = np.arctan2(r_shift, c_shift)                      # :20
+    ids = np.argsort(temp, kind="stable")                    # :21
+    ind = _matlab_round(np.linspace(1, ids.size, k)).astype(np.int64) - 1  # :22
+    return r_shift[ids[ind]].astype(np.int64), c_shift[ids[ind]].astype(np.int64)
+
+
+def distribute_geometry(d1, d2, patch_dims, w_overlap):
+    """patch_pos / block_pos (1-based inclusive).  endoscope/distribute_data.m:38-100,161-173."""
+    min_patch_width = 2 * w_overlap + 3                      # :40
+    pd = np.atleast_1d(np.asarray(patch_dims, dtype=np.float64)).copy()
+    pd[pd < min_patch_width] = min_patch_width               # :47
+    if pd.size == 1:
+        pd = np.array([pd[0], pd[0]])
+    pd = pd[:2]
+    nr_patch = int(_matlab_round(d1 / pd[0]))                # :57
+    nc_patch = int(_matlab_round(d2 / pd[1]))
+
+    def _idx(n_patch, dd, fix_last):
+        if n_patch <= 1:
+            return np.array([1, dd], dtype=np.int64)
+        idx = np.ceil(np.linspace(1, dd, n_patch + 1)).astype(np.int64)   # :62 / :74
+        if fix_last:
+            idx[-1] = dd                                     # :63 (rows only, as in the reference)
+        if idx[1] - idx[0] < min_patch_width:                # :64 / :75
+            idx = np.arange(1, dd + 1, min_patch_width, dtype=np.int64)
+            idx[-1] = dd
+        return idx
+
+    pr = _idx(nr_patch, d1, True)
+    pc = _idx(nc_patch, d2, False)
+    nr_patch = pr.size - 1
+    nc_patch = pc.size - 1
+    patch_pos = np.empty((nr_patch, nc_patch), dtype=object)
+    block_pos = np.empty((nr_patch, nc_patch), dtype=object)
+    for m in range(nr_patch):
+        for n in range(nc_patch):
+            patch_pos[m, n] = np.array([
+                pr[m], pr[m + 1] - (1 if m != nr_patch - 1 else 0),
+                pc[n], pc[n + 1] - (1 if n != nc_patch - 1 else 0)], dtype=np.int64)    # :167
+            block_pos[m, n] = np.array([
+                max(1, pr[m] - w_overlap - 1), min(d1, pr[m + 1] + w_overlap),
+                max(1, pc[n] - w_overlap - 1), min(d2, pc[n + 1] + w_overlap)], dtype=np.int64)  # :168-169
+    return patch_pos, block_pos
+
+
+def build_ring_W(patch, block, d1, d2, r_shift, c_shift):
+    """Initial ring matrix W (d_patch x d_block, uniform 1/count rows).
+
+    @Sources2D/initComponents_parallel.m:222-236 (dup. update_background_parallel.m:88-99).
+    """
+    r0, r1, c0, c1 = [int(v) for v in patch]
+    br0, br1, bc0, bc1 = [int(v) for v in block]
+    nr, nc = r1 - r0 + 1, c1 - c0 + 1
+    nr_b, nc_b = br1 - br0 + 1, bc1 - bc0 + 1
+    csub, rsub = np.meshgrid(np.arange(c0, c1 + 1), np.arange(r0, r1 + 1))   # :223
+    csub = csub.reshape(-1, 1, order="F")
+    rsub = rsub.reshape(-1, 1, order="F")
+    ii = np.repeat(np.arange(nr * nc)[:, None], r_shift.size, axis=1)        # :226
+    csub = csub + c_shift[None, :]
+    rsub = rsub + r_shift[None, :]
+    ind = (csub >= 1) & (csub <= d2) & (rsub >= 1) & (rsub <= d1)           # :229
+    jj = (csub - bc0) * nr_b + (rsub - br0 + 1) - 1                          # :230 (0-based)
+    temp = sp.csr_matrix((np.ones(int(ind.sum())), (ii[ind], jj[ind])),
+                         shape=(nr * nc, nr_b * nc_b))                       # :232
+    temp.sum_duplicates()
+    temp.sort_indices()
+    cnt = np.asarray(temp.sum(axis=1)).ravel()
+    return sp.diags(1.0 / cnt) @ temp                                        # :233
+
+
+def ind_patch_mask(patch, block):
+    """Logical nr_b x nc_b mask of patch pixels inside the block, flattened column-major.
+
+    update_spatial_parallel.m:140-141.
+    """
+    r0, r1, c0, c1 = [int(v) for v in patch]
+    br0, br1, bc0, bc1 = [int(v) for v in block]
+    m = np.zeros((br1 - br0 + 1, bc1 - bc0 + 1), dtype=bool)
+    m[r0 - br0:r1 - br0 + 1, c0 - bc0:c1 - bc0 + 1] = True
+    return m.reshape(-1, order="F")
+
+
+# --------------------------------------------------------------------------- #
+# background: ring model
+# --------------------------------------------------------------------------- #
+def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection=True):
+    """[W, b0] = fit_ring_model(...).  endoscope/fit_ring_model.m:1-127.
+
+    Y: d_b x T, A: d_b x K (dense or sparse), C: K x T, W_old: sparse d x d_b.
+    The outlier branch (:50-56, :62-67) is implemented for NaN thresh only
+    (no demo sets thresh_outlier) and raises otherwise.
+    """
+    Y = np.asarray(Y)
+    d_b, T = Y.shape
+    if A is None or A.shape[1] == 0:
+        A = np.ones((d_b, 1)); C = np.zeros((1, T))          # :15-17 (isempty(A))
+    if sp.issparse(A):
+        A = A.toarray()                                      # :18-23
+    A = np.asarray(A, dtype=np.float64)
+    C = np.asarray(C, dtype=np.float64)
+    W_old = sp.csr_matrix(W_old)
+    W_old.sort_indices()
+    # first run? (:25): number of distinct values in row 1, implicit zeros included
+    row0 = W_old.getrow(0)
+    vals = set(np.unique(row0.data).tolist())
+    if row0.nnz < W_old.shape[1]:
+        vals.add(0.0)
+    if len(vals) == 2:
+        ind_active = np.ones(W_old.shape[0], dtype=bool)     # :26
+    else:
+        ind_active = np.asarray(abs(W_old) @ A.sum(axis=1)).ravel() > 0     # :28
+    if ind_patch is None:
+        ind_patch = np.ones(d_b, dtype=bool)                 # :35
+    ind_patch = np.asarray(ind_patch, dtype=bool).ravel()
+
+    Ymean = Y.astype(np.float64).mean(axis=1)                # :42
+    Cmean = C.mean(axis=1)                                   # :43
+    b0 = Ymean[ind_patch] - A[ind_patch, :] @ Cmean          # :44
+    Yc = Y.astype(np.float64) - Ymean[:, None]               # :45
+    Cc = C - Cmean[:, None]                                  # :46
+    Bf = Yc - A @ Cc                                         # :47
+
+    if not np.isnan(thresh_outlier):
+        raise NotImplementedError("outlier branch (fit_ring_model.m:50-56) not restated")
+
+    pmax = int(np.max(np.asarray((W_old > 0).sum(axis=1)).ravel()))          # :60
+    nmax = pmax * 100                                        # :61
+    ind_pixels = np.nonzero(ind_patch)[0]                    # :71
+    d = ind_pixels.size
+    W = W_old.copy().tolil()
+    T = Bf.shape[1]
+    if with_projection:
+        nk = min(int(_matlab_round(T / 1)), nmax)            # :84
+        k = T // nk                                          # :85
+        if k != 1:
+            Bf = Bf[:, ::k]                                  # :87
+    vec_ones = np.ones((1, Bf.shape[1]))                     # :91 / :69
+    indptr, indices, data = W_old.indptr, W_old.indices, W_old.data
+    new_data = data.copy()
+    for m in range(d):                                       # :92 / :112
+        if not ind_active[m]:
+            continue
+        idx = ind_pixels[m]
+        sl = slice(indptr[m], indptr[m + 1])
+        nzmask = data[sl] != 0                               # :99 ind_ring = (W_old(m,:)~=0)
+        ring = indices[sl][nzmask]
+        y = Bf[idx, :]
+        X = np.vstack([Bf[ring, :], vec_ones])               # :101
+        XX = X @ X.T                                         # :103
+        Xy = X @ y                                           # :104
+        w = np.linalg.solve(XX + np.eye(XX.shape[0]) * np.trace(XX) * 1e-5, Xy)   # :106
+        pos = np.nonzero(nzmask)[0] + indptr[m]
+        new_data[pos] = w[:-1] + 1e-100                      # :107
+    W = sp.csr_matrix((new_data, indices.copy(), indptr.copy()), shape=W_old.shape)
+    return W, b0
+
+
+def ring_frame_stride(W_old, T, with_projection=True):
+    """The subsampling stride k of fit_ring_model.m:60,84-87 (helper for tests)."""
+    pmax = int(np.max(np.asarray((sp.csr_matrix(W_old) > 0).sum(axis=1)).ravel()))
+    if not with_projection:
+        return 1
+    nk = min(T, pmax * 100)
+    return T // nk
+
+
+# --------------------------------------------------------------------------- #
+# residual / background subtraction  (the "R1" expression)
+# --------------------------------------------------------------------------- #
+def residual_ysig(Y_block, A_prev, C_prev, W, b0, ind_patch):
+    """Ysig = Y(patch,:) - W*(Y - A_prev*C_prev) - (b0 - W*mean(...,2)).
+
+    @Sources2D/update_spatial_parallel.m:162-166 (= update_temporal_parallel.m:149-152).
+    """
+    Yb = np.asarray(Y_block, dtype=np.float64)
+    if A_prev is not None and A_prev.shape[1] > 0:
+        tmp_Y = Yb - (A_prev @ np.asarray(C_prev, dtype=np.float64))         # :163
+    else:
+        tmp_Y = Yb.copy()
+    ind_patch = np.asarray(ind_patch, dtype=bool).ravel()
+    W = sp.csr_matrix(W)
+    b0 = np.asarray(b0, dtype=np.float64).ravel()
+    return (Yb[ind_patch, :] - W @ tmp_Y) - (b0 - W @ tmp_Y.mean(axis=1))[:, None]   # :166
+
+
+# --------------------------------------------------------------------------- #
+# spatial
+# --------------------------------------------------------------------------- #
+def _prep_spatial(Y, A, C, active_pixel):
+    A = np.array(A.toarray() if sp.issparse(A) else A, dtype=np.float64, copy=True)
+    C = np.asarray(C, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    if active_pixel is None:
+        active = np.ones(A.shape, dtype=bool)
+    else:
+        active = np.asarray(active_pixel.toarray() if sp.issparse(active_pixel) else active_pixel).astype(bool)
+    return Y, A, C, active
+
+
+def HALS_spatial(Y, A, C, active_pixel=None, maxIter=1):
+    """utilities/HALS_spatial.m:1-45."""
+    Y, A, C, active = _prep_spatial(Y, A, C, active_pixel)
+    A[~active] = 0                                           # :26
+    K = A.shape[1]
+    Cmean = C.mean(axis=1); Ymean = Y.mean(axis=1); T = C.shape[1]
+    U = Y @ C.T - T * np.outer(Ymean, Cmean)                 # :31
+    V = C @ C.T - T * np.outer(Cmean, Cmean)                 # :32
+    cc = np.diag(V).copy()                                   # :33
+    for _ in range(maxIter):                                 # :36
+        for k in range(K):
+            if cc[k] == 0:
+                continue
+            ti = active[:, k]
+            ak = np.maximum(0, A[ti, k] + (U[ti, k] - A[ti, :] @ V[:, k]) / cc[k])   # :42
+            A[ti, k] = ak
+    return A
+
+
+def HALS_spatial_thresh(Y, A, C, active_pixel, maxIter, sn):
+    """utilities/HALS_spatial_thresh.m:1-53."""
+    Y, A, C, active = _prep_spatial(Y, A, C, active_pixel)
+    sn = np.asarray(sn, dtype=np.float64).reshape(-1)        # :27
+    A[~active] = 0                                           # :29
+    K = A.shape[1]
+    Cmean = C.mean(axis=1); Ymean = Y.mean(axis=1); T = C.shape[1]
+    U = Y @ C.T - T * np.outer(Ymean, Cmean)                 # :34
+    V = C @ C.T - T * np.outer(Cmean, Cmean)                 # :35
+    cc = np.diag(V).copy()                                   # :36
+    with np.errstate(divide="ignore"):
+        cc_thr = 3.0 / np.sqrt(cc)                           # :37
+    for _ in range(maxIter):                                 # :40
+        for k in range(K):
+            if cc[k] == 0:
+                continue
+            ti = active[:, k]
+            if ti.sum() == 0:
+                A[:, k] = 0                                  # :46-48
+                continue
+            ak = A[ti, k] + (U[ti, k] - A[ti, :] @ V[:, k]) / cc[k]          # :50
+            ak[ak < sn[ti] * cc_thr[k]] = 0                  # :51
+            A[ti, k] = ak
+    return A
+
+
+def nnls(A, b, s=None, tol=1e-9, maxIter=None):
+    """endoscope/nnls_spatial.m:41-109 (local function nnls)."""
+    A = np.asarray(A, dtype=np.float64); b = np.asarray(b, dtype=np.float64).ravel()
+    p = A.shape[1]
+    if s is None:
+        s = np.zeros(p)
+    if maxIter is None:
+        maxIter = p
+    if (s > 0).sum() > maxIter:
+        s = np.zeros(p)
+    mu = np.zeros(0)
+    for _ in range(maxIter):                                 # :76
+        l = b - A @ s                                        # :77
+        Pset = s > 0                                         # :78
+        if l.size == 0 or l.max() < tol:                     # :80
+            break
+        temp = int(np.argmax(l))                             # :84
+        Pset[temp] = True
+        if Pset.sum() > maxIter:                             # :86
+            break
+        while Pset.any():                                    # :90
+            mu = np.linalg.solve(A[np.ix_(Pset, Pset)], b[Pset])            # :93
+            if np.all(mu > tol):                             # :98
+                break
+            sP = s[Pset]
+            temp2 = sP / (sP - mu)                           # :102
+            temp2 = temp2[~(mu > tol)]                       # :103
+            a = temp2.min()                                  # :104
+            s[Pset] = sP + a * (mu - sP)                     # :105
+            Pset[s < tol] = False                            # :106
+        s[Pset] = mu                                         # :109
+    return s
+
+
+def nnls_spatial(Y, A, C, active_pixel=None, maxN=5):
+    """endoscope/nnls_spatial.m:1-38."""
+    Y = np.asarray(Y, dtype=np.float64); C = np.asarray(C, dtype=np.float64)
+    d = Y.shape[0]; K = C.shape[0]
+    if active_pixel is None:
+        active = np.ones((d, K), dtype=bool)
+    else:
+        active = np.asarray(active_pixel.toarray() if sp.issparse(active_pixel) else active_pixel).astype(bool)
+    Yc = Y - Y.mean(axis=1, keepdims=True)                   # :26-27
+    Cc = C - C.mean(axis=1, keepdims=True)                   # :28
+    CC = Cc @ Cc.T                                           # :29
+    YC = Cc @ Yc.T                                           # :30
+    ind_fit = np.nonzero(active.sum(axis=1) > 1e-9)[0]       # :31
+    Aout = np.zeros((d, K))                                  # :32
+    for m in ind_fit:                                        # :35
+        ind = active[m, :]
+        Aout[m, ind] = nnls(CC[np.ix_(ind, ind)], YC[ind, m], None, 1e-4, maxN)   # :37
+    return Aout
+
+
+# --------------------------------------------------------------------------- #
+# temporal
+# --------------------------------------------------------------------------- #
+def HALS_temporal(Y, A, C, maxIter=1, deconv_options=None):
+    """utilities/HALS_temporal.m:1-119 -- no-deconvolution branch (:64-68).
+
+    Returns (C, C_raw, cc).  The deconvolution branch (:70-104) needs OASIS and
+    MATLAB toolbox semantics (pwelch, fminbnd) that are parity-unpinned; it is
+    restated separately in oracle/oasis_oracle.py when present.
+    """
+    if deconv_options is not None:
+        raise NotImplementedError("deconvolution branch not restated in this oracle")
+    Y = np.asarray(Y, dtype=np.float64)
+    A = np.asarray(A.toarray() if sp.issparse(A) else A, dtype=np.float64)   # :47
+    C = np.array(C, dtype=np.float64, copy=True)
+    K = A.shape[1]; T = Y.shape[1]
+    C_old = C.copy()                                         # :43
+    C_raw = np.zeros((K, T))                                 # :45
+    U = A.T @ Y                                              # :48
+    V = A.T @ A                                              # :49
+    aa = np.diag(V).copy()                                   # :50
+    ind_update = np.nonzero(aa > 0)[0]                       # :51
+    for _ in range(maxIter):                                 # :59
+        for k in ind_update:
+            ck_raw = C[k, :] + (U[k, :] - V[k, :] @ C) / aa[k]               # :62
+            ck_raw = ck_raw - ck_raw.min()                   # :66
+            C[k, :] = ck_raw                                 # :67
+            C_raw[k, :] = ck_raw                             # :68
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cc = ((C * C_old).sum(axis=1) - T * C.mean(axis=1) * C_old.mean(axis=1)) / (
+            C.std(axis=1, ddof=1) * C_old.std(axis=1, ddof=1) * T)           # :116
+    return C, C_raw, cc
+
+
+# --------------------------------------------------------------------------- #
+# search location / post-processing
+# --------------------------------------------------------------------------- #
+def com(A, d1, d2):
+    """utilities/com.m:1-28 (2-D case).  Returns K x 2 (row, col), 1-based coordinates."""
+    A = sp.csc_matrix(A)
+    x = np.tile(np.arange(1, d1 + 1), d2).astype(np.float64)                 # Coor.x :21
+    y = np.repeat(np.arange(1, d2 + 1), d1).astype(np.float64)               # Coor.y :22
+    s = np.asarray(A.sum(axis=0)).ravel()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cm = np.vstack([A.T @ x, A.T @ y]).T / s[:, None]    # :24
+    cm[cm < 0] = 0                                           # :26
+    cm[cm[:, 0] > d1, 0] = d1
+    cm[cm[:, 1] > d2, 1] = d2
+    return cm
+
+
+def determine_search_location(A, d1, d2, min_size=3, max_size=8, dist=3):
+    """'ellipse' method.  utilities/determine_search_location.m:50-104."""
+    A = sp.csc_matrix(A, dtype=np.float64, copy=True).tolil()
+    d, nr = A.shape
+    ind_empty = np.asarray(A.sum(axis=0)).ravel() == 0       # :52
+    if ind_empty.any():
+        for k in np.nonzero(ind_empty)[0]:
+            A[0, k] = 1                                      # :54
+    A = A.tocsc()
+    x = np.tile(np.arange(1, d1 + 1), d2).astype(np.float64)
+    y = np.repeat(np.arange(1, d2 + 1), d1).astype(np.float64)
+    cm = com(A, d1, d2)                                      # :63
+    IND = np.zeros((d, nr), dtype=bool)
+    for i in range(nr):                                      # :71
+        a = np.asarray(A[:, i].todense()).ravel()
+        cor = np.stack([x - cm[i, 0], y - cm[i, 1]], axis=1)
+        Vr = (cor.T * a) @ cor / a.sum()                     # :73
+        D, V = np.linalg.eigh((Vr + Vr.T) / 2)               # :74 (ascending like MATLAB eig of sym.)
+        d11 = min(max_size ** 2, max(min_size ** 2, D[0]))   # :81
+        d22 = min(max_size ** 2, max(min_size ** 2, D[1]))   # :82
+        IND[:, i] = np.sqrt((cor @ V[:, 0]) ** 2 / d11 + (cor @ V[:, 1]) ** 2 / d22) <= dist   # :84
+    if ind_empty.any():
+        IND[:, ind_empty] = False                            # :103
+    return IND
+
+
+def _imopen_square(img, sz):
+    """Grey opening with a flat sz x sz square; MATLAB pads erosion with +inf and dilation with -inf."""
+    from scipy.ndimage import minimum_filter, maximum_filter
+    er = minimum_filter(img, size=sz, mode="constant", cval=np.inf)
+    return maximum_filter(er, size=sz, mode="constant", cval=-np.inf)
+
+
+def connectivity_constraint(img, thr=0.01, sz=5):
+    """endoscope/connectivity_constraint.m:1-18.  img: d1 x d2."""
+    from scipy.ndimage import label
+    img = np.array(img, dtype=np.float64, copy=True)
+    ind_max = int(np.argmax(img.reshape(-1, order="F")))     # :10 first max, column-major
+    ai_open = _imopen_square(img, sz)                        # :12-13
+    temp = ai_open > img.max() * thr                         # :15
+    l, _ = label(temp, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])          # :16 bwlabel(.,4)
+    lf = l.reshape(-1, order="F")
+    keep = (lf == lf[ind_max]).reshape(img.shape, order="F")
+    img[~keep] = 0                                           # :18
+    return img
+
+
+def post_process_spatial(A_img):
+    """@Sources2D/post_process_spatial.m:19-32 with the default constraints (connected only).
+
+    A_img: d1 x d2 x K.  Returns d x K (column-major flattening).
+    """
+    d1, d2, K = A_img.shape
+    out = np.zeros((d1 * d2, K))
+    for m in range(K):
+        out[:, m] = connectivity_constraint(A_img[:, :, m]).reshape(-1, order="F")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# method level: the three Sources2D update methods on a patched FOV
+# --------------------------------------------------------------------------- #
+class OracleSources2D:
+    """Float64 restatement of the three @Sources2D update methods (ring model, bg_ssub=1).
+
+    State mirrors Sources2D.m:10-57: A (d x K), C, C_raw (K x T), W{.}, b0{.}, b0_new,
+    A_prev, C_prev, P.sn, P.Ymean.  ``Yfull`` is the whole video as d1 x d2 x T;
+    blocks are cut from it the way get_patch_data.m:50-93 returns them.
+    """
+
+    def __init__(self, Yfull, d1, d2, T, patch_dims, ring_radius, A, C, sn, *,
+                 spatial_algorithm="hals", maxIter=5, num_neighbors=None,
+                 min_size=3, max_size=8, dist=3, bg_acceleration=True):
+        self.Y = Yfull
+        self.d1, self.d2, self.T = d1, d2, T
+        self.ring_radius = ring_radius
+        self.patch_pos, self.block_pos = distribute_geometry(d1, d2, patch_dims, ring_radius)  # Sources2D.m:236
+        self.A = sp.csc_matrix(A, dtype=np.float64)
+        self.C = np.array(C, dtype=np.float64)
+        self.C_raw = self.C.copy()
+        self.A_prev = self.A.copy()
+        self.C_prev = self.C.copy()
+        self.sn = np.asarray(sn, dtype=np.float64).reshape(d1, d2, order="F")
+        self.spatial_algorithm = spatial_algorithm
+        self.maxIter = maxIter
+        self.search = dict(min_size=min_size, max_size=max_size, dist=dist)
+        self.bg_acceleration = bg_acceleration
+        r_shift, c_shift = get_nhood(ring_radius, num_neighbors)
+        self.W, self.b0, self.Ymean = {}, {}, {}
+        for idx in np.ndindex(self.patch_pos.shape):
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            self.W[idx] = build_ring_W(p, b, d1, d2, r_shift, c_shift)
+            self.b0[idx] = np.zeros((p[1] - p[0] + 1) * (p[3] - p[2] + 1))   # initComponents_parallel.m:221
+            self.Ymean[idx] = self._block(p).astype(np.float64).mean(axis=1)  # P.Ymean (:338-339)
+        self.b0_new = None
+
+    # -- helpers ------------------------------------------------------------
+    def _block(self, pos):
+        r0, r1, c0, c1 = [int(v) for v in pos]
+        blk = self.Y[r0 - 1:r1, c0 - 1:c1, :]
+        return blk.reshape(-1, self.T, order="F")
+
+    def _mask(self, pos):
+        r0, r1, c0, c1 = [int(v) for v in pos]
+        m = np.zeros((self.d1, self.d2), dtype=bool)
+        m[r0 - 1:r1, c0 - 1:c1] = True
+        return m.reshape(-1, order="F")
+
+    def _patches(self):
+        # MATLAB linear order over the nr_patch x nc_patch cell: rows fastest
+        nr, nc = self.patch_pos.shape
+        return [(m, n) for n in range(nc) for m in range(nr)]
+
+    def reconstruct_b0(self):
+        out = np.zeros((self.d1, self.d2))
+        for idx in self._patches():
+            r0, r1, c0, c1 = [int(v) for v in self.patch_pos[idx]]
+            out[r0 - 1:r1, c0 - 1:c1] = self.b0[idx].reshape(r1 - r0 + 1, c1 - c0 + 1, order="F")
+        return out
+
+    def _ymean_full(self):
+        out = np.zeros((self.d1, self.d2))
+        for idx in self._patches():
+            r0, r1, c0, c1 = [int(v) for v in self.patch_pos[idx]]
+            out[r0 - 1:r1, c0 - 1:c1] = self.Ymean[idx].reshape(r1 - r0 + 1, c1 - c0 + 1, order="F")
+        return out
+
+    # -- background -----------------------------------------------------------
+    def update_background_parallel(self):
+        """@Sources2D/update_background_parallel.m:121-146,176-230,311-317."""
+        first = self._patches()[0]
+        row0 = sp.csr_matrix(self.W[first]).getrow(0)
+        vals = set(np.unique(row0.data).tolist())
+        if row0.nnz < row0.shape[1]:
+            vals.add(0.0)
+        flag_first = len(vals) == 2                          # :143
+        for idx in self._patches():
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            mask = self._mask(b)
+            ind = np.asarray((sp.csr_matrix(mask.astype(np.float64)) @ self.A).todense()).ravel() > 0   # :128
+            A_block = self.A[mask, :][:, ind]                # :129
+            C_block = self.C[ind, :]                         # :130
+            if A_block.shape[1] == 0 and not flag_first:     # :188
+                continue
+            ip = ind_patch_mask(p, b)                        # :203-204
+            Yb = self._block(b)                              # :208
+            sn_patch = self.sn.reshape(-1, order="F")[mask][ip]
+            self.W[idx], self.b0[idx] = fit_ring_model(Yb, A_block, C_block, self.W[idx], np.nan,
+                                                       sn_patch, ip, self.bg_acceleration)   # :218
+        self.b0_new = self.reconstruct_b0()                  # :315
+        self.A_prev = self.A.copy()                          # :316
+        self.C_prev = self.C.copy()                          # :317
+
+    # -- spatial -----------------------------------------------------------------
+    def update_spatial_parallel(self):
+        """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""
+        d1, d2 = self.d1, self.d2
+        IND = determine_search_location(self.A, d1, d2, **self.search)     # :66
+        K = self.A.shape[1]
+        A_ = np.zeros((d1 * d2, K))
+        Aprev_dense_any = self.A_prev
+        for idx in self._patches():
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            mb, mp = self._mask(b), self._mask(p)
+            halo = mb & ~mp                                  # mask==1 after patch overwritten with 2 (:84-85)
+            ind = np.nonzero(IND[mp, :].any(axis=0))[0]      # :87
+            if ind.size == 0:
+                continue                                     # :121-124 (update_sn=false)
+            A_patch = self.A[mb, :][:, ind]                  # :88
+            IND_patch = IND[mp, :][:, ind]                   # :89
+            sn_patch = self.sn.reshape(-1, order="F")[mp]    # :90
+            C_patch = self.C[ind, :]                         # :91
+            indp = np.nonzero(np.asarray(Aprev_dense_any[halo, :].sum(axis=0)).ravel() > 0)[0]   # :96 (halo only!)
+            A_prev_b = self.A_prev[mb, :][:, indp]           # :97
+            C_prev_b = self.C_prev[indp, :]                  # :98
+            ip = ind_patch_mask(p, b)
+            Yb = self._block(b)                              # :147
+            Ysig = residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)   # :162-166
+            A_pp = A_patch[ip, :]                            # :199
+            if self.spatial_algorithm == "hals":
+                temp = HALS_spatial(Ysig, A_pp, C_patch, IND_patch, 3)      # :203
+            elif self.spatial_algorithm == "hals_thresh":
+                temp = HALS_spatial_thresh(Ysig, A_pp, C_patch, IND_patch, 3, sn_patch)   # :205
+            else:
+                temp = nnls_spatial(Ysig, A_pp, C_patch, IND_patch, 20)     # :211
+            rows = np.nonzero(mp)[0]
+            for j, k in enumerate(ind):                      # :324-334 (write, not accumulate)
+                A_[rows, k] = temp[:, j]
+        self.A_raw = A_.copy()
+        A_img = A_.reshape(d1, d2, K, order="F")
+        self.A = sp.csc_matrix(post_process_spatial(A_img))  # :341
+        self.b0_new = self._ymean_full() - np.asarray(
+            self.A @ self.C.mean(axis=1)).reshape(d1, d2, order="F")        # :349
+
+    # -- temporal ----------------------------------------------------------------
+    def update_temporal_parallel(self):
+        """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295 (use_c_hat=true, no deconv)."""
+        K, T = self.C.shape
+        C_new = np.zeros((K, T)); aa = np.zeros(K)
+        for idx in self._patches():
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            mb = self._mask(b)
+            ind = np.nonzero(np.asarray(self.A[mb, :].sum(axis=0)).ravel() > 0)[0]          # :83
+            if ind.size == 0:
+                continue                                     # :123
+            A_b = self.A[mb, :][:, ind]                      # :84
+            C_b = self.C[ind, :]                             # :86
+            indp = np.nonzero(np.asarray(self.A_prev[mb, :].sum(axis=0)).ravel() > 0)[0]    # :90
+            A_prev_b = self.A_prev[mb, :][:, indp]
+            C_prev_b = self.C_prev[indp, :]
+            ip = ind_patch_mask(p, b)
+            Yb = self._block(b)
+            Ysig = residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)    # :149-152
+            A_pp = A_b[ip, :]
+            _, C_raw_p, _ = HALS_temporal(Ysig, A_pp, C_b, self.maxIter, None)             # :180
+            aa_p = np.asarray(A_pp.multiply(A_pp).sum(axis=0)).ravel()                      # :181
+            for j, k in enumerate(ind):                      # :269-278
+                C_new[k, :] += C_raw_p[j, :] * aa_p[j]
+                aa[k] += aa_p[j]
+        aa[aa == 0] = 1                                      # :279
+        self.C_raw = C_new / aa[:, None]                     # :280
+        self.C_raw = self.C_raw - self.C_raw.min(axis=1, keepdims=True)     # :285
+        self.C = self.C_raw.copy()                           # :286
+        self.b0_new = self._ymean_full() - np.asarray(
+            self.A @ self.C.mean(axis=1)).reshape(self.d1, self.d2, order="F")              # :293
