@@ -1,0 +1,78 @@
+"""ctypes binding of the C ABI declared in include/cnmfe.h.
+
+There is no CPU fallback: if the HIP shared library is missing or does not load,
+importing this module raises.  Build it with ``python -m cnmf_e_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnmfe_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "cnmf_e_amd: %s not found -- the HIP engine is mandatory (no CPU fallback). "
+        "Run `python -m cnmf_e_amd.build` (needs hipcc)." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+c_ctx = C.c_void_p
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+
+# every symbol include/cnmfe.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "cnmfe_last_error": (C.c_char_p, []),
+    "cnmfe_version": (C.c_char_p, []),
+    "cnmfe_create": (c_ctx, [C.c_int]),
+    "cnmfe_destroy": (None, [c_ctx]),
+    "cnmfe_patch_create": (C.c_int, [c_ctx, C.c_int, i32p, i32p, C.c_int32, C.c_int32, C.c_int64]),
+    "cnmfe_upload_block": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    "cnmfe_get_ymean": (C.c_int, [c_ctx, C.c_int, f64p]),
+    "cnmfe_ring_init": (C.c_int, [c_ctx, C.c_int, C.c_int32, C.c_int32]),
+    "cnmfe_ring_nnz": (C.c_int, [c_ctx, C.c_int, i64p, i32p]),
+    "cnmfe_ring_get_csr": (C.c_int, [c_ctx, C.c_int, i64p, i32p, f32p]),
+    "cnmfe_ring_set_values": (C.c_int, [c_ctx, C.c_int, f32p]),
+    "cnmfe_ring_first_run": (C.c_int, [c_ctx, C.c_int, C.POINTER(C.c_int)]),
+    "cnmfe_b0_get": (C.c_int, [c_ctx, C.c_int, f32p]),
+    "cnmfe_b0_set": (C.c_int, [c_ctx, C.c_int, f32p]),
+    "cnmfe_fit_ring_model": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,
+                                       C.c_double, C.c_int, f32p, i64p]),
+    "cnmfe_residual": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_void_p, C.c_int]),
+    "cnmfe_update_spatial": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,
+                                       i64p, i32p, f32p, C.c_int32, f32p]),
+    "cnmfe_hals_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,
+                                      f32p, f32p, f32p]),
+    "cnmfe_post_process_spatial": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, f32p, u8p]),
+    "cnmfe_profile_enable": (C.c_int, [c_ctx, C.c_int]),
+    "cnmfe_profile_reset": (C.c_int, [c_ctx]),
+    "cnmfe_profile_count": (C.c_int, [c_ctx]),
+    "cnmfe_profile_get": (C.c_int, [c_ctx, C.c_int, C.c_char_p, C.c_int, f64p, i64p]),
+    "cnmfe_synchronize": (C.c_int, [c_ctx]),
+    "cnmfe_set_option": (C.c_int, [c_ctx, C.c_char_p, C.c_int64]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == missing export
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+# enums of include/cnmfe.h
+F32, F64, U16, U8, F16 = 0, 1, 2, 3, 4
+HOST, DEVICE = 0, 1
+COLMAJOR, ROWMAJOR = 0, 1
+SPATIAL_HALS, SPATIAL_HALS_THRESH, SPATIAL_NNLS = 0, 1, 2
+
+
+class CnmfeError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise CnmfeError("cnmfe error %d: %s" % (rc, lib.cnmfe_last_error().decode("utf-8", "replace")))

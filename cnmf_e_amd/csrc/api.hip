@@ -1,0 +1,519 @@
+// C-ABI surface + context / data-plane / ring-pattern plumbing.   (gfx950 only)
+#include "common.hpp"
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+namespace cnmfe {
+thread_local char g_err[1024] = "";
+
+// ---------------------------------------------------------------------------------
+// dtype conversion on upload
+// ---------------------------------------------------------------------------------
+template <class S> __device__ inline float to_f32(S v) { return (float)v; }
+template <> __device__ inline float to_f32<__half>(__half v) { return __half2float(v); }
+
+template <class S>
+__global__ void k_convert(const S *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = to_f32<S>(src[i]);
+}
+
+// temporal mean of every block pixel, double accumulation (fit_ring_model.m:42, P.Ymean)
+__global__ void k_ymean(const float *__restrict__ Y, int64_t d_b, int64_t T, double *__restrict__ ym, float *__restrict__ ymf) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= d_b) return;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t t = 0;
+    for (; t + 3 < T; t += 4) {
+        s0 += Y[(t + 0) * d_b + q]; s1 += Y[(t + 1) * d_b + q];
+        s2 += Y[(t + 2) * d_b + q]; s3 += Y[(t + 3) * d_b + q];
+    }
+    for (; t < T; ++t) s0 += Y[t * d_b + q];
+    double m = ((s0 + s1) + (s2 + s3)) / (double)T;
+    ym[q] = m; ymf[q] = (float)m;
+}
+
+// W = 1/count on the in-FOV ring neighbours (initComponents_parallel.m:229-233)
+__global__ void k_ring_init(float *__restrict__ W, int64_t d, int nr, int p, const int *__restrict__ dr, const int *__restrict__ dc,
+                            int r0, int c0, int d1, int d2) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= d) return;
+    int r = r0 + (int)(m % nr), c = c0 + (int)(m / nr);     // absolute 1-based
+    int cnt = 0;
+    for (int i = 0; i < p; ++i) { int rr = r + dr[i], cc = c + dc[i]; cnt += (rr >= 1 && rr <= d1 && cc >= 1 && cc <= d2); }
+    float v = cnt ? 1.0f / (float)cnt : 0.0f;
+    for (int i = 0; i < p; ++i) { int rr = r + dr[i], cc = c + dc[i];
+        W[(int64_t)i * d + m] = (rr >= 1 && rr <= d1 && cc >= 1 && cc <= d2) ? v : 0.0f; }
+}
+
+// K x T column-major (k fastest) -> [k][ldc] row-major
+__global__ void k_transpose_in(const float *__restrict__ src, float *__restrict__ dst, int K, int64_t T, int64_t ldc) {
+    __shared__ float tile[32][33];
+    int64_t t0 = (int64_t)blockIdx.x * 32; int k0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int64_t t = t0 + j; int k = k0 + threadIdx.x;
+        tile[j][threadIdx.x] = (t < T && k < K) ? src[t * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int k = k0 + j; int64_t t = t0 + threadIdx.x;
+        if (k < K && t < T) dst[(int64_t)k * ldc + t] = tile[threadIdx.x][j];
+    }
+}
+__global__ void k_transpose_out(const float *__restrict__ src, int64_t ldc, float *__restrict__ dst, int K, int64_t T) {
+    __shared__ float tile[32][33];
+    int64_t t0 = (int64_t)blockIdx.x * 32; int k0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int k = k0 + j; int64_t t = t0 + threadIdx.x;
+        tile[j][threadIdx.x] = (k < K && t < T) ? src[(int64_t)k * ldc + t] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int64_t t = t0 + j; int k = k0 + threadIdx.x;
+        if (t < T && k < K) dst[t * K + k] = tile[threadIdx.x][j];
+    }
+}
+
+int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_t T, int order, int64_t *ldc_out) {
+    int64_t ldc = (T + 3) & ~int64_t(3);
+    *ldc_out = ldc;
+    RET(dst.ensure(std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
+    if (K == 0) return 0;
+    CK(hipMemsetAsync(dst.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    if (order == CNMFE_ROWMAJOR) {
+        CK(hipMemcpy2DAsync(dst.p, ldc * sizeof(float), C, T * sizeof(float), T * sizeof(float), K, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        RET(ctx->stage.ensure((size_t)K * T * sizeof(float)));
+        CK(hipMemcpyAsync(ctx->stage.p, C, (size_t)K * T * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        dim3 g((unsigned)((T + 31) / 32), (unsigned)((K + 31) / 32)), b(32, 8);
+        LAUNCH(ctx, "transpose_in", k_transpose_in, g, b, 0, ctx->stage.as<float>(), dst.as<float>(), K, T, ldc);
+    }
+    return 0;
+}
+
+int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int32_t K, int64_t T, int order) {
+    if (K == 0 || !C) return 0;
+    if (order == CNMFE_ROWMAJOR) {
+        CK(hipMemcpy2DAsync(C, T * sizeof(float), dC, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        RET(ctx->stage.ensure((size_t)K * T * sizeof(float)));
+        dim3 g((unsigned)((T + 31) / 32), (unsigned)((K + 31) / 32)), b(32, 8);
+        LAUNCH(ctx, "transpose_out", k_transpose_out, g, b, 0, dC, ldc, ctx->stage.as<float>(), K, T);
+        CK(hipMemcpyAsync(C, ctx->stage.p, (size_t)K * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
+    if (P->ymean_valid) return 0;
+    if (P->frames_uploaded < P->T) return fail(CNMFE_ESTATE, "block has %lld of %lld frames uploaded", (long long)P->frames_uploaded, (long long)P->T);
+    RET(P->ymean_d.ensure(P->d_b * sizeof(double)));
+    RET(P->ymean_f.ensure(P->d_b * sizeof(float)));
+    LAUNCH(ctx, "ymean", k_ymean, dim3((unsigned)((P->d_b + 255) / 256)), dim3(256), 0,
+           P->Y.as<float>(), P->d_b, P->T, P->ymean_d.as<double>(), P->ymean_f.as<float>());
+    P->ymean_valid = true;
+    return 0;
+}
+
+// length(unique(W_old(1,:)))==2 on row 1 of the resident W, implicit zeros of the sparse row included
+int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first) {
+    const int p = P->p;
+    std::vector<float> row0(p);
+    CK(hipMemcpy2DAsync(row0.data(), sizeof(float), P->W.p, P->d * sizeof(float), sizeof(float), p, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    std::vector<float> u;
+    const int r = P->prect[0], c = P->prect[2];
+    int nvalid = 0;
+    for (int i = 0; i < p; ++i) {
+        const int rr = r + P->dr[i], cc = c + P->dc[i];
+        if (rr < 1 || rr > P->d1 || cc < 1 || cc > P->d2) continue;
+        ++nvalid; u.push_back(row0[i]);
+    }
+    if (nvalid < P->d_b) u.push_back(0.f);
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    *first = u.size() == 2;
+    return 0;
+}
+
+// ring offsets: get_nhood.m:1-25, then sorted by (dc, dr) == MATLAB sparse column order
+static void ring_offsets(int radius, int k, std::vector<int32_t> &dr, std::vector<int32_t> &dc) {
+    dr.clear(); dc.clear();
+    for (int c = -radius; c <= radius; ++c)
+        for (int r = -radius; r <= radius; ++r) {
+            int d2 = c * c + r * r;                         // R>=radius && R<radius+1 on integers (:10-11)
+            if (d2 >= radius * radius && d2 < (radius + 1) * (radius + 1)) { dr.push_back(r); dc.push_back(c); }
+        }
+    int n = (int)dr.size();
+    if (k <= 0 || k > n) return;                            // :17
+    std::vector<int> ids(n);
+    for (int i = 0; i < n; ++i) ids[i] = i;
+    std::vector<double> ang(n);
+    for (int i = 0; i < n; ++i) ang[i] = atan2((double)dr[i], (double)dc[i]);    // :20
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return ang[a] < ang[b]; });   // :21
+    std::vector<std::pair<int, int>> sel;
+    for (int j = 0; j < k; ++j) {
+        double x = (k == 1) ? 1.0 : 1.0 + (double)(n - 1) * j / (double)(k - 1);               // linspace(1,n,k)
+        int idx = (int)floor(x + 0.5) - 1;                                                        // round()
+        sel.push_back({dc[ids[idx]], dr[ids[idx]]});
+    }
+    std::sort(sel.begin(), sel.end());
+    sel.erase(std::unique(sel.begin(), sel.end()), sel.end());
+    dr.clear(); dc.clear();
+    for (auto &s : sel) { dc.push_back(s.first); dr.push_back(s.second); }
+}
+}  // namespace cnmfe
+
+using namespace cnmfe;
+
+cnmfe_ctx::~cnmfe_ctx() {
+    for (auto &kv : patches) delete kv.second;
+    prof.drain();
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+extern "C" {
+
+const char *cnmfe_last_error(void) { return g_err; }
+const char *cnmfe_version(void) { return "cnmfe-mi355x 0.1 (gfx950)"; }
+
+cnmfe_ctx *cnmfe_create(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(CNMFE_EHIP, "no HIP device visible (%s)", hipGetErrorString(e)); return nullptr; }
+    if (device < 0 || device >= n) { fail(CNMFE_EINVAL, "device %d out of range (0..%d)", device, n - 1); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(CNMFE_EHIP, "hipSetDevice(%d) failed", device); return nullptr; }
+    cnmfe_ctx *ctx = new cnmfe_ctx();
+    ctx->device = device;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    return ctx;
+}
+
+void cnmfe_destroy(cnmfe_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+}
+
+int cnmfe_synchronize(cnmfe_ctx *ctx) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
+    static const char *known[] = {"r1_variant", "gram_mode", "debug", nullptr};
+    for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
+    return fail(CNMFE_EINVAL, "unknown option '%s'", name);
+}
+
+int cnmfe_patch_create(cnmfe_ctx *ctx, int patch_id, const int32_t pr[4], const int32_t br[4], int32_t d1, int32_t d2, int64_t T) {
+    if (!ctx || !pr || !br) return fail(CNMFE_EINVAL, "null argument");
+    if (d1 <= 0 || d2 <= 0 || T <= 0) return fail(CNMFE_EINVAL, "bad dims d1=%d d2=%d T=%lld", d1, d2, (long long)T);
+    if (!(1 <= br[0] && br[0] <= pr[0] && pr[0] <= pr[1] && pr[1] <= br[1] && br[1] <= d1 &&
+          1 <= br[2] && br[2] <= pr[2] && pr[2] <= pr[3] && pr[3] <= br[3] && br[3] <= d2))
+        return fail(CNMFE_EINVAL, "patch [%d %d %d %d] must lie inside block [%d %d %d %d] inside the %dx%d FOV",
+                    pr[0], pr[1], pr[2], pr[3], br[0], br[1], br[2], br[3], d1, d2);
+    CK(hipSetDevice(ctx->device));
+    if (ctx->patches.count(patch_id)) { delete ctx->patches[patch_id]; ctx->patches.erase(patch_id); }
+    Patch *P = new Patch();
+    memcpy(P->prect, pr, sizeof(P->prect)); memcpy(P->brect, br, sizeof(P->brect));
+    P->d1 = d1; P->d2 = d2; P->T = T;
+    P->nr = pr[1] - pr[0] + 1; P->nc = pr[3] - pr[2] + 1;
+    P->nr_b = br[1] - br[0] + 1; P->nc_b = br[3] - br[2] + 1;
+    P->roff = pr[0] - br[0]; P->coff = pr[2] - br[2];
+    P->d = (int64_t)P->nr * P->nc; P->d_b = (int64_t)P->nr_b * P->nc_b;
+    int rc = P->Y.ensure((size_t)P->d_b * T * sizeof(float));
+    if (rc) { delete P; return rc; }
+    ctx->patches[patch_id] = P;
+    return 0;
+}
+
+int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, int memspace, int64_t t0, int64_t nt) {
+    if (!ctx || !Y) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (t0 < 0 || nt <= 0 || t0 + nt > P->T) return fail(CNMFE_EINVAL, "frames [%lld,%lld) outside [0,%lld)", (long long)t0, (long long)(t0 + nt), (long long)P->T);
+    CK(hipSetDevice(ctx->device));
+    size_t esz = dtype == CNMFE_F32 ? 4 : dtype == CNMFE_F64 ? 8 : dtype == CNMFE_U16 ? 2 : dtype == CNMFE_U8 ? 1 : dtype == CNMFE_F16 ? 2 : 0;
+    if (!esz) return fail(CNMFE_EINVAL, "unknown dtype %d", dtype);
+    if (memspace != CNMFE_HOST && memspace != CNMFE_DEVICE) return fail(CNMFE_EINVAL, "unknown memspace %d", memspace);
+    float *dst = P->Y.as<float>() + t0 * P->d_b;
+    int64_t n = nt * P->d_b;
+    if (dtype == CNMFE_F32) {
+        CK(hipMemcpyAsync(dst, Y, (size_t)n * 4, memspace == CNMFE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        // stage in slabs of <= 64 Mi elements, convert on device
+        const int64_t slab = int64_t(1) << 26;
+        for (int64_t o = 0; o < n; o += slab) {
+            int64_t m = std::min(slab, n - o);
+            const void *src = (const char *)Y + (size_t)o * esz;
+            if (memspace == CNMFE_HOST) {
+                RET(ctx->stage.ensure((size_t)m * esz));
+                CK(hipMemcpyAsync(ctx->stage.p, src, (size_t)m * esz, hipMemcpyHostToDevice, ctx->stream));
+                src = ctx->stage.p;
+            }
+            dim3 g((unsigned)std::min<int64_t>((m + 255) / 256, 65535)), b(256);
+            switch (dtype) {
+                case CNMFE_F64: LAUNCH(ctx, "convert", k_convert<double>, g, b, 0, (const double *)src, dst + o, m); break;
+                case CNMFE_U16: LAUNCH(ctx, "convert", k_convert<uint16_t>, g, b, 0, (const uint16_t *)src, dst + o, m); break;
+                case CNMFE_U8:  LAUNCH(ctx, "convert", k_convert<uint8_t>, g, b, 0, (const uint8_t *)src, dst + o, m); break;
+                default:        LAUNCH(ctx, "convert", k_convert<__half>, g, b, 0, (const __half *)src, dst + o, m); break;
+            }
+            if (memspace == CNMFE_HOST) CK(hipStreamSynchronize(ctx->stream));   // staging buffer reuse
+        }
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    P->frames_uploaded += nt;
+    P->ymean_valid = false; P->ysig_valid = false;
+    if (ctx->ysig_patch == patch_id) ctx->ysig_patch = -1;
+    return 0;
+}
+
+int cnmfe_get_ymean(cnmfe_ctx *ctx, int patch_id, double *out) {
+    if (!ctx || !out) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    CK(hipSetDevice(ctx->device));
+    RET(ensure_ymean(ctx, P));
+    CK(hipMemcpyAsync(out, P->ymean_d.p, P->d_b * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_neighbors) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (radius < 1 || radius > 64) return fail(CNMFE_EINVAL, "ring radius %d out of range", radius);
+    CK(hipSetDevice(ctx->device));
+    ring_offsets(radius, num_neighbors, P->dr, P->dc);
+    P->p = (int32_t)P->dr.size(); P->radius = radius;
+    if (P->p > PMAX_RING) return fail(CNMFE_EUNSUPPORTED, "ring with %d neighbours exceeds the supported %d", P->p, PMAX_RING);
+    // every in-FOV ring neighbour of a patch pixel must be inside the block
+    int h = radius;
+    if ((P->prect[0] - P->brect[0] < std::min(h, P->prect[0] - 1)) || (P->brect[1] - P->prect[1] < std::min(h, P->d1 - P->prect[1])) ||
+        (P->prect[2] - P->brect[2] < std::min(h, P->prect[2] - 1)) || (P->brect[3] - P->prect[3] < std::min(h, P->d2 - P->prect[3])))
+        return fail(CNMFE_EINVAL, "block halo is narrower than the ring radius %d", radius);
+    RET(to_dev(ctx, P->ring_dr, P->dr.data(), P->dr.size()));
+    RET(to_dev(ctx, P->ring_dc, P->dc.data(), P->dc.size()));
+    RET(P->W.ensure((size_t)P->p * P->d * sizeof(float)));
+    RET(P->b0.ensure(P->d * sizeof(double)));
+    CK(hipMemsetAsync(P->b0.p, 0, P->d * sizeof(double), ctx->stream));          // initComponents_parallel.m:221
+    LAUNCH(ctx, "ring_init", k_ring_init, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
+           P->W.as<float>(), P->d, P->nr, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->prect[0], P->prect[2], P->d1, P->d2);
+    CK(hipStreamSynchronize(ctx->stream));
+    P->ring_ready = true; P->ysig_valid = false;
+    return 0;
+}
+
+static int64_t ring_count_nnz(const Patch *P) {
+    int64_t nnz = 0;
+    for (int i = 0; i < P->p; ++i) {
+        // rows r with 1 <= r + dr <= d1 within the patch rows, same for columns
+        int64_t rlo = std::max<int64_t>(P->prect[0], 1 - P->dr[i]), rhi = std::min<int64_t>(P->prect[1], P->d1 - P->dr[i]);
+        int64_t clo = std::max<int64_t>(P->prect[2], 1 - P->dc[i]), chi = std::min<int64_t>(P->prect[3], P->d2 - P->dc[i]);
+        if (rhi >= rlo && chi >= clo) nnz += (rhi - rlo + 1) * (chi - clo + 1);
+    }
+    return nnz;
+}
+
+int cnmfe_ring_nnz(cnmfe_ctx *ctx, int patch_id, int64_t *nnz, int32_t *p) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    if (nnz) *nnz = ring_count_nnz(P);
+    if (p) *p = P->p;
+    return 0;
+}
+
+int cnmfe_ring_get_csr(cnmfe_ctx *ctx, int patch_id, int64_t *rowptr, int32_t *col, float *val) {
+    if (!ctx || !rowptr || !col || !val) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    CK(hipSetDevice(ctx->device));
+    std::vector<float> W((size_t)P->p * P->d);
+    CK(hipMemcpyAsync(W.data(), P->W.p, W.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    int64_t e = 0;
+    for (int64_t m = 0; m < P->d; ++m) {
+        rowptr[m] = e;
+        int r = P->prect[0] + (int)(m % P->nr), c = P->prect[2] + (int)(m / P->nr);
+        for (int i = 0; i < P->p; ++i) {
+            int rr = r + P->dr[i], cc = c + P->dc[i];
+            if (rr < 1 || rr > P->d1 || cc < 1 || cc > P->d2) continue;
+            col[e] = (int32_t)((int64_t)(cc - P->brect[2]) * P->nr_b + (rr - P->brect[0]));
+            val[e] = W[(size_t)i * P->d + m];
+            ++e;
+        }
+    }
+    rowptr[P->d] = e;
+    return 0;
+}
+
+int cnmfe_ring_set_values(cnmfe_ctx *ctx, int patch_id, const float *val) {
+    if (!ctx || !val) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    CK(hipSetDevice(ctx->device));
+    std::vector<float> W((size_t)P->p * P->d, 0.f);
+    int64_t e = 0;
+    for (int64_t m = 0; m < P->d; ++m) {
+        int r = P->prect[0] + (int)(m % P->nr), c = P->prect[2] + (int)(m / P->nr);
+        for (int i = 0; i < P->p; ++i) {
+            int rr = r + P->dr[i], cc = c + P->dc[i];
+            if (rr < 1 || rr > P->d1 || cc < 1 || cc > P->d2) continue;
+            W[(size_t)i * P->d + m] = val[e++];
+        }
+    }
+    CK(hipMemcpyAsync(P->W.p, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    P->ysig_valid = false;
+    return 0;
+}
+
+int cnmfe_ring_first_run(cnmfe_ctx *ctx, int patch_id, int *first_run) {
+    if (!ctx || !first_run) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    CK(hipSetDevice(ctx->device));
+    bool f = false;
+    RET(ring_first_run(ctx, P, &f));
+    *first_run = f ? 1 : 0;
+    return 0;
+}
+
+int cnmfe_b0_get(cnmfe_ctx *ctx, int patch_id, float *b0) {
+    if (!ctx || !b0) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    CK(hipSetDevice(ctx->device));
+    std::vector<double> tmp(P->d);
+    CK(hipMemcpyAsync(tmp.data(), P->b0.p, P->d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < P->d; ++i) b0[i] = (float)tmp[i];
+    return 0;
+}
+
+int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0) {
+    if (!ctx || !b0) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    CK(hipSetDevice(ctx->device));
+    std::vector<double> tmp(P->d);
+    for (int64_t i = 0; i < P->d; ++i) tmp[i] = (double)b0[i];
+    CK(hipMemcpyAsync(P->b0.p, tmp.data(), P->d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    P->ysig_valid = false;
+    return 0;
+}
+
+static int check_csc(const char *what, int32_t K, int64_t nrow, const int64_t *colptr, const int32_t *rowidx) {
+    if (K < 0) return fail(CNMFE_EINVAL, "%s: K=%d", what, K);
+    if (K == 0) return 0;
+    if (!colptr) return fail(CNMFE_EINVAL, "%s: null colptr", what);
+    if (colptr[0] != 0) return fail(CNMFE_EINVAL, "%s: colptr[0] != 0", what);
+    for (int32_t k = 0; k < K; ++k) if (colptr[k + 1] < colptr[k]) return fail(CNMFE_EINVAL, "%s: colptr not monotone at %d", what, k);
+    int64_t nnz = colptr[K];
+    if (nnz && !rowidx) return fail(CNMFE_EINVAL, "%s: null rowidx", what);
+    for (int32_t k = 0; k < K; ++k)
+        for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
+            if (rowidx[e] < 0 || rowidx[e] >= nrow) return fail(CNMFE_EINVAL, "%s: row index %d out of [0,%lld)", what, rowidx[e], (long long)nrow);
+            if (e > colptr[k] && rowidx[e] <= rowidx[e - 1]) return fail(CNMFE_EINVAL, "%s: rows of column %d not strictly ascending", what, k);
+        }
+    return 0;
+}
+
+int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                         const float *A_val, const float *C, int c_order, double thresh_outlier, int with_projection,
+                         float *b0_out, int64_t info[4]) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    if (!(thresh_outlier != thresh_outlier))
+        return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 outlier branch is not built)");
+    RET(check_csc("A", K, P->d_b, A_colptr, A_rowidx));
+    if (K > 0 && (!A_val || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
+    CK(hipSetDevice(ctx->device));
+    RET(ensure_ymean(ctx, P));
+    int64_t dummy[4];
+    int rc = bg_fit_ring(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, b0_out, info ? info : dummy);
+    P->ysig_valid = false;
+    if (ctx->ysig_patch == patch_id) ctx->ysig_patch = -1;
+    return rc;
+}
+
+int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
+                   const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    RET(check_csc("A_prev", Ksel, P->d_b, A_colptr, A_rowidx));
+    if (Ksel > 0 && (!A_val || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
+    CK(hipSetDevice(ctx->device));
+    RET(ensure_ymean(ctx, P));
+    return residual_run(ctx, P, patch_id, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);
+}
+
+int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K, const int64_t *A_colptr,
+                         const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+                         const int64_t *IND_colptr, const int32_t *IND_rowidx, const float *sn, int32_t param, float *A_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (algorithm < CNMFE_SPATIAL_HALS || algorithm > CNMFE_SPATIAL_NNLS) return fail(CNMFE_EINVAL, "unknown spatial algorithm %d", algorithm);
+    if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
+    RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
+    RET(check_csc("IND", K, P->d, IND_colptr, IND_rowidx));
+    if (!C || !A_out) return fail(CNMFE_EINVAL, "null C / A_out");
+    if (algorithm == CNMFE_SPATIAL_HALS_THRESH && !sn) return fail(CNMFE_EINVAL, "HALS_THRESH needs sn");
+    if (param <= 0) return fail(CNMFE_EINVAL, "maxIter/maxN must be positive");
+    CK(hipSetDevice(ctx->device));
+    return spatial_run(ctx, P, algorithm, K, A_colptr, A_rowidx, A_val, C, c_order, IND_colptr, IND_rowidx, sn, param, A_out);
+}
+
+int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                        const float *A_val, const float *C_in, int c_order, int32_t maxIter,
+                        float *C_out, float *C_raw_out, float *aa_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
+    RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
+    if (!A_val || !C_in) return fail(CNMFE_EINVAL, "null A_val / C_in");
+    if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
+    CK(hipSetDevice(ctx->device));
+    return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out);
+}
+
+int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr,
+                               const int32_t *A_rowidx, const float *A_val, uint8_t *keep) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (d1 <= 0 || d2 <= 0) return fail(CNMFE_EINVAL, "bad dims");
+    RET(check_csc("A", K, (int64_t)d1 * d2, A_colptr, A_rowidx));
+    if (K == 0) return 0;
+    if (!A_val || !keep) return fail(CNMFE_EINVAL, "null A_val / keep");
+    CK(hipSetDevice(ctx->device));
+    return postproc_run(ctx, d1, d2, K, A_colptr, A_rowidx, A_val, keep);
+}
+
+int cnmfe_profile_enable(cnmfe_ctx *ctx, int on) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.drain(); ctx->prof.on = on != 0; return 0; }
+int cnmfe_profile_reset(cnmfe_ctx *ctx) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.reset(); return 0; }
+int cnmfe_profile_count(cnmfe_ctx *ctx) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.drain(); return (int)ctx->prof.names.size(); }
+int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int cap, double *total_ms, int64_t *calls) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    ctx->prof.drain();
+    if (i < 0 || i >= (int)ctx->prof.names.size()) return fail(CNMFE_EINVAL, "profile index %d out of range", i);
+    if (name && cap > 0) { strncpy(name, ctx->prof.names[i].c_str(), cap - 1); name[cap - 1] = 0; }
+    if (total_ms) *total_ms = ctx->prof.total_ms[i];
+    if (calls) *calls = ctx->prof.calls[i];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,421 @@
+// B1/B2: ring-model background fit  ==  endoscope/fit_ring_model.m:1-127  on the resident block.
+//
+// The reference regresses, per patch pixel m, the centred background residual Bf(m,:) on the
+// <=p ring neighbours Bf(ring(m),:) plus a constant: a (p+1)x(p+1) Gram + solve per pixel, with the
+// operands GATHERED rows of one shared matrix (naive: 2*d*(p+1)^2*T flop and d*p*T gathered floats).
+// MI355X formulation ("local covariance"):
+//   B1  Bf = (Y - Ymean) - A*(C - Cmean)  written once, fp32, tiled as [16x16-pixel block][frame][256]
+//   B2a Cov(a,b) = sum_t Bf(a,t)*Bf(b,t) for every pair of pixels whose 16x16 blocks are within
+//       +-2 blocks: a block-sparse SYRK, 256x256xT' GEMMs on the fp64 MFMA pipe
+//       (v_mfma_f64_16x16x4_f64; fp32 inputs are exact in fp64, accumulation is fp64 like MATLAB's)
+//   B2b per pixel: gather the (p+1)^2 Gram and the RHS from the covariance table, add the ridge
+//       1e-5*trace (fit_ring_model.m:106), Cholesky-solve in fp64 in LDS, write the p weights.
+// Every ring pair of every patch pixel lies within +-2 blocks, so B2a computes each needed
+// covariance exactly once (symmetric pairs once) instead of once per centre pixel.
+#include "common.hpp"
+
+namespace cnmfe {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct BgGeom {
+    int nr, nc, nr_b, nc_b, roff, coff;    // patch / block sizes, patch origin in block
+    int r0_abs, c0_abs;                    // absolute 1-based row/col of block pixel (0,0)
+    int d1, d2;
+    int nbr, nbc;                          // 16x16 blocks tiling the block region
+    int64_t d, d_b, T, Tp, Tpad;           // Tp frames used (stride kstride), padded to a multiple of 16
+    int kstride;
+    int p;
+};
+
+// ---- B1 ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_build_bf(const float *__restrict__ Y, const float *__restrict__ ymean_f, BgGeom g,
+                                                  const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
+                                                  const float *__restrict__ Cc, int64_t ldc, float *__restrict__ bf, int tchunk) {
+    const int blk = blockIdx.x;                    // 16x16 block id, column-major over (nbr, nbc)
+    const int bi = blk % g.nbr, bj = blk / g.nbr;
+    const int lp = threadIdx.x;                    // local pixel: (lp & 15) row, (lp >> 4) col
+    const int rb = bi * BLK + (lp & 15), cb = bj * BLK + (lp >> 4);
+    const bool in = rb < g.nr_b && cb < g.nc_b;
+    const int64_t q = in ? (int64_t)cb * g.nr_b + rb : 0;
+    const float ym = in ? ymean_f[q] : 0.f;
+    int e0 = 0, e1 = 0;
+    if (in && arow) { e0 = arow[q]; e1 = arow[q + 1]; }
+    const int64_t tp0 = (int64_t)blockIdx.y * tchunk;
+    const int64_t tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
+    float *out = bf + ((int64_t)blk * g.Tpad) * BLKPX + lp;
+    for (int64_t tp = tp0; tp < tp1; ++tp) {
+        float v = 0.f;
+        if (in && tp < g.Tp) {
+            const int64_t t = tp * g.kstride;
+            v = Y[t * g.d_b + q] - ym;
+            for (int e = e0; e < e1; ++e) v -= aval[e] * Cc[(int64_t)acol[e] * ldc + t];
+        }
+        out[tp * BLKPX] = v;
+    }
+}
+
+// row sums of Bf over the used frames (the "ones" row of X, fit_ring_model.m:101)
+__global__ void __launch_bounds__(256) k_rowsum(const float *__restrict__ bf, int64_t Tpad, double *__restrict__ rs) {
+    const int64_t blk = blockIdx.x;
+    const float *src = bf + blk * Tpad * BLKPX + threadIdx.x;
+    double s0 = 0, s1 = 0;
+    int64_t t = 0;
+    for (; t + 1 < Tpad; t += 2) { s0 += src[t * BLKPX]; s1 += src[(t + 1) * BLKPX]; }
+    if (t < Tpad) s0 += src[t * BLKPX];
+    rs[blk * BLKPX + threadIdx.x] = s0 + s1;
+}
+
+// ---- B2a: block-sparse SYRK on the fp64 matrix pipe ---------------------------------------------
+// One workgroup = one 128x128 quadrant of one 256x256 block-pair covariance; 4 waves in 2x2, each
+// 64x64 = 4x4 MFMA tiles (v_mfma_f64_16x16x4_f64: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D[row=(l>>4)+4*reg][col=l&15]).  K (=frames) advances 16 per LDS stage, fp32 tiles [16][128] with
+// the row stride padded to 144 floats so the four k-rows of a fragment hit different bank halves.
+constexpr int GK = 16, GLD = 144;
+
+__global__ void __launch_bounds__(256, 2) k_gram_f64(const float *__restrict__ bf, int64_t Tpad, const int2 *__restrict__ pairs,
+                                                     int npairs, double *__restrict__ cov) {
+    __shared__ __attribute__((aligned(16))) float sA[2][GK * GLD];
+    __shared__ __attribute__((aligned(16))) float sB[2][GK * GLD];
+    // XCD-aware remap: consecutive logical ids (same I block, neighbouring J) share an L2
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    const int pair = bid >> 2, quad = bid & 3;
+    if (pair >= npairs) return;
+    const int ih = quad & 1, jh = quad >> 1;
+    const int2 pr = pairs[pair];
+    const float *gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 128;
+    const float *gB = bf + ((int64_t)pr.y * Tpad) * BLKPX + jh * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    // staging: 16 rows x 128 floats = 512 float4 per operand, 2 per thread
+    const int lr = tid >> 5, lc = (tid & 31) * 4;       // rows lr and lr+8
+    float4 ra0, ra1, rb0, rb1;
+    auto gload = [&](int64_t t0) {
+        ra0 = *reinterpret_cast<const float4 *>(gA + (t0 + lr) * BLKPX + lc);
+        ra1 = *reinterpret_cast<const float4 *>(gA + (t0 + lr + 8) * BLKPX + lc);
+        rb0 = *reinterpret_cast<const float4 *>(gB + (t0 + lr) * BLKPX + lc);
+        rb1 = *reinterpret_cast<const float4 *>(gB + (t0 + lr + 8) * BLKPX + lc);
+    };
+    auto sstore = [&](int buf) {
+        *reinterpret_cast<float4 *>(&sA[buf][lr * GLD + lc]) = ra0;
+        *reinterpret_cast<float4 *>(&sA[buf][(lr + 8) * GLD + lc]) = ra1;
+        *reinterpret_cast<float4 *>(&sB[buf][lr * GLD + lc]) = rb0;
+        *reinterpret_cast<float4 *>(&sB[buf][(lr + 8) * GLD + lc]) = rb1;
+    };
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    const int nst = (int)(Tpad / GK);
+    gload(0); sstore(0);
+    __syncthreads();
+    const int fa = wi * 64 + (lane & 15), fb = wj * 64 + (lane & 15), fk = lane >> 4;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) gload((int64_t)(st + 1) * GK);
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = (double)sA[buf][(kk + fk) * GLD + fa + i * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = (double)sB[buf][(kk + fk) * GLD + fb + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nst) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    double *out = cov + (int64_t)pair * BLKPX * BLKPX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ih * 128 + wi * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int col = jh * 128 + wj * 64 + j * 16 + (lane & 15);
+                out[(int64_t)row * BLKPX + col] = acc[i][j][r];
+            }
+}
+
+// ---- helpers on the covariance table ----------------------------------------------------------------
+struct CovTab {
+    const double *cov; const int *pair_of;   // pair_of[blk*NREL + rel] or -1
+    int nbr, nbc;
+};
+// canonical displacement index: dC in {0,1,2}; dC==0 -> dR in {0,1,2} (0..2); dC==1 -> dR in -2..2 (3..7); dC==2 -> (8..12)
+__device__ __forceinline__ int rel_index(int dR, int dC) { return dC == 0 ? dR : (dC == 1 ? 5 + dR : 10 + dR); }
+// Cov(a,b) for block pixels a=(ra,ca), b=(rb,cb) (block coordinates)
+__device__ __forceinline__ double cov_lookup(const CovTab &t, int ra, int ca, int rb, int cb) {
+    int ia = ra >> 4, ja = ca >> 4, ib = rb >> 4, jb = cb >> 4;
+    int dR = ib - ia, dC = jb - ja;
+    if (dC < 0 || (dC == 0 && dR < 0)) {          // swap so that the displacement is canonical
+        int t0;
+        t0 = ra; ra = rb; rb = t0; t0 = ca; ca = cb; cb = t0;
+        t0 = ia; ia = ib; ib = t0; t0 = ja; ja = jb; jb = t0;
+        dR = -dR; dC = -dC;
+    }
+    const int pidx = t.pair_of[(ja * t.nbr + ia) * NREL + rel_index(dR, dC)];
+    const int la = (ra & 15) + ((ca & 15) << 4), lb = (rb & 15) + ((cb & 15) << 4);
+    return t.cov[((int64_t)pidx * BLKPX + la) * BLKPX + lb];
+}
+
+// ---- B2b: per-pixel assemble + ridge + Cholesky solve (one 64-lane workgroup per pixel) ----------
+// Packed lower triangle in LDS (fp64).  Neighbours outside the FOV keep a unit diagonal / zero RHS so
+// the system size is always n = p+1; they are excluded from the trace and get weight 0.
+__global__ void __launch_bounds__(64) k_ring_solve(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
+                                                   const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
+                                                   float *__restrict__ W) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int p = g.p, n = p + 1;
+    double *L = sm;                               // n(n+1)/2 packed, row i at i(i+1)/2
+    double *rhs = sm + (n * (n + 1)) / 2;         // n
+    int *nb = reinterpret_cast<int *>(rhs + n);   // n: packed (rb | cb<<16) or -1 if the neighbour is outside the FOV
+    const int64_t m = blockIdx.x;
+    if (active && !active[m]) return;
+    const int lane = threadIdx.x;
+    const int prow = (int)(m % g.nr), pcol = (int)(m / g.nr);
+    const int rbm = prow + g.roff, cbm = pcol + g.coff;          // centre in block coords
+    for (int i = lane; i < p; i += 64) {
+        const int rb = rbm + dr[i], cb = cbm + dc[i];
+        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;        // absolute 1-based
+        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
+    }
+    __syncthreads();
+    // assemble: rows 0..p-1 ring neighbours, row p = ones
+    for (int i = 0; i < n; ++i) {
+        const int ni = i < p ? nb[i] : 0;
+        for (int j = lane; j <= i; j += 64) {
+            double v;
+            if (i < p) {
+                const int nj = nb[j];
+                if (ni < 0 || nj < 0) v = (i == j) ? 1.0 : 0.0;
+                else v = cov_lookup(tab, ni & 0xffff, ni >> 16, nj & 0xffff, nj >> 16);
+            } else if (j < p) {
+                const int nj = nb[j];
+                v = nj < 0 ? 0.0 : rowsum[(((nj >> 16) >> 4) * g.nbr + ((nj & 0xffff) >> 4)) * BLKPX + ((nj & 0xffff) & 15) + ((((nj >> 16)) & 15) << 4)];
+            } else v = (double)g.Tp;
+            L[(i * (i + 1)) / 2 + j] = v;
+        }
+        if (lane == 0) {
+            double y;
+            if (i < p) y = ni < 0 ? 0.0 : cov_lookup(tab, ni & 0xffff, ni >> 16, rbm, cbm);
+            else y = rowsum[((cbm >> 4) * g.nbr + (rbm >> 4)) * BLKPX + (rbm & 15) + ((cbm & 15) << 4)];
+            rhs[i] = y;
+        }
+    }
+    __syncthreads();
+    // ridge: lambda = 1e-5 * trace over real rows (fit_ring_model.m:106)
+    double tr = 0;
+    for (int i = lane; i < n; i += 64) if (i == p || nb[i] >= 0) tr += L[(i * (i + 1)) / 2 + i];
+    for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+    const double lam = tr * 1e-5;
+    for (int i = lane; i < n; i += 64) if (i == p || nb[i] >= 0) L[(i * (i + 1)) / 2 + i] += lam;
+    __syncthreads();
+    // right-looking Cholesky, lane-per-row
+    for (int j = 0; j < n; ++j) {
+        const double djj = sqrt(L[(j * (j + 1)) / 2 + j]);
+        __syncthreads();
+        if (lane == 0) L[(j * (j + 1)) / 2 + j] = djj;
+        const double inv = 1.0 / djj;
+        for (int i = j + 1 + lane; i < n; i += 64) L[(i * (i + 1)) / 2 + j] *= inv;
+        __syncthreads();
+        for (int i = j + 1 + lane; i < n; i += 64) {
+            const double lij = L[(i * (i + 1)) / 2 + j];
+            double *row = L + (i * (i + 1)) / 2;
+            for (int k = j + 1; k <= i; ++k) row[k] -= lij * L[(k * (k + 1)) / 2 + j];
+        }
+        __syncthreads();
+    }
+    // forward substitution L z = rhs (column sweep), then back substitution L^T w = z
+    for (int j = 0; j < n; ++j) {
+        if (lane == 0) rhs[j] /= L[(j * (j + 1)) / 2 + j];
+        __syncthreads();
+        const double zj = rhs[j];
+        for (int i = j + 1 + lane; i < n; i += 64) rhs[i] -= L[(i * (i + 1)) / 2 + j] * zj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (lane == 0) rhs[j] /= L[(j * (j + 1)) / 2 + j];
+        __syncthreads();
+        const double wj = rhs[j];
+        for (int i = lane; i < j; i += 64) rhs[i] -= L[(j * (j + 1)) / 2 + i] * wj;
+        __syncthreads();
+    }
+    for (int i = lane; i < p; i += 64) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)rhs[i] : 0.f;   // intercept rhs[p] is discarded (:107)
+}
+
+// pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60) and the first-run test on row 1 (:25)
+__global__ void k_count_pos(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (m < d) for (int i = 0; i < p; ++i) c += W[(int64_t)i * d + m] > 0.f;
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(c, o); c = v > c ? v : c; }
+    if ((threadIdx.x & 63) == 0) atomicMax(pmax, c);
+}
+
+// ind_active = abs(W_old)*sum(A,2) > 0  (fit_ring_model.m:28)
+__global__ void k_active(const float *__restrict__ W, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
+                         const float *__restrict__ asum, unsigned char *__restrict__ active, int *__restrict__ nactive) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int on = 0;
+    if (m < g.d) {
+        const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
+        float s = 0.f;
+        for (int i = 0; i < g.p; ++i) {
+            const int rb = rbm + dr[i], cb = cbm + dc[i];
+            if (rb < 0 || rb >= g.nr_b || cb < 0 || cb >= g.nc_b) continue;
+            s += fabsf(W[(int64_t)i * g.d + m]) * asum[(int64_t)cb * g.nr_b + rb];
+        }
+        on = s > 0.f;
+        active[m] = (unsigned char)on;
+    }
+    unsigned long long b = __ballot(on);
+    if ((threadIdx.x & 63) == 0) atomicAdd(nactive, (int)__popcll(b));
+}
+
+// b0 = Ymean(ind_patch) - A(ind_patch,:)*Cmean   (fit_ring_model.m:44), double
+__global__ void k_b0(const double *__restrict__ ymean, BgGeom g, const int *__restrict__ arow, const int *__restrict__ acol,
+                     const float *__restrict__ aval, const double *__restrict__ Cmean, double *__restrict__ b0) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= g.d) return;
+    const int64_t q = (int64_t)((int)(m / g.nr) + g.coff) * g.nr_b + (int)(m % g.nr) + g.roff;
+    double v = ymean[q];
+    if (arow) for (int e = arow[q]; e < arow[q + 1]; ++e) v -= (double)aval[e] * Cmean[acol[e]];
+    b0[m] = v;
+}
+
+int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4]) {
+    const int64_t T = P->T;
+    const int p = P->p;
+    DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
+           &dMisc = ctx->tmp[6], &dAsum = ctx->tmp[7], &dActive = ctx->tmp[8], &dPairs = ctx->tmp[9], &dPairOf = ctx->tmp[10];
+    // isempty(A) -> A = ones(d,1), C = zeros(1,T)  (fit_ring_model.m:15-17): Bf = Y - Ymean, b0 = Ymean
+    const bool has_a = K > 0 && A_colptr[K] > 0;
+    const bool a_empty = K == 0;
+    int64_t ldc = 4;
+    HostCSR csr;
+    if (has_a) {
+        RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
+        RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
+        csc_to_csr(P->d_b, K, A_colptr, A_rowidx, A_val, csr);
+        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
+        RET(to_dev(ctx, dArow, rp.data(), rp.size()));
+        RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
+        RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+    }
+    // ---- first-run test (:25): row 1 of W_old has exactly two distinct values (0 and 1/count) ----
+    bool first_run = false;
+    RET(ring_first_run(ctx, P, &first_run));
+    RET(dMisc.ensure(64));
+    CK(hipMemsetAsync(dMisc.p, 0, 64, ctx->stream));
+    LAUNCH(ctx, "bg_count_pos", k_count_pos, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->W.as<float>(), P->d, p, dMisc.as<int>());
+    int h_misc[2] = {0, 0};
+    CK(hipMemcpyAsync(h_misc, dMisc.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    const int pmax = h_misc[0];
+    int kstride = 1;
+    if (with_projection) {                                // :84-87
+        int64_t nk = std::min<int64_t>(T, (int64_t)pmax * 100);
+        if (nk < 1) nk = 1;
+        kstride = (int)(T / nk);
+        if (kstride < 1) kstride = 1;
+    }
+    BgGeom g;
+    g.nr = P->nr; g.nc = P->nc; g.nr_b = P->nr_b; g.nc_b = P->nc_b; g.roff = P->roff; g.coff = P->coff;
+    g.r0_abs = P->brect[0]; g.c0_abs = P->brect[2]; g.d1 = P->d1; g.d2 = P->d2;
+    g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
+    g.d = P->d; g.d_b = P->d_b; g.T = T; g.kstride = kstride;
+    g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
+    g.Tpad = (g.Tp + GK - 1) / GK * GK;
+    g.p = p;
+    const int nblk = g.nbr * g.nbc;
+
+    // ---- ind_active (:25-29) ----
+    RET(dActive.ensure(P->d));
+    int64_t nactive = P->d;
+    if (first_run) {
+        CK(hipMemsetAsync(dActive.p, 1, P->d, ctx->stream));
+    } else {
+        std::vector<float> asum(P->d_b, 0.f);
+        if (a_empty) std::fill(asum.begin(), asum.end(), 1.0f);
+        else if (has_a) for (int64_t q = 0; q < P->d_b; ++q) { double s = 0; for (int64_t e = csr.rowptr[q]; e < csr.rowptr[q + 1]; ++e) s += csr.val[e]; asum[q] = (float)s; }
+        RET(to_dev(ctx, dAsum, asum.data(), asum.size()));
+        CK(hipMemsetAsync(dMisc.p, 0, 64, ctx->stream));
+        LAUNCH(ctx, "bg_active", k_active, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->W.as<float>(), g,
+               P->ring_dr.as<int>(), P->ring_dc.as<int>(), dAsum.as<float>(), dActive.as<unsigned char>(), dMisc.as<int>());
+        CK(hipMemcpyAsync(h_misc, dMisc.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        nactive = h_misc[0];
+    }
+    // ---- b0 (:44) ----
+    LAUNCH(ctx, "bg_b0", k_b0, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->ymean_d.as<double>(), g,
+           has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCm.as<double>(), P->b0.as<double>());
+
+    if (nactive > 0) {
+        // ---- B1: Bf tiled ----
+        RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
+        const int tchunk = (int)std::max<int64_t>(64, (g.Tpad + 15) / 16);
+        dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
+        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Y.as<float>(), P->ymean_f.as<float>(), g,
+               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk);
+        RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
+        LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>());
+        // ---- pair list: blocks that hold ring pixels of some patch pixel, displacement within +-2 ----
+        // a block is "touched" if it lies within one block of a block containing patch pixels
+        std::vector<char> touched(nblk, 0);
+        {
+            int pi0 = P->roff / BLK, pi1 = (P->roff + P->nr - 1) / BLK, pj0 = P->coff / BLK, pj1 = (P->coff + P->nc - 1) / BLK;
+            for (int j = std::max(0, pj0 - 1); j <= std::min(g.nbc - 1, pj1 + 1); ++j)
+                for (int i = std::max(0, pi0 - 1); i <= std::min(g.nbr - 1, pi1 + 1); ++i) touched[j * g.nbr + i] = 1;
+        }
+        std::vector<int2> pairs; std::vector<int> pair_of((size_t)nblk * NREL, -1);
+        for (int j = 0; j < g.nbc; ++j)
+            for (int i = 0; i < g.nbr; ++i) {
+                if (!touched[j * g.nbr + i]) continue;
+                for (int dC = 0; dC <= 2; ++dC)
+                    for (int dR = (dC == 0 ? 0 : -2); dR <= 2; ++dR) {
+                        int i2 = i + dR, j2 = j + dC;
+                        if (i2 < 0 || i2 >= g.nbr || j2 >= g.nbc || !touched[j2 * g.nbr + i2]) continue;
+                        int rel = dC == 0 ? dR : (dC == 1 ? 5 + dR : 10 + dR);
+                        pair_of[(size_t)(j * g.nbr + i) * NREL + rel] = (int)pairs.size();
+                        pairs.push_back(make_int2(j * g.nbr + i, j2 * g.nbr + i2));
+                    }
+            }
+        const int npairs = (int)pairs.size();
+        RET(to_dev(ctx, dPairs, pairs.data(), pairs.size()));
+        RET(to_dev(ctx, dPairOf, pair_of.data(), pair_of.size()));
+        RET(ctx->cov.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
+        int nwg = npairs * 4;
+        nwg = (nwg + 7) / 8 * 8;                            // multiple of 8 for the XCD remap (extra workgroups exit)
+        LAUNCH(ctx, "bg_gram_f64", k_gram_f64, dim3(nwg), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, dPairs.as<int2>(), npairs, ctx->cov.as<double>());
+        // ---- B2b ----
+        CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc;
+        const int n = p + 1;
+        size_t shmem = ((size_t)(n * (n + 1)) / 2 + n) * sizeof(double) + (size_t)n * sizeof(int);
+        shmem = (shmem + 15) & ~size_t(15);
+        if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "bg_ring_solve", k_ring_solve, dim3((unsigned)P->d), dim3(64), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
+               ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
+    }
+    if (b0_out) {
+        std::vector<double> tmp(P->d);
+        CK(hipMemcpyAsync(tmp.data(), P->b0.p, P->d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < P->d; ++i) b0_out[i] = (float)tmp[i];
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    info[0] = first_run ? 1 : 0; info[1] = kstride; info[2] = nactive; info[3] = pmax;
+    return 0;
+}
+
+}  // namespace cnmfe

@@ -1,0 +1,169 @@
+// Shared internals of the CNMF-E HIP engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include "../../include/cnmfe.h"
+
+namespace cnmfe {
+
+extern thread_local char g_err[1024];
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return cnmfe::fail(CNMFE_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)
+#define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
+
+// ---- owned device buffer -----------------------------------------------------
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(CNMFE_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want; return 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- per-kernel event timing ---------------------------------------------------
+struct Profiler {
+    bool on = false;
+    struct Rec { hipEvent_t a, b; int id; };
+    std::vector<std::string> names;
+    std::vector<double> total_ms; std::vector<int64_t> calls;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    int id_of(const char *n) {
+        for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i;
+        names.push_back(n); total_ms.push_back(0); calls.push_back(0); return (int)names.size() - 1;
+    }
+    hipEvent_t ev() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+                      hipEvent_t e; (void)hipEventCreate(&e); return e; }
+    void begin(const char *n, hipStream_t s, Rec &r) { r.id = id_of(n); r.a = ev(); r.b = ev(); (void)hipEventRecord(r.a, s); }
+    void end(hipStream_t s, Rec &r) { (void)hipEventRecord(r.b, s); pending.push_back(r); }
+    void drain() {
+        for (auto &r : pending) {
+            (void)hipEventSynchronize(r.b); float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b);
+            total_ms[r.id] += ms; calls[r.id] += 1; pool.push_back(r.a); pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+    void reset() { drain(); for (auto &t : total_ms) t = 0; for (auto &c : calls) c = 0; }
+    ~Profiler() { drain(); for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+// launch wrapper: LAUNCH(ctx, "name", kernel, grid, block, shmem, args...)
+#define LAUNCH(ctx, name, kern, grid, block, shmem, ...) do { \
+    cnmfe::Profiler::Rec pr_; bool pon_ = (ctx)->prof.on; \
+    if (pon_) (ctx)->prof.begin(name, (ctx)->stream, pr_); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+    if (pon_) (ctx)->prof.end((ctx)->stream, pr_); \
+    hipError_t le_ = hipGetLastError(); \
+    if (le_ != hipSuccess) return cnmfe::fail(CNMFE_EHIP, "launch %s failed: %s", name, hipGetErrorString(le_)); \
+} while (0)
+
+constexpr int PMAX_RING = 128;    // max ring neighbours supported (r=18 -> 120)
+constexpr int BLK = 16;           // 16x16-pixel covariance blocks
+constexpr int BLKPX = BLK * BLK;
+constexpr int NREL = 13;          // canonical block displacements for the block-sparse SYRK
+
+// ---- sparse helpers (host) ------------------------------------------------------
+struct HostCSR { std::vector<int64_t> rowptr; std::vector<int32_t> col; std::vector<float> val; std::vector<int32_t> src; };
+// CSC (ncol columns, nrow rows) -> CSR with `src` = index into the CSC arrays
+inline void csc_to_csr(int64_t nrow, int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, HostCSR &out) {
+    int64_t nnz = colptr[ncol];
+    out.rowptr.assign(nrow + 1, 0); out.col.resize(nnz); out.val.resize(nnz); out.src.resize(nnz);
+    for (int64_t e = 0; e < nnz; ++e) out.rowptr[rowidx[e] + 1]++;
+    for (int64_t r = 0; r < nrow; ++r) out.rowptr[r + 1] += out.rowptr[r];
+    std::vector<int64_t> cur(out.rowptr.begin(), out.rowptr.end() - 1);
+    for (int32_t k = 0; k < ncol; ++k)
+        for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
+            int64_t pos = cur[rowidx[e]]++; out.col[pos] = k; out.val[pos] = val ? val[e] : 1.0f; out.src[pos] = (int32_t)e;
+        }
+}
+
+// ---- per-patch resident state ----------------------------------------------------
+struct Patch {
+    int32_t prect[4], brect[4];        // 1-based inclusive [r0 r1 c0 c1]
+    int32_t d1 = 0, d2 = 0;
+    int32_t nr = 0, nc = 0, nr_b = 0, nc_b = 0;
+    int32_t roff = 0, coff = 0;        // patch origin inside the block (0-based)
+    int64_t T = 0, d = 0, d_b = 0;
+    DevBuf Y;                          // T x d_b fp32
+    DevBuf ymean_d;                    // d_b double
+    DevBuf ymean_f;                    // d_b float
+    bool ymean_valid = false;
+    int64_t frames_uploaded = 0;
+    // ring
+    int32_t radius = 0, p = 0;         // p ring offsets
+    std::vector<int32_t> dr, dc;       // ring offsets, (dc, dr)-sorted == MATLAB find() order
+    DevBuf ring_dr, ring_dc;           // int32[p]
+    DevBuf W;                          // p x d fp32, offset-major; 0 where the neighbour is outside the FOV
+    DevBuf b0;                         // d fp64 (kept in double on the device; the ABI converts)
+    bool ring_ready = false;
+    bool ysig_valid = false;
+};
+
+}  // namespace cnmfe
+
+struct cnmfe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cnmfe::Profiler prof;
+    std::map<int, cnmfe::Patch *> patches;
+    // scratch shared by all patches of this context (sized for the largest)
+    cnmfe::DevBuf ysig;       // d x T fp32 (frame-major) of the patch last passed to cnmfe_residual
+    int ysig_patch = -1;
+    cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
+    cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
+    cnmfe::DevBuf rowsum;     // [blk][256] double
+    cnmfe::DevBuf tmp[12];    // small scratch
+    cnmfe::DevBuf stage;      // upload staging
+    std::map<std::string, int64_t> opts;
+    int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }
+    ~cnmfe_ctx();
+};
+
+namespace cnmfe {
+inline Patch *get_patch(cnmfe_ctx *ctx, int id) { auto it = ctx->patches.find(id); return it == ctx->patches.end() ? nullptr : it->second; }
+// upload a host vector to a DevBuf on the context stream
+template <class T> inline int to_dev(cnmfe_ctx *ctx, DevBuf &b, const T *h, size_t n) {
+    RET(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) CK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+// [k][t] row-major fp32 copy of a K x T matrix given in `order`; device result has row stride ldc (multiple of 4)
+int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_t T, int order, int64_t *ldc);
+int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int32_t K, int64_t T, int order);
+
+// implemented in the kernel translation units
+int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4]);
+int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace);
+int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                const float *A_val, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                const float *sn, int32_t param, float *A_out);
+int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                 const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out);
+int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                 const float *A_val, uint8_t *keep);
+int ensure_ymean(cnmfe_ctx *ctx, Patch *P);
+int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
+int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean);
+}  // namespace cnmfe

@@ -1,0 +1,500 @@
+// S1-S4 / T1-T3 / S6: spatial HALS / NNLS, temporal HALS and the spatial post-processing on the
+// resident Ysig (d x T fp32, frame-major) of one patch.
+//
+// Sparsity is the structure here: A is only ever non-zero on the search mask IND, so U = Ysig*C'
+// (HALS_spatial.m:31) is evaluated on nnz(IND) entries instead of d*K, V = C*C' / A'*A only on the
+// pairs of neurons that share a pixel, and the strictly sequential k = 1..K Gauss-Seidel order of
+// HALS_spatial.m:37 / HALS_temporal.m:60 is reproduced exactly by a level schedule: neuron k waits
+// for every smaller-index neuron it shares a pixel with; neurons of one level are independent.
+#include "common.hpp"
+#include <math.h>
+
+namespace cnmfe {
+
+// ---- S1: U(e) = sum_t Ysig(m_e, t) * Cc(k_e, t)   (Cc centred => equals Y*C' - T*Ymean*Cmean') ----
+__global__ void __launch_bounds__(256) k_proj_spatial(const float *__restrict__ ysig, int64_t d, int64_t T, const int *__restrict__ erow,
+                                                      const int *__restrict__ ecol, int64_t nnz, const float *__restrict__ Cc, int64_t ldc,
+                                                      int64_t tchunk, float *__restrict__ part) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int64_t t0 = (int64_t)blockIdx.y * tchunk, t1 = t0 + tchunk < T ? t0 + tchunk : T;
+    const float *y = ysig + erow[e];
+    const float *c = Cc + (int64_t)ecol[e] * ldc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t t = t0;
+    for (; t + 3 < t1; t += 4) {
+        a0 = fmaf(y[t * d], c[t], a0); a1 = fmaf(y[(t + 1) * d], c[t + 1], a1);
+        a2 = fmaf(y[(t + 2) * d], c[t + 2], a2); a3 = fmaf(y[(t + 3) * d], c[t + 3], a3);
+    }
+    for (; t < t1; ++t) a0 = fmaf(y[t * d], c[t], a0);
+    part[(int64_t)blockIdx.y * nnz + e] = (a0 + a1) + (a2 + a3);
+}
+__global__ void k_reduce_parts(const float *__restrict__ part, int64_t n, int nparts, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0;
+    for (int j = 0; j < nparts; ++j) s += part[(int64_t)j * n + e];
+    out[e] = (float)s;
+}
+
+// ---- S2: V(k1,k2) = <Cc(k1,:), Cc(k2,:)> for the listed pairs, written symmetrically into dense K x K ----
+__global__ void __launch_bounds__(256) k_pair_gram(const float *__restrict__ Cc, int64_t ldc, int64_t T, const int2 *__restrict__ pairs,
+                                                   int K, float *__restrict__ V) {
+    const int2 pr = pairs[blockIdx.x];
+    const float *a = Cc + (int64_t)pr.x * ldc, *b = Cc + (int64_t)pr.y * ldc;
+    double s = 0;
+    for (int64_t t = threadIdx.x; t < T; t += 256) s += (double)a[t] * (double)b[t];
+    __shared__ double red[256];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { V[(int64_t)pr.x * K + pr.y] = (float)red[0]; V[(int64_t)pr.y * K + pr.x] = (float)red[0]; }
+}
+
+// ---- S3: one Gauss-Seidel level of HALS_spatial / HALS_spatial_thresh ---------------------------------
+// ak = A(ind,k) + (U(ind,k) - A(ind,:)*V(:,k)) / cc(k);  plain: max(0,.) (HALS_spatial.m:42);
+// thresh: ak(ak < sn*3/sqrt(cc)) = 0 (HALS_spatial_thresh.m:50-51).
+__global__ void __launch_bounds__(128) k_hals_spatial(const int *__restrict__ lvl, const int64_t *__restrict__ colptr, const int *__restrict__ erow,
+                                                      const int *__restrict__ rptr, const int *__restrict__ rcol, const int *__restrict__ rsrc,
+                                                      const float *__restrict__ U, const float *__restrict__ V, int K,
+                                                      const float *__restrict__ sn, int thresh, float *__restrict__ Aval) {
+    const int k = lvl[blockIdx.x];
+    const float cc = V[(int64_t)k * K + k];
+    if (cc == 0.f) return;                                         // :38-40
+    const float cthr = 3.0f / sqrtf(cc);
+    for (int64_t e = colptr[k] + threadIdx.x; e < colptr[k + 1]; e += blockDim.x) {
+        const int m = erow[e];
+        float s = 0.f;
+        for (int r = rptr[m]; r < rptr[m + 1]; ++r) s = fmaf(Aval[rsrc[r]], V[(int64_t)rcol[r] * K + k], s);
+        float ak = Aval[e] + (U[e] - s) / cc;
+        if (thresh) { if (ak < sn[m] * cthr) ak = 0.f; }
+        else ak = fmaxf(0.f, ak);
+        Aval[e] = ak;
+    }
+}
+
+// ---- S4: nnls_spatial.m:26-38 + nnls() :41-109, one thread per pixel, fp64 --------------------------
+constexpr int NN_MAX = 16;
+__device__ inline bool solve_small(int n, double *M /* n x n row-major, destroyed */, double *b /* in: rhs, out: x */) {
+    for (int c = 0; c < n; ++c) {
+        int piv = c; double best = fabs(M[c * n + c]);
+        for (int r = c + 1; r < n; ++r) { double v = fabs(M[r * n + c]); if (v > best) { best = v; piv = r; } }
+        if (best == 0.0) return false;
+        if (piv != c) { for (int j = 0; j < n; ++j) { double t = M[c * n + j]; M[c * n + j] = M[piv * n + j]; M[piv * n + j] = t; }
+                        double t = b[c]; b[c] = b[piv]; b[piv] = t; }
+        const double inv = 1.0 / M[c * n + c];
+        for (int r = c + 1; r < n; ++r) {
+            const double f = M[r * n + c] * inv;
+            if (f != 0.0) { for (int j = c; j < n; ++j) M[r * n + j] -= f * M[c * n + j]; b[r] -= f * b[c]; }
+        }
+    }
+    for (int r = n - 1; r >= 0; --r) { double s = b[r]; for (int j = r + 1; j < n; ++j) s -= M[r * n + j] * b[j]; b[r] = s / M[r * n + r]; }
+    return true;
+}
+
+__global__ void __launch_bounds__(64) k_nnls_spatial(int64_t d, const int *__restrict__ rptr, const int *__restrict__ rcol, const int *__restrict__ rsrc,
+                                                     const float *__restrict__ U, const float *__restrict__ V, int K, int maxN, double tol,
+                                                     float *__restrict__ Aval) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= d) return;
+    const int r0 = rptr[m], n = rptr[m + 1] - r0;
+    if (n <= 0) return;
+    double G[NN_MAX * NN_MAX], b[NN_MAX], s[NN_MAX], mu[NN_MAX], Ms[NN_MAX * NN_MAX];
+    bool P[NN_MAX];
+    int idx[NN_MAX];
+    for (int i = 0; i < n; ++i) {
+        b[i] = (double)U[rsrc[r0 + i]];
+        for (int j = 0; j < n; ++j) G[i * n + j] = (double)V[(int64_t)rcol[r0 + i] * K + rcol[r0 + j]];
+        s[i] = 0.0; mu[i] = 0.0;
+    }
+    for (int it = 0; it < maxN; ++it) {                                      // :76
+        double lmax = -1e300; int imax = 0;
+        for (int i = 0; i < n; ++i) {
+            double l = b[i];
+            for (int j = 0; j < n; ++j) l -= G[i * n + j] * s[j];            // :77
+            P[i] = s[i] > 0.0;                                               // :78
+            if (l > lmax) { lmax = l; imax = i; }                            // first maximum
+        }
+        if (lmax < tol) break;                                               // :80
+        P[imax] = true;                                                      // :85
+        int np = 0; for (int i = 0; i < n; ++i) np += P[i];
+        if (np > maxN) break;                                                // :86
+        bool have_mu = false;
+        while (np > 0) {                                                     // :90
+            int q = 0;
+            for (int i = 0; i < n; ++i) if (P[i]) idx[q++] = i;
+            for (int a = 0; a < q; ++a) { mu[a] = b[idx[a]]; for (int c = 0; c < q; ++c) Ms[a * q + c] = G[idx[a] * n + idx[c]]; }
+            if (!solve_small(q, Ms, mu)) {                                   // catch branch :94-96
+                for (int a = 0; a < q; ++a) { mu[a] = b[idx[a]]; for (int c = 0; c < q; ++c) Ms[a * q + c] = G[idx[a] * n + idx[c]] + (a == c ? tol : 0.0); }
+                solve_small(q, Ms, mu);
+            }
+            have_mu = true;
+            bool all_pos = true;
+            for (int a = 0; a < q; ++a) all_pos = all_pos && (mu[a] > tol);
+            if (all_pos) break;                                              // :98
+            double amin = 1e300;
+            for (int a = 0; a < q; ++a) if (!(mu[a] > tol)) { double v = s[idx[a]] / (s[idx[a]] - mu[a]); if (v < amin) amin = v; }   // :102-104
+            for (int a = 0; a < q; ++a) s[idx[a]] += amin * (mu[a] - s[idx[a]]);   // :105
+            np = 0;
+            for (int i = 0; i < n; ++i) { if (s[i] < tol) P[i] = false; np += P[i]; }   // :106
+            have_mu = false;
+        }
+        if (have_mu) { int q = 0; for (int i = 0; i < n; ++i) if (P[i]) s[i] = mu[q++]; }   // :109
+    }
+    for (int i = 0; i < n; ++i) Aval[rsrc[r0 + i]] = (float)s[i];
+}
+
+// ---- T1: U(k,t) = sum_e A(e) * Ysig(m_e, t)  (HALS_temporal.m:48) --------------------------------------
+// one workgroup per (neuron, frame chunk); a wave owns frames t = t0 + wave, +4, ...; lanes stride the
+// neuron's pixels and a 6-step DPP butterfly finishes the dot product.
+__global__ void __launch_bounds__(256) k_proj_temporal(const float *__restrict__ ysig, int64_t d, int64_t T, const int64_t *__restrict__ colptr,
+                                                       const int *__restrict__ erow, const float *__restrict__ aval, int64_t tchunk,
+                                                       float *__restrict__ U, int64_t ldc) {
+    const int k = blockIdx.x;
+    const int64_t e0 = colptr[k], e1 = colptr[k + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.y * tchunk, t1 = t0 + tchunk < T ? t0 + tchunk : T;
+    for (int64_t t = t0 + wave; t < t1; t += 4) {
+        const float *y = ysig + t * d;
+        float s = 0.f;
+        for (int64_t e = e0 + lane; e < e1; e += 64) s = fmaf(aval[e], y[erow[e]], s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) U[(int64_t)k * ldc + t] = s;
+    }
+}
+
+// ---- T2: V(k,k') = <A(:,k), A(:,k')> on the overlap pairs: merge of two sorted columns per thread ----
+__global__ void k_ata_pairs(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
+                            const int *__restrict__ nk, const int *__restrict__ nidx, int nn, float *__restrict__ nval) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    const int k = nk[i], k2 = nidx[i];
+    int64_t a = colptr[k], ae = colptr[k + 1], b = colptr[k2], be = colptr[k2 + 1];
+    double s = 0;
+    while (a < ae && b < be) {
+        const int ra = erow[a], rb = erow[b];
+        if (ra == rb) { s += (double)aval[a] * (double)aval[b]; ++a; ++b; }
+        else if (ra < rb) ++a; else ++b;
+    }
+    nval[i] = (float)s;
+}
+
+// ---- T3: one Gauss-Seidel level of HALS_temporal (no-deconvolution branch :62-68) --------------------
+__global__ void __launch_bounds__(256) k_hals_temporal(const int *__restrict__ lvl, const int *__restrict__ nptr, const int *__restrict__ nidx,
+                                                       const float *__restrict__ nval, const float *__restrict__ aa, const float *__restrict__ U,
+                                                       float *__restrict__ C, float *__restrict__ Craw, int64_t ldc, int64_t T) {
+    const int k = lvl[blockIdx.x];
+    const float a = aa[k];
+    float *ck = C + (int64_t)k * ldc;
+    const float *uk = U + (int64_t)k * ldc;
+    const int n0 = nptr[k], n1 = nptr[k + 1];
+    float mn = INFINITY;
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        float vc = 0.f;
+        for (int j = n0; j < n1; ++j) vc = fmaf(nval[j], C[(int64_t)nidx[j] * ldc + t], vc);    // V(k,:)*C
+        const float v = ck[t] + (uk[t] - vc) / a;                                                  // :62
+        Craw[(int64_t)k * ldc + t] = v;
+        mn = fminf(mn, v);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = mn; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    mn = red[0];
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        const float v = Craw[(int64_t)k * ldc + t] - mn;                                           // :66
+        Craw[(int64_t)k * ldc + t] = v; ck[t] = v;                                                 // :67-68
+    }
+}
+
+// ---- S6: connectivity_constraint.m:1-18 on a per-neuron box -------------------------------------------
+constexpr int PP_MAX = 64;    // max box side (bbox + 2 px margin each side)
+__global__ void __launch_bounds__(256) k_connectivity(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
+                                                      const int4 *__restrict__ box /* r0,c0,h,w (0-based, box incl. margin) */, int d1, int d2,
+                                                      unsigned char *__restrict__ keep) {
+    __shared__ float img[PP_MAX * PP_MAX];
+    __shared__ float er[PP_MAX * PP_MAX];
+    __shared__ int lab[PP_MAX * PP_MAX];
+    __shared__ float smax; __shared__ int sarg; __shared__ int changed;
+    __shared__ float redv[256]; __shared__ int redi[256];
+    const int k = blockIdx.x;
+    const int4 bx = box[k];
+    const int r0 = bx.x, c0 = bx.y, h = bx.z, w = bx.w, n = h * w;
+    const int64_t e0 = colptr[k], e1 = colptr[k + 1];
+    if (e1 == e0) return;
+    for (int i = threadIdx.x; i < n; i += 256) img[i] = 0.f;
+    __syncthreads();
+    // image + first maximum in column-major order (connectivity_constraint.m:10)
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int pix = erow[e], r = pix % d1, c = pix / d1;
+        const float v = aval[e];
+        img[(c - c0) * h + (r - r0)] = v;
+        if (v > bv || (v == bv && pix < bi)) { bv = v; bi = pix; }
+    }
+    redv[threadIdx.x] = bv; redi[threadIdx.x] = bi; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v2 = redv[threadIdx.x + o]; const int i2 = redi[threadIdx.x + o];
+            if (v2 > redv[threadIdx.x] || (v2 == redv[threadIdx.x] && i2 < redi[threadIdx.x])) { redv[threadIdx.x] = v2; redi[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { smax = redv[0]; sarg = redi[0]; }
+    __syncthreads();
+    // the image maximum also sees the zeros outside the support
+    const float vmax = fmaxf(smax, 0.f);
+    // grey erosion with a 5x5 square; outside the FOV is ignored (+inf padding), outside the box is 0
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int lr = i % h, lc = i / h;
+        float mnv = INFINITY;
+        for (int dc = -2; dc <= 2; ++dc) for (int dr = -2; dr <= 2; ++dr) {
+            const int rr = lr + dr, cc = lc + dc, ar = r0 + rr, ac = c0 + cc;
+            if (ar < 0 || ar >= d1 || ac < 0 || ac >= d2) continue;
+            const float v = (rr >= 0 && rr < h && cc >= 0 && cc < w) ? img[cc * h + rr] : 0.f;
+            mnv = fminf(mnv, v);
+        }
+        er[i] = mnv;
+    }
+    __syncthreads();
+    // dilation -> opening; temp = ai_open > max*thr (:15); initial labels
+    const float thr = vmax * 0.01f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int lr = i % h, lc = i / h;
+        if (r0 + lr < 0 || r0 + lr >= d1 || c0 + lc < 0 || c0 + lc >= d2) { lab[i] = 0; continue; }   // box cell outside the FOV
+        float mxv = -INFINITY;
+        for (int dc = -2; dc <= 2; ++dc) for (int dr = -2; dr <= 2; ++dr) {
+            const int rr = lr + dr, cc = lc + dc, ar = r0 + rr, ac = c0 + cc;
+            if (ar < 0 || ar >= d1 || ac < 0 || ac >= d2) continue;
+            const float v = (rr >= 0 && rr < h && cc >= 0 && cc < w) ? er[cc * h + rr] : 0.f;
+            mxv = fmaxf(mxv, v);
+        }
+        lab[i] = mxv > thr ? i + 1 : 0;
+    }
+    __syncthreads();
+    // 4-connected components by min-label propagation (bwlabel(.,4), :16; only "same component" matters)
+    for (int iter = 0; iter < PP_MAX * PP_MAX; ++iter) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            int l = lab[i];
+            if (!l) continue;
+            const int lr = i % h, lc = i / h;
+            int best = l;
+            if (lr > 0) { int v = lab[i - 1]; if (v && v < best) best = v; }
+            if (lr < h - 1) { int v = lab[i + 1]; if (v && v < best) best = v; }
+            if (lc > 0) { int v = lab[i - h]; if (v && v < best) best = v; }
+            if (lc < w - 1) { int v = lab[i + h]; if (v && v < best) best = v; }
+            if (best < l) { lab[i] = best; changed = 1; }
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    const int am = sarg;
+    const int lmax = lab[((am / d1) - c0) * h + ((am % d1) - r0)];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int pix = erow[e], r = pix % d1, c = pix / d1;
+        keep[e] = lab[(c - c0) * h + (r - r0)] == lmax ? 1 : 0;        // img(l ~= l(ind_max)) = 0  (:18)
+    }
+}
+
+// =============================================================================================
+// host orchestration
+// =============================================================================================
+struct PairGraph {
+    std::vector<int2> pairs;                 // k1 <= k2, unique, diagonal included for every k
+    std::vector<std::vector<int>> lower;     // lower[k] = neighbours with smaller index
+    std::vector<std::vector<int>> levels;    // neurons per Gauss-Seidel level, ascending k inside a level
+};
+
+// co-occurrence graph of columns from a CSR (row -> columns), plus the order-preserving level schedule
+static void build_graph(int K, const HostCSR &csr, int64_t nrow, const std::vector<char> &include, PairGraph &g) {
+    std::vector<std::pair<int, int>> pr;
+    for (int64_t r = 0; r < nrow; ++r) {
+        const int64_t a = csr.rowptr[r], b = csr.rowptr[r + 1];
+        for (int64_t i = a; i < b; ++i) for (int64_t j = i + 1; j < b; ++j) {
+            int k1 = csr.col[i], k2 = csr.col[j];
+            if (k1 > k2) std::swap(k1, k2);
+            pr.push_back({k1, k2});
+        }
+    }
+    std::sort(pr.begin(), pr.end());
+    pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+    g.pairs.clear(); g.lower.assign(K, {});
+    for (int k = 0; k < K; ++k) g.pairs.push_back(make_int2(k, k));
+    for (auto &p : pr) { g.pairs.push_back(make_int2(p.first, p.second)); g.lower[p.second].push_back(p.first); }
+    std::vector<int> lvl(K, 0);
+    int nl = 0;
+    for (int k = 0; k < K; ++k) {
+        int l = 0;
+        for (int a : g.lower[k]) if (include[a]) l = std::max(l, lvl[a] + 1);
+        lvl[k] = l;
+        if (include[k]) nl = std::max(nl, l + 1);
+    }
+    g.levels.assign(nl, {});
+    for (int k = 0; k < K; ++k) if (include[k]) g.levels[lvl[k]].push_back(k);
+}
+
+int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                const float *A_val, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                const float *sn, int32_t param, float *A_out) {
+    const int64_t T = P->T, d = P->d, nnz = IND_colptr[K];
+    if (nnz == 0) return 0;
+    if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(IND) too large");
+    DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2];
+    DevBuf dColptr, dErow, dEcol, dRptr, dRcol, dRsrc, dAval, dU, dPart, dV, dPairs, dSn, dLvl;
+    int64_t ldc;
+    RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
+    RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
+    // A restricted to the IND pattern (A(~active_pixel) = 0, HALS_spatial.m:26); NNLS starts from 0 (:32)
+    std::vector<float> aval(nnz, 0.f);
+    std::vector<int32_t> ecol(nnz);
+    for (int32_t k = 0; k < K; ++k) {
+        int64_t a = A_colptr ? A_colptr[k] : 0, ae = A_colptr ? A_colptr[k + 1] : 0;
+        for (int64_t e = IND_colptr[k]; e < IND_colptr[k + 1]; ++e) {
+            ecol[e] = k;
+            while (a < ae && A_rowidx[a] < IND_rowidx[e]) ++a;
+            if (a < ae && A_rowidx[a] == IND_rowidx[e] && algorithm != CNMFE_SPATIAL_NNLS) aval[e] = A_val[a];
+        }
+    }
+    HostCSR csr; csc_to_csr(d, K, IND_colptr, IND_rowidx, nullptr, csr);
+    int maxrow = 0;
+    for (int64_t m = 0; m < d; ++m) maxrow = std::max<int>(maxrow, (int)(csr.rowptr[m + 1] - csr.rowptr[m]));
+    if (algorithm == CNMFE_SPATIAL_NNLS && maxrow > NN_MAX)
+        return fail(CNMFE_EUNSUPPORTED, "a pixel lies in %d search masks; the NNLS kernel supports %d", maxrow, NN_MAX);
+    std::vector<int32_t> rptr(csr.rowptr.begin(), csr.rowptr.end());
+    RET(to_dev(ctx, dColptr, IND_colptr, (size_t)K + 1));
+    RET(to_dev(ctx, dErow, IND_rowidx, (size_t)nnz));
+    RET(to_dev(ctx, dEcol, ecol.data(), (size_t)nnz));
+    RET(to_dev(ctx, dRptr, rptr.data(), rptr.size()));
+    RET(to_dev(ctx, dRcol, csr.col.data(), csr.col.size()));
+    RET(to_dev(ctx, dRsrc, csr.src.data(), csr.src.size()));
+    RET(to_dev(ctx, dAval, aval.data(), aval.size()));
+    if (sn) RET(to_dev(ctx, dSn, sn, (size_t)d));
+    // S1
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(32, T / 256));
+    const int64_t tchunk = (T + nparts - 1) / nparts;
+    RET(dPart.ensure((size_t)nparts * nnz * sizeof(float)));
+    RET(dU.ensure((size_t)nnz * sizeof(float)));
+    LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, ctx->ysig.as<float>(), d, T,
+           dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
+    LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
+    // S2 on the co-occurrence pairs
+    std::vector<char> include(K, 1);
+    PairGraph g; build_graph(K, csr, d, include, g);
+    RET(to_dev(ctx, dPairs, g.pairs.data(), g.pairs.size()));
+    RET(dV.ensure((size_t)K * K * sizeof(float)));
+    CK(hipMemsetAsync(dV.p, 0, (size_t)K * K * sizeof(float), ctx->stream));
+    LAUNCH(ctx, "spatial_pair_gram", k_pair_gram, dim3((unsigned)g.pairs.size()), dim3(256), 0, dCc.as<float>(), ldc, T, dPairs.as<int2>(), K, dV.as<float>());
+    if (algorithm == CNMFE_SPATIAL_NNLS) {
+        LAUNCH(ctx, "spatial_nnls", k_nnls_spatial, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, d, dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(),
+               dU.as<float>(), dV.as<float>(), K, (int)param, 1e-4, dAval.as<float>());
+    } else {
+        std::vector<int> flat; std::vector<int> off;
+        for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
+        RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
+        for (int it = 0; it < param; ++it)
+            for (size_t l = 0; l < g.levels.size(); ++l)
+                LAUNCH(ctx, "spatial_hals_level", k_hals_spatial, dim3((unsigned)g.levels[l].size()), dim3(128), 0, dLvl.as<int>() + off[l],
+                       dColptr.as<int64_t>(), dErow.as<int>(), dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K,
+                       dSn.as<float>(), algorithm == CNMFE_SPATIAL_HALS_THRESH ? 1 : 0, dAval.as<float>());
+    }
+    CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                 const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out) {
+    const int64_t T = P->T, d = P->d, nnz = A_colptr[K];
+    if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(A) too large");
+    DevBuf &dC = ctx->tmp[0];
+    DevBuf dColptr, dErow, dAval, dU, dCraw, dNk, dNidx, dNval, dNptr, dAa, dLvl;
+    int64_t ldc;
+    RET(upload_traces(ctx, dC, C_in, K, T, c_order, &ldc));
+    RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
+    RET(to_dev(ctx, dErow, A_rowidx, (size_t)nnz));
+    RET(to_dev(ctx, dAval, A_val, (size_t)nnz));
+    RET(dU.ensure((size_t)K * ldc * sizeof(float)));
+    RET(dCraw.ensure((size_t)K * ldc * sizeof(float)));
+    CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dCraw.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));             // C_raw = zeros(K,T)  (:45)
+    // T1
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, T / 128));
+    const int64_t tchunk = (T + nchunk - 1) / nchunk;
+    if (nnz > 0)
+        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, ctx->ysig.as<float>(), d, T, dColptr.as<int64_t>(),
+               dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
+    // T2: overlap graph + V values (neighbour lists include k itself: V(k,k) = aa(k))
+    HostCSR csr; csc_to_csr(d, K, A_colptr, A_rowidx, A_val, csr);
+    std::vector<char> nonempty(K, 0);
+    for (int k = 0; k < K; ++k) nonempty[k] = A_colptr[k + 1] > A_colptr[k];
+    PairGraph g; build_graph(K, csr, d, nonempty, g);
+    std::vector<std::vector<int>> nb(K);
+    for (auto &p : g.pairs) { nb[p.x].push_back(p.y); if (p.x != p.y) nb[p.y].push_back(p.x); }
+    std::vector<int> nptr(K + 1, 0), nk, nidx, diag(K, 0);
+    for (int k = 0; k < K; ++k) {
+        std::sort(nb[k].begin(), nb[k].end());
+        nptr[k] = (int)nidx.size();
+        for (int j : nb[k]) { if (j == k) diag[k] = (int)nidx.size(); nk.push_back(k); nidx.push_back(j); }
+    }
+    nptr[K] = (int)nidx.size();
+    const int nn = (int)nidx.size();
+    RET(to_dev(ctx, dNk, nk.data(), nk.size())); RET(to_dev(ctx, dNidx, nidx.data(), nidx.size())); RET(to_dev(ctx, dNptr, nptr.data(), nptr.size()));
+    RET(dNval.ensure((size_t)std::max(1, nn) * sizeof(float)));
+    LAUNCH(ctx, "temporal_ata_pairs", k_ata_pairs, dim3((nn + 255) / 256), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
+           dNk.as<int>(), dNidx.as<int>(), nn, dNval.as<float>());
+    std::vector<float> nval(nn);
+    CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    std::vector<float> aa(K);
+    std::vector<char> upd(K);
+    for (int k = 0; k < K; ++k) { aa[k] = nval[diag[k]]; upd[k] = aa[k] > 0.f; }                // ind_update = find(aa>0)  (:51)
+    RET(to_dev(ctx, dAa, aa.data(), aa.size()));
+    // T3: level schedule over the neurons that are updated
+    build_graph(K, csr, d, upd, g);
+    std::vector<int> flat, off;
+    for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
+    RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
+    for (int it = 0; it < maxIter; ++it)
+        for (size_t l = 0; l < g.levels.size(); ++l)
+            LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
+                   dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dU.as<float>(), dC.as<float>(), dCraw.as<float>(), ldc, T);
+    RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));
+    RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw_out, K, T, c_order));
+    if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                 const float *A_val, uint8_t *keep) {
+    const int64_t nnz = A_colptr[K];
+    if (nnz == 0) return 0;
+    std::vector<int4> box(K);
+    for (int k = 0; k < K; ++k) {
+        int rmin = d1, rmax = -1, cmin = d2, cmax = -1;
+        for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
+            int r = A_rowidx[e] % d1, c = A_rowidx[e] / d1;
+            rmin = std::min(rmin, r); rmax = std::max(rmax, r); cmin = std::min(cmin, c); cmax = std::max(cmax, c);
+        }
+        if (rmax < 0) { box[k] = make_int4(0, 0, 0, 0); continue; }
+        int h = rmax - rmin + 5, w = cmax - cmin + 5;
+        if (h > PP_MAX || w > PP_MAX)
+            return fail(CNMFE_EUNSUPPORTED, "footprint %d spans %dx%d pixels; post-processing supports %dx%d", k, h - 4, w - 4, PP_MAX - 4, PP_MAX - 4);
+        box[k] = make_int4(rmin - 2, cmin - 2, h, w);
+    }
+    DevBuf dColptr, dErow, dAval, dBox, dKeep;
+    RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
+    RET(to_dev(ctx, dErow, A_rowidx, (size_t)nnz));
+    RET(to_dev(ctx, dAval, A_val, (size_t)nnz));
+    RET(to_dev(ctx, dBox, box.data(), box.size()));
+    RET(dKeep.ensure((size_t)nnz));
+    CK(hipMemsetAsync(dKeep.p, 0, (size_t)nnz, ctx->stream));
+    LAUNCH(ctx, "spatial_connectivity", k_connectivity, dim3(K), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
+           dBox.as<int4>(), d1, d2, dKeep.as<unsigned char>());
+    CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // namespace cnmfe

@@ -1,0 +1,377 @@
+// R1: the residual / background-subtraction kernel.
+//   Ysig = Y(patch,:) - b0 - W * (R - mean_t R),   R = Y_block - A_prev * C_prev
+// (update_spatial_parallel.m:162-166 == update_temporal_parallel.m:149-152, rearranged so that
+//  only centred quantities are accumulated in fp32).
+//
+// HBM-bound by design: one read of the block video + one write of Ysig.  A workgroup owns a
+// TR x TC tile of centre pixels for a whole segment of frames.  The 96..128 ring weights of a
+// thread's pixel live in VGPRs for the lifetime of the workgroup; per chunk of 4 frames the
+// (TR+2r) x (TC+2r) halo of the centred residual is staged once in LDS as float4-per-pixel
+// and every ring neighbour is one conflict-free ds_read_b128 + 4 FMAs.
+#include "common.hpp"
+
+namespace cnmfe {
+
+// row means (double) and centred copy of a [k][ldc] trace matrix
+__global__ void k_center_traces(const float *__restrict__ C, int64_t ldc, int64_t T, float *__restrict__ Cc, double *__restrict__ Cmean) {
+    int k = blockIdx.x;
+    const float *row = C + (int64_t)k * ldc;
+    __shared__ double red[256];
+    double s = 0;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) s += row[t];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    double mean = red[0] / (double)T;
+    if (threadIdx.x == 0) Cmean[k] = mean;
+    float *out = Cc + (int64_t)k * ldc;
+    for (int64_t t = threadIdx.x; t < ldc; t += blockDim.x) out[t] = t < T ? (float)((double)row[t] - mean) : 0.f;
+}
+
+int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean) {
+    RET(Cc.ensure(std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
+    RET(Cmean.ensure(std::max<int32_t>(1, K) * sizeof(double)));
+    if (K > 0) LAUNCH(ctx, "center_traces", k_center_traces, dim3(K), dim3(256), 0, C, ldc, T, Cc.as<float>(), Cmean.as<double>());
+    return 0;
+}
+
+// dlt[m] = ymean_f[q(m)] - b0[m]   (double arithmetic, float result: it is small, = A*Cmean at m)
+__global__ void k_dlt(const float *__restrict__ ymean_f, const double *__restrict__ b0, float *__restrict__ dlt,
+                      int64_t d, int nr, int nr_b, int roff, int coff) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= d) return;
+    int64_t q = (int64_t)((int)(m / nr) + coff) * nr_b + (int)(m % nr) + roff;
+    dlt[m] = (float)((double)ymean_f[q] - b0[m]);
+}
+
+struct R1Args {
+    const float *Y; int64_t d_b; int nr_b, nc_b;
+    int nr, nc, roff, coff; int64_t d;
+    int64_t T, tseg;
+    const float *W; int p, h;
+    const int *offs;                 // generic path only: p entries (dc*HR + dr)
+    const float *ymean_f; const float *dlt;
+    const int *arow; const int *acol; const float *aval; const float *Cc; int64_t ldc;   // A_prev CSR over block pixels (or null)
+    float *Ysig;
+    int ntile_r;
+};
+
+// compile-time ring of get_nhood(R) in MATLAB find() order (column offset slow, row offset fast)
+template <int R> struct RingTab { int n; int dr[PMAX_RING]; int dc[PMAX_RING]; };
+template <int R> constexpr RingTab<R> make_ring() {
+    RingTab<R> t{};
+    int n = 0;
+    for (int c = -R; c <= R; ++c)
+        for (int r = -R; r <= R; ++r) {
+            int d2 = c * c + r * r;
+            if (d2 >= R * R && d2 < (R + 1) * (R + 1)) { t.dr[n] = r; t.dc[n] = c; ++n; }
+        }
+    t.n = n;
+    return t;
+}
+template <int R> struct RingConst { static constexpr RingTab<R> tab = make_ring<R>(); };
+
+// stage the centred residual halo of frames [t0, t0+nf):  R' = (Y - Ymean) - A_prev*(C_prev - mean)
+template <int NT, bool HAS_AC>
+__device__ __forceinline__ void stage_halo(const R1Args &a, float4 *halo, int tid, int HR, int NH, int hr0, int hc0, int64_t t0, int nf) {
+#pragma unroll 2
+    for (int idx = tid; idx < NH; idx += NT) {
+        const int hr = idx % HR, hc = idx / HR;
+        const int rb = hr0 + hr, cb = hc0 + hc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b) {
+            const int64_t q = (int64_t)cb * a.nr_b + rb;
+            const float *y = a.Y + t0 * a.d_b + q;
+            const float ym = a.ymean_f[q];
+            v.x = y[0] - ym;
+            v.y = nf > 1 ? y[a.d_b] - ym : 0.f;
+            v.z = nf > 2 ? y[2 * a.d_b] - ym : 0.f;
+            v.w = nf > 3 ? y[3 * a.d_b] - ym : 0.f;
+            if (HAS_AC) {
+                for (int e = a.arow[q]; e < a.arow[q + 1]; ++e) {
+                    const float av = a.aval[e];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.acol[e] * a.ldc + t0);
+                    v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
+                }
+            }
+        }
+        halo[idx] = v;
+    }
+}
+
+__device__ __forceinline__ void store_ysig(const R1Args &a, int64_t t0, int nf, int64_t qc, int64_t m, float ym_c, float dl, float4 acc) {
+    const float *y = a.Y + t0 * a.d_b + qc;
+    float *o = a.Ysig + t0 * a.d + m;
+    o[0] = (y[0] - ym_c) + dl - acc.x;
+    if (nf > 1) o[a.d] = (y[a.d_b] - ym_c) + dl - acc.y;
+    if (nf > 2) o[2 * a.d] = (y[2 * a.d_b] - ym_c) + dl - acc.z;
+    if (nf > 3) o[3 * a.d] = (y[3 * a.d_b] - ym_c) + dl - acc.w;
+}
+
+// uniform base + 32-bit per-lane byte offset: lowers to `global_load_dword v, v_off, s[base:base+1]`, so a
+// frame-invariant address costs ONE VGPR instead of a hoisted 64-bit pointer pair per array.
+__device__ __forceinline__ float ld_off(const float *base, uint32_t byteoff) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byteoff);
+}
+__device__ __forceinline__ int ld_off(const int *base, uint32_t byteoff) {
+    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byteoff);
+}
+__device__ __forceinline__ void st_off(float *base, uint32_t byteoff, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byteoff) = v;
+}
+
+// waves/SIMD the register allocator must leave room for: weights (P VGPRs) + working registers
+template <int P, int NT> struct R1Occ { static constexpr int value = 2; };
+
+// ---- specialised kernel: ring radius known at compile time --------------------------------------
+// every neighbour address is `thread base + immediate`, so a neighbour costs one ds_read_b128 and
+// four FMAs and no address arithmetic; the P weights stay in VGPRs for the workgroup's lifetime.
+template <int R, int TR, int TC, bool HAS_AC>
+__global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::value)) k_residual_r(R1Args a) {
+    constexpr int NT = TR * TC;
+    constexpr int P = RingConst<R>::tab.n;
+    constexpr int HR = TR + 2 * R, HC = TC + 2 * R, NH = HR * HC;
+    constexpr int NIT = (NH + NT - 1) / NT;                 // halo pixels staged per thread
+    extern __shared__ __attribute__((aligned(16))) float4 halo[];
+    const int tid = threadIdx.x;
+    const int tile_r = blockIdx.x % a.ntile_r, tile_c = blockIdx.x / a.ntile_r;
+    const int tr = tid % TR, tc = tid / TR;
+    const int pr = tile_r * TR + tr, pc = tile_c * TC + tc;
+    const bool valid = pr < a.nr && pc < a.nc;
+    const int64_t m = valid ? (int64_t)pc * a.nr + pr : 0;
+    const int64_t qc = valid ? (int64_t)(pc + a.coff) * a.nr_b + (pr + a.roff) : 0;
+    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
+    const float4 *hb = halo + (tc * HR + tr);           // biased base: neighbour (dr,dc) at hb[(dc+R)*HR + (dr+R)]
+
+    // frame-invariant staging plan of this thread: BYTE offset inside a frame (or ~0u outside the block)
+    // of the NIT halo pixels it stages, and a bit per pixel that A_prev has entries there.
+    uint32_t qoff[NIT];
+    unsigned acmask = 0;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int idx = tid + j * NT;
+        const int hr = idx % HR, hc = idx / HR;
+        const int rb = hr0 + hr, cb = hc0 + hc;
+        const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
+        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 4u : ~0u;
+        if (HAS_AC && in) acmask |= (ld_off(a.arow, qoff[j] + 4u) > ld_off(a.arow, qoff[j])) ? (1u << j) : 0u;
+    }
+    const uint32_t mb = (uint32_t)m * 4u, qcb = (uint32_t)qc * 4u;
+
+    float w[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) w[i] = ld_off(a.W + (int64_t)i * a.d, mb);      // threads off the patch read pixel 0 and never store
+    const float ym_c = ld_off(a.ymean_f, qcb);
+    const float dl = ld_off(a.dlt, mb);
+
+    const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
+    const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
+    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
+        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
+        // frames past the end of the video are clamped to the last one: loaded, never stored
+        const float *y0 = a.Y + t0 * a.d_b;
+        const float *y1 = a.Y + (t0 + (nf > 1 ? 1 : 0)) * a.d_b;
+        const float *y2 = a.Y + (t0 + (nf > 2 ? 2 : nf - 1)) * a.d_b;
+        const float *y3 = a.Y + (t0 + (nf > 3 ? 3 : nf - 1)) * a.d_b;
+        // ---- stage R' = (Y - Ymean) - A_prev*(C_prev - mean) for the halo, float4 (4 frames) per pixel ----
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int idx = tid + j * NT;
+            const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
+            const float ym = ld_off(a.ymean_f, qo);
+            float4 v = make_float4(ld_off(y0, qo) - ym, ld_off(y1, qo) - ym, ld_off(y2, qo) - ym, ld_off(y3, qo) - ym);
+            if (HAS_AC && ((acmask >> j) & 1u)) {
+                for (int e = ld_off(a.arow, qo); e < ld_off(a.arow, qo + 4u); ++e) {
+                    const float av = a.aval[e];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.acol[e] * a.ldc + t0);
+                    v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
+                }
+            }
+            if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NIT * NT == NH || idx < NH) halo[idx] = v;
+            // compiler-level fence every 2 pixels: caps the loads in flight per thread at 10 so the P ring
+            // weights are not spilled to make room (other waves of the CU provide the memory parallelism)
+            asm volatile("" ::: "memory");
+        }
+        __syncthreads();
+        // ---- ring product: groups of G neighbours = G ds_read_b128 then 4G FMAs.  The empty asm is a
+        // compiler-level memory fence: without it all P reads (4 VGPRs each) are hoisted and spill. ----
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int G = 4;
+        static_assert(P % G == 0, "ring size must be a multiple of the read group");
+#pragma unroll
+        for (int g = 0; g < P / G; ++g) {
+            float4 r[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                r[j] = hb[(RingConst<R>::tab.dc[g * G + j] + R) * HR + (RingConst<R>::tab.dr[g * G + j] + R)];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const float wi = w[g * G + j];
+                acc.x = fmaf(wi, r[j].x, acc.x); acc.y = fmaf(wi, r[j].y, acc.y);
+                acc.z = fmaf(wi, r[j].z, acc.z); acc.w = fmaf(wi, r[j].w, acc.w);
+            }
+            // ties this group's FMAs (through acc) into the memory order, so the next group's reads
+            // cannot be issued before them and pile up in registers
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+        }
+        if (valid) {
+            float *o = a.Ysig + t0 * a.d;
+            st_off(o, mb, (ld_off(y0, qcb) - ym_c) + dl - acc.x);
+            if (nf > 1) st_off(o + a.d, mb, (ld_off(y1, qcb) - ym_c) + dl - acc.y);
+            if (nf > 2) st_off(o + 2 * a.d, mb, (ld_off(y2, qcb) - ym_c) + dl - acc.z);
+            if (nf > 3) st_off(o + 3 * a.d, mb, (ld_off(y3, qcb) - ym_c) + dl - acc.w);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- generic kernel: any ring (runtime offsets, weights streamed from L2) --------------------------
+template <bool HAS_AC>
+__global__ void __launch_bounds__(256) k_residual_gen(R1Args a) {
+    constexpr int NT = 256, TR = 16;
+    extern __shared__ __attribute__((aligned(16))) float4 halo[];
+    const int h = a.h, HR = TR + 2 * h, HC = TR + 2 * h, NH = HR * HC;
+    const int tid = threadIdx.x;
+    const int tile_r = blockIdx.x % a.ntile_r, tile_c = blockIdx.x / a.ntile_r;
+    const int tr = tid % TR, tc = tid / TR;
+    const int pr = tile_r * TR + tr, pc = tile_c * TR + tc;
+    const bool valid = pr < a.nr && pc < a.nc;
+    const int64_t m = valid ? (int64_t)pc * a.nr + pr : 0;
+    const int64_t qc = (int64_t)(pc + a.coff) * a.nr_b + (pr + a.roff);
+    const int hr0 = tile_r * TR + a.roff - h, hc0 = tile_c * TR + a.coff - h;
+    const int base = (tc + h) * HR + (tr + h);
+    const float ym_c = valid ? a.ymean_f[qc] : 0.f;
+    const float dl = valid ? a.dlt[m] : 0.f;
+    const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
+    const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
+    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
+        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
+        stage_halo<NT, HAS_AC>(a, halo, tid, HR, NH, hr0, hc0, t0, nf);
+        __syncthreads();
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            for (int i = 0; i < a.p; ++i) {
+                const float wi = a.W[(int64_t)i * a.d + m];
+                const float4 r = halo[base + a.offs[i]];
+                acc.x = fmaf(wi, r.x, acc.x); acc.y = fmaf(wi, r.y, acc.y);
+                acc.z = fmaf(wi, r.z, acc.z); acc.w = fmaf(wi, r.w, acc.w);
+            }
+            store_ysig(a, t0, nf, qc, m, ym_c, dl, acc);
+        }
+        __syncthreads();
+    }
+}
+
+template <int R, int TR, int TC>
+static int launch_r1(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid) {
+    constexpr size_t shmem = (size_t)(TR + 2 * R) * (TC + 2 * R) * sizeof(float4);
+    static_assert(shmem <= 160 * 1024, "halo tile exceeds LDS");
+    if (shmem > 64 * 1024) {
+        CK(hipFuncSetAttribute((const void *)k_residual_r<R, TR, TC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        CK(hipFuncSetAttribute((const void *)k_residual_r<R, TR, TC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    }
+    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_r<R, TR, TC, true>), grid, dim3(TR * TC), shmem, a);
+    else        LAUNCH(ctx, "residual_r1", (k_residual_r<R, TR, TC, false>), grid, dim3(TR * TC), shmem, a);
+    return 0;
+}
+
+template <int R>
+static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
+    // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
+    dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
+    switch (variant) {
+        case 1: return launch_r1<R, 32, 8>(ctx, a, has_ac, grid);
+        case 2: return launch_r1<R, 32, 16>(ctx, a, has_ac, grid);
+        case 3: return launch_r1<R, 64, 4>(ctx, a, has_ac, grid);
+        case 4: return launch_r1<R, 64, 8>(ctx, a, has_ac, grid);
+        default: return launch_r1<R, 16, 16>(ctx, a, has_ac, grid);
+    }
+}
+
+static void tile_shape(int variant, int &TR, int &TC) {
+    TR = 16; TC = 16;
+    if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2) { TR = 32; TC = 16; }
+    else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
+}
+
+int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace) {
+    const int64_t T = P->T;
+    RET(ctx->ysig.ensure((size_t)P->d * T * sizeof(float)));
+    DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
+           &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7];
+    int64_t ldc = 4;
+    bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
+    if (has_ac) {
+        RET(upload_traces(ctx, dC, C, Ksel, T, c_order, &ldc));
+        RET(center_traces(ctx, dC.as<float>(), ldc, Ksel, T, dCc, dCm));
+        HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
+        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
+        RET(to_dev(ctx, dArow, rp.data(), rp.size()));
+        RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
+        RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+    }
+    RET(dDlt.ensure(P->d * sizeof(float)));
+    LAUNCH(ctx, "r1_dlt", k_dlt, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
+           P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
+
+    // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
+    int variant = (int)ctx->opt("r1_variant", 0);
+    const int h = P->radius;
+    bool full_ring = true;
+    { int n = 0;
+      for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
+          if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
+      if (n != P->p) full_ring = false; }
+    const bool special = full_ring && (h == 15 || h == 18) && variant >= 0;
+    int TR = 16, TC = 16;
+    if (special) tile_shape(variant, TR, TC);
+    const int HR = TR + 2 * h, HC = TC + 2 * h;
+
+    R1Args a;
+    a.Y = P->Y.as<float>(); a.d_b = P->d_b; a.nr_b = P->nr_b; a.nc_b = P->nc_b;
+    a.nr = P->nr; a.nc = P->nc; a.roff = P->roff; a.coff = P->coff; a.d = P->d;
+    a.T = T;
+    a.W = P->W.as<float>(); a.p = P->p; a.h = h; a.offs = nullptr;
+    a.ymean_f = P->ymean_f.as<float>(); a.dlt = dDlt.as<float>();
+    a.arow = has_ac ? dArow.as<int>() : nullptr; a.acol = has_ac ? dAcol.as<int>() : nullptr;
+    a.aval = has_ac ? dAval.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
+    a.Ysig = ctx->ysig.as<float>();
+    a.ntile_r = (P->nr + TR - 1) / TR;
+    const int ntile_c = (P->nc + TC - 1) / TC;
+    const int64_t ntiles = (int64_t)a.ntile_r * ntile_c;
+    // enough workgroups to fill 256 CUs several times over; segments are a multiple of 4 frames
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((T + 255) / 256, (4096 + ntiles - 1) / ntiles));
+    int64_t tseg = ((T + nseg - 1) / nseg + 3) & ~int64_t(3);
+    nseg = (T + tseg - 1) / tseg;
+    a.tseg = tseg;
+    int rc;
+    if (special) {
+        rc = h == 15 ? launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg) : launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);
+    } else {
+        std::vector<int32_t> offs(std::max(1, P->p), 0);
+        for (int i = 0; i < P->p; ++i) offs[i] = P->dc[i] * HR + P->dr[i];
+        RET(to_dev(ctx, dOffs, offs.data(), offs.size()));
+        a.offs = dOffs.as<int>();
+        size_t shmem = (size_t)HR * HC * sizeof(float4);
+        if (shmem > 160 * 1024) return fail(CNMFE_EUNSUPPORTED, "ring radius %d needs %zu B of LDS per tile", h, shmem);
+        if (shmem > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void *)k_residual_gen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            CK(hipFuncSetAttribute((const void *)k_residual_gen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        }
+        dim3 grid((unsigned)ntiles, (unsigned)nseg);
+        if (has_ac) LAUNCH(ctx, "residual_r1_generic", k_residual_gen<true>, grid, dim3(256), shmem, a);
+        else        LAUNCH(ctx, "residual_r1_generic", k_residual_gen<false>, grid, dim3(256), shmem, a);
+        rc = 0;
+    }
+    RET(rc);
+    ctx->ysig_patch = pid; P->ysig_valid = true;
+    if (Ysig_out) {
+        CK(hipMemcpyAsync(Ysig_out, ctx->ysig.p, (size_t)P->d * T * sizeof(float),
+                          out_memspace == CNMFE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // namespace cnmfe

@@ -1,0 +1,194 @@
+"""Thin numpy-facing wrapper over the C ABI (one Engine == one cnmfe_ctx == one GPU).
+
+Mirrors the reference's per-patch kernel functions (SURVEY.md section 8(b) level 2):
+  fit_ring_model, the residual expression, HALS_spatial(_thresh), nnls_spatial,
+  HALS_temporal, post_process_spatial.
+All arrays cross the boundary as plain pointers; sparse matrices are scipy CSC
+(MATLAB's layout).  Trace matrices are numpy (K, T) C-order == CNMFE_ROWMAJOR.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+
+_DT = {np.dtype(np.float32): L.F32, np.dtype(np.float64): L.F64, np.dtype(np.uint16): L.U16,
+       np.dtype(np.uint8): L.U8, np.dtype(np.float16): L.F16}
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None and a.size else C.cast(None, t)
+
+
+def _csc(A, nrow):
+    """-> (K, colptr int64, rowidx int32, val float32) with sorted, de-duplicated columns."""
+    A = sp.csc_matrix(A)
+    if A.shape[0] != nrow:
+        raise ValueError("sparse matrix has %d rows, expected %d" % (A.shape[0], nrow))
+    if not A.has_canonical_format:
+        A = A.copy(); A.sum_duplicates(); A.sort_indices()
+    return (A.shape[1], np.ascontiguousarray(A.indptr, dtype=np.int64),
+            np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.data, dtype=np.float32))
+
+
+def _traces(Cm, K, T):
+    Cm = np.ascontiguousarray(Cm, dtype=np.float32)
+    if Cm.shape != (K, T):
+        raise ValueError("trace matrix has shape %s, expected %s" % (Cm.shape, (K, T)))
+    return Cm
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self._ctx = L.lib.cnmfe_create(int(device))
+        if not self._ctx:
+            raise L.CnmfeError("cnmfe_create failed: " + L.lib.cnmfe_last_error().decode())
+        self.device = device
+        self._patch = {}
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            L.lib.cnmfe_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data plane ---------------------------------------------------------
+    def create_patch(self, pid, patch_rect, block_rect, d1, d2, T):
+        pr = np.asarray(patch_rect, dtype=np.int32); br = np.asarray(block_rect, dtype=np.int32)
+        L.check(L.lib.cnmfe_patch_create(self._ctx, pid, _p(pr, L.i32p), _p(br, L.i32p), d1, d2, T))
+        nr, nc = int(pr[1] - pr[0] + 1), int(pr[3] - pr[2] + 1)
+        nrb, ncb = int(br[1] - br[0] + 1), int(br[3] - br[2] + 1)
+        self._patch[pid] = dict(d=nr * nc, d_b=nrb * ncb, T=int(T), nr=nr, nc=nc, nr_b=nrb, nc_b=ncb)
+
+    def upload_block(self, pid, Y, t0=0):
+        """Y: (nt, d_b) host array (float32/float64/uint16/uint8/float16), frames t0..t0+nt."""
+        Y = np.ascontiguousarray(Y)
+        info = self._patch[pid]
+        if Y.ndim != 2 or Y.shape[1] != info["d_b"]:
+            raise ValueError("block must be (frames, %d), got %s" % (info["d_b"], Y.shape))
+        L.check(L.lib.cnmfe_upload_block(self._ctx, pid, Y.ctypes.data_as(C.c_void_p), _DT[Y.dtype], L.HOST, t0, Y.shape[0]))
+
+    def upload_block_device(self, pid, dev_ptr, nt, t0=0, dtype=L.F32):
+        """dev_ptr: raw device address of an (nt, d_b) array already in HBM (e.g. torch tensor .data_ptr())."""
+        L.check(L.lib.cnmfe_upload_block(self._ctx, pid, C.c_void_p(int(dev_ptr)), dtype, L.DEVICE, t0, nt))
+
+    def ymean(self, pid):
+        out = np.empty(self._patch[pid]["d_b"], dtype=np.float64)
+        L.check(L.lib.cnmfe_get_ymean(self._ctx, pid, _p(out, L.f64p)))
+        return out
+
+    # ---- ring -----------------------------------------------------------------
+    def ring_init(self, pid, radius, num_neighbors=None):
+        L.check(L.lib.cnmfe_ring_init(self._ctx, pid, int(radius), int(num_neighbors or 0)))
+
+    def ring_csr(self, pid):
+        nnz = C.c_int64(); p = C.c_int32()
+        L.check(L.lib.cnmfe_ring_nnz(self._ctx, pid, C.byref(nnz), C.byref(p)))
+        info = self._patch[pid]
+        rowptr = np.empty(info["d"] + 1, dtype=np.int64)
+        col = np.empty(nnz.value, dtype=np.int32); val = np.empty(nnz.value, dtype=np.float32)
+        L.check(L.lib.cnmfe_ring_get_csr(self._ctx, pid, _p(rowptr, L.i64p), _p(col, L.i32p), _p(val, L.f32p)))
+        return sp.csr_matrix((val, col, rowptr), shape=(info["d"], info["d_b"]))
+
+    def ring_first_run(self, pid):
+        f = C.c_int()
+        L.check(L.lib.cnmfe_ring_first_run(self._ctx, pid, C.byref(f)))
+        return bool(f.value)
+
+    def ring_set_values(self, pid, val):
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        L.check(L.lib.cnmfe_ring_set_values(self._ctx, pid, _p(val, L.f32p)))
+
+    def b0(self, pid):
+        out = np.empty(self._patch[pid]["d"], dtype=np.float32)
+        L.check(L.lib.cnmfe_b0_get(self._ctx, pid, _p(out, L.f32p)))
+        return out
+
+    def set_b0(self, pid, b0):
+        b0 = np.ascontiguousarray(b0, dtype=np.float32)
+        L.check(L.lib.cnmfe_b0_set(self._ctx, pid, _p(b0, L.f32p)))
+
+    # ---- kernels ----------------------------------------------------------------
+    def fit_ring_model(self, pid, A_block, C_block, thresh_outlier=float("nan"), with_projection=True, want_b0=True):
+        """[W, b0] = fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection); W stays resident."""
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_block, info["d_b"]) if A_block is not None else (0, None, None, None)
+        Cm = _traces(C_block, K, info["T"]) if K else None
+        b0 = np.empty(info["d"], dtype=np.float32) if want_b0 else None
+        inf = np.zeros(4, dtype=np.int64)
+        L.check(L.lib.cnmfe_fit_ring_model(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p),
+                                           L.ROWMAJOR, float(thresh_outlier), int(bool(with_projection)), _p(b0, L.f32p), _p(inf, L.i64p)))
+        return b0, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
+
+    def residual(self, pid, A_prev_block=None, C_prev=None, want=False):
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_prev_block, info["d_b"]) if A_prev_block is not None and A_prev_block.shape[1] else (0, None, None, None)
+        Cm = _traces(C_prev, K, info["T"]) if K else None
+        out = np.empty((info["T"], info["d"]), dtype=np.float32) if want else None
+        L.check(L.lib.cnmfe_residual(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+                                     out.ctypes.data_as(C.c_void_p) if want else C.c_void_p(None), L.HOST))
+        return out
+
+    def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3):
+        """Returns the updated A as a CSC matrix with exactly IND's pattern (explicit zeros kept)."""
+        info = self._patch[pid]
+        alg = {"hals": L.SPATIAL_HALS, "hals_thresh": L.SPATIAL_HALS_THRESH, "nnls": L.SPATIAL_NNLS}[algorithm]
+        K, cp, ri, va = _csc(A_patch, info["d"])
+        IND = sp.csc_matrix(IND_patch).astype(np.float32)
+        IND.sort_indices()
+        K2, icp, iri, _ = _csc(IND, info["d"])
+        if K2 != K:
+            raise ValueError("A and IND disagree on K")
+        Cm = _traces(C_patch, K, info["T"])
+        snf = np.ascontiguousarray(sn, dtype=np.float32).ravel() if sn is not None else None
+        out = np.zeros(icp[-1], dtype=np.float32)
+        L.check(L.lib.cnmfe_update_spatial(self._ctx, pid, alg, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+                                           _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), _p(out, L.f32p)))
+        return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
+
+    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5):
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_patch, info["d"])
+        Cm = _traces(C_patch, K, info["T"])
+        Cout = np.empty_like(Cm); Craw = np.empty_like(Cm); aa = np.empty(K, dtype=np.float32)
+        L.check(L.lib.cnmfe_hals_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+                                          int(maxIter), _p(Cout, L.f32p), _p(Craw, L.f32p), _p(aa, L.f32p)))
+        return Cout, Craw, aa
+
+    def post_process_spatial(self, A_full, d1, d2):
+        K, cp, ri, va = _csc(A_full, d1 * d2)
+        keep = np.zeros(cp[-1], dtype=np.uint8)
+        L.check(L.lib.cnmfe_post_process_spatial(self._ctx, d1, d2, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(keep, L.u8p)))
+        out = sp.csc_matrix((va * keep, ri.copy(), cp.copy()), shape=(d1 * d2, K))
+        out.eliminate_zeros()
+        return out
+
+    # ---- measurement ---------------------------------------------------------------
+    def profile(self, on=True):
+        L.check(L.lib.cnmfe_profile_enable(self._ctx, int(on)))
+
+    def profile_reset(self):
+        L.check(L.lib.cnmfe_profile_reset(self._ctx))
+
+    def profile_table(self):
+        n = L.lib.cnmfe_profile_count(self._ctx)
+        out = {}
+        for i in range(n):
+            name = C.create_string_buffer(128); ms = C.c_double(); calls = C.c_int64()
+            L.check(L.lib.cnmfe_profile_get(self._ctx, i, name, 128, C.byref(ms), C.byref(calls)))
+            out[name.value.decode()] = dict(total_ms=ms.value, calls=calls.value)
+        return out
+
+    def synchronize(self):
+        L.check(L.lib.cnmfe_synchronize(self._ctx))
+
+    def set_option(self, name, value):
+        L.check(L.lib.cnmfe_set_option(self._ctx, name.encode(), int(value)))

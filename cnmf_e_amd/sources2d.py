@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's ``Sources2D`` update methods on top of the HIP engine.
+
+The reference is MATLAB (`ca_source_extraction/@Sources2D/`); there is no MATLAB in the build image,
+so the host side above the C ABI is Python and keeps the reference's names, argument meaning and
+error behaviour for the ONE path this project covers:
+
+    update_background_parallel(use_parallel)            @Sources2D/update_background_parallel.m:1
+    update_spatial_parallel(use_parallel, update_sn)    @Sources2D/update_spatial_parallel.m:1
+    update_temporal_parallel(use_parallel, use_c_hat)   @Sources2D/update_temporal_parallel.m:1
+
+Per-patch slicing (which neurons / pixels go to which patch, how results are stitched) is host
+logic exactly as in the reference; every numerical kernel runs on the GPU through
+``cnmf_e_amd.engine.Engine`` (no CPU fallback).  Patches can be sharded over ranks of a
+``torch.distributed`` group (one process per GPU): background and spatial updates need no
+collective on the data path, the temporal update does ONE all-reduce of ``aa .* C_raw`` and ``aa``
+(update_temporal_parallel.m:269-280).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+from .engine import Engine
+
+__all__ = ["Options", "PatchedVideo", "Sources2D", "distribute_geometry", "determine_search_location"]
+
+
+# --------------------------------------------------------------------------------------
+# options actually read by the hot path (CNMFSetParms.m)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Options:
+    d1: int = 0
+    d2: int = 0
+    ring_radius: int = 15            # CNMFSetParms.m:106
+    num_neighbors: int | None = None  # :109
+    bg_ssub: int = 1                 # :107
+    bg_acceleration: bool = True     # :108
+    thresh_outlier: float = float("nan")   # :112
+    background_model: str = "ring"   # demo_large_data_1p.m:54
+    spatial_algorithm: str = "hals"  # :117  ('hals' | 'hals_thresh' | 'nnls')
+    search_method: str = "ellipse"   # :48
+    min_size: float = 3.0            # :51
+    max_size: float = 8.0            # :52
+    dist: float = 3.0                # :53
+    maxIter: int = 5                 # :36
+    deconv_flag: bool = False        # :101 (the deconvolution branch is not built yet)
+    spatial_constraints: dict = field(default_factory=lambda: {"circular": False, "connected": True})   # :116
+
+
+def _mround(x):
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
+
+
+def distribute_geometry(d1, d2, patch_dims, w_overlap):
+    """patch_pos / block_pos exactly as endoscope/distribute_data.m:38-100,161-173 lays them out
+    (1-based inclusive [r0 r1 c0 c1]; block = patch grown by w_overlap+1, clipped)."""
+    minw = 2 * w_overlap + 3
+    pd = np.atleast_1d(np.asarray(patch_dims, dtype=np.float64)).copy()
+    pd[pd < minw] = minw
+    pd = np.array([pd[0], pd[0]]) if pd.size == 1 else pd[:2]
+    nrp, ncp = int(_mround(d1 / pd[0])), int(_mround(d2 / pd[1]))
+
+    def edges(n, dd, rows):
+        if n <= 1:
+            return np.array([1, dd], dtype=np.int64)
+        e = np.ceil(np.linspace(1, dd, n + 1)).astype(np.int64)
+        if rows:
+            e[-1] = dd
+        if e[1] - e[0] < minw:
+            e = np.arange(1, dd + 1, minw, dtype=np.int64)
+            e[-1] = dd
+        return e
+
+    er, ec = edges(nrp, d1, True), edges(ncp, d2, False)
+    nrp, ncp = er.size - 1, ec.size - 1
+    patch_pos, block_pos = {}, {}
+    for m in range(nrp):
+        for n in range(ncp):
+            patch_pos[(m, n)] = np.array([er[m], er[m + 1] - (m != nrp - 1), ec[n], ec[n + 1] - (n != ncp - 1)], dtype=np.int64)
+            block_pos[(m, n)] = np.array([max(1, er[m] - w_overlap - 1), min(d1, er[m + 1] + w_overlap),
+                                          max(1, ec[n] - w_overlap - 1), min(d2, ec[n + 1] + w_overlap)], dtype=np.int64)
+    return (nrp, ncp), patch_pos, block_pos
+
+
+def _rect_pixels(rect, d1):
+    """global column-major pixel indices of a rectangle, in the rectangle's own column-major order"""
+    r0, r1, c0, c1 = [int(v) for v in rect]
+    rr = np.arange(r0 - 1, r1)
+    cc = np.arange(c0 - 1, c1)
+    return (cc[None, :] * d1 + rr[:, None]).reshape(-1, order="F")
+
+
+def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
+    """'ellipse' search masks, utilities/determine_search_location.m:50-104 + utilities/com.m:20-28.
+    Vectorised over neurons; returns a boolean CSC matrix (d x K)."""
+    A = sp.csc_matrix(A, dtype=np.float64)
+    d, K = A.shape
+    A.sort_indices()
+    coo = A.tocoo()
+    pix, col, val = coo.row, coo.col, coo.data
+    x = (pix % d1 + 1).astype(np.float64)
+    y = (pix // d1 + 1).astype(np.float64)
+    s = np.bincount(col, weights=val, minlength=K)
+    empty = s == 0                                                        # :52
+    ss = np.where(empty, 1.0, s)
+    cmx = np.bincount(col, weights=val * x, minlength=K) / ss             # com.m:24
+    cmy = np.bincount(col, weights=val * y, minlength=K) / ss
+    cmx = np.clip(cmx, 0, d1); cmy = np.clip(cmy, 0, d2)                  # com.m:26-28
+    dx, dy = x - cmx[col], y - cmy[col]
+    vxx = np.bincount(col, weights=val * dx * dx, minlength=K) / ss       # :73
+    vxy = np.bincount(col, weights=val * dx * dy, minlength=K) / ss
+    vyy = np.bincount(col, weights=val * dy * dy, minlength=K) / ss
+    M = np.stack([np.stack([vxx, vxy], -1), np.stack([vxy, vyy], -1)], -2)
+    D, V = np.linalg.eigh(M)                                              # :74 ascending eigenvalues
+    d11 = np.minimum(max_size ** 2, np.maximum(min_size ** 2, D[:, 0]))   # :81
+    d22 = np.minimum(max_size ** 2, np.maximum(min_size ** 2, D[:, 1]))   # :82
+    R = int(np.ceil(dist * max_size)) + 1
+    off = np.arange(-R, R + 1)
+    rows = np.floor(cmx)[:, None] + off[None, :]                           # (K, W) candidate rows (1-based)
+    cols = np.floor(cmy)[:, None] + off[None, :]
+    ex = rows - cmx[:, None]
+    ey = cols - cmy[:, None]
+    # (cor*V(:,1))^2/d11 + (cor*V(:,2))^2/d22 <= dist^2                    (:84)
+    p1 = ex[:, :, None] * V[:, 0, 0][:, None, None] + ey[:, None, :] * V[:, 1, 0][:, None, None]
+    p2 = ex[:, :, None] * V[:, 0, 1][:, None, None] + ey[:, None, :] * V[:, 1, 1][:, None, None]
+    inside = np.sqrt(p1 ** 2 / d11[:, None, None] + p2 ** 2 / d22[:, None, None]) <= dist
+    inside &= (rows >= 1)[:, :, None] & (rows <= d1)[:, :, None] & (cols >= 1)[:, None, :] & (cols <= d2)[:, None, :]
+    inside &= ~empty[:, None, None]                                        # :102-104
+    kk, ri, ci = np.nonzero(inside)
+    gp = ((cols[kk, ci] - 1) * d1 + (rows[kk, ri] - 1)).astype(np.int64)
+    IND = sp.csc_matrix((np.ones(kk.size, dtype=bool), (gp, kk)), shape=(d, K))
+    IND.sort_indices()
+    return IND
+
+
+# --------------------------------------------------------------------------------------
+# the blocked, GPU-resident video ( == mat_data + get_patch_data of the reference )
+# --------------------------------------------------------------------------------------
+class PatchedVideo:
+    """Geometry of distribute_data + one resident block per owned patch.
+
+    rank/world_size shard the patches round-robin in MATLAB's linear patch order
+    (SURVEY.md section 8(e)); each rank uploads only the blocks of the patches it owns.
+    """
+
+    def __init__(self, d1, d2, T, patch_dims, ring_radius, engine: Engine, rank=0, world_size=1):
+        self.d1, self.d2, self.T = int(d1), int(d2), int(T)
+        self.dims = (self.d1, self.d2, self.T)
+        self.w_overlap = int(ring_radius)                                  # Sources2D.m:236
+        (self.nr_patch, self.nc_patch), self.patch_pos, self.block_pos = distribute_geometry(d1, d2, patch_dims, ring_radius)
+        # MATLAB linear index over the nr_patch x nc_patch cell: row index fastest
+        self.order = [(m, n) for n in range(self.nc_patch) for m in range(self.nr_patch)]
+        self.engine = engine
+        self.rank, self.world_size = rank, world_size
+        self.owned = [idx for i, idx in enumerate(self.order) if i % world_size == rank]
+        self.pid = {idx: i for i, idx in enumerate(self.order)}
+        self.patch_pix = {idx: _rect_pixels(self.patch_pos[idx], d1) for idx in self.order}
+        self.block_pix = {idx: _rect_pixels(self.block_pos[idx], d1) for idx in self.order}
+        self.ind_patch = {}
+        for idx in self.order:
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            mask = np.zeros((b[1] - b[0] + 1, b[3] - b[2] + 1), dtype=bool)
+            mask[p[0] - b[0]:p[1] - b[0] + 1, p[2] - b[2]:p[3] - b[2] + 1] = True   # update_spatial_parallel.m:140-141
+            self.ind_patch[idx] = np.nonzero(mask.reshape(-1, order="F"))[0]
+        for idx in self.owned:
+            engine.create_patch(self.pid[idx], self.patch_pos[idx], self.block_pos[idx], d1, d2, T)
+
+    def upload_from_full(self, Y_td, chunk=512):
+        """Y_td: (T, d1*d2) host video, frame-major / pixels column-major (MATLAB d x T)."""
+        for idx in self.owned:
+            bp = self.block_pix[idx]
+            for t0 in range(0, self.T, chunk):
+                self.engine.upload_block(self.pid[idx], Y_td[t0:t0 + chunk][:, bp], t0)
+
+    def upload_block_device(self, idx, dev_ptr):
+        self.engine.upload_block_device(self.pid[idx], dev_ptr, self.T)
+
+
+# --------------------------------------------------------------------------------------
+# Sources2D
+# --------------------------------------------------------------------------------------
+class Sources2D:
+    """State and the three update methods of the reference's handle class (Sources2D.m:10-57):
+    A (d x K sparse), A_prev, C, C_prev, C_raw (K x T), W{.}/b0{.} (resident on the GPU per patch,
+    fetch with ``get_W`` / ``get_b0``), b0_new, options, P (sn, Ymean)."""
+
+    def __init__(self, video: PatchedVideo, options: Options, A, C, sn, dist_group=None):
+        if options.background_model != "ring":
+            raise ValueError("only the ring background model is built (north star); got %r" % options.background_model)
+        if options.bg_ssub != 1:
+            raise NotImplementedError("bg_ssub > 1 (imresize around W) is not built yet")
+        self.video = video
+        self.options = options
+        options.d1, options.d2 = video.d1, video.d2
+        self.engine = video.engine
+        d = video.d1 * video.d2
+        self.A = sp.csc_matrix(A, dtype=np.float32)
+        if self.A.shape[0] != d:
+            raise ValueError("A must have d1*d2 rows")
+        self.C = np.ascontiguousarray(C, dtype=np.float32)
+        self.C_raw = self.C.copy()
+        self.A_prev = self.A.copy()
+        self.C_prev = self.C.copy()
+        self.P = {"sn": np.asarray(sn, dtype=np.float32).reshape(-1).copy(), "Ymean": {}}
+        self.b0_new = None
+        self.dist = dist_group
+        for idx in video.owned:                                           # initComponents_parallel.m:213-236
+            self.engine.ring_init(video.pid[idx], options.ring_radius, options.num_neighbors)
+            self.P["Ymean"][idx] = self.engine.ymean(video.pid[idx])[video.ind_patch[idx]]      # :338-339, patch part
+        self._ymean_full = None
+
+    # -- accessors ------------------------------------------------------------------
+    def get_W(self, idx):
+        return self.engine.ring_csr(self.video.pid[idx])
+
+    def get_b0(self, idx):
+        return self.engine.b0(self.video.pid[idx])
+
+    def _need_data(self):
+        if self.video is None:
+            raise RuntimeError("No data file selected")                   # update_spatial_parallel.m:13-38
+
+    def reconstruct_b0(self):
+        """Sources2D.m:1153-1190: stitch b0{m} into a d1 x d2 image (owned patches; all-reduced if sharded)."""
+        v = self.video
+        out = np.zeros(v.d1 * v.d2, dtype=np.float32)
+        for idx in v.owned:
+            out[v.patch_pix[idx]] = self.get_b0(idx)
+        out = self._allreduce(out)
+        return out.reshape(v.d1, v.d2, order="F")
+
+    def ymean_full(self):
+        if self._ymean_full is None:
+            v = self.video
+            out = np.zeros(v.d1 * v.d2, dtype=np.float64)
+            for idx in v.owned:
+                out[v.patch_pix[idx]] = self.P["Ymean"][idx]
+            self._ymean_full = self._allreduce(out)
+        return self._ymean_full
+
+    def _allreduce(self, arr):
+        if self.dist is None or self.video.world_size == 1:
+            return arr
+        import torch
+        import torch.distributed as td
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if td.get_backend(self.dist) == "nccl":
+            t = t.cuda()
+        td.all_reduce(t, group=self.dist)
+        return t.cpu().numpy()
+
+    def _update_b0_new(self):
+        v = self.video
+        self.b0_new = (self.ymean_full() - np.asarray(self.A @ self.C.mean(axis=1, dtype=np.float64)).ravel()) \
+            .reshape(v.d1, v.d2, order="F")                               # update_spatial_parallel.m:349
+
+    # -- background -------------------------------------------------------------------
+    def update_background_parallel(self, use_parallel=True):
+        """@Sources2D/update_background_parallel.m:121-146,176-230,311-317 (ring model, bg_ssub = 1)."""
+        self._need_data()
+        v, o = self.video, self.options
+        A_csr = self.A.tocsr()
+        infos = {}
+        for idx in v.owned:
+            bp = v.block_pix[idx]
+            Ab = A_csr[bp]
+            ind = np.asarray(Ab.sum(axis=0)).ravel() > 0                   # :128
+            A_block = Ab[:, ind].tocsc()                                   # :129
+            C_block = self.C[ind]                                          # :130
+            # "stop updating B because A&C doesn't change in this area" (:188-199) is decided by the engine's
+            # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
+            if A_block.shape[1] == 0 and not self._first_run(idx):
+                continue
+            _, infos[idx] = self.engine.fit_ring_model(v.pid[idx], A_block if A_block.shape[1] else None, C_block,
+                                                       o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218
+        self.b0_new = self.reconstruct_b0()                                # :315
+        self.A_prev = self.A.copy()                                        # :316
+        self.C_prev = self.C.copy()                                        # :317
+        return infos
+
+    def _first_run(self, idx):
+        """flag_first = (length(unique(W{1}(1,:)))==2)  (update_background_parallel.m:143); the same value test,
+        evaluated on this patch's own W{m} so that sharded ranks need no broadcast of patch 1."""
+        return self.engine.ring_first_run(self.video.pid[idx])
+
+    # -- spatial ----------------------------------------------------------------------
+    def update_spatial_parallel(self, use_parallel=True, update_sn=False):
+        """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""
+        self._need_data()
+        if update_sn:
+            raise NotImplementedError("update_sn=true (GetSn / pwelch over the residual, :191-194) is not built yet")
+        v, o = self.video, self.options
+        if o.search_method != "ellipse":
+            raise NotImplementedError("only search_method='ellipse' is built")
+        IND = determine_search_location(self.A, v.d1, v.d2, o.min_size, o.max_size, o.dist)     # :66
+        IND_csr = IND.tocsr()
+        A_csr = self.A.tocsr()
+        Aprev_csr = self.A_prev.tocsr()
+        K = self.A.shape[1]
+        rows, cols, vals = [], [], []
+        for idx in v.owned:
+            pp, bp, ip = v.patch_pix[idx], v.block_pix[idx], v.ind_patch[idx]
+            INDp = IND_csr[pp]
+            ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]                          # :87
+            if ind.size == 0:
+                continue                                                                             # :121-124
+            A_patch = A_csr[pp][:, ind].tocsc()                                                     # :88,199
+            IND_patch = INDp[:, ind].tocsc()                                                        # :89
+            sn_patch = self.P["sn"][pp]                                                             # :90
+            C_patch = self.C[ind]                                                                   # :91
+            # A_prev restricted to neurons that touch the HALO only (mask==1 after the patch is set to 2, :84-85,96)
+            halo = np.setdiff1d(bp, pp, assume_unique=True)
+            if halo.size:
+                indp = np.nonzero(np.asarray(Aprev_csr[halo].sum(axis=0)).ravel() > 0)[0]
+            else:
+                indp = np.zeros(0, dtype=np.int64)
+            A_prev_b = Aprev_csr[bp][:, indp].tocsc() if indp.size else None                        # :97
+            C_prev_b = self.C_prev[indp] if indp.size else None                                     # :98
+            self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                    # :162-166
+            param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
+            Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
+                                              sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
+            coo = Anew.tocoo()
+            rows.append(pp[coo.row]); cols.append(ind[coo.col]); vals.append(coo.data)             # :324-334 (patches are disjoint)
+        d = v.d1 * v.d2
+        if rows:
+            A_ = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(d, K))
+        else:
+            A_ = sp.csc_matrix((d, K), dtype=np.float32)
+        A_ = self._gather_sparse(A_)
+        A_.eliminate_zeros()
+        A_.sort_indices()
+        self.A_raw = A_
+        if o.spatial_constraints.get("circular", False):
+            raise NotImplementedError("circular_constraints is off by default and not built")
+        self.A = self.engine.post_process_spatial(A_, v.d1, v.d2) if o.spatial_constraints.get("connected", True) else A_   # :341
+        self._update_b0_new()                                                                        # :347-351
+
+    def _gather_sparse(self, A_):
+        """all-gather of the per-rank rows of A (disjoint pixel sets, no reduction)."""
+        if self.dist is None or self.video.world_size == 1:
+            return A_
+        import torch.distributed as td
+        coo = A_.tocoo()
+        parts = [None] * self.video.world_size
+        td.all_gather_object(parts, (coo.row, coo.col, coo.data), group=self.dist)
+        r = np.concatenate([p[0] for p in parts]); c = np.concatenate([p[1] for p in parts]); d_ = np.concatenate([p[2] for p in parts])
+        return sp.csc_matrix((d_, (r, c)), shape=A_.shape)
+
+    # -- temporal -----------------------------------------------------------------------
+    def update_temporal_parallel(self, use_parallel=True, use_c_hat=True):
+        """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295."""
+        self._need_data()
+        if not use_c_hat:
+            raise NotImplementedError("fast_temporal (use_c_hat=false, :314-337) is not used by the demo and not built")
+        v, o = self.video, self.options
+        if o.deconv_flag:
+            raise NotImplementedError("deconv_flag=true (OASIS inside the sweep, HALS_temporal.m:70-104) is not built yet")
+        K, T = self.C.shape
+        A_csr = self.A.tocsr()
+        Aprev_csr = self.A_prev.tocsr()
+        acc = np.zeros((K, T), dtype=np.float32)                           # sum over patches of aa .* C_raw  (:274)
+        aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
+        for idx in v.owned:
+            pp, bp = v.patch_pix[idx], v.block_pix[idx]
+            Ab = A_csr[bp]
+            ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                              # :83
+            if ind.size == 0:
+                continue                                                                              # :123
+            C_patch = self.C[ind]                                                                    # :86
+            indp = np.nonzero(np.asarray(Aprev_csr[bp].sum(axis=0)).ravel() > 0)[0]                  # :90
+            A_prev_b = Aprev_csr[bp][:, indp].tocsc() if indp.size else None                         # :91
+            C_prev_b = self.C_prev[indp] if indp.size else None
+            self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                     # :149-152
+            A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
+            _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)       # :180-181
+            acc[ind] += C_raw_p * aa_p[:, None]                                                      # :274
+            aa_tot[ind] += aa_p                                                                      # :275
+        if self.dist is not None and v.world_size > 1:                    # the overlap-region stitch: ONE all-reduce
+            packed = self._allreduce(np.concatenate([acc.ravel(), aa_tot.astype(np.float32)]))
+            acc = packed[:K * T].reshape(K, T); aa_tot = packed[K * T:].astype(np.float64)
+        aa_tot[aa_tot == 0] = 1                                                                       # :279
+        C_raw = acc / aa_tot[:, None].astype(np.float32)                                           # :280
+        C_raw = C_raw - C_raw.min(axis=1, keepdims=True)                                             # :285
+        self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
+        self.C = self.C_raw.copy()                                                                    # :286
+        self._update_b0_new()                                                                         # :291-295

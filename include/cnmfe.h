@@ -1,0 +1,151 @@
+/*
+ * cnmfe.h -- C ABI of the MI355X-native CNMF-E factor-update engine.
+ *
+ * This is the drop-in boundary for ONE path of zhoupc/CNMF_E: the alternating
+ * ring-background -> spatial -> temporal update that
+ * demos/demo_large_data_1p.m:199-201 runs through
+ *   @Sources2D/update_background_parallel.m, update_spatial_parallel.m,
+ *   update_temporal_parallel.m
+ * and, per patch, through the plain MATLAB functions listed beside each entry
+ * point below (file:line are into the reference tree).  A MEX gateway
+ * (matlab/cnmfe_mex.cpp) or any FFI (ctypes: cnmf_e_amd/_lib.py) binds exactly
+ * these symbols.  No C++/torch types cross the boundary.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative CNMFE_E* code;
+ *     cnmfe_last_error() returns a thread-local message.  Nothing throws.
+ *   - arrays are MATLAB-shaped: the video block is d_b x T column-major, i.e.
+ *     frame after frame, each frame an nr_b x nc_b image with the ROW index
+ *     fastest.  Pixel linear indices are 0-based inside the ABI.
+ *   - sparse matrices are CSC (MATLAB's native layout: Jc = colptr, Ir = rowidx),
+ *     64-bit column pointers, 32-bit 0-based row indices, rows sorted per column.
+ *   - bulk values are float32 (the engine computes in fp32 with fp64 where it
+ *     matters: means, the ring regression Gram/solve, NNLS); index arrays int32/int64.
+ *   - the caller owns every pointer it passes; the context owns all device memory.
+ *     "out" buffers are caller-allocated; a NULL out pointer means "keep the
+ *     result resident only".
+ *   - a context is single-threaded and bound to one GPU (one context per GPU,
+ *     one process per GPU).
+ */
+#ifndef CNMFE_H
+#define CNMFE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cnmfe_ctx cnmfe_ctx;
+
+enum { CNMFE_OK = 0, CNMFE_EINVAL = -1, CNMFE_ENOMEM = -2, CNMFE_EHIP = -3,
+       CNMFE_ESTATE = -4, CNMFE_EUNSUPPORTED = -5 };
+
+/* element type of the video handed to cnmfe_upload_block */
+enum { CNMFE_F32 = 0, CNMFE_F64 = 1, CNMFE_U16 = 2, CNMFE_U8 = 3, CNMFE_F16 = 4 };
+/* where a bulk pointer lives */
+enum { CNMFE_HOST = 0, CNMFE_DEVICE = 1 };
+/* memory order of a K x T trace matrix */
+enum { CNMFE_COLMAJOR = 0 /* MATLAB: element (k,t) at k + t*K */,
+       CNMFE_ROWMAJOR = 1 /* numpy:  element (k,t) at k*T + t */ };
+/* spatial algorithm (options.spatial_algorithm, CNMFSetParms.m:117) */
+enum { CNMFE_SPATIAL_HALS = 0, CNMFE_SPATIAL_HALS_THRESH = 1, CNMFE_SPATIAL_NNLS = 2 };
+
+const char *cnmfe_last_error(void);
+const char *cnmfe_version(void);
+
+/* ---- context ------------------------------------------------------------ */
+cnmfe_ctx *cnmfe_create(int device);          /* NULL on failure (see cnmfe_last_error) */
+void       cnmfe_destroy(cnmfe_ctx *ctx);
+
+/* ---- data plane: one resident block per patch ----------------------------
+ * Replaces get_patch_data(mat_data, tmp_patch, frame_range, true)
+ * (endoscope/get_patch_data.m:50-93) at update_background_parallel.m:208,
+ * update_spatial_parallel.m:147, update_temporal_parallel.m:137: the block is
+ * uploaded once and stays in HBM.
+ * patch_rect/block_rect = [r0 r1 c0 c1], 1-based inclusive, exactly
+ * mat_data.patch_pos{m} / block_pos{m} (distribute_data.m:165-171). */
+int cnmfe_patch_create(cnmfe_ctx *ctx, int patch_id, const int32_t patch_rect[4],
+                       const int32_t block_rect[4], int32_t d1, int32_t d2, int64_t T);
+/* frames [t0, t0+nt) of the block, nt x d_b elements of `dtype`, frame-major */
+int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, int memspace,
+                       int64_t t0, int64_t nt);
+/* P.Ymean{m} (initComponents_parallel.m:338-339): temporal mean of the BLOCK, d_b doubles */
+int cnmfe_get_ymean(cnmfe_ctx *ctx, int patch_id, double *ymean_block);
+
+/* ---- B0: ring pattern -----------------------------------------------------
+ * get_nhood(radius, num_neighbors) (endoscope/get_nhood.m:1-25) + the W builder
+ * at initComponents_parallel.m:213-236: fixed ring sparsity pattern, W = 1/count,
+ * b0 = 0.  num_neighbors <= 0 means [] (all ring pixels). */
+int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_neighbors);
+int cnmfe_ring_nnz(cnmfe_ctx *ctx, int patch_id, int64_t *nnz, int32_t *p);
+/* W{m} as CSR (d x d_b): rowptr[d+1], col[nnz] (block pixel, ascending), val[nnz] */
+int cnmfe_ring_get_csr(cnmfe_ctx *ctx, int patch_id, int64_t *rowptr, int32_t *col, float *val);
+int cnmfe_ring_set_values(cnmfe_ctx *ctx, int patch_id, const float *val /* nnz, CSR order */);
+/* the reference's first-run test, by VALUE inspection of row 1 of W{m}:
+ * length(unique(W_old(1,:)))==2   (fit_ring_model.m:25, update_background_parallel.m:143) */
+int cnmfe_ring_first_run(cnmfe_ctx *ctx, int patch_id, int *first_run);
+int cnmfe_b0_get(cnmfe_ctx *ctx, int patch_id, float *b0 /* d */);
+int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0 /* d */);
+
+/* ---- B1/B2: [W, b0] = fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection)
+ * endoscope/fit_ring_model.m:1-127.  Y = the resident block, W_old = the resident W{m}
+ * (first-run detection by value inspection of row 1, :25; ind_active, :28; frame stride k,
+ * :60,84-87).  A is d_b x K CSC (block rows), C is K x T.  thresh_outlier must be NaN
+ * (the outlier branch :50-56 is dead in every demo; anything else -> CNMFE_EUNSUPPORTED).
+ * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels, info[3]=pmax. */
+int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
+                         const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+                         double thresh_outlier, int with_projection,
+                         float *b0_out /* d or NULL */, int64_t info[4]);
+
+/* ---- R1: the residual / background-subtraction expression
+ *   Ysig = Y(ind_patch,:) - W*(Y - A_prev*C_prev) - (b0 - W*mean(Y - A_prev*C_prev, 2))
+ * update_spatial_parallel.m:162-166 == update_temporal_parallel.m:149-152.
+ * A_prev is d_b x Ksel CSC (block rows), C_prev Ksel x T.  The result (d x T fp32,
+ * frame-major) stays resident for the HALS/NNLS calls below; Ysig_out may be NULL. */
+int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_colptr,
+                   const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+                   float *Ysig_out, int out_memspace);
+
+/* ---- S1-S4: A = HALS_spatial(Y,A,C,active_pixel,maxIter)            utilities/HALS_spatial.m:1-45
+ *             A = HALS_spatial_thresh(Y,A,C,active_pixel,maxIter,sn)  utilities/HALS_spatial_thresh.m:1-53
+ *             A = nnls_spatial(Y,A,C,active_pixel,maxN)               endoscope/nnls_spatial.m:1-109
+ * Y = the resident Ysig of this patch (cnmfe_residual must have been called).
+ * A is d x K CSC over PATCH rows, IND (active_pixel) d x K CSC pattern, sn d floats
+ * (HALS_THRESH only).  param = maxIter (HALS*) or maxN (NNLS).  The result has exactly
+ * the IND pattern: A_out[nnz(IND)] in IND's CSC order (entries may be 0). */
+int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
+                         const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                         const float *C, int c_order,
+                         const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                         const float *sn, int32_t param, float *A_out);
+
+/* ---- T1-T3: [C, C_raw, ~, ~] = HALS_temporal(Y, A, C, maxIter, [])   utilities/HALS_temporal.m:1-119
+ * (no-deconvolution branch :64-68).  Y = resident Ysig.  A d x K CSC over PATCH rows.
+ * Outputs in c_order; aa_out[k] = sum(A(:,k).^2) (update_temporal_parallel.m:181). */
+int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
+                        const int32_t *A_rowidx, const float *A_val, const float *C_in, int c_order,
+                        int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out);
+
+/* ---- S6: post_process_spatial (connected = true, circular = false)
+ * @Sources2D/post_process_spatial.m:19-32 -> endoscope/connectivity_constraint.m:1-18.
+ * A is the whole-FOV d1*d2 x K CSC; keep[nnz] receives 1 for entries that survive. */
+int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K,
+                               const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                               uint8_t *keep);
+
+/* ---- measurement: per-kernel HIP-event timing on the engine's stream --------- */
+int cnmfe_profile_enable(cnmfe_ctx *ctx, int on);
+int cnmfe_profile_reset(cnmfe_ctx *ctx);
+/* number of distinct kernel names seen; name/total_ms/calls of the i-th */
+int cnmfe_profile_count(cnmfe_ctx *ctx);
+int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *calls);
+int cnmfe_synchronize(cnmfe_ctx *ctx);
+/* tunables for A/B runs (name = "r1_variant", "gram_mode", ...); unknown names -> CNMFE_EINVAL */
+int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNMFE_H */

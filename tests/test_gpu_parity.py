@@ -1,0 +1,263 @@
+"""GPU parity: the HIP engine (through the C ABI) against the float64 CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 engine vs float64 oracle):
+  Ysig, U-derived quantities, C : rel Frobenius <= 1e-4
+  W values                     : rel Frobenius <= 1e-3  (ridge-regularised (p+1)x(p+1) solves, fp32 video)
+  A after thresholding         : identical support except where |a - thr| is within 1e-4 relative of the threshold
+"""
+import numpy as np
+import scipy.sparse as sp
+import pytest
+
+import cnmfe_oracle as orc
+from cnmf_e_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cnmf_e_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+class Case:
+    """one FOV, one or more patches; engine blocks uploaded; oracle pieces alongside"""
+
+    def __init__(self, eng, d1, d2, T, K, r, seed, patch_dims=None, dtype=np.float32, gSig=1.5, gSiz=7, min_sep=4):
+        from cnmf_e_amd.sources2d import PatchedVideo
+        self.f = synth.make_factors(d1, d2, T, K, seed, gSig=gSig, gSiz=gSiz, min_sep=min_sep)
+        self.Y = synth.make_video(self.f, np.float32)                    # (T, d)
+        self.Yup = self.Y.astype(dtype)
+        self.d1, self.d2, self.T, self.K, self.r = d1, d2, T, K, r
+        self.video = PatchedVideo(d1, d2, T, patch_dims or [d1, d2], r, eng)
+        self.video.upload_from_full(self.Yup)
+        self.eng = eng
+        for idx in self.video.owned:
+            eng.ring_init(self.video.pid[idx], r)
+        self.rs, self.cs = orc.get_nhood(r)
+
+    def block(self, idx):
+        return self.Yup[:, self.video.block_pix[idx]].T.astype(np.float64)   # d_b x T
+
+    def W0(self, idx):
+        return orc.build_ring_W(self.video.patch_pos[idx], self.video.block_pos[idx], self.d1, self.d2, self.rs, self.cs)
+
+    def ipmask(self, idx):
+        m = np.zeros(self.video.block_pix[idx].size, dtype=bool)
+        m[self.video.ind_patch[idx]] = True
+        return m
+
+
+def test_geometry_matches_oracle():
+    from cnmf_e_amd.sources2d import distribute_geometry
+    for (d1, d2, pdims, w) in [(512, 512, [128, 128], 15), (64, 48, [64, 48], 5), (100, 90, [33, 31], 6), (256, 256, [64, 128], 15)]:
+        (nr, nc), pp, bp = distribute_geometry(d1, d2, pdims, w)
+        opp, obp = orc.distribute_geometry(d1, d2, pdims, w)
+        assert (nr, nc) == opp.shape
+        for m in range(nr):
+            for n in range(nc):
+                assert list(pp[(m, n)]) == list(opp[m, n]) and list(bp[(m, n)]) == list(obp[m, n])
+
+
+@pytest.mark.parametrize("r,dims,pdims", [(5, (40, 36), None), (5, (40, 36), [20, 18]), (15, (64, 56), None), (18, (50, 44), None)])
+def test_ring_init_and_ymean(eng, r, dims, pdims):
+    c = Case(eng, dims[0], dims[1], 64, 3, r, 5, pdims)
+    for idx in c.video.owned:
+        W = eng.ring_csr(c.video.pid[idx])
+        W0 = c.W0(idx).tocsr(); W0.sort_indices()
+        assert W.shape == W0.shape and W.nnz == W0.nnz
+        assert np.array_equal(W.indptr, W0.indptr) and np.array_equal(W.indices, W0.indices)
+        assert np.allclose(W.data, W0.data, rtol=1e-6)
+        assert eng.ring_first_run(c.video.pid[idx])
+        ym = eng.ymean(c.video.pid[idx])
+        assert np.allclose(ym, c.block(idx).mean(axis=1), rtol=1e-7, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.float64, np.float16, np.uint8])
+def test_upload_dtypes(eng, dtype):
+    from cnmf_e_amd.sources2d import PatchedVideo
+    rng = np.random.default_rng(0)
+    d1, d2, T = 20, 16, 40
+    hi = 200 if dtype == np.uint8 else 1500
+    Y = rng.integers(0, hi, size=(T, d1 * d2)).astype(dtype)
+    v = PatchedVideo(d1, d2, T, [d1, d2], 3, eng)
+    v.upload_from_full(Y, chunk=16)
+    ym = eng.ymean(0)
+    assert np.allclose(ym, Y.astype(np.float64).mean(axis=0), rtol=1e-7, atol=1e-5)
+
+
+@pytest.mark.parametrize("r,dims,pdims,T", [(5, (40, 36), None, 203), (5, (40, 36), [20, 18], 64), (15, (64, 56), None, 66), (15, (70, 60), [35, 30], 32), (18, (50, 44), None, 30)])
+@pytest.mark.parametrize("with_ac", [False, True])
+def test_residual_parity(eng, r, dims, pdims, T, with_ac):
+    c = Case(eng, dims[0], dims[1], T, 5, r, 7, pdims)
+    rng = np.random.default_rng(1)
+    for idx in c.video.owned:
+        pid = c.video.pid[idx]
+        W0 = c.W0(idx).tocsr(); W0.sort_indices()
+        Wv = W0.copy(); Wv.data = (W0.data * (1 + 0.5 * rng.standard_normal(W0.nnz))).astype(np.float32).astype(np.float64)
+        eng.ring_set_values(pid, Wv.data)
+        b0 = (1000 + rng.standard_normal(Wv.shape[0]) * 10).astype(np.float32)
+        eng.set_b0(pid, b0)
+        bp = c.video.block_pix[idx]
+        if with_ac:
+            A_b = c.f.A_init.tocsr()[bp].tocsc().astype(np.float32)
+            C_b = c.f.C_init
+        else:
+            A_b, C_b = None, None
+        got = eng.residual(pid, A_b, C_b, want=True)                       # (T, d)
+        ref = orc.residual_ysig(c.block(idx), A_b.astype(np.float64) if with_ac else None, C_b, Wv, b0.astype(np.float64), c.ipmask(idx))
+        assert got.shape == ref.T.shape
+        assert rel(got.T, ref) <= 1e-4, rel(got.T, ref)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_residual_variants_agree(eng, variant):
+    c = Case(eng, 80, 72, 24, 4, 15, 3)
+    rng = np.random.default_rng(2)
+    W0 = c.W0((0, 0)).tocsr(); W0.sort_indices()
+    eng.ring_set_values(0, (W0.data * (1 + 0.5 * rng.standard_normal(W0.nnz))).astype(np.float32))
+    eng.set_b0(0, np.full(W0.shape[0], 990.0, dtype=np.float32))
+    A_b = c.f.A_init.tocsc().astype(np.float32)
+    eng.set_option("r1_variant", -1)          # generic kernel
+    base = eng.residual(0, A_b, c.f.C_init, want=True)
+    eng.set_option("r1_variant", variant)
+    got = eng.residual(0, A_b, c.f.C_init, want=True)
+    eng.set_option("r1_variant", 0)
+    assert rel(got, base) <= 2e-6, rel(got, base)
+
+
+@pytest.mark.parametrize("r,dims,pdims,T", [(5, (40, 36), None, 300), (5, (44, 40), [22, 20], 200), (15, (48, 40), None, 120)])
+def test_fit_ring_model_parity(eng, r, dims, pdims, T):
+    c = Case(eng, dims[0], dims[1], T, 5, r, 11, pdims)
+    A = c.f.A_init.astype(np.float32)
+    for idx in c.video.owned:
+        pid = c.video.pid[idx]
+        bp = c.video.block_pix[idx]
+        A_b = A.tocsr()[bp].tocsc()
+        keep = np.asarray(A_b.sum(axis=0)).ravel() > 0
+        A_b = A_b[:, keep]; C_b = c.f.C_init[keep]
+        W_old = c.W0(idx)
+        for run in range(2):
+            b0, info = eng.fit_ring_model(pid, A_b if A_b.shape[1] else None, C_b)
+            Wref, b0ref = orc.fit_ring_model(c.block(idx), A_b.astype(np.float64), C_b, W_old, np.nan, None, c.ipmask(idx), True)
+            assert info["first_run"] == (run == 0)
+            assert info["frame_stride"] == orc.ring_frame_stride(W_old, T, True)
+            W = eng.ring_csr(pid)
+            Wref = Wref.tocsr(); Wref.sort_indices()
+            assert np.array_equal(W.indices, Wref.indices)
+            assert rel(W.data, Wref.data) <= 1e-3, (run, rel(W.data, Wref.data))
+            assert np.allclose(b0, b0ref, rtol=1e-6, atol=1e-3)
+            # what matters downstream: the reconstructed fluctuating background W*Bf
+            W_old = Wref
+
+
+def _spatial_inputs(c, idx):
+    from cnmf_e_amd.sources2d import determine_search_location
+    IND = determine_search_location(c.f.A_init, c.d1, c.d2)
+    INDo = orc.determine_search_location(c.f.A_init, c.d1, c.d2)
+    assert (IND.toarray() != INDo).sum() == 0
+    pp = c.video.patch_pix[idx]
+    INDp = IND.tocsr()[pp]
+    ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]
+    return INDp[:, ind].tocsc(), c.f.A_init.tocsr()[pp][:, ind].tocsc().astype(np.float32), c.f.C_init[ind], ind
+
+
+@pytest.mark.parametrize("alg", ["hals", "hals_thresh", "nnls"])
+@pytest.mark.parametrize("dims,pdims", [((40, 36), None), ((44, 40), [22, 20])])
+def test_update_spatial_parity(eng, alg, dims, pdims):
+    c = Case(eng, dims[0], dims[1], 400, 6, 5, 13, pdims, min_sep=3)
+    for idx in c.video.owned:
+        pid = c.video.pid[idx]
+        eng.fit_ring_model(pid, None, None)
+        ysig = eng.residual(pid, None, None, want=True).T.astype(np.float64)          # d x T
+        INDp, A_p, C_p, ind = _spatial_inputs(c, idx)
+        if ind.size == 0:
+            continue
+        sn = c.f.sn[c.video.patch_pix[idx]]
+        param = 20 if alg == "nnls" else 3
+        got = eng.update_spatial(pid, alg, A_p, C_p, INDp, sn, param).toarray()
+        if alg == "hals":
+            ref = orc.HALS_spatial(ysig, A_p, C_p, INDp, 3)
+        elif alg == "hals_thresh":
+            ref = orc.HALS_spatial_thresh(ysig, A_p, C_p, INDp, 3, sn)
+        else:
+            ref = orc.nnls_spatial(ysig, A_p, C_p, INDp, 20)
+        mism = (got != 0) != (ref != 0)
+        # support may differ only for entries sitting on the threshold / on the nonnegativity boundary
+        assert mism.sum() <= max(2, 0.01 * (ref != 0).sum()), mism.sum()
+        ok = ~mism
+        assert rel(got[ok], ref[ok]) <= 2e-4, rel(got[ok], ref[ok])
+
+
+@pytest.mark.parametrize("dims,pdims", [((40, 36), None), ((44, 40), [22, 20])])
+def test_hals_temporal_parity(eng, dims, pdims):
+    c = Case(eng, dims[0], dims[1], 403, 6, 5, 17, pdims, min_sep=3)
+    for idx in c.video.owned:
+        pid = c.video.pid[idx]
+        eng.fit_ring_model(pid, None, None)
+        ysig = eng.residual(pid, None, None, want=True).T.astype(np.float64)
+        pp = c.video.patch_pix[idx]
+        A_p = c.f.A_init.tocsr()[pp].tocsc().astype(np.float32)
+        keep = np.ones(A_p.shape[1], dtype=bool)
+        keep[0] = True                       # keep every column, including ones that are empty on this patch (aa = 0 -> skipped)
+        C_p = c.f.C_init
+        Cg, Crawg, aa = eng.hals_temporal(pid, A_p, C_p, 5)
+        Cr, Crawr, _ = orc.HALS_temporal(ysig, A_p.astype(np.float64), C_p, 5, None)
+        assert np.allclose(aa, np.asarray(A_p.multiply(A_p).sum(axis=0)).ravel(), rtol=1e-5)
+        assert rel(Cg, Cr) <= 1e-4, rel(Cg, Cr)
+        assert rel(Crawg, Crawr) <= 1e-4
+
+
+def test_post_process_spatial_parity(eng):
+    rng = np.random.default_rng(3)
+    d1, d2, K = 48, 40, 6
+    f = synth.make_factors(d1, d2, 10, K, 21, gSig=2.0, gSiz=9, min_sep=6)
+    A = f.A_true.toarray()
+    # add isolated specks and a second blob so that the connectivity constraint has something to remove
+    for k in range(K):
+        pix = rng.integers(0, d1 * d2, 6)
+        A[pix, k] += rng.uniform(0.05, 0.4, 6)
+    A[:, 0] += 0.6 * f.A_true[:, 1].toarray().ravel()
+    As = sp.csc_matrix(A.astype(np.float32))
+    got = eng.post_process_spatial(As, d1, d2).toarray()
+    ref = orc.post_process_spatial(As.toarray().astype(np.float64).reshape(d1, d2, K, order="F"))
+    assert np.array_equal(got != 0, ref != 0)
+    assert np.allclose(got, ref, rtol=1e-6)
+
+
+@pytest.mark.parametrize("alg", ["hals", "nnls"])
+def test_method_level_iteration_parity(eng, alg):
+    """Sources2D.update_background/spatial/temporal_parallel on a 2x2-patch FOV vs the oracle's method-level restatement."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 44, 40, 300, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video.upload_from_full(Y)
+    opt = Options(ring_radius=r, spatial_algorithm=alg, maxIter=3)
+    s = Sources2D(video, opt, f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn,
+                            spatial_algorithm=alg, maxIter=3)
+    for it in range(2):
+        s.update_background_parallel(); o.update_background_parallel()
+        for idx in video.owned:
+            Wg = s.get_W(idx); Wr = sp.csr_matrix(o.W[idx]); Wr.sort_indices()
+            assert rel(Wg.data, Wr.data) <= 2e-3, (it, rel(Wg.data, Wr.data))
+        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-5, atol=1e-2)
+        s.update_spatial_parallel(); o.update_spatial_parallel()
+        Ag, Ar = s.A.toarray(), o.A.toarray()
+        mism = ((Ag != 0) != (Ar != 0)).sum()
+        assert mism <= max(3, 0.02 * (Ar != 0).sum()), (it, mism)
+        same = (Ag != 0) == (Ar != 0)
+        assert rel(Ag[same], Ar[same]) <= 2e-3, (it, rel(Ag[same], Ar[same]))
+        s.update_temporal_parallel(); o.update_temporal_parallel()
+        assert rel(s.C, o.C) <= 2e-3, (it, rel(s.C, o.C))
+        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-4, atol=5e-2)

@@ -1,0 +1,101 @@
+"""CPU-side checks (run with -m "not gpu"): the C-ABI library loads and exports every symbol the header
+declares, fails loudly without a GPU, and the Python host logic agrees with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import scipy.sparse as sp
+import pytest
+
+import cnmfe_oracle as orc
+from cnmf_e_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_lib():
+    return os.path.exists(os.path.join(ROOT, "cnmf_e_amd", "libcnmfe_hip.so"))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not _have_lib():
+        import cnmf_e_amd.build as b
+        b.build(verbose=False)
+    return True
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "cnmfe.h")).read()
+    names = set(re.findall(r"\b(cnmfe_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    lib = ctypes.CDLL(os.path.join(ROOT, "cnmf_e_amd", "libcnmfe_hip.so"))
+    for n in sorted(names):
+        assert hasattr(lib, n), "library does not export %s" % n
+    from cnmf_e_amd import _lib
+    assert set(_lib.PROTOTYPES) == names, set(_lib.PROTOTYPES) ^ names
+
+
+def test_no_silent_cpu_fallback(built):
+    """Without a GPU the engine must refuse to start (no CPU fallback anywhere in the product)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cnmf_e_amd.engine import Engine
+    from cnmf_e_amd._lib import CnmfeError
+    with pytest.raises(CnmfeError):
+        Engine(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cnmf_e_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "cnmfe_oracle" not in src and "import oracle" not in src, fn
+
+
+def test_geometry_matches_oracle():
+    from cnmf_e_amd.sources2d import distribute_geometry
+    for (d1, d2, pdims, w) in [(512, 512, [128, 128], 15), (64, 48, [64, 48], 5), (100, 90, [33, 31], 6),
+                               (256, 256, [64, 128], 15), (1024, 1024, [128, 128], 15), (75, 130, [30], 4)]:
+        (nr, nc), pp, bp = distribute_geometry(d1, d2, pdims, w)
+        opp, obp = orc.distribute_geometry(d1, d2, pdims, w)
+        assert (nr, nc) == opp.shape
+        for m in range(nr):
+            for n in range(nc):
+                assert list(pp[(m, n)]) == list(opp[m, n]) and list(bp[(m, n)]) == list(obp[m, n])
+
+
+def test_search_location_matches_oracle():
+    from cnmf_e_amd.sources2d import determine_search_location
+    f = synth.make_factors(60, 50, 20, 12, 3, gSig=2.0, gSiz=9, min_sep=4)
+    A = f.A_init.tolil()
+    A[:, 3] = 0                       # an empty component -> all-false column (determine_search_location.m:52-55,102-104)
+    A = A.tocsc()
+    IND = determine_search_location(A, 60, 50)
+    ref = orc.determine_search_location(A, 60, 50)
+    assert IND.shape == ref.shape
+    assert np.array_equal(IND.toarray(), ref)
+    assert IND[:, 3].nnz == 0
+    # elongated component + different expansion parameters
+    B = f.A_true.tolil()
+    B[10 * 60 + 5:10 * 60 + 25, 0] = 1.0
+    IND2 = determine_search_location(B.tocsc(), 60, 50, 2, 6, 2.5)
+    ref2 = orc.determine_search_location(B.tocsc(), 60, 50, 2, 6, 2.5)
+    assert np.array_equal(IND2.toarray(), ref2)
+
+
+def test_ring_offsets_c_abi_order():
+    """the engine's ring order (dc slow, dr fast) is MATLAB's find() order used by the oracle"""
+    for r in (4, 5, 9, 15, 18):
+        rs, cs = orc.get_nhood(r)
+        k = 0
+        for c in range(-r, r + 1):
+            for rr in range(-r, r + 1):
+                d2 = c * c + rr * rr
+                if r * r <= d2 < (r + 1) * (r + 1):
+                    assert rs[k] == rr and cs[k] == c
+                    k += 1
+        assert k == rs.size
