@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- CNMF-E iterations/s (background + spatial + temporal) on MI355X.
+
+One "step" = Sources2D.update_background_parallel + update_spatial_parallel + update_temporal_parallel
+(demos/demo_large_data_1p.m:199-201) on synthetic data already resident in HBM.
+N=1: BASELINE.json configs[2] (headline): 512x512x10000 fp32, K=500, ring_radius=15, 1 patch.
+N>1: weak scaling -- the FOV grows to 512 x (512*N) (1 x N patches of 512x512, 500 neurons each); every
+rank owns one patch (with its ring halo) and the temporal update does one RCCL all-reduce of the
+[K x T] stitch (update_temporal_parallel.m:269-280).  value = patch-iterations per second over all ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: d1, d2(per GPU), T, K(per GPU), ring radius, seed
+    "c3": (512, 512, 10000, 500, 15, 2),     # BASELINE.json configs[2] (headline)
+    "c2": (256, 256, 3000, 200, 15, 1),      # BASELINE.json configs[1]
+    "tiny": (96, 96, 600, 18, 15, 5),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+F64_MFMA_PEAK_TF = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (157.3 TF), spec
+F32_MFMA_PEAK_TF = 157.3
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The float64 NumPy restatement of the reference (oracle/, 'port') timed on a bounded sample of the
+    same workload and scaled by the d*T work ratio to the headline size."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cnmfe_oracle as orc
+    from cnmf_e_amd import synth
+    d1, d2, T, r = 96, 96, 1500, 15
+    K = max(2, int(round(500 * d1 * d2 / (512.0 * 512.0))))
+    f = synth.make_factors(d1, d2, T, K, 9)
+    Y = synth.make_video(f, np.float32)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [d1, d2], r, f.A_init.astype(np.float32), f.C_init, f.sn,
+                            spatial_algorithm="hals", maxIter=5)
+    t0 = time.time()
+    o.update_background_parallel(); o.update_spatial_parallel(); o.update_temporal_parallel()
+    dt = time.time() - t0
+    scale = (512.0 * 512.0 * 10000.0) / (d1 * d2 * T)
+    try:
+        import threadpoolctl
+        thr = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    return {"value": 1.0 / (dt * scale), "unit": "iter/s (512x512x10000-equivalent)", "cores": int(thr), "kind": "port",
+            "sample": "one full iteration of the float64 NumPy restatement (oracle/cnmfe_oracle.py, not MATLAB) on %dx%dx%d, K=%d, r=%d "
+                      "took %.2f s; scaled by the d*T work ratio %.1f to 512x512x10000" % (d1, d2, T, K, r, dt, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--alg", default="hals", help="spatial algorithm: hals | hals_thresh | nnls")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        import torch.distributed as td
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        group = td.group.WORLD
+
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.engine import Engine
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+
+    d1, d2p, T, Kp, r, seed = CONFIGS[a.config]
+    d2, K = d2p * world, Kp * world
+    f = synth.make_factors(d1, d2, T, K, seed)
+    eng = Engine(local)
+    video = PatchedVideo(d1, d2, T, [d1, d2p], r, eng, rank=rank, world_size=world)
+    for idx in video.owned:                                   # synthesise each owned block directly in HBM
+        Yb = synth.make_video_device(f, "cuda:%d" % local, pixels=video.block_pix[idx])
+        torch.cuda.synchronize()
+        video.upload_block_device(idx, Yb.data_ptr())
+        del Yb
+    torch.cuda.empty_cache()
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=5, deconv_flag=False),
+                  f.A_init, f.C_init, f.sn, dist_group=group)
+    eng.profile(True)
+
+    def step():
+        s.update_background_parallel()
+        s.update_spatial_parallel()
+        s.update_temporal_parallel()
+
+    def fence():
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as td
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return
+    n_patches = video.nr_patch * video.nc_patch
+    value = n_patches * a.steps / dt
+    tab = eng.profile_table()
+    kern = {k: {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / a.steps,
+                "ms_per_step": v["total_ms"] / a.steps} for k, v in tab.items() if v["calls"]}
+    dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+    # ---- roofline of the dominant kernel; algorithmic work per launch from SURVEY.md section 8(d) ----
+    P = {idx: video.patch_pix[idx].size for idx in video.owned}
+    B = {idx: video.block_pix[idx].size for idx in video.owned}
+    idx0 = video.owned[0]
+    d, d_b, p = P[idx0], B[idx0], 96 if r == 15 else None
+    roof = None
+    def r1_roof():
+        if "residual_r1" not in kern:
+            return None
+        bytes_r1 = 4.0 * d_b * T + 4.0 * d * T + 8.0 * d * p + 4.0 * Kp * T       # read Y + write Ysig + W + C
+        ms = kern["residual_r1"]["ms_per_call"]
+        return {"bound": "hbm", "achieved": bytes_r1 / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_r1 / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "residual_r1", "ms_per_launch": ms,
+                "algorithmic_bytes_per_launch": bytes_r1}
+    def gram_roof(name, peak):
+        ms = kern[name]["ms_per_call"]
+        flops_alg = 2.0 * d * (p + 1) ** 2 * T / 2.0        # SURVEY 8(d) B2, symmetric count, first run (T' = T)
+        return {"bound": "mfma", "achieved": flops_alg / ms / 1e9, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops_alg / ms / 1e9 / peak, "traffic": None, "kernel": name, "ms_per_launch": ms,
+                "algorithmic_flops_per_launch": flops_alg,
+                "note": "algorithmic = 2*d*(p+1)^2*T/2 of the reference's per-pixel Gram (SURVEY 8(d)); the engine's "
+                        "block-sparse SYRK executes fewer flops (see DESIGN.md), so frac may exceed the pipe utilisation"}
+    if dom.startswith("bg_gram"):
+        roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else F32_MFMA_PEAK_TF)
+    elif dom == "residual_r1":
+        roof = r1_roof()
+    else:
+        roof = {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": dom,
+                "ms_per_launch": kern[dom]["ms_per_call"]}
+    out = {
+        "metric": "cnmfe_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
+                               "spatial=%s, deconv_flag=false" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg),
+                   "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
+                   "parallelism": "patch-parallel x%d" % world},
+        "roofline": roof,
+        "roofline_r1": r1_roof(),
+        "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,27 +138,41 @@ def make_video(f: SynthFactors, dtype=np.float32) -> np.ndarray:
     return np.ascontiguousarray(Y.astype(dtype))
 
 
-def make_video_device(f: SynthFactors, device="cuda:0", chunk=500):
-    """Synthesise the (T, d) float32 video directly in HBM with torch (noise from a torch
-    generator seeded with ``f.seed``); returns the torch tensor."""
+def make_video_device(f: SynthFactors, device="cuda:0", chunk=500, pixels=None):
+    """Synthesise the (T, npix) float32 video directly in HBM with torch; returns the torch tensor.
+
+    ``pixels``: global column-major pixel indices of a rectangle (e.g. one block), default the whole FOV.
+    The noise of FOV column c comes from a generator seeded with (seed, c), so two ranks that synthesise
+    overlapping blocks (ring halos) see identical data in the overlap.
+    """
     import torch
     dev = torch.device(device)
+    pix = np.arange(f.d, dtype=np.int64) if pixels is None else np.asarray(pixels, dtype=np.int64)
+    npix = pix.size
+    col_of = pix // f.d1
+    cols = np.unique(col_of)
+    nrb = npix // cols.size
+    rows = pix[:nrb] % f.d1
+    assert np.array_equal(pix, (cols[None, :] * f.d1 + rows[:, None]).reshape(-1, order="F")), "pixels must form a rectangle"
+    r0, r1 = int(rows[0]), int(rows[-1]) + 1
     g = torch.Generator(device=dev)
-    g.manual_seed(int(f.seed) + 7919)
-    Y = torch.empty((f.T, f.d), dtype=torch.float32, device=dev)
-    A = f.A_true.tocoo()
-    At = torch.sparse_coo_tensor(np.vstack([A.col, A.row]), A.data.astype(np.float32),
-                                 (f.K, f.d), device=dev).coalesce() if f.K > 0 else None
-    field = torch.from_numpy(f.bg_field).to(dev)
+    Y = torch.empty((f.T, npix), dtype=torch.float32, device=dev)
+    for j, c in enumerate(cols):
+        g.manual_seed(int(f.seed) * 1000003 + 7919 + int(c))
+        Y[:, j * nrb:(j + 1) * nrb] = torch.randn((f.T, f.d1), generator=g, device=dev, dtype=torch.float32)[:, r0:r1]
+    A = f.A_true.tocsr()[pix].tocoo()
+    At = torch.sparse_coo_tensor(np.vstack([A.row, A.col]), A.data.astype(np.float32),
+                                 (npix, f.K), device=dev).coalesce() if f.K > 0 and A.nnz else None
+    field = torch.from_numpy(f.bg_field[pix]).to(dev)
     bt = torch.from_numpy(f.bg_time).to(dev)
     Ct = torch.from_numpy(f.C_true).to(dev)
-    sn = torch.from_numpy(f.sn).to(dev)
+    sn = torch.from_numpy(f.sn[pix]).to(dev)
     for t0 in range(0, f.T, chunk):
         t1 = min(f.T, t0 + chunk)
-        blk = torch.randn((t1 - t0, f.d), generator=g, device=dev, dtype=torch.float32) * sn[None, :]
+        blk = Y[t0:t1]
+        blk *= sn[None, :]
         blk += bt[t0:t1, None] * field[None, :]
         blk += f.bg_const
         if At is not None:
-            blk += torch.sparse.mm(At.t(), Ct[:, t0:t1]).t()
-        Y[t0:t1] = blk
+            blk += torch.sparse.mm(At, Ct[:, t0:t1]).t()
     return Y
