@@ -253,6 +253,145 @@ __global__ void __launch_bounds__(64) k_ring_solve(CovTab tab, BgGeom g, const i
     for (int i = lane; i < p; i += 64) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)rhs[i] : 0.f;   // intercept rhs[p] is discarded (:107)
 }
 
+// ---- B2b v2: panel-blocked Cholesky, 256 threads per pixel ------------------------------------------
+// The system is augmented with the right-hand side as row n of the packed lower triangle, so the
+// factorisation leaves z = L^-1 g in that row (forward substitution for free).  Per panel of PW
+// columns: wave 0 factors the (n-j0+1) x PW panel entirely in registers (lane = row, column broadcasts
+// by v_readlane), then all 4 waves apply the rank-PW update to the trailing triangle, 8 fp64 FMAs per
+// element visit.  Back substitution is a 97-step readlane chain in wave 0.
+constexpr int PW = 8;
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+
+__global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
+                                                     const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
+                                                     float *__restrict__ W) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int p = g.p, n = p + 1, na = n + 1;
+    double *L = sm;                                   // rows 0..n packed; row n = [g ; unused]
+    double *red = sm + tri(na);                       // 4 partial traces
+    int *nb = reinterpret_cast<int *>(red + 4);       // p neighbour codes
+    const int64_t m = blockIdx.x;
+    if (active && !active[m]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
+    for (int i = tid; i < p; i += 256) {
+        const int rb = rbm + dr[i], cb = cbm + dc[i];
+        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
+        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
+    }
+    __syncthreads();
+    auto rsum = [&](int rb, int cb) { return rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + (rb & 15) + ((cb & 15) << 4)]; };
+    // ---- assemble (flat index over the packed triangle: independent lookups, 19 per thread) ----
+    const int ne = tri(na);
+    for (int e = tid; e < ne; e += 256) {
+        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (tri(i + 1) <= e) ++i;
+        while (tri(i) > e) --i;
+        const int j = e - tri(i);
+        double v;
+        if (i < p) {
+            const int ni = nb[i], nj = nb[j];
+            if (ni < 0 || nj < 0) v = (i == j) ? 1.0 : 0.0;
+            else v = cov_lookup(tab, ni & 0xffff, ni >> 16, nj & 0xffff, nj >> 16);
+        } else if (i == p) {                           // the row of ones (fit_ring_model.m:101)
+            if (j < p) { const int nj = nb[j]; v = nj < 0 ? 0.0 : rsum(nj & 0xffff, nj >> 16); }
+            else v = (double)g.Tp;
+        } else {                                       // right-hand side X*y' (:104)
+            if (j < p) { const int nj = nb[j]; v = nj < 0 ? 0.0 : cov_lookup(tab, nj & 0xffff, nj >> 16, rbm, cbm); }
+            else if (j == p) v = rsum(rbm, cbm);
+            else v = 0.0;
+        }
+        L[e] = v;
+    }
+    __syncthreads();
+    // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
+    double tr = 0;
+    if (tid < n && (tid == p || nb[tid] >= 0)) tr = L[tri(tid) + tid];
+    for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+    if (lane == 0) red[wave] = tr;
+    __syncthreads();
+    const double lam = ((red[0] + red[1]) + (red[2] + red[3])) * 1e-5;
+    if (tid < n && (tid == p || nb[tid] >= 0)) L[tri(tid) + tid] += lam;
+    __syncthreads();
+    // ---- blocked right-looking Cholesky over columns 0..n-1; rows 0..n ----
+    for (int j0 = 0; j0 < n; j0 += PW) {
+        const int w = n - j0 < PW ? n - j0 : PW;
+        if (wave == 0) {
+            const int ra = j0 + lane, rb = j0 + lane + 64;
+            double a[PW], b[PW];
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) {
+                a[jj] = (jj < w && ra < na && j0 + jj <= ra) ? L[tri(ra) + j0 + jj] : 0.0;
+                b[jj] = (jj < w && rb < na) ? L[tri(rb) + j0 + jj] : 0.0;
+            }
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) {
+                if (jj < w) {
+                    const double dj = sqrt(readlane_f64(a[jj], jj));
+                    const double inv = 1.0 / dj;
+                    if (lane == jj) a[jj] = dj; else if (lane > jj) a[jj] *= inv;
+                    b[jj] *= inv;
+#pragma unroll
+                    for (int c = jj + 1; c < PW; ++c) {
+                        if (c < w) {
+                            const double lcj = readlane_f64(a[jj], c);
+                            if (lane >= c) a[c] -= a[jj] * lcj;
+                            b[c] -= b[jj] * lcj;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) {
+                if (jj < w && ra < na && j0 + jj <= ra) L[tri(ra) + j0 + jj] = a[jj];
+                if (jj < w && rb < na) L[tri(rb) + j0 + jj] = b[jj];
+            }
+        }
+        __syncthreads();
+        const int j1 = j0 + w;
+        const int ti = tid & 15, tk = tid >> 4;
+        for (int i = j1 + ti; i <= n; i += 16) {
+            double li[PW];
+            const double *ri = L + tri(i) + j0;
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) li[jj] = jj < w ? ri[jj] : 0.0;
+            const int kmax = i < n - 1 ? i : n - 1;
+            for (int k = j1 + tk; k <= kmax; k += 16) {
+                const double *rk = L + tri(k) + j0;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < PW; jj += 2) {
+                    s0 = fma(li[jj], jj < w ? rk[jj] : 0.0, s0);
+                    s1 = fma(li[jj + 1], jj + 1 < w ? rk[jj + 1] : 0.0, s1);
+                }
+                L[tri(i) + k] -= s0 + s1;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- back substitution L^T w = z (z = row n), wave 0, lane owns entries lane and lane+64 ----
+    if (wave == 0) {
+        const double *zrow = L + tri(n);
+        double za = lane < n ? zrow[lane] : 0.0;
+        double zb = lane + 64 < n ? zrow[lane + 64] : 0.0;
+        for (int j = n - 1; j >= 0; --j) {
+            const double *rj = L + tri(j);
+            const double zj = j < 64 ? readlane_f64(za, j) : readlane_f64(zb, j - 64);
+            const double wj = zj / rj[j];
+            if (lane == (j & 63)) { if (j < 64) za = wj; else zb = wj; }
+            if (lane < j) za -= rj[lane] * wj;
+            if (lane + 64 < j) zb -= rj[lane + 64] * wj;
+        }
+        if (lane < p) W[(int64_t)lane * g.d + m] = nb[lane] >= 0 ? (float)za : 0.f;
+        if (lane + 64 < p) W[(int64_t)(lane + 64) * g.d + m] = nb[lane + 64] >= 0 ? (float)zb : 0.f;   // intercept (index p) discarded (:107)
+    }
+}
+
 // pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60) and the first-run test on row 1 (:25)
 __global__ void k_count_pos(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,11 +540,20 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc;
         const int n = p + 1;
-        size_t shmem = ((size_t)(n * (n + 1)) / 2 + n) * sizeof(double) + (size_t)n * sizeof(int);
-        shmem = (shmem + 15) & ~size_t(15);
-        if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "bg_ring_solve", k_ring_solve, dim3((unsigned)P->d), dim3(64), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-               ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
+        if (ctx->opt("solve_mode", 2) == 2 && n + 1 <= 128) {
+            const int na = n + 1;
+            size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4) * sizeof(double) + (size_t)p * sizeof(int);
+            shmem = (shmem + 15) & ~size_t(15);
+            if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            LAUNCH(ctx, "bg_ring_solve", k_ring_solve2, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
+                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
+        } else {
+            size_t shmem = ((size_t)(n * (n + 1)) / 2 + n) * sizeof(double) + (size_t)n * sizeof(int);
+            shmem = (shmem + 15) & ~size_t(15);
+            if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            LAUNCH(ctx, "bg_ring_solve_v1", k_ring_solve, dim3((unsigned)P->d), dim3(64), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
+                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
+        }
     }
     if (b0_out) {
         std::vector<double> tmp(P->d);

@@ -131,16 +131,21 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     constexpr int P = RingConst<R>::tab.n;
     constexpr int HR = TR + 2 * R, HC = TC + 2 * R, NH = HR * HC;
     constexpr int NIT = (NH + NT - 1) / NT;                 // halo pixels staged per thread
-    extern __shared__ __attribute__((aligned(16))) float4 halo[];
+    extern __shared__ __attribute__((aligned(16))) float4 halo[];     // two buffers of NH float4
     const int tid = threadIdx.x;
-    const int tile_r = blockIdx.x % a.ntile_r, tile_c = blockIdx.x / a.ntile_r;
+    // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous range of tiles
+    // (column-major over the tile grid) so that the halos neighbouring tiles share stay in one L2.
+    int bid = blockIdx.x;
+    const int ntile = gridDim.x;
+    if (ntile % 8 == 0) bid = (bid % 8) * (ntile / 8) + bid / 8;
+    const int tile_r = bid % a.ntile_r, tile_c = bid / a.ntile_r;
     const int tr = tid % TR, tc = tid / TR;
     const int pr = tile_r * TR + tr, pc = tile_c * TC + tc;
     const bool valid = pr < a.nr && pc < a.nc;
     const int64_t m = valid ? (int64_t)pc * a.nr + pr : 0;
     const int64_t qc = valid ? (int64_t)(pc + a.coff) * a.nr_b + (pr + a.roff) : 0;
     const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
-    const float4 *hb = halo + (tc * HR + tr);           // biased base: neighbour (dr,dc) at hb[(dc+R)*HR + (dr+R)]
+    const int hbase = tc * HR + tr;                     // biased base: neighbour (dr,dc) at halo[hbase + (dc+R)*HR + (dr+R)]
 
     // frame-invariant staging plan of this thread: BYTE offset inside a frame (or ~0u outside the block)
     // of the NIT halo pixels it stages, and a bit per pixel that A_prev has entries there.
@@ -156,29 +161,38 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
         if (HAS_AC && in) acmask |= (ld_off(a.arow, qoff[j] + 4u) > ld_off(a.arow, qoff[j])) ? (1u << j) : 0u;
     }
     const uint32_t mb = (uint32_t)m * 4u, qcb = (uint32_t)qc * 4u;
+    int ce0 = 0, ce1 = 0;                               // A_prev entries at the centre pixel
+    if (HAS_AC && valid) { ce0 = ld_off(a.arow, qcb); ce1 = ld_off(a.arow, qcb + 4u); }
 
     float w[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) w[i] = ld_off(a.W + (int64_t)i * a.d, mb);      // threads off the patch read pixel 0 and never store
-    const float ym_c = ld_off(a.ymean_f, qcb);
     const float dl = ld_off(a.dlt, mb);
 
     const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
     const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
-    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
+
+    float pre[NIT][4];                                  // raw frames of the NEXT chunk, in flight during the ring product
+    auto issue = [&](int64_t t0) {                      // frames past the end are clamped to the last one: loaded, never stored
         const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
-        // frames past the end of the video are clamped to the last one: loaded, never stored
         const float *y0 = a.Y + t0 * a.d_b;
         const float *y1 = a.Y + (t0 + (nf > 1 ? 1 : 0)) * a.d_b;
         const float *y2 = a.Y + (t0 + (nf > 2 ? 2 : nf - 1)) * a.d_b;
         const float *y3 = a.Y + (t0 + (nf > 3 ? 3 : nf - 1)) * a.d_b;
-        // ---- stage R' = (Y - Ymean) - A_prev*(C_prev - mean) for the halo, float4 (4 frames) per pixel ----
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
+            pre[j][0] = ld_off(y0, qo); pre[j][1] = ld_off(y1, qo); pre[j][2] = ld_off(y2, qo); pre[j][3] = ld_off(y3, qo);
+        }
+    };
+    // R' = (Y - Ymean) - A_prev*(C_prev - mean), float4 (4 frames) per halo pixel
+    auto commit = [&](int64_t t0, float4 *buf) {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int idx = tid + j * NT;
             const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
             const float ym = ld_off(a.ymean_f, qo);
-            float4 v = make_float4(ld_off(y0, qo) - ym, ld_off(y1, qo) - ym, ld_off(y2, qo) - ym, ld_off(y3, qo) - ym);
+            float4 v = make_float4(pre[j][0] - ym, pre[j][1] - ym, pre[j][2] - ym, pre[j][3] - ym);
             if (HAS_AC && ((acmask >> j) & 1u)) {
                 for (int e = ld_off(a.arow, qo); e < ld_off(a.arow, qo + 4u); ++e) {
                     const float av = a.aval[e];
@@ -187,14 +201,21 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
                 }
             }
             if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NIT * NT == NH || idx < NH) halo[idx] = v;
-            // compiler-level fence every 2 pixels: caps the loads in flight per thread at 10 so the P ring
-            // weights are not spilled to make room (other waves of the CU provide the memory parallelism)
-            asm volatile("" ::: "memory");
+            if (NIT * NT == NH || idx < NH) buf[idx] = v;
         }
-        __syncthreads();
-        // ---- ring product: groups of G neighbours = G ds_read_b128 then 4G FMAs.  The empty asm is a
-        // compiler-level memory fence: without it all P reads (4 VGPRs each) are hoisted and spill. ----
+    };
+
+    issue(tbeg);
+    commit(tbeg, halo);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
+        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
+        const bool more = t0 + 4 < tend;
+        if (more) issue(t0 + 4);                        // global loads of the next chunk fly under the ring product
+        const float4 *hb = halo + cur * NH + hbase;
+        // ---- ring product: groups of G neighbours = G ds_read_b128 then 4G FMAs.  The asm ties each
+        // group's FMAs into the memory order: without it all P reads are hoisted (4 VGPRs each) and spill. ----
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         constexpr int G = 4;
         static_assert(P % G == 0, "ring size must be a multiple of the read group");
@@ -210,17 +231,26 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
                 acc.x = fmaf(wi, r[j].x, acc.x); acc.y = fmaf(wi, r[j].y, acc.y);
                 acc.z = fmaf(wi, r[j].z, acc.z); acc.w = fmaf(wi, r[j].w, acc.w);
             }
-            // ties this group's FMAs (through acc) into the memory order, so the next group's reads
-            // cannot be issued before them and pile up in registers
             asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
         }
         if (valid) {
+            // Ysig = (Y - Ymean)(centre) + (Ymean - b0) - W*R' ; the centre's (Y - Ymean) = R'(centre) + A_prev*Cc(centre)
+            float4 c = hb[R * HR + R];
+            if (HAS_AC) {
+                for (int e = ce0; e < ce1; ++e) {
+                    const float av = a.aval[e];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.acol[e] * a.ldc + t0);
+                    c.x += av * c4.x; c.y += av * c4.y; c.z += av * c4.z; c.w += av * c4.w;
+                }
+            }
             float *o = a.Ysig + t0 * a.d;
-            st_off(o, mb, (ld_off(y0, qcb) - ym_c) + dl - acc.x);
-            if (nf > 1) st_off(o + a.d, mb, (ld_off(y1, qcb) - ym_c) + dl - acc.y);
-            if (nf > 2) st_off(o + 2 * a.d, mb, (ld_off(y2, qcb) - ym_c) + dl - acc.z);
-            if (nf > 3) st_off(o + 3 * a.d, mb, (ld_off(y3, qcb) - ym_c) + dl - acc.w);
+            st_off(o, mb, c.x + dl - acc.x);
+            if (nf > 1) st_off(o + a.d, mb, c.y + dl - acc.y);
+            if (nf > 2) st_off(o + 2 * a.d, mb, c.z + dl - acc.z);
+            if (nf > 3) st_off(o + 3 * a.d, mb, c.w + dl - acc.w);
         }
+        if (more) commit(t0 + 4, halo + (cur ^ 1) * NH);
+        cur ^= 1;
         __syncthreads();
     }
 }
@@ -264,7 +294,7 @@ __global__ void __launch_bounds__(256) k_residual_gen(R1Args a) {
 
 template <int R, int TR, int TC>
 static int launch_r1(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid) {
-    constexpr size_t shmem = (size_t)(TR + 2 * R) * (TC + 2 * R) * sizeof(float4);
+    constexpr size_t shmem = 2 * (size_t)(TR + 2 * R) * (TC + 2 * R) * sizeof(float4);   // double-buffered halo
     static_assert(shmem <= 160 * 1024, "halo tile exceeds LDS");
     if (shmem > 64 * 1024) {
         CK(hipFuncSetAttribute((const void *)k_residual_r<R, TR, TC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
