@@ -43,6 +43,43 @@ __global__ void k_dlt(const float *__restrict__ ymean_f, const double *__restric
     dlt[m] = (float)((double)ymean_f[q] - b0[m]);
 }
 
+// W*A_prev per patch pixel (ELL rows): wa(m,k) = sum_i W(m,i) * A_prev(m + o_i, k), accumulated in ring order.
+// One thread per pixel; its <= WA_CAP (k, value) slots live in LDS ([slot][thread], conflict-free).
+constexpr int WA_CAP_ = 32;
+__global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, int64_t d, int nr, int nr_b, int nc_b, int roff, int coff, int p,
+                                                 const int *__restrict__ dr, const int *__restrict__ dc, const int *__restrict__ arow,
+                                                 const int *__restrict__ acol, const float *__restrict__ aval,
+                                                 int *__restrict__ wa_cnt, int *__restrict__ wa_k, float *__restrict__ wa_v, int *__restrict__ overflow) {
+    __shared__ int tk[WA_CAP_][128];
+    __shared__ float tv[WA_CAP_][128];
+    const int64_t m = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (m >= d) return;
+    const int t = threadIdx.x;
+    const int rbm = (int)(m % nr) + roff, cbm = (int)(m / nr) + coff;
+    int n = 0;
+    for (int i = 0; i < p; ++i) {
+        const float w = W[(int64_t)i * d + m];
+        const int rb = rbm + dr[i], cb = cbm + dc[i];
+        if (w == 0.f || rb < 0 || rb >= nr_b || cb < 0 || cb >= nc_b) continue;
+        const int64_t q = (int64_t)cb * nr_b + rb;
+        for (int e = arow[q]; e < arow[q + 1]; ++e) {
+            const int k = acol[e];
+            int s = 0;
+            while (s < n && tk[s][t] != k) ++s;
+            if (s == n) {
+                if (n == WA_CAP_) { *overflow = 1; continue; }
+                tk[s][t] = k; tv[s][t] = 0.f; ++n;
+            }
+            tv[s][t] = fmaf(w, aval[e], tv[s][t]);
+        }
+    }
+    wa_cnt[m] = n;
+    for (int s = 0; s < n; ++s) { wa_k[(int64_t)s * d + m] = tk[s][t]; wa_v[(int64_t)s * d + m] = tv[s][t]; }
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int WA_CAP = WA_CAP_;   // max neurons whose footprint a pixel's ring may touch
+
 struct R1Args {
     const float *Y; int64_t d_b; int nr_b, nc_b;
     int nr, nc, roff, coff; int64_t d;
@@ -50,7 +87,9 @@ struct R1Args {
     const float *W; int p, h;
     const int *offs;                 // generic path only: p entries (dc*HR + dr)
     const float *ymean_f; const float *dlt;
-    const int *arow; const int *acol; const float *aval; const float *Cc; int64_t ldc;   // A_prev CSR over block pixels (or null)
+    // A_prev*C_prev enters through linearity: W*(A*Cc) = (W*A)*Cc.  wa_* is the per-pixel ELL table of W*A
+    // ([slot][pixel], WA_CAP slots), wa_cnt[pixel] its length; Cc the centred traces [k][ldc].
+    const int *wa_cnt; const int *wa_k; const float *wa_v; const float *Cc; int64_t ldc;
     float *Ysig;
     int ntile_r;
 };
@@ -70,8 +109,8 @@ template <int R> constexpr RingTab<R> make_ring() {
 }
 template <int R> struct RingConst { static constexpr RingTab<R> tab = make_ring<R>(); };
 
-// stage the centred residual halo of frames [t0, t0+nf):  R' = (Y - Ymean) - A_prev*(C_prev - mean)
-template <int NT, bool HAS_AC>
+// stage the centred video halo of frames [t0, t0+nf):  Y' = Y - Ymean
+template <int NT>
 __device__ __forceinline__ void stage_halo(const R1Args &a, float4 *halo, int tid, int HR, int NH, int hr0, int hc0, int64_t t0, int nf) {
 #pragma unroll 2
     for (int idx = tid; idx < NH; idx += NT) {
@@ -86,18 +125,24 @@ __device__ __forceinline__ void stage_halo(const R1Args &a, float4 *halo, int ti
             v.y = nf > 1 ? y[a.d_b] - ym : 0.f;
             v.z = nf > 2 ? y[2 * a.d_b] - ym : 0.f;
             v.w = nf > 3 ? y[3 * a.d_b] - ym : 0.f;
-            if (HAS_AC) {
-                for (int e = a.arow[q]; e < a.arow[q + 1]; ++e) {
-                    const float av = a.aval[e];
-                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.acol[e] * a.ldc + t0);
-                    v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
-                }
-            }
         }
         halo[idx] = v;
     }
 }
 
+// (W*A)*Cc at pixel m for frames t0..t0+3
+__device__ __forceinline__ float4 wa_term(const R1Args &a, int64_t m, int64_t t0) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = a.wa_cnt[m];
+    for (int e = 0; e < n; ++e) {
+        const float v = a.wa_v[(int64_t)e * a.d + m];
+        const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + m] * a.ldc + t0);
+        s.x = fmaf(v, c4.x, s.x); s.y = fmaf(v, c4.y, s.y); s.z = fmaf(v, c4.z, s.z); s.w = fmaf(v, c4.w, s.w);
+    }
+    return s;
+}
+
+// Ysig = (Y - Ymean)(centre) + (Ymean - b0) - W*Y' + (W*A)*Cc
 __device__ __forceinline__ void store_ysig(const R1Args &a, int64_t t0, int nf, int64_t qc, int64_t m, float ym_c, float dl, float4 acc) {
     const float *y = a.Y + t0 * a.d_b + qc;
     float *o = a.Ysig + t0 * a.d + m;
@@ -148,9 +193,8 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     const int hbase = tc * HR + tr;                     // biased base: neighbour (dr,dc) at halo[hbase + (dc+R)*HR + (dr+R)]
 
     // frame-invariant staging plan of this thread: BYTE offset inside a frame (or ~0u outside the block)
-    // of the NIT halo pixels it stages, and a bit per pixel that A_prev has entries there.
+    // of the NIT halo pixels it stages
     uint32_t qoff[NIT];
-    unsigned acmask = 0;
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
         const int idx = tid + j * NT;
@@ -158,15 +202,33 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
         const int rb = hr0 + hr, cb = hc0 + hc;
         const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
         qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 4u : ~0u;
-        if (HAS_AC && in) acmask |= (ld_off(a.arow, qoff[j] + 4u) > ld_off(a.arow, qoff[j])) ? (1u << j) : 0u;
     }
-    const uint32_t mb = (uint32_t)m * 4u, qcb = (uint32_t)qc * 4u;
-    int ce0 = 0, ce1 = 0;                               // A_prev entries at the centre pixel
-    if (HAS_AC && valid) { ce0 = ld_off(a.arow, qcb); ce1 = ld_off(a.arow, qcb + 4u); }
-
-    float w[P];
+    float ymj[NIT];
 #pragma unroll
-    for (int i = 0; i < P; ++i) w[i] = ld_off(a.W + (int64_t)i * a.d, mb);      // threads off the patch read pixel 0 and never store
+    for (int j = 0; j < NIT; ++j) ymj[j] = ld_off(a.ymean_f, qoff[j] == ~0u ? 0u : qoff[j]);
+    const uint32_t mb = (uint32_t)m * 4u, qcb = (uint32_t)qc * 4u;
+    (void)qcb;
+    // (W*A_prev) row of this pixel: the first WA_PRE entries are kept in registers (frame-invariant) and their
+    // trace samples are fetched at the top of every iteration so they land under the ring product
+    constexpr int WA_PRE = 4;
+    uint32_t wko[WA_PRE]; float wvv[WA_PRE]; int nwa = 0;
+    if (HAS_AC) {
+        nwa = valid ? a.wa_cnt[m] : 0;
+#pragma unroll
+        for (int e = 0; e < WA_PRE; ++e) {
+            const bool on = e < nwa;
+            wko[e] = on ? (uint32_t)a.wa_k[(int64_t)e * a.d + m] * (uint32_t)(a.ldc * 4) : 0u;
+            wvv[e] = on ? a.wa_v[(int64_t)e * a.d + m] : 0.f;
+        }
+    }
+
+    static_assert(P % 2 == 0, "ring size must be even (weights are held as pairs)");
+    f2 wp[P / 2];
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) {                   // threads off the patch read pixel 0 and never store
+        wp[i].x = ld_off(a.W + (int64_t)(2 * i) * a.d, mb);
+        wp[i].y = ld_off(a.W + (int64_t)(2 * i + 1) * a.d, mb);
+    }
     const float dl = ld_off(a.dlt, mb);
 
     const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
@@ -185,62 +247,83 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
             pre[j][0] = ld_off(y0, qo); pre[j][1] = ld_off(y1, qo); pre[j][2] = ld_off(y2, qo); pre[j][3] = ld_off(y3, qo);
         }
     };
-    // R' = (Y - Ymean) - A_prev*(C_prev - mean), float4 (4 frames) per halo pixel
-    auto commit = [&](int64_t t0, float4 *buf) {
+    // Y' = Y - Ymean, float4 (4 frames) per halo pixel
+    auto commit = [&](float4 *buf) {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int idx = tid + j * NT;
-            const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
-            const float ym = ld_off(a.ymean_f, qo);
+            const float ym = ymj[j];
             float4 v = make_float4(pre[j][0] - ym, pre[j][1] - ym, pre[j][2] - ym, pre[j][3] - ym);
-            if (HAS_AC && ((acmask >> j) & 1u)) {
-                for (int e = ld_off(a.arow, qo); e < ld_off(a.arow, qo + 4u); ++e) {
-                    const float av = a.aval[e];
-                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.acol[e] * a.ldc + t0);
-                    v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
-                }
-            }
             if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (NIT * NT == NH || idx < NH) buf[idx] = v;
         }
     };
 
     issue(tbeg);
-    commit(tbeg, halo);
+    commit(halo);
     __syncthreads();
     int cur = 0;
     for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
         const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
         const bool more = t0 + 4 < tend;
         if (more) issue(t0 + 4);                        // global loads of the next chunk fly under the ring product
+        float4 wc[WA_PRE];
+        if (HAS_AC) {
+#pragma unroll
+            for (int e = 0; e < WA_PRE; ++e)
+                wc[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.Cc + t0) + wko[e]);
+        }
         const float4 *hb = halo + cur * NH + hbase;
         // ---- ring product: groups of G neighbours = G ds_read_b128 then 4G FMAs.  The asm ties each
         // group's FMAs into the memory order: without it all P reads are hoisted (4 VGPRs each) and spill. ----
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        constexpr int G = 4;
+        f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+        constexpr int G = 4, NG = P / G, D = 3;         // D groups of reads in flight ahead of the FMAs (<= 15 outstanding: lgkmcnt is 4 bits)
         static_assert(P % G == 0, "ring size must be a multiple of the read group");
+        float4 r[D + 1][G];
 #pragma unroll
-        for (int g = 0; g < P / G; ++g) {
-            float4 r[G];
+        for (int g = 0; g < D; ++g)
 #pragma unroll
             for (int j = 0; j < G; ++j)
-                r[j] = hb[(RingConst<R>::tab.dc[g * G + j] + R) * HR + (RingConst<R>::tab.dr[g * G + j] + R)];
+                r[g][j] = hb[(RingConst<R>::tab.dc[g * G + j] + R) * HR + (RingConst<R>::tab.dr[g * G + j] + R)];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + D < NG) {
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    r[(g + D) % (D + 1)][j] = hb[(RingConst<R>::tab.dc[(g + D) * G + j] + R) * HR + (RingConst<R>::tab.dr[(g + D) * G + j] + R)];
+            }
 #pragma unroll
             for (int j = 0; j < G; ++j) {
-                const float wi = w[g * G + j];
-                acc.x = fmaf(wi, r[j].x, acc.x); acc.y = fmaf(wi, r[j].y, acc.y);
-                acc.z = fmaf(wi, r[j].z, acc.z); acc.w = fmaf(wi, r[j].w, acc.w);
+                // two v_pk_fma_f32 (2 FMAs per lane each) instead of four v_fma_f32.  Weights live as PAIRS
+                // (w[2k], w[2k+1]) in one 64-bit VGPR pair; op_sel/op_sel_hi broadcast the low or the high
+                // half to both packed lanes, so a weight still costs one VGPR (hipcc would splat it into two).
+                const float4 rv = r[g % (D + 1)][j];
+                const f2 r01 = {rv.x, rv.y}, r23 = {rv.z, rv.w};
+                const f2 wv = wp[(g * G + j) >> 1];
+                if (((g * G + j) & 1) == 0) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc01) : "v"(wv), "v"(r01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc23) : "v"(wv), "v"(r23));
+                } else {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc01) : "v"(wv), "v"(r01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc23) : "v"(wv), "v"(r23));
+                }
             }
-            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+            asm volatile("" : "+v"(acc01), "+v"(acc23) : : "memory");
         }
+        const float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
         if (valid) {
-            // Ysig = (Y - Ymean)(centre) + (Ymean - b0) - W*R' ; the centre's (Y - Ymean) = R'(centre) + A_prev*Cc(centre)
+            // Ysig = (Y - Ymean)(centre) + (Ymean - b0) - W*Y' + (W*A_prev)*Cc ; the centre's Y' is in the halo
             float4 c = hb[R * HR + R];
             if (HAS_AC) {
-                for (int e = ce0; e < ce1; ++e) {
-                    const float av = a.aval[e];
-                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.acol[e] * a.ldc + t0);
-                    c.x += av * c4.x; c.y += av * c4.y; c.z += av * c4.z; c.w += av * c4.w;
+#pragma unroll
+                for (int e = 0; e < WA_PRE; ++e) {
+                    c.x = fmaf(wvv[e], wc[e].x, c.x); c.y = fmaf(wvv[e], wc[e].y, c.y);
+                    c.z = fmaf(wvv[e], wc[e].z, c.z); c.w = fmaf(wvv[e], wc[e].w, c.w);
+                }
+                for (int e = WA_PRE; e < nwa; ++e) {    // rare: more than WA_PRE footprints under this pixel's ring
+                    const float v = a.wa_v[(int64_t)e * a.d + m];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + m] * a.ldc + t0);
+                    c.x = fmaf(v, c4.x, c.x); c.y = fmaf(v, c4.y, c.y); c.z = fmaf(v, c4.z, c.z); c.w = fmaf(v, c4.w, c.w);
                 }
             }
             float *o = a.Ysig + t0 * a.d;
@@ -249,7 +332,7 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
             if (nf > 2) st_off(o + 2 * a.d, mb, c.z + dl - acc.z);
             if (nf > 3) st_off(o + 3 * a.d, mb, c.w + dl - acc.w);
         }
-        if (more) commit(t0 + 4, halo + (cur ^ 1) * NH);
+        if (more) commit(halo + (cur ^ 1) * NH);
         cur ^= 1;
         __syncthreads();
     }
@@ -276,10 +359,11 @@ __global__ void __launch_bounds__(256) k_residual_gen(R1Args a) {
     const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
     for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
         const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
-        stage_halo<NT, HAS_AC>(a, halo, tid, HR, NH, hr0, hc0, t0, nf);
+        stage_halo<NT>(a, halo, tid, HR, NH, hr0, hc0, t0, nf);
         __syncthreads();
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
+            if (HAS_AC) { const float4 s4 = wa_term(a, m, t0); acc.x = -s4.x; acc.y = -s4.y; acc.z = -s4.z; acc.w = -s4.w; }
             for (int i = 0; i < a.p; ++i) {
                 const float wi = a.W[(int64_t)i * a.d + m];
                 const float4 r = halo[base + a.offs[i]];
@@ -329,7 +413,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     const int64_t T = P->T;
     RET(ctx->ysig.ensure((size_t)P->d * T * sizeof(float)));
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
-           &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7];
+           &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10], &dFlag = ctx->tmp[11];
     int64_t ldc = 4;
     bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
     if (has_ac) {
@@ -340,13 +424,25 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         RET(to_dev(ctx, dArow, rp.data(), rp.size()));
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+        RET(dWaCnt.ensure(P->d * sizeof(int)));
+        RET(dWaK.ensure((size_t)WA_CAP * P->d * sizeof(int)));
+        RET(dWaV.ensure((size_t)WA_CAP * P->d * sizeof(float)));
+        RET(dFlag.ensure(64));
+        CK(hipMemsetAsync(dFlag.p, 0, 64, ctx->stream));
+        LAUNCH(ctx, "r1_ring_wa", k_ring_wa, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
+               P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(),
+               dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dFlag.as<int>());
+        int flag = 0;
+        CK(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        if (flag) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than %d footprints of A_prev", WA_CAP);
     }
     RET(dDlt.ensure(P->d * sizeof(float)));
     LAUNCH(ctx, "r1_dlt", k_dlt, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
            P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
 
     // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
-    int variant = (int)ctx->opt("r1_variant", 0);
+    int variant = (int)ctx->opt("r1_variant", 2);
     const int h = P->radius;
     bool full_ring = true;
     { int n = 0;
@@ -364,8 +460,8 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     a.T = T;
     a.W = P->W.as<float>(); a.p = P->p; a.h = h; a.offs = nullptr;
     a.ymean_f = P->ymean_f.as<float>(); a.dlt = dDlt.as<float>();
-    a.arow = has_ac ? dArow.as<int>() : nullptr; a.acol = has_ac ? dAcol.as<int>() : nullptr;
-    a.aval = has_ac ? dAval.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
+    a.wa_cnt = has_ac ? dWaCnt.as<int>() : nullptr; a.wa_k = has_ac ? dWaK.as<int>() : nullptr;
+    a.wa_v = has_ac ? dWaV.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
     a.Ysig = ctx->ysig.as<float>();
     a.ntile_r = (P->nr + TR - 1) / TR;
     const int ntile_c = (P->nc + TC - 1) / TC;

@@ -1,0 +1,78 @@
+"""TEST DOUBLE ONLY: an Engine-shaped object whose kernels are the float64 oracle functions.
+
+It exists so that the host-side logic of cnmf_e_amd.sources2d (patch sharding over ranks, slicing,
+stitching, the all-reduce / all-gather of the N>1 path) can be exercised on CPU under gloo.  It is
+never importable from the product package and never used on a GPU box for parity claims."""
+import numpy as np
+import scipy.sparse as sp
+
+import cnmfe_oracle as orc
+
+
+class FakeEngine:
+    def __init__(self):
+        self.p = {}
+
+    def create_patch(self, pid, patch_rect, block_rect, d1, d2, T):
+        pr = np.asarray(patch_rect); br = np.asarray(block_rect)
+        nrb, ncb = int(br[1] - br[0] + 1), int(br[3] - br[2] + 1)
+        self.p[pid] = dict(pr=pr, br=br, d1=d1, d2=d2, T=T, Y=np.zeros((T, nrb * ncb), np.float64), ip=orc.ind_patch_mask(pr, br))
+
+    def upload_block(self, pid, Y, t0=0):
+        self.p[pid]["Y"][t0:t0 + Y.shape[0]] = Y
+
+    def ymean(self, pid):
+        return self.p[pid]["Y"].mean(axis=0)
+
+    def ring_init(self, pid, radius, num_neighbors=None):
+        q = self.p[pid]
+        rs, cs = orc.get_nhood(radius, num_neighbors)
+        q["W"] = orc.build_ring_W(q["pr"], q["br"], q["d1"], q["d2"], rs, cs).tocsr()
+        q["b0"] = np.zeros(int(q["ip"].sum()))
+
+    def ring_csr(self, pid):
+        return self.p[pid]["W"]
+
+    def ring_first_run(self, pid):
+        row = self.p[pid]["W"].getrow(0)
+        vals = set(np.unique(row.data).tolist())
+        if row.nnz < row.shape[1]:
+            vals.add(0.0)
+        return len(vals) == 2
+
+    def b0(self, pid):
+        return self.p[pid]["b0"]
+
+    def fit_ring_model(self, pid, A_block, C_block, thresh_outlier=float("nan"), with_projection=True, want_b0=True):
+        q = self.p[pid]
+        A = None if A_block is None else sp.csc_matrix(A_block).astype(np.float64)
+        W, b0 = orc.fit_ring_model(q["Y"].T, A, C_block, q["W"], thresh_outlier, None, q["ip"], with_projection)
+        q["W"], q["b0"] = W.tocsr(), b0
+        return b0, {}
+
+    def residual(self, pid, A_prev_block=None, C_prev=None, want=False):
+        q = self.p[pid]
+        A = None if A_prev_block is None else sp.csc_matrix(A_prev_block).astype(np.float64)
+        q["Ysig"] = orc.residual_ysig(q["Y"].T, A, C_prev, q["W"], q["b0"], q["ip"])
+        return q["Ysig"].T if want else None
+
+    def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3):
+        Y = self.p[pid]["Ysig"]
+        A = sp.csc_matrix(A_patch).astype(np.float64)
+        IND = sp.csc_matrix(IND_patch).toarray().astype(bool)
+        if algorithm == "hals":
+            out = orc.HALS_spatial(Y, A, C_patch, IND, param)
+        elif algorithm == "hals_thresh":
+            out = orc.HALS_spatial_thresh(Y, A, C_patch, IND, param, sn)
+        else:
+            out = orc.nnls_spatial(Y, A, C_patch, IND, param)
+        return sp.csc_matrix(out)
+
+    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5):
+        A = sp.csc_matrix(A_patch).astype(np.float64)
+        C, C_raw, _ = orc.HALS_temporal(self.p[pid]["Ysig"], A, C_patch, maxIter, None)
+        return C, C_raw, np.asarray(A.multiply(A).sum(axis=0)).ravel()
+
+    def post_process_spatial(self, A_full, d1, d2):
+        A = sp.csc_matrix(A_full).toarray().astype(np.float64)
+        return sp.csc_matrix(orc.post_process_spatial(A.reshape(d1, d2, A.shape[1], order="F")))

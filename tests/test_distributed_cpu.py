@@ -1,0 +1,57 @@
+"""world_size-2 gloo test of the N>1 path (patch sharding + the temporal all-reduce stitch + the spatial
+row gather) on CPU.  Kernels are a test double (tests/fake_engine.py) because the HIP engine needs a GPU;
+what is under test is cnmf_e_amd.sources2d's distributed host logic."""
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASE = dict(d1=40, d2=44, T=150, K=6, r=4, seed=31)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    from fake_engine import FakeEngine
+    c = CASE
+    f = synth.make_factors(c["d1"], c["d2"], c["T"], c["K"], c["seed"], gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(c["d1"], c["d2"], c["T"], [20, 22], c["r"], FakeEngine(), rank=rank, world_size=world)
+    assert len(video.owned) == 4 // world
+    video.upload_from_full(Y.astype(np.float64))
+    s = Sources2D(video, Options(ring_radius=c["r"], spatial_algorithm="hals", maxIter=3), f.A_init, f.C_init, f.sn,
+                  dist_group=td.group.WORLD)
+    s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+    if rank == 0:
+        np.savez(out, A=s.A.toarray(), C=s.C, b0_new=s.b0_new)
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_iteration_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cnmfe_oracle as orc
+    from cnmf_e_amd import synth
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    c = CASE
+    f = synth.make_factors(c["d1"], c["d2"], c["T"], c["K"], c["seed"], gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    o = orc.OracleSources2D(Y.T.reshape(c["d1"], c["d2"], c["T"], order="F"), c["d1"], c["d2"], c["T"], [20, 22], c["r"],
+                            f.A_init.astype(np.float32), f.C_init, f.sn, spatial_algorithm="hals", maxIter=3)
+    o.update_background_parallel(); o.update_spatial_parallel(); o.update_temporal_parallel()
+    assert np.allclose(got["A"], o.A.toarray(), rtol=1e-4, atol=1e-6)
+    assert np.allclose(got["C"], o.C, rtol=1e-4, atol=1e-4)
+    assert np.allclose(got["b0_new"], o.b0_new, rtol=1e-5, atol=1e-2)
