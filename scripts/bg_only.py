@@ -1,0 +1,25 @@
+"""background-fit-only driver for PMC passes: python scripts/bg_only.py --cfg c3 [--mode 2]"""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--mode", type=int, default=2); ap.add_argument("--reps", type=int, default=1)
+a = ap.parse_args()
+import torch
+from cnmf_e_amd import synth
+from cnmf_e_amd.engine import Engine
+from cnmf_e_amd.sources2d import PatchedVideo
+CFG = {"c2": (256, 256, 3000, 200, 15, 1), "c3": (512, 512, 10000, 500, 15, 2)}
+d1, d2, T, K, r, seed = CFG[a.cfg]
+f = synth.make_factors(d1, d2, T, K, seed)
+Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
+eng = Engine(0)
+video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
+eng.ring_init(0, r)
+eng.set_option("gram_mode", a.mode)
+eng.profile(True)
+for _ in range(a.reps):
+    eng.fit_ring_model(0, f.A_init.astype(np.float32), f.C_init)
+print(eng.profile_table())

@@ -70,6 +70,13 @@ def main():
             if v["calls"]:
                 print("   %-24s %9.3f ms  x%d" % (k, v["total_ms"], v["calls"]))
         print("   K=%d nnz(A)=%d  C range %.3g..%.3g" % (s.A.shape[1], s.A.nnz, s.C.min(), s.C.max()), flush=True)
+    if a.iters:
+        import cProfile, pstats, io
+        pr = cProfile.Profile(); pr.enable()
+        s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+        pr.disable()
+        st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(28)
+        print("\n".join(l[:150] for l in st.getvalue().splitlines()[:48]))
     # planted-model sanity
     A = s.A
     cors = []

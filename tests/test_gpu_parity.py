@@ -261,3 +261,26 @@ def test_method_level_iteration_parity(eng, alg):
         s.update_temporal_parallel(); o.update_temporal_parallel()
         assert rel(s.C, o.C) <= 2e-3, (it, rel(s.C, o.C))
         assert np.allclose(s.b0_new, o.b0_new, rtol=1e-4, atol=5e-2)
+
+
+@pytest.mark.parametrize("gram_mode", [1, 2])
+def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
+    """gram_mode 1 = fp64 matrix pipe, 2 = fp32 pipe with fp64 shadow accumulation; debug=1 NaN-poisons the
+    covariance table so that a lookup into a pruned (never computed) sub-tile cannot go unnoticed."""
+    c = Case(eng, 70, 66, 160, 5, 15, 19, [35, 33])
+    eng.set_option("debug", 1); eng.set_option("gram_mode", gram_mode)
+    try:
+        for idx in c.video.owned:
+            pid = c.video.pid[idx]
+            bp = c.video.block_pix[idx]
+            A_b = c.f.A_init.astype(np.float32).tocsr()[bp].tocsc()
+            keep = np.asarray(A_b.sum(axis=0)).ravel() > 0
+            A_b = A_b[:, keep]; C_b = c.f.C_init[keep]
+            b0, info = eng.fit_ring_model(pid, A_b if A_b.shape[1] else None, C_b)
+            Wref, _ = orc.fit_ring_model(c.block(idx), A_b.astype(np.float64), C_b, c.W0(idx), np.nan, None, c.ipmask(idx), True)
+            W = eng.ring_csr(pid)
+            assert np.all(np.isfinite(W.data))
+            Wref = Wref.tocsr(); Wref.sort_indices()
+            assert rel(W.data, Wref.data) <= (1e-4 if gram_mode == 1 else 1e-3), rel(W.data, Wref.data)
+    finally:
+        eng.set_option("debug", 0); eng.set_option("gram_mode", 2)
