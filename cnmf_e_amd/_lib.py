@@ -25,6 +25,12 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 u8p = C.POINTER(C.c_uint8)
 
+class DeconvOpts(C.Structure):
+    """struct cnmfe_deconv_opts (include/cnmfe.h)"""
+    _fields_ = [("type", C.c_int32), ("method", C.c_int32), ("smin", C.c_double), ("lambda_", C.c_double),
+                ("max_tau", C.c_double), ("optimize_b", C.c_int32), ("optimize_pars", C.c_int32), ("maxIter", C.c_int32)]
+
+
 # every symbol include/cnmfe.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "cnmfe_last_error": (C.c_char_p, []),
@@ -48,6 +54,9 @@ PROTOTYPES = {
                                        i64p, i32p, f32p, C.c_int32, f32p]),
     "cnmfe_hals_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,
                                       f32p, f32p, f32p]),
+    "cnmfe_hals_temporal_deconv": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,
+                                             C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p, f32p, f32p]),
+    "cnmfe_deconv_temporal": (C.c_int, [c_ctx, C.c_int32, C.c_int64, f32p, C.c_int, C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p]),
     "cnmfe_post_process_spatial": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, f32p, u8p]),
     "cnmfe_profile_enable": (C.c_int, [c_ctx, C.c_int]),
     "cnmfe_profile_reset": (C.c_int, [c_ctx]),

@@ -489,7 +489,32 @@ int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if (!A_val || !C_in) return fail(CNMFE_EINVAL, "null A_val / C_in");
     if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
     CK(hipSetDevice(ctx->device));
-    return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out);
+    return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, nullptr, nullptr, nullptr, nullptr);
+}
+
+int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                               const float *A_val, const float *C_in, int c_order, int32_t maxIter, const cnmfe_deconv_opts *opts,
+                               float *kernel_pars, float *C_out, float *C_raw_out, float *S_out, float *sn_out, float *aa_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
+    RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
+    if (!A_val || !C_in || !opts || !kernel_pars) return fail(CNMFE_EINVAL, "null A_val / C_in / opts / kernel_pars");
+    if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
+    CK(hipSetDevice(ctx->device));
+    return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, opts, kernel_pars, S_out, sn_out);
+}
+
+int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,
+                          float *C_out, float *S_out, float *kernel_pars_out, float *sn_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (K < 0 || T <= 0) return fail(CNMFE_EINVAL, "bad K / T");
+    if (K == 0) return 0;
+    if (!C_raw || !opts || !C_out) return fail(CNMFE_EINVAL, "null C_raw / opts / C_out");
+    CK(hipSetDevice(ctx->device));
+    return deconv_all_run(ctx, K, T, C_raw, c_order, opts, C_out, S_out, kernel_pars_out, sn_out);
 }
 
 int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr,

@@ -1,0 +1,498 @@
+// T4/T6: AR(1) FOOPSI deconvolution (OASIS) of calcium traces on the GPU, one workgroup per trace.
+//   deconvolveCa.m:61-123,199-206 (type 'ar1', method 'foopsi')  ->  foopsi_oasisAR1.m:36-180  ->  oasisAR1.m:30-109
+//   GetSn.m:19-46 (pwelch defaults)      estimate_time_constant.m:21-66 (p = 1)
+// Callers: the deconvolution branch of HALS_temporal (utilities/HALS_temporal.m:70-104, fused here with the
+// HALS row update :62) and @Sources2D/deconvTemporal.m:29-105.
+//
+// All scalar logic is fp64 like the reference; traces are fp32 rows.  Phases of one workgroup (256 threads):
+//   raw trace -> LDS | bitonic sort (median, 15 % quantile) | Welch PSD via radix-2 FFT in LDS (sn) |
+//   autocovariance (g) | OASIS pool stack, sequential on lane 0 | Brent fminbnd over g, each rss(g) evaluated in
+//   parallel over <=64-sample tasks of the pools | solution c, s written in parallel.
+// MathWorks semantics restated (parity unpinned, see oracle/oasis_oracle.py): pwelch, fminbnd (TolX 1e-4), quantile.
+#include "common.hpp"
+#include <math.h>
+
+namespace cnmfe {
+
+struct DeconvCfg {
+    int T, P2, nfft, L, nov, nseg;     // trace length, pow2 >= T, Welch geometry
+    int maxIter;                       // foopsi iterations (20 inside HALS_temporal, 10 in deconvTemporal)
+    int optimize_b, optimize_g;
+    double smin_opt, lam, gmax;
+    int hals;                          // 1: fuse the HALS row update and the median baseline (HALS_temporal.m:62,78)
+    int last;                          // HALS: last sweep -> also write C_raw, S (:100-103)
+};
+
+struct DeconvIO {
+    const int *list;                   // neuron ids handled by this launch
+    float *C; float *Craw; float *S; int64_t ldc;
+    const float *U; const int *nptr; const int *nidx; const float *nval; const float *aa;   // HALS inputs
+    float *pars; float *sn_out; float *b_out;
+    double *pv, *pw; int *pt, *pl;     // pool scratch, T entries per trace slot
+    int *tk_pool, *tk_off, *tk_len;    // task scratch, 2*T per trace slot
+    double *tk_val;
+    double *pnum;                      // per-pool numerators, T per trace slot
+};
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    const int tid = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const double r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+// in-place radix-2 FFT of n complex points in LDS (re, im), 256 threads
+__device__ void fft_lds(float *re, float *im, int n, int logn) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) {                       // bit reversal
+        const int j = (int)(__brev((unsigned)i) >> (32 - logn));
+        if (j > i) { float t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+    __syncthreads();
+    for (int s = 1; s <= logn; ++s) {
+        const int half = 1 << (s - 1);
+        for (int b = tid; b < n / 2; b += 256) {
+            const int grp = b / half, pos = b % half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            float sn_, cs_;
+            sincospif(-(float)pos / (float)half, &sn_, &cs_);
+            const float xr = re[i1] * cs_ - im[i1] * sn_, xi = re[i1] * sn_ + im[i1] * cs_;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + xr; im[i0] = ui + xi; re[i1] = ur - xr; im[i1] = ui - xi;
+        }
+        __syncthreads();
+    }
+}
+
+// GetSn(y): Welch PSD (Hamming L, 50 % overlap, nfft) averaged as exp(mean(log(psd/2))) over 0.25 <= f <= 0.5
+__device__ double get_sn(const float *y, const DeconvCfg &c, float *re, float *im, double *red) {
+    const int tid = threadIdx.x;
+    const int nfft = c.nfft, L = c.L, step = c.L - c.nov;
+    int logn = 0; while ((1 << logn) < nfft) ++logn;
+    const int k0 = (nfft + 3) / 4, k1 = nfft / 2;              // bins with 0.25 <= k/nfft <= 0.5
+    const int nb = k1 - k0 + 1;
+    constexpr int MAXB = 16;                                   // bins per thread (nfft <= 16384)
+    float acc[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) acc[i] = 0.f;
+    double w2 = 0;
+    for (int i = tid; i < L; i += 256) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; }
+    w2 = block_sum(w2, red);
+    for (int sg = 0; sg < c.nseg; ++sg) {
+        for (int i = tid; i < nfft; i += 256) {
+            float v = 0.f;
+            if (i < L) v = y[sg * step + i] * (float)(0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)));
+            re[i] = v; im[i] = 0.f;
+        }
+        __syncthreads();
+        fft_lds(re, im, nfft, logn);
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) { const int k = k0 + tid + i * 256; if (k <= k1) acc[i] += re[k] * re[k] + im[k] * im[k]; }
+        __syncthreads();
+    }
+    double ls = 0;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int k = k0 + tid + i * 256;
+        if (k <= k1) {
+            double psd = (double)acc[i] / ((double)c.nseg * w2);
+            if (k != nfft / 2) psd *= 2.0;                     // one-sided: Nyquist bin is not doubled
+            ls += log(psd / 2.0);
+        }
+    }
+    ls = block_sum(ls, red);
+    return sqrt(exp(ls / (double)nb));
+}
+
+// estimate_time_constant(y, 1, sn): returns g, or a negative flag (-2) when |g| > 1
+__device__ double est_g(const float *y, double shift, int T, double sn, double *red) {
+    const int tid = threadIdx.x;
+    double m = 0;
+    for (int t = tid; t < T; t += 256) m += (double)y[t] - shift;
+    m = block_sum(m, red) / T;
+    double xc[7];
+    for (int k = 0; k <= 6; ++k) {
+        double s = 0;
+        for (int t = tid; t + k < T; t += 256) s += ((double)y[t + k] - shift - m) * ((double)y[t] - shift - m);
+        xc[k] = block_sum(s, red) / T;
+    }
+    double num = 0, den = 0;
+    for (int i = 0; i < 6; ++i) { const double a = xc[i] - (i == 0 ? sn * sn : 0.0); num += a * xc[i + 1]; den += a * a; }
+    double g = num / den;
+    if (fabs(g) > 1.0) return -2.0;
+    if (g < 0) g = 0.15;
+    return g;
+}
+
+struct Pools { double *v, *w; int *t, *l; int n; };
+
+// oasisAR1 on lane 0: left-to-right pool stack.  Input pools: singletons of (y - b) when `warm` is 0, else the
+// current pool list (v, w recomputed by the caller).  gl = g^l is carried multiplicatively.
+__device__ void oasis_seq(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, int warm) {
+    const int nin = warm ? P.n : T;
+    // the stack is built in place: output index <= input index, so reading input i never sees an overwritten slot
+    double cv, cw, cgl; int ct, cl;
+    if (warm) { cv = P.v[0]; cw = P.w[0]; ct = P.t[0]; cl = P.l[0]; cgl = pow(g, (double)cl); }
+    else { cv = ((double)y[0] - bsub) - lam * (1 - g); if (T == 1) cv = ((double)y[0] - bsub) - lam; cw = 1.0; ct = 1; cl = 1; cgl = g; }
+    int top = 0;                                  // number of pools already on the stack (below cur)
+    double crat = cv / cw;
+    for (int i = 1; i < nin; ++i) {
+        double nv, nw; int nt, nl; double ngl;
+        if (warm) { nv = P.v[i]; nw = P.w[i]; nt = P.t[i]; nl = P.l[i]; ngl = pow(g, (double)nl); }
+        else { nv = ((double)y[i] - bsub) - (i == T - 1 ? lam : lam * (1 - g)); nw = 1.0; nt = i + 1; nl = 1; ngl = g; }
+        if (nv / nw >= crat * cgl + smin) {       // oasisAR1.m:64-65: no violation, advance
+            P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl; ++top;
+            cv = nv; cw = nw; ct = nt; cl = nl; cgl = ngl; crat = cv / cw;
+            continue;
+        }
+        cv += nv * cgl; cw += nw * cgl * cgl; cl += nl; cgl *= ngl; crat = cv / cw;      // :74-76 merge
+        while (top > 0) {                          // :83-95 backtrack
+            const double pv = P.v[top - 1], pw = P.w[top - 1]; const int pl = P.l[top - 1];
+            const double pgl = pow(g, (double)pl);
+            const double lim = pv / pw * pgl;
+            if (!(crat < (lim > 0.0 ? lim : 0.0) + smin)) break;
+            cv = pv + cv * pgl; cw = pw + cw * pgl * pgl; ct = P.t[top - 1]; cl = pl + cl; cgl = pgl * cgl; crat = cv / cw;
+            --top;
+        }
+    }
+    P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
+    P.n = top + 1;
+}
+
+// split the pools into tasks of <= 64 samples (lane 0)
+__device__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
+    int nt = 0;
+    for (int p = 0; p < P.n; ++p)
+        for (int off = 0; off < P.l[p]; off += 64) {
+            io.tk_pool[base2 + nt] = p; io.tk_off[base2 + nt] = off;
+            io.tk_len[base2 + nt] = P.l[p] - off < 64 ? P.l[p] - off : 64; ++nt;
+        }
+    return nt;
+}
+
+// per-pool numerators num_p = sum_j yp(t_p + j) g^j, deterministic (task partials, then a per-pool ordered sum)
+__device__ void pool_numerators(const float *y, double bsub, double lam, double g, const Pools &P, const DeconvIO &io, int64_t base2,
+                                int ntask, double *num /* >= P.n, global */) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < ntask; k += 256) {
+        const int p = io.tk_pool[base2 + k], off = io.tk_off[base2 + k], len = io.tk_len[base2 + k];
+        const int t0 = P.t[p] - 1 + off;
+        double gj = pow(g, (double)off), s = 0;
+        for (int j = 0; j < len; ++j) { s += (((double)y[t0 + j] - bsub) - lam * (1 - g)) * gj; gj *= g; }
+        io.tk_val[base2 + k] = s;
+    }
+    __syncthreads();
+    for (int k = tid; k < ntask; k += 256) {
+        if (io.tk_off[base2 + k] != 0) continue;                 // first task of its pool sums the pool's tasks in order
+        const int p = io.tk_pool[base2 + k];
+        double s = 0;
+        for (int q = k; q < ntask && io.tk_pool[base2 + q] == p; ++q) s += io.tk_val[base2 + q];
+        num[p] = s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double hh_of(double g, int l) {       // cumsum(h.*h)(l) = sum_{j<l} g^(2j)
+    double s = 0, q = 1.0; const double g2 = g * g;
+    if (l > 512) return (1.0 - pow(g2, (double)l)) / (1.0 - g2);
+    for (int j = 0; j < l; ++j) { s += q; q *= g2; }
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[8];
+    __shared__ int sh_i[4];
+    const int tid = threadIdx.x, T = c.T;
+    const int slot = blockIdx.x, k = io.list[slot];
+    float *y = sm;                                  // T raw samples (fp32), persistent
+    float *scr = sm + ((T + 3) & ~3);               // scratch: sort buffer P2 | FFT re, im (2*nfft)
+    const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
+    Pools P; P.v = io.pv + base; P.w = io.pw + base; P.t = io.pt + base; P.l = io.pl + base; P.n = 0;
+    double *num = io.pnum + base;                   // per-pool numerators
+
+    // ---- raw trace into LDS; HALS: ck_raw = C(k,:) + (U(k,:) - V(k,:)*C)/aa(k)  (HALS_temporal.m:62) ----
+    float *ck = io.C + (int64_t)k * io.ldc;
+    if (c.hals) {
+        const float a = io.aa[k];
+        const int n0 = io.nptr[k], n1 = io.nptr[k + 1];
+        for (int t = tid; t < T; t += 256) {
+            float vc = 0.f;
+            for (int j = n0; j < n1; ++j) vc = fmaf(io.nval[j], io.C[(int64_t)io.nidx[j] * io.ldc + t], vc);
+            y[t] = ck[t] + (io.U[(int64_t)k * io.ldc + t] - vc) / a;
+        }
+    } else {
+        const float *src = io.Craw + (int64_t)k * io.ldc;
+        for (int t = tid; t < T; t += 256) y[t] = src[t];
+    }
+    __syncthreads();
+    // NaN guard of deconvTemporal.m:37-40
+    int bad = 0;
+    for (int t = tid; t < T; t += 256) bad |= !(y[t] == y[t]);
+    bad = __syncthreads_or(bad);
+    if (bad) {
+        for (int t = tid; t < T; t += 256) { ck[t] = 0.f; io.S[(int64_t)k * io.ldc + t] = 0.f; if (io.Craw) io.Craw[(int64_t)k * io.ldc + t] = 0.f; }
+        return;
+    }
+    // ---- bitonic sort of a copy (median of HALS_temporal.m:78, quantile of foopsi_oasisAR1.m:93) ----
+    for (int i = tid; i < c.P2; i += 256) scr[i] = i < T ? y[i] : INFINITY;
+    __syncthreads();
+    for (int kk = 2; kk <= c.P2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < c.P2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float a = scr[i], b = scr[ixj];
+                    const bool up = (i & kk) == 0;
+                    if ((a > b) == up) { scr[i] = b; scr[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    double bsub = 0.0;                               // everything subtracted from the raw trace so far
+    const double q15pos = 0.15 * T - 0.5;
+    double q15;
+    { const int qi = (int)floor(q15pos);
+      q15 = q15pos <= 0 ? (double)scr[0] : (q15pos >= T - 1 ? (double)scr[T - 1] : (double)scr[qi] + (q15pos - qi) * ((double)scr[qi + 1] - (double)scr[qi])); }
+    if (c.hals) {
+        const float med = 0.5f * (scr[(T - 1) / 2] + scr[T / 2]);
+        double s = 0, n = 0;
+        for (int t = tid; t < T; t += 256) if (y[t] < med) { s += y[t]; n += 1; }
+        s = block_sum(s, red); n = block_sum(n, red);
+        bsub = s / n;                                // b = mean(ck_raw(ck_raw < median(ck_raw)))
+    }
+    __syncthreads();
+    // ---- noise level (GetSn on the raw trace: HALS_temporal.m:79, deconvTemporal.m:45) ----
+    const double sn = get_sn(y, c, scr, scr + c.nfft, red);
+    // ---- time constant (deconvolveCa.m:73-89) ----
+    double g = (double)io.pars[k];
+    if (g == 0.0) {
+        g = est_g(y, bsub, T, sn, red);
+        if (g < -1.0) {                              // no stable AR(1): c = s = 0, pars = 0
+            for (int t = tid; t < T; t += 256) {
+                const float raw = (float)((double)y[t] - bsub);
+                ck[t] = raw;                         // "if sum(abs(ck))==0, ck = ck_raw" (HALS_temporal.m:95-97, deconvTemporal.m:53-55)
+                if (!c.hals || c.last) { io.S[(int64_t)k * io.ldc + t] = 0.f; io.Craw[(int64_t)k * io.ldc + t] = raw; }
+            }
+            if (tid == 0) { io.pars[k] = 0.f; io.sn_out[k] = (float)sn; io.b_out[k] = 0.f; }
+            return;
+        }
+    }
+    const double smin = c.smin_opt < 0 ? -c.smin_opt * sn : c.smin_opt;       // deconvolveCa.m:116-118
+    const double lam = c.lam;
+    double mean_y = 0;
+    for (int t = tid; t < T; t += 256) mean_y += (double)y[t] - bsub;
+    mean_y = block_sum(mean_y, red) / T;
+
+    // ---- foopsi_oasisAR1.m:82-117 ----
+    double b = c.optimize_b ? (q15 - bsub) : 0.0;    // :93 quantile(y, .15) of the baseline-subtracted trace
+    int optimize_g = c.optimize_g;
+    int ntask = 0;
+    if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+    __syncthreads();
+    P.n = sh_i[0]; ntask = sh_i[1];
+    const int niter = c.optimize_b ? c.maxIter : (optimize_g ? 1 : 0);
+    for (int it = 0; it < niter; ++it) {
+        // sum of the current solution: c(t) = max(0, v/w) g^j on each pool
+        double ssol = 0;
+        for (int q = tid; q < ntask; q += 256) {
+            const int p = io.tk_pool[base2 + q], off = io.tk_off[base2 + q], len = io.tk_len[base2 + q];
+            const double r = P.v[p] / P.w[p];
+            double gj = pow(g, (double)off) * (r > 0 ? r : 0.0);
+            for (int j = 0; j < len; ++j) { ssol += gj; gj *= g; }
+        }
+        ssol = block_sum(ssol, red);
+        if (c.optimize_b) b = mean_y - ssol / T;     // :98 b = mean(y - solution)
+        if (!optimize_g) break;                      // :113-115
+        const double g0 = g;
+        if (g > c.gmax) {                            // :104-108
+            const double sn2 = get_sn(y, c, scr, scr + c.nfft, red);
+            const double g2 = est_g(y, bsub, T, sn2, red);
+            if (g2 >= -1.0) g = g2;
+            if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+            __syncthreads();
+            P.n = sh_i[0]; ntask = sh_i[1];
+            break;
+        }
+        // ---- update_g (:122-180): Brent's fminbnd of rss(g) on [0,1] ----
+        double sumy2 = 0;
+        for (int t = tid; t < T; t += 256) { const double v = (double)y[t] - (bsub + b); sumy2 += v * v; }
+        sumy2 = block_sum(sumy2, red);
+        auto rss = [&](double gg) -> double {
+            pool_numerators(y, bsub + b, lam, gg, P, io, base2, ntask, num);
+            double s = 0;
+            for (int p = tid; p < P.n; p += 256) { const double nm = num[p]; if (nm > 0) s += nm * nm / hh_of(gg, P.l[p]); }
+            s = block_sum(s, red);
+            return sumy2 - s;                        // ||y - c||^2 with c = max(num/hh, 0) h on every pool (lam = 0 form)
+        };
+        double xf, glast;
+        {   // Brent (fminbnd), TolX = 1e-4; all threads run the same scalar code
+            const double seps = 1.4901161193847656e-08, cgold = 0.3819660112501051, tol = 1e-4;
+            double a = 0.0, bb = 1.0;
+            double v = a + cgold * (bb - a), w = v; xf = v;
+            double d = 0.0, e = 0.0, x = xf;
+            double fx = rss(x); glast = x;
+            double fv = fx, fw = fx;
+            double xm = 0.5 * (a + bb), tol1 = seps * fabs(xf) + tol / 3.0, tol2 = 2.0 * tol1;
+            int iter = 0;
+            while (fabs(xf - xm) > (tol2 - 0.5 * (bb - a)) && iter < 500) {
+                ++iter;
+                bool gs = true;
+                if (fabs(e) > tol1) {
+                    gs = false;
+                    double r = (xf - w) * (fx - fv), q = (xf - v) * (fx - fw), pq = (xf - v) * q - (xf - w) * r;
+                    q = 2.0 * (q - r);
+                    if (q > 0.0) pq = -pq;
+                    q = fabs(q); r = e; e = d;
+                    if (fabs(pq) < fabs(0.5 * q * r) && pq > q * (a - xf) && pq < q * (bb - xf)) {
+                        d = pq / q; x = xf + d;
+                        if ((x - a) < tol2 || (bb - x) < tol2) { const double si = (xm - xf) >= 0 ? 1.0 : -1.0; d = tol1 * si; }
+                    } else gs = true;
+                }
+                if (gs) { e = xf >= xm ? a - xf : bb - xf; d = cgold * e; }
+                const double si = d >= 0 ? 1.0 : -1.0;
+                x = xf + si * fmax(fabs(d), tol1);
+                const double fu = rss(x); glast = x;
+                if (fu <= fx) { if (x >= xf) a = xf; else bb = xf; v = w; fv = fw; w = xf; fw = fx; xf = x; fx = fu; }
+                else {
+                    if (x < xf) a = x; else bb = x;
+                    if (fu <= fw || w == xf) { v = w; fv = fw; w = x; fw = fu; }
+                    else if (fu <= fv || v == xf || v == w) { v = x; fv = fu; }
+                }
+                xm = 0.5 * (a + bb); tol1 = seps * fabs(xf) + tol / 3.0; tol2 = 2.0 * tol1;
+            }
+        }
+        g = xf;
+        // warm-started pools: v = yp' * h(g), w = cumsum(h_last.^2)(l) with h_last from the LAST rss_g call (:155-161, sic)
+        pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, num);
+        for (int p = tid; p < P.n; p += 256) { P.v[p] = num[p]; P.w[p] = hh_of(glast, P.l[p]); }
+        __syncthreads();
+        if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 1); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+        __syncthreads();
+        P.n = sh_i[0]; ntask = sh_i[1];
+        if (fabs(g - g0) / g0 < 1e-3) optimize_g = 0;            // :110-112
+        if (!c.optimize_b) break;
+    }
+    // ---- solution (oasisAR1.m:100-109) and outputs ----
+    float *so = io.S + (int64_t)k * io.ldc;
+    const bool wr = !c.hals || c.last;
+    double sabs = 0;
+    for (int q = tid; q < ntask; q += 256) {
+        const int p = io.tk_pool[base2 + q], off = io.tk_off[base2 + q], len = io.tk_len[base2 + q];
+        const double r = P.v[p] / P.w[p];
+        double gj = pow(g, (double)off) * (r > 0 ? r : 0.0);
+        const int t0 = P.t[p] - 1 + off;
+        for (int j = 0; j < len; ++j) { double cv = gj; if (!(cv == cv) || isinf(cv)) cv = 0.0; scr[t0 + j] = (float)cv; sabs += fabs(cv); gj *= g; }
+    }
+    sabs = block_sum(sabs, red);
+    __syncthreads();
+    const double btot = bsub + b;                     // HALS: ck_raw - b - tmp_options.b ; deconvTemporal: ck_raw - options.b
+    for (int t = tid; t < T; t += 256) {
+        const float raw = (float)((double)y[t] - btot);
+        ck[t] = sabs == 0.0 ? raw : scr[t];
+        if (wr) { so[t] = 0.f; io.Craw[(int64_t)k * io.ldc + t] = raw; }
+    }
+    __syncthreads();
+    if (wr)
+        for (int p = 1 + tid; p < P.n; p += 256) {    // s(t_p) = c(t_p) - g c(t_p - 1) at pool starts
+            const int t0 = P.t[p] - 1;
+            so[t0] = (float)((double)scr[t0] - g * (double)scr[t0 - 1]);
+        }
+    if (tid == 0) { io.pars[k] = (float)g; io.sn_out[k] = (float)sn; io.b_out[k] = (float)b; }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------
+struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list; };
+
+int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg &c, size_t &shmem) {
+    if (!o) return fail(CNMFE_EINVAL, "null deconvolution options");
+    if (o->type != 1 || o->method != 1) return fail(CNMFE_EUNSUPPORTED, "only type 'ar1' / method 'foopsi' is built (demo_large_data_1p.m:38-43)");
+    if (T < 64 || T > 32768) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= 32768 frames (got %lld)", (long long)T);
+    c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
+    c.L = (int)(T / 4.5); c.nov = c.L / 2;
+    c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
+    c.nseg = (int)((T - c.nov) / (c.L - c.nov));
+    c.maxIter = in_sweep ? 20 : (o->maxIter > 0 ? o->maxIter : 10);          // HALS_temporal.m:92 passes 'maxIter', 20
+    c.optimize_b = o->optimize_b; c.optimize_g = o->optimize_pars;
+    c.smin_opt = o->smin; c.lam = o->lambda; c.gmax = exp(-1.0 / (o->max_tau > 0 ? o->max_tau : 100.0));
+    c.hals = in_sweep; c.last = 0;
+    if (o->lambda != 0.0) return fail(CNMFE_EUNSUPPORTED, "lambda != 0 is not built");
+    size_t scr = std::max<size_t>((size_t)c.P2, 2 * (size_t)c.nfft);
+    scr = std::max<size_t>(scr, (size_t)T);
+    shmem = ((((size_t)T + 3) & ~size_t(3)) + scr) * sizeof(float);
+    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the deconvolution kernel's LDS", (long long)T);
+    return 0;
+}
+
+int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const int *d_list, int n, DeconvScratch &s) {
+    if (n <= 0) return 0;
+    const int64_t T = c.T;
+    RET(s.pv.ensure((size_t)n * T * 8)); RET(s.pw.ensure((size_t)n * T * 8));
+    RET(s.pt.ensure((size_t)n * T * 4)); RET(s.pl.ensure((size_t)n * T * 4));
+    RET(s.tkp.ensure((size_t)n * 2 * T * 4)); RET(s.tko.ensure((size_t)n * 2 * T * 4)); RET(s.tkl.ensure((size_t)n * 2 * T * 4));
+    RET(s.tkv.ensure((size_t)n * 2 * T * 8)); RET(s.pnum.ensure((size_t)n * T * 8));
+    io.list = d_list;
+    io.pv = s.pv.as<double>(); io.pw = s.pw.as<double>(); io.pt = s.pt.as<int>(); io.pl = s.pl.as<int>();
+    io.tk_pool = s.tkp.as<int>(); io.tk_off = s.tko.as<int>(); io.tk_len = s.tkl.as<int>(); io.tk_val = s.tkv.as<double>(); io.pnum = s.pnum.as<double>();
+    if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv, dim3(n), dim3(256), shmem, c, io);
+    return 0;
+}
+
+int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64_t T, int K, int maxIter, const std::vector<std::vector<int>> &levels,
+                           const int *dLvl, const std::vector<int> &off, float *dC, float *dCraw, float *dS, int64_t ldc, const float *dU,
+                           const int *dNptr, const int *dNidx, const float *dNval, const float *dAa, float *dPars, float *dSn) {
+    DeconvCfg c; size_t shmem;
+    RET(deconv_setup(dopts, T, 1, c, shmem));
+    DeconvScratch scr; DevBuf dB;
+    RET(dB.ensure((size_t)K * sizeof(float)));
+    DeconvIO io;
+    io.C = dC; io.Craw = dCraw; io.S = dS; io.ldc = ldc; io.U = dU; io.nptr = dNptr; io.nidx = dNidx; io.nval = dNval; io.aa = dAa;
+    io.pars = dPars; io.sn_out = dSn; io.b_out = dB.as<float>();
+    for (int it = 0; it < maxIter; ++it) {
+        c.last = it == maxIter - 1;
+        for (size_t l = 0; l < levels.size(); ++l)
+            RET(deconv_launch(ctx, c, shmem, io, dLvl + off[l], (int)levels[l].size(), scr));
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,
+                   float *C_out, float *S_out, float *pars_out, float *sn_out) {
+    DeconvCfg c; size_t shmem;
+    RET(deconv_setup(opts, T, 0, c, shmem));
+    DevBuf dCraw, dC, dS, dPars, dSn, dB, dList; DeconvScratch scr;
+    int64_t ldc;
+    RET(upload_traces(ctx, dCraw, C_raw, K, T, c_order, &ldc));
+    RET(dC.ensure((size_t)K * ldc * sizeof(float))); RET(dS.ensure((size_t)K * ldc * sizeof(float)));
+    CK(hipMemsetAsync(dC.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    RET(dPars.ensure((size_t)K * sizeof(float))); RET(dSn.ensure((size_t)K * sizeof(float))); RET(dB.ensure((size_t)K * sizeof(float)));
+    CK(hipMemsetAsync(dPars.p, 0, (size_t)K * sizeof(float), ctx->stream));         // fresh time-constant estimate for every trace
+    CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
+    std::vector<int> list(K);
+    for (int k = 0; k < K; ++k) list[k] = k;
+    RET(to_dev(ctx, dList, list.data(), list.size()));
+    DeconvIO io;
+    io.C = dC.as<float>(); io.Craw = dCraw.as<float>(); io.S = dS.as<float>(); io.ldc = ldc;
+    io.U = nullptr; io.nptr = nullptr; io.nidx = nullptr; io.nval = nullptr; io.aa = nullptr;
+    io.pars = dPars.as<float>(); io.sn_out = dSn.as<float>(); io.b_out = dB.as<float>();
+    // batches bound the pool/task scratch (7 arrays of T per trace)
+    const int batch = 512;
+    for (int k0 = 0; k0 < K; k0 += batch)
+        RET(deconv_launch(ctx, c, shmem, io, dList.as<int>() + k0, std::min(batch, K - k0), scr));
+    RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));
+    RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw, K, T, c_order));
+    RET(download_traces(ctx, dS.as<float>(), ldc, S_out, K, T, c_order));
+    if (pars_out) CK(hipMemcpyAsync(pars_out, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // namespace cnmfe

@@ -403,8 +403,15 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     return 0;
 }
 
+// implemented in deconv.hip
+struct DeconvCfg; struct DeconvIO; struct DeconvScratch;
+int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64_t T, int K, int maxIter, const std::vector<std::vector<int>> &levels,
+                           const int *dLvl, const std::vector<int> &off, float *dC, float *dCraw, float *dS, int64_t ldc, const float *dU,
+                           const int *dNptr, const int *dNidx, const float *dNval, const float *dAa, float *dPars, float *dSn);
+
 int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
-                 const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out) {
+                 const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out,
+                 const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out) {
     const int64_t T = P->T, d = P->d, nnz = A_colptr[K];
     if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(A) too large");
     DevBuf &dC = ctx->tmp[0];
@@ -455,10 +462,25 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     std::vector<int> flat, off;
     for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
     RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
-    for (int it = 0; it < maxIter; ++it)
-        for (size_t l = 0; l < g.levels.size(); ++l)
-            LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
-                   dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dU.as<float>(), dC.as<float>(), dCraw.as<float>(), ldc, T);
+    if (!dopts) {
+        for (int it = 0; it < maxIter; ++it)
+            for (size_t l = 0; l < g.levels.size(); ++l)
+                LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
+                       dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dU.as<float>(), dC.as<float>(), dCraw.as<float>(), ldc, T);
+    } else {
+        DevBuf dS, dPars, dSn;
+        RET(dS.ensure((size_t)K * ldc * sizeof(float)));
+        CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));                 // S = zeros(K,T)  (:55)
+        RET(to_dev(ctx, dPars, kernel_pars, (size_t)K));
+        RET(dSn.ensure((size_t)K * sizeof(float)));
+        CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
+        RET(temporal_deconv_sweeps(ctx, dopts, T, K, maxIter, g.levels, dLvl.as<int>(), off, dC.as<float>(), dCraw.as<float>(), dS.as<float>(), ldc,
+                                   dU.as<float>(), dNptr.as<int>(), dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dPars.as<float>(), dSn.as<float>()));
+        RET(download_traces(ctx, dS.as<float>(), ldc, S_out, K, T, c_order));
+        CK(hipMemcpyAsync(kernel_pars, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
     RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));
     RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw_out, K, T, c_order));
     if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));

@@ -163,6 +163,42 @@ class Engine:
                                           int(maxIter), _p(Cout, L.f32p), _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Cout, Craw, aa
 
+    @staticmethod
+    def _dopts(deconv_options, maxIter=10):
+        """deconv_options struct of demo_large_data_1p.m:38-43 -> cnmfe_deconv_opts"""
+        o = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+        o.update(deconv_options or {})
+        if str(o["type"]).lower() != "ar1" or str(o["method"]).lower() != "foopsi":
+            raise NotImplementedError("only deconv_options type='ar1', method='foopsi' is built")
+        return L.DeconvOpts(1, 1, float(o["smin"]), float(o.get("lambda", 0.0)), float(o["max_tau"]),
+                            int(bool(o["optimize_b"])), int(bool(o["optimize_pars"])), int(o.get("maxIter", maxIter)))
+
+    def hals_temporal_deconv(self, pid, A_patch, C_patch, maxIter, deconv_options, kernel_pars=None):
+        """[C, C_raw, results_deconv] = HALS_temporal(Y, A, C, maxIter, deconv_options): returns
+        (C, C_raw, S, sn, kernel_pars, aa)."""
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_patch, info["d"])
+        Cm = _traces(C_patch, K, info["T"])
+        Cout = np.empty_like(Cm); Craw = np.empty_like(Cm); S = np.empty_like(Cm)
+        aa = np.empty(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
+        pars = np.zeros(K, dtype=np.float32) if kernel_pars is None else np.ascontiguousarray(kernel_pars, dtype=np.float32).copy()
+        opts = self._dopts(deconv_options)
+        L.check(L.lib.cnmfe_hals_temporal_deconv(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+                                                 int(maxIter), C.byref(opts), _p(pars, L.f32p), _p(Cout, L.f32p), _p(Craw, L.f32p),
+                                                 _p(S, L.f32p), _p(sn, L.f32p), _p(aa, L.f32p)))
+        return Cout, Craw, S, sn, pars, aa
+
+    def deconv_temporal(self, C_raw, deconv_options):
+        """obj.deconvTemporal(): returns (C, C_raw, S, kernel_pars, sn)"""
+        Craw = np.ascontiguousarray(C_raw, dtype=np.float32).copy()
+        K, T = Craw.shape
+        Cout = np.empty_like(Craw); S = np.empty_like(Craw)
+        pars = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
+        opts = self._dopts(deconv_options)
+        L.check(L.lib.cnmfe_deconv_temporal(self._ctx, K, T, _p(Craw, L.f32p), L.ROWMAJOR, C.byref(opts), _p(Cout, L.f32p), _p(S, L.f32p),
+                                            _p(pars, L.f32p), _p(sn, L.f32p)))
+        return Cout, Craw, S, pars, sn
+
     def post_process_spatial(self, A_full, d1, d2):
         K, cp, ri, va = _csc(A_full, d1 * d2)
         keep = np.zeros(cp[-1], dtype=np.uint8)

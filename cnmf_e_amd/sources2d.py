@@ -46,7 +46,9 @@ class Options:
     max_size: float = 8.0            # :52
     dist: float = 3.0                # :53
     maxIter: int = 5                 # :36
-    deconv_flag: bool = False        # :101 (the deconvolution branch is not built yet)
+    deconv_flag: bool = False        # :101
+    deconv_options: dict = field(default_factory=lambda: {"type": "ar1", "method": "foopsi", "smin": -5.0,
+                                                          "optimize_pars": True, "optimize_b": True, "max_tau": 100.0})   # demo_large_data_1p.m:38-43
     spatial_constraints: dict = field(default_factory=lambda: {"circular": False, "connected": True})   # :116
 
 
@@ -257,6 +259,24 @@ class Sources2D:
         self.b0_new = (self.ymean_full() - np.asarray(self.A @ self.C.mean(axis=1, dtype=np.float64)).ravel()) \
             .reshape(v.d1, v.d2, order="F")                               # update_spatial_parallel.m:349
 
+    def deconvTemporal(self):
+        """@Sources2D/deconvTemporal.m:29-105: deconvolve every row of C_raw again (fresh time constants); sets
+        C, C_raw, S, P.kernel_pars, P.neuron_sn.  Rows are sharded over ranks and all-reduced when distributed."""
+        K = self.C_raw.shape[0]
+        if K == 0:
+            return self.C_raw.copy()
+        v = self.video
+        rows = np.arange(K)[v.rank::v.world_size] if (self.dist is not None and v.world_size > 1) else np.arange(K)
+        C = np.zeros_like(self.C_raw); Craw = np.zeros_like(self.C_raw); S = np.zeros_like(self.C_raw)
+        kp = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
+        if rows.size:
+            C[rows], Craw[rows], S[rows], kp[rows], sn[rows] = self.engine.deconv_temporal(self.C_raw[rows], self.options.deconv_options)
+        if rows.size != K:
+            C, Craw, S, kp, sn = (self._allreduce(x) for x in (C, Craw, S, kp, sn))
+        self.C, self.C_raw, self.S = C, Craw, S
+        self.P["kernel_pars"], self.P["neuron_sn"] = kp, sn
+        return C
+
     # -- background -------------------------------------------------------------------
     def update_background_parallel(self, use_parallel=True):
         """@Sources2D/update_background_parallel.m:121-146,176-230,311-317 (ring model, bg_ssub = 1)."""
@@ -357,8 +377,6 @@ class Sources2D:
         if not use_c_hat:
             raise NotImplementedError("fast_temporal (use_c_hat=false, :314-337) is not used by the demo and not built")
         v, o = self.video, self.options
-        if o.deconv_flag:
-            raise NotImplementedError("deconv_flag=true (OASIS inside the sweep, HALS_temporal.m:70-104) is not built yet")
         K, T = self.C.shape
         A_csr = self.A.tocsr()
         Aprev_csr = self.A_prev.tocsr()
@@ -376,7 +394,10 @@ class Sources2D:
             C_prev_b = self.C_prev[indp] if indp.size else None
             self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                     # :149-152
             A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
-            _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)       # :180-181
+            if o.deconv_flag:                                                                         # :106-110
+                _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)
+            else:
+                _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)   # :180-181
             acc[ind] += C_raw_p * aa_p[:, None]                                                      # :274
             aa_tot[ind] += aa_p                                                                      # :275
         if self.dist is not None and v.world_size > 1:                    # the overlap-region stitch: ONE all-reduce
@@ -384,7 +405,11 @@ class Sources2D:
             acc = packed[:K * T].reshape(K, T); aa_tot = packed[K * T:].astype(np.float64)
         aa_tot[aa_tot == 0] = 1                                                                       # :279
         C_raw = acc / aa_tot[:, None].astype(np.float32)                                           # :280
-        C_raw = C_raw - C_raw.min(axis=1, keepdims=True)                                             # :285
-        self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
-        self.C = self.C_raw.copy()                                                                    # :286
+        if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
+            self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
+            self.C = self.deconvTemporal()
+        else:
+            C_raw = C_raw - C_raw.min(axis=1, keepdims=True)                                         # :285
+            self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
+            self.C = self.C_raw.copy()                                                                # :286
         self._update_b0_new()                                                                         # :291-295

@@ -128,6 +128,32 @@ int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
                         const int32_t *A_rowidx, const float *A_val, const float *C_in, int c_order,
                         int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out);
 
+/* ---- T4/T6: deconvolution (options.deconv_flag = true) ---------------------------------------
+ * deconv_options of demos/demo_large_data_1p.m:38-43; only type 'ar1' + method 'foopsi' is built. */
+typedef struct cnmfe_deconv_opts {
+    int32_t type;            /* 1 = 'ar1' */
+    int32_t method;          /* 1 = 'foopsi' */
+    double  smin;            /* negative: |smin| * noise level (deconvolveCa.m:116-118) */
+    double  lambda;          /* must be 0 */
+    double  max_tau;         /* gmax = exp(-1/max_tau) (deconvolveCa.m:119) */
+    int32_t optimize_b;
+    int32_t optimize_pars;
+    int32_t maxIter;         /* deconvTemporal only (default 10); HALS_temporal forces 20 (HALS_temporal.m:92) */
+} cnmfe_deconv_opts;
+
+/* [C, C_raw, results_deconv] = HALS_temporal(Y, A, C, maxIter, deconv_options)   utilities/HALS_temporal.m:70-104
+ * (the deconvolution branch: per row GetSn + deconvolveCa inside the Gauss-Seidel sweep).
+ * kernel_pars[K] in/out (0 = not yet estimated), S_out / sn_out receive results_deconv.S / .sn. */
+int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
+                               const int32_t *A_rowidx, const float *A_val, const float *C_in, int c_order,
+                               int32_t maxIter, const cnmfe_deconv_opts *opts, float *kernel_pars,
+                               float *C_out, float *C_raw_out, float *S_out, float *sn_out, float *aa_out);
+/* obj.deconvTemporal()  (@Sources2D/deconvTemporal.m:29-105): every row of C_raw (K x T, in/out: the fitted
+ * baseline is subtracted) is deconvolved with a fresh time-constant estimate. */
+int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order,
+                          const cnmfe_deconv_opts *opts, float *C_out, float *S_out,
+                          float *kernel_pars_out, float *sn_out);
+
 /* ---- S6: post_process_spatial (connected = true, circular = false)
  * @Sources2D/post_process_spatial.m:19-32 -> endoscope/connectivity_constraint.m:1-18.
  * A is the whole-FOV d1*d2 x K CSC; keep[nnz] receives 1 for entries that survive. */

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--variants", default="0,1,2,3,4")
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--alg", default="hals")
+    ap.add_argument("--deconv", action="store_true")
     a = ap.parse_args()
     import torch
     from cnmf_e_amd import synth
@@ -38,7 +39,7 @@ def main():
     video.upload_block_device((0, 0), Yd.data_ptr())
     del Yd
     torch.cuda.empty_cache()
-    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=5), f.A_init, f.C_init, f.sn)
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=5, deconv_flag=a.deconv), f.A_init, f.C_init, f.sn)
     eng.profile(True)
     # R1 variant sweep (spatial-call flavour: no A_prev; temporal-call flavour: all neurons)
     bytes_r1 = 4.0 * d1 * d2 * T * 2

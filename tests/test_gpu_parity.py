@@ -284,3 +284,62 @@ def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
             assert rel(W.data, Wref.data) <= (1e-4 if gram_mode == 1 else 1e-3), rel(W.data, Wref.data)
     finally:
         eng.set_option("debug", 0); eng.set_option("gram_mode", 2)
+
+
+def _deconv_case(eng, T=1500, K=5):
+    c = Case(eng, 40, 36, T, K, 5, 29, None, min_sep=5)
+    pid = 0
+    eng.fit_ring_model(pid, None, None)
+    ysig = eng.residual(pid, None, None, want=True).T.astype(np.float64)
+    A_p = c.f.A_true.tocsc().astype(np.float32)
+    return c, pid, ysig, A_p
+
+
+def test_deconv_temporal_parity(eng):
+    """obj.deconvTemporal(): GetSn + estimate_time_constant + AR(1) FOOPSI per trace vs the float64 oracle.
+    OASIS is a discrete active-set method: a pool boundary can move by a frame when a comparison is within
+    rounding, so traces are compared in norm and spikes by matched events."""
+    import oasis_oracle as oo
+    c, pid, ysig, A_p = _deconv_case(eng)
+    _, Craw0, _ = eng.hals_temporal(pid, A_p, c.f.C_init, 3)
+    Craw0 = Craw0 + 0.7                                   # give the traces a baseline to find
+    Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Craw0, None)
+    Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Craw0.astype(np.float64))
+    assert np.allclose(sng, snr, rtol=2e-4)
+    assert np.allclose(parsg, parsr, atol=2e-3), (parsg, parsr)
+    for k in range(Cg.shape[0]):
+        assert rel(Cg[k], Cr[k]) <= 2e-2, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 1e-2
+        eg, er = np.nonzero(Sg[k] > 0)[0], np.nonzero(Sr[k] > 0)[0]
+        assert abs(len(eg) - len(er)) <= max(2, 0.05 * len(er)), (k, len(eg), len(er))
+
+
+def test_hals_temporal_deconv_parity(eng):
+    """the deconvolution branch of HALS_temporal (per-row GetSn + deconvolveCa inside the Gauss-Seidel sweep)"""
+    import oasis_oracle as oo
+    c, pid, ysig, A_p = _deconv_case(eng, T=1200, K=4)
+    Cg, Crawg, Sg, sng, parsg, aa = eng.hals_temporal_deconv(pid, A_p, c.f.C_init, 2, None)
+    Cr, Crawr, Sr, snr, parsr = oo.HALS_temporal_deconv(ysig, A_p.astype(np.float64), c.f.C_init, 2)
+    assert np.allclose(sng, snr, rtol=1e-3)
+    assert np.allclose(parsg, np.array(parsr, dtype=np.float64), atol=3e-3), (parsg, parsr)
+    for k in range(Cg.shape[0]):
+        assert rel(Cg[k], Cr[k]) <= 3e-2, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 2e-2, (k, rel(Crawg[k], Crawr[k]))
+        assert np.corrcoef(Cg[k], c.f.C_true[k])[0, 1] > 0.95
+
+
+def test_method_level_iteration_with_deconvolution(eng):
+    """deconv_flag=true through Sources2D.update_temporal_parallel: runs, recovers the planted traces, S is sparse."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 44, 40, 1000, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=2, deconv_flag=True), f.A_init, f.C_init, f.sn)
+    s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+    assert s.S.shape == s.C.shape and np.all(s.S >= 0)
+    assert (s.S > 0).mean() < 0.05
+    for k in range(K):
+        assert np.corrcoef(s.C[k], f.C_true[k])[0, 1] > 0.9
+    assert np.all((s.P["kernel_pars"] > 0.8) & (s.P["kernel_pars"] < 1.0))
