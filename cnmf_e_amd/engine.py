@@ -128,13 +128,18 @@ class Engine:
                                            L.ROWMAJOR, float(thresh_outlier), int(bool(with_projection)), _p(b0, L.f32p), _p(inf, L.i64p)))
         return b0, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
 
-    def residual(self, pid, A_prev_block=None, C_prev=None, want=False):
+    def residual(self, pid, A_prev_block=None, C_prev=None, want=False, out_dev_ptr=None):
+        """want=True returns Ysig as a (T, d) host array; out_dev_ptr: raw device address of a (T, d) fp32 buffer that
+        receives a device-to-device copy instead."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_prev_block, info["d_b"]) if A_prev_block is not None and A_prev_block.shape[1] else (0, None, None, None)
         Cm = _traces(C_prev, K, info["T"]) if K else None
         out = np.empty((info["T"], info["d"]), dtype=np.float32) if want else None
-        L.check(L.lib.cnmfe_residual(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
-                                     out.ctypes.data_as(C.c_void_p) if want else C.c_void_p(None), L.HOST))
+        if out_dev_ptr is not None:
+            dst, space = C.c_void_p(int(out_dev_ptr)), L.DEVICE
+        else:
+            dst, space = (out.ctypes.data_as(C.c_void_p) if want else C.c_void_p(None)), L.HOST
+        L.check(L.lib.cnmfe_residual(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR, dst, space))
         return out
 
     def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3):

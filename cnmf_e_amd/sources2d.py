@@ -204,8 +204,8 @@ class Sources2D:
             raise ValueError("A must have d1*d2 rows")
         self.C = np.ascontiguousarray(C, dtype=np.float32)
         self.C_raw = self.C.copy()
-        self.A_prev = self.A.copy()
-        self.C_prev = self.C.copy()
+        self.A_prev = self.A          # snapshots: A and C are only ever REPLACED by the update methods, never mutated in place
+        self.C_prev = self.C
         self.P = {"sn": np.asarray(sn, dtype=np.float32).reshape(-1).copy(), "Ymean": {}}
         self.b0_new = None
         self.dist = dist_group
@@ -254,9 +254,36 @@ class Sources2D:
         td.all_reduce(t, group=self.dist)
         return t.cpu().numpy()
 
+    def _cmean(self):
+        """mean(obj.C, 2), cached per C object (K x T can be hundreds of MB when many ranks share one FOV)"""
+        if getattr(self, "_cmean_of", None) is not self.C:
+            self._cmean_val = self.C.mean(axis=1, dtype=np.float64)
+            self._cmean_of = self.C
+        return self._cmean_val
+
+    def _stitch_distributed(self, acc, aa_tot):
+        """C_raw(k,:) = sum_m aa_m(k) C_raw_m(k,:) / sum_m aa_m(k)  (update_temporal_parallel.m:269-280) with ONE
+        all-reduce of [acc ; aa] over the process group; division (and, without deconvolution, the row-minimum
+        subtraction :285) happen on the device the collective ran on."""
+        import torch
+        import torch.distributed as td
+        K, T = acc.shape
+        nccl = td.get_backend(self.dist) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+        buf = torch.empty((K, T + 1), dtype=torch.float32, device=dev)
+        buf[:, :T] = torch.from_numpy(acc).to(dev)
+        buf[:, T] = torch.from_numpy(aa_tot.astype(np.float32)).to(dev)
+        td.all_reduce(buf, group=self.dist)
+        aa = buf[:, T:T + 1].clone()
+        aa[aa == 0] = 1                                                                               # :279
+        C_raw = buf[:, :T] / aa                                                                       # :280
+        if not self.options.deconv_flag:
+            C_raw = C_raw - C_raw.min(dim=1, keepdim=True).values                                     # :285
+        return C_raw.cpu().numpy()
+
     def _update_b0_new(self):
         v = self.video
-        self.b0_new = (self.ymean_full() - np.asarray(self.A @ self.C.mean(axis=1, dtype=np.float64)).ravel()) \
+        self.b0_new = (self.ymean_full() - np.asarray(self.A @ self._cmean()).ravel()) \
             .reshape(v.d1, v.d2, order="F")                               # update_spatial_parallel.m:349
 
     def deconvTemporal(self):
@@ -297,8 +324,8 @@ class Sources2D:
             _, infos[idx] = self.engine.fit_ring_model(v.pid[idx], A_block if A_block.shape[1] else None, C_block,
                                                        o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218
         self.b0_new = self.reconstruct_b0()                                # :315
-        self.A_prev = self.A.copy()                                        # :316
-        self.C_prev = self.C.copy()                                        # :317
+        self.A_prev = self.A                                               # :316 (no copy needed: A, C are replaced, not mutated)
+        self.C_prev = self.C                                               # :317
         return infos
 
     def _first_run(self, idx):
@@ -315,7 +342,7 @@ class Sources2D:
         v, o = self.video, self.options
         if o.search_method != "ellipse":
             raise NotImplementedError("only search_method='ellipse' is built")
-        IND = determine_search_location(self.A, v.d1, v.d2, o.min_size, o.max_size, o.dist)     # :66
+        IND = self._search_location_owned()                                                      # :66
         IND_csr = IND.tocsr()
         A_csr = self.A.tocsr()
         Aprev_csr = self.A_prev.tocsr()
@@ -359,6 +386,32 @@ class Sources2D:
         self.A = self.engine.post_process_spatial(A_, v.d1, v.d2) if o.spatial_constraints.get("connected", True) else A_   # :341
         self._update_b0_new()                                                                        # :347-351
 
+    def _search_location_owned(self):
+        """IND = determine_search_location(obj.A, ...) (:66), evaluated only for the neurons that can reach a patch
+        this rank owns (bounding box of the footprint grown by the largest possible ellipse); all other columns are
+        empty here and belong to other ranks.  Single rank: every neuron."""
+        v, o = self.video, self.options
+        K = self.A.shape[1]
+        if v.world_size == 1:
+            return determine_search_location(self.A, v.d1, v.d2, o.min_size, o.max_size, o.dist)
+        A = self.A.tocsc()
+        reach = int(np.ceil(o.dist * o.max_size)) + 2
+        cand = np.zeros(K, dtype=bool)
+        nzcols = np.nonzero(np.diff(A.indptr) > 0)[0]
+        rr, cc = A.indices % v.d1, A.indices // v.d1
+        starts = A.indptr[nzcols]
+        rmin = np.minimum.reduceat(rr, starts); rmax = np.maximum.reduceat(rr, starts)
+        cmin = np.minimum.reduceat(cc, starts); cmax = np.maximum.reduceat(cc, starts)
+        for idx in v.owned:
+            r0, r1, c0, c1 = [int(x) - 1 for x in v.patch_pos[idx]]
+            hit = (rmax + reach >= r0) & (rmin - reach <= r1) & (cmax + reach >= c0) & (cmin - reach <= c1)
+            cand[nzcols[hit]] = True
+        sel = np.nonzero(cand)[0]
+        sub = determine_search_location(A[:, sel], v.d1, v.d2, o.min_size, o.max_size, o.dist).tocoo()
+        IND = sp.csc_matrix((sub.data, (sub.row, sel[sub.col])), shape=(v.d1 * v.d2, K))
+        IND.sort_indices()
+        return IND
+
     def _gather_sparse(self, A_):
         """all-gather of the per-rank rows of A (disjoint pixel sets, no reduction)."""
         if self.dist is None or self.video.world_size == 1:
@@ -401,15 +454,16 @@ class Sources2D:
             acc[ind] += C_raw_p * aa_p[:, None]                                                      # :274
             aa_tot[ind] += aa_p                                                                      # :275
         if self.dist is not None and v.world_size > 1:                    # the overlap-region stitch: ONE all-reduce
-            packed = self._allreduce(np.concatenate([acc.ravel(), aa_tot.astype(np.float32)]))
-            acc = packed[:K * T].reshape(K, T); aa_tot = packed[K * T:].astype(np.float64)
-        aa_tot[aa_tot == 0] = 1                                                                       # :279
-        C_raw = acc / aa_tot[:, None].astype(np.float32)                                           # :280
+            C_raw = self._stitch_distributed(acc, aa_tot)
+        else:
+            aa_tot[aa_tot == 0] = 1                                                                   # :279
+            C_raw = acc / aa_tot[:, None].astype(np.float32)                                         # :280
         if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.deconvTemporal()
         else:
-            C_raw = C_raw - C_raw.min(axis=1, keepdims=True)                                         # :285
+            if not (self.dist is not None and v.world_size > 1):
+                C_raw = C_raw - C_raw.min(axis=1, keepdims=True)                                     # :285
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
-            self.C = self.C_raw.copy()                                                                # :286
+            self.C = self.C_raw                                                                       # :286
         self._update_b0_new()                                                                         # :291-295
