@@ -389,8 +389,17 @@ static int launch_r1(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid) {
     return 0;
 }
 
+}  // namespace cnmfe
+#include "resid_arc.hpp"
+namespace cnmfe {
+
 template <int R>
 static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
+    if constexpr (R == 15) {                              // arc kernel: radius 15 only (16-bit ds_read immediates, LDS size)
+        if (variant == 5) return launch_r1_arc<R, 4>(ctx, a, has_ac, ntile_c, nseg);
+        if (variant == 6) return launch_r1_arc<R, 2>(ctx, a, has_ac, ntile_c, nseg);
+        if (variant == 7) return launch_r1_arc<R, 2, 1>(ctx, a, has_ac, ntile_c, nseg);      // ablation: staging + stores only
+    }
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
     switch (variant) {
@@ -406,6 +415,7 @@ static void tile_shape(int variant, int &TR, int &TC) {
     TR = 16; TC = 16;
     if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2) { TR = 32; TC = 16; }
     else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
+    else if (variant >= 5 && variant <= 7) { TR = ARC_TR; TC = ARC_TC; }
 }
 
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
@@ -449,6 +459,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
       for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
+    if (h == 18 && variant >= 5) variant = 2;             // arc kernel: radius 15 only (ds_read immediates)
     const bool special = full_ring && (h == 15 || h == 18) && variant >= 0;
     int TR = 16, TC = 16;
     if (special) tile_shape(variant, TR, TC);

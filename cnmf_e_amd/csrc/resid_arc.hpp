@@ -1,0 +1,293 @@
+// R1 "arc roles": the ring product with LDS-value reuse.   (included by resid.hip; gfx950 only)
+//
+// In the one-pixel-per-thread kernel every FMA group needs its own 16-byte LDS read, so the LDS pipe
+// (256 B/clk/CU) caps the kernel at ~40 % of HBM.  Here the ring is split into four arcs (left/right: runs of
+// consecutive row offsets at a fixed column offset; top/bottom: runs of consecutive column offsets at a fixed
+// row offset) and a thread owns P adjacent centre pixels ALONG the run direction of its arc.  One staged value
+// R'(q) then feeds up to P centres (q - m in the arc for several of the thread's m), so a run of length L costs
+// L+P-1 reads for P*L FMA groups.  Each centre is covered by four threads (one per arc); their partial sums meet
+// in an LDS tile and a final pass adds the centre term and stores Ysig.
+//
+// Tile 16 rows x 32 columns (512 centres), halo row stride HRp odd (== 1 mod 16) so that both lane->column
+// (vertical roles) and lane->row with a per-quarter rotation (horizontal roles) hit 16 distinct 16-byte slots in
+// every ds_read_b128 lane group.  Threads = 4 roles x 512/P.
+#pragma once
+
+namespace cnmfe {
+
+constexpr int ARC_TR = 16, ARC_TC = 32;
+
+template <int R> struct ArcTab {
+    int n[4];                 // offsets per arc: 0 = left, 1 = right, 2 = top, 3 = bottom
+    int ring[4][40];          // index into the full ring (W rows), in run order
+    int nrun[4];
+    int rfix[4][24];          // fixed offset of the run (dc for arcs 0/1, dr for arcs 2/3)
+    int rs[4][24];            // first moving offset of the run
+    int rl[4][24];            // run length
+    int ra0[4][24];           // arc-local index of the run's first offset
+};
+
+template <int R> constexpr ArcTab<R> make_arcs() {
+    ArcTab<R> t{};
+    constexpr RingTab<R> ring = make_ring<R>();
+    int fx[4][40] = {}, mv[4][40] = {}, id[4][40] = {};
+    for (int a = 0; a < 4; ++a) t.n[a] = 0;
+    for (int i = 0; i < ring.n; ++i) {
+        const int dr = ring.dr[i], dc = ring.dc[i];
+        const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
+        int a;
+        if (adc > adr) a = dc < 0 ? 0 : 1;
+        else if (adr > adc) a = dr < 0 ? 2 : 3;
+        else a = (dc < 0 && dr < 0) ? 0 : (dc > 0 && dr > 0) ? 1 : (dr < 0 ? 2 : 3);
+        const int k = t.n[a]++;
+        fx[a][k] = a < 2 ? dc : dr; mv[a][k] = a < 2 ? dr : dc; id[a][k] = i;
+    }
+    for (int a = 0; a < 4; ++a) {
+        // sort by (fixed, moving)
+        for (int i = 1; i < t.n[a]; ++i)
+            for (int j = i; j > 0 && (fx[a][j] < fx[a][j - 1] || (fx[a][j] == fx[a][j - 1] && mv[a][j] < mv[a][j - 1])); --j) {
+                int x = fx[a][j]; fx[a][j] = fx[a][j - 1]; fx[a][j - 1] = x;
+                x = mv[a][j]; mv[a][j] = mv[a][j - 1]; mv[a][j - 1] = x;
+                x = id[a][j]; id[a][j] = id[a][j - 1]; id[a][j - 1] = x;
+            }
+        t.nrun[a] = 0;
+        for (int i = 0; i < t.n[a]; ++i) {
+            t.ring[a][i] = id[a][i];
+            if (i > 0 && fx[a][i] == fx[a][i - 1] && mv[a][i] == mv[a][i - 1] + 1) { t.rl[a][t.nrun[a] - 1]++; continue; }
+            const int r = t.nrun[a]++;
+            t.rfix[a][r] = fx[a][i]; t.rs[a][r] = mv[a][i]; t.rl[a][r] = 1; t.ra0[a][r] = i;
+        }
+    }
+    return t;
+}
+template <int R> struct ArcConst { static constexpr ArcTab<R> tab = make_arcs<R>(); };
+
+// flat per-role program for P centres per thread: the LDS reads in order, and for every read the (centre j,
+// arc-local weight index a) pairs it feeds
+template <int R, int P> struct ArcProg {
+    int nl[4];
+    int fix[4][96], mov[4][96];       // offsets of the value read: (dr, dc) = ARC < 2 ? (mov, fix) : (fix, mov)
+    int nf[4][96];
+    int fj[4][96][4], fa[4][96][4];
+};
+template <int R, int P> constexpr ArcProg<R, P> make_prog() {
+    ArcProg<R, P> g{};
+    constexpr ArcTab<R> t = make_arcs<R>();
+    for (int arc = 0; arc < 4; ++arc) {
+        int li = 0;
+        for (int run = 0; run < t.nrun[arc]; ++run)
+            for (int x = 0; x < t.rl[arc][run] + P - 1; ++x) {
+                g.fix[arc][li] = t.rfix[arc][run]; g.mov[arc][li] = t.rs[arc][run] + x;
+                int nf = 0;
+                for (int j = 0; j < P; ++j) {
+                    const int u = x - j;
+                    if (u >= 0 && u < t.rl[arc][run]) { g.fj[arc][li][nf] = j; g.fa[arc][li][nf] = t.ra0[arc][run] + u; ++nf; }
+                }
+                g.nf[arc][li] = nf;
+                ++li;
+            }
+        g.nl[arc] = li;
+    }
+    return g;
+}
+template <int R, int P> struct ProgConst { static constexpr ArcProg<R, P> tab = make_prog<R, P>(); };
+
+// the ring product of one role: ARC in 0..3, P centres per thread.  hb = thread base in the halo:
+//   vertical roles  (ARC 0/1): &halo[c * HRp + g*P]      -> value of (row g*P + i, col c + j) at hb[(j+R)*HRp + (i+R)]
+//   horizontal roles(ARC 2/3): &halo[h*P * HRp + r]      -> value of (row r + i, col h*P + j) at the same expression
+// wp[j][a/2] holds the arc weights of centre j as pairs; acc[j][0] = frames 0,1, acc[j][1] = frames 2,3.
+template <int R, int ARC, int P, int HRp, int NW>
+__device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][NW], f2 (&acc)[P][2]) {
+    constexpr int NL = ProgConst<R, P>::tab.nl[ARC];
+    constexpr int D = 4;                                   // LDS reads in flight ahead of their FMAs
+    float4 r[D + 1];
+#define ARC_ADDR(li) (ARC < 2 ? hb + (ProgConst<R, P>::tab.fix[ARC][li] + R) * HRp + (ProgConst<R, P>::tab.mov[ARC][li] + R) \
+                              : hb + (ProgConst<R, P>::tab.mov[ARC][li] + R) * HRp + (ProgConst<R, P>::tab.fix[ARC][li] + R))
+#pragma unroll
+    for (int li = 0; li < D; ++li) if (li < NL) r[li] = *ARC_ADDR(li);
+#pragma unroll
+    for (int li = 0; li < NL; ++li) {
+        if (li + D < NL) r[(li + D) % (D + 1)] = *ARC_ADDR(li + D);
+        const float4 rv = r[li % (D + 1)];
+        const f2 r01 = {rv.x, rv.y}, r23 = {rv.z, rv.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < ProgConst<R, P>::tab.nf[ARC][li]) {
+                const int j = ProgConst<R, P>::tab.fj[ARC][li][q], a = ProgConst<R, P>::tab.fa[ARC][li][q];
+                const f2 wv = wp[j][a >> 1];
+                if ((a & 1) == 0) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j][0]) : "v"(wv), "v"(r01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j][1]) : "v"(wv), "v"(r23));
+                } else {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[j][0]) : "v"(wv), "v"(r01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[j][1]) : "v"(wv), "v"(r23));
+                }
+            }
+        }
+        // keep later reads from being hoisted above these FMAs (register pressure), see k_residual_r
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]) : : "memory");
+    }
+#undef ARC_ADDR
+}
+
+template <int R, int P, bool HAS_AC, int ABL = 0>
+__global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Args a) {
+    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC;             // 512 centres
+    constexpr int NT = 4 * NC / P;                                    // threads
+    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
+    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;                    // odd, == 1 (mod 16)
+    constexpr int NH = HR * HC, NHp = HRp * HC;
+    constexpr int NIT = (NH + NT - 1) / NT;
+    constexpr int NA = ArcConst<R>::tab.n[0];                         // offsets per arc (equal for all four)
+    static_assert(ArcConst<R>::tab.n[1] == NA && ArcConst<R>::tab.n[2] == NA && ArcConst<R>::tab.n[3] == NA && NA % 2 == 0, "arcs must be balanced");
+    constexpr int NW = NA / 2;
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHp] | part[4][NC]
+    float4 *halo = lds, *part = lds + 2 * NHp;
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int ntile = gridDim.x;
+    if (ntile % 8 == 0) bid = (bid % 8) * (ntile / 8) + bid / 8;      // XCD-aware tile order
+    const int tile_r = bid % a.ntile_r, tile_c = bid / a.ntile_r;
+    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
+
+    // ---- role geometry ----
+    constexpr int TPR = NC / P;                                       // threads per role
+    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;   // wave-uniform role (TPR is a multiple of 64)
+    int cr[P], cc[P];                                                 // tile-local (row, col) of the thread's centres
+    int hbase;
+    if (role < 2) {                                                   // vertical groups: lane -> column, 32-lane half -> row group
+        const int c = rt & 31, g = rt >> 5;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
+        hbase = c * HRp + g * P;
+    } else {                                                          // horizontal groups: 16-lane quarter -> column group, rotated rows
+        const int q = rt >> 4, i = rt & 15;
+        const int sq = (q * P * HRp) & 15;
+        const int r = (i - sq) & 15;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
+        hbase = q * P * HRp + r;
+    }
+    // ---- arc weights of the P centres, as pairs ----
+    f2 wp[P][NW];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
+        const int64_t m = (pr < a.nr && pc < a.nc) ? (int64_t)pc * a.nr + pr : 0;     // off-patch centres read pixel 0; never stored
+        const uint32_t mb = (uint32_t)m * 4u;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int i0, i1;
+            if (role == 0) { i0 = ArcConst<R>::tab.ring[0][2 * k]; i1 = ArcConst<R>::tab.ring[0][2 * k + 1]; }
+            else if (role == 1) { i0 = ArcConst<R>::tab.ring[1][2 * k]; i1 = ArcConst<R>::tab.ring[1][2 * k + 1]; }
+            else if (role == 2) { i0 = ArcConst<R>::tab.ring[2][2 * k]; i1 = ArcConst<R>::tab.ring[2][2 * k + 1]; }
+            else { i0 = ArcConst<R>::tab.ring[3][2 * k]; i1 = ArcConst<R>::tab.ring[3][2 * k + 1]; }
+            wp[j][k].x = ld_off(a.W + (int64_t)i0 * a.d, mb);
+            wp[j][k].y = ld_off(a.W + (int64_t)i1 * a.d, mb);
+        }
+    }
+    // ---- staging plan (frame-invariant) ----
+    uint32_t qoff[NIT]; int hidx[NIT]; float ymj[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int idx = tid + j * NT;
+        const int hr = idx % HR, hc = idx / HR;
+        const int rb = hr0 + hr, cb = hc0 + hc;
+        const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
+        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 4u : ~0u;
+        hidx[j] = idx < NH ? hc * HRp + hr : -1;
+        ymj[j] = ld_off(a.ymean_f, in ? qoff[j] : 0u);
+    }
+    // ---- final-pass centre of this thread (threads < NC) ----
+    const int fr = tid % TR, fc = (tid / TR) % TC;
+    const int fpr = tile_r * TR + fr, fpc = tile_c * TC + fc;
+    const bool fvalid = tid < NC && fpr < a.nr && fpc < a.nc;
+    const int64_t fm = fvalid ? (int64_t)fpc * a.nr + fpr : 0;
+    const uint32_t fmb = (uint32_t)fm * 4u;
+    const float dl = ld_off(a.dlt, fmb);
+    const int nwa = (HAS_AC && fvalid) ? a.wa_cnt[fm] : 0;
+
+    const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
+    const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
+    float pre[NIT][4];
+    auto issue = [&](int64_t t0) {
+        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
+        const float *y0 = a.Y + t0 * a.d_b;
+        const float *y1 = a.Y + (t0 + (nf > 1 ? 1 : 0)) * a.d_b;
+        const float *y2 = a.Y + (t0 + (nf > 2 ? 2 : nf - 1)) * a.d_b;
+        const float *y3 = a.Y + (t0 + (nf > 3 ? 3 : nf - 1)) * a.d_b;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
+            pre[j][0] = ld_off(y0, qo); pre[j][1] = ld_off(y1, qo); pre[j][2] = ld_off(y2, qo); pre[j][3] = ld_off(y3, qo);
+        }
+    };
+    auto commit = [&](float4 *buf) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const float ym = ymj[j];
+            float4 v = make_float4(pre[j][0] - ym, pre[j][1] - ym, pre[j][2] - ym, pre[j][3] - ym);
+            if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hidx[j] >= 0) buf[hidx[j]] = v;
+        }
+    };
+    issue(tbeg);
+    commit(halo);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
+        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
+        const bool more = t0 + 4 < tend;
+        if (more) issue(t0 + 4);
+        const float4 *hb = halo + cur * NHp + hbase;
+        f2 acc[P][2];
+#pragma unroll
+        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
+        if (ABL == 1) { acc[0][0].x = hb[R * HRp + R].x * wp[0][0].x; }      // ablation: no ring product
+        else if (role == 0) arc_product<R, 0, P, HRp, NW>(hb, wp, acc);
+        else if (role == 1) arc_product<R, 1, P, HRp, NW>(hb, wp, acc);
+        else if (role == 2) arc_product<R, 2, P, HRp, NW>(hb, wp, acc);
+        else arc_product<R, 3, P, HRp, NW>(hb, wp, acc);
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            part[role * NC + cc[j] * TR + cr[j]] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        __syncthreads();
+        if (fvalid) {
+            const int ci = fc * TR + fr;
+            const float4 p0 = part[ci], p1 = part[NC + ci], p2 = part[2 * NC + ci], p3 = part[3 * NC + ci];
+            float4 c = halo[cur * NHp + (fc + R) * HRp + (fr + R)];   // (Y - Ymean) at the centre
+            if (HAS_AC) {
+                for (int e = 0; e < nwa; ++e) {
+                    const float v = a.wa_v[(int64_t)e * a.d + fm];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + fm] * a.ldc + t0);
+                    c.x = fmaf(v, c4.x, c.x); c.y = fmaf(v, c4.y, c.y); c.z = fmaf(v, c4.z, c.z); c.w = fmaf(v, c4.w, c.w);
+                }
+            }
+            float *o = a.Ysig + t0 * a.d;
+            st_off(o, fmb, c.x + dl - ((p0.x + p1.x) + (p2.x + p3.x)));
+            if (nf > 1) st_off(o + a.d, fmb, c.y + dl - ((p0.y + p1.y) + (p2.y + p3.y)));
+            if (nf > 2) st_off(o + 2 * a.d, fmb, c.z + dl - ((p0.z + p1.z) + (p2.z + p3.z)));
+            if (nf > 3) st_off(o + 3 * a.d, fmb, c.w + dl - ((p0.w + p1.w) + (p2.w + p3.w)));
+        }
+        if (more) commit(halo + (cur ^ 1) * NHp);
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+template <int R, int P, int ABL = 0>
+static int launch_r1_arc(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
+    constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1;
+    constexpr size_t shmem = (2 * (size_t)HRp * HC + 4 * (size_t)ARC_TR * ARC_TC) * sizeof(float4);
+    static_assert(shmem <= 160 * 1024, "arc kernel exceeds LDS");
+    static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
+    constexpr int NT = 4 * ARC_TR * ARC_TC / P;
+    dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
+    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, true, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, true, ABL>), grid, dim3(NT), shmem, a);
+    else        LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, false, ABL>), grid, dim3(NT), shmem, a);
+    return 0;
+}
+
+}  // namespace cnmfe
