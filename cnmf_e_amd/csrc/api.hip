@@ -34,6 +34,21 @@ __global__ void k_ymean(const float *__restrict__ Y, int64_t d_b, int64_t T, dou
     ym[q] = m; ymf[q] = (float)m;
 }
 
+// resident layout: Yc4[c][q] = (Y[4c..4c+3][q] - Ymean[q]) as one float4 (frames past T are 0)
+__global__ void k_center4(const float *__restrict__ Y, const float *__restrict__ ymf, int64_t d_b, int64_t T, float4 *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= d_b) return;
+    const int64_t c = blockIdx.y;
+    const float m = ymf[q];
+    const int64_t t = 4 * c;
+    float4 v;
+    v.x = Y[t * d_b + q] - m;
+    v.y = t + 1 < T ? Y[(t + 1) * d_b + q] - m : 0.f;
+    v.z = t + 2 < T ? Y[(t + 2) * d_b + q] - m : 0.f;
+    v.w = t + 3 < T ? Y[(t + 3) * d_b + q] - m : 0.f;
+    out[c * d_b + q] = v;
+}
+
 // W = 1/count on the in-FOV ring neighbours (initComponents_parallel.m:229-233)
 __global__ void k_ring_init(float *__restrict__ W, int64_t d, int nr, int p, const int *__restrict__ dr, const int *__restrict__ dc,
                             int r0, int c0, int d1, int d2) {
@@ -113,6 +128,13 @@ int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
     RET(P->ymean_f.ensure(P->d_b * sizeof(float)));
     LAUNCH(ctx, "ymean", k_ymean, dim3((unsigned)((P->d_b + 255) / 256)), dim3(256), 0,
            P->Y.as<float>(), P->d_b, P->T, P->ymean_d.as<double>(), P->ymean_f.as<float>());
+    // build the resident centred / 4-frame-interleaved copy, then drop the upload staging
+    P->Tc = (P->T + 3) / 4;
+    RET(P->Yc4.ensure((size_t)P->Tc * P->d_b * sizeof(float4)));
+    LAUNCH(ctx, "center4", k_center4, dim3((unsigned)((P->d_b + 255) / 256), (unsigned)P->Tc), dim3(256), 0,
+           P->Y.as<float>(), P->ymean_f.as<float>(), P->d_b, P->T, P->Yc4.as<float4>());
+    CK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(P->Y.p); P->Y.p = nullptr; P->Y.cap = 0;
     P->ymean_valid = true;
     return 0;
 }
@@ -229,6 +251,7 @@ int cnmfe_patch_create(cnmfe_ctx *ctx, int patch_id, const int32_t pr[4], const 
     P->d = (int64_t)P->nr * P->nc; P->d_b = (int64_t)P->nr_b * P->nc_b;
     int rc = P->Y.ensure((size_t)P->d_b * T * sizeof(float));
     if (rc) { delete P; return rc; }
+    P->Tc = (T + 3) / 4;
     ctx->patches[patch_id] = P;
     return 0;
 }
@@ -242,6 +265,10 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     size_t esz = dtype == CNMFE_F32 ? 4 : dtype == CNMFE_F64 ? 8 : dtype == CNMFE_U16 ? 2 : dtype == CNMFE_U8 ? 1 : dtype == CNMFE_F16 ? 2 : 0;
     if (!esz) return fail(CNMFE_EINVAL, "unknown dtype %d", dtype);
     if (memspace != CNMFE_HOST && memspace != CNMFE_DEVICE) return fail(CNMFE_EINVAL, "unknown memspace %d", memspace);
+    if (!P->Y.p) {                                   // a re-upload after the block was finalised: start over
+        RET(P->Y.ensure((size_t)P->d_b * P->T * sizeof(float)));
+        P->frames_uploaded = 0;
+    }
     float *dst = P->Y.as<float>() + t0 * P->d_b;
     int64_t n = nt * P->d_b;
     if (dtype == CNMFE_F32) {

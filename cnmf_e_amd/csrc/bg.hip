@@ -35,7 +35,7 @@ struct BgGeom {
 };
 
 // ---- B1 ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_build_bf(const float *__restrict__ Y, const float *__restrict__ ymean_f, BgGeom g,
+__global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g,
                                                   const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
                                                   const float *__restrict__ Cc, int64_t ldc, float *__restrict__ bf, int tchunk) {
     const int blk = blockIdx.x;                    // 16x16 block id, column-major over (nbr, nbc)
@@ -45,20 +45,36 @@ __global__ void __launch_bounds__(256) k_build_bf(const float *__restrict__ Y, c
     const int rb = bi * BLK + lr, cb = bj * BLK + lc;
     const bool in = rb < g.nr_b && cb < g.nc_b;
     const int64_t q = in ? (int64_t)cb * g.nr_b + rb : 0;
-    const float ym = in ? ymean_f[q] : 0.f;
     int e0 = 0, e1 = 0;
     if (in && arow) { e0 = arow[q]; e1 = arow[q + 1]; }
-    const int64_t tp0 = (int64_t)blockIdx.y * tchunk;
+    const int64_t tp0 = (int64_t)blockIdx.y * tchunk;          // tchunk is a multiple of 4
     const int64_t tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
     float *out = bf + ((int64_t)blk * g.Tpad) * BLKPX + lp;
-    for (int64_t tp = tp0; tp < tp1; ++tp) {
-        float v = 0.f;
-        if (in && tp < g.Tp) {
-            const int64_t t = tp * g.kstride;
-            v = Y[t * g.d_b + q] - ym;
-            for (int e = e0; e < e1; ++e) v -= aval[e] * Cc[(int64_t)acol[e] * ldc + t];
+    if (g.kstride == 1) {                          // the video is resident centred: Bf = Yc - A*(C - Cmean), 4 frames per load
+        for (int64_t tp = tp0; tp < tp1; tp += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t c = tp >> 2;
+            if (in && c < Tc) {
+                v = Y4[c * g.d_b + q];
+                for (int e = e0; e < e1; ++e) {
+                    const float av = aval[e];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(Cc + (int64_t)acol[e] * ldc + tp);
+                    v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
+                }
+            }
+            out[tp * BLKPX] = v.x; out[(tp + 1) * BLKPX] = v.y; out[(tp + 2) * BLKPX] = v.z; out[(tp + 3) * BLKPX] = v.w;
         }
-        out[tp * BLKPX] = v;
+    } else {                                       // frame subsampling Bf(:, 1:k:end)  (fit_ring_model.m:87)
+        const float *Ys = reinterpret_cast<const float *>(Y4);
+        for (int64_t tp = tp0; tp < tp1; ++tp) {
+            float v = 0.f;
+            if (in && tp < g.Tp) {
+                const int64_t t = tp * g.kstride;
+                v = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)];
+                for (int e = e0; e < e1; ++e) v -= aval[e] * Cc[(int64_t)acol[e] * ldc + t];
+            }
+            out[tp * BLKPX] = v;
+        }
     }
 }
 
@@ -547,9 +563,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     if (nactive > 0) {
         // ---- B1: Bf tiled ----
         RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
-        const int tchunk = (int)std::max<int64_t>(64, (g.Tpad + 15) / 16);
+        const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 3) & ~int64_t(3));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
-        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Y.as<float>(), P->ymean_f.as<float>(), g,
+        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk);
         RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
         LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>());

@@ -104,7 +104,9 @@ struct Patch {
     int32_t nr = 0, nc = 0, nr_b = 0, nc_b = 0;
     int32_t roff = 0, coff = 0;        // patch origin inside the block (0-based)
     int64_t T = 0, d = 0, d_b = 0;
-    DevBuf Y;                          // T x d_b fp32
+    DevBuf Y;                          // upload staging: T x d_b fp32, frame-major; released once Yc4 is built
+    DevBuf Yc4;                        // the RESIDENT video: centred (Y - Ymean), 4-frame interleaved: [ceil(T/4)][d_b] float4
+    int64_t Tc = 0;                    // ceil(T/4)
     DevBuf ymean_d;                    // d_b double
     DevBuf ymean_f;                    // d_b float
     bool ymean_valid = false;

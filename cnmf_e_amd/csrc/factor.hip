@@ -12,21 +12,20 @@
 namespace cnmfe {
 
 // ---- S1: U(e) = sum_t Ysig(m_e, t) * Cc(k_e, t)   (Cc centred => equals Y*C' - T*Ymean*Cmean') ----
-__global__ void __launch_bounds__(256) k_proj_spatial(const float *__restrict__ ysig, int64_t d, int64_t T, const int *__restrict__ erow,
+__global__ void __launch_bounds__(256) k_proj_spatial(const float4 *__restrict__ ysig4, int64_t d, int64_t T, const int *__restrict__ erow,
                                                       const int *__restrict__ ecol, int64_t nnz, const float *__restrict__ Cc, int64_t ldc,
                                                       int64_t tchunk, float *__restrict__ part) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
-    const int64_t t0 = (int64_t)blockIdx.y * tchunk, t1 = t0 + tchunk < T ? t0 + tchunk : T;
-    const float *y = ysig + erow[e];
-    const float *c = Cc + (int64_t)ecol[e] * ldc;
+    const int64_t t0 = (int64_t)blockIdx.y * tchunk, t1 = t0 + tchunk < T ? t0 + tchunk : T;      // tchunk is a multiple of 4
+    const float4 *y = ysig4 + erow[e];
+    const float *c = Cc + (int64_t)ecol[e] * ldc;            // centred traces are 0 beyond T, so padded frames drop out
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int64_t t = t0;
-    for (; t + 3 < t1; t += 4) {
-        a0 = fmaf(y[t * d], c[t], a0); a1 = fmaf(y[(t + 1) * d], c[t + 1], a1);
-        a2 = fmaf(y[(t + 2) * d], c[t + 2], a2); a3 = fmaf(y[(t + 3) * d], c[t + 3], a3);
+    for (int64_t t = t0; t < t1; t += 4) {
+        const float4 yv = y[(t >> 2) * d];
+        const float4 cv = *reinterpret_cast<const float4 *>(c + t);
+        a0 = fmaf(yv.x, cv.x, a0); a1 = fmaf(yv.y, cv.y, a1); a2 = fmaf(yv.z, cv.z, a2); a3 = fmaf(yv.w, cv.w, a3);
     }
-    for (; t < t1; ++t) a0 = fmaf(y[t * d], c[t], a0);
     part[(int64_t)blockIdx.y * nnz + e] = (a0 + a1) + (a2 + a3);
 }
 __global__ void k_reduce_parts(const float *__restrict__ part, int64_t n, int nparts, float *__restrict__ out) {
@@ -146,19 +145,26 @@ __global__ void __launch_bounds__(64) k_nnls_spatial(int64_t d, const int *__res
 // ---- T1: U(k,t) = sum_e A(e) * Ysig(m_e, t)  (HALS_temporal.m:48) --------------------------------------
 // one workgroup per (neuron, frame chunk); a wave owns frames t = t0 + wave, +4, ...; lanes stride the
 // neuron's pixels and a 6-step DPP butterfly finishes the dot product.
-__global__ void __launch_bounds__(256) k_proj_temporal(const float *__restrict__ ysig, int64_t d, int64_t T, const int64_t *__restrict__ colptr,
-                                                       const int *__restrict__ erow, const float *__restrict__ aval, int64_t tchunk,
+__global__ void __launch_bounds__(256) k_proj_temporal(const float4 *__restrict__ ysig4, int64_t d, int64_t T, const int64_t *__restrict__ colptr,
+                                                       const int *__restrict__ erow, const float *__restrict__ aval, int64_t cchunk,
                                                        float *__restrict__ U, int64_t ldc) {
     const int k = blockIdx.x;
     const int64_t e0 = colptr[k], e1 = colptr[k + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t0 = (int64_t)blockIdx.y * tchunk, t1 = t0 + tchunk < T ? t0 + tchunk : T;
-    for (int64_t t = t0 + wave; t < t1; t += 4) {
-        const float *y = ysig + t * d;
-        float s = 0.f;
-        for (int64_t e = e0 + lane; e < e1; e += 64) s = fmaf(aval[e], y[erow[e]], s);
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) U[(int64_t)k * ldc + t] = s;
+    const int64_t Tc = (T + 3) >> 2;
+    const int64_t c0 = (int64_t)blockIdx.y * cchunk, c1 = c0 + cchunk < Tc ? c0 + cchunk : Tc;     // 4-frame groups
+    for (int64_t c = c0 + wave; c < c1; c += 4) {
+        const float4 *y = ysig4 + c * d;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int64_t e = e0 + lane; e < e1; e += 64) {
+            const float av = aval[e]; const float4 yv = y[erow[e]];
+            s0 = fmaf(av, yv.x, s0); s1 = fmaf(av, yv.y, s1); s2 = fmaf(av, yv.z, s2); s3 = fmaf(av, yv.w, s3);
+        }
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o); }
+        if (lane == 0) {
+            float *u = U + (int64_t)k * ldc + 4 * c;        // ldc is a multiple of 4 >= T: the padded tail is never read
+            u[0] = s0; u[1] = s1; u[2] = s2; u[3] = s3;
+        }
     }
 }
 
@@ -372,10 +378,10 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     if (sn) RET(to_dev(ctx, dSn, sn, (size_t)d));
     // S1
     const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(32, T / 256));
-    const int64_t tchunk = (T + nparts - 1) / nparts;
+    const int64_t tchunk = ((T + nparts - 1) / nparts + 3) & ~int64_t(3);
     RET(dPart.ensure((size_t)nparts * nnz * sizeof(float)));
     RET(dU.ensure((size_t)nnz * sizeof(float)));
-    LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, ctx->ysig.as<float>(), d, T,
+    LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, ctx->ysig.as<float4>(), d, T,
            dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
     LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
     // S2 on the co-occurrence pairs
@@ -426,10 +432,11 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
     CK(hipMemsetAsync(dCraw.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));             // C_raw = zeros(K,T)  (:45)
     // T1
-    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, T / 128));
-    const int64_t tchunk = (T + nchunk - 1) / nchunk;
+    const int64_t Tc = (T + 3) / 4;
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
+    const int64_t tchunk = (Tc + nchunk - 1) / nchunk;                                              // in 4-frame groups
     if (nnz > 0)
-        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, ctx->ysig.as<float>(), d, T, dColptr.as<int64_t>(),
+        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, ctx->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
     // T2: overlap graph + V values (neighbour lists include k itself: V(k,k) = aa(k))
     HostCSR csr; csc_to_csr(d, K, A_colptr, A_rowidx, A_val, csr);

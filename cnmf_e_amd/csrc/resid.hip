@@ -34,6 +34,18 @@ int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_
     return 0;
 }
 
+// Ysig4 [T/4][d] float4  ->  frame-major [T][d]
+__global__ void k_ysig_unpack(const float4 *__restrict__ src, int64_t d, int64_t T, float *__restrict__ dst) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= d) return;
+    const int64_t c = blockIdx.y, t = 4 * c;
+    const float4 v = src[c * d + m];
+    dst[t * d + m] = v.x;
+    if (t + 1 < T) dst[(t + 1) * d + m] = v.y;
+    if (t + 2 < T) dst[(t + 2) * d + m] = v.z;
+    if (t + 3 < T) dst[(t + 3) * d + m] = v.w;
+}
+
 // dlt[m] = ymean_f[q(m)] - b0[m]   (double arithmetic, float result: it is small, = A*Cmean at m)
 __global__ void k_dlt(const float *__restrict__ ymean_f, const double *__restrict__ b0, float *__restrict__ dlt,
                       int64_t d, int nr, int nr_b, int roff, int coff) {
@@ -81,7 +93,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int WA_CAP = WA_CAP_;   // max neurons whose footprint a pixel's ring may touch
 
 struct R1Args {
-    const float *Y; int64_t d_b; int nr_b, nc_b;
+    const float4 *Y4; int64_t d_b; int nr_b, nc_b;      // resident video: centred, [T/4][d_b] float4
     int nr, nc, roff, coff; int64_t d;
     int64_t T, tseg;
     const float *W; int p, h;
@@ -90,7 +102,7 @@ struct R1Args {
     // A_prev*C_prev enters through linearity: W*(A*Cc) = (W*A)*Cc.  wa_* is the per-pixel ELL table of W*A
     // ([slot][pixel], WA_CAP slots), wa_cnt[pixel] its length; Cc the centred traces [k][ldc].
     const int *wa_cnt; const int *wa_k; const float *wa_v; const float *Cc; int64_t ldc;
-    float *Ysig;
+    float4 *Ysig4;                   // output, [T/4][d] float4
     int ntile_r;
 };
 
@@ -109,23 +121,15 @@ template <int R> constexpr RingTab<R> make_ring() {
 }
 template <int R> struct RingConst { static constexpr RingTab<R> tab = make_ring<R>(); };
 
-// stage the centred video halo of frames [t0, t0+nf):  Y' = Y - Ymean
+// stage the centred video halo of the 4-frame chunk c4: one 16-byte load per halo pixel
 template <int NT>
-__device__ __forceinline__ void stage_halo(const R1Args &a, float4 *halo, int tid, int HR, int NH, int hr0, int hc0, int64_t t0, int nf) {
+__device__ __forceinline__ void stage_halo(const R1Args &a, float4 *halo, int tid, int HR, int NH, int hr0, int hc0, int64_t c4) {
 #pragma unroll 2
     for (int idx = tid; idx < NH; idx += NT) {
         const int hr = idx % HR, hc = idx / HR;
         const int rb = hr0 + hr, cb = hc0 + hc;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b) {
-            const int64_t q = (int64_t)cb * a.nr_b + rb;
-            const float *y = a.Y + t0 * a.d_b + q;
-            const float ym = a.ymean_f[q];
-            v.x = y[0] - ym;
-            v.y = nf > 1 ? y[a.d_b] - ym : 0.f;
-            v.z = nf > 2 ? y[2 * a.d_b] - ym : 0.f;
-            v.w = nf > 3 ? y[3 * a.d_b] - ym : 0.f;
-        }
+        if (rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b) v = a.Y4[c4 * a.d_b + (int64_t)cb * a.nr_b + rb];
         halo[idx] = v;
     }
 }
@@ -142,26 +146,16 @@ __device__ __forceinline__ float4 wa_term(const R1Args &a, int64_t m, int64_t t0
     return s;
 }
 
-// Ysig = (Y - Ymean)(centre) + (Ymean - b0) - W*Y' + (W*A)*Cc
-__device__ __forceinline__ void store_ysig(const R1Args &a, int64_t t0, int nf, int64_t qc, int64_t m, float ym_c, float dl, float4 acc) {
-    const float *y = a.Y + t0 * a.d_b + qc;
-    float *o = a.Ysig + t0 * a.d + m;
-    o[0] = (y[0] - ym_c) + dl - acc.x;
-    if (nf > 1) o[a.d] = (y[a.d_b] - ym_c) + dl - acc.y;
-    if (nf > 2) o[2 * a.d] = (y[2 * a.d_b] - ym_c) + dl - acc.z;
-    if (nf > 3) o[3 * a.d] = (y[3 * a.d_b] - ym_c) + dl - acc.w;
-}
-
-// uniform base + 32-bit per-lane byte offset: lowers to `global_load_dword v, v_off, s[base:base+1]`, so a
+// uniform base + 32-bit per-lane byte offset: lowers to `global_load v, v_off, s[base:base+1]`, so a
 // frame-invariant address costs ONE VGPR instead of a hoisted 64-bit pointer pair per array.
 __device__ __forceinline__ float ld_off(const float *base, uint32_t byteoff) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byteoff);
 }
-__device__ __forceinline__ int ld_off(const int *base, uint32_t byteoff) {
-    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byteoff);
+__device__ __forceinline__ float4 ld4_off(const float4 *base, uint32_t byteoff) {
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byteoff);
 }
-__device__ __forceinline__ void st_off(float *base, uint32_t byteoff, float v) {
-    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byteoff) = v;
+__device__ __forceinline__ void st4_off(float4 *base, uint32_t byteoff, float4 v) {
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + byteoff) = v;
 }
 
 // waves/SIMD the register allocator must leave room for: weights (P VGPRs) + working registers
@@ -201,13 +195,10 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
         const int hr = idx % HR, hc = idx / HR;
         const int rb = hr0 + hr, cb = hc0 + hc;
         const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
-        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 4u : ~0u;
+        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 16u : ~0u;
     }
-    float ymj[NIT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) ymj[j] = ld_off(a.ymean_f, qoff[j] == ~0u ? 0u : qoff[j]);
-    const uint32_t mb = (uint32_t)m * 4u, qcb = (uint32_t)qc * 4u;
-    (void)qcb;
+    const uint32_t mb = (uint32_t)m * 4u;
+    (void)qc;
     // (W*A_prev) row of this pixel: the first WA_PRE entries are kept in registers (frame-invariant) and their
     // trace samples are fetched at the top of every iteration so they land under the ring product
     constexpr int WA_PRE = 4;
@@ -234,26 +225,18 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
     const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
 
-    float pre[NIT][4];                                  // raw frames of the NEXT chunk, in flight during the ring product
-    auto issue = [&](int64_t t0) {                      // frames past the end are clamped to the last one: loaded, never stored
-        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
-        const float *y0 = a.Y + t0 * a.d_b;
-        const float *y1 = a.Y + (t0 + (nf > 1 ? 1 : 0)) * a.d_b;
-        const float *y2 = a.Y + (t0 + (nf > 2 ? 2 : nf - 1)) * a.d_b;
-        const float *y3 = a.Y + (t0 + (nf > 3 ? 3 : nf - 1)) * a.d_b;
+    float4 pre[NIT];                                    // the NEXT chunk's halo values, in flight during the ring product
+    auto issue = [&](int64_t t0) {                      // one 16-byte load per staged pixel (4 frames)
+        const float4 *y4 = a.Y4 + (t0 >> 2) * a.d_b;
 #pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
-            pre[j][0] = ld_off(y0, qo); pre[j][1] = ld_off(y1, qo); pre[j][2] = ld_off(y2, qo); pre[j][3] = ld_off(y3, qo);
-        }
+        for (int j = 0; j < NIT; ++j) pre[j] = ld4_off(y4, qoff[j] == ~0u ? 0u : qoff[j]);
     };
     // Y' = Y - Ymean, float4 (4 frames) per halo pixel
     auto commit = [&](float4 *buf) {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int idx = tid + j * NT;
-            const float ym = ymj[j];
-            float4 v = make_float4(pre[j][0] - ym, pre[j][1] - ym, pre[j][2] - ym, pre[j][3] - ym);
+            float4 v = pre[j];
             if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (NIT * NT == NH || idx < NH) buf[idx] = v;
         }
@@ -264,7 +247,6 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     __syncthreads();
     int cur = 0;
     for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
-        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
         const bool more = t0 + 4 < tend;
         if (more) issue(t0 + 4);                        // global loads of the next chunk fly under the ring product
         float4 wc[WA_PRE];
@@ -326,11 +308,7 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
                     c.x = fmaf(v, c4.x, c.x); c.y = fmaf(v, c4.y, c.y); c.z = fmaf(v, c4.z, c.z); c.w = fmaf(v, c4.w, c.w);
                 }
             }
-            float *o = a.Ysig + t0 * a.d;
-            st_off(o, mb, c.x + dl - acc.x);
-            if (nf > 1) st_off(o + a.d, mb, c.y + dl - acc.y);
-            if (nf > 2) st_off(o + 2 * a.d, mb, c.z + dl - acc.z);
-            if (nf > 3) st_off(o + 3 * a.d, mb, c.w + dl - acc.w);
+            st4_off(a.Ysig4 + (t0 >> 2) * a.d, mb * 4u, make_float4(c.x + dl - acc.x, c.y + dl - acc.y, c.z + dl - acc.z, c.w + dl - acc.w));
         }
         if (more) commit(halo + (cur ^ 1) * NH);
         cur ^= 1;
@@ -353,13 +331,12 @@ __global__ void __launch_bounds__(256) k_residual_gen(R1Args a) {
     const int64_t qc = (int64_t)(pc + a.coff) * a.nr_b + (pr + a.roff);
     const int hr0 = tile_r * TR + a.roff - h, hc0 = tile_c * TR + a.coff - h;
     const int base = (tc + h) * HR + (tr + h);
-    const float ym_c = valid ? a.ymean_f[qc] : 0.f;
     const float dl = valid ? a.dlt[m] : 0.f;
+    (void)qc;
     const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
     const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
     for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
-        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
-        stage_halo<NT>(a, halo, tid, HR, NH, hr0, hc0, t0, nf);
+        stage_halo<NT>(a, halo, tid, HR, NH, hr0, hc0, t0 >> 2);
         __syncthreads();
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
@@ -370,7 +347,8 @@ __global__ void __launch_bounds__(256) k_residual_gen(R1Args a) {
                 acc.x = fmaf(wi, r.x, acc.x); acc.y = fmaf(wi, r.y, acc.y);
                 acc.z = fmaf(wi, r.z, acc.z); acc.w = fmaf(wi, r.w, acc.w);
             }
-            store_ysig(a, t0, nf, qc, m, ym_c, dl, acc);
+            const float4 c = halo[base];                 // (Y - Ymean) at the centre
+            a.Ysig4[(t0 >> 2) * a.d + m] = make_float4(c.x + dl - acc.x, c.y + dl - acc.y, c.z + dl - acc.z, c.w + dl - acc.w);
         }
         __syncthreads();
     }
@@ -421,7 +399,7 @@ static void tile_shape(int variant, int &TR, int &TC) {
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace) {
     const int64_t T = P->T;
-    RET(ctx->ysig.ensure((size_t)P->d * T * sizeof(float)));
+    RET(ctx->ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
            &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10], &dFlag = ctx->tmp[11];
     int64_t ldc = 4;
@@ -466,14 +444,14 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     const int HR = TR + 2 * h, HC = TC + 2 * h;
 
     R1Args a;
-    a.Y = P->Y.as<float>(); a.d_b = P->d_b; a.nr_b = P->nr_b; a.nc_b = P->nc_b;
+    a.Y4 = P->Yc4.as<float4>(); a.d_b = P->d_b; a.nr_b = P->nr_b; a.nc_b = P->nc_b;
     a.nr = P->nr; a.nc = P->nc; a.roff = P->roff; a.coff = P->coff; a.d = P->d;
     a.T = T;
     a.W = P->W.as<float>(); a.p = P->p; a.h = h; a.offs = nullptr;
     a.ymean_f = P->ymean_f.as<float>(); a.dlt = dDlt.as<float>();
     a.wa_cnt = has_ac ? dWaCnt.as<int>() : nullptr; a.wa_k = has_ac ? dWaK.as<int>() : nullptr;
     a.wa_v = has_ac ? dWaV.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
-    a.Ysig = ctx->ysig.as<float>();
+    a.Ysig4 = ctx->ysig.as<float4>();
     a.ntile_r = (P->nr + TR - 1) / TR;
     const int ntile_c = (P->nc + TC - 1) / TC;
     const int64_t ntiles = (int64_t)a.ntile_r * ntile_c;
@@ -503,9 +481,13 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     }
     RET(rc);
     ctx->ysig_patch = pid; P->ysig_valid = true;
-    if (Ysig_out) {
-        CK(hipMemcpyAsync(Ysig_out, ctx->ysig.p, (size_t)P->d * T * sizeof(float),
-                          out_memspace == CNMFE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (Ysig_out) {                                      // the ABI hands Ysig out frame-major (d x T column-major)
+        float *dstp = Ysig_out;
+        if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)P->d * T * sizeof(float))); dstp = ctx->stage.as<float>(); }
+        LAUNCH(ctx, "ysig_unpack", k_ysig_unpack, dim3((unsigned)((P->d + 255) / 256), (unsigned)P->Tc), dim3(256), 0,
+               ctx->ysig.as<float4>(), P->d, T, dstp);
+        if (out_memspace != CNMFE_DEVICE)
+            CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     CK(hipStreamSynchronize(ctx->stream));
     return 0;

@@ -187,16 +187,15 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
         }
     }
     // ---- staging plan (frame-invariant) ----
-    uint32_t qoff[NIT]; int hidx[NIT]; float ymj[NIT];
+    uint32_t qoff[NIT]; int hidx[NIT];
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
         const int idx = tid + j * NT;
         const int hr = idx % HR, hc = idx / HR;
         const int rb = hr0 + hr, cb = hc0 + hc;
         const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
-        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 4u : ~0u;
+        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 16u : ~0u;
         hidx[j] = idx < NH ? hc * HRp + hr : -1;
-        ymj[j] = ld_off(a.ymean_f, in ? qoff[j] : 0u);
     }
     // ---- final-pass centre of this thread (threads < NC) ----
     const int fr = tid % TR, fc = (tid / TR) % TC;
@@ -209,24 +208,16 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
 
     const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
     const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
-    float pre[NIT][4];
-    auto issue = [&](int64_t t0) {
-        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
-        const float *y0 = a.Y + t0 * a.d_b;
-        const float *y1 = a.Y + (t0 + (nf > 1 ? 1 : 0)) * a.d_b;
-        const float *y2 = a.Y + (t0 + (nf > 2 ? 2 : nf - 1)) * a.d_b;
-        const float *y3 = a.Y + (t0 + (nf > 3 ? 3 : nf - 1)) * a.d_b;
+    float4 pre[NIT];
+    auto issue = [&](int64_t t0) {                      // one 16-byte load per staged pixel (4 frames)
+        const float4 *y4 = a.Y4 + (t0 >> 2) * a.d_b;
 #pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const uint32_t qo = qoff[j] == ~0u ? 0u : qoff[j];
-            pre[j][0] = ld_off(y0, qo); pre[j][1] = ld_off(y1, qo); pre[j][2] = ld_off(y2, qo); pre[j][3] = ld_off(y3, qo);
-        }
+        for (int j = 0; j < NIT; ++j) pre[j] = ld4_off(y4, qoff[j] == ~0u ? 0u : qoff[j]);
     };
     auto commit = [&](float4 *buf) {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const float ym = ymj[j];
-            float4 v = make_float4(pre[j][0] - ym, pre[j][1] - ym, pre[j][2] - ym, pre[j][3] - ym);
+            float4 v = pre[j];
             if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (hidx[j] >= 0) buf[hidx[j]] = v;
         }
@@ -236,7 +227,6 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
     __syncthreads();
     int cur = 0;
     for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
-        const int nf = (int)(tend - t0 < 4 ? tend - t0 : 4);
         const bool more = t0 + 4 < tend;
         if (more) issue(t0 + 4);
         const float4 *hb = halo + cur * NHp + hbase;
@@ -263,11 +253,9 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
                     c.x = fmaf(v, c4.x, c.x); c.y = fmaf(v, c4.y, c.y); c.z = fmaf(v, c4.z, c.z); c.w = fmaf(v, c4.w, c.w);
                 }
             }
-            float *o = a.Ysig + t0 * a.d;
-            st_off(o, fmb, c.x + dl - ((p0.x + p1.x) + (p2.x + p3.x)));
-            if (nf > 1) st_off(o + a.d, fmb, c.y + dl - ((p0.y + p1.y) + (p2.y + p3.y)));
-            if (nf > 2) st_off(o + 2 * a.d, fmb, c.z + dl - ((p0.z + p1.z) + (p2.z + p3.z)));
-            if (nf > 3) st_off(o + 3 * a.d, fmb, c.w + dl - ((p0.w + p1.w) + (p2.w + p3.w)));
+            st4_off(a.Ysig4 + (t0 >> 2) * a.d, fmb * 4u,
+                    make_float4(c.x + dl - ((p0.x + p1.x) + (p2.x + p3.x)), c.y + dl - ((p0.y + p1.y) + (p2.y + p3.y)),
+                                c.z + dl - ((p0.z + p1.z) + (p2.z + p3.z)), c.w + dl - ((p0.w + p1.w) + (p2.w + p3.w))));
         }
         if (more) commit(halo + (cur ^ 1) * NHp);
         cur ^= 1;
