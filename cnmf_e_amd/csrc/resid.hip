@@ -104,6 +104,7 @@ struct R1Args {
     const int *wa_cnt; const int *wa_k; const float *wa_v; const float *Cc; int64_t ldc;
     float4 *Ysig4;                   // output, [T/4][d] float4
     int ntile_r;
+    const int *tile_map;         // dispatch slot -> tile_r | tile_c << 16 (XCD-compact order, built on the host)
 };
 
 // compile-time ring of get_nhood(R) in MATLAB find() order (column offset slow, row offset fast)
@@ -174,10 +175,8 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     const int tid = threadIdx.x;
     // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous range of tiles
     // (column-major over the tile grid) so that the halos neighbouring tiles share stay in one L2.
-    int bid = blockIdx.x;
-    const int ntile = gridDim.x;
-    if (ntile % 8 == 0) bid = (bid % 8) * (ntile / 8) + bid / 8;
-    const int tile_r = bid % a.ntile_r, tile_c = bid / a.ntile_r;
+    const int tmap = a.tile_map[blockIdx.x];
+    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
     const int tr = tid % TR, tc = tid / TR;
     const int pr = tile_r * TR + tr, pc = tile_c * TC + tc;
     const bool valid = pr < a.nr && pc < a.nc;
@@ -316,6 +315,33 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     }
 }
 
+// Dispatch order of the tiles.  Workgroup b of a launch runs on XCD b % 8 and each XCD starts its workgroups in
+// order, 32 resident at a time (one per CU: the halo buffers fill the LDS).  The 32 tiles an XCD works on
+// together stream the same frames at the same pace, so the halo pixels they share are fetched from the fabric
+// once and served from that XCD's L2 afterwards: the fabric-side read amplification is the halo'd area of the
+// *union* of those 32 tiles over its own area.  order 1 therefore hands every XCD compact, near-square groups
+// of 32 tiles (super-tiles); order 0 is the plain column-major strip.
+static int build_tile_map(cnmfe_ctx *ctx, DevBuf &buf, int ntr, int ntc, int TR, int TC, int h, int order) {
+    const int n = ntr * ntc;
+    std::vector<int32_t> logical; logical.reserve(n);
+    if (order == 0) {
+        for (int c = 0; c < ntc; ++c) for (int r = 0; r < ntr; ++r) logical.push_back(r | (c << 16));
+    } else {
+        int sr = 32, sc = 1; double best = 1e300;
+        for (int a2 = 1; a2 <= 32; a2 *= 2) {
+            const int b2 = 32 / a2;
+            const double area = (double)(std::min(a2, ntr) * TR + 2 * h) * (std::min(b2, ntc) * TC + 2 * h);
+            if (area < best) { best = area; sr = a2; sc = b2; }
+        }
+        for (int C = 0; C < ntc; C += sc) for (int Rr = 0; Rr < ntr; Rr += sr)
+            for (int c = C; c < std::min(C + sc, ntc); ++c) for (int r = Rr; r < std::min(Rr + sr, ntr); ++r)
+                logical.push_back(r | (c << 16));
+    }
+    std::vector<int32_t> map(n);
+    for (int b = 0; b < n; ++b) map[b] = logical[n % 8 == 0 ? (b % 8) * (n / 8) + b / 8 : b];
+    return to_dev(ctx, buf, map.data(), map.size());
+}
+
 // ---- generic kernel: any ring (runtime offsets, weights streamed from L2) --------------------------
 template <bool HAS_AC>
 __global__ void __launch_bounds__(256) k_residual_gen(R1Args a) {
@@ -376,7 +402,9 @@ static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac
     if constexpr (R == 15) {                              // arc kernel: radius 15 only (16-bit ds_read immediates, LDS size)
         if (variant == 5) return launch_r1_arc<R, 4>(ctx, a, has_ac, ntile_c, nseg);
         if (variant == 6) return launch_r1_arc<R, 2>(ctx, a, has_ac, ntile_c, nseg);
-        if (variant == 7) return launch_r1_arc<R, 2, 1>(ctx, a, has_ac, ntile_c, nseg);      // ablation: staging + stores only
+        if (variant == 7) return launch_r1_arc<R, 2, 1, 3>(ctx, a, has_ac, ntile_c, nseg);   // ablation: staging + stores only, 3 chunks in flight
+        if (variant == 8) return launch_r1_arc<R, 4, 0, 2>(ctx, a, has_ac, ntile_c, nseg);   // 2 chunks in flight
+        if (variant == 9) return launch_r1_arc<R, 4, 0, 3>(ctx, a, has_ac, ntile_c, nseg);   // 3 chunks in flight
     }
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
@@ -393,7 +421,7 @@ static void tile_shape(int variant, int &TR, int &TC) {
     TR = 16; TC = 16;
     if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2) { TR = 32; TC = 16; }
     else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
-    else if (variant >= 5 && variant <= 7) { TR = ARC_TR; TC = ARC_TC; }
+    else if (variant >= 5 && variant <= 9) { TR = ARC_TR; TC = ARC_TC; }
 }
 
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
@@ -462,6 +490,8 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     a.tseg = tseg;
     int rc;
     if (special) {
+        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
+        a.tile_map = dOffs.as<int>();
         rc = h == 15 ? launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg) : launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);
     } else {
         std::vector<int32_t> offs(std::max(1, P->p), 0);

@@ -12,6 +12,7 @@
 // (vertical roles) and lane->row with a per-quarter rotation (horizontal roles) hit 16 distinct 16-byte slots in
 // every ds_read_b128 lane group.  Threads = 4 roles x 512/P.
 #pragma once
+#include <type_traits>
 
 namespace cnmfe {
 
@@ -130,7 +131,7 @@ __device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][
 #undef ARC_ADDR
 }
 
-template <int R, int P, bool HAS_AC, int ABL = 0>
+template <int R, int P, bool HAS_AC, int ABL = 0, int PD = 1>
 __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Args a) {
     constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC;             // 512 centres
     constexpr int NT = 4 * NC / P;                                    // threads
@@ -144,10 +145,8 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
     extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHp] | part[4][NC]
     float4 *halo = lds, *part = lds + 2 * NHp;
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
-    const int ntile = gridDim.x;
-    if (ntile % 8 == 0) bid = (bid % 8) * (ntile / 8) + bid / 8;      // XCD-aware tile order
-    const int tile_r = bid % a.ntile_r, tile_c = bid / a.ntile_r;
+    const int tmap = a.tile_map[blockIdx.x];                          // XCD-compact tile order (build_tile_map)
+    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
     const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
 
     // ---- role geometry ----
@@ -208,27 +207,31 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
 
     const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
     const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
-    float4 pre[NIT];
-    auto issue = [&](int64_t t0) {                      // one 16-byte load per staged pixel (4 frames)
+    // PD chunks of 16-byte loads are kept in flight: chunk c+PD is issued while chunk c is computed.  The chunk loop is
+    // unrolled PD times so that the PD register sets pre[s] are indexed statically.
+    float4 pre[PD][NIT];
+    auto issue = [&](auto slot, int64_t t0) {           // one 16-byte load per staged pixel (4 frames)
+        constexpr int S = decltype(slot)::value;
         const float4 *y4 = a.Y4 + (t0 >> 2) * a.d_b;
 #pragma unroll
-        for (int j = 0; j < NIT; ++j) pre[j] = ld4_off(y4, qoff[j] == ~0u ? 0u : qoff[j]);
+        for (int j = 0; j < NIT; ++j) pre[S][j] = ld4_off(y4, qoff[j] == ~0u ? 0u : qoff[j]);
     };
-    auto commit = [&](float4 *buf) {
+    auto commit = [&](auto slot, float4 *buf) {
+        constexpr int S = decltype(slot)::value;
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            float4 v = pre[j];
+            float4 v = pre[S][j];
             if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (hidx[j] >= 0) buf[hidx[j]] = v;
         }
     };
-    issue(tbeg);
-    commit(halo);
-    __syncthreads();
     int cur = 0;
-    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
+    // one chunk: halo[cur] holds chunk t0; pre[S] holds chunk t0+4 (if any); chunk t0+4*PD is issued into the slot that
+    // chunk t0's data just left, i.e. slot (S + PD - 1) % PD
+    auto step = [&](auto slot, int64_t t0) {
+        constexpr int S = decltype(slot)::value;
+        if (t0 + 4 * PD < tend) issue(std::integral_constant<int, (S + PD - 1) % PD>{}, t0 + 4 * PD);
         const bool more = t0 + 4 < tend;
-        if (more) issue(t0 + 4);
         const float4 *hb = halo + cur * NHp + hbase;
         f2 acc[P][2];
 #pragma unroll
@@ -257,13 +260,24 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
                     make_float4(c.x + dl - ((p0.x + p1.x) + (p2.x + p3.x)), c.y + dl - ((p0.y + p1.y) + (p2.y + p3.y)),
                                 c.z + dl - ((p0.z + p1.z) + (p2.z + p3.z)), c.w + dl - ((p0.w + p1.w) + (p2.w + p3.w))));
         }
-        if (more) commit(halo + (cur ^ 1) * NHp);
+        if (more) commit(slot, halo + (cur ^ 1) * NHp);      // chunk t0+4 lives in pre[S]
         cur ^= 1;
         __syncthreads();
+    };
+    // prologue: chunk 0 straight into halo[0]; chunks 1..PD-1 into slots 0..PD-2 (step<S> expects chunk t0+4 in pre[S])
+    issue(std::integral_constant<int, 0>{}, tbeg);
+    commit(std::integral_constant<int, 0>{}, halo);
+    if (PD > 1 && tbeg + 4 < tend) issue(std::integral_constant<int, 0>{}, tbeg + 4);        // PD-1 chunks in flight at loop entry
+    if (PD > 2 && tbeg + 8 < tend) issue(std::integral_constant<int, 1 % PD>{}, tbeg + 8);
+    __syncthreads();
+    for (int64_t t0 = tbeg; t0 < tend; t0 += 4 * PD) {
+        step(std::integral_constant<int, 0>{}, t0);
+        if (PD > 1 && t0 + 4 < tend) step(std::integral_constant<int, 1 % PD>{}, t0 + 4);
+        if (PD > 2 && t0 + 8 < tend) step(std::integral_constant<int, 2 % PD>{}, t0 + 8);
     }
 }
 
-template <int R, int P, int ABL = 0>
+template <int R, int P, int ABL = 0, int PD = 1>
 static int launch_r1_arc(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
     constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1;
     constexpr size_t shmem = (2 * (size_t)HRp * HC + 4 * (size_t)ARC_TR * ARC_TC) * sizeof(float4);
@@ -271,10 +285,10 @@ static int launch_r1_arc(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile
     static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
     constexpr int NT = 4 * ARC_TR * ARC_TC / P;
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
-    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, true, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, true, ABL>), grid, dim3(NT), shmem, a);
-    else        LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, false, ABL>), grid, dim3(NT), shmem, a);
+    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, true, ABL, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, false, ABL, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, true, ABL, PD>), grid, dim3(NT), shmem, a);
+    else        LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, false, ABL, PD>), grid, dim3(NT), shmem, a);
     return 0;
 }
 

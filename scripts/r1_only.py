@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="c3"); ap.add_argument("--variant", type=int, default=2); ap.add_argument("--ac", action="store_true")
-ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--reps", type=int, default=2); ap.add_argument("--order", type=int, default=1)
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -19,7 +19,7 @@ eng = Engine(0)
 video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
 video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
 eng.ring_init(0, r)
-eng.set_option("r1_variant", a.variant)
+eng.set_option("r1_variant", a.variant); eng.set_option("tile_order", a.order)
 eng.profile(True)
 A_b = f.A_init.astype(np.float32) if a.ac else None
 for _ in range(a.reps):

@@ -118,7 +118,7 @@ def test_residual_parity(eng, r, dims, pdims, T, with_ac):
         assert rel(got.T, ref) <= 1e-4, rel(got.T, ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9])
 def test_residual_variants_agree(eng, variant):
     c = Case(eng, 80, 72, 24, 4, 15, 3)
     rng = np.random.default_rng(2)
