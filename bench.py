@@ -157,6 +157,24 @@ def main():
                 "algorithmic_flops_per_launch": flops_alg,
                 "note": "algorithmic = 2*d*(p+1)^2*T/2 of the reference's per-pixel Gram (SURVEY 8(d)); the engine's "
                         "block-sparse SYRK executes fewer flops (see DESIGN.md), so frac may exceed the pipe utilisation"}
+    def pmc_traffic(kernel_substr):
+        """HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of THIS command (profiles/<round>/
+        *_pmc_FETCH_SIZE_*.csv, *_pmc_WRITE_SIZE_*.csv; separate passes, scripts/profile_round.sh).  FETCH_SIZE is
+        doubled: gfx950 reports 16-B/lane coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM section; calibrated
+        on bg_build_bf = one 10.5 GB sweep).  None when no summary for this config is present."""
+        import csv, glob
+        if a.config != "c3" or world != 1:
+            return None
+        tot = 0.0
+        for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_c3_pmc_%s_v*.csv" % counter)))
+            if not files:
+                return None
+            rows = [r_ for r_ in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")) if kernel_substr in r_["kernel"]]
+            if not rows:
+                return None
+            tot += mult * 1024.0 * sum(float(r_["value_per_launch_KiB"]) for r_ in rows) / len(rows)
+        return tot
     if dom.startswith("bg_gram"):
         roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else F32_MFMA_PEAK_TF)
     elif dom == "residual_r1":
@@ -164,6 +182,13 @@ def main():
     else:
         roof = {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": dom,
                 "ms_per_launch": kern[dom]["ms_per_call"]}
+    if roof.get("kernel", "").startswith("bg_gram"):
+        roof["traffic"] = pmc_traffic("k_gram")
+    r1r = r1_roof()
+    if r1r is not None:
+        r1r["traffic"] = pmc_traffic("k_residual")
+        if roof.get("kernel") == "residual_r1":
+            roof["traffic"] = r1r["traffic"]
     out = {
         "metric": "cnmfe_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -173,7 +198,7 @@ def main():
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
                    "parallelism": "patch-parallel x%d" % world},
         "roofline": roof,
-        "roofline_r1": r1_roof(),
+        "roofline_r1": r1r,
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
     }
     if not a.no_cpu_baseline and world == 1:
