@@ -32,6 +32,7 @@ struct BgGeom {
     int64_t d, d_b, T, Tp, Tpad;           // Tp frames used (stride kstride), padded to a multiple of 16
     int kstride;
     int p;
+    int bf4;                               // Bf layout: 0 = [blk][frame][256], 1 = [blk][frame/4][256][4] (k_gram4)
 };
 
 // ---- B1 ------------------------------------------------------------------------------------------
@@ -62,7 +63,8 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
                     v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
                 }
             }
-            out[tp * BLKPX] = v.x; out[(tp + 1) * BLKPX] = v.y; out[(tp + 2) * BLKPX] = v.z; out[(tp + 3) * BLKPX] = v.w;
+            if (g.bf4) reinterpret_cast<float4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = v;
+            else { out[tp * BLKPX] = v.x; out[(tp + 1) * BLKPX] = v.y; out[(tp + 2) * BLKPX] = v.z; out[(tp + 3) * BLKPX] = v.w; }
         }
     } else {                                       // frame subsampling Bf(:, 1:k:end)  (fit_ring_model.m:87)
         const float *Ys = reinterpret_cast<const float *>(Y4);
@@ -73,14 +75,22 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
                 v = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)];
                 for (int e = e0; e < e1; ++e) v -= aval[e] * Cc[(int64_t)acol[e] * ldc + t];
             }
-            out[tp * BLKPX] = v;
+            if (g.bf4) bf[(((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 4 + (tp & 3)] = v;
+            else out[tp * BLKPX] = v;
         }
     }
 }
 
 // row sums of Bf over the used frames (the "ones" row of X, fit_ring_model.m:101)
-__global__ void __launch_bounds__(256) k_rowsum(const float *__restrict__ bf, int64_t Tpad, double *__restrict__ rs) {
+__global__ void __launch_bounds__(256) k_rowsum(const float *__restrict__ bf, int64_t Tpad, double *__restrict__ rs, int bf4) {
     const int64_t blk = blockIdx.x;
+    if (bf4) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(bf) + blk * (Tpad >> 2) * BLKPX + threadIdx.x;
+        double s0 = 0, s1 = 0;
+        for (int64_t c = 0; c < (Tpad >> 2); ++c) { const float4 v = src4[c * BLKPX]; s0 += (double)v.x + (double)v.z; s1 += (double)v.y + (double)v.w; }
+        rs[blk * BLKPX + threadIdx.x] = s0 + s1;
+        return;
+    }
     const float *src = bf + blk * Tpad * BLKPX + threadIdx.x;
     double s0 = 0, s1 = 0;
     int64_t t = 0;
@@ -203,6 +213,284 @@ __global__ void __launch_bounds__(256, 2) k_gram2(const float *__restrict__ bf, 
                 out[(int64_t)(ih * 128 + i * 16 + rr) * BLKPX + jh * 128 + j * 16 + fl] = acc[sidx][r];
             }
         }
+}
+
+// ---- B2a v3: the same work items, operands staged by LDS-DMA ------------------------------------------
+// k_gram2 is bound by the latency x concurrency of its panel stream (one 16 KB stage per workgroup in flight,
+// ~8 MB chip-wide, 2.9 TB/s at ~2.8 us): its 247 VGPRs leave no room for deeper register staging.  Here the
+// stages go global -> LDS directly (global_load_lds_dwordx4, no VGPRs), GR_NBUF-1 stages ahead.  The DMA writes
+// LDS lane-linearly, so the row padding of v2 is replaced by a swizzle applied on the GLOBAL side: LDS row f
+// (frame) holds pixel (c ^ 16*(f&1)) at column c, which sends the four k-rows of an MFMA fragment to
+// alternating bank halves exactly like the 144-float stride did, and keeps every 512-B frame row coalesced.
+// The asm loads are invisible to hipcc's waitcnt bookkeeping: completion is counted by hand (vmcnt), then a raw
+// s_barrier publishes the stage; loads past the last stage are clamped, not skipped, so the count is uniform.
+constexpr int GR_NBUF = 4, GR_STAGE_F = 2 * GK * 128;          // floats per stage: A half + B half, [16][128] each
+
+__device__ __forceinline__ void glds16(const float *base, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+template <bool F32>
+__global__ void __launch_bounds__(256, 2) k_gram3(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
+                                                  const int *__restrict__ work, int nwork, const unsigned short *__restrict__ needmask,
+                                                  int flush_every, double *__restrict__ cov) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // the ONLY LDS object (a second one de-pipelines the DMA)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    if (bid >= nwork) return;
+    const int wk = work[bid];
+    const int pair = wk >> 2, quad = wk & 3;
+    const int ih = quad & 1, jh = quad >> 1;
+    const int4 pr = pairs[pair];
+    const float *gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 128;
+    const float *gB = bf + ((int64_t)pr.y * Tpad) * BLKPX + jh * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned need = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx) {
+        const int i = sidx >> 1, j = ((wave + i) & 3) + 4 * (sidx & 1);
+        need |= ((needmask[pr.z * 16 + ih * 8 + i] >> (jh * 8 + j)) & 1u) << sidx;
+    }
+    need = __builtin_amdgcn_readfirstlane(need);
+    const bool probe = (flush_every >> 16) != 0; flush_every &= 0xffff;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    // DMA geometry: one wave-instruction = 64 lanes x 16 B = two frame rows of a 128-pixel half.  Wave w moves
+    // frame pairs w and w+4 of both halves.  Lane: row fr = lane>>5, 4-pixel group g = lane&31, swizzled source.
+    const int fr = lane >> 5, gq = lane & 31;
+    const unsigned vo0 = (unsigned)(((2 * wave + fr) * BLKPX + ((gq ^ (4 * fr)) * 4)) * 4);
+    const unsigned vo1 = vo0 + 8u * BLKPX * 4u;
+    const unsigned dA0 = lds0 + (unsigned)wave * 1024u, dA1 = dA0 + 4096u, dB0 = dA0 + 8192u, dB1 = dA0 + 12288u;
+    const int nst = (int)(Tpad / GK);
+    auto issue = [&](int st) {
+        int sc = st < nst ? st : nst - 1;                               // clamp: keeps the vmcnt arithmetic uniform
+        if (probe) sc = 0;                                              // A/B probe: every stage re-reads stage 0 (no fabric traffic)
+        const float *sa = gA + (int64_t)sc * GK * BLKPX, *sb = gB + (int64_t)sc * GK * BLKPX;
+        const unsigned bo = (unsigned)(st & (GR_NBUF - 1)) * (GR_STAGE_F * 4u);
+        glds16(sa, vo0, dA0 + bo); glds16(sa, vo1, dA1 + bo);
+        glds16(sb, vo0, dB0 + bo); glds16(sb, vo1, dB1 + bo);
+    };
+    double4_t acc[16];
+    float4_t facc[16];
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx) { acc[sidx] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sidx] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+    const int fl = lane & 15, fk = lane >> 4, par = fk & 1;
+    // fragment read bases (floats): row fk, column (tile ^ par)*16 + fl  ->  even/odd tile pointers
+    const int rbase = fk * 128 + fl;
+    const int aE = rbase + (par ? 16 : 0), aO = rbase + (par ? 0 : 16);
+    int bo8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = ((wave + (q & 3)) & 3) + 4 * (q >> 2);
+        bo8[q] = GK * 128 + rbase + ((j ^ par) * 16);
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < GR_NBUF - 1; ++s0) issue(s0);
+    int since = 0;
+    for (int st = 0; st < nst; ++st) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * (GR_NBUF - 2)) : "memory");    // this wave's part of stage st has landed
+        __builtin_amdgcn_s_barrier();                                                // ... and everybody else's; buffer st-1 is free
+        asm volatile("" ::: "memory");
+        issue(st + GR_NBUF - 1);
+        if (need) {
+            const float *sb_ = smem + (st & (GR_NBUF - 1)) * GR_STAGE_F;
+            // fragments of k-step kk+4 are issued before the MFMAs of k-step kk; the empty asm makes the current
+            // 16 fragments "used" at this point, so hipcc cannot sink each ds_read next to its (conditional) MFMA
+            // and wait out one LDS latency per sub-tile (it did: 16 x lgkmcnt(0) in the first k-step)
+            float fr_[2][16];
+            auto ldfrag = [&](float *f, int kk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = sb_[kk * 128 + ((i & 1) ? aO : aE) + (i & ~1) * 16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[8 + q] = sb_[kk * 128 + bo8[q]];
+            };
+            ldfrag(fr_[0], 0);
+#pragma unroll
+            for (int kk = 0; kk < GK; kk += 4) {
+                float *f = fr_[(kk >> 2) & 1];
+                if (kk + 4 < GK) ldfrag(fr_[((kk >> 2) + 1) & 1], kk + 4);
+                asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                                  "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
+#pragma unroll
+                for (int sidx = 0; sidx < 16; ++sidx)
+                    if ((need >> sidx) & 1u) {
+                        const float b = f[8 + ((sidx >> 1) & 3) + 4 * (sidx & 1)];
+                        if (F32) facc[sidx] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[sidx >> 1], b, facc[sidx], 0, 0, 0);
+                        else acc[sidx] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)f[sidx >> 1], (double)b, acc[sidx], 0, 0, 0);
+                    }
+            }
+            if (F32 && (++since == flush_every || st + 1 == nst)) {
+                since = 0;
+#pragma unroll
+                for (int sidx = 0; sidx < 16; ++sidx)
+                    if ((need >> sidx) & 1u) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[sidx][r] += (double)facc[sidx][r];
+                        facc[sidx] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the clamped tail loads before the LDS is released
+    double *out = cov + (int64_t)pair * BLKPX * BLKPX;
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx)
+        if ((need >> sidx) & 1u) {
+            const int i = sidx >> 1, j = ((wave + i) & 3) + 4 * (sidx & 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = F32 ? ((lane >> 4) * 4 + r) : ((lane >> 4) + 4 * r);
+                out[(int64_t)(ih * 128 + i * 16 + rr) * BLKPX + jh * 128 + j * 16 + fl] = acc[sidx][r];
+            }
+        }
+}
+
+// ---- B2a v4: dense tile slots --------------------------------------------------------------------------
+// v2/v3 run at 77 TF/s although neither the fabric (probe: every stage re-reading stage 0 changes nothing) nor
+// the LDS latency bounds them: a wave owns a FIXED 16-slot pattern of the quadrant and tests `need` per slot, and
+// hipcc turns that into two scalar branches per MFMA -- the issue stream, not the matrix pipe, is saturated, and
+// the four waves of a workgroup are unevenly loaded (84 %).  Here the host lists the needed 16x16 sub-tiles of
+// every (displacement class, quadrant); tile t of an item goes to wave t%4, slot t/4, so slots are dense, the
+// waves are balanced to within one tile, and the stage body is straight-line code instantiated per slot count.
+// Bf is stored [block][frame/4][256][4] (like the resident video): a lane's A (or B) fragment for ALL FOUR
+// k-steps of a 16-frame stage is ONE conflict-free ds_read_b128 (lane (l&15, l>>4) reads quad-row l>>4: MFMA m
+// contracts frames {4*(l>>4) + m}), at lane base + a per-slot scalar tile offset.
+constexpr int G4_NBUF = 4, G4_STAGE_F = 2 * GK * 128, G4_MAXSLOT = 16;
+
+struct G4Wave {                       // per-wave constants of a work item (all wave-uniform except lbase, vo0, vo1)
+    const float *gA, *gB;
+    unsigned vo0, vo1, dA0;
+    int lbase, nst, flush_every, ns, lane;
+    double *out;                      // cov + pair*256*256 + (ih*128)*256 + jh*128
+};
+
+// the whole stage loop for a wave that owns NS slots (the last one only if `ns == NS`): instantiated per NS and
+// selected ONCE per workgroup, so the loop body is branch-free straight-line code with its own register allocation
+// (a switch inside the loop made hipcc keep the fp64 shadows in scratch: 456 spilled VGPRs)
+template <bool F32, int NS>
+__device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, const int *__restrict__ tlw) {
+    int ao[NS], bo[NS], ti[NS], tj[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const int code = __builtin_amdgcn_readfirstlane(sl < w.ns ? tlw[sl * 4] : 0);
+        ti[sl] = code & 7; tj[sl] = code >> 4;
+        ao[sl] = ti[sl] * 64; bo[sl] = GK * 128 + tj[sl] * 64;
+    }
+    const bool last = w.ns == NS;
+    auto issue = [&](int st) {
+        const int sc = st < w.nst ? st : w.nst - 1;                      // clamp: keeps the vmcnt arithmetic uniform
+        const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
+        const unsigned d = w.dA0 + (unsigned)(st & (G4_NBUF - 1)) * (G4_STAGE_F * 4u);
+        glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
+        glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
+    };
+    double4_t acc[NS];
+    float4_t facc[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) { acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s0 = 0; s0 < G4_NBUF - 1; ++s0) issue(s0);
+    int since = 0;
+    for (int st = 0; st < w.nst; ++st) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * (G4_NBUF - 2)) : "memory");    // this wave's part of stage st has landed
+        __builtin_amdgcn_s_barrier();                                                // ... and everybody else's; buffer st-1 is free
+        asm volatile("" ::: "memory");
+        issue(st + G4_NBUF - 1);
+        int lb = w.lbase;
+        asm volatile("" : "+v"(lb));            // opaque per stage: no hoisting of 2*NS per-slot address VGPRs out of the loop
+        const float *lp = smem + (st & (G4_NBUF - 1)) * G4_STAGE_F + lb;
+        // fragments are fetched two slots ahead; the compiler barrier pins each fetch between its neighbours' MFMAs
+        float4 fa[3], fb[3];
+        auto ld = [&](int sl) {
+            fa[sl % 3] = *reinterpret_cast<const float4 *>(lp + ao[sl]);
+            fb[sl % 3] = *reinterpret_cast<const float4 *>(lp + bo[sl]);
+        };
+        ld(0);
+        if (NS > 1) ld(1);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            if (sl + 2 < NS) ld(sl + 2);
+            asm volatile("" ::: "memory");
+            if (sl == NS - 1 && !last) break;
+            const float4 a4 = fa[sl % 3], b4 = fb[sl % 3];
+            if (F32) {
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, facc[sl], 0, 0, 0);
+            } else {
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.x, (double)b4.x, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.y, (double)b4.y, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.z, (double)b4.z, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.w, (double)b4.w, acc[sl], 0, 0, 0);
+            }
+        }
+        if (F32 && (++since == w.flush_every || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
+            since = 0;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[sl][r] += (double)facc[sl][r];
+                facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the clamped tail loads before the LDS is released
+    const int fl = w.lane & 15;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+        if (sl < NS - 1 || last) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // D layouts: fp32 16x16 -> row = (lane>>4)*4 + r ; fp64 16x16 -> row = (lane>>4) + 4*r
+                const int rr = F32 ? ((w.lane >> 4) * 4 + r) : ((w.lane >> 4) + 4 * r);
+                w.out[(int64_t)(ti[sl] * 16 + rr) * BLKPX + tj[sl] * 16 + fl] = acc[sl][r];
+            }
+        }
+}
+
+template <bool F32>
+__global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
+                                                  const int *__restrict__ work, int nwork, const int *__restrict__ tl_cnt,
+                                                  const int *__restrict__ tl, int flush_every, double *__restrict__ cov) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // the ONLY LDS object (a second one de-pipelines the DMA)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    if (bid >= nwork) return;
+    const int wk = work[bid];
+    const int pair = wk >> 2, quad = wk & 3;
+    const int ih = quad & 1, jh = quad >> 1;
+    const int4 pr = pairs[pair];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lidx = pr.z * 4 + quad;
+    const int cnt = __builtin_amdgcn_readfirstlane(tl_cnt[lidx]);
+    G4Wave w;
+    w.gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 512;             // a quad-row is 256 px x 4 frames; half ih starts at px 128
+    w.gB = bf + ((int64_t)pr.y * Tpad) * BLKPX + jh * 512;
+    // DMA: one wave-instruction = 64 px x 4 frames (1 KB) of one quad-row.  Per half and stage: 4 quad-rows x 2 = 8
+    // instructions; wave w moves instruction w (quad-row w>>1, pixels (w&1)*64..) and w+4 (quad-row 2 + (w>>1)).
+    w.vo0 = (unsigned)((((wave >> 1) * BLKPX + (wave & 1) * 64 + lane) * 4) * 4);
+    w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
+    w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
+    w.lbase = (lane >> 4) * 512 + (lane & 15) * 4;                     // quad-row l>>4, pixel l&15 of the tile, 4 frames
+    w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
+    w.ns = cnt > wave ? (cnt - wave + 3) >> 2 : 0;                     // this wave's slots: tiles wave, wave+4, ...
+    w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX + jh * 128;
+    const int *tlw = tl + lidx * 64 + wave;
+    switch ((cnt + 3) >> 2) {                                          // slots of the busiest wave; the others skip the last one
+#define G4_CASE(N) case N: gram4_run<F32, N>(w, smem, tlw); break;
+        G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
+        G4_CASE(9) G4_CASE(10) G4_CASE(11) G4_CASE(12) G4_CASE(13) G4_CASE(14) G4_CASE(15) G4_CASE(16)
+#undef G4_CASE
+        default: break;
+    }
 }
 
 // ---- helpers on the covariance table ----------------------------------------------------------------
@@ -536,6 +824,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.d = P->d; g.d_b = P->d_b; g.T = T; g.kstride = kstride;
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
     g.Tpad = (g.Tp + GK - 1) / GK * GK;
+    g.bf4 = ctx->opt("gram_kernel", 4) == 4 ? 1 : 0;
     g.p = p;
     const int nblk = g.nbr * g.nbc;
 
@@ -568,7 +857,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk);
         RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>());
+        LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>(), g.bf4);
         // ---- pair list: blocks that hold ring pixels of some patch pixel, displacement within +-2 ----
         // a block is "touched" if it lies within one block of a block containing patch pixels
         std::vector<char> touched(nblk, 0);
@@ -635,7 +924,50 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(ctx->cov.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
         if (ctx->opt("debug", 0)) CK(hipMemsetAsync(ctx->cov.p, 0xff, (size_t)npairs * BLKPX * BLKPX * sizeof(double), ctx->stream));   // NaN-poison skipped sub-tiles
         int nwg = (nwork + 7) / 8 * 8;                      // multiple of 8 for the XCD remap (extra workgroups exit)
-        if (ctx->opt("gram_mode", 2) == 2)
+        const bool f32s = ctx->opt("gram_mode", 2) == 2;
+        if (g.bf4) {
+            // tile lists per (displacement class, quadrant): needed 16x16 sub-tiles as i | j << 4 (quadrant coordinates)
+            std::vector<int> tcnt(NREL * 4, 0);
+            std::vector<int> tlist((size_t)NREL * 4 * 64, 0);
+            for (int rel = 0; rel < NREL; ++rel)
+                for (int q = 0; q < 4; ++q) {
+                    const int ih = q & 1, jh = q >> 1;
+                    int n = 0;
+                    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j)
+                        if ((needmask[rel * 16 + ih * 8 + i] >> (jh * 8 + j)) & 1) tlist[(size_t)(rel * 4 + q) * 64 + n++] = i | (j << 4);
+                    tcnt[rel * 4 + q] = n;
+                }
+            DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
+            RET(to_dev(ctx, dTcnt, tcnt.data(), tcnt.size()));
+            RET(to_dev(ctx, dTl, tlist.data(), tlist.size()));
+            const size_t shmem = (size_t)G4_NBUF * G4_STAGE_F * sizeof(float);
+            static bool attr4 = false;
+            if (!attr4) {
+                CK(hipFuncSetAttribute((const void *)k_gram4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                CK(hipFuncSetAttribute((const void *)k_gram4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                attr4 = true;
+            }
+            if (f32s)
+                LAUNCH(ctx, "bg_gram_f32s", k_gram4<true>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), (int)ctx->opt("gram_flush", 4), ctx->cov.as<double>());
+            else
+                LAUNCH(ctx, "bg_gram_f64", k_gram4<false>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), 0, ctx->cov.as<double>());
+        } else if (ctx->opt("gram_kernel", 4) == 3) {
+            const size_t shmem = (size_t)GR_NBUF * GR_STAGE_F * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                CK(hipFuncSetAttribute((const void *)k_gram3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                CK(hipFuncSetAttribute((const void *)k_gram3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                attr_set = true;
+            }
+            if (f32s)
+                LAUNCH(ctx, "bg_gram_f32s", k_gram3<true>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16), ctx->cov.as<double>());
+            else
+                LAUNCH(ctx, "bg_gram_f64", k_gram3<false>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dNeed.as<unsigned short>(), 0, ctx->cov.as<double>());
+        } else if (f32s)
             LAUNCH(ctx, "bg_gram_f32s", k_gram2<true>, dim3(nwg), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                    dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4), ctx->cov.as<double>());
         else

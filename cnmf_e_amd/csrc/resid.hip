@@ -492,12 +492,14 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     if (special) {
         RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
         a.tile_map = dOffs.as<int>();
+        CK(hipStreamSynchronize(ctx->stream));           // the host-side staging vectors die with this call; the stream is near-idle here
         rc = h == 15 ? launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg) : launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);
     } else {
         std::vector<int32_t> offs(std::max(1, P->p), 0);
         for (int i = 0; i < P->p; ++i) offs[i] = P->dc[i] * HR + P->dr[i];
         RET(to_dev(ctx, dOffs, offs.data(), offs.size()));
         a.offs = dOffs.as<int>();
+        CK(hipStreamSynchronize(ctx->stream));
         size_t shmem = (size_t)HR * HC * sizeof(float4);
         if (shmem > 160 * 1024) return fail(CNMFE_EUNSUPPORTED, "ring radius %d needs %zu B of LDS per tile", h, shmem);
         if (shmem > 64 * 1024) {
@@ -518,8 +520,10 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
                ctx->ysig.as<float4>(), P->d, T, dstp);
         if (out_memspace != CNMFE_DEVICE)
             CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
     }
-    CK(hipStreamSynchronize(ctx->stream));
+    // without an output buffer the call returns with the kernel in flight: every consumer of Ysig is an engine
+    // call on the same stream, so the caller's host work overlaps the sweep (include/cnmfe.h, cnmfe_residual)
     return 0;
 }
 

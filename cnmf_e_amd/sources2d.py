@@ -162,6 +162,7 @@ class PatchedVideo:
         self.patch_pix = {idx: _rect_pixels(self.patch_pos[idx], d1) for idx in self.order}
         self.block_pix = {idx: _rect_pixels(self.block_pos[idx], d1) for idx in self.order}
         self.ind_patch = {}
+        self._halo = {}
         for idx in self.order:
             p, b = self.patch_pos[idx], self.block_pos[idx]
             mask = np.zeros((b[1] - b[0] + 1, b[3] - b[2] + 1), dtype=bool)
@@ -169,6 +170,13 @@ class PatchedVideo:
             self.ind_patch[idx] = np.nonzero(mask.reshape(-1, order="F"))[0]
         for idx in self.owned:
             engine.create_patch(self.pid[idx], self.patch_pos[idx], self.block_pos[idx], d1, d2, T)
+
+    def halo_pix(self, idx):
+        """block pixels outside the patch (mask==1 in update_spatial_parallel.m:84-85), cached"""
+        h = self._halo.get(idx)
+        if h is None:
+            h = self._halo[idx] = np.setdiff1d(self.block_pix[idx], self.patch_pix[idx], assume_unique=True)
+        return h
 
     def upload_from_full(self, Y_td, chunk=512):
         """Y_td: (T, d1*d2) host video, frame-major / pixels column-major (MATLAB d x T)."""
@@ -207,7 +215,7 @@ class Sources2D:
         self.A_prev = self.A          # snapshots: A and C are only ever REPLACED by the update methods, never mutated in place
         self.C_prev = self.C
         self.P = {"sn": np.asarray(sn, dtype=np.float32).reshape(-1).copy(), "Ymean": {}}
-        self.b0_new = None
+        self._b0_new_val = None; self._b0_new_src = None
         self.dist = dist_group
         for idx in video.owned:                                           # initComponents_parallel.m:213-236
             self.engine.ring_init(video.pid[idx], options.ring_radius, options.num_neighbors)
@@ -282,9 +290,24 @@ class Sources2D:
         return C_raw.cpu().numpy()
 
     def _update_b0_new(self):
-        v = self.video
-        self.b0_new = (self.ymean_full() - np.asarray(self.A @ self._cmean()).ravel()) \
-            .reshape(v.d1, v.d2, order="F")                               # update_spatial_parallel.m:349
+        """obj.b0_new = Ymean - A*mean(C,2) (update_spatial_parallel.m:349).  Evaluated on first read from the
+        (A, C) of this moment -- both are replaced, never mutated, so holding the references is a snapshot."""
+        self.ymean_full()                                                 # (collective when sharded: keep it eager)
+        self._b0_new_src = (self.A, self.C)
+
+    @property
+    def b0_new(self):
+        if self._b0_new_src is not None:
+            A, Cm = self._b0_new_src
+            v = self.video
+            cm = self._cmean() if Cm is self.C else Cm.mean(axis=1, dtype=np.float64)
+            self._b0_new_val = (self.ymean_full() - np.asarray(A @ cm).ravel()).reshape(v.d1, v.d2, order="F")
+            self._b0_new_src = None
+        return self._b0_new_val
+
+    @b0_new.setter
+    def b0_new(self, val):
+        self._b0_new_val, self._b0_new_src = val, None
 
     def deconvTemporal(self):
         """@Sources2D/deconvTemporal.m:29-105: deconvolve every row of C_raw again (fresh time constants); sets
@@ -342,31 +365,37 @@ class Sources2D:
         v, o = self.video, self.options
         if o.search_method != "ellipse":
             raise NotImplementedError("only search_method='ellipse' is built")
-        IND = self._search_location_owned()                                                      # :66
-        IND_csr = IND.tocsr()
-        A_csr = self.A.tocsr()
         Aprev_csr = self.A_prev.tocsr()
         K = self.A.shape[1]
         rows, cols, vals = [], [], []
+        IND_csr = A_csr = None
         for idx in v.owned:
             pp, bp, ip = v.patch_pix[idx], v.block_pix[idx], v.ind_patch[idx]
-            INDp = IND_csr[pp]
-            ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]                          # :87
-            if ind.size == 0:
-                continue                                                                             # :121-124
-            A_patch = A_csr[pp][:, ind].tocsc()                                                     # :88,199
-            IND_patch = INDp[:, ind].tocsc()                                                        # :89
-            sn_patch = self.P["sn"][pp]                                                             # :90
-            C_patch = self.C[ind]                                                                   # :91
             # A_prev restricted to neurons that touch the HALO only (mask==1 after the patch is set to 2, :84-85,96)
-            halo = np.setdiff1d(bp, pp, assume_unique=True)
+            halo = v.halo_pix(idx)
             if halo.size:
                 indp = np.nonzero(np.asarray(Aprev_csr[halo].sum(axis=0)).ravel() > 0)[0]
             else:
                 indp = np.zeros(0, dtype=np.int64)
             A_prev_b = Aprev_csr[bp][:, indp].tocsc() if indp.size else None                        # :97
             C_prev_b = self.C_prev[indp] if indp.size else None                                     # :98
-            self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                    # :162-166
+            launched = IND_csr is None
+            if launched:
+                # the residual sweep (:162-166) does not depend on the search mask: start it (the call returns with
+                # the kernel in flight) and build IND (:66) on the host underneath it
+                self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)
+                IND_csr = self._search_location_owned().tocsr()
+                A_csr = self.A.tocsr()
+            INDp = IND_csr[pp]
+            ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]                          # :87
+            if ind.size == 0:
+                continue                                                                             # :121-124
+            if not launched:
+                self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                # :162-166
+            A_patch = A_csr[pp][:, ind].tocsc()                                                     # :88,199
+            IND_patch = INDp[:, ind].tocsc()                                                        # :89
+            sn_patch = self.P["sn"][pp]                                                             # :90
+            C_patch = self.C[ind]                                                                   # :91
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
             Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                               sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
@@ -433,7 +462,7 @@ class Sources2D:
         K, T = self.C.shape
         A_csr = self.A.tocsr()
         Aprev_csr = self.A_prev.tocsr()
-        acc = np.zeros((K, T), dtype=np.float32)                           # sum over patches of aa .* C_raw  (:274)
+        acc = None                                                         # sum over patches of aa .* C_raw  (:274)
         aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
@@ -451,19 +480,28 @@ class Sources2D:
                 _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)
             else:
                 _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)   # :180-181
-            acc[ind] += C_raw_p * aa_p[:, None]                                                      # :274
+            contrib = C_raw_p * aa_p[:, None].astype(np.float32)                                     # :274
+            if acc is None and ind.size == K:
+                acc = contrib                                              # first patch sees every neuron: no scatter-add needed
+            else:
+                if acc is None:
+                    acc = np.zeros((K, T), dtype=np.float32)
+                acc[ind] += contrib
             aa_tot[ind] += aa_p                                                                      # :275
+        if acc is None:
+            acc = np.zeros((K, T), dtype=np.float32)
         if self.dist is not None and v.world_size > 1:                    # the overlap-region stitch: ONE all-reduce
             C_raw = self._stitch_distributed(acc, aa_tot)
         else:
             aa_tot[aa_tot == 0] = 1                                                                   # :279
-            C_raw = acc / aa_tot[:, None].astype(np.float32)                                         # :280
+            C_raw = acc
+            C_raw /= aa_tot[:, None].astype(np.float32)                                              # :280
         if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.deconvTemporal()
         else:
             if not (self.dist is not None and v.world_size > 1):
-                C_raw = C_raw - C_raw.min(axis=1, keepdims=True)                                     # :285
+                C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.C_raw                                                                       # :286
         self._update_b0_new()                                                                         # :291-295

@@ -103,7 +103,9 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
  *   Ysig = Y(ind_patch,:) - W*(Y - A_prev*C_prev) - (b0 - W*mean(Y - A_prev*C_prev, 2))
  * update_spatial_parallel.m:162-166 == update_temporal_parallel.m:149-152.
  * A_prev is d_b x Ksel CSC (block rows), C_prev Ksel x T.  The result (d x T fp32,
- * frame-major) stays resident for the HALS/NNLS calls below; Ysig_out may be NULL. */
+ * frame-major) stays resident for the HALS/NNLS calls below; Ysig_out may be NULL, and then
+ * the call returns with the sweep still running on the context's stream (all inputs have been
+ * consumed; later calls on this context are stream-ordered behind it and report its errors). */
 int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_colptr,
                    const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                    float *Ysig_out, int out_memspace);
