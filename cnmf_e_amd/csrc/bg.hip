@@ -32,6 +32,7 @@ struct BgGeom {
     int64_t d, d_b, T, Tp, Tpad;           // Tp frames used (stride kstride), padded to a multiple of 16
     int kstride;
     int p;
+    int p_radius, nbw;                     // largest |offset| of the ring; blocks per side of the (2*radius+1)-pixel window
     int bf4;                               // Bf layout: 0 = [blk][frame][256], 1 = [blk][frame/4][256][4] (k_gram4)
 };
 
@@ -614,15 +615,27 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+// 1/sqrt(x) in fp64: hardware seed (v_rsq_f64, ~2^-26) + two Newton steps.  The library sqrt + divide of the
+// pivot cost ~100 fp64 instructions per column on the critical path of wave 0 (97 columns per pixel).
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
 
 __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
                                                      const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
-                                                     float *__restrict__ W) {
+                                                     float *__restrict__ W, int probe) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = g.p, n = p + 1, na = n + 1;
     double *L = sm;                                   // rows 0..n packed; row n = [g ; unused]
     double *red = sm + tri(na);                       // 4 partial traces
-    int *nb = reinterpret_cast<int *>(red + 4);       // p neighbour codes
+    double *dinv = red + 4;                           // 1 / L(j,j), na entries
+    int *nb = reinterpret_cast<int *>(dinv + na);     // p neighbour codes
+    int *node = nb + p;                               // p+1 node codes (block-local), see the assembly
+    int *pt = node + p + 1;                           // nbw^4 block-pair codes
     const int64_t m = blockIdx.x;
     if (active && !active[m]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -634,27 +647,69 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
     }
     __syncthreads();
     auto rsum = [&](int rb, int cb) { return rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + lp_of(rb & 15, cb & 15)]; };
-    // ---- assemble (flat index over the packed triangle: independent lookups, 19 per thread) ----
-    const int ne = tri(na);
-    for (int e = tid; e < ne; e += 256) {
-        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (tri(i + 1) <= e) ++i;
-        while (tri(i) > e) --i;
-        const int j = e - tri(i);
-        double v;
-        if (i < p) {
-            const int ni = nb[i], nj = nb[j];
-            if (ni < 0 || nj < 0) v = (i == j) ? 1.0 : 0.0;
-            else v = cov_lookup(tab, ni & 0xffff, ni >> 16, nj & 0xffff, nj >> 16);
-        } else if (i == p) {                           // the row of ones (fit_ring_model.m:101)
-            if (j < p) { const int nj = nb[j]; v = nj < 0 ? 0.0 : rsum(nj & 0xffff, nj >> 16); }
-            else v = (double)g.Tp;
-        } else {                                       // right-hand side X*y' (:104)
-            if (j < p) { const int nj = nb[j]; v = nj < 0 ? 0.0 : cov_lookup(tab, nj & 0xffff, nj >> 16, rbm, cbm); }
-            else if (j == p) v = rsum(rbm, cbm);
-            else v = 0.0;
+    // ---- assemble the packed triangle ----
+    // The p ring neighbours and the centre (node p) lie within a 31x31 window = at most 3x3 16x16 blocks.  The
+    // pair-table indirection of cov_lookup is resolved once per block pair (81 lookups, PT in LDS); every entry of the
+    // triangle is then ONE independent 8-byte load, issued eight at a time per thread (the two-level dependent
+    // lookup per entry, 19 entries per thread in sequence, left this kernel waiting on memory latency).
+    const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;     // arithmetic shift: floor
+    const int nbw = g.nbw, nb2 = nbw * nbw;                                     // window: nbw x nbw blocks (3 for radius 15, 4 for 18)
+    for (int q = tid; q < nb2 * nb2; q += 256) {
+        const int a = q / nb2, b = q % nb2;
+        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
+        int code = -1;
+        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
+            int dR = ib - ia, dC = jb - ja, sw = 0;
+            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
+            const int pidx = tab.pair_of[(ja * tab.nbr + ia) * NREL + rel_index(dR, dC)];
+            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
         }
-        L[e] = v;
+        pt[q] = code;
+    }
+    // node codes: local block (0..8) << 8 | local pixel (4x4-patch order); node p = the centre pixel
+    for (int i = tid; i <= p; i += 256) {
+        const int c = i < p ? nb[i] : (rbm | (cbm << 16));
+        int nc = -1;
+        if (c >= 0) { const int rb = c & 0xffff, cb = c >> 16; nc = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15); }
+        node[i] = nc;
+    }
+    __syncthreads();
+    const int ne = tri(na);
+    if (probe & 1) { for (int e = tid; e < ne; e += 256) L[e] = 0.0; if (tid < na) L[tri(tid) + tid] = 1.0; }   // A/B probe: no assembly
+    else
+    for (int e0 = tid; e0 < ne; e0 += 256 * 8) {
+        const double *src[8]; double val[8]; int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            src[u] = nullptr; val[u] = 0.0; idx[u] = e;
+            if (e < ne) {
+                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while (tri(i + 1) <= e) ++i;
+                while (tri(i) > e) --i;
+                const int j = e - tri(i);
+                int na_ = -1, nb_ = -1;                 // the two nodes whose covariance this entry is (or -1)
+                if (i < p) { na_ = node[i]; nb_ = node[j]; if (na_ < 0 || nb_ < 0) { val[u] = (i == j) ? 1.0 : 0.0; na_ = -1; } }
+                else if (i == p) {                      // the row of ones (fit_ring_model.m:101)
+                    if (j < p) { const int nj = nb[j]; if (nj >= 0) src[u] = &rowsum[(((nj >> 16) >> 4) * g.nbr + ((nj & 0xffff) >> 4)) * BLKPX + lp_of(nj & 15, (nj >> 16) & 15)]; }
+                    else val[u] = (double)g.Tp;
+                } else {                                // right-hand side X*y' (:104)
+                    if (j < p) { na_ = node[j]; nb_ = node[p]; if (na_ < 0) na_ = -1; }
+                    else if (j == p) src[u] = &rowsum[((cbm >> 4) * g.nbr + (rbm >> 4)) * BLKPX + lp_of(rbm & 15, cbm & 15)];
+                }
+                if (na_ >= 0) {
+                    const int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
+                    int la = na_ & 255, lb = nb_ & 255;
+                    if (code & 2) { const int t0 = la; la = lb; lb = t0; }
+                    if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }   // self pair: upper patch triangle only
+                    src[u] = tab.cov + ((int64_t)(code >> 2) * BLKPX + la) * BLKPX + lb;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (src[u]) val[u] = *src[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (idx[u] < ne) L[idx[u]] = val[u];
     }
     __syncthreads();
     // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
@@ -667,9 +722,9 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
     if (tid < n && (tid == p || nb[tid] >= 0)) L[tri(tid) + tid] += lam;
     __syncthreads();
     // ---- blocked right-looking Cholesky over columns 0..n-1; rows 0..n ----
-    for (int j0 = 0; j0 < n; j0 += PW) {
+    for (int j0 = 0; j0 < ((probe & 2) ? 0 : n); j0 += PW) {
         const int w = n - j0 < PW ? n - j0 : PW;
-        if (wave == 0) {
+        if (wave == 0 && !(probe & 8)) {
             const int ra = j0 + lane, rb = j0 + lane + 64;
             double a[PW], b[PW];
 #pragma unroll
@@ -680,9 +735,10 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
 #pragma unroll
             for (int jj = 0; jj < PW; ++jj) {
                 if (jj < w) {
-                    const double dj = sqrt(readlane_f64(a[jj], jj));
-                    const double inv = 1.0 / dj;
-                    if (lane == jj) a[jj] = dj; else if (lane > jj) a[jj] *= inv;
+                    const double piv = readlane_f64(a[jj], jj);
+                    const double inv = rsqrt_f64(piv);
+                    const double dj = piv * inv;
+                    if (lane == jj) { a[jj] = dj; dinv[j0 + jj] = inv; } else if (lane > jj) a[jj] *= inv;
                     b[jj] *= inv;
 #pragma unroll
                     for (int c = jj + 1; c < PW; ++c) {
@@ -703,34 +759,47 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
         __syncthreads();
         const int j1 = j0 + w;
         const int ti = tid & 15, tk = tid >> 4;
-        for (int i = j1 + ti; i <= n; i += 16) {
-            double li[PW];
-            const double *ri = L + tri(i) + j0;
+        // four rows (i, i+16, i+32, i+48) per thread: one fetch of panel row k serves four elements -- the LDS pipe,
+        // not the fp64 FMAs, bounds this kernel (10 LDS operations per element visit before, 4 now)
+        for (int ib = j1 + ti; ib <= ((probe & 16) ? -1 : n); ib += 64) {
+            double li[4][PW];
 #pragma unroll
-            for (int jj = 0; jj < PW; ++jj) li[jj] = jj < w ? ri[jj] : 0.0;
-            const int kmax = i < n - 1 ? i : n - 1;
+            for (int r = 0; r < 4; ++r) {
+                const int i = ib + 16 * r;
+                const double *ri = L + tri(i <= n ? i : n) + j0;
+#pragma unroll
+                for (int jj = 0; jj < PW; ++jj) li[r][jj] = (jj < w && i <= n) ? ri[jj] : 0.0;
+            }
+            const int itop = ib + 48 <= n ? ib + 48 : (ib + 32 <= n ? ib + 32 : (ib + 16 <= n ? ib + 16 : ib));
+            const int kmax = itop < n - 1 ? itop : n - 1;
             for (int k = j1 + tk; k <= kmax; k += 16) {
                 const double *rk = L + tri(k) + j0;
-                double s0 = 0.0, s1 = 0.0;
+                double rkv[PW];
 #pragma unroll
-                for (int jj = 0; jj < PW; jj += 2) {
-                    s0 = fma(li[jj], jj < w ? rk[jj] : 0.0, s0);
-                    s1 = fma(li[jj + 1], jj + 1 < w ? rk[jj + 1] : 0.0, s1);
+                for (int jj = 0; jj < PW; ++jj) rkv[jj] = jj < w ? rk[jj] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ib + 16 * r;
+                    if (i <= n && k <= i) {
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < PW; jj += 2) { s0 = fma(li[r][jj], rkv[jj], s0); s1 = fma(li[r][jj + 1], rkv[jj + 1], s1); }
+                        L[tri(i) + k] -= s0 + s1;
+                    }
                 }
-                L[tri(i) + k] -= s0 + s1;
             }
         }
         __syncthreads();
     }
     // ---- back substitution L^T w = z (z = row n), wave 0, lane owns entries lane and lane+64 ----
-    if (wave == 0) {
+    if (wave == 0 && !(probe & 4)) {
         const double *zrow = L + tri(n);
         double za = lane < n ? zrow[lane] : 0.0;
         double zb = lane + 64 < n ? zrow[lane + 64] : 0.0;
         for (int j = n - 1; j >= 0; --j) {
             const double *rj = L + tri(j);
             const double zj = j < 64 ? readlane_f64(za, j) : readlane_f64(zb, j - 64);
-            const double wj = zj / rj[j];
+            const double wj = zj * dinv[j];
             if (lane == (j & 63)) { if (j < 64) za = wj; else zb = wj; }
             if (lane < j) za -= rj[lane] * wj;
             if (lane + 64 < j) zb -= rj[lane + 64] * wj;
@@ -825,6 +894,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
     g.Tpad = (g.Tp + GK - 1) / GK * GK;
     g.bf4 = ctx->opt("gram_kernel", 4) == 4 ? 1 : 0;
+    g.p_radius = 0;
+    for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
+    g.nbw = ((2 * g.p_radius) >> 4) + 2;
     g.p = p;
     const int nblk = g.nbr * g.nbc;
 
@@ -978,11 +1050,11 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         const int n = p + 1;
         if (ctx->opt("solve_mode", 2) == 2 && n + 1 <= 128) {
             const int na = n + 1;
-            size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4) * sizeof(double) + (size_t)p * sizeof(int);
+            size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4 + na) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
             shmem = (shmem + 15) & ~size_t(15);
             if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             LAUNCH(ctx, "bg_ring_solve", k_ring_solve2, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
+                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>(), (int)ctx->opt("solve_probe", 0));
         } else {
             size_t shmem = ((size_t)(n * (n + 1)) / 2 + n) * sizeof(double) + (size_t)n * sizeof(int);
             shmem = (shmem + 15) & ~size_t(15);

@@ -334,12 +334,15 @@ class Sources2D:
         v, o = self.video, self.options
         A_csr = self.A.tocsr()
         infos = {}
+        self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update
+        self._prev_blocks = {}                                             # (ind, A_block) per patch: what the temporal update's residual needs
         for idx in v.owned:
             bp = v.block_pix[idx]
             Ab = A_csr[bp]
             ind = np.asarray(Ab.sum(axis=0)).ravel() > 0                   # :128
             A_block = Ab[:, ind].tocsc()                                   # :129
             C_block = self.C[ind]                                          # :130
+            self._prev_blocks[idx] = (np.nonzero(ind)[0], A_block)
             # "stop updating B because A&C doesn't change in this area" (:188-199) is decided by the engine's
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
             if A_block.shape[1] == 0 and not self._first_run(idx):
@@ -348,8 +351,27 @@ class Sources2D:
                                                        o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218
         self.b0_new = self.reconstruct_b0()                                # :315
         self.A_prev = self.A                                               # :316 (no copy needed: A, C are replaced, not mutated)
+        self._prev_csr_src = self.A
         self.C_prev = self.C                                               # :317
         return infos
+
+    def _prev_csr_of(self):
+        """A_prev in CSR; cached by update_background_parallel when A_prev is the A it fitted against"""
+        if getattr(self, "_prev_csr_src", None) is not self.A_prev:
+            self._prev_csr = self.A_prev.tocsr()
+            self._prev_csr_src = self.A_prev
+            self._prev_blocks = {}
+        return self._prev_csr
+
+    def _prev_block_of(self, idx):
+        """(ind, A_prev(block rows, ind)) for the neurons of A_prev that touch the block (update_temporal_parallel.m:90-91)"""
+        Aprev_csr = self._prev_csr_of()
+        hit = self._prev_blocks.get(idx)
+        if hit is None:
+            Ab = Aprev_csr[self.video.block_pix[idx]]
+            ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]
+            hit = self._prev_blocks[idx] = (ind, Ab[:, ind].tocsc())
+        return hit
 
     def _first_run(self, idx):
         """flag_first = (length(unique(W{1}(1,:)))==2)  (update_background_parallel.m:143); the same value test,
@@ -365,7 +387,7 @@ class Sources2D:
         v, o = self.video, self.options
         if o.search_method != "ellipse":
             raise NotImplementedError("only search_method='ellipse' is built")
-        Aprev_csr = self.A_prev.tocsr()
+        Aprev_csr = self._prev_csr_of()
         K = self.A.shape[1]
         rows, cols, vals = [], [], []
         IND_csr = A_csr = None
@@ -460,21 +482,25 @@ class Sources2D:
             raise NotImplementedError("fast_temporal (use_c_hat=false, :314-337) is not used by the demo and not built")
         v, o = self.video, self.options
         K, T = self.C.shape
-        A_csr = self.A.tocsr()
-        Aprev_csr = self.A_prev.tocsr()
+        A_csr = None
         acc = None                                                         # sum over patches of aa .* C_raw  (:274)
         aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
+            indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
+            C_prev_b = self.C_prev[indp] if indp.size else None
+            launched = A_csr is None
+            if launched:
+                # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
+                self.engine.residual(v.pid[idx], A_prev_b if indp.size else None, C_prev_b)
+                A_csr = self.A.tocsr()
             Ab = A_csr[bp]
             ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                              # :83
             if ind.size == 0:
                 continue                                                                              # :123
+            if not launched:
+                self.engine.residual(v.pid[idx], A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self.C[ind]                                                                    # :86
-            indp = np.nonzero(np.asarray(Aprev_csr[bp].sum(axis=0)).ravel() > 0)[0]                  # :90
-            A_prev_b = Aprev_csr[bp][:, indp].tocsc() if indp.size else None                         # :91
-            C_prev_b = self.C_prev[indp] if indp.size else None
-            self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                     # :149-152
             A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
             if o.deconv_flag:                                                                         # :106-110
                 _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("--cfg", default="c3"); ap.add_argument("--mode", type=int, default=2); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--kernels", default="3,2"); ap.add_argument("--probe", type=int, default=0)
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--mode", type=int, default=2); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--kernels", default="3,2"); ap.add_argument("--probe", type=int, default=0); ap.add_argument("--sprobes", default="0")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -21,13 +21,15 @@ eng.ring_init(0, r)
 eng.set_option("gram_mode", a.mode); eng.set_option("gram_probe", a.probe)
 eng.profile(True)
 Ws = {}
-for gk in [int(x) for x in a.kernels.split(",")]:
-    eng.set_option("gram_kernel", gk); eng.profile_reset()
+for sp_ in [int(x) for x in a.sprobes.split(",")]:
+  for gk in [int(x) for x in a.kernels.split(",")]:
+    eng.set_option("gram_kernel", gk); eng.set_option("solve_probe", sp_); eng.profile_reset()
     for _ in range(a.reps):
         eng.fit_ring_model(0, f.A_init.astype(np.float32), f.C_init)
     tab = eng.profile_table()
-    print("gram_kernel %d:" % gk, {k: round(v["total_ms"] / v["calls"], 3) for k, v in tab.items() if k.startswith("bg_") and v["calls"]}, flush=True)
+    print("solve_probe %d gram_kernel %d:" % (sp_, gk), {k: round(v["total_ms"] / v["calls"], 3) for k, v in tab.items() if k.startswith("bg_") and v["calls"]}, flush=True)
     Ws[gk] = eng.ring_csr(0).data.copy()
+    if sp_: eng.ring_init(0, r)
 ks = list(Ws)
 for k in ks[1:]:
     print("max |W_%d - W_%d| / max|W| = %.3e" % (k, ks[0], np.abs(Ws[k] - Ws[ks[0]]).max() / np.abs(Ws[ks[0]]).max()))
