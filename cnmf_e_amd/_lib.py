@@ -50,8 +50,10 @@ PROTOTYPES = {
     "cnmfe_fit_ring_model": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,
                                        C.c_double, C.c_int, f32p, i64p]),
     "cnmfe_residual": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_void_p, C.c_int]),
+    "cnmfe_get_sn": (C.c_int, [c_ctx, C.c_int, f32p]),
     "cnmfe_update_spatial": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,
                                        i64p, i32p, f32p, C.c_int32, f32p]),
+    "cnmfe_fast_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, C.c_int, f32p, f32p]),
     "cnmfe_hals_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,
                                       f32p, f32p, f32p]),
     "cnmfe_hals_temporal_deconv": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,

@@ -486,6 +486,16 @@ int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_
     return residual_run(ctx, P, patch_id, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);
 }
 
+int cnmfe_get_sn(cnmfe_ctx *ctx, int patch_id, float *sn_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!sn_out) return fail(CNMFE_EINVAL, "null sn_out");
+    CK(hipSetDevice(ctx->device));
+    return sn_pixels_run(ctx, P, sn_out);
+}
+
 int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K, const int64_t *A_colptr,
                          const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx, const float *sn, int32_t param, float *A_out) {
@@ -532,6 +542,19 @@ int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const in
     if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
     CK(hipSetDevice(ctx->device));
     return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, opts, kernel_pars, S_out, sn_out);
+}
+
+int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                        int c_order, float *C_raw_out, float *aa_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
+    RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
+    if (!A_val || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");
+    CK(hipSetDevice(ctx->device));
+    return fast_temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, c_order, C_raw_out, aa_out);
 }
 
 int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,

@@ -164,6 +164,9 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
 int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                  const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out,
                  const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out);
+int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out);
+int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                      int c_order, float *C_raw_out, float *aa_out);
 int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,
                    float *C_out, float *S_out, float *pars_out, float *sn_out);
 int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,

@@ -405,6 +405,41 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     if (tid == 0) { io.pars[k] = (float)g; io.sn_out[k] = (float)sn; io.b_out[k] = (float)b; }
 }
 
+// ---- S5: per-pixel noise of the resident residual, sn = GetSn(Ysig)  (update_spatial_parallel.m:191-194) -------
+// One workgroup per patch pixel: its trace is gathered out of Ysig4 (4 frames per 16-byte load) into LDS, then the
+// same Welch estimator as for the traces.
+__global__ void __launch_bounds__(256) k_sn_pixels(DeconvCfg c, const float4 *__restrict__ ysig4, int64_t d, float *__restrict__ sn) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red[4];
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x, T = c.T;
+    const int Tal = (T + 3) & ~3;
+    float *y = lds, *scr = lds + Tal;
+    for (int q = tid; q < (T + 3) / 4; q += 256) *reinterpret_cast<float4 *>(y + 4 * q) = ysig4[(int64_t)q * d + m];
+    __syncthreads();
+    const double v = get_sn(y, c, scr, scr + c.nfft, red);
+    if (tid == 0) sn[m] = (float)v;
+}
+
+int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
+    const int64_t T = P->T;
+    if (T < 64 || T > 32768) return fail(CNMFE_EUNSUPPORTED, "GetSn on the device supports 64 <= T <= 32768 frames (got %lld)", (long long)T);
+    DeconvCfg c{};
+    c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
+    c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
+    c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
+    c.nseg = (int)((T - c.nov) / (c.L - c.nov));
+    const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft) * sizeof(float);
+    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the GetSn kernel's LDS", (long long)T);
+    if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    DevBuf &dSn = ctx->tmp[14];
+    RET(dSn.ensure((size_t)P->d * sizeof(float)));
+    LAUNCH(ctx, "spatial_sn_pixels", k_sn_pixels, dim3((unsigned)P->d), dim3(256), shmem, c, ctx->ysig.as<float4>(), P->d, dSn.as<float>());
+    CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------
 struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list; };
 

@@ -415,6 +415,53 @@ int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64
                            const int *dLvl, const std::vector<int> &off, float *dC, float *dCraw, float *dS, int64_t ldc, const float *dU,
                            const int *dNptr, const int *dNidx, const float *dNval, const float *dAa, float *dPars, float *dSn);
 
+// ---- fast_temporal (use_c_hat = false): C_raw = (A .* [A >= max(A)/2])' * Y ./ aa   (update_temporal_parallel.m:314-337)
+__global__ void k_scale_rows(float *__restrict__ U, int64_t ldc, int64_t T, const float *__restrict__ inv) {
+    const int k = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) U[(int64_t)k * ldc + t] *= inv[k];
+}
+
+int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                      int c_order, float *C_raw_out, float *aa_out) {
+    const int64_t T = P->T, d = P->d, nnz = A_colptr[K];
+    if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(A) too large");
+    // tmp_A = A .* (A ./ max(A,[],1) >= 0.5), aa = sum(tmp_A.^2, 1); aa == 0 -> 1/inf = 0 (:327-333)
+    std::vector<float> av((size_t)std::max<int64_t>(1, nnz)), inv(K), aa(K);
+    for (int k = 0; k < K; ++k) {
+        double mx = 0.0;                                                   // max over the (sparse) column: implicit zeros count
+        bool any = false;
+        for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) { if (!any || A_val[e] > mx) mx = A_val[e]; any = true; }
+        if (any && A_colptr[k + 1] - A_colptr[k] < d && mx < 0.0) mx = 0.0;
+        double s = 0.0;
+        for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
+            const double a = A_val[e];
+            const bool keep = (a * (1.0 / mx)) >= 0.5;                     // NaN (mx == 0) compares false, like MATLAB's ge
+            av[e] = keep ? (float)a : 0.f;
+            if (keep) s += a * a;
+        }
+        aa[k] = (float)s; inv[k] = s > 0.0 ? (float)(1.0 / s) : 0.f;
+    }
+    DevBuf dColptr, dErow, dAval, dU, dInv;
+    const int64_t ldc = (T + 3) & ~int64_t(3);
+    RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
+    RET(to_dev(ctx, dErow, A_rowidx, (size_t)nnz));
+    RET(to_dev(ctx, dAval, av.data(), (size_t)nnz));
+    RET(to_dev(ctx, dInv, inv.data(), (size_t)K));
+    RET(dU.ensure((size_t)K * ldc * sizeof(float)));
+    CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    const int64_t Tc = (T + 3) / 4;
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
+    const int64_t tchunk = (Tc + nchunk - 1) / nchunk;
+    if (nnz > 0)
+        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, ctx->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
+               dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
+    LAUNCH(ctx, "temporal_scale_rows", k_scale_rows, dim3((unsigned)((T + 255) / 256), (unsigned)K), dim3(256), 0, dU.as<float>(), ldc, T, dInv.as<float>());
+    RET(download_traces(ctx, dU.as<float>(), ldc, C_raw_out, K, T, c_order));
+    if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));
+    return 0;
+}
+
 int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                  const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out,
                  const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out) {

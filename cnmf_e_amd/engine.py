@@ -142,6 +142,12 @@ class Engine:
         L.check(L.lib.cnmfe_residual(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR, dst, space))
         return out
 
+    def get_sn(self, pid):
+        """sn = GetSn(Ysig) per patch pixel (update_spatial_parallel.m:191-194); needs residual() first"""
+        out = np.empty(self._patch[pid]["d"], dtype=np.float32)
+        L.check(L.lib.cnmfe_get_sn(self._ctx, pid, _p(out, L.f32p)))
+        return out
+
     def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3):
         """Returns the updated A as a CSC matrix with exactly IND's pattern (explicit zeros kept)."""
         info = self._patch[pid]
@@ -167,6 +173,15 @@ class Engine:
         L.check(L.lib.cnmfe_hals_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
                                           int(maxIter), _p(Cout, L.f32p), _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Cout, Craw, aa
+
+    def fast_temporal(self, pid, A_patch):
+        """[aa, C_raw] = fast_temporal(Ysig, A) (update_temporal_parallel.m:314-337); returns (C_raw, aa)"""
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_patch, info["d"])
+        Craw = np.empty((K, info["T"]), dtype=np.float32); aa = np.empty(K, dtype=np.float32)
+        L.check(L.lib.cnmfe_fast_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), L.ROWMAJOR,
+                                          _p(Craw, L.f32p), _p(aa, L.f32p)))
+        return Craw, aa
 
     @staticmethod
     def _dopts(deconv_options, maxIter=10):

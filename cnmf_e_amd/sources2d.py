@@ -382,9 +382,8 @@ class Sources2D:
     def update_spatial_parallel(self, use_parallel=True, update_sn=False):
         """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""
         self._need_data()
-        if update_sn:
-            raise NotImplementedError("update_sn=true (GetSn / pwelch over the residual, :191-194) is not built yet")
         v, o = self.video, self.options
+        sn_new = np.zeros(v.d1 * v.d2, dtype=np.float64) if update_sn else None                  # :101-102
         if o.search_method != "ellipse":
             raise NotImplementedError("only search_method='ellipse' is built")
         Aprev_csr = self._prev_csr_of()
@@ -410,13 +409,18 @@ class Sources2D:
                 A_csr = self.A.tocsr()
             INDp = IND_csr[pp]
             ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]                          # :87
-            if ind.size == 0:
+            if ind.size == 0 and not update_sn:
                 continue                                                                             # :121-124
             if not launched:
                 self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                # :162-166
+            sn_patch = self.P["sn"][pp]                                                             # :90,154
+            if update_sn:
+                sn_patch = self.engine.get_sn(v.pid[idx])                                           # :191-194  sn_patch = GetSn(Ypatch)
+                sn_new[pp] = sn_patch
+            if ind.size == 0:
+                continue                                                                             # :196-199
             A_patch = A_csr[pp][:, ind].tocsc()                                                     # :88,199
             IND_patch = INDp[:, ind].tocsc()                                                        # :89
-            sn_patch = self.P["sn"][pp]                                                             # :90
             C_patch = self.C[ind]                                                                   # :91
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
             Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
@@ -429,6 +433,8 @@ class Sources2D:
         else:
             A_ = sp.csc_matrix((d, K), dtype=np.float32)
         A_ = self._gather_sparse(A_)
+        if update_sn:
+            self.P["sn"] = self._allreduce(sn_new).astype(np.float32)                               # :336-337 (patches are disjoint)
         A_.eliminate_zeros()
         A_.sort_indices()
         self.A_raw = A_
@@ -478,8 +484,6 @@ class Sources2D:
     def update_temporal_parallel(self, use_parallel=True, use_c_hat=True):
         """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295."""
         self._need_data()
-        if not use_c_hat:
-            raise NotImplementedError("fast_temporal (use_c_hat=false, :314-337) is not used by the demo and not built")
         v, o = self.video, self.options
         K, T = self.C.shape
         A_csr = None
@@ -502,7 +506,9 @@ class Sources2D:
                 self.engine.residual(v.pid[idx], A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self.C[ind]                                                                    # :86
             A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
-            if o.deconv_flag:                                                                         # :106-110
+            if not use_c_hat:                                                                         # :174-175
+                C_raw_p, aa_p = self.engine.fast_temporal(v.pid[idx], A_pp)
+            elif o.deconv_flag:                                                                       # :106-110
                 _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)
             else:
                 _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)   # :180-181

@@ -110,6 +110,12 @@ int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_
                    const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                    float *Ysig_out, int out_memspace);
 
+/* ---- S5: sn = GetSn(Ysig) of every patch pixel (update_sn = true)
+ * @Sources2D/update_spatial_parallel.m:191-194 -> OASIS_matlab/functions/GetSn.m:33-47
+ * (Welch PSD with pwelch's defaults, sn = sqrt(exp(mean(log(psd/2)))) over 0.25 <= f <= 0.5).
+ * Ysig = the resident residual of this patch (cnmfe_residual must have been called).  sn_out: d floats. */
+int cnmfe_get_sn(cnmfe_ctx *ctx, int patch_id, float *sn_out);
+
 /* ---- S1-S4: A = HALS_spatial(Y,A,C,active_pixel,maxIter)            utilities/HALS_spatial.m:1-45
  *             A = HALS_spatial_thresh(Y,A,C,active_pixel,maxIter,sn)  utilities/HALS_spatial_thresh.m:1-53
  *             A = nnls_spatial(Y,A,C,active_pixel,maxN)               endoscope/nnls_spatial.m:1-109
@@ -122,6 +128,14 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
                          const float *C, int c_order,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx,
                          const float *sn, int32_t param, float *A_out);
+
+/* ---- fast_temporal (use_c_hat = false)                @Sources2D/update_temporal_parallel.m:174-175,314-337
+ *   tmp_A = A .* (A ./ max(A,[],1) >= 0.5);  aa = sum(tmp_A.^2,1);  C_raw = (tmp_A' * Ysig) ./ aa'
+ * (rows with aa == 0 are 0 and report aa = 0).  A is d x K CSC over PATCH rows; Ysig = the resident
+ * residual of this patch.  C_raw_out K x T, aa_out K floats (may be NULL). */
+int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
+                        const int32_t *A_rowidx, const float *A_val, int c_order,
+                        float *C_raw_out, float *aa_out);
 
 /* ---- T1-T3: [C, C_raw, ~, ~] = HALS_temporal(Y, A, C, maxIter, [])   utilities/HALS_temporal.m:1-119
  * (no-deconvolution branch :64-68).  Y = resident Ysig.  A d x K CSC over PATCH rows.

@@ -354,6 +354,22 @@ def nnls_spatial(Y, A, C, active_pixel=None, maxN=5):
 # --------------------------------------------------------------------------- #
 # temporal
 # --------------------------------------------------------------------------- #
+def fast_temporal(Y, A):
+    """[aa, C_raw] = fast_temporal(Y, A)  (@Sources2D/update_temporal_parallel.m:314-337): the mean fluorescence
+    over the pixels at >= half the footprint's maximum."""
+    A = np.asarray(A.todense()) if sp.issparse(A) else np.asarray(A, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tmpA = A * (1.0 / A.max(axis=0, keepdims=True))      # :327
+        ind_max = tmpA >= 0.5                                # :328 (NaN compares false)
+    tmp_A = A * ind_max                                      # :329
+    aa = (tmp_A ** 2).sum(axis=0)                            # :330
+    ind = aa == 0                                            # :331
+    aa_div = aa.copy(); aa_div[ind] = np.inf                 # :332
+    C_raw = (tmp_A.T @ Y) / aa_div[:, None]                  # :333
+    aa[ind] = 0                                              # :334
+    return aa, C_raw
+
+
 def HALS_temporal(Y, A, C, maxIter=1, deconv_options=None):
     """utilities/HALS_temporal.m:1-119 -- no-deconvolution branch (:64-68).
 
@@ -556,20 +572,21 @@ class OracleSources2D:
         self.C_prev = self.C.copy()                          # :317
 
     # -- spatial -----------------------------------------------------------------
-    def update_spatial_parallel(self):
+    def update_spatial_parallel(self, update_sn=False):
         """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""
         d1, d2 = self.d1, self.d2
         IND = determine_search_location(self.A, d1, d2, **self.search)     # :66
         K = self.A.shape[1]
         A_ = np.zeros((d1 * d2, K))
         Aprev_dense_any = self.A_prev
+        sn_new = np.array(self.sn, dtype=np.float64).reshape(-1, order="F").copy() if update_sn else None   # :101-102
         for idx in self._patches():
             p, b = self.patch_pos[idx], self.block_pos[idx]
             mb, mp = self._mask(b), self._mask(p)
             halo = mb & ~mp                                  # mask==1 after patch overwritten with 2 (:84-85)
             ind = np.nonzero(IND[mp, :].any(axis=0))[0]      # :87
-            if ind.size == 0:
-                continue                                     # :121-124 (update_sn=false)
+            if ind.size == 0 and not update_sn:
+                continue                                     # :121-124
             A_patch = self.A[mb, :][:, ind]                  # :88
             IND_patch = IND[mp, :][:, ind]                   # :89
             sn_patch = self.sn.reshape(-1, order="F")[mp]    # :90
@@ -580,6 +597,12 @@ class OracleSources2D:
             ip = ind_patch_mask(p, b)
             Yb = self._block(b)                              # :147
             Ysig = residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)   # :162-166
+            if update_sn:                                    # :191-194  sn_patch = GetSn(Ypatch)
+                from oasis_oracle import GetSn
+                sn_patch = np.array([GetSn(row) for row in Ysig])
+                sn_new[mp] = sn_patch
+            if ind.size == 0:
+                continue                                     # :196-199
             A_pp = A_patch[ip, :]                            # :199
             if self.spatial_algorithm == "hals":
                 temp = HALS_spatial(Ysig, A_pp, C_patch, IND_patch, 3)      # :203
@@ -591,14 +614,16 @@ class OracleSources2D:
             for j, k in enumerate(ind):                      # :324-334 (write, not accumulate)
                 A_[rows, k] = temp[:, j]
         self.A_raw = A_.copy()
+        if update_sn:
+            self.sn = sn_new.reshape(np.shape(self.sn), order="F") if np.ndim(self.sn) == 2 else sn_new   # :336-337
         A_img = A_.reshape(d1, d2, K, order="F")
         self.A = sp.csc_matrix(post_process_spatial(A_img))  # :341
         self.b0_new = self._ymean_full() - np.asarray(
             self.A @ self.C.mean(axis=1)).reshape(d1, d2, order="F")        # :349
 
     # -- temporal ----------------------------------------------------------------
-    def update_temporal_parallel(self):
-        """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295 (use_c_hat=true, no deconv)."""
+    def update_temporal_parallel(self, use_c_hat=True):
+        """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295 (no deconv)."""
         K, T = self.C.shape
         C_new = np.zeros((K, T)); aa = np.zeros(K)
         for idx in self._patches():
@@ -616,8 +641,11 @@ class OracleSources2D:
             Yb = self._block(b)
             Ysig = residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)    # :149-152
             A_pp = A_b[ip, :]
-            _, C_raw_p, _ = HALS_temporal(Ysig, A_pp, C_b, self.maxIter, None)             # :180
-            aa_p = np.asarray(A_pp.multiply(A_pp).sum(axis=0)).ravel()                      # :181
+            if not use_c_hat:
+                aa_p, C_raw_p = fast_temporal(Ysig, A_pp)                                   # :174-175
+            else:
+                _, C_raw_p, _ = HALS_temporal(Ysig, A_pp, C_b, self.maxIter, None)         # :180
+                aa_p = np.asarray(A_pp.multiply(A_pp).sum(axis=0)).ravel()                  # :181
             for j, k in enumerate(ind):                      # :269-278
                 C_new[k, :] += C_raw_p[j, :] * aa_p[j]
                 aa[k] += aa_p[j]

@@ -56,6 +56,10 @@ class FakeEngine:
         q["Ysig"] = orc.residual_ysig(q["Y"].T, A, C_prev, q["W"], q["b0"], q["ip"])
         return q["Ysig"].T if want else None
 
+    def get_sn(self, pid):
+        import oasis_oracle as oo
+        return np.array([oo.GetSn(row) for row in self.p[pid]["Ysig"]], dtype=np.float32)
+
     def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3):
         Y = self.p[pid]["Ysig"]
         A = sp.csc_matrix(A_patch).astype(np.float64)
@@ -67,6 +71,10 @@ class FakeEngine:
         else:
             out = orc.nnls_spatial(Y, A, C_patch, IND, param)
         return sp.csc_matrix(out)
+
+    def fast_temporal(self, pid, A_patch):
+        aa, C_raw = orc.fast_temporal(self.p[pid]["Ysig"], sp.csc_matrix(A_patch).astype(np.float64))
+        return C_raw, aa
 
     def hals_temporal(self, pid, A_patch, C_patch, maxIter=5):
         A = sp.csc_matrix(A_patch).astype(np.float64)

@@ -15,7 +15,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, update_sn):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -31,27 +31,33 @@ def _worker(rank, world, port, out):
     video.upload_from_full(Y.astype(np.float64))
     s = Sources2D(video, Options(ring_radius=c["r"], spatial_algorithm="hals", maxIter=3), f.A_init, f.C_init, f.sn,
                   dist_group=td.group.WORLD)
-    s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+    s.update_background_parallel(); s.update_spatial_parallel(update_sn=update_sn); s.update_temporal_parallel()
     if rank == 0:
-        np.savez(out, A=s.A.toarray(), C=s.C, b0_new=s.b0_new)
+        np.savez(out, A=s.A.toarray(), C=s.C, b0_new=s.b0_new, sn=s.P["sn"])
     td.barrier()
     td.destroy_process_group()
 
 
-def test_two_rank_sharded_iteration_matches_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("update_sn", [False, True])
+def test_two_rank_sharded_iteration_matches_single_process(tmp_path, update_sn):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnmfe_oracle as orc
     from cnmf_e_amd import synth
     out = str(tmp_path / "r0.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, update_sn), nprocs=2, join=True)
     got = np.load(out)
     c = CASE
     f = synth.make_factors(c["d1"], c["d2"], c["T"], c["K"], c["seed"], gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
     o = orc.OracleSources2D(Y.T.reshape(c["d1"], c["d2"], c["T"], order="F"), c["d1"], c["d2"], c["T"], [20, 22], c["r"],
                             f.A_init.astype(np.float32), f.C_init, f.sn, spatial_algorithm="hals", maxIter=3)
-    o.update_background_parallel(); o.update_spatial_parallel(); o.update_temporal_parallel()
+    o.update_background_parallel(); o.update_spatial_parallel(update_sn=update_sn); o.update_temporal_parallel()
+    if update_sn:
+        assert np.allclose(got["sn"], np.asarray(o.sn).reshape(-1, order="F"), rtol=1e-5)
     assert np.allclose(got["A"], o.A.toarray(), rtol=1e-4, atol=1e-6)
     assert np.allclose(got["C"], o.C, rtol=1e-4, atol=1e-4)
     assert np.allclose(got["b0_new"], o.b0_new, rtol=1e-5, atol=1e-2)

@@ -343,3 +343,65 @@ def test_method_level_iteration_with_deconvolution(eng):
     for k in range(K):
         assert np.corrcoef(s.C[k], f.C_true[k])[0, 1] > 0.9
     assert np.all((s.P["kernel_pars"] > 0.8) & (s.P["kernel_pars"] < 1.0))
+
+
+@pytest.mark.parametrize("T", [300, 1000])
+def test_get_sn_pixels_parity(eng, T):
+    """S5: sn = GetSn(Ysig) per pixel (update_spatial_parallel.m:191-194, GetSn.m:33-47) vs the float64 restatement.
+    Tolerance 2e-4 relative: the device runs Welch's FFT in fp32."""
+    import oasis_oracle as oo
+    c = Case(eng, 30, 28, T, 5, 5, seed=5)
+    idx = c.video.owned[0]; pid = c.video.pid[idx]
+    Ysig = eng.residual(pid, None, None, want=True)                       # (T, d)
+    got = eng.get_sn(pid)
+    ref = np.array([oo.GetSn(Ysig[:, m].astype(np.float64)) for m in range(Ysig.shape[1])])
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref) / ref) <= 2e-4, np.max(np.abs(got - ref) / ref)
+
+
+def test_method_level_update_sn(eng):
+    """update_spatial_parallel(update_sn=true) with the thresholded HALS: P.sn is replaced by GetSn of the residual and
+    feeds the threshold of the same call (update_spatial_parallel.m:101-102,191-194,205,336-337)."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 44, 40, 300, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 29, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals_thresh", maxIter=3), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn,
+                            spatial_algorithm="hals_thresh", maxIter=3)
+    s.update_background_parallel(); o.update_background_parallel()
+    s.update_spatial_parallel(update_sn=True); o.update_spatial_parallel(update_sn=True)
+    sn_ref = np.asarray(o.sn).reshape(-1, order="F")
+    assert np.max(np.abs(s.P["sn"] - sn_ref) / sn_ref) <= 5e-4
+    assert not np.allclose(s.P["sn"], np.asarray(f.sn).reshape(-1))      # it really was re-estimated
+    Ag, Ar = s.A.toarray(), o.A.toarray()
+    mism = ((Ag != 0) != (Ar != 0)).sum()
+    assert mism <= max(3, 0.02 * (Ar != 0).sum()), mism
+    same = (Ag != 0) == (Ar != 0)
+    assert rel(Ag[same], Ar[same]) <= 2e-3
+
+
+def test_fast_temporal_parity(eng):
+    """use_c_hat=false: fast_temporal (update_temporal_parallel.m:314-337) at the ABI and at method level."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    c = Case(eng, 36, 32, 240, 6, 5, seed=41)
+    idx = c.video.owned[0]; pid = c.video.pid[idx]
+    Ysig = eng.residual(pid, None, None, want=True).T.astype(np.float64)     # d x T
+    A = sp.csc_matrix(c.f.A_init.astype(np.float32))
+    A = sp.hstack([A, sp.csc_matrix((A.shape[0], 1), dtype=np.float32)]).tocsc()    # an empty footprint: aa = 0, row of zeros
+    Craw, aa = eng.fast_temporal(pid, A)
+    aa_ref, Craw_ref = orc.fast_temporal(Ysig, A.astype(np.float64))
+    assert np.allclose(aa, aa_ref, rtol=1e-6) and aa[-1] == 0 and not Craw[-1].any()
+    assert rel(Craw, Craw_ref) <= 1e-5
+    d1, d2, T, K, r = 44, 40, 300, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
+    s.update_background_parallel(); o.update_background_parallel()
+    s.update_temporal_parallel(use_c_hat=False); o.update_temporal_parallel(use_c_hat=False)
+    assert rel(s.C, o.C) <= 1e-3, rel(s.C, o.C)
