@@ -227,11 +227,6 @@ __global__ void __launch_bounds__(256, 2) k_gram2(const float *__restrict__ bf, 
 // s_barrier publishes the stage; loads past the last stage are clamped, not skipped, so the count is uniform.
 constexpr int GR_NBUF = 4, GR_STAGE_F = 2 * GK * 128;          // floats per stage: A half + B half, [16][128] each
 
-__device__ __forceinline__ void glds16(const float *base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
-}
 
 template <bool F32>
 __global__ void __launch_bounds__(256, 2) k_gram3(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,

@@ -164,6 +164,16 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
 int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                  const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out,
                  const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out);
+#ifdef __HIPCC__
+// LDS-DMA: 64 lanes x 16 B, global (uniform base + per-lane 32-bit byte offset) -> LDS [lds_dst + lane*16].  Invisible to
+// hipcc's s_waitcnt bookkeeping: count completion by hand (vmcnt), then barrier, then read (cdna_hip_programming 5.7).
+__device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+#endif
+
 int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out);
 int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                       int c_order, float *C_raw_out, float *aa_out);

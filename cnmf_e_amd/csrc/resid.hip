@@ -315,6 +315,220 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
     }
 }
 
+// ---- specialised kernel, LDS-DMA staging (r1_variant 10) -------------------------------------------------
+// Same ring product as k_residual_r, but the halo goes global -> LDS directly (global_load_lds_dwordx4): no staging
+// VGPRs, no ds_write commit phase (49 KB per chunk through the 79 B/clk store path), and the halo of chunk c+2 is in
+// flight while chunk c is consumed (three LDS buffers, ONE barrier per chunk).  The DMA writes lane-linearly, so a
+// buffer is 48 wave-instructions x 64 slots of 16 B; slots past the halo and halo pixels outside the block fetch a
+// clamped address: their ring weights are exactly 0 (every neighbour outside the block is outside the FOV).
+constexpr int R1_TKMAX = 64;                // traces staged per tile and chunk (one DMA instruction)
+constexpr int R1_KBM = 8192;                // neurons the tile-list bitmap covers (beyond: per-pixel global loads)
+constexpr int R1_OVF = 384;                 // workgroup-wide list of (W*A) entries beyond the 4 a pixel keeps in registers
+
+template <int R, int TR, int TC, bool HAS_AC, int NBUF>
+__global__ void __launch_bounds__(TR *TC, 2) k_residual_dma(R1Args a) {
+    constexpr int NT = TR * TC, NW = NT / 64;
+    constexpr int P = RingConst<R>::tab.n;
+    constexpr int HR = TR + 2 * R, HC = TC + 2 * R, NH = HR * HC;
+    constexpr int NIT = (NH + NT - 1) / NT;                 // DMA instructions per wave and chunk
+    constexpr int NHp = NIT * NT;                           // slots per buffer; NBUF buffers: chunk c+NBUF-1 in flight under chunk c
+    // the only LDS object: NBUF halo buffers | NBUF trace buffers of R1_TKMAX float4 | tile-list scratch (HAS_AC)
+    extern __shared__ __attribute__((aligned(16))) float4 halo[];
+    float4 *tbuf = halo + NBUF * NHp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tmap = a.tile_map[blockIdx.x];
+    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
+    const int tr = tid % TR, tc = tid / TR;
+    const int pr = tile_r * TR + tr, pc = tile_c * TC + tc;
+    const bool valid = pr < a.nr && pc < a.nc;
+    const int64_t m = valid ? (int64_t)pc * a.nr + pr : 0;
+    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
+    const int hbase = tc * HR + tr;                     // biased base: neighbour (dr,dc) at halo[hbase + (dc+R)*HR + (dr+R)]
+    // DMA plan: instruction j of wave w fills slots (j*NW + w)*64 + lane
+    uint32_t qoff[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int idx = (j * NW + wave) * 64 + lane;
+        const int hr = idx % HR, hc = idx / HR;
+        int rb = hr0 + hr, cb = hc0 + hc;
+        rb = rb < 0 ? 0 : (rb >= a.nr_b ? a.nr_b - 1 : rb);
+        cb = cb < 0 ? 0 : (cb >= a.nc_b ? a.nc_b - 1 : cb);
+        qoff[j] = idx < NH ? (uint32_t)(cb * a.nr_b + rb) * 16u : 0u;
+    }
+    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4 *)halo;
+    const unsigned lds0 = ldsA + (unsigned)wave * 1024u;
+    const uint32_t mb = (uint32_t)m * 4u;
+    // ---- (W*A_prev) rows: the tile's traces are staged in LDS once per chunk (wave 0, one DMA instruction), every
+    // pixel reads its <= WA_PRE samples from there.  The tile list is the union of wa_k over the tile's pixels, built
+    // here with a bitmap; entries it cannot hold (more than R1_TKMAX traces per tile, more than WA_PRE per pixel,
+    // neuron index >= R1_KBM) fall back to per-pixel global loads in the epilogue.
+    constexpr int WA_PRE = 8;                            // entries per pixel held in registers; the rest go through the overflow list
+    int wsl[WA_PRE]; float wvv[WA_PRE]; int nwa = 0; bool spill = false;
+    int ov0 = 0, ov1 = 0;                                // this pixel's range in the workgroup's overflow list (entries >= WA_PRE)
+    uint32_t tkoff = 0;                                  // wave 0: byte offset of trace tk[lane] in Cc
+    unsigned *bm = reinterpret_cast<unsigned *>(tbuf + NBUF * R1_TKMAX);      // R1_KBM/32 words
+    int *pre = reinterpret_cast<int *>(bm + R1_KBM / 32);                    // exclusive popcount prefix, R1_KBM/32 + 1; then the list counter
+    int *tk = pre + R1_KBM / 32 + 2;                                         // R1_TKMAX neuron ids
+    int2 *ovl = reinterpret_cast<int2 *>(tk + R1_TKMAX);                     // R1_OVF (trace slot, weight bits)
+    if (HAS_AC) {
+        for (int w = tid; w < R1_KBM / 32; w += NT) bm[w] = 0u;
+        if (tid < R1_TKMAX) tk[tid] = 0;
+        if (tid == 0) pre[R1_KBM / 32 + 1] = 0;
+        __syncthreads();
+        nwa = valid ? a.wa_cnt[m] : 0;
+        for (int e = 0; e < nwa; ++e) {                  // every trace this pixel needs goes on the tile list
+            const int k = a.wa_k[(int64_t)e * a.d + m];
+            if (k < R1_KBM) atomicOr(&bm[k >> 5], 1u << (k & 31));
+        }
+        __syncthreads();
+        if (tid == 0) { int s_ = 0; for (int w = 0; w < R1_KBM / 32; ++w) { pre[w] = s_; s_ += __popc(bm[w]); } pre[R1_KBM / 32] = s_; }
+        __syncthreads();
+        for (int k = tid; k < R1_KBM; k += NT) {
+            const unsigned word = bm[k >> 5];
+            if ((word >> (k & 31)) & 1u) { const int pos = pre[k >> 5] + __popc(word & ((1u << (k & 31)) - 1u)); if (pos < R1_TKMAX) tk[pos] = k; }
+        }
+        auto slot_of = [&](int k) {
+            if (k >= R1_KBM) return -1;
+            const unsigned word = bm[k >> 5];
+            const int sl = pre[k >> 5] + __popc(word & ((1u << (k & 31)) - 1u));
+            return sl < R1_TKMAX ? sl : -1;
+        };
+#pragma unroll
+        for (int e = 0; e < WA_PRE; ++e) {
+            wsl[e] = -1; wvv[e] = 0.f;
+            if (e < nwa) {
+                const int sl = slot_of(a.wa_k[(int64_t)e * a.d + m]);
+                if (sl >= 0) { wsl[e] = sl; wvv[e] = a.wa_v[(int64_t)e * a.d + m]; }
+                else { wsl[e] = -2; spill = true; }           // not on the tile list: global fallback in the epilogue
+            }
+        }
+        if (nwa > WA_PRE) {
+            const int n = nwa - WA_PRE;
+            ov0 = atomicAdd(&pre[R1_KBM / 32 + 1], n); ov1 = ov0 + n;
+            bool ok = ov1 <= R1_OVF;
+            for (int e = WA_PRE; e < nwa && ok; ++e) {
+                const int sl = slot_of(a.wa_k[(int64_t)e * a.d + m]);
+                if (sl < 0) ok = false;
+                else ovl[ov0 + e - WA_PRE] = make_int2(sl, __float_as_int(a.wa_v[(int64_t)e * a.d + m]));
+            }
+            if (!ok) { ov0 = ov1 = 0; spill = true; }            // list full / trace not staged: this pixel's tail goes the global way
+        }
+        __syncthreads();
+        tkoff = (uint32_t)tk[lane] * (uint32_t)(a.ldc * 4);
+    }
+    static_assert(P % 2 == 0, "ring size must be even (weights are held as pairs)");
+    f2 wp[P / 2];
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) {                   // threads off the patch read pixel 0 and never store
+        wp[i].x = ld_off(a.W + (int64_t)(2 * i) * a.d, mb);
+        wp[i].y = ld_off(a.W + (int64_t)(2 * i + 1) * a.d, mb);
+    }
+    const float dl = ld_off(a.dlt, mb);
+    const int64_t cbeg = ((int64_t)blockIdx.y * a.tseg) >> 2;
+    const int64_t tend = (int64_t)blockIdx.y * a.tseg + a.tseg < a.T ? (int64_t)blockIdx.y * a.tseg + a.tseg : a.T;
+    const int64_t cend = (tend + 3) >> 2;                   // chunks [cbeg, cend)
+    const bool tw = HAS_AC && wave == 0;                    // the wave that also moves the traces
+    auto issue = [&](int64_t c) {
+        const int64_t cc = c < cend ? c : cend - 1;         // clamp: the vmcnt arithmetic stays uniform
+        const float4 *y4 = a.Y4 + cc * a.d_b;
+        const int b = (int)((c - cbeg) % NBUF);
+        const unsigned dst = lds0 + (unsigned)b * (unsigned)(NHp * 16);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) glds16(y4, qoff[j], dst + (unsigned)(j * NW) * 1024u);
+        if (tw) glds16(a.Cc + 4 * cc, tkoff, ldsA + (unsigned)(NBUF * NHp + b * R1_TKMAX) * 16u);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the loads above are the compiler's; start the hand count from zero
+#pragma unroll
+    for (int q = 0; q < NBUF - 1; ++q) issue(cbeg + q);
+    for (int64_t c = cbeg; c < cend; ++c) {
+        // outstanding after this wait: at most the loads of the NBUF-2 younger chunks (stores may retire out of order
+        // with loads: counting only the younger LOADS is safe either way)
+        if (tw) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NIT + 1) * (NBUF - 2)) : "memory");
+        else    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NIT * (NBUF - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(c + NBUF - 1);
+        const int64_t t0 = c << 2;
+        const int cb_ = (int)((c - cbeg) % NBUF);
+        const float4 *hb = halo + cb_ * NHp + hbase;
+        f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+        constexpr int G = 4, NG = P / G, D = 3;
+        static_assert(P % G == 0, "ring size must be a multiple of the read group");
+        float4 r[D + 1][G];
+#pragma unroll
+        for (int g = 0; g < D; ++g)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                r[g][j] = hb[(RingConst<R>::tab.dc[g * G + j] + R) * HR + (RingConst<R>::tab.dr[g * G + j] + R)];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + D < NG) {
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    r[(g + D) % (D + 1)][j] = hb[(RingConst<R>::tab.dc[(g + D) * G + j] + R) * HR + (RingConst<R>::tab.dr[(g + D) * G + j] + R)];
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const float4 rv = r[g % (D + 1)][j];
+                const f2 r01 = {rv.x, rv.y}, r23 = {rv.z, rv.w};
+                const f2 wv = wp[(g * G + j) >> 1];
+                if (((g * G + j) & 1) == 0) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc01) : "v"(wv), "v"(r01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc23) : "v"(wv), "v"(r23));
+                } else {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc01) : "v"(wv), "v"(r01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc23) : "v"(wv), "v"(r23));
+                }
+            }
+            asm volatile("" : "+v"(acc01), "+v"(acc23) : : "memory");
+        }
+        const float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+        float4 cv = hb[R * HR + R];
+        if (HAS_AC) {
+            const float4 *tb = tbuf + cb_ * R1_TKMAX;
+#pragma unroll
+            for (int e = 0; e < WA_PRE; ++e) {
+                const float4 c4 = tb[wsl[e] >= 0 ? wsl[e] : 0];
+                cv.x = fmaf(wvv[e], c4.x, cv.x); cv.y = fmaf(wvv[e], c4.y, cv.y);
+                cv.z = fmaf(wvv[e], c4.z, cv.z); cv.w = fmaf(wvv[e], c4.w, cv.w);
+            }
+            for (int q = ov0; q < ov1; ++q) {               // entries beyond WA_PRE: (slot, weight) pairs in LDS, no global access
+                const int2 en = ovl[q];
+                const float4 c4 = tb[en.x]; const float v = __int_as_float(en.y);
+                cv.x = fmaf(v, c4.x, cv.x); cv.y = fmaf(v, c4.y, cv.y); cv.z = fmaf(v, c4.z, cv.z); cv.w = fmaf(v, c4.w, cv.w);
+            }
+        }
+        if (valid) {
+            if (HAS_AC && spill) {                          // rare: entries neither the tile list nor the overflow list could hold
+                for (int e = 0; e < nwa; ++e) {
+                    if (e < WA_PRE ? wsl[e] != -2 : ov1 > ov0) continue;
+                    const float v = a.wa_v[(int64_t)e * a.d + m];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + m] * a.ldc + t0);
+                    cv.x = fmaf(v, c4.x, cv.x); cv.y = fmaf(v, c4.y, cv.y); cv.z = fmaf(v, c4.z, cv.z); cv.w = fmaf(v, c4.w, cv.w);
+                }
+            }
+            st4_off(a.Ysig4 + c * a.d, mb * 4u, make_float4(cv.x + dl - acc.x, cv.y + dl - acc.y, cv.z + dl - acc.z, cv.w + dl - acc.w));
+        }
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the clamped tail loads before the LDS is released
+}
+
+template <int R, int TR, int TC>
+static int launch_r1_dma(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid) {
+    constexpr int NT = TR * TC, NH = (TR + 2 * R) * (TC + 2 * R), NIT = (NH + NT - 1) / NT;
+    constexpr int NBUF = (size_t)3 * (NIT * NT + R1_TKMAX) * sizeof(float4) + 4096 <= 160 * 1024 ? 3 : 2;
+    const size_t shmem = (size_t)NBUF * NIT * NT * sizeof(float4) + (size_t)NBUF * R1_TKMAX * sizeof(float4) +
+                         (size_t)(R1_KBM / 32 + R1_KBM / 32 + 2 + R1_TKMAX + 2 * R1_OVF) * sizeof(int);
+    if (shmem > 160 * 1024) return fail(CNMFE_EUNSUPPORTED, "ring radius %d: LDS-DMA halo needs %zu B", R, shmem);
+    CK(hipFuncSetAttribute((const void *)k_residual_dma<R, TR, TC, true, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CK(hipFuncSetAttribute((const void *)k_residual_dma<R, TR, TC, false, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_dma<R, TR, TC, true, NBUF>), grid, dim3(NT), shmem, a);
+    else        LAUNCH(ctx, "residual_r1", (k_residual_dma<R, TR, TC, false, NBUF>), grid, dim3(NT), shmem, a);
+    return 0;
+}
+
 // Dispatch order of the tiles.  Workgroup b of a launch runs on XCD b % 8 and each XCD starts its workgroups in
 // order, 32 resident at a time (one per CU: the halo buffers fill the LDS).  The 32 tiles an XCD works on
 // together stream the same frames at the same pace, so the halo pixels they share are fetched from the fabric
@@ -409,6 +623,7 @@ static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
     switch (variant) {
+        case 10: return launch_r1_dma<R, 32, 16>(ctx, a, has_ac, grid);
         case 1: return launch_r1<R, 32, 8>(ctx, a, has_ac, grid);
         case 2: return launch_r1<R, 32, 16>(ctx, a, has_ac, grid);
         case 3: return launch_r1<R, 64, 4>(ctx, a, has_ac, grid);
@@ -419,7 +634,7 @@ static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac
 
 static void tile_shape(int variant, int &TR, int &TC) {
     TR = 16; TC = 16;
-    if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2) { TR = 32; TC = 16; }
+    if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2 || variant == 10) { TR = 32; TC = 16; }
     else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
     else if (variant >= 5 && variant <= 9) { TR = ARC_TR; TC = ARC_TC; }
 }
@@ -458,14 +673,14 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
            P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
 
     // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
-    int variant = (int)ctx->opt("r1_variant", 2);
+    int variant = (int)ctx->opt("r1_variant", 10);
     const int h = P->radius;
     bool full_ring = true;
     { int n = 0;
       for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
-    if (h == 18 && variant >= 5) variant = 2;             // arc kernel: radius 15 only (ds_read immediates)
+    if (h == 18 && variant >= 5 && variant <= 9) variant = 2;   // arc kernel: radius 15 only (ds_read immediates)
     const bool special = full_ring && (h == 15 || h == 18) && variant >= 0;
     int TR = 16, TC = 16;
     if (special) tile_shape(variant, TR, TC);

@@ -142,7 +142,11 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
     constexpr int NA = ArcConst<R>::tab.n[0];                         // offsets per arc (equal for all four)
     static_assert(ArcConst<R>::tab.n[1] == NA && ArcConst<R>::tab.n[2] == NA && ArcConst<R>::tab.n[3] == NA && NA % 2 == 0, "arcs must be balanced");
     constexpr int NW = NA / 2;
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHp] | part[4][NC]
+    // partial sums: the vertical roles write lane -> column at a fixed row, so their tiles use a column stride of
+    // TRp = 17 slots (odd: the 8 lanes of a ds_write_b128 group land on 8 distinct bank octets; with stride 16 they
+    // collided 8-way -- SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles); the horizontal roles write lane -> row.
+    constexpr int TRp = TR + 1, NCp = TRp * TC;
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHp] | part: 2 x NCp (vertical) + 2 x NC (horizontal)
     float4 *halo = lds, *part = lds + 2 * NHp;
     const int tid = threadIdx.x;
     const int tmap = a.tile_map[blockIdx.x];                          // XCD-compact tile order (build_tile_map)
@@ -243,11 +247,12 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
         else arc_product<R, 3, P, HRp, NW>(hb, wp, acc);
 #pragma unroll
         for (int j = 0; j < P; ++j)
-            part[role * NC + cc[j] * TR + cr[j]] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+            part[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + (role - 2) * NC + cc[j] * TR + cr[j]] =
+                make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
         __syncthreads();
         if (fvalid) {
-            const int ci = fc * TR + fr;
-            const float4 p0 = part[ci], p1 = part[NC + ci], p2 = part[2 * NC + ci], p3 = part[3 * NC + ci];
+            const int ci = fc * TR + fr, cv = fc * TRp + fr;
+            const float4 p0 = part[cv], p1 = part[NCp + cv], p2 = part[2 * NCp + ci], p3 = part[2 * NCp + NC + ci];
             float4 c = halo[cur * NHp + (fc + R) * HRp + (fr + R)];   // (Y - Ymean) at the centre
             if (HAS_AC) {
                 for (int e = 0; e < nwa; ++e) {
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
 template <int R, int P, int ABL = 0, int PD = 1>
 static int launch_r1_arc(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
     constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1;
-    constexpr size_t shmem = (2 * (size_t)HRp * HC + 4 * (size_t)ARC_TR * ARC_TC) * sizeof(float4);
+    constexpr size_t shmem = (2 * (size_t)HRp * HC + 2 * (size_t)(ARC_TR + 1) * ARC_TC + 2 * (size_t)ARC_TR * ARC_TC) * sizeof(float4);
     static_assert(shmem <= 160 * 1024, "arc kernel exceeds LDS");
     static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
     constexpr int NT = 4 * ARC_TR * ARC_TC / P;

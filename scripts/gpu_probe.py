@@ -55,7 +55,7 @@ def main():
             key = "residual_r1" if "residual_r1" in tab and tab["residual_r1"]["calls"] else "residual_r1_generic"
             ms = tab[key]["total_ms"] / max(1, tab[key]["calls"])
             print("R1 variant %2d %-4s: %8.3f ms  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (v, flavour, ms, bytes_r1 / ms / 1e6, bytes_r1 / ms / 1e6 / 80), flush=True)
-    eng.set_option("r1_variant", 2)
+    eng.set_option("r1_variant", 10)
     for it in range(a.iters):
         eng.profile_reset()
         torch.cuda.synchronize(); t0 = time.time()

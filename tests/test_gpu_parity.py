@@ -118,7 +118,7 @@ def test_residual_parity(eng, r, dims, pdims, T, with_ac):
         assert rel(got.T, ref) <= 1e-4, rel(got.T, ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10])
 def test_residual_variants_agree(eng, variant):
     c = Case(eng, 80, 72, 24, 4, 15, 3)
     rng = np.random.default_rng(2)
@@ -130,7 +130,7 @@ def test_residual_variants_agree(eng, variant):
     base = eng.residual(0, A_b, c.f.C_init, want=True)
     eng.set_option("r1_variant", variant)
     got = eng.residual(0, A_b, c.f.C_init, want=True)
-    eng.set_option("r1_variant", 2)
+    eng.set_option("r1_variant", 10)
     assert rel(got, base) <= 2e-6, rel(got, base)
 
 
@@ -405,3 +405,28 @@ def test_fast_temporal_parity(eng):
     s.update_background_parallel(); o.update_background_parallel()
     s.update_temporal_parallel(use_c_hat=False); o.update_temporal_parallel(use_c_hat=False)
     assert rel(s.C, o.C) <= 1e-3, rel(s.C, o.C)
+
+
+def test_residual_dma_many_footprints(eng):
+    """R1 LDS-DMA kernel (variant 10) when a tile's rings touch more traces than its LDS trace buffer holds (64) and a
+    pixel's ring touches more than 4 footprints: the overflow goes through the per-pixel global fallback."""
+    c = Case(eng, 80, 72, 24, 4, 15, 3)
+    rng = np.random.default_rng(7)
+    W0 = c.W0((0, 0)).tocsr(); W0.sort_indices()
+    eng.ring_set_values(0, (W0.data * (1 + 0.5 * rng.standard_normal(W0.nnz))).astype(np.float32))
+    eng.set_b0(0, np.full(W0.shape[0], 990.0, dtype=np.float32))
+    K, d = 160, 80 * 72
+    rows, cols, vals = [], [], []
+    for k in range(K):
+        r0, c0 = rng.integers(0, 78), rng.integers(0, 70)
+        for dr in range(3):
+            for dc in range(3):
+                rows.append((c0 + dc) * 80 + r0 + dr); cols.append(k); vals.append(rng.random() + 0.1)
+    A_b = sp.csc_matrix((np.array(vals, np.float32), (rows, cols)), shape=(d, K)); A_b.sum_duplicates()
+    Cm = rng.random((K, 24)).astype(np.float32) * 5
+    eng.set_option("r1_variant", -1)
+    base = eng.residual(0, A_b, Cm, want=True)
+    eng.set_option("r1_variant", 10)
+    got = eng.residual(0, A_b, Cm, want=True)
+    eng.set_option("r1_variant", 10)
+    assert rel(got, base) <= 2e-6, rel(got, base)
