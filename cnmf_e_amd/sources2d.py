@@ -332,6 +332,7 @@ class Sources2D:
         """@Sources2D/update_background_parallel.m:121-146,176-230,311-317 (ring model, bg_ssub = 1)."""
         self._need_data()
         v, o = self.video, self.options
+        self._prefetch_search_location()
         A_csr = self.A.tocsr()
         infos = {}
         self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update
@@ -405,7 +406,7 @@ class Sources2D:
                 # the residual sweep (:162-166) does not depend on the search mask: start it (the call returns with
                 # the kernel in flight) and build IND (:66) on the host underneath it
                 self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)
-                IND_csr = self._search_location_owned().tocsr()
+                IND_csr = self._search_location_csr()
                 A_csr = self.A.tocsr()
             INDp = IND_csr[pp]
             ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]                          # :87
@@ -443,15 +444,34 @@ class Sources2D:
         self.A = self.engine.post_process_spatial(A_, v.d1, v.d2) if o.spatial_constraints.get("connected", True) else A_   # :341
         self._update_b0_new()                                                                        # :347-351
 
-    def _search_location_owned(self):
+    def _prefetch_search_location(self):
+        """The search mask of the NEXT spatial update depends on A only, which the background update leaves alone: build it
+        on a host thread while the (blocking, GIL-free) fit_ring_model call keeps the GPU busy."""
+        if self.options.search_method != "ellipse":
+            return
+        import concurrent.futures as cf
+        if getattr(self, "_pool", None) is None:
+            self._pool = cf.ThreadPoolExecutor(max_workers=1)
+        A = self.A
+        self._ind_future = (A, self._pool.submit(lambda: self._search_location_owned(A).tocsr()))
+
+    def _search_location_csr(self):
+        fut = getattr(self, "_ind_future", None)
+        self._ind_future = None
+        if fut is not None and fut[0] is self.A:
+            return fut[1].result()
+        return self._search_location_owned().tocsr()
+
+    def _search_location_owned(self, A=None):
         """IND = determine_search_location(obj.A, ...) (:66), evaluated only for the neurons that can reach a patch
         this rank owns (bounding box of the footprint grown by the largest possible ellipse); all other columns are
         empty here and belong to other ranks.  Single rank: every neuron."""
         v, o = self.video, self.options
-        K = self.A.shape[1]
+        A = self.A if A is None else A
+        K = A.shape[1]
         if v.world_size == 1:
-            return determine_search_location(self.A, v.d1, v.d2, o.min_size, o.max_size, o.dist)
-        A = self.A.tocsc()
+            return determine_search_location(A, v.d1, v.d2, o.min_size, o.max_size, o.dist)
+        A = A.tocsc()
         reach = int(np.ceil(o.dist * o.max_size)) + 2
         cand = np.zeros(K, dtype=bool)
         nzcols = np.nonzero(np.diff(A.indptr) > 0)[0]
