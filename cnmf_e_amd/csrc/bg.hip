@@ -378,7 +378,8 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
     }
     const bool last = w.ns == NS;
     auto issue = [&](int st) {
-        const int sc = st < w.nst ? st : w.nst - 1;                      // clamp: keeps the vmcnt arithmetic uniform
+        int sc = st < w.nst ? st : w.nst - 1;                            // clamp: keeps the vmcnt arithmetic uniform
+        if (w.flush_every >> 16) sc = 0;                                 // A/B probe (gram_probe): every stage re-reads stage 0 -> no fabric traffic
         const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
         const unsigned d = w.dA0 + (unsigned)(st & (G4_NBUF - 1)) * (G4_STAGE_F * 4u);
         glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
@@ -425,7 +426,7 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.w, (double)b4.w, acc[sl], 0, 0, 0);
             }
         }
-        if (F32 && (++since == w.flush_every || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
+        if (F32 && (++since == (w.flush_every & 0xffff) || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
             since = 0;
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
@@ -1016,7 +1017,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
             if (f32s)
                 LAUNCH(ctx, "bg_gram_f32s", k_gram4<true>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), (int)ctx->opt("gram_flush", 4), ctx->cov.as<double>());
+                       dTcnt.as<int>(), dTl.as<int>(), (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16), ctx->cov.as<double>());
             else
                 LAUNCH(ctx, "bg_gram_f64", k_gram4<false>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), 0, ctx->cov.as<double>());
