@@ -75,12 +75,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    # test hook for a 1-GPU box: CNMFE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two ranks
+    # on one device); the driver's multi-GPU runs leave it unset and get one rank per GPU over nccl (= RCCL)
+    one_dev = os.environ.get("CNMFE_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     group = None
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if one_dev:
+            td.init_process_group(backend="gloo")
+        else:
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         group = td.group.WORLD
 
     from cnmf_e_amd import synth

@@ -269,18 +269,21 @@ class Sources2D:
             self._cmean_of = self.C
         return self._cmean_val
 
-    def _stitch_distributed(self, acc, aa_tot):
+    def _stitch_distributed(self, pieces, K, T):
         """C_raw(k,:) = sum_m aa_m(k) C_raw_m(k,:) / sum_m aa_m(k)  (update_temporal_parallel.m:269-280) with ONE
-        all-reduce of [acc ; aa] over the process group; division (and, without deconvolution, the row-minimum
-        subtraction :285) happen on the device the collective ran on."""
+        all-reduce of [acc ; aa] over the process group.  The per-patch rows are weighted and scattered on the device
+        the collective runs on, and so are the division and (without deconvolution) the row-minimum subtraction (:285)."""
         import torch
         import torch.distributed as td
-        K, T = acc.shape
         nccl = td.get_backend(self.dist) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-        buf = torch.empty((K, T + 1), dtype=torch.float32, device=dev)
-        buf[:, :T] = torch.from_numpy(acc).to(dev)
-        buf[:, T] = torch.from_numpy(aa_tot.astype(np.float32)).to(dev)
+        buf = torch.zeros((K, T + 1), dtype=torch.float32, device=dev)
+        for ind, C_raw_p, aa_p in pieces:
+            it = torch.from_numpy(np.ascontiguousarray(ind, dtype=np.int64)).to(dev)
+            w = torch.from_numpy(np.ascontiguousarray(aa_p, dtype=np.float32)).to(dev)
+            rows = torch.from_numpy(np.ascontiguousarray(C_raw_p, dtype=np.float32)).to(dev)
+            buf[:, :T].index_add_(0, it, rows * w[:, None])                                          # :274
+            buf[:, T].index_add_(0, it, w)                                                           # :275
         td.all_reduce(buf, group=self.dist)
         aa = buf[:, T:T + 1].clone()
         aa[aa == 0] = 1                                                                               # :279
@@ -509,6 +512,8 @@ class Sources2D:
         A_csr = None
         acc = None                                                         # sum over patches of aa .* C_raw  (:274)
         aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
+        sharded = self.dist is not None and v.world_size > 1
+        pieces = []
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
@@ -532,6 +537,9 @@ class Sources2D:
                 _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)
             else:
                 _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)   # :180-181
+            if sharded:
+                pieces.append((ind, C_raw_p, aa_p))                        # scattered and weighted on the collective's device
+                continue
             contrib = C_raw_p * aa_p[:, None].astype(np.float32)                                     # :274
             if acc is None and ind.size == K:
                 acc = contrib                                              # first patch sees every neuron: no scatter-add needed
@@ -540,11 +548,11 @@ class Sources2D:
                     acc = np.zeros((K, T), dtype=np.float32)
                 acc[ind] += contrib
             aa_tot[ind] += aa_p                                                                      # :275
-        if acc is None:
-            acc = np.zeros((K, T), dtype=np.float32)
-        if self.dist is not None and v.world_size > 1:                    # the overlap-region stitch: ONE all-reduce
-            C_raw = self._stitch_distributed(acc, aa_tot)
+        if sharded:                                                        # the overlap-region stitch: ONE all-reduce
+            C_raw = self._stitch_distributed(pieces, K, T)
         else:
+            if acc is None:
+                acc = np.zeros((K, T), dtype=np.float32)
             aa_tot[aa_tot == 0] = 1                                                                   # :279
             C_raw = acc
             C_raw /= aa_tot[:, None].astype(np.float32)                                              # :280
@@ -552,8 +560,8 @@ class Sources2D:
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.deconvTemporal()
         else:
-            if not (self.dist is not None and v.world_size > 1):
-                C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285
+            if not sharded:
+                C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285 (sharded: done on the device)
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.C_raw                                                                       # :286
         self._update_b0_new()                                                                         # :291-295
