@@ -107,6 +107,10 @@ struct R1Args {
     const int *tile_map;         // dispatch slot -> tile_r | tile_c << 16 (XCD-compact order, built on the host)
 };
 
+constexpr int R1_TKMAX = 64;                // traces staged per tile and chunk (one DMA instruction)
+constexpr int R1_KBM = 8192;                // neurons the tile-list bitmap covers (beyond: per-pixel global loads)
+constexpr int R1_OVF = 384;                 // workgroup-wide list of (W*A) entries beyond those a pixel keeps in registers
+
 // compile-time ring of get_nhood(R) in MATLAB find() order (column offset slow, row offset fast)
 template <int R> struct RingTab { int n; int dr[PMAX_RING]; int dc[PMAX_RING]; };
 template <int R> constexpr RingTab<R> make_ring() {
@@ -321,9 +325,6 @@ __global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::
 // flight while chunk c is consumed (three LDS buffers, ONE barrier per chunk).  The DMA writes lane-linearly, so a
 // buffer is 48 wave-instructions x 64 slots of 16 B; slots past the halo and halo pixels outside the block fetch a
 // clamped address: their ring weights are exactly 0 (every neighbour outside the block is outside the FOV).
-constexpr int R1_TKMAX = 64;                // traces staged per tile and chunk (one DMA instruction)
-constexpr int R1_KBM = 8192;                // neurons the tile-list bitmap covers (beyond: per-pixel global loads)
-constexpr int R1_OVF = 384;                 // workgroup-wide list of (W*A) entries beyond the 4 a pixel keeps in registers
 
 template <int R, int TR, int TC, bool HAS_AC, int NBUF>
 __global__ void __launch_bounds__(TR *TC, 2) k_residual_dma(R1Args a) {
@@ -619,6 +620,7 @@ static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac
         if (variant == 7) return launch_r1_arc<R, 2, 1, 3>(ctx, a, has_ac, ntile_c, nseg);   // ablation: staging + stores only, 3 chunks in flight
         if (variant == 8) return launch_r1_arc<R, 4, 0, 2>(ctx, a, has_ac, ntile_c, nseg);   // 2 chunks in flight
         if (variant == 9) return launch_r1_arc<R, 4, 0, 3>(ctx, a, has_ac, ntile_c, nseg);   // 3 chunks in flight
+        if (variant == 11) return launch_r1_arc_dma<R>(ctx, a, has_ac, ntile_c, nseg);         // arc roles on LDS-DMA staging
     }
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
@@ -636,7 +638,7 @@ static void tile_shape(int variant, int &TR, int &TC) {
     TR = 16; TC = 16;
     if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2 || variant == 10) { TR = 32; TC = 16; }
     else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
-    else if (variant >= 5 && variant <= 9) { TR = ARC_TR; TC = ARC_TC; }
+    else if ((variant >= 5 && variant <= 9) || variant == 11) { TR = ARC_TR; TC = ARC_TC; }
 }
 
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
@@ -673,14 +675,14 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
            P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
 
     // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
-    int variant = (int)ctx->opt("r1_variant", 10);
+    int variant = (int)ctx->opt("r1_variant", 11);
     const int h = P->radius;
     bool full_ring = true;
     { int n = 0;
       for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
-    if (h == 18 && variant >= 5 && variant <= 9) variant = 2;   // arc kernel: radius 15 only (ds_read immediates)
+    if (h == 18 && ((variant >= 5 && variant <= 9) || variant == 11)) variant = 10;   // arc kernels: radius 15 only (ds_read immediates)
     const bool special = full_ring && (h == 15 || h == 18) && variant >= 0;
     int TR = 16, TC = 16;
     if (special) tile_shape(variant, TR, TC);

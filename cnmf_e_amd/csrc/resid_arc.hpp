@@ -282,6 +282,230 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
     }
 }
 
+// ---- arc roles on LDS-DMA staging (r1_variant 11) -------------------------------------------------------------
+// The ring product of k_residual_arc (P = 4: half the LDS reads of the one-pixel-per-thread kernel) with the halo
+// staged by global_load_lds_dwordx4 as in k_residual_dma: two halo buffers (the partial sums take the third's room),
+// chunk c+1 in flight under chunk c, traces of the A_prev flavour staged in LDS.  Two barriers per chunk: halo
+// landed / partial sums complete.
+template <int R, bool HAS_AC>
+__global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma(R1Args a) {
+    constexpr int P = 4;
+    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC, NT = NC, NWV = NT / 64;
+    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
+    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;
+    constexpr int NHp = HRp * HC;
+    constexpr int NIT = (NHp + NT - 1) / NT, NHs = NIT * NT;          // DMA slots per buffer (lane-linear image of [HC][HRp])
+    constexpr int NA = ArcConst<R>::tab.n[0];
+    static_assert(ArcConst<R>::tab.n[1] == NA && ArcConst<R>::tab.n[2] == NA && ArcConst<R>::tab.n[3] == NA && NA % 2 == 0, "arcs must be balanced");
+    constexpr int NW = NA / 2;
+    constexpr int TRp = TR + 1, NCp = TRp * TC;
+    constexpr int NBUF = 2;
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHs] | part | tbuf[2][R1_TKMAX] | scratch
+    float4 *halo = lds, *part = lds + NBUF * NHs, *tbuf = part + 2 * NCp + 2 * NC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tmap = a.tile_map[blockIdx.x];
+    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
+    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
+    // ---- role geometry (as k_residual_arc) ----
+    constexpr int TPR = NC / P;
+    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;
+    int cr[P], cc[P];
+    int hbase;
+    if (role < 2) {
+        const int c = rt & 31, g = rt >> 5;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
+        hbase = c * HRp + g * P;
+    } else {
+        const int q = rt >> 4, i = rt & 15;
+        const int sq = (q * P * HRp) & 15;
+        const int r = (i - sq) & 15;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
+        hbase = q * P * HRp + r;
+    }
+    f2 wp[P][NW];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
+        const int64_t m = (pr < a.nr && pc < a.nc) ? (int64_t)pc * a.nr + pr : 0;
+        const uint32_t mb = (uint32_t)m * 4u;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int i0, i1;
+            if (role == 0) { i0 = ArcConst<R>::tab.ring[0][2 * k]; i1 = ArcConst<R>::tab.ring[0][2 * k + 1]; }
+            else if (role == 1) { i0 = ArcConst<R>::tab.ring[1][2 * k]; i1 = ArcConst<R>::tab.ring[1][2 * k + 1]; }
+            else if (role == 2) { i0 = ArcConst<R>::tab.ring[2][2 * k]; i1 = ArcConst<R>::tab.ring[2][2 * k + 1]; }
+            else { i0 = ArcConst<R>::tab.ring[3][2 * k]; i1 = ArcConst<R>::tab.ring[3][2 * k + 1]; }
+            wp[j][k].x = ld_off(a.W + (int64_t)i0 * a.d, mb);
+            wp[j][k].y = ld_off(a.W + (int64_t)i1 * a.d, mb);
+        }
+    }
+    // ---- DMA plan: instruction j of wave w fills slots (j*NWV + w)*64 + lane of the [HC][HRp] image ----
+    uint32_t qoff[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int idx = (j * NWV + wave) * 64 + lane;
+        const int hr = idx % HRp, hc = idx / HRp;
+        int rb = hr0 + hr, cb = hc0 + (hc < HC ? hc : HC - 1);
+        rb = rb < 0 ? 0 : (rb >= a.nr_b ? a.nr_b - 1 : rb);
+        cb = cb < 0 ? 0 : (cb >= a.nc_b ? a.nc_b - 1 : cb);
+        qoff[j] = (uint32_t)(cb * a.nr_b + rb) * 16u;
+    }
+    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds;
+    const unsigned lds0 = ldsA + (unsigned)wave * 1024u;
+    // ---- final-pass centre of this thread ----
+    const int fr = tid % TR, fc = tid / TR;
+    const int fpr = tile_r * TR + fr, fpc = tile_c * TC + fc;
+    const bool fvalid = fpr < a.nr && fpc < a.nc;
+    const int64_t fm = fvalid ? (int64_t)fpc * a.nr + fpr : 0;
+    const uint32_t fmb = (uint32_t)fm * 4u;
+    const float dl = ld_off(a.dlt, fmb);
+    // ---- (W*A_prev): tile trace list + per-pixel (slot, weight) entries, as in k_residual_dma ----
+    constexpr int WA_PRE = 8;
+    int wsl[WA_PRE]; float wvv[WA_PRE]; int nwa = 0; bool spill = false;
+    int ov0 = 0, ov1 = 0;
+    uint32_t tkoff = 0;
+    unsigned *bm = reinterpret_cast<unsigned *>(tbuf + NBUF * R1_TKMAX);
+    int *pre = reinterpret_cast<int *>(bm + R1_KBM / 32);
+    int *tk = pre + R1_KBM / 32 + 2;
+    int2 *ovl = reinterpret_cast<int2 *>(tk + R1_TKMAX);
+    if (HAS_AC) {
+        for (int w = tid; w < R1_KBM / 32; w += NT) bm[w] = 0u;
+        if (tid < R1_TKMAX) tk[tid] = 0;
+        if (tid == 0) pre[R1_KBM / 32 + 1] = 0;
+        __syncthreads();
+        nwa = fvalid ? a.wa_cnt[fm] : 0;
+        for (int e = 0; e < nwa; ++e) {
+            const int k = a.wa_k[(int64_t)e * a.d + fm];
+            if (k < R1_KBM) atomicOr(&bm[k >> 5], 1u << (k & 31));
+        }
+        __syncthreads();
+        if (tid == 0) { int s_ = 0; for (int w = 0; w < R1_KBM / 32; ++w) { pre[w] = s_; s_ += __popc(bm[w]); } pre[R1_KBM / 32] = s_; }
+        __syncthreads();
+        for (int k = tid; k < R1_KBM; k += NT) {
+            const unsigned word = bm[k >> 5];
+            if ((word >> (k & 31)) & 1u) { const int pos = pre[k >> 5] + __popc(word & ((1u << (k & 31)) - 1u)); if (pos < R1_TKMAX) tk[pos] = k; }
+        }
+        auto slot_of = [&](int k) {
+            if (k >= R1_KBM) return -1;
+            const unsigned word = bm[k >> 5];
+            const int sl = pre[k >> 5] + __popc(word & ((1u << (k & 31)) - 1u));
+            return sl < R1_TKMAX ? sl : -1;
+        };
+#pragma unroll
+        for (int e = 0; e < WA_PRE; ++e) {
+            wsl[e] = -1; wvv[e] = 0.f;
+            if (e < nwa) {
+                const int sl = slot_of(a.wa_k[(int64_t)e * a.d + fm]);
+                if (sl >= 0) { wsl[e] = sl; wvv[e] = a.wa_v[(int64_t)e * a.d + fm]; }
+                else { wsl[e] = -2; spill = true; }
+            }
+        }
+        if (nwa > WA_PRE) {
+            const int n = nwa - WA_PRE;
+            ov0 = atomicAdd(&pre[R1_KBM / 32 + 1], n); ov1 = ov0 + n;
+            bool ok = ov1 <= R1_OVF;
+            for (int e = WA_PRE; e < nwa && ok; ++e) {
+                const int sl = slot_of(a.wa_k[(int64_t)e * a.d + fm]);
+                if (sl < 0) ok = false;
+                else ovl[ov0 + e - WA_PRE] = make_int2(sl, __float_as_int(a.wa_v[(int64_t)e * a.d + fm]));
+            }
+            if (!ok) { ov0 = ov1 = 0; spill = true; }
+        }
+        __syncthreads();
+        tkoff = (uint32_t)tk[lane] * (uint32_t)(a.ldc * 4);
+    }
+    const int64_t cbeg = ((int64_t)blockIdx.y * a.tseg) >> 2;
+    const int64_t tend = (int64_t)blockIdx.y * a.tseg + a.tseg < a.T ? (int64_t)blockIdx.y * a.tseg + a.tseg : a.T;
+    const int64_t cend = (tend + 3) >> 2;
+    const bool tw = HAS_AC && wave == 0;
+    auto issue = [&](int64_t c) {
+        const int64_t cx = c < cend ? c : cend - 1;
+        const float4 *y4 = a.Y4 + cx * a.d_b;
+        const int b = (int)((c - cbeg) & 1);
+        const unsigned dst = lds0 + (unsigned)b * (unsigned)(NHs * 16);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) glds16(y4, qoff[j], dst + (unsigned)(j * NWV) * 1024u);
+        if (tw) glds16(a.Cc + 4 * cx, tkoff, ldsA + (unsigned)((NBUF * NHs + 2 * NCp + 2 * NC) + b * R1_TKMAX) * 16u);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(cbeg);
+    for (int64_t c = cbeg; c < cend; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's part of chunk c (and its stores of chunk c-1)
+        __builtin_amdgcn_s_barrier();                           // halo(c) complete; everybody is past the final pass of c-1
+        asm volatile("" ::: "memory");
+        issue(c + 1);
+        const int cb_ = (int)((c - cbeg) & 1);
+        const float4 *hb = halo + cb_ * NHs + hbase;
+        f2 acc[P][2];
+#pragma unroll
+        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
+        if (role == 0) arc_product<R, 0, P, HRp, NW>(hb, wp, acc);
+        else if (role == 1) arc_product<R, 1, P, HRp, NW>(hb, wp, acc);
+        else if (role == 2) arc_product<R, 2, P, HRp, NW>(hb, wp, acc);
+        else arc_product<R, 3, P, HRp, NW>(hb, wp, acc);
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            part[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + (role - 2) * NC + cc[j] * TR + cr[j]] =
+                make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // partial sums complete
+        asm volatile("" ::: "memory");
+        {
+            const int ci = fc * TR + fr, cv_ = fc * TRp + fr;
+            const float4 p0 = part[cv_], p1 = part[NCp + cv_], p2 = part[2 * NCp + ci], p3 = part[2 * NCp + NC + ci];
+            float4 cv = halo[cb_ * NHs + (fc + R) * HRp + (fr + R)];
+            if (HAS_AC) {
+                const float4 *tb = tbuf + cb_ * R1_TKMAX;
+#pragma unroll
+                for (int e = 0; e < WA_PRE; ++e) {
+                    const float4 c4 = tb[wsl[e] >= 0 ? wsl[e] : 0];
+                    cv.x = fmaf(wvv[e], c4.x, cv.x); cv.y = fmaf(wvv[e], c4.y, cv.y);
+                    cv.z = fmaf(wvv[e], c4.z, cv.z); cv.w = fmaf(wvv[e], c4.w, cv.w);
+                }
+                for (int q = ov0; q < ov1; ++q) {
+                    const int2 en = ovl[q];
+                    const float4 c4 = tb[en.x]; const float v = __int_as_float(en.y);
+                    cv.x = fmaf(v, c4.x, cv.x); cv.y = fmaf(v, c4.y, cv.y); cv.z = fmaf(v, c4.z, cv.z); cv.w = fmaf(v, c4.w, cv.w);
+                }
+            }
+            if (fvalid) {
+                if (HAS_AC && spill) {
+                    for (int e = 0; e < nwa; ++e) {
+                        if (e < WA_PRE ? wsl[e] != -2 : ov1 > ov0) continue;
+                        const float v = a.wa_v[(int64_t)e * a.d + fm];
+                        const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + fm] * a.ldc + (c << 2));
+                        cv.x = fmaf(v, c4.x, cv.x); cv.y = fmaf(v, c4.y, cv.y); cv.z = fmaf(v, c4.z, cv.z); cv.w = fmaf(v, c4.w, cv.w);
+                    }
+                }
+                st4_off(a.Ysig4 + c * a.d, fmb * 4u,
+                        make_float4(cv.x + dl - ((p0.x + p1.x) + (p2.x + p3.x)), cv.y + dl - ((p0.y + p1.y) + (p2.y + p3.y)),
+                                    cv.z + dl - ((p0.z + p1.z) + (p2.z + p3.z)), cv.w + dl - ((p0.w + p1.w) + (p2.w + p3.w))));
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int R>
+static int launch_r1_arc_dma(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
+    constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1, NT = ARC_TR * ARC_TC;
+    constexpr int NIT = (HRp * HC + NT - 1) / NT;
+    constexpr size_t shmem = (2 * (size_t)NIT * NT + 2 * (size_t)(ARC_TR + 1) * ARC_TC + 2 * (size_t)ARC_TR * ARC_TC + 2 * R1_TKMAX) * sizeof(float4) +
+                             (size_t)(R1_KBM / 32 + R1_KBM / 32 + 2 + R1_TKMAX + 2 * R1_OVF) * sizeof(int);
+    static_assert(shmem <= 160 * 1024, "arc DMA kernel exceeds LDS");
+    static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
+    dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
+    CK(hipFuncSetAttribute((const void *)k_residual_arc_dma<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CK(hipFuncSetAttribute((const void *)k_residual_arc_dma<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_arc_dma<R, true>), grid, dim3(NT), shmem, a);
+    else        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma<R, false>), grid, dim3(NT), shmem, a);
+    return 0;
+}
+
 template <int R, int P, int ABL = 0, int PD = 1>
 static int launch_r1_arc(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
     constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1;

@@ -118,7 +118,7 @@ def test_residual_parity(eng, r, dims, pdims, T, with_ac):
         assert rel(got.T, ref) <= 1e-4, rel(got.T, ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11])
 def test_residual_variants_agree(eng, variant):
     c = Case(eng, 80, 72, 24, 4, 15, 3)
     rng = np.random.default_rng(2)
@@ -407,7 +407,8 @@ def test_fast_temporal_parity(eng):
     assert rel(s.C, o.C) <= 1e-3, rel(s.C, o.C)
 
 
-def test_residual_dma_many_footprints(eng):
+@pytest.mark.parametrize("variant", [10, 11])
+def test_residual_dma_many_footprints(eng, variant):
     """R1 LDS-DMA kernel (variant 10) when a tile's rings touch more traces than its LDS trace buffer holds (64) and a
     pixel's ring touches more than 4 footprints: the overflow goes through the per-pixel global fallback."""
     c = Case(eng, 80, 72, 24, 4, 15, 3)
@@ -426,7 +427,7 @@ def test_residual_dma_many_footprints(eng):
     Cm = rng.random((K, 24)).astype(np.float32) * 5
     eng.set_option("r1_variant", -1)
     base = eng.residual(0, A_b, Cm, want=True)
-    eng.set_option("r1_variant", 10)
+    eng.set_option("r1_variant", variant)
     got = eng.residual(0, A_b, Cm, want=True)
     eng.set_option("r1_variant", 10)
     assert rel(got, base) <= 2e-6, rel(got, base)
