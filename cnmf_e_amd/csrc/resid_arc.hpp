@@ -97,10 +97,9 @@ template <int R, int P> struct ProgConst { static constexpr ArcProg<R, P> tab = 
 //   vertical roles  (ARC 0/1): &halo[c * HRp + g*P]      -> value of (row g*P + i, col c + j) at hb[(j+R)*HRp + (i+R)]
 //   horizontal roles(ARC 2/3): &halo[h*P * HRp + r]      -> value of (row r + i, col h*P + j) at the same expression
 // wp[j][a/2] holds the arc weights of centre j as pairs; acc[j][0] = frames 0,1, acc[j][1] = frames 2,3.
-template <int R, int ARC, int P, int HRp, int NW>
+template <int R, int ARC, int P, int HRp, int NW, int D = 4>
 __device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][NW], f2 (&acc)[P][2]) {
-    constexpr int NL = ProgConst<R, P>::tab.nl[ARC];
-    constexpr int D = 4;                                   // LDS reads in flight ahead of their FMAs
+    constexpr int NL = ProgConst<R, P>::tab.nl[ARC];       // D = LDS reads in flight ahead of their FMAs
     float4 r[D + 1];
 #define ARC_ADDR(li) (ARC < 2 ? hb + (ProgConst<R, P>::tab.fix[ARC][li] + R) * HRp + (ProgConst<R, P>::tab.mov[ARC][li] + R) \
                               : hb + (ProgConst<R, P>::tab.mov[ARC][li] + R) * HRp + (ProgConst<R, P>::tab.fix[ARC][li] + R))
@@ -287,7 +286,7 @@ __global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Ar
 // staged by global_load_lds_dwordx4 as in k_residual_dma: two halo buffers (the partial sums take the third's room),
 // chunk c+1 in flight under chunk c, traces of the A_prev flavour staged in LDS.  Two barriers per chunk: halo
 // landed / partial sums complete.
-template <int R, bool HAS_AC>
+template <int R, bool HAS_AC, int ARC_D = 4>
 __global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma(R1Args a) {
     constexpr int P = 4;
     constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC, NT = NC, NWV = NT / 64;
@@ -442,10 +441,10 @@ __global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma(R1Args a
         f2 acc[P][2];
 #pragma unroll
         for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
-        if (role == 0) arc_product<R, 0, P, HRp, NW>(hb, wp, acc);
-        else if (role == 1) arc_product<R, 1, P, HRp, NW>(hb, wp, acc);
-        else if (role == 2) arc_product<R, 2, P, HRp, NW>(hb, wp, acc);
-        else arc_product<R, 3, P, HRp, NW>(hb, wp, acc);
+        if (role == 0) arc_product<R, 0, P, HRp, NW, ARC_D>(hb, wp, acc);
+        else if (role == 1) arc_product<R, 1, P, HRp, NW, ARC_D>(hb, wp, acc);
+        else if (role == 2) arc_product<R, 2, P, HRp, NW, ARC_D>(hb, wp, acc);
+        else arc_product<R, 3, P, HRp, NW, ARC_D>(hb, wp, acc);
 #pragma unroll
         for (int j = 0; j < P; ++j)
             part[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + (role - 2) * NC + cc[j] * TR + cr[j]] =
