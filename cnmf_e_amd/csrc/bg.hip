@@ -805,6 +805,253 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
     }
 }
 
+// ---- B2b v3 (experimental, solve_mode=3; NOT the default) -----------------------------------------------
+// Correct (same parity tests as v2) but slower: 34 ms vs 23 ms at 512x512, p=96.  The matrix of one pixel is 72 KB
+// whether it sits in LDS (v2: 3 workgroups per CU) or in registers (here: 253 VGPR+AGPR, 2 workgroups per CU), so the
+// register-resident form buys no occupancy, and its 16x16 diagonal factor + explicit inverse (wave 0, ~1500
+// instructions per block) is a longer serial chain than v2's 8-column register panel.  Kept for the MFMA trailing
+// update (the part that does work), which is the piece to graft onto v2's LDS layout.
+// ---- B2b v3: the normal equations of one pixel as MFMA accumulator tiles ----------------------------------
+// v2 keeps the packed triangle in LDS (41 KB: 3 workgroups per CU) and every phase is a chain of LDS round trips
+// with multi-way bank conflicts on the triangle (probes: assembly 3, panel 6, trailing update 8.6, back substitution
+// 4 ms).  Here the matrix lives in REGISTERS as 16x16 fp64 tiles in v_mfma_f64_16x16x4 accumulator layout, split
+// over the four waves by row block; LDS only carries the current block column.
+//   unknowns 0..p (p neighbours + intercept) padded with identity to 112 = 7 row blocks; the right-hand side is an
+//   8th row block (row 0 real), so it is eliminated by the same TRSM/update code and ends up as z = L^-1 g.
+//   step kb: owners publish block column kb -> wave 0 factors the 16x16 diagonal tile and inverts it (registers,
+//   lane = row, v_readlane broadcasts) -> every owner: L(I,kb) = A(I,kb) * Linv^T on the MFMA pipe -> trailing
+//   update A(I,J) -= L(I,kb) L(J,kb)^T, 4 MFMAs per tile.  Back substitution by row blocks with the stored inverses.
+constexpr int S3_NU = 7, S3_NB = 8, S3_LD = 17, S3_TILE = 16 * S3_LD, S3_NSLOT = 11;
+
+__device__ __forceinline__ double4_t s3_mfma(double a, double b, double4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+__global__ void __launch_bounds__(256) k_ring_solve3(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
+                                                     const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
+                                                     float *__restrict__ W) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int p = g.p;
+    double *panel = sm;                                   // S3_NB tiles [16][S3_LD]: block column kb (A, then L)
+    double *linv = panel + S3_NB * S3_TILE;               // S3_NU tiles: inverse of every diagonal factor
+    double *zv = linv + S3_NU * S3_TILE;                  // 128: z = L^-1 g
+    double *av = zv + 128;                                // 128: accumulated L^T w of the blocks below
+    double *wv = av + 128;                                // 128: solution
+    double *sc = wv + 128;                                // 8 scalars
+    int *nb = reinterpret_cast<int *>(sc + 8);            // p neighbour codes
+    int *node = nb + p;                                   // p+1 node codes
+    int *pt = node + p + 1;                               // nbw^4 block-pair codes
+    const int64_t m = blockIdx.x;
+    if (active && !active[m]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lg = lane >> 4;             // accumulator layout: element r of a tile is (row lg + 4r, col lc)
+    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
+    for (int i = tid; i < p; i += 256) {
+        const int rb = rbm + dr[i], cb = cbm + dc[i];
+        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
+        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
+    }
+    if (tid < 8) sc[tid] = 0.0;
+    for (int i = tid; i < 128; i += 256) { av[i] = 0.0; zv[i] = 0.0; wv[i] = 0.0; }
+    __syncthreads();
+    const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;
+    const int nbw = g.nbw, nb2 = nbw * nbw;
+    for (int q = tid; q < nb2 * nb2; q += 256) {
+        const int a = q / nb2, b = q % nb2;
+        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
+        int code = -1;
+        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
+            int dR = ib - ia, dC = jb - ja, sw = 0;
+            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
+            const int pidx = tab.pair_of[(ja * tab.nbr + ia) * NREL + rel_index(dR, dC)];
+            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
+        }
+        pt[q] = code;
+    }
+    for (int i = tid; i <= p; i += 256) {
+        const int c = i < p ? nb[i] : (rbm | (cbm << 16));
+        int nc = -1;
+        if (c >= 0) { const int rb = c & 0xffff, cb = c >> 16; nc = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15); }
+        node[i] = nc;
+    }
+    __syncthreads();
+    // covariance of two nodes (block-local codes), through the block-pair table
+    auto cov_ptr = [&](int na_, int nb_) -> const double * {
+        const int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
+        int la = na_ & 255, lb = nb_ & 255;
+        if (code & 2) { const int t0 = la; la = lb; lb = t0; }
+        if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }
+        return tab.cov + ((int64_t)(code >> 2) * BLKPX + la) * BLKPX + lb;
+    };
+    auto rs_ptr = [&](int c) -> const double * {           // rowsum of a block pixel code (rb | cb << 16)
+        const int rb = c & 0xffff, cb = c >> 16;
+        return &rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + lp_of(rb & 15, cb & 15)];
+    };
+    // element (i, j) of the augmented system: i in 0..111 unknown rows (i > p: identity padding), i >= 112: rhs block
+    auto elem = [&](int i, int j, double &val) -> const double * {
+        val = 0.0;
+        if (i >= 16 * S3_NU) {                             // right-hand side X*y' (fit_ring_model.m:104), row 0 of block 7
+            if (i != 16 * S3_NU) return nullptr;
+            if (j < p) return (node[j] >= 0) ? cov_ptr(node[j], node[p]) : nullptr;
+            if (j == p) return rs_ptr(rbm | (cbm << 16));
+            return nullptr;
+        }
+        if (i < j) { const int t0 = i; i = j; j = t0; }
+        if (i > p) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
+        if (i == p) {                                      // the row of ones (:101)
+            if (j == p) { val = (double)g.Tp; return nullptr; }
+            return nb[j] >= 0 ? rs_ptr(nb[j]) : nullptr;
+        }
+        if (node[i] < 0 || node[j] < 0) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
+        return cov_ptr(node[i], node[j]);
+    };
+    // tile slots of this wave: row blocks Ia = 7 - wave (slots 0..6, J = slot) and Ib = wave (slots 7..10, J = slot - 7)
+    const int Ia = 7 - wave, Ib = wave;
+    auto slotI = [&](int s_) { return s_ < 7 ? Ia : Ib; };
+    auto slotJ = [&](int s_) { return s_ < 7 ? s_ : s_ - 7; };
+    auto slotOn = [&](int s_) { return s_ < 7 ? (s_ <= (Ia < 6 ? Ia : 6)) : (s_ - 7 <= Ib); };
+    double4_t acc[S3_NSLOT];
+#pragma unroll
+    for (int s_ = 0; s_ < S3_NSLOT; ++s_) {
+        acc[s_] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (slotOn(s_)) {
+            const int I = slotI(s_), J = slotJ(s_);
+            const double *ptr[4]; double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ptr[r] = elem(16 * I + lg + 4 * r, 16 * J + lc, v[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ptr[r]) v[r] = *ptr[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s_][r] = v[r];
+        }
+    }
+    // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
+    {
+        double tr = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * slotI(s_) + lg + 4 * r;
+                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) tr += acc[s_][r];
+                }
+            }
+        for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+        if (lane == 0) atomicAdd(&sc[0], tr);
+        __syncthreads();
+        const double lam = sc[0] * 1e-5;
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * slotI(s_) + lg + 4 * r;
+                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) acc[s_][r] += lam;
+                }
+            }
+    }
+    // fragment of an LDS tile X for MFMA k-step mq: X[lc][4*mq + lg]  (serves as A operand of X*Y^T and as B operand of Y*X^T)
+    auto frag = [&](const double *X, int mq) { return X[lc * S3_LD + 4 * mq + lg]; };
+    // ---- blocked Cholesky over the unknown blocks ----
+    for (int kb = 0; kb < S3_NU; ++kb) {
+        // a. publish block column kb
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotJ(s_) == kb) {
+                double *X = panel + slotI(s_) * S3_TILE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * S3_LD + lc] = acc[s_][r];
+            }
+        __syncthreads();
+        // c. wave 0: Cholesky of the diagonal tile and its inverse (lane = row lc; the four lane groups work in lockstep)
+        if (wave == 0) {
+            const double *X = panel + kb * S3_TILE;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = X[lc * S3_LD + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double piv = readlane_f64(a[c], c);
+                const double inv = rsqrt_f64(piv);
+                a[c] = lc == c ? piv * inv : a[c] * inv;                  // column c of L (rows above the diagonal are junk, never used)
+#pragma unroll
+                for (int c2 = c + 1; c2 < 16; ++c2) {
+                    const double l2 = readlane_f64(a[c], c2);              // L[c2][c]
+                    a[c2] = fma(-a[c], l2, a[c2]);
+                }
+            }
+            // inverse: lane lc computes COLUMN lc of Linv by forward substitution: x_r = (d_{r,lc} - sum_{q<r} L[r][q] x_q) / L[r][r]
+            double x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double s_ = (r == lc) ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < r; ++q) s_ = fma(-readlane_f64(a[q], r), x[q], s_);      // L[r][q] lives in lane r, register q
+                const double dinv = 1.0 / readlane_f64(a[r], r);
+                x[r] = (r < lc) ? 0.0 : s_ * dinv;
+            }
+            if (lg == 0) {
+                double *Li = linv + kb * S3_TILE;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Li[r * S3_LD + lc] = x[r];                     // Linv[r][lc]
+            }
+        }
+        __syncthreads();
+        // e. L(I,kb) = A(I,kb) * Linv^T for the blocks below the diagonal (and the right-hand side block)
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotJ(s_) == kb && slotI(s_) > kb) {
+                double *X = panel + slotI(s_) * S3_TILE;
+                const double *Li = linv + kb * S3_TILE;
+                double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) t = s3_mfma(frag(X, mq), frag(Li, mq), t);
+                acc[s_] = t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * S3_LD + lc] = t[r];
+            }
+        __syncthreads();
+        // g. trailing update A(I,J) -= L(I,kb) * L(J,kb)^T
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotJ(s_) > kb) {
+                const double *XI = panel + slotI(s_) * S3_TILE, *XJ = panel + slotJ(s_) * S3_TILE;
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) acc[s_] = s3_mfma(-frag(XI, mq), frag(XJ, mq), acc[s_]);
+            }
+        __syncthreads();
+    }
+    // ---- z = row 0 of the right-hand side block ----
+    if (wave == 0 && lg == 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < 7; ++s_) zv[16 * s_ + lc] = acc[s_][0];
+    }
+    __syncthreads();
+    // ---- back substitution L^T w = z by row blocks, bottom up ----
+    for (int kb = S3_NU - 1; kb >= 0; --kb) {
+        if (wave == 0) {                                   // w_kb = Linv_kk^T (z_kb - acc_kb): lane lc -> entry lc
+            const double *Li = linv + kb * S3_TILE;
+            double w_ = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w_ = fma(Li[r * S3_LD + lc], zv[16 * kb + r] - av[16 * kb + r], w_);
+            if (lg == 0) wv[16 * kb + lc] = w_;
+        }
+        __syncthreads();
+        // acc_J += L(kb,J)^T w_kb for J < kb: the owner of row block kb holds those tiles
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotI(s_) == kb && slotJ(s_) < kb) {
+                double q = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q = fma(acc[s_][r], wv[16 * kb + lg + 4 * r], q);
+                q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                if (lg == 0) av[16 * slotJ(s_) + lc] += q;
+            }
+        __syncthreads();
+    }
+    for (int i = tid; i < p; i += 256) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)wv[i] : 0.f;   // intercept (index p) discarded (:107)
+}
+
 // pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60) and the first-run test on row 1 (:25)
 __global__ void k_count_pos(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1044,7 +1291,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc;
         const int n = p + 1;
-        if (ctx->opt("solve_mode", 2) == 2 && n + 1 <= 128) {
+        if (ctx->opt("solve_mode", 2) == 3 && n <= 16 * S3_NU) {
+            size_t shmem = ((size_t)(S3_NB + S3_NU) * S3_TILE + 3 * 128 + 8) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
+            shmem = (shmem + 15) & ~size_t(15);
+            LAUNCH(ctx, "bg_ring_solve", k_ring_solve3, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
+                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
+        } else if (ctx->opt("solve_mode", 2) >= 2 && n + 1 <= 128) {
             const int na = n + 1;
             size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4 + na) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
             shmem = (shmem + 15) & ~size_t(15);
