@@ -628,8 +628,7 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
     const int p = g.p, n = p + 1, na = n + 1;
     double *L = sm;                                   // rows 0..n packed; row n = [g ; unused]
     double *red = sm + tri(na);                       // 4 partial traces
-    double *dinv = red + 4;                           // 1 / L(j,j), na entries
-    int *nb = reinterpret_cast<int *>(dinv + na);     // p neighbour codes
+    int *nb = reinterpret_cast<int *>(red + 4);       // p neighbour codes
     int *node = nb + p;                               // p+1 node codes (block-local), see the assembly
     int *pt = node + p + 1;                           // nbw^4 block-pair codes
     const int64_t m = blockIdx.x;
@@ -734,7 +733,9 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
                     const double piv = readlane_f64(a[jj], jj);
                     const double inv = rsqrt_f64(piv);
                     const double dj = piv * inv;
-                    if (lane == jj) { a[jj] = dj; dinv[j0 + jj] = inv; } else if (lane > jj) a[jj] *= inv;
+                    (void)dj;                                  // the diagonal slot keeps 1/L(j,j): that is all back substitution needs, and
+                    if (lane == jj) a[jj] = inv;               // dropping the separate array brings the workgroup under 40 KB of LDS (4 per CU)
+                    else if (lane > jj) a[jj] *= inv;
                     b[jj] *= inv;
 #pragma unroll
                     for (int c = jj + 1; c < PW; ++c) {
@@ -754,7 +755,7 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
         }
         __syncthreads();
         const int j1 = j0 + w;
-        const int ti = tid & 15, tk = tid >> 4;
+        const int ti = tid >> 4, tk = tid & 15;       // lanes run along k: L(i, k..k+15) is contiguous in the packed triangle (conflict-free RMW)
         // four rows (i, i+16, i+32, i+48) per thread: one fetch of panel row k serves four elements -- the LDS pipe,
         // not the fp64 FMAs, bounds this kernel (10 LDS operations per element visit before, 4 now)
         for (int ib = j1 + ti; ib <= ((probe & 16) ? -1 : n); ib += 64) {
@@ -795,7 +796,7 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
         for (int j = n - 1; j >= 0; --j) {
             const double *rj = L + tri(j);
             const double zj = j < 64 ? readlane_f64(za, j) : readlane_f64(zb, j - 64);
-            const double wj = zj * dinv[j];
+            const double wj = zj * rj[j];
             if (lane == (j & 63)) { if (j < 64) za = wj; else zb = wj; }
             if (lane < j) za -= rj[lane] * wj;
             if (lane + 64 < j) zb -= rj[lane + 64] * wj;
@@ -1298,7 +1299,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                    ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
         } else if (ctx->opt("solve_mode", 2) >= 2 && n + 1 <= 128) {
             const int na = n + 1;
-            size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4 + na) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
+            size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
             shmem = (shmem + 15) & ~size_t(15);
             if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             LAUNCH(ctx, "bg_ring_solve", k_ring_solve2, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
