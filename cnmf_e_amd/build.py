@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcnmfe_hip.so")
-SOURCES = ["api.hip", "resid.hip", "bg.hip", "factor.hip", "deconv.hip"]
+SOURCES = ["api.hip", "resid.hip", "bg.hip", "factor.hip", "deconv.hip", "ssub.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -454,6 +454,7 @@ static int check_csc(const char *what, int32_t K, int64_t nrow, const int64_t *c
         }
     return 0;
 }
+extern "C++" { namespace cnmfe { int check_csc_pub(const char *what, int32_t ncol, int64_t nrow, const int64_t *colptr, const int32_t *rowidx) { return check_csc(what, ncol, nrow, colptr, rowidx); } } }
 
 int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                          const float *A_val, const float *C, int c_order, double thresh_outlier, int with_projection,

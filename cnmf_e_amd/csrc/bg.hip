@@ -1094,7 +1094,7 @@ __global__ void k_b0(const double *__restrict__ ymean, BgGeom g, const int *__re
 }
 
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
-                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4]) {
+                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only) {
     const int64_t T = P->T;
     const int p = P->p;
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
@@ -1112,6 +1112,15 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(to_dev(ctx, dArow, rp.data(), rp.size()));
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+    }
+    if (b0_only & 1) {                                    // bg_ssub > 1: b0 = mean(Y - A*C, 2) on the patch (update_background_parallel.m:222-223)
+        BgGeom g0{};
+        g0.nr = P->nr; g0.nc = P->nc; g0.nr_b = P->nr_b; g0.nc_b = P->nc_b; g0.roff = P->roff; g0.coff = P->coff; g0.d = P->d; g0.d_b = P->d_b;
+        LAUNCH(ctx, "bg_b0", k_b0, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->ymean_d.as<double>(), g0,
+               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCm.as<double>(), P->b0.as<double>());
+        CK(hipStreamSynchronize(ctx->stream));
+        P->ysig_valid = false;
+        return 0;
     }
     // ---- first-run test (:25): row 1 of W_old has exactly two distinct values (0 and 1/count) ----
     bool first_run = false;
@@ -1151,7 +1160,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         CK(hipMemsetAsync(dActive.p, 1, P->d, ctx->stream));
     } else {
         std::vector<float> asum(P->d_b, 0.f);
-        if (a_empty) std::fill(asum.begin(), asum.end(), 1.0f);
+        // isempty(A) -> A = ones(d,1) (:14-16).  Bit 1 of b0_only: the reference passes A = [] because it subtracted A*C itself (bg_ssub > 1)
+        if (a_empty || (b0_only & 2)) std::fill(asum.begin(), asum.end(), 1.0f);
         else if (has_a) for (int64_t q = 0; q < P->d_b; ++q) { double s = 0; for (int64_t e = csr.rowptr[q]; e < csr.rowptr[q + 1]; ++e) s += csr.val[e]; asum[q] = (float)s; }
         RET(to_dev(ctx, dAsum, asum.data(), asum.size()));
         CK(hipMemsetAsync(dMisc.p, 0, 64, ctx->stream));

@@ -130,6 +130,8 @@ struct cnmfe_ctx {
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)
     cnmfe::DevBuf ysig;       // d x T fp32 (frame-major) of the patch last passed to cnmfe_residual
+    cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
+    cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
     int ysig_patch = -1;
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
@@ -155,9 +157,11 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
 
 // implemented in the kernel translation units
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
-                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4]);
+                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only = 0);
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
-                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace);
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr);
+int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out_memspace);
+int check_csc_pub(const char *what, int32_t ncol, int64_t nrow, const int64_t *colptr, const int32_t *rowidx);
 int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                 const float *A_val, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
                 const float *sn, int32_t param, float *A_out);

@@ -641,10 +641,24 @@ static void tile_shape(int variant, int &TR, int &TC) {
     else if ((variant >= 5 && variant <= 9) || variant == 11) { TR = ARC_TR; TC = ARC_TC; }
 }
 
-int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
-                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace) {
+// the ABI hands Ysig out frame-major (d x T column-major); resident it is 4-frame interleaved
+int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out_memspace) {
     const int64_t T = P->T;
-    RET(ctx->ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
+    float *dstp = Ysig_out;
+    if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)P->d * T * sizeof(float))); dstp = ctx->stage.as<float>(); }
+    LAUNCH(ctx, "ysig_unpack", k_ysig_unpack, dim3((unsigned)((P->d + 255) / 256), (unsigned)P->Tc), dim3(256), 0,
+           ysig.as<float4>(), P->d, T, dstp);
+    if (out_memspace != CNMFE_DEVICE)
+        CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf) {
+    const int64_t T = P->T;
+    DevBuf &ysig = outbuf ? *outbuf : ctx->ysig;             // bg_ssub > 1 sweeps the low-resolution patch into its own buffer
+    RET(ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
            &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10], &dFlag = ctx->tmp[11];
     int64_t ldc = 4;
@@ -696,7 +710,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     a.ymean_f = P->ymean_f.as<float>(); a.dlt = dDlt.as<float>();
     a.wa_cnt = has_ac ? dWaCnt.as<int>() : nullptr; a.wa_k = has_ac ? dWaK.as<int>() : nullptr;
     a.wa_v = has_ac ? dWaV.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
-    a.Ysig4 = ctx->ysig.as<float4>();
+    a.Ysig4 = ysig.as<float4>();
     a.ntile_r = (P->nr + TR - 1) / TR;
     const int ntile_c = (P->nc + TC - 1) / TC;
     const int64_t ntiles = (int64_t)a.ntile_r * ntile_c;
@@ -729,16 +743,9 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         rc = 0;
     }
     RET(rc);
-    ctx->ysig_patch = pid; P->ysig_valid = true;
-    if (Ysig_out) {                                      // the ABI hands Ysig out frame-major (d x T column-major)
-        float *dstp = Ysig_out;
-        if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)P->d * T * sizeof(float))); dstp = ctx->stage.as<float>(); }
-        LAUNCH(ctx, "ysig_unpack", k_ysig_unpack, dim3((unsigned)((P->d + 255) / 256), (unsigned)P->Tc), dim3(256), 0,
-               ctx->ysig.as<float4>(), P->d, T, dstp);
-        if (out_memspace != CNMFE_DEVICE)
-            CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-    }
+    if (!outbuf) ctx->ysig_patch = pid;
+    P->ysig_valid = true;
+    if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
     // without an output buffer the call returns with the kernel in flight: every consumer of Ysig is an engine
     // call on the same stream, so the caller's host work overlaps the sweep (include/cnmfe.h, cnmfe_residual)
     return 0;

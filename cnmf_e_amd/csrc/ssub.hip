@@ -1,0 +1,309 @@
+// bg_ssub > 1: the ring model on a spatially downsampled block.
+//   @Sources2D/initComponents_parallel.m:237-251      W on the ceil(nr_b/s) x ceil(nc_b/s) grid, ring radius ceil(r/s)
+//   @Sources2D/update_background_parallel.m:219-230   b0 = mean(Y - A*C); W fitted on imresize(., 1/s, 'nearest')
+//   @Sources2D/update_spatial_parallel.m:167-178      Ysig = Y(patch) - up(W * down(R - mean R))(patch) - b0
+//   (= update_temporal_parallel.m:153-165)            down = imresize(., 1/s) (bicubic, antialiased), up = imresize(., [nr_b nc_b])
+//
+// Design: both resizes are fixed linear maps, so the downsampled data are resident videos of their own.  Every real patch
+// gets two DERIVED patches whose "FOV" is the low-resolution block (patch == block, so the ring is clipped at the block
+// exactly like initComponents_parallel.m:246 does):
+//   fit patch:  nearest-neighbour samples of the centred video  -> cnmfe_fit_ring_model's kernels run on it unchanged
+//   res patch:  bicubic-antialiased downsample of the centred video, mean 0, b0 0 -> the R1 kernels run on it unchanged and
+//               give  down(Y') - W * down(R - mean R);  A_prev enters as down(A_prev) (linearity), built on the host.
+// What is new here is only the resampling: imresize's `contributions` restated from MathWorks' documentation (the source is
+// not in the reference; PARITY UNPINNED like every toolbox function), one gather kernel, one separable
+// downsample kernel (set-up time) and a two-pass separable upsample fused with the final combination (per call).
+#include "common.hpp"
+#include <cmath>
+
+namespace cnmfe {
+
+// ---- imresize contributions -----------------------------------------------------------------------------
+struct Taps {
+    int n_in = 0, n_out = 0, P = 0;
+    std::vector<int> idx;      // [n_out * P] source index, mirrored into 0..n_in-1
+    std::vector<float> w;      // [n_out * P] weights, rows normalised to 1
+};
+
+static double cubic_k(double x) {
+    const double ax = std::fabs(x), ax2 = ax * ax, ax3 = ax2 * ax;
+    if (ax <= 1) return 1.5 * ax3 - 2.5 * ax2 + 1;
+    if (ax <= 2) return -0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2;
+    return 0.0;
+}
+
+static Taps make_taps(int n_in, int n_out, double scale, bool nearest) {
+    Taps t; t.n_in = n_in; t.n_out = n_out;
+    double kw = nearest ? 1.0 : 4.0;
+    const bool stretch = !nearest && scale < 1.0;            // antialiasing: kernel stretched by 1/scale when shrinking
+    if (stretch) kw /= scale;
+    t.P = (int)std::ceil(kw) + 2;
+    t.idx.resize((size_t)n_out * t.P); t.w.resize((size_t)n_out * t.P);
+    std::vector<double> wd(t.P);
+    for (int o = 0; o < n_out; ++o) {
+        const double x = o + 1.0, u = x / scale + 0.5 * (1.0 - 1.0 / scale);
+        const double left = std::floor(u - kw / 2);
+        double sum = 0;
+        for (int i = 0; i < t.P; ++i) {
+            const double d = u - (left + i);
+            double h;
+            if (nearest) h = (d >= -0.5 && d < 0.5) ? 1.0 : 0.0;
+            else h = stretch ? scale * cubic_k(scale * d) : cubic_k(d);
+            wd[i] = h; sum += h;
+        }
+        for (int i = 0; i < t.P; ++i) {
+            long v = (long)left + i - 1;                          // 0-based virtual index
+            const long per = 2L * n_in;
+            long mth = ((v % per) + per) % per;                   // aux = [1:n n:-1:1]
+            const int src = (int)(mth < n_in ? mth : per - 1 - mth);
+            t.idx[(size_t)o * t.P + i] = src; t.w[(size_t)o * t.P + i] = (float)(wd[i] / sum);
+        }
+    }
+    return t;
+}
+
+// ---- kernels --------------------------------------------------------------------------------------------
+// derived video by pixel selection (imresize 'nearest'): dst[c][q] = src[c][sel[q]]
+__global__ void __launch_bounds__(256) k_derive_gather(const float4 *__restrict__ src, int64_t d_src, const int *__restrict__ sel,
+                                                       float4 *__restrict__ dst, int64_t d_dst) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (q < d_dst) dst[c * d_dst + q] = src[c * d_src + sel[q]];
+}
+__global__ void __launch_bounds__(256) k_gather_mean(const double *__restrict__ src, const int *__restrict__ sel, double *__restrict__ dd,
+                                                     float *__restrict__ df, int64_t n) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < n) { const double v = src[sel[q]]; dd[q] = v; df[q] = (float)v; }
+}
+// separable resample of a column-major image per 4-frame group: dst(ro,co) = sum_i sum_j wr[ro][i] wc[co][j] src(ir[ro][i], ic[co][j])
+__global__ void __launch_bounds__(256) k_resample2d(const float4 *__restrict__ src, int nr_in, int64_t d_in, float4 *__restrict__ dst, int nr_out,
+                                                    int64_t d_out, const int *__restrict__ ir, const float *__restrict__ wr, int Pr,
+                                                    const int *__restrict__ ic, const float *__restrict__ wc, int Pc) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (q >= d_out) return;
+    const int ro = (int)(q % nr_out), co = (int)(q / nr_out);
+    const float4 *s = src + c * d_in;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Pc; ++j) {
+        const float wj = wc[co * Pc + j];
+        if (wj == 0.f) continue;
+        const float4 *col = s + (int64_t)ic[co * Pc + j] * nr_in;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < Pr; ++i) {
+            const float wi = wr[ro * Pr + i];
+            const float4 v = col[ir[ro * Pr + i]];
+            t.x = fmaf(wi, v.x, t.x); t.y = fmaf(wi, v.y, t.y); t.z = fmaf(wi, v.z, t.z); t.w = fmaf(wi, v.w, t.w);
+        }
+        acc.x = fmaf(wj, t.x, acc.x); acc.y = fmaf(wj, t.y, acc.y); acc.z = fmaf(wj, t.z, acc.z); acc.w = fmaf(wj, t.w, acc.w);
+    }
+    dst[c * d_out + q] = acc;
+}
+// upsample pass A (columns): tmp(rl, cb) = sum_j wc[cb][j] * (Ylow - YsigLow)(rl, ic[cb][j])      [low rows x full columns]
+__global__ void __launch_bounds__(256) k_up_cols(const float4 *__restrict__ ylow, const float4 *__restrict__ yslow, int d1s, int64_t d_low,
+                                                 float4 *__restrict__ tmp, int nc_b, const int *__restrict__ ic, const float *__restrict__ wc, int Pc) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    const int64_t n = (int64_t)d1s * nc_b;
+    if (q >= n) return;
+    const int rl = (int)(q % d1s), cb = (int)(q / d1s);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Pc; ++j) {
+        const float wj = wc[cb * Pc + j];
+        if (wj == 0.f) continue;
+        const int64_t o = c * d_low + (int64_t)ic[cb * Pc + j] * d1s + rl;
+        const float4 a = ylow[o], b = yslow[o];                  // W * (...) = Ylow' - YsigLow (the res patch has mean 0 and b0 0)
+        acc.x = fmaf(wj, a.x - b.x, acc.x); acc.y = fmaf(wj, a.y - b.y, acc.y); acc.z = fmaf(wj, a.z - b.z, acc.z); acc.w = fmaf(wj, a.w - b.w, acc.w);
+    }
+    tmp[c * n + q] = acc;
+}
+// upsample pass B (rows) + combination: Ysig(m) = Y'(centre) + (Ymean - b0) - sum_i wr[rb][i] * tmp(ir[rb][i], cb)
+__global__ void __launch_bounds__(256) k_up_rows_combine(const float4 *__restrict__ tmp, int d1s, int nc_b, const float4 *__restrict__ Y4, int64_t d_b,
+                                                         int nr_b, int nr, int roff, int coff, int64_t d, const float *__restrict__ dlt,
+                                                         const int *__restrict__ ir, const float *__restrict__ wr, int Pr, float4 *__restrict__ ysig) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (m >= d) return;
+    const int rb = (int)(m % nr) + roff, cb = (int)(m / nr) + coff;
+    const float4 *col = tmp + c * (int64_t)d1s * nc_b + (int64_t)cb * d1s;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < Pr; ++i) {
+        const float wi = wr[rb * Pr + i];
+        if (wi == 0.f) continue;
+        const float4 v = col[ir[rb * Pr + i]];
+        acc.x = fmaf(wi, v.x, acc.x); acc.y = fmaf(wi, v.y, acc.y); acc.z = fmaf(wi, v.z, acc.z); acc.w = fmaf(wi, v.w, acc.w);
+    }
+    const float4 y = Y4[c * d_b + (int64_t)cb * nr_b + rb];
+    const float dl = dlt[m];
+    ysig[c * d + m] = make_float4(y.x + dl - acc.x, y.y + dl - acc.y, y.z + dl - acc.z, y.w + dl - acc.w);
+}
+__global__ void k_dlt2(const float *__restrict__ ymean_f, const double *__restrict__ b0, float *__restrict__ dlt, int64_t d, int nr, int nr_b, int roff, int coff) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= d) return;
+    const int64_t q = (int64_t)((int)(m / nr) + coff) * nr_b + (int)(m % nr) + roff;
+    dlt[m] = (float)((double)ymean_f[q] - b0[m]);
+}
+
+static void low_dims(const Patch *P, int ssub, int &d1s, int &d2s) { d1s = (P->nr_b + ssub - 1) / ssub; d2s = (P->nc_b + ssub - 1) / ssub; }
+
+int ssub_derive(cnmfe_ctx *ctx, Patch *S, int dst_id, int ssub, int mode) {
+    RET(ensure_ymean(ctx, S));
+    int d1s, d2s; low_dims(S, ssub, d1s, d2s);
+    if (ctx->patches.count(dst_id)) { delete ctx->patches[dst_id]; ctx->patches.erase(dst_id); }
+    Patch *P = new Patch();
+    const int32_t rect[4] = {1, d1s, 1, d2s};
+    memcpy(P->prect, rect, sizeof(rect)); memcpy(P->brect, rect, sizeof(rect));
+    P->d1 = d1s; P->d2 = d2s; P->T = S->T; P->Tc = S->Tc;
+    P->nr = P->nr_b = d1s; P->nc = P->nc_b = d2s; P->roff = P->coff = 0;
+    P->d = P->d_b = (int64_t)d1s * d2s;
+    ctx->patches[dst_id] = P;
+    RET(P->Yc4.ensure((size_t)P->Tc * P->d_b * sizeof(float4)));
+    RET(P->ymean_d.ensure(P->d_b * sizeof(double)));
+    RET(P->ymean_f.ensure(P->d_b * sizeof(float)));
+    const double scale = 1.0 / ssub;
+    Taps tr = make_taps(S->nr_b, d1s, scale, mode == CNMFE_DERIVE_NEAREST), tc = make_taps(S->nc_b, d2s, scale, mode == CNMFE_DERIVE_NEAREST);
+    dim3 grid((unsigned)((P->d_b + 255) / 256), (unsigned)P->Tc);
+    if (mode == CNMFE_DERIVE_NEAREST) {
+        std::vector<int> sel((size_t)P->d_b);
+        for (int co = 0; co < d2s; ++co)
+            for (int ro = 0; ro < d1s; ++ro) {
+                int ri = 0, ci = 0;
+                for (int i = 0; i < tr.P; ++i) if (tr.w[(size_t)ro * tr.P + i] != 0.f) ri = tr.idx[(size_t)ro * tr.P + i];
+                for (int j = 0; j < tc.P; ++j) if (tc.w[(size_t)co * tc.P + j] != 0.f) ci = tc.idx[(size_t)co * tc.P + j];
+                sel[(size_t)co * d1s + ro] = ci * S->nr_b + ri;
+            }
+        DevBuf dSel;
+        RET(to_dev(ctx, dSel, sel.data(), sel.size()));
+        LAUNCH(ctx, "ssub_derive_gather", k_derive_gather, grid, dim3(256), 0, S->Yc4.as<float4>(), S->d_b, dSel.as<int>(), P->Yc4.as<float4>(), P->d_b);
+        LAUNCH(ctx, "ssub_gather_mean", k_gather_mean, dim3((unsigned)((P->d_b + 255) / 256)), dim3(256), 0, S->ymean_d.as<double>(), dSel.as<int>(),
+               P->ymean_d.as<double>(), P->ymean_f.as<float>(), P->d_b);
+        CK(hipStreamSynchronize(ctx->stream));
+    } else {
+        DevBuf dIr, dWr, dIc, dWc;
+        RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
+        RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
+        LAUNCH(ctx, "ssub_derive_bicubic", k_resample2d, grid, dim3(256), 0, S->Yc4.as<float4>(), S->nr_b, S->d_b, P->Yc4.as<float4>(), d1s, P->d_b,
+               dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P);
+        CK(hipMemsetAsync(P->ymean_d.p, 0, P->d_b * sizeof(double), ctx->stream));
+        CK(hipMemsetAsync(P->ymean_f.p, 0, P->d_b * sizeof(float), ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    P->ymean_valid = true; P->frames_uploaded = P->T;
+    return 0;
+}
+
+// A restricted to the sampled pixels (nearest) or pushed through the bicubic downsample (linear map): d_low x K CSC
+static void a_low(const Patch *S, int ssub, bool nearest, int32_t K, const int64_t *cp, const int32_t *ri, const float *va,
+                  std::vector<int64_t> &ocp, std::vector<int32_t> &ori, std::vector<float> &ova) {
+    int d1s, d2s; low_dims(S, ssub, d1s, d2s);
+    Taps tr = make_taps(S->nr_b, d1s, 1.0 / ssub, nearest), tc = make_taps(S->nc_b, d2s, 1.0 / ssub, nearest);
+    // transposed taps: for every input index the (output, weight) pairs it feeds
+    std::vector<std::vector<std::pair<int, float>>> fr(S->nr_b), fc(S->nc_b);
+    for (int o = 0; o < d1s; ++o) for (int i = 0; i < tr.P; ++i) { const float w = tr.w[(size_t)o * tr.P + i]; if (w != 0.f) fr[tr.idx[(size_t)o * tr.P + i]].push_back({o, w}); }
+    for (int o = 0; o < d2s; ++o) for (int j = 0; j < tc.P; ++j) { const float w = tc.w[(size_t)o * tc.P + j]; if (w != 0.f) fc[tc.idx[(size_t)o * tc.P + j]].push_back({o, w}); }
+    const int64_t dl = (int64_t)d1s * d2s;
+    std::vector<double> acc((size_t)dl, 0.0);
+    std::vector<char> hit((size_t)dl, 0);
+    std::vector<int32_t> touched;
+    ocp.assign(K + 1, 0); ori.clear(); ova.clear();
+    for (int32_t k = 0; k < K; ++k) {
+        touched.clear();
+        for (int64_t e = cp[k]; e < cp[k + 1]; ++e) {
+            const int r = ri[e] % S->nr_b, c = ri[e] / S->nr_b;
+            for (auto &pr : fr[r]) for (auto &pc : fc[c]) {
+                const int32_t q = pc.first * d1s + pr.first;
+                if (!hit[q]) { hit[q] = 1; touched.push_back(q); }
+                acc[q] += (double)pr.second * pc.second * va[e];
+            }
+        }
+        std::sort(touched.begin(), touched.end());
+        for (int32_t q : touched) { if (acc[q] != 0.0) { ori.push_back(q); ova.push_back((float)acc[q]); } acc[q] = 0.0; hit[q] = 0; }
+        ocp[k + 1] = (int64_t)ori.size();
+    }
+}
+
+int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, const int64_t *cp, const int32_t *ri, const float *va,
+             const float *C, int c_order, int with_projection, int64_t info[4]) {
+    std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
+    if (K > 0) a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
+    // W: fit_ring_model(imresize(Y - A*C, 1/s, 'nearest'), [], [], W_old, ...)  (update_background_parallel.m:224-227)
+    RET(bg_fit_ring(ctx, F, K, K > 0 ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, with_projection, nullptr, info, /*A = [] for ind_active*/ 2));
+    if (R && R != F) {
+        if (R->p != F->p || R->d != F->d) return fail(CNMFE_ESTATE, "fit / residual low-resolution patches have different rings");
+        CK(hipMemcpyAsync(R->W.p, F->W.p, (size_t)F->p * F->d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        R->ysig_valid = false;
+    }
+    // b0 = mean(Y - A*C, 2) on the patch pixels (:222-223) = Ymean - A*mean(C)
+    RET(bg_fit_ring(ctx, M, K, cp, ri, va, C, c_order, with_projection, nullptr, nullptr, /*b0_only=*/1));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int ssub, int32_t K, const int64_t *cp, const int32_t *ri,
+                  const float *va, const float *C, int c_order, float *Ysig_out, int out_memspace) {
+    int d1s, d2s; low_dims(M, ssub, d1s, d2s);
+    if (R->d1 != d1s || R->d2 != d2s || R->T != M->T) return fail(CNMFE_ESTATE, "patch %d is not the low-resolution residual patch of patch %d", res_id, pid);
+    std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
+    const bool has_a = K > 0 && cp[K] > 0;
+    if (has_a) a_low(M, ssub, false, K, cp, ri, va, ocp, ori, ova);
+    // low-resolution sweep: ysig_low = down(Y') - W * (down(Y') - down(A_prev) (C - mean C))
+    RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low));
+    // upsample W*(...) to the block (imresize(Bf, [nr_block nc_block])) and combine on the patch pixels
+    Taps tr = make_taps(d1s, M->nr_b, (double)M->nr_b / d1s, false), tc = make_taps(d2s, M->nc_b, (double)M->nc_b / d2s, false);
+    DevBuf &dIr = ctx->tmp[0], &dWr = ctx->tmp[1], &dIc = ctx->tmp[2], &dWc = ctx->tmp[3], &dDlt = ctx->tmp[7];
+    RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
+    RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
+    CK(hipStreamSynchronize(ctx->stream));                    // the tap vectors die with this call
+    const int64_t ntmp = (int64_t)d1s * M->nc_b;
+    RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));
+    RET(ctx->ysig.ensure((size_t)M->d * M->Tc * sizeof(float4)));
+    RET(dDlt.ensure(M->d * sizeof(float)));
+    LAUNCH(ctx, "r1_dlt", k_dlt2, dim3((unsigned)((M->d + 255) / 256)), dim3(256), 0, M->ymean_f.as<float>(), M->b0.as<double>(), dDlt.as<float>(),
+           M->d, M->nr, M->nr_b, M->roff, M->coff);
+    LAUNCH(ctx, "ssub_up_cols", k_up_cols, dim3((unsigned)((ntmp + 255) / 256), (unsigned)M->Tc), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(),
+           d1s, R->d_b, ctx->up_tmp.as<float4>(), M->nc_b, dIc.as<int>(), dWc.as<float>(), tc.P);
+    LAUNCH(ctx, "ssub_up_rows_combine", k_up_rows_combine, dim3((unsigned)((M->d + 255) / 256), (unsigned)M->Tc), dim3(256), 0, ctx->up_tmp.as<float4>(), d1s,
+           M->nc_b, M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(), tr.P,
+           ctx->ysig.as<float4>());
+    ctx->ysig_patch = pid; M->ysig_valid = true;
+    if (Ysig_out) RET(ysig_export(ctx, M, ctx->ysig, Ysig_out, out_memspace));
+    return 0;
+}
+
+}  // namespace cnmfe
+
+using namespace cnmfe;
+
+int cnmfe_patch_derive(cnmfe_ctx *ctx, int src_patch, int new_patch, int32_t ssub, int mode) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *S = get_patch(ctx, src_patch);
+    if (!S) return fail(CNMFE_ESTATE, "patch %d not created", src_patch);
+    if (ssub < 2 || ssub > 8) return fail(CNMFE_EINVAL, "bg_ssub %d out of range (2..8)", ssub);
+    if (mode != CNMFE_DERIVE_NEAREST && mode != CNMFE_DERIVE_BICUBIC) return fail(CNMFE_EINVAL, "unknown derive mode %d", mode);
+    if (new_patch == src_patch) return fail(CNMFE_EINVAL, "a patch cannot be derived onto itself");
+    CK(hipSetDevice(ctx->device));
+    return ssub_derive(ctx, S, new_patch, ssub, mode);
+}
+
+int cnmfe_fit_ring_model_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int res_patch, int32_t ssub, int32_t K, const int64_t *A_colptr,
+                              const int32_t *A_rowidx, const float *A_val, const float *C, int c_order, double thresh_outlier,
+                              int with_projection, int64_t info[4]) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *M = get_patch(ctx, patch_id), *F = get_patch(ctx, fit_patch), *R = get_patch(ctx, res_patch);
+    if (!M || !F || !R) return fail(CNMFE_ESTATE, "patch %d / %d / %d not created", patch_id, fit_patch, res_patch);
+    if (!F->ring_ready || !R->ring_ready || !M->ring_ready) return fail(CNMFE_ESTATE, "rings not initialised");
+    if (thresh_outlier == thresh_outlier) return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 is not built)");
+    if (K < 0) return fail(CNMFE_EINVAL, "K=%d", K);
+    if (K > 0) { RET(check_csc_pub("A", K, M->d_b, A_colptr, A_rowidx)); if (!A_val || !C) return fail(CNMFE_EINVAL, "null A_val / C"); }
+    CK(hipSetDevice(ctx->device));
+    return ssub_fit(ctx, M, F, R, ssub, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, info);
+}
+
+int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssub, int32_t Ksel, const int64_t *A_colptr,
+                        const int32_t *A_rowidx, const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *M = get_patch(ctx, patch_id), *R = get_patch(ctx, res_patch);
+    if (!M || !R) return fail(CNMFE_ESTATE, "patch %d / %d not created", patch_id, res_patch);
+    if (!M->ring_ready || !R->ring_ready) return fail(CNMFE_ESTATE, "rings not initialised");
+    if (Ksel < 0) return fail(CNMFE_EINVAL, "Ksel=%d", Ksel);
+    if (Ksel > 0) { RET(check_csc_pub("A_prev", Ksel, M->d_b, A_colptr, A_rowidx)); if (!A_val || !C) return fail(CNMFE_EINVAL, "null A_val / C"); }
+    CK(hipSetDevice(ctx->device));
+    RET(ensure_ymean(ctx, M));
+    return ssub_residual(ctx, M, patch_id, R, res_patch, ssub, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);
+}

@@ -128,6 +128,33 @@ class Engine:
                                            L.ROWMAJOR, float(thresh_outlier), int(bool(with_projection)), _p(b0, L.f32p), _p(inf, L.i64p)))
         return b0, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
 
+    # -- bg_ssub > 1 ---------------------------------------------------------------------------------------------
+    def patch_derive(self, src_pid, new_pid, ssub, mode):
+        """low-resolution patch of src_pid (mode 'nearest' | 'bicubic'); its FOV is the ceil(nr_b/s) x ceil(nc_b/s) grid"""
+        src = self._patch[src_pid]
+        L.check(L.lib.cnmfe_patch_derive(self._ctx, src_pid, new_pid, int(ssub), 0 if mode == "nearest" else 1))
+        d1s, d2s = -(-src["nr_b"] // ssub), -(-src["nc_b"] // ssub)
+        self._patch[new_pid] = dict(d=d1s * d2s, d_b=d1s * d2s, T=src["T"], nr=d1s, nc=d2s, nr_b=d1s, nc_b=d2s)
+
+    def fit_ring_model_ssub(self, pid, fit_pid, res_pid, ssub, A_block, C_block, thresh_outlier=float("nan"), with_projection=True):
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_block, info["d_b"]) if A_block is not None else (0, None, None, None)
+        Cm = _traces(C_block, K, info["T"]) if K else None
+        inf = np.zeros(4, dtype=np.int64)
+        L.check(L.lib.cnmfe_fit_ring_model_ssub(self._ctx, pid, fit_pid, res_pid, int(ssub), K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p),
+                                                _p(Cm, L.f32p), L.ROWMAJOR, float(thresh_outlier), int(bool(with_projection)), _p(inf, L.i64p)))
+        return None, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
+
+    def residual_ssub(self, pid, res_pid, ssub, A_prev_block=None, C_prev=None, want=False):
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_prev_block, info["d_b"]) if A_prev_block is not None and A_prev_block.shape[1] else (0, None, None, None)
+        Cm = _traces(C_prev, K, info["T"]) if K else None
+        out = np.empty((info["T"], info["d"]), dtype=np.float32) if want else None
+        dst = out.ctypes.data_as(C.c_void_p) if want else C.c_void_p(None)
+        L.check(L.lib.cnmfe_residual_ssub(self._ctx, pid, res_pid, int(ssub), K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p),
+                                          L.ROWMAJOR, dst, L.HOST))
+        return out
+
     def residual(self, pid, A_prev_block=None, C_prev=None, want=False, out_dev_ptr=None):
         """want=True returns Ysig as a (T, d) host array; out_dev_ptr: raw device address of a (T, d) fp32 buffer that
         receives a device-to-device copy instead."""

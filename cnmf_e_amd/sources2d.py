@@ -200,8 +200,8 @@ class Sources2D:
     def __init__(self, video: PatchedVideo, options: Options, A, C, sn, dist_group=None):
         if options.background_model != "ring":
             raise ValueError("only the ring background model is built (north star); got %r" % options.background_model)
-        if options.bg_ssub != 1:
-            raise NotImplementedError("bg_ssub > 1 (imresize around W) is not built yet")
+        if not (1 <= int(options.bg_ssub) <= 8):
+            raise ValueError("bg_ssub must be in 1..8")
         self.video = video
         self.options = options
         options.d1, options.d2 = video.d1, video.d2
@@ -217,14 +217,32 @@ class Sources2D:
         self.P = {"sn": np.asarray(sn, dtype=np.float32).reshape(-1).copy(), "Ymean": {}}
         self._b0_new_val = None; self._b0_new_src = None
         self.dist = dist_group
+        self.ssub = int(options.bg_ssub)
+        npatch = len(video.order)
+        # bg_ssub > 1: every patch gets two low-resolution companions on the device (cnmfe.h, cnmfe_patch_derive)
+        self.pid_fit = {idx: npatch + 2 * video.pid[idx] for idx in video.order}
+        self.pid_res = {idx: npatch + 2 * video.pid[idx] + 1 for idx in video.order}
         for idx in video.owned:                                           # initComponents_parallel.m:213-236
             self.engine.ring_init(video.pid[idx], options.ring_radius, options.num_neighbors)
+            if self.ssub > 1:                                             # :214,237-251: rr = ceil(r/bg_ssub), W on the low-resolution block
+                rr = -(-int(options.ring_radius) // self.ssub)
+                self.engine.patch_derive(video.pid[idx], self.pid_fit[idx], self.ssub, "nearest")
+                self.engine.patch_derive(video.pid[idx], self.pid_res[idx], self.ssub, "bicubic")
+                self.engine.ring_init(self.pid_fit[idx], rr, options.num_neighbors)
+                self.engine.ring_init(self.pid_res[idx], rr, options.num_neighbors)
             self.P["Ymean"][idx] = self.engine.ymean(video.pid[idx])[video.ind_patch[idx]]      # :338-339, patch part
         self._ymean_full = None
 
     # -- accessors ------------------------------------------------------------------
     def get_W(self, idx):
-        return self.engine.ring_csr(self.video.pid[idx])
+        return self.engine.ring_csr(self.video.pid[idx] if self.ssub == 1 else self.pid_fit[idx])
+
+    def _residual(self, idx, A_prev_b, C_prev_b):
+        """the background-subtraction expression of update_spatial_parallel.m:162-178 / update_temporal_parallel.m:149-165"""
+        if self.ssub == 1:
+            self.engine.residual(self.video.pid[idx], A_prev_b, C_prev_b)
+        else:
+            self.engine.residual_ssub(self.video.pid[idx], self.pid_res[idx], self.ssub, A_prev_b, C_prev_b)
 
     def get_b0(self, idx):
         return self.engine.b0(self.video.pid[idx])
@@ -351,8 +369,13 @@ class Sources2D:
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
             if A_block.shape[1] == 0 and not self._first_run(idx):
                 continue
-            _, infos[idx] = self.engine.fit_ring_model(v.pid[idx], A_block if A_block.shape[1] else None, C_block,
-                                                       o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218
+            if self.ssub == 1:
+                _, infos[idx] = self.engine.fit_ring_model(v.pid[idx], A_block if A_block.shape[1] else None, C_block,
+                                                           o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218
+            else:                                                                                                # :219-230
+                _, infos[idx] = self.engine.fit_ring_model_ssub(v.pid[idx], self.pid_fit[idx], self.pid_res[idx], self.ssub,
+                                                                A_block if A_block.shape[1] else None, C_block,
+                                                                o.thresh_outlier, o.bg_acceleration)
         self.b0_new = self.reconstruct_b0()                                # :315
         self.A_prev = self.A                                               # :316 (no copy needed: A, C are replaced, not mutated)
         self._prev_csr_src = self.A
@@ -380,7 +403,7 @@ class Sources2D:
     def _first_run(self, idx):
         """flag_first = (length(unique(W{1}(1,:)))==2)  (update_background_parallel.m:143); the same value test,
         evaluated on this patch's own W{m} so that sharded ranks need no broadcast of patch 1."""
-        return self.engine.ring_first_run(self.video.pid[idx])
+        return self.engine.ring_first_run(self.video.pid[idx] if self.ssub == 1 else self.pid_fit[idx])
 
     # -- spatial ----------------------------------------------------------------------
     def update_spatial_parallel(self, use_parallel=True, update_sn=False):
@@ -408,7 +431,7 @@ class Sources2D:
             if launched:
                 # the residual sweep (:162-166) does not depend on the search mask: start it (the call returns with
                 # the kernel in flight) and build IND (:66) on the host underneath it
-                self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)
+                self._residual(idx, A_prev_b, C_prev_b)
                 IND_csr = self._search_location_csr()
                 A_csr = self.A.tocsr()
             INDp = IND_csr[pp]
@@ -416,7 +439,7 @@ class Sources2D:
             if ind.size == 0 and not update_sn:
                 continue                                                                             # :121-124
             if not launched:
-                self.engine.residual(v.pid[idx], A_prev_b, C_prev_b)                                # :162-166
+                self._residual(idx, A_prev_b, C_prev_b)                                # :162-166
             sn_patch = self.P["sn"][pp]                                                             # :90,154
             if update_sn:
                 sn_patch = self.engine.get_sn(v.pid[idx])                                           # :191-194  sn_patch = GetSn(Ypatch)
@@ -521,14 +544,14 @@ class Sources2D:
             launched = A_csr is None
             if launched:
                 # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
-                self.engine.residual(v.pid[idx], A_prev_b if indp.size else None, C_prev_b)
+                self._residual(idx, A_prev_b if indp.size else None, C_prev_b)
                 A_csr = self.A.tocsr()
             Ab = A_csr[bp]
             ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                              # :83
             if ind.size == 0:
                 continue                                                                              # :123
             if not launched:
-                self.engine.residual(v.pid[idx], A_prev_b if indp.size else None, C_prev_b)          # :149-152
+                self._residual(idx, A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self.C[ind]                                                                    # :86
             A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175

@@ -99,6 +99,29 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
                          double thresh_outlier, int with_projection,
                          float *b0_out /* d or NULL */, int64_t info[4]);
 
+/* ---- bg_ssub > 1: the ring model on a spatially downsampled block
+ * W lives on the ceil(nr_b/s) x ceil(nc_b/s) grid with ring radius ceil(r/s)  (@Sources2D/initComponents_parallel.m:214,237-251).
+ * cnmfe_patch_derive creates a patch whose FOV is that grid and whose resident video is computed on the device from the
+ * source patch: CNMFE_DERIVE_NEAREST = imresize(., 1/s, 'nearest') (what fit_ring_model sees, update_background_parallel.m:224),
+ * CNMFE_DERIVE_BICUBIC = imresize(., 1/s) of the centred video (what W multiplies, update_spatial_parallel.m:171-172).
+ * Call cnmfe_ring_init(new_patch, ceil(r/s), num_neighbors) on both afterwards. */
+enum { CNMFE_DERIVE_NEAREST = 0, CNMFE_DERIVE_BICUBIC = 1 };
+int cnmfe_patch_derive(cnmfe_ctx *ctx, int src_patch, int new_patch, int32_t ssub, int mode);
+
+/* update_background_parallel.m:219-230:  b0 = mean(Y - A*C, 2)(patch);  W = fit_ring_model(imresize(Y - A*C, 1/s, 'nearest'), [], [], W_old, ...).
+ * A is d_b x K CSC over BLOCK rows of patch_id; W is fitted on fit_patch and copied to res_patch; b0 is set on patch_id.  info as in
+ * cnmfe_fit_ring_model (of the low-resolution fit). */
+int cnmfe_fit_ring_model_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int res_patch, int32_t ssub, int32_t K,
+                              const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+                              double thresh_outlier, int with_projection, int64_t info[4]);
+
+/* update_spatial_parallel.m:167-178 == update_temporal_parallel.m:153-165:
+ *   Ysig = Y(ind_patch,:) - imresize(W * imresize(R - mean(R,2), 1/s), [nr_block nc_block])(ind_patch,:) - b0,  R = Y - A_prev*C_prev.
+ * The result stays resident as the Ysig of patch_id (for cnmfe_update_spatial / cnmfe_hals_temporal / cnmfe_get_sn). */
+int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssub, int32_t Ksel, const int64_t *A_colptr,
+                        const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+                        float *Ysig_out /* d x T or NULL */, int out_memspace);
+
 /* ---- R1: the residual / background-subtraction expression
  *   Ysig = Y(ind_patch,:) - W*(Y - A_prev*C_prev) - (b0 - W*mean(Y - A_prev*C_prev, 2))
  * update_spatial_parallel.m:162-166 == update_temporal_parallel.m:149-152.

@@ -123,6 +123,91 @@ def build_ring_W(patch, block, d1, d2, r_shift, c_shift):
     return sp.diags(1.0 / cnt) @ temp                                        # :233
 
 
+# --------------------------------------------------------------------------- #
+# imresize (MathWorks Image Processing Toolbox; NOT in /root/reference: restated from its documented algorithm --
+# separable resampling with `contributions`: output sample x maps to u = x/scale + 0.5*(1 - 1/scale), the kernel is
+# stretched by 1/scale when shrinking with antialiasing, taps are mirrored at the borders and each row of weights is
+# normalised to sum 1.  Bicubic = Keys a=-0.5; 'nearest' = box kernel, no antialiasing.)  PARITY UNPINNED.
+# Used only for bg_ssub > 1 (update_background_parallel.m:224, update_spatial_parallel.m:169-176).
+# --------------------------------------------------------------------------- #
+def _cubic(x):
+    ax = np.abs(x); ax2 = ax * ax; ax3 = ax2 * ax
+    return (1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((ax > 1) & (ax <= 2))
+
+
+def imresize_weights(in_len, out_len, scale, method="bicubic"):
+    """Dense (out_len x in_len) weight matrix of MATLAB's imresize along one dimension."""
+    if method == "nearest":
+        kernel, kw, antialias = (lambda x: ((x >= -0.5) & (x < 0.5)).astype(np.float64)), 1.0, False
+    else:
+        kernel, kw, antialias = _cubic, 4.0, True
+    if scale < 1 and antialias:
+        h = lambda x: scale * kernel(scale * x)
+        kw = kw / scale
+    else:
+        h = kernel
+    x = np.arange(1, out_len + 1, dtype=np.float64)
+    u = x / scale + 0.5 * (1 - 1 / scale)
+    left = np.floor(u - kw / 2)
+    P = int(np.ceil(kw)) + 2
+    ind = left[:, None] + np.arange(P)[None, :]
+    w = h(u[:, None] - ind)
+    w = w / w.sum(axis=1, keepdims=True)
+    aux = np.concatenate([np.arange(1, in_len + 1), np.arange(in_len, 0, -1)])
+    ind = aux[np.mod(ind.astype(np.int64) - 1, aux.size)]                 # mirrored, 1-based
+    M = np.zeros((out_len, in_len))
+    for o in range(out_len):
+        np.add.at(M[o], ind[o] - 1, w[o])
+    return M
+
+
+def imresize_scale(img, scale, method="bicubic"):
+    """imresize(img, scale[, method]) on the first two dims of a 2-D/3-D array; output size ceil(in*scale)."""
+    nr, nc = img.shape[:2]
+    Mr = imresize_weights(nr, int(np.ceil(nr * scale)), scale, method)
+    Mc = imresize_weights(nc, int(np.ceil(nc * scale)), scale, method)
+    out = np.tensordot(Mr, img, axes=(1, 0))                              # rows first (equal scales: order [1 2])
+    return np.moveaxis(np.tensordot(Mc, out, axes=(1, 1)), 0, 1)
+
+
+def imresize_size(img, out_size, method="bicubic"):
+    """imresize(img, [nr nc][, method]): per-dimension scale = out/in."""
+    nr, nc = img.shape[:2]
+    Mr = imresize_weights(nr, out_size[0], out_size[0] / nr, method)
+    Mc = imresize_weights(nc, out_size[1], out_size[1] / nc, method)
+    out = np.tensordot(Mr, img, axes=(1, 0))
+    return np.moveaxis(np.tensordot(Mc, out, axes=(1, 1)), 0, 1)
+
+
+def build_ring_W_ssub(nr_block, nc_block, bg_ssub, r_shift, c_shift):
+    """W on the downsampled block grid (initComponents_parallel.m:237-251): d1s*d2s square, neighbours clipped at the BLOCK."""
+    d1s, d2s = int(np.ceil(nr_block / bg_ssub)), int(np.ceil(nc_block / bg_ssub))
+    csub, rsub = np.meshgrid(np.arange(1, d2s + 1), np.arange(1, d1s + 1))
+    csub = csub.reshape(-1, 1, order="F"); rsub = rsub.reshape(-1, 1, order="F")
+    ii = np.repeat(np.arange(d1s * d2s)[:, None], r_shift.size, axis=1)
+    csub = csub + c_shift[None, :]; rsub = rsub + r_shift[None, :]
+    jj = (csub - 1) * d1s + rsub - 1
+    ind = (csub >= 1) & (csub <= d2s) & (rsub >= 1) & (rsub <= d1s)
+    temp = sp.csr_matrix((np.ones(int(ind.sum())), (ii[ind], jj[ind])), shape=(d1s * d2s, d1s * d2s))
+    temp.sum_duplicates(); temp.sort_indices()
+    cnt = np.asarray(temp.sum(axis=1)).ravel()
+    return sp.diags(1.0 / cnt) @ temp
+
+
+def residual_ysig_ssub(Y_block, A_prev, C_prev, W, b0, ind_patch, nr_block, nc_block, bg_ssub):
+    """update_spatial_parallel.m:167-178 (= update_temporal_parallel.m:153-165): the ring product on the downsampled block."""
+    Yb = np.asarray(Y_block, dtype=np.float64)
+    T = Yb.shape[1]
+    tmp_Y = Yb - (A_prev @ np.asarray(C_prev, dtype=np.float64)) if (A_prev is not None and A_prev.shape[1] > 0) else Yb.copy()
+    temp = (tmp_Y - tmp_Y.mean(axis=1, keepdims=True)).reshape(nr_block, nc_block, T, order="F")    # :171
+    temp = imresize_scale(temp, 1.0 / bg_ssub)                                                          # :172
+    d1s, d2s = temp.shape[:2]
+    Bf = (sp.csr_matrix(W) @ temp.reshape(d1s * d2s, T, order="F")).reshape(d1s, d2s, T, order="F")      # :173
+    Bf = imresize_size(Bf, (nr_block, nc_block)).reshape(nr_block * nc_block, T, order="F")             # :174-175
+    ind_patch = np.asarray(ind_patch, dtype=bool).ravel()
+    return Yb[ind_patch, :] - Bf[ind_patch, :] - np.asarray(b0, dtype=np.float64).ravel()[:, None]       # :177
+
+
 def ind_patch_mask(patch, block):
     """Logical nr_b x nc_b mask of patch pixels inside the block, flattened column-major.
 
@@ -490,7 +575,8 @@ class OracleSources2D:
 
     def __init__(self, Yfull, d1, d2, T, patch_dims, ring_radius, A, C, sn, *,
                  spatial_algorithm="hals", maxIter=5, num_neighbors=None,
-                 min_size=3, max_size=8, dist=3, bg_acceleration=True):
+                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1):
+        self.bg_ssub = int(bg_ssub)
         self.Y = Yfull
         self.d1, self.d2, self.T = d1, d2, T
         self.ring_radius = ring_radius
@@ -505,11 +591,15 @@ class OracleSources2D:
         self.maxIter = maxIter
         self.search = dict(min_size=min_size, max_size=max_size, dist=dist)
         self.bg_acceleration = bg_acceleration
-        r_shift, c_shift = get_nhood(ring_radius, num_neighbors)
+        rr = int(np.ceil(ring_radius / self.bg_ssub))        # initComponents_parallel.m:214
+        r_shift, c_shift = get_nhood(rr, num_neighbors)
         self.W, self.b0, self.Ymean = {}, {}, {}
         for idx in np.ndindex(self.patch_pos.shape):
             p, b = self.patch_pos[idx], self.block_pos[idx]
-            self.W[idx] = build_ring_W(p, b, d1, d2, r_shift, c_shift)
+            if self.bg_ssub == 1:
+                self.W[idx] = build_ring_W(p, b, d1, d2, r_shift, c_shift)
+            else:
+                self.W[idx] = build_ring_W_ssub(int(b[1] - b[0] + 1), int(b[3] - b[2] + 1), self.bg_ssub, r_shift, c_shift)
             self.b0[idx] = np.zeros((p[1] - p[0] + 1) * (p[3] - p[2] + 1))   # initComponents_parallel.m:221
             self.Ymean[idx] = self._block(p).astype(np.float64).mean(axis=1)  # P.Ymean (:338-339)
         self.b0_new = None
@@ -525,6 +615,12 @@ class OracleSources2D:
         m = np.zeros((self.d1, self.d2), dtype=bool)
         m[r0 - 1:r1, c0 - 1:c1] = True
         return m.reshape(-1, order="F")
+
+    def _residual(self, Yb, A_prev_b, C_prev_b, idx, ip, b):
+        if self.bg_ssub == 1:
+            return residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)
+        return residual_ysig_ssub(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip,
+                                  int(b[1] - b[0] + 1), int(b[3] - b[2] + 1), self.bg_ssub)
 
     def _patches(self):
         # MATLAB linear order over the nr_patch x nc_patch cell: rows fastest
@@ -565,8 +661,16 @@ class OracleSources2D:
             ip = ind_patch_mask(p, b)                        # :203-204
             Yb = self._block(b)                              # :208
             sn_patch = self.sn.reshape(-1, order="F")[mask][ip]
-            self.W[idx], self.b0[idx] = fit_ring_model(Yb, A_block, C_block, self.W[idx], np.nan,
-                                                       sn_patch, ip, self.bg_acceleration)   # :218
+            if self.bg_ssub == 1:
+                self.W[idx], self.b0[idx] = fit_ring_model(Yb, A_block, C_block, self.W[idx], np.nan,
+                                                           sn_patch, ip, self.bg_acceleration)   # :218
+            else:                                            # :219-230
+                nr_b, nc_b = int(b[1] - b[0] + 1), int(b[3] - b[2] + 1)
+                temp = np.asarray(Yb, dtype=np.float64) - (A_block @ C_block if A_block.shape[1] else 0.0)      # :221
+                self.b0[idx] = temp.mean(axis=1)[ip]                                                            # :222-223
+                low = imresize_scale(temp.reshape(nr_b, nc_b, self.T, order="F"), 1.0 / self.bg_ssub, "nearest")  # :224
+                low = low.reshape(-1, self.T, order="F")
+                self.W[idx], _ = fit_ring_model(low, None, None, self.W[idx], np.nan, None, None, self.bg_acceleration)   # :227
         self.b0_new = self.reconstruct_b0()                  # :315
         self.A_prev = self.A.copy()                          # :316
         self.C_prev = self.C.copy()                          # :317
@@ -596,7 +700,7 @@ class OracleSources2D:
             C_prev_b = self.C_prev[indp, :]                  # :98
             ip = ind_patch_mask(p, b)
             Yb = self._block(b)                              # :147
-            Ysig = residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)   # :162-166
+            Ysig = self._residual(Yb, A_prev_b, C_prev_b, idx, ip, b)                     # :162-178
             if update_sn:                                    # :191-194  sn_patch = GetSn(Ypatch)
                 from oasis_oracle import GetSn
                 sn_patch = np.array([GetSn(row) for row in Ysig])
@@ -639,7 +743,7 @@ class OracleSources2D:
             C_prev_b = self.C_prev[indp, :]
             ip = ind_patch_mask(p, b)
             Yb = self._block(b)
-            Ysig = residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)    # :149-152
+            Ysig = self._residual(Yb, A_prev_b, C_prev_b, idx, ip, b)                      # :149-165
             A_pp = A_b[ip, :]
             if not use_c_hat:
                 aa_p, C_raw_p = fast_temporal(Ysig, A_pp)                                   # :174-175

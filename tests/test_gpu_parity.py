@@ -445,3 +445,65 @@ def test_fit_ring_solve_modes_agree(eng):
         out[mode] = eng.ring_csr(0).data.copy()
     eng.set_option("solve_mode", 2)
     assert rel(out[3], out[2]) <= 1e-5, rel(out[3], out[2])
+
+
+@pytest.mark.parametrize("dims,pdims,ssub,r", [((40, 36), None, 2, 6), ((45, 38), [23, 19], 2, 6), ((42, 39), None, 3, 9)])
+def test_residual_ssub_parity(eng, dims, pdims, ssub, r):
+    """bg_ssub > 1 (update_spatial_parallel.m:167-178): imresize down -> W -> imresize up, against the restatement
+    (oracle imresize from MathWorks' documented algorithm; parity with MATLAB unpinned).  Odd block sizes included."""
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2 = dims; T, K = 90, 5
+    f = synth.make_factors(d1, d2, T, K, 13, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, pdims or [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    rng = np.random.default_rng(3)
+    rr = -(-r // ssub)
+    rs, cs = orc.get_nhood(rr)
+    npatch = len(video.order)
+    for idx in video.owned:
+        pid = video.pid[idx]; pres = npatch + 2 * pid + 1
+        eng.ring_init(pid, r)
+        eng.patch_derive(pid, pres, ssub, "bicubic")
+        eng.ring_init(pres, rr)
+        p, b = video.patch_pos[idx], video.block_pos[idx]
+        nrb, ncb = int(b[1] - b[0] + 1), int(b[3] - b[2] + 1)
+        W0 = orc.build_ring_W_ssub(nrb, ncb, ssub, rs, cs).tocsr(); W0.sort_indices()
+        Wl = W0.copy(); Wl.data = (W0.data * (1 + 0.5 * rng.standard_normal(W0.nnz))).astype(np.float32).astype(np.float64)
+        eng.ring_set_values(pres, Wl.data.astype(np.float32))
+        b0 = (800 + 50 * rng.standard_normal(video.patch_pix[idx].size)).astype(np.float32)
+        eng.set_b0(pid, b0)
+        bp = video.block_pix[idx]
+        A_b = sp.csc_matrix(f.A_init.tocsr()[bp].astype(np.float32))
+        got = eng.residual_ssub(pid, pres, ssub, A_b, f.C_init, want=True).T.astype(np.float64)       # d x T
+        ip = np.zeros(bp.size, dtype=bool); ip[video.ind_patch[idx]] = True
+        ref = orc.residual_ysig_ssub(Y[:, bp].T.astype(np.float64), A_b.astype(np.float64), f.C_init, Wl, b0.astype(np.float64), ip, nrb, ncb, ssub)
+        assert rel(got, ref) <= 3e-6, (idx, rel(got, ref))
+
+
+def test_method_level_iteration_bg_ssub(eng):
+    """the three update methods with options.bg_ssub = 2 (demo_large_data_1p.m:55) on 2x2 patches vs the oracle"""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 46, 42, 300, 6, 6
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [23, 21], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=3, bg_ssub=2), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [23, 21], r, f.A_init.astype(np.float32), f.C_init, f.sn,
+                            spatial_algorithm="hals", maxIter=3, bg_ssub=2)
+    for it in range(2):
+        s.update_background_parallel(); o.update_background_parallel()
+        for idx in video.owned:
+            Wg = s.get_W(idx); Wr = sp.csr_matrix(o.W[idx]); Wr.sort_indices()
+            assert Wg.shape == Wr.shape
+            assert rel(Wg.data, Wr.data) <= 2e-3, (it, rel(Wg.data, Wr.data))
+        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-5, atol=1e-2)
+        s.update_spatial_parallel(); o.update_spatial_parallel()
+        Ag, Ar = s.A.toarray(), o.A.toarray()
+        mism = ((Ag != 0) != (Ar != 0)).sum()
+        assert mism <= max(3, 0.02 * (Ar != 0).sum()), (it, mism)
+        same = (Ag != 0) == (Ar != 0)
+        assert rel(Ag[same], Ar[same]) <= 2e-3, (it, rel(Ag[same], Ar[same]))
+        s.update_temporal_parallel(); o.update_temporal_parallel()
+        assert rel(s.C, o.C) <= 2e-3, (it, rel(s.C, o.C))
