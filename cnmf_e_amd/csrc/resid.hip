@@ -697,7 +697,10 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
     if (h == 18 && ((variant >= 5 && variant <= 9) || variant == 11)) variant = 10;   // arc kernels: radius 15 only (ds_read immediates)
-    const bool special = full_ring && (h == 15 || h == 18) && variant >= 0;
+    // the low-resolution rings of bg_ssub = 2, 3 (ceil(15/2) = 8, ceil(18/2) = 9, ceil(15/3) = 5, ceil(18/3) = 6): LDS-DMA kernel only
+    const bool small_special = full_ring && (h == 5 || h == 6 || h == 8 || h == 9) && variant >= 0;
+    if (small_special) variant = 10;
+    const bool special = (full_ring && (h == 15 || h == 18) && variant >= 0) || small_special;
     int TR = 16, TC = 16;
     if (special) tile_shape(variant, TR, TC);
     const int HR = TR + 2 * h, HC = TC + 2 * h;
@@ -724,7 +727,13 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
         a.tile_map = dOffs.as<int>();
         CK(hipStreamSynchronize(ctx->stream));           // the host-side staging vectors die with this call; the stream is near-idle here
-        rc = h == 15 ? launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg) : launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);
+        const dim3 gridd((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
+        if (h == 15) rc = launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg);
+        else if (h == 18) rc = launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);
+        else if (h == 8) rc = launch_r1_dma<8, 32, 16>(ctx, a, has_ac, gridd);
+        else if (h == 9) rc = launch_r1_dma<9, 32, 16>(ctx, a, has_ac, gridd);
+        else if (h == 5) rc = launch_r1_dma<5, 32, 16>(ctx, a, has_ac, gridd);
+        else rc = launch_r1_dma<6, 32, 16>(ctx, a, has_ac, gridd);
     } else {
         std::vector<int32_t> offs(std::max(1, P->p), 0);
         for (int i = 0; i < P->p; ++i) offs[i] = P->dc[i] * HR + P->dr[i];

@@ -105,6 +105,20 @@ __global__ void __launch_bounds__(256) k_up_cols(const float4 *__restrict__ ylow
     if (q >= n) return;
     const int rl = (int)(q % d1s), cb = (int)(q / d1s);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (Pc == 6) {                                               // bicubic upsampling: 6 taps; all 12 loads in flight at once
+        int id[6]; float w[6]; float4 a[6], b[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { id[j] = ic[cb * 6 + j]; w[j] = wc[cb * 6 + j]; }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { const int64_t o = c * d_low + (int64_t)id[j] * d1s + rl; a[j] = ylow[o]; b[j] = yslow[o]; }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            acc.x = fmaf(w[j], a[j].x - b[j].x, acc.x); acc.y = fmaf(w[j], a[j].y - b[j].y, acc.y);
+            acc.z = fmaf(w[j], a[j].z - b[j].z, acc.z); acc.w = fmaf(w[j], a[j].w - b[j].w, acc.w);
+        }
+        tmp[c * n + q] = acc;
+        return;
+    }
     for (int j = 0; j < Pc; ++j) {
         const float wj = wc[cb * Pc + j];
         if (wj == 0.f) continue;
@@ -123,6 +137,19 @@ __global__ void __launch_bounds__(256) k_up_rows_combine(const float4 *__restric
     const int rb = (int)(m % nr) + roff, cb = (int)(m / nr) + coff;
     const float4 *col = tmp + c * (int64_t)d1s * nc_b + (int64_t)cb * d1s;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (Pr == 6) {
+        int id[6]; float w[6]; float4 v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { id[i] = ir[rb * 6 + i]; w[i] = wr[rb * 6 + i]; }
+        const float4 y = Y4[c * d_b + (int64_t)cb * nr_b + rb];
+        const float dl = dlt[m];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = col[id[i]];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { acc.x = fmaf(w[i], v[i].x, acc.x); acc.y = fmaf(w[i], v[i].y, acc.y); acc.z = fmaf(w[i], v[i].z, acc.z); acc.w = fmaf(w[i], v[i].w, acc.w); }
+        ysig[c * d + m] = make_float4(y.x + dl - acc.x, y.y + dl - acc.y, y.z + dl - acc.z, y.w + dl - acc.w);
+        return;
+    }
     for (int i = 0; i < Pr; ++i) {
         const float wi = wr[rb * Pr + i];
         if (wi == 0.f) continue;
