@@ -160,6 +160,78 @@ __global__ void __launch_bounds__(256) k_up_rows_combine(const float4 *__restric
     const float dl = dlt[m];
     ysig[c * d + m] = make_float4(y.x + dl - acc.x, y.y + dl - acc.y, y.z + dl - acc.z, y.w + dl - acc.w);
 }
+// upsample + combination in ONE pass (bicubic, 6 taps per dimension): a workgroup owns 64 x 16 patch pixels, stages the low-
+// resolution window of W*(...) = Ylow' - YsigLow that feeds them in LDS (<= 48 x 16 low pixels), interpolates the 16 output
+// columns for every low row into a second LDS tile, then each thread finishes 4 pixels of one output row.  The two-pass version
+// above re-reads every low pixel 6 + 6 times through L2 (12 ms per call at 512x512x10000); this one reads it ~1.1 times.
+constexpr int UF_TR = 64, UF_TC = 16, UF_NLR = 48, UF_NLC = 16;
+__global__ void __launch_bounds__(256) k_up_fused(const float4 *__restrict__ ylow, const float4 *__restrict__ yslow, int d1s, int64_t d_low,
+                                                  const float4 *__restrict__ Y4, int64_t d_b, int nr_b, int nr, int nc, int roff, int coff, int64_t d,
+                                                  const float *__restrict__ dlt, const int *__restrict__ ir, const float *__restrict__ wr,
+                                                  const int *__restrict__ ic, const float *__restrict__ wc, int ntile_r, int64_t Tc, int cseg,
+                                                  float4 *__restrict__ ysig) {
+    __shared__ __attribute__((aligned(16))) float4 low[UF_NLC][UF_NLR];
+    __shared__ __attribute__((aligned(16))) float4 mid[UF_TC][UF_NLR];
+    const int tid = threadIdx.x;
+    const int tile_r = blockIdx.x % ntile_r, tile_c = blockIdx.x / ntile_r;
+    const int pr0 = tile_r * UF_TR, pc0 = tile_c * UF_TC;
+    const int nrow = min(UF_TR, nr - pr0), ncol = min(UF_TC, nc - pc0);
+    // low-resolution window of this tile (taps are mirrored at the borders, so take min / max over all of them)
+    int lo_r = 1 << 30, hi_r = -1, lo_c = 1 << 30, hi_c = -1;
+    for (int q = 0; q < nrow * 6; ++q) { const int v = ir[(pr0 + roff) * 6 + q]; lo_r = min(lo_r, v); hi_r = max(hi_r, v); }
+    for (int q = 0; q < ncol * 6; ++q) { const int v = ic[(pc0 + coff) * 6 + q]; lo_c = min(lo_c, v); hi_c = max(hi_c, v); }
+    const int nlr = hi_r - lo_r + 1, nlc = hi_c - lo_c + 1;           // host guarantees <= UF_NLR, UF_NLC
+    // this thread's output row and its six row taps
+    const int orow = tid & 63, ocg = tid >> 6;                        // pixels (orow, ocg + 4k), k = 0..3
+    const bool rvalid = orow < nrow;
+    int rid[6]; float rw[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { rid[i] = rvalid ? ir[(pr0 + orow + roff) * 6 + i] - lo_r : 0; rw[i] = rvalid ? wr[(pr0 + orow + roff) * 6 + i] : 0.f; }
+    const int64_t c0 = (int64_t)blockIdx.y * cseg, c1 = min(Tc, c0 + cseg);
+    for (int64_t c = c0; c < c1; ++c) {
+        for (int q = tid; q < nlr * nlc; q += 256) {
+            const int lr = q % nlr, lc = q / nlr;
+            const int64_t o = c * d_low + (int64_t)(lo_c + lc) * d1s + lo_r + lr;
+            const float4 a = ylow[o], b = yslow[o];
+            low[lc][lr] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+        }
+        __syncthreads();
+        for (int q = tid; q < ncol * nlr; q += 256) {
+            const int lr = q % nlr, oc = q / nlr;
+            const int cb = pc0 + oc + coff;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float w = wc[cb * 6 + j];
+                const float4 v = low[ic[cb * 6 + j] - lo_c][lr];
+                acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+            }
+            mid[oc][lr] = acc;
+        }
+        __syncthreads();
+        if (rvalid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int oc = ocg + 4 * k;
+                if (oc < ncol) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const float4 v = mid[oc][rid[i]];
+                        acc.x = fmaf(rw[i], v.x, acc.x); acc.y = fmaf(rw[i], v.y, acc.y); acc.z = fmaf(rw[i], v.z, acc.z); acc.w = fmaf(rw[i], v.w, acc.w);
+                    }
+                    const int pr = pr0 + orow, pc = pc0 + oc;
+                    const int64_t m = (int64_t)pc * nr + pr;
+                    const float4 y = Y4[c * d_b + (int64_t)(pc + coff) * nr_b + pr + roff];
+                    const float dl = dlt[m];
+                    ysig[c * d + m] = make_float4(y.x + dl - acc.x, y.y + dl - acc.y, y.z + dl - acc.z, y.w + dl - acc.w);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void k_dlt2(const float *__restrict__ ymean_f, const double *__restrict__ b0, float *__restrict__ dlt, int64_t d, int nr, int nr_b, int roff, int coff) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= d) return;
@@ -283,6 +355,33 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     RET(dDlt.ensure(M->d * sizeof(float)));
     LAUNCH(ctx, "r1_dlt", k_dlt2, dim3((unsigned)((M->d + 255) / 256)), dim3(256), 0, M->ymean_f.as<float>(), M->b0.as<double>(), dDlt.as<float>(),
            M->d, M->nr, M->nr_b, M->roff, M->coff);
+    // the fused kernel needs 6-tap (upsampling) tables and a low-resolution window per 64 x 16 tile that fits its LDS tiles
+    bool fused = tr.P == 6 && tc.P == 6;
+    if (fused) {
+        for (int r0 = M->roff; r0 < M->roff + M->nr && fused; r0 += UF_TR) {
+            int lo = 1 << 30, hi = -1;
+            for (int q = r0 * 6; q < std::min(r0 + UF_TR, M->roff + M->nr) * 6; ++q) { lo = std::min(lo, tr.idx[q]); hi = std::max(hi, tr.idx[q]); }
+            if (hi - lo + 1 > UF_NLR) fused = false;
+        }
+        for (int c0 = M->coff; c0 < M->coff + M->nc && fused; c0 += UF_TC) {
+            int lo = 1 << 30, hi = -1;
+            for (int q = c0 * 6; q < std::min(c0 + UF_TC, M->coff + M->nc) * 6; ++q) { lo = std::min(lo, tc.idx[q]); hi = std::max(hi, tc.idx[q]); }
+            if (hi - lo + 1 > UF_NLC) fused = false;
+        }
+    }
+    if (fused) {
+        const int ntr = (M->nr + UF_TR - 1) / UF_TR, ntc = (M->nc + UF_TC - 1) / UF_TC;
+        const int64_t ntile = (int64_t)ntr * ntc;
+        int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(M->Tc, (4096 + ntile - 1) / ntile));
+        const int cseg = (int)((M->Tc + nseg - 1) / nseg);
+        nseg = (M->Tc + cseg - 1) / cseg;
+        LAUNCH(ctx, "ssub_up_fused", k_up_fused, dim3((unsigned)ntile, (unsigned)nseg), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(), d1s, R->d_b,
+               M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->nc, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(),
+               dIc.as<int>(), dWc.as<float>(), ntr, M->Tc, cseg, ctx->ysig.as<float4>());
+        ctx->ysig_patch = pid; M->ysig_valid = true;
+        if (Ysig_out) RET(ysig_export(ctx, M, ctx->ysig, Ysig_out, out_memspace));
+        return 0;
+    }
     LAUNCH(ctx, "ssub_up_cols", k_up_cols, dim3((unsigned)((ntmp + 255) / 256), (unsigned)M->Tc), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(),
            d1s, R->d_b, ctx->up_tmp.as<float4>(), M->nc_b, dIc.as<int>(), dWc.as<float>(), tc.P);
     LAUNCH(ctx, "ssub_up_rows_combine", k_up_rows_combine, dim3((unsigned)((M->d + 255) / 256), (unsigned)M->Tc), dim3(256), 0, ctx->up_tmp.as<float4>(), d1s,
