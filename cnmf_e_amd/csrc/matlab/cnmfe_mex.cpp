@@ -144,6 +144,55 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         pout[0] = to_double(Co, K, T);
         if (nout > 1) pout[1] = to_double(Cr, K, T);
         if (nout > 2) pout[2] = to_double(aa, K, 1);
+    } else if (!strcmp(cmd, "temporal_deconv")) {            // [C, C_raw, S, pars, sn, aa] = cnmfe_mex('temporal_deconv', h, pid, A, C, maxIter, smin, max_tau)
+        if (nin != 8) FAIL("temporal_deconv: 8 inputs required");
+        Csc A = csc_of(pin[3]);
+        std::vector<float> C = f32_of(pin[4]);
+        size_t K = mxGetM(pin[4]), T = mxGetN(pin[4]);
+        cnmfe_deconv_opts o; memset(&o, 0, sizeof(o));
+        o.type = 1; o.method = 1; o.smin = mxGetScalar(pin[6]); o.max_tau = mxGetScalar(pin[7]); o.optimize_b = 1; o.optimize_pars = 1; o.maxIter = 10;
+        std::vector<float> Co(K * T), Cr(K * T), S(K * T), kp(K), sn(K), aa(K);
+        CHECK(cnmfe_hals_temporal_deconv(c, pid, (int32_t)K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR,
+                                         (int32_t)mxGetScalar(pin[5]), &o, Co.data(), Cr.data(), S.data(), kp.data(), sn.data(), aa.data()));
+        pout[0] = to_double(Co, K, T);
+        if (nout > 1) pout[1] = to_double(Cr, K, T);
+        if (nout > 2) pout[2] = to_double(S, K, T);
+        if (nout > 3) pout[3] = to_double(kp, K, 1);
+        if (nout > 4) pout[4] = to_double(sn, K, 1);
+        if (nout > 5) pout[5] = to_double(aa, K, 1);
+    } else if (!strcmp(cmd, "fast_temporal")) {              // [C_raw, aa] = cnmfe_mex('fast_temporal', h, pid, A, T)   (use_c_hat = false)
+        if (nin != 5) FAIL("fast_temporal: 5 inputs required (h, pid, A, T)");
+        Csc A = csc_of(pin[3]);
+        int64_t info_T = (int64_t)mxGetScalar(pin[4]);
+        std::vector<float> Cr((size_t)A.K * info_T), aa(A.K);
+        CHECK(cnmfe_fast_temporal(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), CNMFE_COLMAJOR, Cr.data(), aa.data()));
+        pout[0] = to_double(Cr, A.K, (size_t)info_T);
+        if (nout > 1) pout[1] = to_double(aa, A.K, 1);
+    } else if (!strcmp(cmd, "get_sn")) {                     // sn = cnmfe_mex('get_sn', h, pid, d)   (update_sn = true)
+        if (nin != 4) FAIL("get_sn: 4 inputs required");
+        size_t d = (size_t)mxGetScalar(pin[3]);
+        std::vector<float> sn(d);
+        CHECK(cnmfe_get_sn(c, pid, sn.data()));
+        pout[0] = to_double(sn, d, 1);
+    } else if (!strcmp(cmd, "derive")) {                     // cnmfe_mex('derive', h, pid, new_pid, bg_ssub, 'nearest'|'bicubic')
+        if (nin != 6) FAIL("derive: 6 inputs required");
+        char md[16]; mxGetString(pin[5], md, sizeof(md));
+        CHECK(cnmfe_patch_derive(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), !strcmp(md, "nearest") ? CNMFE_DERIVE_NEAREST : CNMFE_DERIVE_BICUBIC));
+    } else if (!strcmp(cmd, "fit_ring_ssub")) {              // info = cnmfe_mex('fit_ring_ssub', h, pid, fit_pid, res_pid, bg_ssub, A, C, with_projection)
+        if (nin != 9) FAIL("fit_ring_ssub: 9 inputs required");
+        Csc A = csc_of(pin[6]);
+        std::vector<float> C = A.K ? f32_of(pin[7]) : std::vector<float>();
+        int64_t info[4];
+        CHECK(cnmfe_fit_ring_model_ssub(c, pid, (int)mxGetScalar(pin[3]), (int)mxGetScalar(pin[4]), (int32_t)mxGetScalar(pin[5]), A.K, A.cp.data(),
+                                        A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, mxGetNaN(), mxGetScalar(pin[8]) != 0, info));
+        pout[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
+        for (int i = 0; i < 4; ++i) mxGetPr(pout[0])[i] = (double)info[i];
+    } else if (!strcmp(cmd, "residual_ssub")) {              // cnmfe_mex('residual_ssub', h, pid, res_pid, bg_ssub, A_prev, C_prev)
+        if (nin != 7) FAIL("residual_ssub: 7 inputs required");
+        Csc A = csc_of(pin[5]);
+        std::vector<float> C = A.K ? f32_of(pin[6]) : std::vector<float>();
+        CHECK(cnmfe_residual_ssub(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(),
+                                  CNMFE_COLMAJOR, nullptr, CNMFE_HOST));
     } else if (!strcmp(cmd, "get_ring")) {
         int64_t nnz; int32_t p; CHECK(cnmfe_ring_nnz(c, pid, &nnz, &p));
         // rows = patch pixels: recovered from the CSR row pointer length the caller passes as pin[3] = d, pin[4] = d_b
