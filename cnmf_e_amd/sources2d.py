@@ -353,9 +353,9 @@ class Sources2D:
         """@Sources2D/update_background_parallel.m:121-146,176-230,311-317 (ring model, bg_ssub = 1)."""
         self._need_data()
         v, o = self.video, self.options
-        self._prefetch_search_location()
         A_csr = self.A.tocsr()
         infos = {}
+        prefetched = False
         self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update
         self._prev_blocks = {}                                             # (ind, A_block) per patch: what the temporal update's residual needs
         for idx in v.owned:
@@ -369,6 +369,8 @@ class Sources2D:
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
             if A_block.shape[1] == 0 and not self._first_run(idx):
                 continue
+            if not prefetched:                                             # host thread under the first blocking (GIL-free) fit call
+                self._prefetch_search_location(); prefetched = True
             if self.ssub == 1:
                 _, infos[idx] = self.engine.fit_ring_model(v.pid[idx], A_block if A_block.shape[1] else None, C_block,
                                                            o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218
