@@ -465,7 +465,7 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
     if (!(thresh_outlier != thresh_outlier))
         return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 outlier branch is not built)");
     RET(check_csc("A", K, P->d_b, A_colptr, A_rowidx));
-    if (K > 0 && (!A_val || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
+    if (K > 0 && ((!A_val && A_colptr[K] > 0) || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, P));
     int64_t dummy[4];
@@ -481,7 +481,7 @@ int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_
     Patch *P = get_patch(ctx, patch_id);
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
     RET(check_csc("A_prev", Ksel, P->d_b, A_colptr, A_rowidx));
-    if (Ksel > 0 && (!A_val || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
+    if (Ksel > 0 && ((!A_val && A_colptr[Ksel] > 0) || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, P));
     return residual_run(ctx, P, patch_id, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);
@@ -524,7 +524,7 @@ int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
-    if (!A_val || !C_in) return fail(CNMFE_EINVAL, "null A_val / C_in");
+    if ((!A_val && A_colptr[K] > 0) || !C_in) return fail(CNMFE_EINVAL, "null A_val / C_in");   // all-zero columns are legal: aa = 0, row left alone (HALS_temporal.m:51)
     if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
     CK(hipSetDevice(ctx->device));
     return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, nullptr, nullptr, nullptr, nullptr);
@@ -539,7 +539,7 @@ int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const in
     if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
-    if (!A_val || !C_in || !opts || !kernel_pars) return fail(CNMFE_EINVAL, "null A_val / C_in / opts / kernel_pars");
+    if ((!A_val && A_colptr[K] > 0) || !C_in || !opts || !kernel_pars) return fail(CNMFE_EINVAL, "null A_val / C_in / opts / kernel_pars");
     if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
     CK(hipSetDevice(ctx->device));
     return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, opts, kernel_pars, S_out, sn_out);
@@ -553,7 +553,7 @@ int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
-    if (!A_val || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");
+    if ((!A_val && A_colptr[K] > 0) || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");
     CK(hipSetDevice(ctx->device));
     return fast_temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, c_order, C_raw_out, aa_out);
 }
@@ -574,7 +574,7 @@ int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K
     if (d1 <= 0 || d2 <= 0) return fail(CNMFE_EINVAL, "bad dims");
     RET(check_csc("A", K, (int64_t)d1 * d2, A_colptr, A_rowidx));
     if (K == 0) return 0;
-    if (!A_val || !keep) return fail(CNMFE_EINVAL, "null A_val / keep");
+    if ((!A_val && A_colptr[K] > 0) || !keep) return fail(CNMFE_EINVAL, "null A_val / keep");
     CK(hipSetDevice(ctx->device));
     return postproc_run(ctx, d1, d2, K, A_colptr, A_rowidx, A_val, keep);
 }

@@ -1,0 +1,153 @@
+"""Edge cases of the hot path on the GPU: empty / ragged inputs, argument and state errors of the C ABI
+(the reference has no tests of its own -- SURVEY.md section 4 -- so these follow its code paths: isempty(A) in
+fit_ring_model.m:14-16, patches without neurons in update_*_parallel.m:121-124,123, num_neighbors in get_nhood.m:17-25)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cnmf_e_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _video(eng, d1, d2, T, K, r, seed, pdims=None):
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo
+    f = synth.make_factors(d1, d2, T, K, seed, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, pdims or [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    return f, Y, video
+
+
+@pytest.mark.parametrize("T", [61, 202, 303])
+def test_ragged_frame_counts(eng, T):
+    """T not a multiple of 4 (the resident video is 4-frame interleaved) nor of 16 (the Gram stage): full iteration vs oracle"""
+    import cnmfe_oracle as orc
+    from cnmf_e_amd.sources2d import Sources2D, Options
+    d1, d2, K, r = 40, 36, 4, 5
+    f, Y, video = _video(eng, d1, d2, T, K, r, 3)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [d1, d2], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
+    s.update_background_parallel(); o.update_background_parallel()
+    s.update_spatial_parallel(); o.update_spatial_parallel()
+    s.update_temporal_parallel(); o.update_temporal_parallel()
+    assert rel(s.C, o.C) <= 2e-3 and rel(s.A.toarray(), o.A.toarray()) <= 5e-3
+
+
+def test_no_neurons_at_all(eng):
+    """K = 0: isempty(A) -> A = ones, C = zeros (fit_ring_model.m:14-16); spatial/temporal updates return empty factors"""
+    import cnmfe_oracle as orc
+    from cnmf_e_amd.sources2d import Sources2D, Options
+    d1, d2, T, r = 36, 32, 120, 5
+    f, Y, video = _video(eng, d1, d2, T, 3, r, 5)
+    A0 = sp.csc_matrix((d1 * d2, 0), dtype=np.float32); C0 = np.zeros((0, T), np.float32)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=2), A0, C0, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [d1, d2], r, A0, C0, f.sn, maxIter=2)
+    s.update_background_parallel(); o.update_background_parallel()
+    Wg = s.get_W((0, 0)); Wr = sp.csr_matrix(o.W[(0, 0)]); Wr.sort_indices()
+    assert rel(Wg.data, Wr.data) <= 2e-3
+    assert np.allclose(s.b0_new, o.b0_new, rtol=1e-5, atol=1e-2)
+    s.update_spatial_parallel(); s.update_temporal_parallel()
+    assert s.A.shape == (d1 * d2, 0) and s.C.shape == (0, T)
+
+
+def test_patch_without_neurons_is_skipped(eng):
+    """2x2 patches, all footprints in one corner: the other patches take the `continue` branches (update_*_parallel.m:121-124, :123, :188-199)"""
+    import cnmfe_oracle as orc
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, r = 48, 44, 150, 5
+    f = synth.make_factors(d1, d2, T, 6, 9, gSig=1.5, gSiz=7, min_sep=5)
+    rr, cc = np.meshgrid(np.arange(d1), np.arange(d2), indexing="ij")
+    cols = []
+    for (r0, c0) in ((7, 6), (11, 9)):                                  # two footprints inside the top-left patch, away from its halo
+        g = np.exp(-((rr - r0) ** 2 + (cc - c0) ** 2) / (2 * 1.5 ** 2)); g[g < 0.05] = 0
+        cols.append(sp.csc_matrix(g.reshape(-1, 1, order="F").astype(np.float32)))
+    A0 = sp.hstack(cols).tocsc(); C0 = f.C_init[:2]
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [24, 22], r, eng); video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3), A0, C0, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [24, 22], r, A0.astype(np.float32), C0, f.sn, maxIter=3)
+    for _ in range(2):
+        s.update_background_parallel(); o.update_background_parallel()
+        s.update_spatial_parallel(); o.update_spatial_parallel()
+        s.update_temporal_parallel(); o.update_temporal_parallel()
+    assert rel(s.C, o.C) <= 2e-3
+    assert np.allclose(s.b0_new, o.b0_new, rtol=1e-4, atol=5e-2)
+
+
+def test_num_neighbors_subsampled_ring(eng):
+    """num_neighbors < ring size (get_nhood.m:17-25): the generic R1 kernel and the fit on a thinned ring"""
+    import cnmfe_oracle as orc
+    d1, d2, T, r, nn = 44, 40, 100, 8, 20
+    f, Y, video = _video(eng, d1, d2, T, 4, r, 21)
+    eng.ring_init(0, r, nn)
+    rs, cs = orc.get_nhood(r, nn)
+    W0 = orc.build_ring_W(video.patch_pos[(0, 0)], video.block_pos[(0, 0)], d1, d2, rs, cs).tocsr(); W0.sort_indices()
+    Wg = eng.ring_csr(0)
+    assert np.array_equal(Wg.indices, W0.indices) and np.allclose(Wg.data, W0.data, rtol=1e-6)
+    A = f.A_init.tocsc().astype(np.float32)
+    eng.fit_ring_model(0, A, f.C_init)
+    Wr, b0r = orc.fit_ring_model(Y.T.astype(np.float64), A.astype(np.float64), f.C_init, W0, np.nan, None, np.ones(d1 * d2, bool), True)
+    Wr = sp.csr_matrix(Wr); Wr.sort_indices()
+    assert rel(eng.ring_csr(0).data, Wr.data) <= 2e-3
+    got = eng.residual(0, A, f.C_init, want=True).T
+    ref = orc.residual_ysig(Y.T.astype(np.float64), A.astype(np.float64), f.C_init, sp.csr_matrix((eng.ring_csr(0).data, Wr.indices, Wr.indptr), shape=Wr.shape),
+                            eng.b0(0).astype(np.float64), np.ones(d1 * d2, bool))
+    assert rel(got, ref) <= 1e-4          # fitted weights (cancellation) in fp32 vs float64
+
+
+def test_abi_state_and_argument_errors(eng):
+    from cnmf_e_amd import _lib as L
+    d1, d2, T, r = 30, 28, 64, 5
+    f, Y, video = _video(eng, d1, d2, T, 3, r, 2)
+    A = f.A_init.tocsc().astype(np.float32)
+    with pytest.raises(L.CnmfeError):                      # ring not initialised yet
+        eng.fit_ring_model(0, A, f.C_init)
+    eng.ring_init(0, r)
+    with pytest.raises(L.CnmfeError):                      # HALS before the residual of this patch exists
+        eng.hals_temporal(0, A, f.C_init, 2)
+    with pytest.raises(L.CnmfeError):                      # unknown patch, straight at the C ABI
+        L.check(L.lib.cnmfe_residual(eng._ctx, 7, 0, None, None, None, None, L.ROWMAJOR, None, L.HOST))
+    with pytest.raises(L.CnmfeError):                      # the outlier branch of fit_ring_model is not built: must be NaN
+        eng.fit_ring_model(0, A, f.C_init, thresh_outlier=3.0)
+    cp = np.array([0, 2], np.int64); ri = np.array([5, 3], np.int32); va = np.ones(2, np.float32)     # rows of a column not ascending
+    Cm = np.zeros((1, T), np.float32)
+    with pytest.raises(L.CnmfeError):
+        L.check(L.lib.cnmfe_residual(eng._ctx, 0, 1, cp.ctypes.data_as(L.i64p), ri.ctypes.data_as(L.i32p), va.ctypes.data_as(L.f32p),
+                                     Cm.ctypes.data_as(L.f32p), L.ROWMAJOR, None, L.HOST))
+    ri2 = np.array([3, d1 * d2 + 9], np.int32)                                                           # row index outside the block
+    with pytest.raises(L.CnmfeError):
+        L.check(L.lib.cnmfe_residual(eng._ctx, 0, 1, cp.ctypes.data_as(L.i64p), ri2.ctypes.data_as(L.i32p), va.ctypes.data_as(L.f32p),
+                                     Cm.ctypes.data_as(L.f32p), L.ROWMAJOR, None, L.HOST))
+    with pytest.raises(L.CnmfeError):                      # ring radius out of range
+        eng.ring_init(0, 0)
+    with pytest.raises(L.CnmfeError):                      # unknown tunable
+        eng.set_option("no_such_option", 1)
+    eng.residual(0, A, f.C_init)                            # ... and the context is still usable afterwards
+    C2, Craw, aa = eng.hals_temporal(0, A, f.C_init, 2)
+    assert np.isfinite(C2).all() and C2.shape == f.C_init.shape
+
+
+def test_deconvolution_rejects_unsupported_lengths(eng):
+    from cnmf_e_amd import _lib as L
+    with pytest.raises(L.CnmfeError):
+        eng.deconv_temporal(np.zeros((2, 32), np.float32), dict(type="ar1", method="foopsi"))       # T < 64
+    with pytest.raises((L.CnmfeError, NotImplementedError, ValueError)):
+        eng.deconv_temporal(np.zeros((2, 128), np.float32), dict(type="ar2", method="foopsi"))     # only AR(1) is built
