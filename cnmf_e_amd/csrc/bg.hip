@@ -37,9 +37,13 @@ struct BgGeom {
 };
 
 // ---- B1 ------------------------------------------------------------------------------------------
+// fp32 -> (hi, lo) bf16 pair, round-to-nearest-even: x = hi + lo + O(2^-17 |x|)
+__device__ __forceinline__ unsigned bf16_rne(float x) { const unsigned u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }
+__device__ __forceinline__ void bf16_split(float x, unsigned &hi, unsigned &lo) { hi = bf16_rne(x); lo = bf16_rne(x - __uint_as_float(hi << 16)); }
+
 __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g,
                                                   const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
-                                                  const float *__restrict__ Cc, int64_t ldc, float *__restrict__ bf, int tchunk) {
+                                                  const float *__restrict__ Cc, int64_t ldc, float *__restrict__ bf, int tchunk, double *__restrict__ rs) {
     const int blk = blockIdx.x;                    // 16x16 block id, column-major over (nbr, nbc)
     const int bi = blk % g.nbr, bj = blk / g.nbr;
     const int lp = threadIdx.x;                    // local pixel in 4x4-patch order (lp_of)
@@ -52,6 +56,7 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
     const int64_t tp0 = (int64_t)blockIdx.y * tchunk;          // tchunk is a multiple of 4
     const int64_t tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
     float *out = bf + ((int64_t)blk * g.Tpad) * BLKPX + lp;
+    double rsum = 0.0;                                   // bf4 == 2: the ones-row of X from the exact fp32 values (the split loses 2^-17)
     if (g.kstride == 1) {                          // the video is resident centred: Bf = Yc - A*(C - Cmean), 4 frames per load
         for (int64_t tp = tp0; tp < tp1; tp += 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -64,7 +69,12 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
                     v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
                 }
             }
-            if (g.bf4) reinterpret_cast<float4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = v;
+            if (g.bf4 == 2) {                                          // [hi0..hi3 | lo0..lo3] bf16: the operands of the split-bf16 Gram
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                bf16_split(v.x, h0, l0); bf16_split(v.y, h1, l1); bf16_split(v.z, h2, l2); bf16_split(v.w, h3, l3);
+                reinterpret_cast<uint4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), l0 | (l1 << 16), l2 | (l3 << 16));
+                rsum += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            } else if (g.bf4) reinterpret_cast<float4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = v;
             else { out[tp * BLKPX] = v.x; out[(tp + 1) * BLKPX] = v.y; out[(tp + 2) * BLKPX] = v.z; out[(tp + 3) * BLKPX] = v.w; }
         }
     } else {                                       // frame subsampling Bf(:, 1:k:end)  (fit_ring_model.m:87)
@@ -76,10 +86,16 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
                 v = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)];
                 for (int e = e0; e < e1; ++e) v -= aval[e] * Cc[(int64_t)acol[e] * ldc + t];
             }
-            if (g.bf4) bf[(((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 4 + (tp & 3)] = v;
+            if (g.bf4 == 2) {
+                unsigned h, l; bf16_split(v, h, l);
+                unsigned short *e = reinterpret_cast<unsigned short *>(bf) + (((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 8 + (tp & 3);
+                e[0] = (unsigned short)h; e[4] = (unsigned short)l;
+                rsum += (double)v;
+            } else if (g.bf4) bf[(((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 4 + (tp & 3)] = v;
             else out[tp * BLKPX] = v;
         }
     }
+    if (g.bf4 == 2 && rs) atomicAdd(&rs[(int64_t)blk * BLKPX + lp], rsum);
 }
 
 // row sums of Bf over the used frames (the "ones" row of X, fit_ring_model.m:101)
@@ -367,7 +383,9 @@ struct G4Wave {                       // per-wave constants of a work item (all 
 // the whole stage loop for a wave that owns NS slots (the last one only if `ns == NS`): instantiated per NS and
 // selected ONCE per workgroup, so the loop body is branch-free straight-line code with its own register allocation
 // (a switch inside the loop made hipcc keep the fp64 shadows in scratch: 456 spilled VGPRs)
-template <bool F32, int NS>
+// MODE 0: fp64 MFMA; 1: fp32 MFMA; 2: split bf16 (4 products hi*hi + hi*lo + lo*hi + lo*lo on the bf16 pipe, 16x the fp32 MFMA rate:
+// W error like MODE 1 -- emulation in DESIGN.md -- at a quarter of its matrix-pipe time).  MODE >= 1 folds into fp64 shadows.
+template <int MODE, int NS>
 __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, const int *__restrict__ tlw) {
     int ao[NS], bo[NS], ti[NS], tj[NS];
 #pragma unroll
@@ -414,7 +432,15 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
             asm volatile("" ::: "memory");
             if (sl == NS - 1 && !last) break;
             const float4 a4 = fa[sl % 3], b4 = fb[sl % 3];
-            if (F32) {
+            if (MODE == 2) {
+                typedef short short4_t __attribute__((ext_vector_type(4)));
+                union { float2 f; short4_t s; } ah, al, bh, bl;
+                ah.f = make_float2(a4.x, a4.y); al.f = make_float2(a4.z, a4.w); bh.f = make_float2(b4.x, b4.y); bl.f = make_float2(b4.z, b4.w);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al.s, bl.s, facc[sl], 0, 0, 0);      // smallest term first
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bl.s, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al.s, bh.s, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bh.s, facc[sl], 0, 0, 0);
+            } else if (MODE == 1) {
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, facc[sl], 0, 0, 0);
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, facc[sl], 0, 0, 0);
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, facc[sl], 0, 0, 0);
@@ -426,7 +452,7 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.w, (double)b4.w, acc[sl], 0, 0, 0);
             }
         }
-        if (F32 && (++since == (w.flush_every & 0xffff) || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
+        if (MODE >= 1 && (++since == (w.flush_every & 0xffff) || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
             since = 0;
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
@@ -445,13 +471,13 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // D layouts: fp32 16x16 -> row = (lane>>4)*4 + r ; fp64 16x16 -> row = (lane>>4) + 4*r
-                const int rr = F32 ? ((w.lane >> 4) * 4 + r) : ((w.lane >> 4) + 4 * r);
+                const int rr = MODE >= 1 ? ((w.lane >> 4) * 4 + r) : ((w.lane >> 4) + 4 * r);
                 w.out[(int64_t)(ti[sl] * 16 + rr) * BLKPX + tj[sl] * 16 + fl] = acc[sl][r];
             }
         }
 }
 
-template <bool F32>
+template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
                                                   const int *__restrict__ work, int nwork, const int *__restrict__ tl_cnt,
                                                   const int *__restrict__ tl, int flush_every, double *__restrict__ cov) {
@@ -482,7 +508,7 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
     w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX + jh * 128;
     const int *tlw = tl + lidx * 64 + wave;
     switch ((cnt + 3) >> 2) {                                          // slots of the busiest wave; the others skip the last one
-#define G4_CASE(N) case N: gram4_run<F32, N>(w, smem, tlw); break;
+#define G4_CASE(N) case N: gram4_run<MODE, N>(w, smem, tlw); break;
         G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
         G4_CASE(9) G4_CASE(10) G4_CASE(11) G4_CASE(12) G4_CASE(13) G4_CASE(14) G4_CASE(15) G4_CASE(16)
 #undef G4_CASE
@@ -1146,7 +1172,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.d = P->d; g.d_b = P->d_b; g.T = T; g.kstride = kstride;
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
     g.Tpad = (g.Tp + GK - 1) / GK * GK;
-    g.bf4 = ctx->opt("gram_kernel", 4) == 4 ? 1 : 0;
+    g.bf4 = ctx->opt("gram_kernel", 4) == 4 ? (ctx->opt("gram_mode", 3) == 3 ? 2 : 1) : 0;
     g.p_radius = 0;
     for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
     g.nbw = ((2 * g.p_radius) >> 4) + 2;
@@ -1180,10 +1206,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
         const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 3) & ~int64_t(3));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
-        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
-               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk);
         RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>(), g.bf4);
+        if (g.bf4 == 2) CK(hipMemsetAsync(ctx->rowsum.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
+        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
+               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, ctx->rowsum.as<double>());
+        if (g.bf4 != 2)
+            LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>(), g.bf4);
         // ---- pair list: blocks that hold ring pixels of some patch pixel, displacement within +-2 ----
         // a block is "touched" if it lies within one block of a block containing patch pixels
         std::vector<char> touched(nblk, 0);
@@ -1250,7 +1278,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(ctx->cov.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
         if (ctx->opt("debug", 0)) CK(hipMemsetAsync(ctx->cov.p, 0xff, (size_t)npairs * BLKPX * BLKPX * sizeof(double), ctx->stream));   // NaN-poison skipped sub-tiles
         int nwg = (nwork + 7) / 8 * 8;                      // multiple of 8 for the XCD remap (extra workgroups exit)
-        const bool f32s = ctx->opt("gram_mode", 2) == 2;
+        const bool f32s = ctx->opt("gram_mode", 3) >= 2;
         if (g.bf4) {
             // tile lists per (displacement class, quadrant): needed 16x16 sub-tiles as i | j << 4 (quadrant coordinates)
             std::vector<int> tcnt(NREL * 4, 0);
@@ -1269,15 +1297,20 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             const size_t shmem = (size_t)G4_NBUF * G4_STAGE_F * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
-                CK(hipFuncSetAttribute((const void *)k_gram4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                CK(hipFuncSetAttribute((const void *)k_gram4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                CK(hipFuncSetAttribute((const void *)k_gram4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                CK(hipFuncSetAttribute((const void *)k_gram4<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                CK(hipFuncSetAttribute((const void *)k_gram4<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                 attr4 = true;
             }
-            if (f32s)
-                LAUNCH(ctx, "bg_gram_f32s", k_gram4<true>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16), ctx->cov.as<double>());
+            const int flushw = (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16);
+            if (g.bf4 == 2)
+                LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
+            else if (f32s)
+                LAUNCH(ctx, "bg_gram_f32s", k_gram4<1>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
             else
-                LAUNCH(ctx, "bg_gram_f64", k_gram4<false>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                LAUNCH(ctx, "bg_gram_f64", k_gram4<0>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), 0, ctx->cov.as<double>());
         } else if (ctx->opt("gram_kernel", 4) == 3) {
             const size_t shmem = (size_t)GR_NBUF * GR_STAGE_F * sizeof(float);

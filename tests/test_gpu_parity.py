@@ -263,7 +263,7 @@ def test_method_level_iteration_parity(eng, alg):
         assert np.allclose(s.b0_new, o.b0_new, rtol=1e-4, atol=5e-2)
 
 
-@pytest.mark.parametrize("gram_mode", [1, 2])
+@pytest.mark.parametrize("gram_mode", [1, 2, 3])
 def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
     """gram_mode 1 = fp64 matrix pipe, 2 = fp32 pipe with fp64 shadow accumulation; debug=1 NaN-poisons the
     covariance table so that a lookup into a pruned (never computed) sub-tile cannot go unnoticed."""
@@ -283,7 +283,7 @@ def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
             Wref = Wref.tocsr(); Wref.sort_indices()
             assert rel(W.data, Wref.data) <= (1e-4 if gram_mode == 1 else 1e-3), rel(W.data, Wref.data)
     finally:
-        eng.set_option("debug", 0); eng.set_option("gram_mode", 2)
+        eng.set_option("debug", 0); eng.set_option("gram_mode", 3)
 
 
 def _deconv_case(eng, T=1500, K=5):
