@@ -418,38 +418,60 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
         int lb = w.lbase;
         asm volatile("" : "+v"(lb));            // opaque per stage: no hoisting of 2*NS per-slot address VGPRs out of the loop
         const float *lp = smem + (st & (G4_NBUF - 1)) * G4_STAGE_F + lb;
-        // fragments are fetched two slots ahead; the compiler barrier pins each fetch between its neighbours' MFMAs
-        float4 fa[3], fb[3];
-        auto ld = [&](int sl) {
-            fa[sl % 3] = *reinterpret_cast<const float4 *>(lp + ao[sl]);
-            fb[sl % 3] = *reinterpret_cast<const float4 *>(lp + bo[sl]);
-        };
-        ld(0);
-        if (NS > 1) ld(1);
+        // slots go in batches of two: the fragments of the next batch (4 ds_read_b128) are issued before the current
+        // batch's MFMAs, and the two slots' MFMA chains are interleaved so that no MFMA waits on its predecessor's
+        // result (the one-slot version stalled an LDS latency per slot: hipcc waited lgkmcnt(0) before every chain)
+        float4 fa[2][2], fb[2][2];
+        auto ldb = [&](int buf, int base) {
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (sl + 2 < NS) ld(sl + 2);
+            for (int u = 0; u < 2; ++u)
+                if (base + u < NS) {
+                    fa[buf][u] = *reinterpret_cast<const float4 *>(lp + ao[base + u]);
+                    fb[buf][u] = *reinterpret_cast<const float4 *>(lp + bo[base + u]);
+                }
+        };
+        ldb(0, 0);
+#pragma unroll
+        for (int base = 0; base < NS; base += 2) {
+            const int cur = (base >> 1) & 1;
+            if (base + 2 < NS) ldb(cur ^ 1, base + 2);
             asm volatile("" ::: "memory");
-            if (sl == NS - 1 && !last) break;
-            const float4 a4 = fa[sl % 3], b4 = fb[sl % 3];
+            const bool on0 = true, on1 = (base + 1 < NS - 1) || (base + 1 == NS - 1 && last);
+            const bool only0_last = (base == NS - 1);                   // odd NS: the last slot stands alone
+            const bool do0 = only0_last ? last : on0;
             if (MODE == 2) {
                 typedef short short4_t __attribute__((ext_vector_type(4)));
-                union { float2 f; short4_t s; } ah, al, bh, bl;
-                ah.f = make_float2(a4.x, a4.y); al.f = make_float2(a4.z, a4.w); bh.f = make_float2(b4.x, b4.y); bl.f = make_float2(b4.z, b4.w);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al.s, bl.s, facc[sl], 0, 0, 0);      // smallest term first
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bl.s, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al.s, bh.s, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bh.s, facc[sl], 0, 0, 0);
-            } else if (MODE == 1) {
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, facc[sl], 0, 0, 0);
+                union U { float2 f; short4_t s; };
+                U ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ah[u].f = make_float2(fa[cur][u].x, fa[cur][u].y); al[u].f = make_float2(fa[cur][u].z, fa[cur][u].w);
+                    bh[u].f = make_float2(fb[cur][u].x, fb[cur][u].y); bl[u].f = make_float2(fb[cur][u].z, fb[cur][u].w);
+                }
+#pragma unroll
+                for (int term = 0; term < 4; ++term) {                  // smallest products first: lo*lo, hi*lo, lo*hi, hi*hi
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (base + u >= NS) continue;
+                        if (u == 0 ? !do0 : !on1) continue;
+                        const short4_t av = (term == 0 || term == 2) ? al[u].s : ah[u].s;
+                        const short4_t bv = (term == 0 || term == 1) ? bl[u].s : bh[u].s;
+                        facc[base + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, facc[base + u], 0, 0, 0);
+                    }
+                }
             } else {
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.x, (double)b4.x, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.y, (double)b4.y, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.z, (double)b4.z, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.w, (double)b4.w, acc[sl], 0, 0, 0);
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (base + u >= NS) continue;
+                        if (u == 0 ? !do0 : !on1) continue;
+                        const float av = kq == 0 ? fa[cur][u].x : kq == 1 ? fa[cur][u].y : kq == 2 ? fa[cur][u].z : fa[cur][u].w;
+                        const float bv = kq == 0 ? fb[cur][u].x : kq == 1 ? fb[cur][u].y : kq == 2 ? fb[cur][u].z : fb[cur][u].w;
+                        if (MODE == 1) facc[base + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, facc[base + u], 0, 0, 0);
+                        else acc[base + u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)bv, acc[base + u], 0, 0, 0);
+                    }
+                }
             }
         }
         if (MODE >= 1 && (++since == (w.flush_every & 0xffff) || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
