@@ -30,6 +30,7 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (157.3 TF), spec
 F32_MFMA_PEAK_TF = 157.3
+BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); the split-bf16 Gram issues 4 bf16 products per fp32-equivalent product
 
 
 def cpu_baseline(seconds_budget=30.0):
@@ -185,7 +186,12 @@ def main():
             tot += mult * 1024.0 * sum(float(r_["value_per_launch_KiB"]) for r_ in rows) / len(rows)
         return tot
     if dom.startswith("bg_gram"):
-        roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else F32_MFMA_PEAK_TF)
+        roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else (BF16_MFMA_PEAK_TF if "bf16" in dom else F32_MFMA_PEAK_TF))
+        if "bf16" in dom:
+            roof["note"] = ("algorithmic = 2*d*(p+1)^2*T/2 fp32-equivalent flops of the reference's per-pixel Gram (SURVEY 8(d)); the engine computes every "
+                            "covariance once (block-sparse SYRK, 9.57 TFLOP fp32-equivalent at the headline size) as 4 bf16 MFMA products each "
+                            "(38.3 TFLOP on the bf16 pipe, peak = dense bf16); the kernel is bound by the fabric (385 GB per launch) and per-stage "
+                            "synchronisation, not by the matrix pipe -- see DESIGN.md")
     elif dom == "residual_r1":
         roof = r1_roof()
     else:

@@ -397,7 +397,7 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
     const bool last = w.ns == NS;
     auto issue = [&](int st) {
         int sc = st < w.nst ? st : w.nst - 1;                            // clamp: keeps the vmcnt arithmetic uniform
-        if (w.flush_every >> 16) sc = 0;                                 // A/B probe (gram_probe): every stage re-reads stage 0 -> no fabric traffic
+        if ((w.flush_every >> 16) & 1) sc = 0;                           // A/B probe (gram_probe bit 0): every stage re-reads stage 0 -> no fabric traffic
         const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
         const unsigned d = w.dA0 + (unsigned)(st & (G4_NBUF - 1)) * (G4_STAGE_F * 4u);
         glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
@@ -411,8 +411,10 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
     for (int s0 = 0; s0 < G4_NBUF - 1; ++s0) issue(s0);
     int since = 0;
     for (int st = 0; st < w.nst; ++st) {
+        if (!((w.flush_every >> 16) & 2)) {                                           // (gram_probe bit 1: timing experiment without the stage sync)
         asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * (G4_NBUF - 2)) : "memory");    // this wave's part of stage st has landed
         __builtin_amdgcn_s_barrier();                                                // ... and everybody else's; buffer st-1 is free
+        }
         asm volatile("" ::: "memory");
         issue(st + G4_NBUF - 1);
         int lb = w.lbase;
@@ -499,6 +501,95 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
         }
 }
 
+// split-bf16 on the K=32 instruction: v_mfma_f32_16x16x32_bf16 is the full-rate bf16 MFMA of gfx950 (16 clk for 16384 flop; the
+// K=16 form used by gram4_run<2> takes the same 16 clk for half the work).  One compute step = two 16-frame stages: lane group
+// l>>4 takes quad-row l>>4 of BOTH stages (8 frames); A and B fragments are built identically, so the pairing of frames inside
+// the instruction's k index is irrelevant.  4 ds_read_b128 + 4 MFMAs per tile and 32 frames.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int NS>
+__device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem, const int *__restrict__ tlw) {
+    int ao[NS], bo[NS], ti[NS], tj[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const int code = __builtin_amdgcn_readfirstlane(sl < w.ns ? tlw[sl * 4] : 0);
+        ti[sl] = code & 7; tj[sl] = code >> 4;
+        ao[sl] = ti[sl] * 64; bo[sl] = GK * 128 + tj[sl] * 64;
+    }
+    const bool last = w.ns == NS;
+    const bool probe_nomem = (w.flush_every >> 16) & 1;
+    auto issue2 = [&](int step) {                                   // stages 2*step, 2*step+1 -> buffers (2*step)&3, (2*step+1)&3
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int st = 2 * step + h;
+            int sc = st < w.nst ? st : w.nst - 1;
+            if (probe_nomem) sc = 0;
+            const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
+            const unsigned d = w.dA0 + (unsigned)(st & (G4_NBUF - 1)) * (G4_STAGE_F * 4u);
+            glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
+            glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
+        }
+    };
+    double4_t acc[NS];
+    float4_t facc[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) { acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+    const int nstep = w.nst >> 1;                                   // Tpad is a multiple of 32 in this mode
+    const int flush_steps = max(1, (w.flush_every & 0xffff) >> 1);
+    issue2(0);
+    int since = 0;
+    for (int step = 0; step < nstep; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's part of both stages has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue2(step + 1);
+        int lb = w.lbase;
+        asm volatile("" : "+v"(lb));
+        const float *lp0 = smem + ((2 * step) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
+        const float *lp1 = smem + ((2 * step + 1) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
+        float4 f[2][4];                                              // [buffer][a0 a1 b0 b1]
+        auto ld = [&](int buf, int sl) {
+            f[buf][0] = *reinterpret_cast<const float4 *>(lp0 + ao[sl]); f[buf][1] = *reinterpret_cast<const float4 *>(lp1 + ao[sl]);
+            f[buf][2] = *reinterpret_cast<const float4 *>(lp0 + bo[sl]); f[buf][3] = *reinterpret_cast<const float4 *>(lp1 + bo[sl]);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int cur = sl & 1;
+            if (sl + 1 < NS) ld(cur ^ 1, sl + 1);
+            asm volatile("" ::: "memory");
+            if (sl == NS - 1 && !last) break;
+            union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
+            ah.v = make_float4(f[cur][0].x, f[cur][0].y, f[cur][1].x, f[cur][1].y); al.v = make_float4(f[cur][0].z, f[cur][0].w, f[cur][1].z, f[cur][1].w);
+            bh.v = make_float4(f[cur][2].x, f[cur][2].y, f[cur][3].x, f[cur][3].y); bl.v = make_float4(f[cur][2].z, f[cur][2].w, f[cur][3].z, f[cur][3].w);
+            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, facc[sl], 0, 0, 0);      // smallest products first
+            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, facc[sl], 0, 0, 0);
+            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, facc[sl], 0, 0, 0);
+            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, facc[sl], 0, 0, 0);
+        }
+        if (++since == flush_steps || step + 1 == nstep) {           // fold the fp32 partial sums into the fp64 shadows
+            since = 0;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[sl][r] += (double)facc[sl][r];
+                facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int fl = w.lane & 15;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+        if (sl < NS - 1 || last) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = (w.lane >> 4) * 4 + r;
+                w.out[(int64_t)(ti[sl] * 16 + rr) * BLKPX + tj[sl] * 16 + fl] = acc[sl][r];
+            }
+        }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
                                                   const int *__restrict__ work, int nwork, const int *__restrict__ tl_cnt,
@@ -530,7 +621,7 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
     w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX + jh * 128;
     const int *tlw = tl + lidx * 64 + wave;
     switch ((cnt + 3) >> 2) {                                          // slots of the busiest wave; the others skip the last one
-#define G4_CASE(N) case N: gram4_run<MODE, N>(w, smem, tlw); break;
+#define G4_CASE(N) case N: if (MODE == 2) gram4_run_k32<N>(w, smem, tlw); else gram4_run<MODE == 2 ? 1 : MODE, N>(w, smem, tlw); break;
         G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
         G4_CASE(9) G4_CASE(10) G4_CASE(11) G4_CASE(12) G4_CASE(13) G4_CASE(14) G4_CASE(15) G4_CASE(16)
 #undef G4_CASE
@@ -1193,8 +1284,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
     g.d = P->d; g.d_b = P->d_b; g.T = T; g.kstride = kstride;
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
-    g.Tpad = (g.Tp + GK - 1) / GK * GK;
     g.bf4 = ctx->opt("gram_kernel", 4) == 4 ? (ctx->opt("gram_mode", 3) == 3 ? 2 : 1) : 0;
+    g.Tpad = g.bf4 == 2 ? (g.Tp + 2 * GK - 1) / (2 * GK) * (2 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: steps of two stages
     g.p_radius = 0;
     for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
     g.nbw = ((2 * g.p_radius) >> 4) + 2;
