@@ -215,6 +215,7 @@ def main():
         "roofline": roof,
         "roofline_r1": r1r,
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+        "kernel_calls_per_step": {k: round(v["calls_per_step"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] > 0.5},
     }
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()

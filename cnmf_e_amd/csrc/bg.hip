@@ -1315,16 +1315,6 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
            has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCm.as<double>(), P->b0.as<double>());
 
     if (nactive > 0) {
-        // ---- B1: Bf tiled ----
-        RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
-        const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 3) & ~int64_t(3));
-        dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
-        RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        if (g.bf4 == 2) CK(hipMemsetAsync(ctx->rowsum.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
-        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
-               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, ctx->rowsum.as<double>());
-        if (g.bf4 != 2)
-            LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>(), g.bf4);
         // ---- pair list: blocks that hold ring pixels of some patch pixel, displacement within +-2 ----
         // a block is "touched" if it lies within one block of a block containing patch pixels
         std::vector<char> touched(nblk, 0);
@@ -1392,6 +1382,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         if (ctx->opt("debug", 0)) CK(hipMemsetAsync(ctx->cov.p, 0xff, (size_t)npairs * BLKPX * BLKPX * sizeof(double), ctx->stream));   // NaN-poison skipped sub-tiles
         int nwg = (nwork + 7) / 8 * 8;                      // multiple of 8 for the XCD remap (extra workgroups exit)
         const bool f32s = ctx->opt("gram_mode", 3) >= 2;
+        DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
         if (g.bf4) {
             // tile lists per (displacement class, quadrant): needed 16x16 sub-tiles as i | j << 4 (quadrant coordinates)
             std::vector<int> tcnt(NREL * 4, 0);
@@ -1404,9 +1395,24 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                         if ((needmask[rel * 16 + ih * 8 + i] >> (jh * 8 + j)) & 1) tlist[(size_t)(rel * 4 + q) * 64 + n++] = i | (j << 4);
                     tcnt[rel * 4 + q] = n;
                 }
-            DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
             RET(to_dev(ctx, dTcnt, tcnt.data(), tcnt.size()));
             RET(to_dev(ctx, dTl, tlist.data(), tlist.size()));
+        }
+        // every host-side staging vector of this call has been consumed once the stream drains here -- and nothing heavy is queued
+        // yet: the three big launches below go out back to back, and without an output request the call returns with them in flight
+        CK(hipStreamSynchronize(ctx->stream));
+        // ---- B1: Bf tiled ----
+        RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
+        const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 3) & ~int64_t(3));
+        dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
+        RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
+        if (g.bf4 == 2) CK(hipMemsetAsync(ctx->rowsum.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
+        LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
+               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, ctx->rowsum.as<double>());
+        if (g.bf4 != 2)
+            LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>(), g.bf4);
+
+        if (g.bf4) {
             const size_t shmem = (size_t)G4_NBUF * G4_STAGE_F * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
@@ -1474,8 +1480,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         CK(hipStreamSynchronize(ctx->stream));
         for (int64_t i = 0; i < P->d; ++i) b0_out[i] = (float)tmp[i];
     }
-    CK(hipStreamSynchronize(ctx->stream));
-    info[0] = first_run ? 1 : 0; info[1] = kstride; info[2] = nactive; info[3] = pmax;
+    // without b0_out the call returns with the fit in flight (every later engine call is stream-ordered behind it)
+    if (info) { info[0] = first_run ? 1 : 0; info[1] = kstride; info[2] = nactive; info[3] = pmax; }
+    P->ysig_valid = false;
     return 0;
 }
 

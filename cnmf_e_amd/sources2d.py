@@ -318,6 +318,8 @@ class Sources2D:
 
     @property
     def b0_new(self):
+        if isinstance(self._b0_new_src, str):
+            self._b0_new_val = self.reconstruct_b0(); self._b0_new_src = None
         if self._b0_new_src is not None:
             A, Cm = self._b0_new_src
             v = self.video
@@ -378,7 +380,11 @@ class Sources2D:
                 _, infos[idx] = self.engine.fit_ring_model_ssub(v.pid[idx], self.pid_fit[idx], self.pid_res[idx], self.ssub,
                                                                 A_block if A_block.shape[1] else None, C_block,
                                                                 o.thresh_outlier, o.bg_acceleration)
-        self.b0_new = self.reconstruct_b0()                                # :315
+        if self.dist is not None and v.world_size > 1:
+            self.b0_new = self.reconstruct_b0()                            # :315 (a collective when sharded: evaluate now, on every rank)
+        else:
+            self._b0_new_src = "b0"                                        # :315, evaluated on first read (b0 only changes in this method),
+            #                                                                so the call returns with the fit still running on the GPU
         self.A_prev = self.A                                               # :316 (no copy needed: A, C are replaced, not mutated)
         self._prev_csr_src = self.A
         self.C_prev = self.C                                               # :317

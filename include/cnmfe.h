@@ -93,7 +93,9 @@ int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0 /* d */);
  * (first-run detection by value inspection of row 1, :25; ind_active, :28; frame stride k,
  * :60,84-87).  A is d_b x K CSC (block rows), C is K x T.  thresh_outlier must be NaN
  * (the outlier branch :50-56 is dead in every demo; anything else -> CNMFE_EUNSUPPORTED).
- * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels, info[3]=pmax. */
+ * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels, info[3]=pmax (known before the heavy kernels start).
+ * With b0_out == NULL the call returns while the Gram / solve kernels are still running on the context's stream; every later
+ * call on this context is ordered behind them and reports their errors. */
 int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
                          const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                          double thresh_outlier, int with_projection,
