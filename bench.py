@@ -152,7 +152,7 @@ def main():
     d, d_b, p = P[idx0], B[idx0], 96 if r == 15 else None
     roof = None
     def r1_roof():
-        if "residual_r1" not in kern:
+        if "residual_r1" not in kern or a.bg_ssub != 1:         # bg_ssub > 1: the sweep runs on the low-resolution patch, a different kernel mix
             return None
         bytes_r1 = 4.0 * d_b * T + 4.0 * d * T + 8.0 * d * p + 4.0 * Kp * T       # read Y + write Ysig + W + C
         ms = kern["residual_r1"]["ms_per_call"]
@@ -194,6 +194,11 @@ def main():
                             "synchronisation, not by the matrix pipe -- see DESIGN.md")
     elif dom == "residual_r1":
         roof = r1_roof()
+    elif dom == "ssub_up_fused":                                 # bg_ssub > 1: read Y' + W*(..) at low resolution (two arrays), write Ysig
+        ms = kern[dom]["ms_per_call"]
+        by = 4.0 * d_b * T + 4.0 * d * T + 2 * 4.0 * (d_b / float(a.bg_ssub ** 2)) * T
+        roof = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                "kernel": dom, "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     else:
         roof = {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": dom,
                 "ms_per_launch": kern[dom]["ms_per_call"]}
