@@ -511,11 +511,10 @@ __device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem
     int ao[NS], bo[NS], ti[NS], tj[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-        const int code = __builtin_amdgcn_readfirstlane(sl < w.ns ? tlw[sl * 4] : 0);
+        const int code = __builtin_amdgcn_readfirstlane(sl < w.ns ? tlw[sl] : 0);   // this wave owns a CONTIGUOUS run of the (row-major) tile list
         ti[sl] = code & 7; tj[sl] = code >> 4;
         ao[sl] = ti[sl] * 64; bo[sl] = GK * 128 + tj[sl] * 64;
     }
-    const bool last = w.ns == NS;
     const bool probe_nomem = (w.flush_every >> 16) & 1;
     auto issue2 = [&](int step) {                                   // stages 2*step, 2*step+1 -> buffers (2*step)&3, (2*step+1)&3
 #pragma unroll
@@ -546,25 +545,31 @@ __device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem
         asm volatile("" : "+v"(lb));
         const float *lp0 = smem + ((2 * step) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
         const float *lp1 = smem + ((2 * step + 1) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
-        float4 f[2][4];                                              // [buffer][a0 a1 b0 b1]
-        auto ld = [&](int buf, int sl) {
-            f[buf][0] = *reinterpret_cast<const float4 *>(lp0 + ao[sl]); f[buf][1] = *reinterpret_cast<const float4 *>(lp1 + ao[sl]);
-            f[buf][2] = *reinterpret_cast<const float4 *>(lp0 + bo[sl]); f[buf][3] = *reinterpret_cast<const float4 *>(lp1 + bo[sl]);
-        };
-        ld(0, 0);
+        // fragment registers of the slot in flight (X) and the next one (N): A from stage 0/1, B from stage 0/1.
+        // Consecutive slots of a wave mostly share the tile row, i.e. the A fragment: it is re-read from LDS only when the row
+        // changes (a wave-uniform branch per slot; the LDS pipe and the matrix pipe were at the same 2048 clk per step before).
+        float4 xa0, xa1, xb0, xb1, na0, na1, nb0, nb1;
+        xa0 = *reinterpret_cast<const float4 *>(lp0 + ao[0]); xa1 = *reinterpret_cast<const float4 *>(lp1 + ao[0]);
+        xb0 = *reinterpret_cast<const float4 *>(lp0 + bo[0]); xb1 = *reinterpret_cast<const float4 *>(lp1 + bo[0]);
+        na0 = xa0; na1 = xa1; nb0 = xb0; nb1 = xb1;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int cur = sl & 1;
-            if (sl + 1 < NS) ld(cur ^ 1, sl + 1);
+            if (sl + 1 < NS) {
+                if (ao[sl + 1] != ao[sl]) { na0 = *reinterpret_cast<const float4 *>(lp0 + ao[sl + 1]); na1 = *reinterpret_cast<const float4 *>(lp1 + ao[sl + 1]); }
+                else { na0 = xa0; na1 = xa1; }
+                nb0 = *reinterpret_cast<const float4 *>(lp0 + bo[sl + 1]); nb1 = *reinterpret_cast<const float4 *>(lp1 + bo[sl + 1]);
+            }
             asm volatile("" ::: "memory");
-            if (sl == NS - 1 && !last) break;
-            union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
-            ah.v = make_float4(f[cur][0].x, f[cur][0].y, f[cur][1].x, f[cur][1].y); al.v = make_float4(f[cur][0].z, f[cur][0].w, f[cur][1].z, f[cur][1].w);
-            bh.v = make_float4(f[cur][2].x, f[cur][2].y, f[cur][3].x, f[cur][3].y); bl.v = make_float4(f[cur][2].z, f[cur][2].w, f[cur][3].z, f[cur][3].w);
-            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, facc[sl], 0, 0, 0);      // smallest products first
-            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, facc[sl], 0, 0, 0);
-            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, facc[sl], 0, 0, 0);
-            facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, facc[sl], 0, 0, 0);
+            if (sl < w.ns) {
+                union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
+                ah.v = make_float4(xa0.x, xa0.y, xa1.x, xa1.y); al.v = make_float4(xa0.z, xa0.w, xa1.z, xa1.w);
+                bh.v = make_float4(xb0.x, xb0.y, xb1.x, xb1.y); bl.v = make_float4(xb0.z, xb0.w, xb1.z, xb1.w);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, facc[sl], 0, 0, 0);      // smallest products first
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, facc[sl], 0, 0, 0);
+                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, facc[sl], 0, 0, 0);
+            }
+            xa0 = na0; xa1 = na1; xb0 = nb0; xb1 = nb1;
         }
         if (++since == flush_steps || step + 1 == nstep) {           // fold the fp32 partial sums into the fp64 shadows
             since = 0;
@@ -581,7 +586,7 @@ __device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem
     const int fl = w.lane & 15;
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl)
-        if (sl < NS - 1 || last) {
+        if (sl < w.ns) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = (w.lane >> 4) * 4 + r;
@@ -617,9 +622,11 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
     w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
     w.lbase = (lane >> 4) * 512 + (lane & 15) * 4;                     // quad-row l>>4, pixel l&15 of the tile, 4 frames
     w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
-    w.ns = cnt > wave ? (cnt - wave + 3) >> 2 : 0;                     // this wave's slots: tiles wave, wave+4, ...
+    const int nsmax = (cnt + 3) >> 2;
+    if (MODE == 2) { const int lo_ = wave * nsmax; w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0; }   // tiles [wave*nsmax, ...): a contiguous run
+    else w.ns = cnt > wave ? (cnt - wave + 3) >> 2 : 0;                // tiles wave, wave+4, ...
     w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX + jh * 128;
-    const int *tlw = tl + lidx * 64 + wave;
+    const int *tlw = MODE == 2 ? tl + lidx * 64 + wave * nsmax : tl + lidx * 64 + wave;
     switch ((cnt + 3) >> 2) {                                          // slots of the busiest wave; the others skip the last one
 #define G4_CASE(N) case N: if (MODE == 2) gram4_run_k32<N>(w, smem, tlw); else gram4_run<MODE == 2 ? 1 : MODE, N>(w, smem, tlw); break;
         G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
