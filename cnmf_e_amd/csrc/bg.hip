@@ -1199,6 +1199,246 @@ __global__ void __launch_bounds__(256) k_ring_solve3(CovTab tab, BgGeom g, const
     for (int i = tid; i < p; i += 256) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)wv[i] : 0.f;   // intercept (index p) discarded (:107)
 }
 
+// ---- B2b v4 (experimental, solve_mode=4; NOT the default): v2's 8-column register panel on v3's register-resident
+// trailing matrix.  Correct, 41 ms vs v2's 23 ms: 208 VGPR+AGPR -> 2 workgroups per CU, three barriers per 8-column panel,
+// and the tile publish / read-back round trips make the per-pixel chain (160 k clk) longer than v2's (134 k clk at 3 per CU).
+// Probes: assembly straight into accumulator tiles 9 ms (v2: 3), panel loop 27 ms (panel factor 11), back substitution 6 ms.
+__global__ void __launch_bounds__(256) k_ring_solve4(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
+                                                     const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
+                                                     float *__restrict__ W, int probe) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int p = g.p;
+    double *panel = sm;                                   // S3_NB tiles [16][S3_LD]: block column kb (A, then L)
+    double *linv = panel + S3_NB * S3_TILE;               // S3_NU tiles: inverse of every diagonal factor
+    double *zv = linv + S3_NU * S3_TILE;                  // 128: z = L^-1 g
+    double *av = zv + 128;                                // 128: accumulated L^T w of the blocks below
+    double *wv = av + 128;                                // 128: solution
+    double *sc = wv + 128;                                // 8 scalars
+    double *dinv = sc + 8;                                // 128: 1 / L(j,j)
+    int *nb = reinterpret_cast<int *>(dinv + 128);        // p neighbour codes
+    int *node = nb + p;                                   // p+1 node codes
+    int *pt = node + p + 1;                               // nbw^4 block-pair codes
+    const int64_t m = blockIdx.x;
+    if (active && !active[m]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lg = lane >> 4;             // accumulator layout: element r of a tile is (row lg + 4r, col lc)
+    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
+    for (int i = tid; i < p; i += 256) {
+        const int rb = rbm + dr[i], cb = cbm + dc[i];
+        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
+        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
+    }
+    if (tid < 8) sc[tid] = 0.0;
+    for (int i = tid; i < 128; i += 256) { av[i] = 0.0; zv[i] = 0.0; wv[i] = 0.0; }
+    __syncthreads();
+    const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;
+    const int nbw = g.nbw, nb2 = nbw * nbw;
+    for (int q = tid; q < nb2 * nb2; q += 256) {
+        const int a = q / nb2, b = q % nb2;
+        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
+        int code = -1;
+        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
+            int dR = ib - ia, dC = jb - ja, sw = 0;
+            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
+            const int pidx = tab.pair_of[(ja * tab.nbr + ia) * NREL + rel_index(dR, dC)];
+            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
+        }
+        pt[q] = code;
+    }
+    for (int i = tid; i <= p; i += 256) {
+        const int c = i < p ? nb[i] : (rbm | (cbm << 16));
+        int nc = -1;
+        if (c >= 0) { const int rb = c & 0xffff, cb = c >> 16; nc = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15); }
+        node[i] = nc;
+    }
+    __syncthreads();
+    // covariance of two nodes (block-local codes), through the block-pair table
+    auto cov_ptr = [&](int na_, int nb_) -> const double * {
+        const int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
+        int la = na_ & 255, lb = nb_ & 255;
+        if (code & 2) { const int t0 = la; la = lb; lb = t0; }
+        if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }
+        return tab.cov + ((int64_t)(code >> 2) * BLKPX + la) * BLKPX + lb;
+    };
+    auto rs_ptr = [&](int c) -> const double * {           // rowsum of a block pixel code (rb | cb << 16)
+        const int rb = c & 0xffff, cb = c >> 16;
+        return &rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + lp_of(rb & 15, cb & 15)];
+    };
+    // element (i, j) of the augmented system: i in 0..111 unknown rows (i > p: identity padding), i >= 112: rhs block
+    auto elem = [&](int i, int j, double &val) -> const double * {
+        val = 0.0;
+        if (i >= 16 * S3_NU) {                             // right-hand side X*y' (fit_ring_model.m:104), row 0 of block 7
+            if (i != 16 * S3_NU) return nullptr;
+            if (j < p) return (node[j] >= 0) ? cov_ptr(node[j], node[p]) : nullptr;
+            if (j == p) return rs_ptr(rbm | (cbm << 16));
+            return nullptr;
+        }
+        if (i < j) { const int t0 = i; i = j; j = t0; }
+        if (i > p) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
+        if (i == p) {                                      // the row of ones (:101)
+            if (j == p) { val = (double)g.Tp; return nullptr; }
+            return nb[j] >= 0 ? rs_ptr(nb[j]) : nullptr;
+        }
+        if (node[i] < 0 || node[j] < 0) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
+        return cov_ptr(node[i], node[j]);
+    };
+    // tile slots of this wave: row blocks Ia = 7 - wave (slots 0..6, J = slot) and Ib = wave (slots 7..10, J = slot - 7)
+    const int Ia = 7 - wave, Ib = wave;
+    auto slotI = [&](int s_) { return s_ < 7 ? Ia : Ib; };
+    auto slotJ = [&](int s_) { return s_ < 7 ? s_ : s_ - 7; };
+    auto slotOn = [&](int s_) { return s_ < 7 ? (s_ <= (Ia < 6 ? Ia : 6)) : (s_ - 7 <= Ib); };
+    double4_t acc[S3_NSLOT];
+#pragma unroll
+    for (int s_ = 0; s_ < S3_NSLOT; ++s_) {
+        acc[s_] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (slotOn(s_)) {
+            const int I = slotI(s_), J = slotJ(s_);
+            const double *ptr[4]; double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ptr[r] = elem(16 * I + lg + 4 * r, 16 * J + lc, v[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ptr[r]) v[r] = *ptr[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s_][r] = v[r];
+        }
+    }
+    // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
+    {
+        double tr = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * slotI(s_) + lg + 4 * r;
+                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) tr += acc[s_][r];
+                }
+            }
+        for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
+        if (lane == 0) atomicAdd(&sc[0], tr);
+        __syncthreads();
+        const double lam = sc[0] * 1e-5;
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * slotI(s_) + lg + 4 * r;
+                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) acc[s_][r] += lam;
+                }
+            }
+    }
+    // ---- right-looking Cholesky by 8-column panels: the matrix stays in the accumulator tiles, LDS carries the panel ----
+    constexpr int PS = 9;                                  // panel row stride (doubles): pan[row][0..7]
+    double *pan = panel;                                   // 128 rows
+    for (int pp = 0; pp < ((probe & 2) ? 0 : 2 * S3_NU); ++pp) {
+        const int kb = pp >> 1, h = pp & 1, j0 = 8 * pp;
+        // a. owners publish columns j0..j0+7 (their tile column kb, half h), all rows of their tiles
+        if ((lc >> 3) == h) {
+#pragma unroll
+            for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+                if (slotOn(s_) && slotJ(s_) == kb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pan[(16 * slotI(s_) + lg + 4 * r) * PS + (lc & 7)] = acc[s_][r];
+                }
+        }
+        __syncthreads();
+        // c. wave 0 factors the panel in registers (lane = row j0+lane and j0+lane+64), exactly like k_ring_solve2
+        if (wave == 0 && !(probe & 8)) {
+            const int ra = j0 + lane, rb = j0 + lane + 64;
+            double a[PW], b[PW];
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) {
+                a[jj] = (ra < 128 && j0 + jj <= ra) ? pan[ra * PS + jj] : 0.0;
+                b[jj] = (rb < 128) ? pan[rb * PS + jj] : 0.0;
+            }
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) {
+                const double piv = readlane_f64(a[jj], jj);
+                const double inv = rsqrt_f64(piv);
+                if (lane == jj) { a[jj] = piv * inv; dinv[j0 + jj] = inv; } else if (lane > jj) a[jj] *= inv;
+                b[jj] *= inv;
+#pragma unroll
+                for (int c = jj + 1; c < PW; ++c) {
+                    const double lcj = readlane_f64(a[jj], c);
+                    if (lane >= c) a[c] -= a[jj] * lcj;
+                    b[c] -= b[jj] * lcj;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < PW; ++jj) {
+                if (ra < 128 && j0 + jj <= ra) pan[ra * PS + jj] = a[jj];
+                if (rb < 128) pan[rb * PS + jj] = b[jj];
+            }
+        }
+        __syncthreads();
+        // e1. the factored columns go back into their tiles
+        if ((lc >> 3) == h) {
+#pragma unroll
+            for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+                if (slotOn(s_) && slotJ(s_) == kb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s_][r] = pan[(16 * slotI(s_) + lg + 4 * r) * PS + (lc & 7)];
+                }
+        }
+        // e2. trailing update A(I,J) -= P_I P_J^T (rank 8: two MFMAs) on everything right of the panel
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && (slotJ(s_) > kb || (slotJ(s_) == kb && h == 0))) {
+                const double *PI = pan + (16 * slotI(s_) + lc) * PS + lg, *PJ = pan + (16 * slotJ(s_) + lc) * PS + lg;
+                const bool keep = !(slotJ(s_) == kb && lc < 8);          // columns of the panel itself are finished
+#pragma unroll
+                for (int mq = 0; mq < 2; ++mq) {
+                    const double bv = keep ? PJ[4 * mq] : 0.0;
+                    acc[s_] = s3_mfma(-PI[4 * mq], bv, acc[s_]);
+                }
+            }
+        __syncthreads();
+    }
+    // ---- diagonal tiles to LDS (for the block back substitution), z = row 0 of the right-hand side block ----
+    double *dt = linv;
+#pragma unroll
+    for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+        if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
+            double *X = dt + slotI(s_) * S3_TILE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * S3_LD + lc] = acc[s_][r];
+        }
+    if (wave == 0 && lg == 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < 7; ++s_) zv[16 * s_ + lc] = acc[s_][0];
+    }
+    __syncthreads();
+    // ---- back substitution L^T w = z by row blocks, bottom up ----
+    for (int kb = S3_NU - 1; kb >= ((probe & 4) ? S3_NU : 0); --kb) {
+        if (wave == 0) {                                   // within the block: 16 steps, lane lc holds entry lc (replicated over lg)
+            const double *X = dt + kb * S3_TILE;
+            double t = zv[16 * kb + lc] - av[16 * kb + lc];
+#pragma unroll
+            for (int c = 15; c >= 0; --c) {
+                const double wc = readlane_f64(t, c) * dinv[16 * kb + c];
+                if (lc == c) t = wc;
+                else if (lc < c) t = fma(-X[c * S3_LD + lc], wc, t);
+            }
+            if (lg == 0) wv[16 * kb + lc] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
+            if (slotOn(s_) && slotI(s_) == kb && slotJ(s_) < kb) {
+                double q = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q = fma(acc[s_][r], wv[16 * kb + lg + 4 * r], q);
+                q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                if (lg == 0) av[16 * slotJ(s_) + lc] += q;
+            }
+        __syncthreads();
+    }
+    for (int i = tid; i < p; i += 256) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)wv[i] : 0.f;   // intercept (index p) discarded (:107)
+}
+
+
 // pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60) and the first-run test on row 1 (:25)
 __global__ void k_count_pos(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1461,7 +1701,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc;
         const int n = p + 1;
-        if (ctx->opt("solve_mode", 2) == 3 && n <= 16 * S3_NU) {
+        if (ctx->opt("solve_mode", 2) == 4 && n <= 16 * S3_NU) {
+            size_t shmem = ((size_t)(S3_NB + S3_NU) * S3_TILE + 4 * 128 + 8) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
+            shmem = (shmem + 15) & ~size_t(15);
+            LAUNCH(ctx, "bg_ring_solve", k_ring_solve4, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
+                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>(), (int)ctx->opt("solve_probe", 0));
+        } else if (ctx->opt("solve_mode", 2) == 3 && n <= 16 * S3_NU) {
             size_t shmem = ((size_t)(S3_NB + S3_NU) * S3_TILE + 3 * 128 + 8) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
             shmem = (shmem + 15) & ~size_t(15);
             LAUNCH(ctx, "bg_ring_solve", k_ring_solve3, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("--cfg", default="c3"); ap.add_argument("--mode", type=int, default=2); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--kernels", default="3,2"); ap.add_argument("--probe", type=int, default=0); ap.add_argument("--sprobes", default="0")
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--mode", type=int, default=2); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--kernels", default="3,2"); ap.add_argument("--probe", type=int, default=0); ap.add_argument("--sprobes", default="0"); ap.add_argument("--smode", type=int, default=2)
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -18,7 +18,7 @@ eng = Engine(0)
 video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
 video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
 eng.ring_init(0, r)
-eng.set_option("gram_mode", a.mode); eng.set_option("gram_probe", a.probe)
+eng.set_option("solve_mode", a.smode); eng.set_option("gram_mode", a.mode); eng.set_option("gram_probe", a.probe)
 eng.profile(True)
 Ws = {}
 for sp_ in [int(x) for x in a.sprobes.split(",")]:

@@ -438,13 +438,14 @@ def test_fit_ring_solve_modes_agree(eng):
     c = Case(eng, 48, 40, 120, 4, 15, seed=11)
     A = c.f.A_init.tocsc().astype(np.float32)
     out = {}
-    for mode in (2, 3):
+    for mode in (2, 3, 4):
         eng.ring_init(0, 15)
         eng.set_option("solve_mode", mode)
         eng.fit_ring_model(0, A, c.f.C_init)
         out[mode] = eng.ring_csr(0).data.copy()
     eng.set_option("solve_mode", 2)
     assert rel(out[3], out[2]) <= 1e-5, rel(out[3], out[2])
+    assert rel(out[4], out[2]) <= 1e-5, rel(out[4], out[2])
 
 
 @pytest.mark.parametrize("dims,pdims,ssub,r", [((40, 36), None, 2, 6), ((45, 38), [23, 19], 2, 6), ((42, 39), None, 3, 9)])
