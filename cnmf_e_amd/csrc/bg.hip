@@ -57,7 +57,29 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
     const int64_t tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
     float *out = bf + ((int64_t)blk * g.Tpad) * BLKPX + lp;
     double rsum = 0.0;                                   // bf4 == 2: the ones-row of X from the exact fp32 values (the split loses 2^-17)
-    if (g.kstride == 1) {                          // the video is resident centred: Bf = Yc - A*(C - Cmean), 4 frames per load
+    if (g.kstride == 1 && g.bf4 == 2) {            // split-bf16 operands: 8 frames per iteration -> one 16-byte store per plane
+        for (int64_t tp = tp0; tp < tp1; tp += 8) {
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            const int64_t c = tp >> 2;
+            if (in) {
+                if (c < Tc) v0 = Y4[c * g.d_b + q];
+                if (c + 1 < Tc) v1 = Y4[(c + 1) * g.d_b + q];
+                for (int e = e0; e < e1; ++e) {
+                    const float av = aval[e];
+                    const float *cr = Cc + (int64_t)acol[e] * ldc + tp;
+                    if (c < Tc) { const float4 c4 = *reinterpret_cast<const float4 *>(cr); v0.x -= av * c4.x; v0.y -= av * c4.y; v0.z -= av * c4.z; v0.w -= av * c4.w; }
+                    if (c + 1 < Tc) { const float4 c4 = *reinterpret_cast<const float4 *>(cr + 4); v1.x -= av * c4.x; v1.y -= av * c4.y; v1.z -= av * c4.z; v1.w -= av * c4.w; }
+                }
+            }
+            unsigned h[8], l[8];
+            bf16_split(v0.x, h[0], l[0]); bf16_split(v0.y, h[1], l[1]); bf16_split(v0.z, h[2], l[2]); bf16_split(v0.w, h[3], l[3]);
+            bf16_split(v1.x, h[4], l[4]); bf16_split(v1.y, h[5], l[5]); bf16_split(v1.z, h[6], l[6]); bf16_split(v1.w, h[7], l[7]);
+            uint4 *o16 = reinterpret_cast<uint4 *>(bf) + (((int64_t)blk * (g.Tpad >> 3) + (tp >> 3)) * 2) * BLKPX + lp;    // [blk][frame/8][hi | lo][256 px]
+            o16[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            o16[BLKPX] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            rsum += (((double)v0.x + (double)v0.y) + ((double)v0.z + (double)v0.w)) + (((double)v1.x + (double)v1.y) + ((double)v1.z + (double)v1.w));
+        }
+    } else if (g.kstride == 1) {                   // the video is resident centred: Bf = Yc - A*(C - Cmean), 4 frames per load
         for (int64_t tp = tp0; tp < tp1; tp += 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int64_t c = tp >> 2;
@@ -69,12 +91,7 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
                     v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
                 }
             }
-            if (g.bf4 == 2) {                                          // [hi0..hi3 | lo0..lo3] bf16: the operands of the split-bf16 Gram
-                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                bf16_split(v.x, h0, l0); bf16_split(v.y, h1, l1); bf16_split(v.z, h2, l2); bf16_split(v.w, h3, l3);
-                reinterpret_cast<uint4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), l0 | (l1 << 16), l2 | (l3 << 16));
-                rsum += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-            } else if (g.bf4) reinterpret_cast<float4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = v;
+            if (g.bf4) reinterpret_cast<float4 *>(bf)[((int64_t)blk * (g.Tpad >> 2) + c) * BLKPX + lp] = v;
             else { out[tp * BLKPX] = v.x; out[(tp + 1) * BLKPX] = v.y; out[(tp + 2) * BLKPX] = v.z; out[(tp + 3) * BLKPX] = v.w; }
         }
     } else {                                       // frame subsampling Bf(:, 1:k:end)  (fit_ring_model.m:87)
@@ -88,8 +105,8 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
             }
             if (g.bf4 == 2) {
                 unsigned h, l; bf16_split(v, h, l);
-                unsigned short *e = reinterpret_cast<unsigned short *>(bf) + (((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 8 + (tp & 3);
-                e[0] = (unsigned short)h; e[4] = (unsigned short)l;
+                unsigned short *e = reinterpret_cast<unsigned short *>(bf) + ((((int64_t)blk * (g.Tpad >> 3) + (tp >> 3)) * 2) * BLKPX + lp) * 8 + (tp & 7);
+                e[0] = (unsigned short)h; e[(int64_t)BLKPX * 8] = (unsigned short)l;
                 rsum += (double)v;
             } else if (g.bf4) bf[(((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 4 + (tp & 3)] = v;
             else out[tp * BLKPX] = v;
@@ -543,33 +560,32 @@ __device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem
         issue2(step + 1);
         int lb = w.lbase;
         asm volatile("" : "+v"(lb));
-        const float *lp0 = smem + ((2 * step) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
-        const float *lp1 = smem + ((2 * step + 1) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
-        // fragment registers of the slot in flight (X) and the next one (N): A from stage 0/1, B from stage 0/1.
-        // Consecutive slots of a wave mostly share the tile row, i.e. the A fragment: it is re-read from LDS only when the row
-        // changes (a wave-uniform branch per slot; the LDS pipe and the matrix pipe were at the same 2048 clk per step before).
-        float4 xa0, xa1, xb0, xb1, na0, na1, nb0, nb1;
-        xa0 = *reinterpret_cast<const float4 *>(lp0 + ao[0]); xa1 = *reinterpret_cast<const float4 *>(lp1 + ao[0]);
-        xb0 = *reinterpret_cast<const float4 *>(lp0 + bo[0]); xb1 = *reinterpret_cast<const float4 *>(lp1 + bo[0]);
-        na0 = xa0; na1 = xa1; nb0 = xb0; nb1 = xb1;
+        // the two stages of a step sit in adjacent buffers ((2*step)&3 is 0 or 2); lane group l>>4 owns one of their four 8-frame
+        // rows, whose hi and lo planes ARE the K=32 operands: every fragment is one ds_read_b128, no register shuffling
+        const float *lp = smem + ((2 * step) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
+        // fragment registers of the slot in flight (x) and the next one (n).  Consecutive slots of a wave mostly share the tile row,
+        // i.e. the A fragment: it is re-read from LDS only when the row changes (a wave-uniform branch per slot).
+        float4 xah, xal, xbh, xbl, nah, nal, nbh, nbl;
+        xah = *reinterpret_cast<const float4 *>(lp + ao[0]); xal = *reinterpret_cast<const float4 *>(lp + ao[0] + 512);
+        xbh = *reinterpret_cast<const float4 *>(lp + bo[0]); xbl = *reinterpret_cast<const float4 *>(lp + bo[0] + 512);
+        nah = xah; nal = xal; nbh = xbh; nbl = xbl;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             if (sl + 1 < NS) {
-                if (ao[sl + 1] != ao[sl]) { na0 = *reinterpret_cast<const float4 *>(lp0 + ao[sl + 1]); na1 = *reinterpret_cast<const float4 *>(lp1 + ao[sl + 1]); }
-                else { na0 = xa0; na1 = xa1; }
-                nb0 = *reinterpret_cast<const float4 *>(lp0 + bo[sl + 1]); nb1 = *reinterpret_cast<const float4 *>(lp1 + bo[sl + 1]);
+                if (ao[sl + 1] != ao[sl]) { nah = *reinterpret_cast<const float4 *>(lp + ao[sl + 1]); nal = *reinterpret_cast<const float4 *>(lp + ao[sl + 1] + 512); }
+                else { nah = xah; nal = xal; }
+                nbh = *reinterpret_cast<const float4 *>(lp + bo[sl + 1]); nbl = *reinterpret_cast<const float4 *>(lp + bo[sl + 1] + 512);
             }
             asm volatile("" ::: "memory");
             if (sl < w.ns) {
                 union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
-                ah.v = make_float4(xa0.x, xa0.y, xa1.x, xa1.y); al.v = make_float4(xa0.z, xa0.w, xa1.z, xa1.w);
-                bh.v = make_float4(xb0.x, xb0.y, xb1.x, xb1.y); bl.v = make_float4(xb0.z, xb0.w, xb1.z, xb1.w);
+                ah.v = xah; al.v = xal; bh.v = xbh; bl.v = xbl;
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, facc[sl], 0, 0, 0);      // smallest products first
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, facc[sl], 0, 0, 0);
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, facc[sl], 0, 0, 0);
                 facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, facc[sl], 0, 0, 0);
             }
-            xa0 = na0; xa1 = na1; xb0 = nb0; xb1 = nb1;
+            xah = nah; xal = nal; xbh = nbh; xbl = nbl;
         }
         if (++since == flush_steps || step + 1 == nstep) {           // fold the fp32 partial sums into the fp64 shadows
             since = 0;
@@ -621,6 +637,14 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
     w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
     w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
     w.lbase = (lane >> 4) * 512 + (lane & 15) * 4;                     // quad-row l>>4, pixel l&15 of the tile, 4 frames
+    if (MODE == 2) {
+        // split-bf16 layout: a 16-frame stage of a half is [8-frame row e][plane hi/lo][128 px] x 16 B = 8 instructions of 1 KB;
+        // wave w moves instruction w (row 0: plane (w>>1)&1, pixels (w&1)*64..) and w+4 (row 1).  Lane group l>>4 reads 8-frame row
+        // (l>>4)&1 of stage (l>>4)>>1 of the step.
+        w.vo0 = (unsigned)((((((wave >> 1) & 1) * BLKPX) + (wave & 1) * 64 + lane) * 4) * 4);
+        w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
+        w.lbase = (lane >> 5) * G4_STAGE_F + ((lane >> 4) & 1) * 1024 + (lane & 15) * 4;
+    }
     w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
     const int nsmax = (cnt + 3) >> 2;
     if (MODE == 2) { const int lo_ = wave * nsmax; w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0; }   // tiles [wave*nsmax, ...): a contiguous run
@@ -1650,7 +1674,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         CK(hipStreamSynchronize(ctx->stream));
         // ---- B1: Bf tiled ----
         RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
-        const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 3) & ~int64_t(3));
+        const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 7) & ~int64_t(7));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
         RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
         if (g.bf4 == 2) CK(hipMemsetAsync(ctx->rowsum.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
