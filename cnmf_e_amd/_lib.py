@@ -55,6 +55,7 @@ PROTOTYPES = {
     "cnmfe_residual_ssub": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_void_p, C.c_int]),
     "cnmfe_residual": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_void_p, C.c_int]),
     "cnmfe_get_sn": (C.c_int, [c_ctx, C.c_int, f32p]),
+    "cnmfe_traces_bind": (C.c_int, [c_ctx, C.c_int32, C.c_int64, f32p, C.c_int]),
     "cnmfe_update_spatial": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,
                                        i64p, i32p, f32p, C.c_int32, f32p]),
     "cnmfe_fast_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, C.c_int, f32p, f32p]),
@@ -80,7 +81,7 @@ for _name, (_res, _args) in PROTOTYPES.items():
 # enums of include/cnmfe.h
 F32, F64, U16, U8, F16 = 0, 1, 2, 3, 4
 HOST, DEVICE = 0, 1
-COLMAJOR, ROWMAJOR = 0, 1
+COLMAJOR, ROWMAJOR, BOUND = 0, 1, 2
 SPATIAL_HALS, SPATIAL_HALS_THRESH, SPATIAL_NNLS = 0, 1, 2
 
 

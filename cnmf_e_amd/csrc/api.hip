@@ -95,6 +95,13 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
     *ldc_out = ldc;
     RET(dst.ensure(std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
     if (K == 0) return 0;
+    if (order == CNMFE_BOUND) {                            // the matrix bound with cnmfe_traces_bind: a device copy, no PCIe transfer
+        if (!ctx->bound_valid || ctx->bound_K != K || ctx->bound_T != T)
+            return fail(CNMFE_ESTATE, "no bound trace matrix of %d x %lld (cnmfe_traces_bind)", K, (long long)T);
+        CK(hipMemcpyAsync(dst.p, ctx->bound.p, (size_t)K * ldc * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    if (!C) return fail(CNMFE_EINVAL, "null trace matrix");
     CK(hipMemsetAsync(dst.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
     if (order == CNMFE_ROWMAJOR) {
         CK(hipMemcpy2DAsync(dst.p, ldc * sizeof(float), C, T * sizeof(float), T * sizeof(float), K, hipMemcpyHostToDevice, ctx->stream));
@@ -109,6 +116,7 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
 
 int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int32_t K, int64_t T, int order) {
     if (K == 0 || !C) return 0;
+    if (order == CNMFE_BOUND) order = ctx->bound_order;        // outputs of a call on the bound matrix come back in ITS layout
     if (order == CNMFE_ROWMAJOR) {
         CK(hipMemcpy2DAsync(C, T * sizeof(float), dC, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->stream));
     } else {
@@ -465,7 +473,7 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
     if (!(thresh_outlier != thresh_outlier))
         return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 outlier branch is not built)");
     RET(check_csc("A", K, P->d_b, A_colptr, A_rowidx));
-    if (K > 0 && ((!A_val && A_colptr[K] > 0) || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
+    if (K > 0 && ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND))) return fail(CNMFE_EINVAL, "null A_val / C");
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, P));
     int64_t dummy[4];
@@ -481,7 +489,7 @@ int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_
     Patch *P = get_patch(ctx, patch_id);
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
     RET(check_csc("A_prev", Ksel, P->d_b, A_colptr, A_rowidx));
-    if (Ksel > 0 && ((!A_val && A_colptr[Ksel] > 0) || !C)) return fail(CNMFE_EINVAL, "null A_val / C");
+    if (Ksel > 0 && ((!A_val && A_colptr[Ksel] > 0) || (!C && c_order != CNMFE_BOUND))) return fail(CNMFE_EINVAL, "null A_val / C");
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, P));
     return residual_run(ctx, P, patch_id, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);
@@ -508,7 +516,7 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
     RET(check_csc("IND", K, P->d, IND_colptr, IND_rowidx));
-    if (!C || !A_out) return fail(CNMFE_EINVAL, "null C / A_out");
+    if ((!C && c_order != CNMFE_BOUND) || !A_out) return fail(CNMFE_EINVAL, "null C / A_out");
     if (algorithm == CNMFE_SPATIAL_HALS_THRESH && !sn) return fail(CNMFE_EINVAL, "HALS_THRESH needs sn");
     if (param <= 0) return fail(CNMFE_EINVAL, "maxIter/maxN must be positive");
     CK(hipSetDevice(ctx->device));
@@ -524,7 +532,7 @@ int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
-    if ((!A_val && A_colptr[K] > 0) || !C_in) return fail(CNMFE_EINVAL, "null A_val / C_in");   // all-zero columns are legal: aa = 0, row left alone (HALS_temporal.m:51)
+    if ((!A_val && A_colptr[K] > 0) || (!C_in && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C_in");   // all-zero columns are legal: aa = 0, row left alone (HALS_temporal.m:51)
     if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
     CK(hipSetDevice(ctx->device));
     return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, nullptr, nullptr, nullptr, nullptr);
@@ -539,7 +547,7 @@ int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const in
     if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
-    if ((!A_val && A_colptr[K] > 0) || !C_in || !opts || !kernel_pars) return fail(CNMFE_EINVAL, "null A_val / C_in / opts / kernel_pars");
+    if ((!A_val && A_colptr[K] > 0) || (!C_in && c_order != CNMFE_BOUND) || !opts || !kernel_pars) return fail(CNMFE_EINVAL, "null A_val / C_in / opts / kernel_pars");
     if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
     CK(hipSetDevice(ctx->device));
     return temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, C_out, C_raw_out, aa_out, opts, kernel_pars, S_out, sn_out);
@@ -556,6 +564,20 @@ int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if ((!A_val && A_colptr[K] > 0) || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");
     CK(hipSetDevice(ctx->device));
     return fast_temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, c_order, C_raw_out, aa_out);
+}
+
+int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int c_order) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    ctx->bound_valid = false;
+    if (K == 0 || !C) return 0;                            // unbind
+    if (K < 0 || T <= 0) return fail(CNMFE_EINVAL, "bad K / T");
+    if (c_order != CNMFE_ROWMAJOR && c_order != CNMFE_COLMAJOR) return fail(CNMFE_EINVAL, "bad c_order");
+    CK(hipSetDevice(ctx->device));
+    int64_t ldc;
+    RET(upload_traces(ctx, ctx->bound, C, K, T, c_order, &ldc));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = c_order; ctx->bound_valid = true;
+    return 0;
 }
 
 int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,

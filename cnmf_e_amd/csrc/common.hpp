@@ -130,6 +130,8 @@ struct cnmfe_ctx {
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)
     cnmfe::DevBuf ysig;       // d x T fp32 (frame-major) of the patch last passed to cnmfe_residual
+    cnmfe::DevBuf bound;      // trace matrix bound with cnmfe_traces_bind (K x ldc fp32), passed as c_order = CNMFE_BOUND
+    int32_t bound_K = 0; int64_t bound_T = 0; int bound_order = 1; bool bound_valid = false;
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
     int ysig_patch = -1;

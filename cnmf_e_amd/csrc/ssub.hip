@@ -416,7 +416,7 @@ int cnmfe_fit_ring_model_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int r
     if (!F->ring_ready || !R->ring_ready || !M->ring_ready) return fail(CNMFE_ESTATE, "rings not initialised");
     if (thresh_outlier == thresh_outlier) return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 is not built)");
     if (K < 0) return fail(CNMFE_EINVAL, "K=%d", K);
-    if (K > 0) { RET(check_csc_pub("A", K, M->d_b, A_colptr, A_rowidx)); if ((!A_val && A_colptr[K] > 0) || !C) return fail(CNMFE_EINVAL, "null A_val / C"); }
+    if (K > 0) { RET(check_csc_pub("A", K, M->d_b, A_colptr, A_rowidx)); if ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C"); }
     CK(hipSetDevice(ctx->device));
     return ssub_fit(ctx, M, F, R, ssub, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, info);
 }
@@ -428,7 +428,7 @@ int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssu
     if (!M || !R) return fail(CNMFE_ESTATE, "patch %d / %d not created", patch_id, res_patch);
     if (!M->ring_ready || !R->ring_ready) return fail(CNMFE_ESTATE, "rings not initialised");
     if (Ksel < 0) return fail(CNMFE_EINVAL, "Ksel=%d", Ksel);
-    if (Ksel > 0) { RET(check_csc_pub("A_prev", Ksel, M->d_b, A_colptr, A_rowidx)); if ((!A_val && A_colptr[Ksel] > 0) || !C) return fail(CNMFE_EINVAL, "null A_val / C"); }
+    if (Ksel > 0) { RET(check_csc_pub("A_prev", Ksel, M->d_b, A_colptr, A_rowidx)); if ((!A_val && A_colptr[Ksel] > 0) || (!C && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C"); }
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, M));
     return ssub_residual(ctx, M, patch_id, R, res_patch, ssub, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);

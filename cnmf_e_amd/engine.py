@@ -42,6 +42,27 @@ def _traces(Cm, K, T):
 
 
 class Engine:
+    # -- bound traces: obj.C is the same matrix for several calls of one iteration; bind_traces uploads it once and every
+    # call that is handed THAT array object afterwards passes (NULL, CNMFE_BOUND).  The array must not be mutated in place
+    # while it is bound (Sources2D replaces C, it never writes into it).
+    def bind_traces(self, Cm):
+        Cm = None if Cm is None or Cm.shape[0] == 0 else Cm
+        if Cm is None or Cm.dtype != np.float32 or not Cm.flags["C_CONTIGUOUS"]:
+            self._bound = None
+            L.check(L.lib.cnmfe_traces_bind(self._ctx, 0, 0, None, L.ROWMAJOR))
+            return
+        L.check(L.lib.cnmfe_traces_bind(self._ctx, Cm.shape[0], Cm.shape[1], _p(Cm, L.f32p), L.ROWMAJOR))
+        self._bound = Cm
+
+    def _targs(self, Cm, K, T):
+        """(pointer, c_order, keep-alive) for a K x T trace argument"""
+        if K == 0 or Cm is None:
+            return None, L.ROWMAJOR, None
+        if Cm is getattr(self, "_bound", None) and Cm.shape == (K, T):
+            return None, L.BOUND, None
+        a = _traces(Cm, K, T)
+        return _p(a, L.f32p), L.ROWMAJOR, a
+
     def __init__(self, device: int = 0):
         self._ctx = L.lib.cnmfe_create(int(device))
         if not self._ctx:
@@ -121,11 +142,11 @@ class Engine:
         """[W, b0] = fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection); W stays resident."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_block, info["d_b"]) if A_block is not None else (0, None, None, None)
-        Cm = _traces(C_block, K, info["T"]) if K else None
+        cptr, cord, _keep = self._targs(C_block, K, info["T"])
         b0 = np.empty(info["d"], dtype=np.float32) if want_b0 else None
         inf = np.zeros(4, dtype=np.int64)
-        L.check(L.lib.cnmfe_fit_ring_model(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p),
-                                           L.ROWMAJOR, float(thresh_outlier), int(bool(with_projection)), _p(b0, L.f32p), _p(inf, L.i64p)))
+        L.check(L.lib.cnmfe_fit_ring_model(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr,
+                                           cord, float(thresh_outlier), int(bool(with_projection)), _p(b0, L.f32p), _p(inf, L.i64p)))
         return b0, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
 
     # -- bg_ssub > 1 ---------------------------------------------------------------------------------------------
@@ -139,20 +160,20 @@ class Engine:
     def fit_ring_model_ssub(self, pid, fit_pid, res_pid, ssub, A_block, C_block, thresh_outlier=float("nan"), with_projection=True):
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_block, info["d_b"]) if A_block is not None else (0, None, None, None)
-        Cm = _traces(C_block, K, info["T"]) if K else None
+        cptr, cord, _keep = self._targs(C_block, K, info["T"])
         inf = np.zeros(4, dtype=np.int64)
         L.check(L.lib.cnmfe_fit_ring_model_ssub(self._ctx, pid, fit_pid, res_pid, int(ssub), K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p),
-                                                _p(Cm, L.f32p), L.ROWMAJOR, float(thresh_outlier), int(bool(with_projection)), _p(inf, L.i64p)))
+                                                cptr, cord, float(thresh_outlier), int(bool(with_projection)), _p(inf, L.i64p)))
         return None, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
 
     def residual_ssub(self, pid, res_pid, ssub, A_prev_block=None, C_prev=None, want=False):
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_prev_block, info["d_b"]) if A_prev_block is not None and A_prev_block.shape[1] else (0, None, None, None)
-        Cm = _traces(C_prev, K, info["T"]) if K else None
+        cptr, cord, _keep = self._targs(C_prev, K, info["T"])
         out = np.empty((info["T"], info["d"]), dtype=np.float32) if want else None
         dst = out.ctypes.data_as(C.c_void_p) if want else C.c_void_p(None)
-        L.check(L.lib.cnmfe_residual_ssub(self._ctx, pid, res_pid, int(ssub), K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p),
-                                          L.ROWMAJOR, dst, L.HOST))
+        L.check(L.lib.cnmfe_residual_ssub(self._ctx, pid, res_pid, int(ssub), K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr,
+                                          cord, dst, L.HOST))
         return out
 
     def residual(self, pid, A_prev_block=None, C_prev=None, want=False, out_dev_ptr=None):
@@ -160,13 +181,13 @@ class Engine:
         receives a device-to-device copy instead."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_prev_block, info["d_b"]) if A_prev_block is not None and A_prev_block.shape[1] else (0, None, None, None)
-        Cm = _traces(C_prev, K, info["T"]) if K else None
+        cptr, cord, _keep = self._targs(C_prev, K, info["T"])
         out = np.empty((info["T"], info["d"]), dtype=np.float32) if want else None
         if out_dev_ptr is not None:
             dst, space = C.c_void_p(int(out_dev_ptr)), L.DEVICE
         else:
             dst, space = (out.ctypes.data_as(C.c_void_p) if want else C.c_void_p(None)), L.HOST
-        L.check(L.lib.cnmfe_residual(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR, dst, space))
+        L.check(L.lib.cnmfe_residual(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord, dst, space))
         return out
 
     def get_sn(self, pid):
@@ -185,19 +206,23 @@ class Engine:
         K2, icp, iri, _ = _csc(IND, info["d"])
         if K2 != K:
             raise ValueError("A and IND disagree on K")
-        Cm = _traces(C_patch, K, info["T"])
+        cptr, cord, _keep = self._targs(C_patch, K, info["T"])
         snf = np.ascontiguousarray(sn, dtype=np.float32).ravel() if sn is not None else None
         out = np.zeros(icp[-1], dtype=np.float32)
-        L.check(L.lib.cnmfe_update_spatial(self._ctx, pid, alg, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+        L.check(L.lib.cnmfe_update_spatial(self._ctx, pid, alg, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                            _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), _p(out, L.f32p)))
         return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
 
-    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5):
+    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True):
+        """[C, C_raw] = HALS_temporal(Ysig, A, C, maxIter); want_C=False skips the download of C (the caller of
+        update_temporal_parallel.m:180 only keeps C_raw)."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_patch, info["d"])
-        Cm = _traces(C_patch, K, info["T"])
-        Cout = np.empty_like(Cm); Craw = np.empty_like(Cm); aa = np.empty(K, dtype=np.float32)
-        L.check(L.lib.cnmfe_hals_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+        T = info["T"]
+        cptr, cord, _keep = self._targs(C_patch, K, T)
+        Cout = np.empty((K, T), dtype=np.float32) if want_C else None
+        Craw = np.empty((K, T), dtype=np.float32); aa = np.empty(K, dtype=np.float32)
+        L.check(L.lib.cnmfe_hals_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                           int(maxIter), _p(Cout, L.f32p), _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Cout, Craw, aa
 

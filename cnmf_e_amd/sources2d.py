@@ -217,6 +217,7 @@ class Sources2D:
         self.P = {"sn": np.asarray(sn, dtype=np.float32).reshape(-1).copy(), "Ymean": {}}
         self._b0_new_val = None; self._b0_new_src = None
         self.dist = dist_group
+        self._bind_C()
         self.ssub = int(options.bg_ssub)
         npatch = len(video.order)
         # bg_ssub > 1: every patch gets two low-resolution companions on the device (cnmfe.h, cnmfe_patch_derive)
@@ -236,6 +237,16 @@ class Sources2D:
     # -- accessors ------------------------------------------------------------------
     def get_W(self, idx):
         return self.engine.ring_csr(self.video.pid[idx] if self.ssub == 1 else self.pid_fit[idx])
+
+    @staticmethod
+    def _rows(Cm, ind):
+        """Cm(ind, :) -- the matrix itself when ind is every row (so that a bound trace matrix is recognised by identity)"""
+        return Cm if ind.size == Cm.shape[0] else Cm[ind]
+
+    def _bind_C(self):
+        """one upload of obj.C per iteration instead of one per engine call (cnmfe_traces_bind)"""
+        if hasattr(self.engine, "bind_traces"):
+            self.engine.bind_traces(self.C)
 
     def _residual(self, idx, A_prev_b, C_prev_b):
         """the background-subtraction expression of update_spatial_parallel.m:162-178 / update_temporal_parallel.m:149-165"""
@@ -365,7 +376,7 @@ class Sources2D:
             Ab = A_csr[bp]
             ind = np.asarray(Ab.sum(axis=0)).ravel() > 0                   # :128
             A_block = Ab[:, ind].tocsc()                                   # :129
-            C_block = self.C[ind]                                          # :130
+            C_block = self._rows(self.C, np.nonzero(ind)[0])               # :130
             self._prev_blocks[idx] = (np.nonzero(ind)[0], A_block)
             # "stop updating B because A&C doesn't change in this area" (:188-199) is decided by the engine's
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
@@ -434,7 +445,7 @@ class Sources2D:
             else:
                 indp = np.zeros(0, dtype=np.int64)
             A_prev_b = Aprev_csr[bp][:, indp].tocsc() if indp.size else None                        # :97
-            C_prev_b = self.C_prev[indp] if indp.size else None                                     # :98
+            C_prev_b = self._rows(self.C_prev, indp) if indp.size else None                         # :98
             launched = IND_csr is None
             if launched:
                 # the residual sweep (:162-166) does not depend on the search mask: start it (the call returns with
@@ -456,7 +467,7 @@ class Sources2D:
                 continue                                                                             # :196-199
             A_patch = A_csr[pp][:, ind].tocsc()                                                     # :88,199
             IND_patch = INDp[:, ind].tocsc()                                                        # :89
-            C_patch = self.C[ind]                                                                   # :91
+            C_patch = self._rows(self.C, ind)                                                       # :91
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
             Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                               sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
@@ -548,7 +559,7 @@ class Sources2D:
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
-            C_prev_b = self.C_prev[indp] if indp.size else None
+            C_prev_b = self._rows(self.C_prev, indp) if indp.size else None
             launched = A_csr is None
             if launched:
                 # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
@@ -560,14 +571,14 @@ class Sources2D:
                 continue                                                                              # :123
             if not launched:
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)          # :149-152
-            C_patch = self.C[ind]                                                                    # :86
+            C_patch = self._rows(self.C, ind)                                                        # :86
             A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175
                 C_raw_p, aa_p = self.engine.fast_temporal(v.pid[idx], A_pp)
             elif o.deconv_flag:                                                                       # :106-110
                 _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)
             else:
-                _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter)   # :180-181
+                _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False)   # :180-181
             if sharded:
                 pieces.append((ind, C_raw_p, aa_p))                        # scattered and weighted on the collective's device
                 continue
@@ -590,9 +601,11 @@ class Sources2D:
         if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.deconvTemporal()
+            self._bind_C()
         else:
             if not sharded:
                 C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285 (sharded: done on the device)
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.C_raw                                                                       # :286
+            self._bind_C()
         self._update_b0_new()                                                                         # :291-295

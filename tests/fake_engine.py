@@ -76,7 +76,7 @@ class FakeEngine:
         aa, C_raw = orc.fast_temporal(self.p[pid]["Ysig"], sp.csc_matrix(A_patch).astype(np.float64))
         return C_raw, aa
 
-    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5):
+    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True):
         A = sp.csc_matrix(A_patch).astype(np.float64)
         C, C_raw, _ = orc.HALS_temporal(self.p[pid]["Ysig"], A, C_patch, maxIter, None)
         return C, C_raw, np.asarray(A.multiply(A).sum(axis=0)).ravel()

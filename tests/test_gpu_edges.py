@@ -151,3 +151,34 @@ def test_deconvolution_rejects_unsupported_lengths(eng):
         eng.deconv_temporal(np.zeros((2, 32), np.float32), dict(type="ar1", method="foopsi"))       # T < 64
     with pytest.raises((L.CnmfeError, NotImplementedError, ValueError)):
         eng.deconv_temporal(np.zeros((2, 128), np.float32), dict(type="ar2", method="foopsi"))     # only AR(1) is built
+
+
+def test_bound_traces_equal_uploaded_traces(eng):
+    """cnmfe_traces_bind: (NULL, CNMFE_BOUND) must behave exactly like passing the matrix; a stale or mismatching binding is an error"""
+    from cnmf_e_amd import _lib as L
+    d1, d2, T, r = 36, 32, 96, 5
+    f, Y, video = _video(eng, d1, d2, T, 4, r, 8)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.bind_traces(None)
+    eng.fit_ring_model(0, A, Cm); W_plain = eng.ring_csr(0).data.copy()
+    y_plain = eng.residual(0, A, Cm, want=True)
+    c_plain = eng.hals_temporal(0, A, Cm, 3)
+    eng.ring_init(0, r)
+    eng.bind_traces(Cm)                                     # from here on `Cm` (this very object) goes as (NULL, CNMFE_BOUND)
+    eng.fit_ring_model(0, A, Cm); W_bound = eng.ring_csr(0).data.copy()
+    y_bound = eng.residual(0, A, Cm, want=True)
+    c_bound = eng.hals_temporal(0, A, Cm, 3)
+    assert np.array_equal(W_plain, W_bound) and np.array_equal(y_plain, y_bound)
+    for a, b in zip(c_plain, c_bound):
+        assert np.array_equal(a, b)
+    c_copy = eng.hals_temporal(0, A, Cm.copy(), 3)          # an equal but different array object is simply uploaded
+    assert np.array_equal(c_copy[1], c_plain[1])
+    with pytest.raises(L.CnmfeError):                       # BOUND with a K that does not match the bound matrix
+        L.check(L.lib.cnmfe_residual(eng._ctx, 0, 2, np.array([0, 1, 2], np.int64).ctypes.data_as(L.i64p), np.array([3, 5], np.int32).ctypes.data_as(L.i32p),
+                                     np.ones(2, np.float32).ctypes.data_as(L.f32p), None, L.BOUND, None, L.HOST))
+    eng.bind_traces(None)
+    with pytest.raises(L.CnmfeError):                       # nothing bound any more
+        L.check(L.lib.cnmfe_residual(eng._ctx, 0, 2, np.array([0, 1, 2], np.int64).ctypes.data_as(L.i64p), np.array([3, 5], np.int32).ctypes.data_as(L.i32p),
+                                     np.ones(2, np.float32).ctypes.data_as(L.f32p), None, L.BOUND, None, L.HOST))
