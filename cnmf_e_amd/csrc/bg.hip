@@ -13,6 +13,7 @@
 // Every ring pair of every patch pixel lies within +-2 blocks, so B2a computes each needed
 // covariance exactly once (symmetric pairs once) instead of once per centre pixel.
 #include "common.hpp"
+#include <type_traits>
 
 namespace cnmfe {
 
@@ -392,8 +393,8 @@ constexpr int G4_NBUF = 4, G4_STAGE_F = 2 * GK * 128, G4_MAXSLOT = 16;
 
 struct G4Wave {                       // per-wave constants of a work item (all wave-uniform except lbase, vo0, vo1)
     const float *gA, *gB;
-    unsigned vo0, vo1, dA0;
-    int lbase, nst, flush_every, ns, lane;
+    unsigned vo0, vo1, vo2, dA0;
+    int lbase, lbaseB, nst, flush_every, ns, lane;
     double *out;                      // cov + pair*256*256 + (ih*128)*256 + jh*128
 };
 
@@ -523,80 +524,107 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
 // l>>4 takes quad-row l>>4 of BOTH stages (8 frames); A and B fragments are built identically, so the pairing of frames inside
 // the instruction's k index is irrelevant.  4 ds_read_b128 + 4 MFMAs per tile and 32 frames.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-template <int NS>
+struct G4Frag { float4 ah, al, bh, bl; };                             // hi / lo planes of the A and B fragments of one tile (4 x ds_read_b128)
+// LDS stage geometry (floats) and the DMA of one 16-frame stage, for the two work-item shapes of the split-bf16 mode:
+// G4Quad: 4 waves, item = (block pair, 128x128 quadrant): stage = [A half: e(2) x plane(2) x 128 px][B half: same] x 16 B = 16 KB
+// G4Half: 8 waves, item = (block pair, 128-row half): stage = [A half: e(2) x plane(2) x 128 px][B block: e(2) x plane(2) x 256 px] = 24 KB.
+//         The B stream is shared by both column halves: 768 instead of 1024 pixel-streams per pair cross the fabric (the kernel is bound
+//         by that traffic: 385 GB at 7.7 TB/s per launch with quadrant items at the headline size)
+struct G4Quad {
+    static constexpr int STAGE_F = G4_STAGE_F, APL = 512, BPL = 512, WAVES = 4, LIST = 64, NBUF = 4, DEPTH = 1, NDMA = 4;   // DEPTH steps in flight
+    static __device__ __forceinline__ void issue(const G4Wave &w, int sc, unsigned d) {
+        const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
+        glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
+        glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
+    }
+};
+struct G4Half {
+    static constexpr int STAGE_F = 6144, APL = 512, BPL = 1024, WAVES = 8, LIST = 128, NBUF = 6, DEPTH = 2, NDMA = 3;
+    static __device__ __forceinline__ void issue(const G4Wave &w, int sc, unsigned d) {
+        const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
+        glds16(sa, w.vo0, d); glds16(sb, w.vo1, d + 8192u); glds16(sb, w.vo2, d + 16384u);
+    }
+};
+template <class CFG, int NS>
 __device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem, const int *__restrict__ tlw) {
+    // The non-MFMA VALU work per MFMA decides this loop (PMC: 2.9 VALU instructions per MFMA saturated the issue port at 40 % matrix-pipe
+    // utilisation), so the body is branch-free straight-line code: every slot loads its own four fragments into one of two NAMED register sets
+    // (compile-time ping-pong, no copies), slots past `ns` of the last wave recompute tile 0 and are never stored (the workgroup waits for its
+    // busiest wave anyway), and steps go in pairs: the first product of a pair starts from the inline constant 0 and the pair's sum is folded
+    // into the fp64 shadows (cvt + add, nothing to clear).  64 frames per fold: W error vs the fp64 mode 9e-5 (128 frames: 2e-4).
     int ao[NS], bo[NS], ti[NS], tj[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-        const int code = __builtin_amdgcn_readfirstlane(sl < w.ns ? tlw[sl] : 0);   // this wave owns a CONTIGUOUS run of the (row-major) tile list
+        const int code = __builtin_amdgcn_readfirstlane(tlw[sl < w.ns ? sl : 0]);   // this wave owns a CONTIGUOUS run of the (row-major) tile list
         ti[sl] = code & 7; tj[sl] = code >> 4;
-        ao[sl] = ti[sl] * 64; bo[sl] = GK * 128 + tj[sl] * 64;
+        ao[sl] = ti[sl] * 64; bo[sl] = tj[sl] * 64;
     }
     const bool probe_nomem = (w.flush_every >> 16) & 1;
-    auto issue2 = [&](int step) {                                   // stages 2*step, 2*step+1 -> buffers (2*step)&3, (2*step+1)&3
+    int ib = 0, cb = 0;                                             // stage buffer (even) the next issue fills / the current step reads: both rotate 0, 2, .. NBUF-2
+    auto issue2 = [&](int step) {                                   // stages 2*step, 2*step+1 -> buffers ib, ib+1
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int st = 2 * step + h;
             int sc = st < w.nst ? st : w.nst - 1;
             if (probe_nomem) sc = 0;
-            const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
-            const unsigned d = w.dA0 + (unsigned)(st & (G4_NBUF - 1)) * (G4_STAGE_F * 4u);
-            glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
-            glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
+            CFG::issue(w, sc, w.dA0 + (unsigned)(ib + h) * (CFG::STAGE_F * 4u));
         }
+        ib = ib + 2 == CFG::NBUF ? 0 : ib + 2;
     };
     double4_t acc[NS];
     float4_t facc[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) { acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
-    const int nstep = w.nst >> 1;                                   // Tpad is a multiple of 32 in this mode
-    const int flush_steps = max(1, (w.flush_every & 0xffff) >> 1);
-    issue2(0);
-    int since = 0;
-    for (int step = 0; step < nstep; ++step) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's part of both stages has landed
+    const int nstep = w.nst >> 1;                                   // Tpad is a multiple of 64 in this mode: nstep is even
+    auto ld = [&](const float *lpa, const float *lpb, int sl) {
+        G4Frag f;
+        f.ah = *reinterpret_cast<const float4 *>(lpa + ao[sl]); f.al = *reinterpret_cast<const float4 *>(lpa + ao[sl] + CFG::APL);
+        f.bh = *reinterpret_cast<const float4 *>(lpb + bo[sl]); f.bl = *reinterpret_cast<const float4 *>(lpb + bo[sl] + CFG::BPL);
+        return f;
+    };
+    auto mm = [&](const G4Frag &f, float4_t c0, auto first) {
+        union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
+        ah.v = f.ah; al.v = f.al; bh.v = f.bh; bl.v = f.bl;
+        float4_t c;
+        if constexpr (decltype(first)::value) c = (float4_t){0.f, 0.f, 0.f, 0.f}; else c = c0;
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, c, 0, 0, 0);      // smallest products first (without lo*lo: 47 vs 51 ms, W error 6.6e-4 vs 9.4e-5)
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, c, 0, 0, 0);
+    };
+    auto body = [&](int step, auto first) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * CFG::NDMA * (CFG::DEPTH - 1)) : "memory");   // this wave's part of both stages has landed (younger steps may still fly)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue2(step + 1);
-        int lb = w.lbase;
-        asm volatile("" : "+v"(lb));
+        issue2(step + CFG::DEPTH);
+        int lb = w.lbase, lbB = w.lbaseB;
+        asm volatile("" : "+v"(lb), "+v"(lbB));
         // the two stages of a step sit in adjacent buffers ((2*step)&3 is 0 or 2); lane group l>>4 owns one of their four 8-frame
         // rows, whose hi and lo planes ARE the K=32 operands: every fragment is one ds_read_b128, no register shuffling
-        const float *lp = smem + ((2 * step) & (G4_NBUF - 1)) * G4_STAGE_F + lb;
-        // fragment registers of the slot in flight (x) and the next one (n).  Consecutive slots of a wave mostly share the tile row,
-        // i.e. the A fragment: it is re-read from LDS only when the row changes (a wave-uniform branch per slot).
-        float4 xah, xal, xbh, xbl, nah, nal, nbh, nbl;
-        xah = *reinterpret_cast<const float4 *>(lp + ao[0]); xal = *reinterpret_cast<const float4 *>(lp + ao[0] + 512);
-        xbh = *reinterpret_cast<const float4 *>(lp + bo[0]); xbl = *reinterpret_cast<const float4 *>(lp + bo[0] + 512);
-        nah = xah; nal = xal; nbh = xbh; nbl = xbl;
+        const float *lp = smem + cb * CFG::STAGE_F + lb, *lpb = smem + cb * CFG::STAGE_F + lbB;
+        cb = cb + 2 == CFG::NBUF ? 0 : cb + 2;
+        G4Frag x = ld(lp, lpb, 0), y = x;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (sl + 1 < NS) {
-                if (ao[sl + 1] != ao[sl]) { nah = *reinterpret_cast<const float4 *>(lp + ao[sl + 1]); nal = *reinterpret_cast<const float4 *>(lp + ao[sl + 1] + 512); }
-                else { nah = xah; nal = xal; }
-                nbh = *reinterpret_cast<const float4 *>(lp + bo[sl + 1]); nbl = *reinterpret_cast<const float4 *>(lp + bo[sl + 1] + 512);
-            }
+        for (int sl = 0; sl < NS; sl += 2) {
+            if (sl + 1 < NS) y = ld(lp, lpb, sl + 1);
             asm volatile("" ::: "memory");
-            if (sl < w.ns) {
-                union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
-                ah.v = xah; al.v = xal; bh.v = xbh; bl.v = xbl;
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, facc[sl], 0, 0, 0);      // smallest products first
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, facc[sl], 0, 0, 0);
-                facc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, facc[sl], 0, 0, 0);
-            }
-            xah = nah; xal = nal; xbh = nbh; xbl = nbl;
-        }
-        if (++since == flush_steps || step + 1 == nstep) {           // fold the fp32 partial sums into the fp64 shadows
-            since = 0;
-#pragma unroll
-            for (int sl = 0; sl < NS; ++sl) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[sl][r] += (double)facc[sl][r];
-                facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f};
-            }
+            facc[sl] = mm(x, facc[sl], first);
+            if (sl + 2 < NS) x = ld(lp, lpb, sl + 2);
+            asm volatile("" ::: "memory");
+            if (sl + 1 < NS) facc[sl + 1] = mm(y, facc[sl + 1], first);
         }
         asm volatile("" ::: "memory");
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < CFG::DEPTH; ++s0) issue2(s0);
+    for (int step = 0; step < nstep; step += 2) {
+        body(step, std::true_type{});
+        body(step + 1, std::false_type{});
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {                           // fold the 64-frame fp32 sums into the fp64 shadows
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[sl][r] += (double)facc[sl][r];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int fl = w.lane & 15;
@@ -637,25 +665,68 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
     w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
     w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
     w.lbase = (lane >> 4) * 512 + (lane & 15) * 4;                     // quad-row l>>4, pixel l&15 of the tile, 4 frames
-    if (MODE == 2) {
+    if (MODE >= 2) {
         // split-bf16 layout: a 16-frame stage of a half is [8-frame row e][plane hi/lo][128 px] x 16 B = 8 instructions of 1 KB;
         // wave w moves instruction w (row 0: plane (w>>1)&1, pixels (w&1)*64..) and w+4 (row 1).  Lane group l>>4 reads 8-frame row
         // (l>>4)&1 of stage (l>>4)>>1 of the step.
         w.vo0 = (unsigned)((((((wave >> 1) & 1) * BLKPX) + (wave & 1) * 64 + lane) * 4) * 4);
         w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
         w.lbase = (lane >> 5) * G4_STAGE_F + ((lane >> 4) & 1) * 1024 + (lane & 15) * 4;
+        w.lbaseB = w.lbase + GK * 128;
     }
     w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
     const int nsmax = (cnt + 3) >> 2;
-    if (MODE == 2) { const int lo_ = wave * nsmax; w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0; }   // tiles [wave*nsmax, ...): a contiguous run
+    if (MODE >= 2) { const int lo_ = wave * nsmax; w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0; }   // tiles [wave*nsmax, ...): a contiguous run
     else w.ns = cnt > wave ? (cnt - wave + 3) >> 2 : 0;                // tiles wave, wave+4, ...
     w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX + jh * 128;
-    const int *tlw = MODE == 2 ? tl + lidx * 64 + wave * nsmax : tl + lidx * 64 + wave;
+    const int *tlw = MODE >= 2 ? tl + lidx * 64 + wave * nsmax : tl + lidx * 64 + wave;
     switch ((cnt + 3) >> 2) {                                          // slots of the busiest wave; the others skip the last one
-#define G4_CASE(N) case N: if (MODE == 2) gram4_run_k32<N>(w, smem, tlw); else gram4_run<MODE == 2 ? 1 : MODE, N>(w, smem, tlw); break;
+#define G4_CASE(N) case N: if (MODE == 2) gram4_run_k32<G4Quad, N>(w, smem, tlw); else gram4_run<MODE >= 2 ? 1 : MODE, N>(w, smem, tlw); break;
         G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
         G4_CASE(9) G4_CASE(10) G4_CASE(11) G4_CASE(12) G4_CASE(13) G4_CASE(14) G4_CASE(15) G4_CASE(16)
 #undef G4_CASE
+        default: break;
+    }
+}
+
+// split-bf16 Gram over (block pair, 128-row half) items: 8 waves, one workgroup per CU (96 KB of stage buffers)
+__global__ void __launch_bounds__(512) k_gram5(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
+                                               const int *__restrict__ work, int nwork, const int *__restrict__ tl_cnt,
+                                               const int *__restrict__ tl, int flush_every, double *__restrict__ cov) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    if (bid >= nwork) return;
+    const int wk = work[bid];
+    const int pair = wk >> 1, ih = wk & 1;
+    const int4 pr = pairs[pair];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lidx = pr.z * 2 + ih;
+    const int cnt = __builtin_amdgcn_readfirstlane(tl_cnt[lidx]);
+    G4Wave w;
+    w.gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 512;
+    w.gB = bf + ((int64_t)pr.y * Tpad) * BLKPX;
+    // DMA of a 16-frame stage = 24 wave-instructions of 1 KB: A piece `wave` = (8-frame row wave>>2, plane (wave>>1)&1, 64-px group wave&1);
+    // B pieces `wave` and `wave + 8` = (row 0 / 1, plane wave>>2, group wave&3).  LDS destinations are piece-linear.
+    w.vo0 = (unsigned)((((wave >> 2) * 2 + ((wave >> 1) & 1)) * BLKPX + (wave & 1) * 64 + lane) * 16);
+    w.vo1 = (unsigned)(((wave >> 2) * BLKPX + (wave & 3) * 64 + lane) * 16);
+    w.vo2 = w.vo1 + 2u * BLKPX * 16u;
+    w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
+    w.lbase = (lane >> 5) * G4Half::STAGE_F + ((lane >> 4) & 1) * 1024 + (lane & 15) * 4;
+    w.lbaseB = (lane >> 5) * G4Half::STAGE_F + 2048 + ((lane >> 4) & 1) * 2048 + (lane & 15) * 4;
+    w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
+    const int nsmax = (cnt + 7) >> 3;
+    const int lo_ = wave * nsmax;
+    w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0;      // tiles [wave*nsmax, ...): a contiguous run of the row-major list
+    w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX;
+    const int *tlw = tl + lidx * G4Half::LIST + (w.ns ? lo_ : 0);
+    switch (nsmax) {
+#define G5_CASE(N) case N: gram4_run_k32<G4Half, N>(w, smem, tlw); break;
+        G5_CASE(1) G5_CASE(2) G5_CASE(3) G5_CASE(4) G5_CASE(5) G5_CASE(6) G5_CASE(7) G5_CASE(8)
+        G5_CASE(9) G5_CASE(10) G5_CASE(11) G5_CASE(12) G5_CASE(13) G5_CASE(14) G5_CASE(15) G5_CASE(16)
+#undef G5_CASE
         default: break;
     }
 }
@@ -1555,8 +1626,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
     g.d = P->d; g.d_b = P->d_b; g.T = T; g.kstride = kstride;
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
-    g.bf4 = ctx->opt("gram_kernel", 4) == 4 ? (ctx->opt("gram_mode", 3) == 3 ? 2 : 1) : 0;
-    g.Tpad = g.bf4 == 2 ? (g.Tp + 2 * GK - 1) / (2 * GK) * (2 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: steps of two stages
+    g.bf4 = ctx->opt("gram_kernel", 4) >= 4 ? (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1) : 0;      // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
+    g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
     g.p_radius = 0;
     for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
     g.nbw = ((2 * g.p_radius) >> 4) + 2;
@@ -1635,8 +1706,15 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // work order: pair-major (the 13 displacement classes of one I block are consecutive), so heavy and light
         // quadrants are mixed in time.  (Measured: class-major order, which makes concurrent workgroups equal-cost,
         // was slower -- 150 vs 131 ms at 512x512x10000 -- and did not raise the L2 hit rate.)
+        const bool half_items = g.bf4 == 2 && ctx->opt("gram_kernel", 4) == 5 && ctx->opt("gram_mode", 3) == 3;      // (pair, row half) items on k_gram5
         std::vector<int> work;
-        for (int pp = 0; pp < npairs; ++pp)
+        for (int pp = 0; pp < npairs && half_items; ++pp)
+            for (int ih = 0; ih < 2; ++ih) {
+                bool any = false;
+                for (int pi = ih * 8; pi < ih * 8 + 8; ++pi) if (needmask[pairs[pp].z * 16 + pi]) any = true;
+                if (any) work.push_back(pp * 2 + ih);
+            }
+        for (int pp = 0; pp < npairs && !half_items; ++pp)
             for (int q = 0; q < 4; ++q) {
                 const int ih = q & 1, jh = q >> 1;
                 bool any = false;
@@ -1654,7 +1732,20 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         int nwg = (nwork + 7) / 8 * 8;                      // multiple of 8 for the XCD remap (extra workgroups exit)
         const bool f32s = ctx->opt("gram_mode", 3) >= 2;
         DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
-        if (g.bf4) {
+        if (half_items) {
+            // tile lists per (displacement class, row half): i | j << 4 with i < 8 (rows of the half), j < 16
+            std::vector<int> tcnt(NREL * 2, 0);
+            std::vector<int> tlist((size_t)NREL * 2 * G4Half::LIST, 0);
+            for (int rel = 0; rel < NREL; ++rel)
+                for (int ih = 0; ih < 2; ++ih) {
+                    int n = 0;
+                    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j)
+                        if ((needmask[rel * 16 + ih * 8 + i] >> j) & 1) tlist[(size_t)(rel * 2 + ih) * G4Half::LIST + n++] = i | (j << 4);
+                    tcnt[rel * 2 + ih] = n;
+                }
+            RET(to_dev(ctx, dTcnt, tcnt.data(), tcnt.size()));
+            RET(to_dev(ctx, dTl, tlist.data(), tlist.size()));
+        } else if (g.bf4) {
             // tile lists per (displacement class, quadrant): needed 16x16 sub-tiles as i | j << 4 (quadrant coordinates)
             std::vector<int> tcnt(NREL * 4, 0);
             std::vector<int> tlist((size_t)NREL * 4 * 64, 0);
@@ -1693,7 +1784,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 attr4 = true;
             }
             const int flushw = (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16);
-            if (g.bf4 == 2)
+            if (half_items) {
+                const size_t shmem5 = (size_t)G4Half::NBUF * G4Half::STAGE_F * sizeof(float);
+                static bool attr5 = false;
+                if (!attr5) { CK(hipFuncSetAttribute((const void *)k_gram5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem5)); attr5 = true; }
+                LAUNCH(ctx, "bg_gram_bf16x4", k_gram5, dim3(nwg), dim3(512), shmem5, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
+            } else if (g.bf4 == 2)
                 LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
             else if (f32s)
