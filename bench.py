@@ -167,7 +167,7 @@ def main():
                 "algorithmic_flops_per_launch": flops_alg,
                 "note": "algorithmic = 2*d*(p+1)^2*T/2 of the reference's per-pixel Gram (SURVEY 8(d)); the engine's "
                         "block-sparse SYRK executes fewer flops (see DESIGN.md), so frac may exceed the pipe utilisation"}
-    def pmc_traffic(kernel_substr):
+    def pmc_traffic(kernel_substr, exclude=None):
         """HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of THIS command (profiles/<round>/
         *_pmc_FETCH_SIZE_*.csv, *_pmc_WRITE_SIZE_*.csv; separate passes, scripts/profile_round.sh).  FETCH_SIZE is
         doubled: gfx950 reports 16-B/lane coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM section; calibrated
@@ -180,7 +180,7 @@ def main():
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_c3_pmc_%s_v*.csv" % counter)))
             if not files:
                 return None
-            rows = [r_ for r_ in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")) if kernel_substr in r_["kernel"]]
+            rows = [r_ for r_ in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")) if kernel_substr in r_["kernel"] and not (exclude and exclude in r_["kernel"])]
             if not rows:
                 return None
             tot += mult * 1024.0 * sum(float(r_["value_per_launch_KiB"]) for r_ in rows) / len(rows)
@@ -206,9 +206,15 @@ def main():
         roof["traffic"] = pmc_traffic("k_gram")
     r1r = r1_roof()
     if r1r is not None:
-        r1r["traffic"] = pmc_traffic("k_residual")
+        r1r["traffic"] = pmc_traffic("k_residual", exclude="k_residual_delta")
         if roof.get("kernel") == "residual_r1":
             roof["traffic"] = r1r["traffic"]
+    dlr = None
+    if "residual_delta" in kern and a.bg_ssub == 1:             # the iteration's second residual: resident Ysig + footprint-term difference, one streaming pass
+        ms = kern["residual_delta"]["ms_per_call"]
+        by = 2 * 4.0 * d * T + 4.0 * Kp * T
+        dlr = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
+               "traffic": pmc_traffic("k_residual_delta"), "kernel": "residual_delta", "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     out = {
         "metric": "cnmfe_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -219,6 +225,7 @@ def main():
                    "parallelism": "patch-parallel x%d" % world},
         "roofline": roof,
         "roofline_r1": r1r,
+        "roofline_r1_delta": dlr,
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "kernel_calls_per_step": {k: round(v["calls_per_step"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] > 0.5},
     }

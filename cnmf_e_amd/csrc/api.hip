@@ -236,7 +236,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "debug", nullptr};
+    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "r1_delta", "r1_probe", "debug", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -305,7 +305,6 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     CK(hipStreamSynchronize(ctx->stream));
     P->frames_uploaded += nt;
     P->ymean_valid = false; P->ysig_valid = false;
-    if (ctx->ysig_patch == patch_id) ctx->ysig_patch = -1;
     return 0;
 }
 
@@ -479,7 +478,6 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
     int64_t dummy[4];
     int rc = bg_fit_ring(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, b0_out, info ? info : dummy);
     P->ysig_valid = false;
-    if (ctx->ysig_patch == patch_id) ctx->ysig_patch = -1;
     return rc;
 }
 
@@ -499,7 +497,7 @@ int cnmfe_get_sn(cnmfe_ctx *ctx, int patch_id, float *sn_out) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
-    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (!sn_out) return fail(CNMFE_EINVAL, "null sn_out");
     CK(hipSetDevice(ctx->device));
     return sn_pixels_run(ctx, P, sn_out);
@@ -511,7 +509,7 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
-    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (algorithm < CNMFE_SPATIAL_HALS || algorithm > CNMFE_SPATIAL_NNLS) return fail(CNMFE_EINVAL, "unknown spatial algorithm %d", algorithm);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
@@ -529,7 +527,7 @@ int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
-    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
     if ((!A_val && A_colptr[K] > 0) || (!C_in && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C_in");   // all-zero columns are legal: aa = 0, row left alone (HALS_temporal.m:51)
@@ -544,7 +542,7 @@ int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const in
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
-    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
     if ((!A_val && A_colptr[K] > 0) || (!C_in && c_order != CNMFE_BOUND) || !opts || !kernel_pars) return fail(CNMFE_EINVAL, "null A_val / C_in / opts / kernel_pars");
@@ -558,7 +556,7 @@ int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
-    if (ctx->ysig_patch != patch_id || !P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
     if ((!A_val && A_colptr[K] > 0) || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");

@@ -38,6 +38,7 @@ struct DevBuf {
         cap = want; return 0;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); }
 };
 
 // ---- per-kernel event timing ---------------------------------------------------
@@ -118,7 +119,13 @@ struct Patch {
     DevBuf W;                          // p x d fp32, offset-major; 0 where the neighbour is outside the FOV
     DevBuf b0;                         // d fp64 (kept in double on the device; the ABI converts)
     bool ring_ready = false;
+    // the background-subtracted video of this patch, Ysig4[ceil(T/4)][d] float4, as left by the last cnmfe_residual; valid until the
+    // video, W or b0 change.  It stays resident per patch: a further cnmfe_residual under the same W, b0 differs from it only by the
+    // footprint term (W*A)(C - mean C), whose applied instance is kept beside it (ELL rows + centred traces) -- see residual_run
+    DevBuf ysig;
     bool ysig_valid = false;
+    bool res_ac = false, res_plain = false; int64_t res_ldc = 0;   // res_plain: Ysig came from cnmfe_residual itself (not the bg_ssub path)
+    DevBuf resCnt, resK, resV, resCc;
 };
 
 }  // namespace cnmfe
@@ -129,12 +136,10 @@ struct cnmfe_ctx {
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)
-    cnmfe::DevBuf ysig;       // d x T fp32 (frame-major) of the patch last passed to cnmfe_residual
     cnmfe::DevBuf bound;      // trace matrix bound with cnmfe_traces_bind (K x ldc fp32), passed as c_order = CNMFE_BOUND
     int32_t bound_K = 0; int64_t bound_T = 0; int bound_order = 1; bool bound_valid = false;
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
-    int ysig_patch = -1;
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
     cnmfe::DevBuf rowsum;     // [blk][256] double

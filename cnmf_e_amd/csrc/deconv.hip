@@ -434,7 +434,7 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     DevBuf &dSn = ctx->tmp[14];
     RET(dSn.ensure((size_t)P->d * sizeof(float)));
-    LAUNCH(ctx, "spatial_sn_pixels", k_sn_pixels, dim3((unsigned)P->d), dim3(256), shmem, c, ctx->ysig.as<float4>(), P->d, dSn.as<float>());
+    LAUNCH(ctx, "spatial_sn_pixels", k_sn_pixels, dim3((unsigned)P->d), dim3(256), shmem, c, P->ysig.as<float4>(), P->d, dSn.as<float>());
     CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     return 0;

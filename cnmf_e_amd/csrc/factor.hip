@@ -381,7 +381,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     const int64_t tchunk = ((T + nparts - 1) / nparts + 3) & ~int64_t(3);
     RET(dPart.ensure((size_t)nparts * nnz * sizeof(float)));
     RET(dU.ensure((size_t)nnz * sizeof(float)));
-    LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, ctx->ysig.as<float4>(), d, T,
+    LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, P->ysig.as<float4>(), d, T,
            dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
     LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
     // S2 on the co-occurrence pairs
@@ -454,7 +454,7 @@ int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colp
     const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
     const int64_t tchunk = (Tc + nchunk - 1) / nchunk;
     if (nnz > 0)
-        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, ctx->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
+        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
     LAUNCH(ctx, "temporal_scale_rows", k_scale_rows, dim3((unsigned)((T + 255) / 256), (unsigned)K), dim3(256), 0, dU.as<float>(), ldc, T, dInv.as<float>());
     RET(download_traces(ctx, dU.as<float>(), ldc, C_raw_out, K, T, c_order));
@@ -483,7 +483,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
     const int64_t tchunk = (Tc + nchunk - 1) / nchunk;                                              // in 4-frame groups
     if (nnz > 0)
-        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, ctx->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
+        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
     // T2: overlap graph + V values (neighbour lists include k itself: V(k,k) = aa(k))
     HostCSR csr; csc_to_csr(d, K, A_colptr, A_rowidx, A_val, csr);

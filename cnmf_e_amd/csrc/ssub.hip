@@ -351,7 +351,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     CK(hipStreamSynchronize(ctx->stream));                    // the tap vectors die with this call
     const int64_t ntmp = (int64_t)d1s * M->nc_b;
     RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));
-    RET(ctx->ysig.ensure((size_t)M->d * M->Tc * sizeof(float4)));
+    RET(M->ysig.ensure((size_t)M->d * M->Tc * sizeof(float4)));
     RET(dDlt.ensure(M->d * sizeof(float)));
     LAUNCH(ctx, "r1_dlt", k_dlt2, dim3((unsigned)((M->d + 255) / 256)), dim3(256), 0, M->ymean_f.as<float>(), M->b0.as<double>(), dDlt.as<float>(),
            M->d, M->nr, M->nr_b, M->roff, M->coff);
@@ -377,18 +377,18 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
         nseg = (M->Tc + cseg - 1) / cseg;
         LAUNCH(ctx, "ssub_up_fused", k_up_fused, dim3((unsigned)ntile, (unsigned)nseg), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(), d1s, R->d_b,
                M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->nc, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(),
-               dIc.as<int>(), dWc.as<float>(), ntr, M->Tc, cseg, ctx->ysig.as<float4>());
-        ctx->ysig_patch = pid; M->ysig_valid = true;
-        if (Ysig_out) RET(ysig_export(ctx, M, ctx->ysig, Ysig_out, out_memspace));
+               dIc.as<int>(), dWc.as<float>(), ntr, M->Tc, cseg, M->ysig.as<float4>());
+        M->ysig_valid = true; M->res_plain = false;
+        if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
         return 0;
     }
     LAUNCH(ctx, "ssub_up_cols", k_up_cols, dim3((unsigned)((ntmp + 255) / 256), (unsigned)M->Tc), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(),
            d1s, R->d_b, ctx->up_tmp.as<float4>(), M->nc_b, dIc.as<int>(), dWc.as<float>(), tc.P);
     LAUNCH(ctx, "ssub_up_rows_combine", k_up_rows_combine, dim3((unsigned)((M->d + 255) / 256), (unsigned)M->Tc), dim3(256), 0, ctx->up_tmp.as<float4>(), d1s,
            M->nc_b, M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(), tr.P,
-           ctx->ysig.as<float4>());
-    ctx->ysig_patch = pid; M->ysig_valid = true;
-    if (Ysig_out) RET(ysig_export(ctx, M, ctx->ysig, Ysig_out, out_memspace));
+           M->ysig.as<float4>());
+    M->ysig_valid = true; M->res_plain = false;
+    if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
     return 0;
 }
 

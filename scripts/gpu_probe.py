@@ -40,7 +40,7 @@ def main():
     del Yd
     torch.cuda.empty_cache()
     s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=5, deconv_flag=a.deconv), f.A_init, f.C_init, f.sn)
-    eng.profile(True)
+    eng.profile(True); eng.set_option("r1_delta", 0)   # variant timings: always the full ring sweep
     # R1 variant sweep (spatial-call flavour: no A_prev; temporal-call flavour: all neurons)
     bytes_r1 = 4.0 * d1 * d2 * T * 2
     A_b = f.A_init.astype(np.float32)
@@ -55,7 +55,7 @@ def main():
             key = "residual_r1" if "residual_r1" in tab and tab["residual_r1"]["calls"] else "residual_r1_generic"
             ms = tab[key]["total_ms"] / max(1, tab[key]["calls"])
             print("R1 variant %2d %-4s: %8.3f ms  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (v, flavour, ms, bytes_r1 / ms / 1e6, bytes_r1 / ms / 1e6 / 80), flush=True)
-    eng.set_option("r1_variant", 10)
+    eng.set_option("r1_variant", 11); eng.set_option("r1_delta", 1)
     for it in range(a.iters):
         eng.profile_reset()
         torch.cuda.synchronize(); t0 = time.time()

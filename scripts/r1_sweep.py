@@ -25,7 +25,7 @@ for v in [int(x) for x in a.variants.split(",")]:
         eng.set_option("r1_variant", v); eng.set_option("tile_order", o)
         for ac in ([False, True] if a.ac else [False]):
             eng.residual(0, A_b if ac else None, f.C_init if ac else None)
-            eng.profile(True); eng.profile_reset()
+            eng.profile(True); eng.profile_reset(); eng.set_option("r1_delta", 0)   # variant timings: always the full ring sweep
             for _ in range(a.reps):
                 eng.residual(0, A_b if ac else None, f.C_init if ac else None)
             tab = eng.profile_table()

@@ -182,3 +182,42 @@ def test_bound_traces_equal_uploaded_traces(eng):
     with pytest.raises(L.CnmfeError):                       # nothing bound any more
         L.check(L.lib.cnmfe_residual(eng._ctx, 0, 2, np.array([0, 1, 2], np.int64).ctypes.data_as(L.i64p), np.array([3, 5], np.int32).ctypes.data_as(L.i32p),
                                      np.ones(2, np.float32).ctypes.data_as(L.f32p), None, L.BOUND, None, L.HOST))
+
+
+def test_incremental_residual_equals_full_sweep(eng):
+    """A second cnmfe_residual under the same W, b0 is the resident Ysig plus the difference of two footprint terms (r1_delta, default on):
+    every transition (none -> A, A -> A', A -> none, none -> none) must agree with the full ring sweep, and a change of W or b0 must
+    force the sweep"""
+    d1, d2, T, r = 44, 40, 96, 5
+    f, Y, video = _video(eng, d1, d2, T, 6, r, 9)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.fit_ring_model(0, A, Cm)
+    sel = [np.arange(0), np.arange(6), np.array([1, 4]), np.arange(0), np.arange(0), np.array([0, 2, 3, 5])]
+    def run(delta):
+        eng.set_option("r1_delta", delta)
+        eng.set_b0(0, eng.b0(0))                        # invalidates the resident Ysig: the first call is a full sweep
+        out = []
+        for s in sel:
+            out.append(eng.residual(0, A[:, s] if len(s) else None, Cm[s] if len(s) else None, want=True))
+        return out
+    try:
+        full, inc = run(0), run(1)
+        tab = None
+        scale = max(np.abs(x).max() for x in full)
+        for a, b in zip(full, inc):
+            assert np.abs(a - b).max() <= 2e-6 * scale
+        eng.profile(True); eng.profile_reset()
+        eng.residual(0, A, Cm)                              # delta (A' -> A)
+        eng.fit_ring_model(0, A, Cm); eng.set_b0(0, eng.b0(0))      # new W, b0 (b0 rounded to fp32 so that the round trip below is exact)
+        eng.residual(0, A[:, :3], Cm[:3])                   # must be a sweep
+        tab = eng.profile_table(); eng.profile(False)
+        assert tab["residual_delta"]["calls"] == 1
+        assert sum(v["calls"] for k, v in tab.items() if k.startswith("residual_r1")) == 1
+        y_after = eng.residual(0, A[:, :3], Cm[:3], want=True)
+        eng.set_option("r1_delta", 0); eng.set_b0(0, eng.b0(0))
+        y_ref = eng.residual(0, A[:, :3], Cm[:3], want=True)
+        assert np.abs(y_after - y_ref).max() <= 2e-6 * scale
+    finally:
+        eng.set_option("r1_delta", 1)
