@@ -366,18 +366,22 @@ class Sources2D:
         """@Sources2D/update_background_parallel.m:121-146,176-230,311-317 (ring model, bg_ssub = 1)."""
         self._need_data()
         v, o = self.video, self.options
-        A_csr = self.A.tocsr()
+        # the block slices of the current A: prepared by the temporal update under its GPU work when A has not changed since
+        cached = getattr(self, "_cur_blocks_src", None) is self.A
+        A_csr = self._cur_csr if cached else self.A.tocsr()
         infos = {}
         prefetched = False
         self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update
         self._prev_blocks = {}                                             # (ind, A_block) per patch: what the temporal update's residual needs
         for idx in v.owned:
-            bp = v.block_pix[idx]
-            Ab = A_csr[bp]
-            ind = np.asarray(Ab.sum(axis=0)).ravel() > 0                   # :128
-            A_block = Ab[:, ind].tocsc()                                   # :129
-            C_block = self._rows(self.C, np.nonzero(ind)[0])               # :130
-            self._prev_blocks[idx] = (np.nonzero(ind)[0], A_block)
+            if cached and idx in self._cur_blocks:
+                ind_nz, A_block = self._cur_blocks[idx]
+            else:
+                Ab = A_csr[v.block_pix[idx]]
+                ind_nz = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]   # :128
+                A_block = Ab[:, ind_nz].tocsc()                            # :129
+            C_block = self._rows(self.C, ind_nz)                           # :130
+            self._prev_blocks[idx] = (ind_nz, A_block)
             # "stop updating B because A&C doesn't change in this area" (:188-199) is decided by the engine's
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
             if A_block.shape[1] == 0 and not self._first_run(idx):
@@ -556,6 +560,7 @@ class Sources2D:
         aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
         sharded = self.dist is not None and v.world_size > 1
         pieces = []
+        single = None
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
@@ -565,8 +570,11 @@ class Sources2D:
                 # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)
                 A_csr = self.A.tocsr()
+                self._cur_csr, self._cur_blocks, self._cur_blocks_src = A_csr, {}, self.A
             Ab = A_csr[bp]
             ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                              # :83
+            # the next background update fits against this same A (update_background_parallel.m:128-130): slice it now, under the sweep
+            self._cur_blocks[idx] = (ind, Ab[:, ind].tocsc())
             if ind.size == 0:
                 continue                                                                              # :123
             if not launched:
@@ -582,6 +590,12 @@ class Sources2D:
             if sharded:
                 pieces.append((ind, C_raw_p, aa_p))                        # scattered and weighted on the collective's device
                 continue
+            if len(v.owned) == 1 and ind.size == K and use_c_hat and not o.deconv_flag:
+                # one patch sees every neuron: aa.*C_raw./aa (:274-280) is C_raw itself, rows with aa = 0 are zero, and HALS_temporal
+                # already subtracted each row's minimum (HALS_temporal.m:64-68), so :285 changes nothing
+                C_raw_p[aa_p == 0] = 0
+                single = C_raw_p
+                continue
             contrib = C_raw_p * aa_p[:, None].astype(np.float32)                                     # :274
             if acc is None and ind.size == K:
                 acc = contrib                                              # first patch sees every neuron: no scatter-add needed
@@ -592,6 +606,8 @@ class Sources2D:
             aa_tot[ind] += aa_p                                                                      # :275
         if sharded:                                                        # the overlap-region stitch: ONE all-reduce
             C_raw = self._stitch_distributed(pieces, K, T)
+        elif single is not None:
+            C_raw = single
         else:
             if acc is None:
                 acc = np.zeros((K, T), dtype=np.float32)
@@ -603,7 +619,7 @@ class Sources2D:
             self.C = self.deconvTemporal()
             self._bind_C()
         else:
-            if not sharded:
+            if not sharded and single is None:
                 C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285 (sharded: done on the device)
             self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.C_raw                                                                       # :286

@@ -1,0 +1,47 @@
+"""Host-side timeline of one iteration at the headline size: time inside every Engine call and the Python time between calls.
+python scripts/host_timeline.py [--iters 3]"""
+import argparse, os, sys, time, functools
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1)
+a = ap.parse_args()
+import torch
+from cnmf_e_amd import synth
+from cnmf_e_amd.engine import Engine
+from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+d1, d2, T, K, r, seed = 512, 512, 10000, 500, 15, 2
+f = synth.make_factors(d1, d2, T, K, seed)
+Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
+eng = Engine(0)
+video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
+log = []
+import threading
+main = threading.get_ident()
+for name in dir(Engine):
+    fn = getattr(Engine, name)
+    if name.startswith("_") or not callable(fn): continue
+    def wrap(fn, name):
+        @functools.wraps(fn)
+        def w(*x, **k):
+            t0 = time.perf_counter(); r_ = fn(*x, **k); t1 = time.perf_counter()
+            log.append((name, t0, t1, threading.get_ident() == main)); return r_
+        return w
+    setattr(Engine, name, wrap(fn, name))
+s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub), f.A_init, f.C_init, f.sn)
+marks = []
+for it in range(a.iters):
+    torch.cuda.synchronize(); del log[:]; t0 = time.perf_counter()
+    s.update_background_parallel(); tb = time.perf_counter()
+    s.update_spatial_parallel(); ts = time.perf_counter()
+    s.update_temporal_parallel(); tt = time.perf_counter()
+    torch.cuda.synchronize(); te = time.perf_counter()
+    print("iteration %d: %.1f ms" % (it, (te - t0) * 1e3), flush=True)
+print("last iteration: bg %.1f  spatial %.1f  temporal %.1f  drain %.1f  total %.1f ms" % ((tb - t0) * 1e3, (ts - tb) * 1e3, (tt - ts) * 1e3, (te - tt) * 1e3, (te - t0) * 1e3))
+prev = t0
+for name, a0, a1, on_main in log:
+    if not on_main:
+        print("      [thread] %-22s %.2f ms (at %.1f)" % (name, (a1 - a0) * 1e3, (a0 - t0) * 1e3)); continue
+    print("%7.2f ms python | %-22s %7.2f ms in call (at %.1f)" % ((a0 - prev) * 1e3, name, (a1 - a0) * 1e3, (a0 - t0) * 1e3)); prev = a1
+print("%7.2f ms python tail" % ((tt - prev) * 1e3))
