@@ -731,6 +731,167 @@ __global__ void __launch_bounds__(512) k_gram5(const float *__restrict__ bf, int
     }
 }
 
+// ---- B2a', incremental: Cov(Bf) from the covariance of the VIDEO ------------------------------------------------
+// Bf = Yc - A Cc (fit_ring_model.m:45-47), so  sum_t Bf_i Bf_j = sum_t Yc_i Yc_j - sum_k A_jk U~_ik - sum_k A_ik U~_jk  with
+// U~_ik = sum_t (Yc_i - 1/2 sum_l A_il Cc_l)(t) Cc_k(t)   (the 1/2 shares the A G A' term between the two sums; G = Cc Cc').
+// The first term does not depend on A, C: it is computed ONCE per patch and frame stride on the fp64 matrix pipe (the block-sparse
+// SYRK above on Yc alone) and kept; every later fit only needs U~ for pixels within two 16x16 blocks of a footprint -- per block a
+// (256 px) x (footprints near it, <= 64) x T' GEMM on the fp64 pipe, 0.1-0.2 TFLOP instead of 9.6 -- and one sweep over the table.
+// Everything is fp64 (exact fp32 products, fp64 sums): the difference of the two large terms keeps ~1e-13 relative accuracy.
+constexpr int WIN_NLB = 64;
+
+// csum[k] = sum over the used frames of Cc_k  (the ones-row of X: rowsum(Bf) = rowsum(Yc) - A csum)
+__global__ void __launch_bounds__(256) k_trace_subsum(const float *__restrict__ Cc, int64_t ldc, int64_t Tp, int kstride, double *__restrict__ csum) {
+    const float *row = Cc + (int64_t)blockIdx.x * ldc;
+    __shared__ double red[256];
+    double s = 0;
+    for (int64_t tp = threadIdx.x; tp < Tp; tp += 256) s += (double)row[tp * kstride];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) csum[blockIdx.x] = red[0];
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, const int *__restrict__ arow, const int *__restrict__ acol,
+                                                  const float *__restrict__ aval, const float *__restrict__ Cc, int64_t ldc, int K, const int *__restrict__ lst_ptr,
+                                                  const int *__restrict__ lst_k, const short *__restrict__ slot_of, const int *__restrict__ blk_list, double *__restrict__ Ut) {
+    __shared__ __attribute__((aligned(16))) double Z[2][BLKPX][4];
+    __shared__ __attribute__((aligned(16))) float4 TR[2][NT * 16];
+    const int blk = blk_list[blockIdx.x];
+    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+    const int bi = blk % g.nbr, bj = blk / g.nbr;
+    const int tid = threadIdx.x, lp = tid;
+    const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
+    const int rb = bi * BLK + lr, cb = bj * BLK + lc;
+    const bool in = rb < g.nr_b && cb < g.nc_b;
+    const int64_t q = in ? (int64_t)cb * g.nr_b + rb : 0;
+    int e0 = 0, e1 = 0;
+    if (in) { e0 = arow[q]; e1 = arow[q + 1]; }
+    int sl[4]; float ha[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        sl[u] = 0; ha[u] = 0.f;
+        if (e0 + u < e1) { sl[u] = slot_of[(int64_t)blk * K + acol[e0 + u]]; ha[u] = 0.5f * aval[e0 + u]; }
+    }
+    const int kk = (tid < NT * 16 && tid < nl) ? lst_k[l0 + tid] : -1;
+    const float *Ys = reinterpret_cast<const float *>(Y4);
+    auto loadY = [&](int64_t c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!in) return v;
+        if (g.kstride == 1) { if (c < Tc) v = Y4[c * g.d_b + q]; return v; }
+        float *pv = &v.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t tp = 4 * c + u; if (tp < g.Tp) { const int64_t t = tp * g.kstride; pv[u] = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)]; } }
+        return v;
+    };
+    auto loadT = [&](int64_t c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < 0) return v;
+        const float *row = Cc + (int64_t)kk * ldc;
+        if (g.kstride == 1) return *reinterpret_cast<const float4 *>(row + 4 * c);        // rows are zero-padded to ldc
+        float *pv = &v.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t tp = 4 * c + u; if (tp < g.Tp) pv[u] = row[tp * g.kstride]; }
+        return v;
+    };
+    const int64_t nchunk = (g.Tp + 3) >> 2;
+    double4_t acc[4][NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, kq = lane >> 4;
+    float4 yv = loadY(0), tv = loadT(0);
+    for (int64_t c = 0; c < nchunk; ++c) {
+        const int buf = (int)(c & 1);
+        if (tid < NT * 16) TR[buf][tid] = tv;
+        __syncthreads();                                     // traces of chunk c in place (and nobody is still reading this buffer: barrier B of c-1)
+        double z0 = yv.x, z1 = yv.y, z2 = yv.z, z3 = yv.w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 t = TR[buf][sl[u]];
+            const double h = ha[u];
+            z0 -= h * (double)t.x; z1 -= h * (double)t.y; z2 -= h * (double)t.z; z3 -= h * (double)t.w;
+        }
+        for (int e = e0 + 4; e < e1; ++e) {
+            const float4 t = TR[buf][slot_of[(int64_t)blk * K + acol[e]]];
+            const double h = 0.5 * (double)aval[e];
+            z0 -= h * (double)t.x; z1 -= h * (double)t.y; z2 -= h * (double)t.z; z3 -= h * (double)t.w;
+        }
+        Z[buf][lp][0] = z0; Z[buf][lp][1] = z1; Z[buf][lp][2] = z2; Z[buf][lp][3] = z3;
+        if (c + 1 < nchunk) { yv = loadY(c + 1); tv = loadT(c + 1); }
+        __syncthreads();                                     // Z of chunk c in place
+        double bv[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = (double)reinterpret_cast<const float *>(&TR[buf][b * 16 + fi])[kq];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double av = Z[buf][(wave * 4 + a) * 16 + fi][kq];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D layout (fp64 16x16): row = (lane>>4) + 4r, col = lane&15
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int slot = b * 16 + fi;
+            if (slot < nl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ut[(int64_t)(l0 + slot) * BLKPX + (wave * 4 + a) * 16 + kq + 4 * r] = acc[a][b][r];
+        }
+}
+
+// cov(pair)(i,j) = base(pair)(i,j) - sum_{k at j} A_jk U~_a(k, i) - sum_{k at i} A_ik U~_b(k, j)  over the needed 16x16 sub-tiles
+__global__ void __launch_bounds__(256) k_cov_correct(const double *__restrict__ base, double *__restrict__ cov, const int4 *__restrict__ pairs,
+                                                     const unsigned short *__restrict__ needmask, BgGeom g, int K, const int *__restrict__ arow,
+                                                     const int *__restrict__ acol, const float *__restrict__ aval, const int *__restrict__ lst_ptr,
+                                                     const short *__restrict__ slot_of, const double *__restrict__ Ut) {
+    const int pair = blockIdx.x;
+    const int4 pr = pairs[pair];
+    const int ba = pr.x, bb = pr.y, rel = pr.z;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int la = lst_ptr[ba], lb = lst_ptr[bb];
+    auto pix = [&](int blk, int lp, int &e0, int &e1) {
+        const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
+        const int rb = (blk % g.nbr) * BLK + lr, cb = (blk / g.nbr) * BLK + lc;
+        e0 = e1 = 0;
+        if (rb < g.nr_b && cb < g.nc_b) { const int64_t q = (int64_t)cb * g.nr_b + rb; e0 = arow[q]; e1 = arow[q + 1]; }
+    };
+    const double *bp = base + (int64_t)pair * BLKPX * BLKPX;
+    double *cp = cov + (int64_t)pair * BLKPX * BLKPX;
+    for (int pi = 0; pi < 16; ++pi) {
+        const unsigned mask = needmask[rel * 16 + pi];
+        if (!mask) continue;
+        const int ilp = pi * 16 + ty;
+        int ei0, ei1; pix(ba, ilp, ei0, ei1);
+        for (int pj = 0; pj < 16; ++pj) {
+            if (!((mask >> pj) & 1u)) continue;
+            const int jlp = pj * 16 + tx;
+            int ej0, ej1; pix(bb, jlp, ej0, ej1);
+            const int idx = ilp * BLKPX + jlp;
+            double v = bp[idx];
+            for (int e = ej0; e < ej1; ++e) v -= (double)aval[e] * Ut[(int64_t)(la + slot_of[(int64_t)ba * K + acol[e]]) * BLKPX + ilp];
+            for (int e = ei0; e < ei1; ++e) v -= (double)aval[e] * Ut[(int64_t)(lb + slot_of[(int64_t)bb * K + acol[e]]) * BLKPX + jlp];
+            cp[idx] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rowsum_correct(const double *__restrict__ base, double *__restrict__ rs, BgGeom g, const int *__restrict__ arow,
+                                                        const int *__restrict__ acol, const float *__restrict__ aval, const double *__restrict__ csum) {
+    const int blk = blockIdx.x, lp = threadIdx.x;
+    const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
+    const int rb = (blk % g.nbr) * BLK + lr, cb = (blk / g.nbr) * BLK + lc;
+    double v = base[(int64_t)blk * BLKPX + lp];
+    if (rb < g.nr_b && cb < g.nc_b) {
+        const int64_t q = (int64_t)cb * g.nr_b + rb;
+        for (int e = arow[q]; e < arow[q + 1]; ++e) v -= (double)aval[e] * csum[acol[e]];
+    }
+    rs[(int64_t)blk * BLKPX + lp] = v;
+}
+
 // ---- helpers on the covariance table ----------------------------------------------------------------
 struct CovTab {
     const double *cov; const int *pair_of;   // pair_of[blk*NREL + rel] or -1
@@ -1626,7 +1787,42 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
     g.d = P->d; g.d_b = P->d_b; g.T = T; g.kstride = kstride;
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
-    g.bf4 = ctx->opt("gram_kernel", 4) >= 4 ? (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1) : 0;      // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
+    g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
+    // ---- incremental Gram (k_win_proj / k_cov_correct above): per 16x16 block, the footprints with a pixel within two blocks of it ----
+    bool incr = ctx->opt("gram_incremental", 1) != 0 && ctx->opt("gram_kernel", 4) >= 4 && !(b0_only & 2) && !P->derived && K < 32768;
+    std::vector<int> lst_ptr, lst_k, blk_nt[4];
+    std::vector<short> slot_of;
+    if (incr) {
+        const int nblk_ = g.nbr * g.nbc;
+        std::vector<std::vector<int>> bl(nblk_);
+        std::vector<int> own(nblk_, -1), seen(nblk_, -1), mark;
+        for (int k = 0; k < K && has_a; ++k) {
+            mark.clear();
+            for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
+                const int q = A_rowidx[e], b_ = ((q / P->nr_b) >> 4) * g.nbr + ((q % P->nr_b) >> 4);
+                if (own[b_] != k) { own[b_] = k; mark.push_back(b_); }
+            }
+            for (int b_ : mark)
+                for (int dj = -2; dj <= 2; ++dj)
+                    for (int di = -2; di <= 2; ++di) {
+                        const int i2 = b_ % g.nbr + di, j2 = b_ / g.nbr + dj;
+                        if (i2 < 0 || i2 >= g.nbr || j2 < 0 || j2 >= g.nbc) continue;
+                        const int nb_ = j2 * g.nbr + i2;
+                        if (seen[nb_] != k) { seen[nb_] = k; bl[nb_].push_back(k); }
+                    }
+        }
+        lst_ptr.assign(nblk_ + 1, 0);
+        slot_of.assign((size_t)nblk_ * std::max(1, K), (short)-1);
+        for (int b_ = 0; b_ < nblk_ && incr; ++b_) {
+            const int n = (int)bl[b_].size();
+            if (n > WIN_NLB) { incr = false; break; }                       // denser than the window kernel is built for: direct Gram
+            lst_ptr[b_ + 1] = lst_ptr[b_] + n;
+            for (int s_ = 0; s_ < n; ++s_) { lst_k.push_back(bl[b_][s_]); slot_of[(size_t)b_ * K + bl[b_][s_]] = (short)s_; }
+            if (n) blk_nt[(n - 1) >> 4].push_back(b_);
+        }
+    }
+    const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
+    g.bf4 = incr ? 1 : (ctx->opt("gram_kernel", 4) >= 4 ? (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1) : 0);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
     g.p_radius = 0;
     for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
@@ -1730,7 +1926,6 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(ctx->cov.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
         if (ctx->opt("debug", 0)) CK(hipMemsetAsync(ctx->cov.p, 0xff, (size_t)npairs * BLKPX * BLKPX * sizeof(double), ctx->stream));   // NaN-poison skipped sub-tiles
         int nwg = (nwork + 7) / 8 * 8;                      // multiple of 8 for the XCD remap (extra workgroups exit)
-        const bool f32s = ctx->opt("gram_mode", 3) >= 2;
         DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
         if (half_items) {
             // tile lists per (displacement class, row half): i | j << 4 with i < 8 (rows of the half), j < 16
@@ -1763,16 +1958,25 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // every host-side staging vector of this call has been consumed once the stream drains here -- and nothing heavy is queued
         // yet: the three big launches below go out back to back, and without an output request the call returns with them in flight
         CK(hipStreamSynchronize(ctx->stream));
+        // incremental: the table of the video alone is built once (fp64 pipe) and kept with the patch; later fits skip B1 / B2a entirely
+        DevBuf &covT = incr ? P->cov_base : ctx->cov, &rsT = incr ? P->rowsum_base : ctx->rowsum;
+        const bool f32s = !incr && ctx->opt("gram_mode", 3) >= 2;
+        const bool has_a_bf = has_a && !incr;
+        if (incr) {
+            RET(P->cov_base.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
+            if (build_base && ctx->opt("debug", 0)) CK(hipMemsetAsync(P->cov_base.p, 0xff, (size_t)npairs * BLKPX * BLKPX * sizeof(double), ctx->stream));
+        }
+        if (!incr || build_base) {
         // ---- B1: Bf tiled ----
         RET(ctx->bf.ensure((size_t)nblk * g.Tpad * BLKPX * sizeof(float)));
         const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 7) & ~int64_t(7));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
-        RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        if (g.bf4 == 2) CK(hipMemsetAsync(ctx->rowsum.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
+        RET(rsT.ensure((size_t)nblk * BLKPX * sizeof(double)));
+        if (g.bf4 == 2) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
-               has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, ctx->rowsum.as<double>());
+               has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());
         if (g.bf4 != 2)
-            LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, ctx->rowsum.as<double>(), g.bf4);
+            LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, rsT.as<double>(), g.bf4);
 
         if (g.bf4) {
             const size_t shmem = (size_t)G4_NBUF * G4_STAGE_F * sizeof(float);
@@ -1789,16 +1993,16 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 static bool attr5 = false;
                 if (!attr5) { CK(hipFuncSetAttribute((const void *)k_gram5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem5)); attr5 = true; }
                 LAUNCH(ctx, "bg_gram_bf16x4", k_gram5, dim3(nwg), dim3(512), shmem5, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
+                       dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
             } else if (g.bf4 == 2)
                 LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
+                       dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
             else if (f32s)
                 LAUNCH(ctx, "bg_gram_f32s", k_gram4<1>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), flushw, ctx->cov.as<double>());
+                       dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
             else
                 LAUNCH(ctx, "bg_gram_f64", k_gram4<0>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), 0, ctx->cov.as<double>());
+                       dTcnt.as<int>(), dTl.as<int>(), 0, covT.as<double>());
         } else if (ctx->opt("gram_kernel", 4) == 3) {
             const size_t shmem = (size_t)GR_NBUF * GR_STAGE_F * sizeof(float);
             static bool attr_set = false;
@@ -1809,16 +2013,47 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
             if (f32s)
                 LAUNCH(ctx, "bg_gram_f32s", k_gram3<true>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16), ctx->cov.as<double>());
+                       dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16), covT.as<double>());
             else
                 LAUNCH(ctx, "bg_gram_f64", k_gram3<false>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dNeed.as<unsigned short>(), 0, ctx->cov.as<double>());
+                       dNeed.as<unsigned short>(), 0, covT.as<double>());
         } else if (f32s)
             LAUNCH(ctx, "bg_gram_f32s", k_gram2<true>, dim3(nwg), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                   dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4), ctx->cov.as<double>());
+                   dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4), covT.as<double>());
         else
             LAUNCH(ctx, "bg_gram_f64", k_gram2<false>, dim3(nwg), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                   dNeed.as<unsigned short>(), 0, ctx->cov.as<double>());
+                   dNeed.as<unsigned short>(), 0, covT.as<double>());
+        if (incr) { P->base_valid = true; P->base_kstride = kstride; }
+        }
+        if (incr) {
+            // ---- B2a': U~ on the blocks near footprints, then one sweep base -> cov ----
+            DevBuf &dLp = ctx->inc[0], &dLk = ctx->inc[1], &dSlot = ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5];
+            RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
+            if (has_a) {
+                std::vector<int> blall; int off_nt[5] = {0, 0, 0, 0, 0};
+                for (int t = 0; t < 4; ++t) { blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end()); off_nt[t + 1] = (int)blall.size(); }
+                RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
+                RET(to_dev(ctx, dLk, lst_k.data(), lst_k.size()));
+                RET(to_dev(ctx, dSlot, slot_of.data(), slot_of.size()));
+                RET(to_dev(ctx, dBl, blall.data(), blall.size()));
+                RET(dUt.ensure(std::max<size_t>(1, lst_k.size()) * BLKPX * sizeof(double)));
+                RET(dCsum.ensure((size_t)K * sizeof(double)));
+                CK(hipStreamSynchronize(ctx->stream));                 // the staging vectors above die with this scope
+                LAUNCH(ctx, "bg_trace_subsum", k_trace_subsum, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, g.Tp, g.kstride, dCsum.as<double>());
+#define WIN_LAUNCH(NT) if (off_nt[NT] > off_nt[NT - 1]) LAUNCH(ctx, "bg_win_proj", (k_win_proj<NT>), dim3((unsigned)(off_nt[NT] - off_nt[NT - 1])), dim3(256), 0, \
+                    P->Yc4.as<float4>(), P->Tc, g, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, (int)K, dLp.as<int>(), dLk.as<int>(), \
+                    dSlot.as<short>(), dBl.as<int>() + off_nt[NT - 1], dUt.as<double>())
+                WIN_LAUNCH(4); WIN_LAUNCH(3); WIN_LAUNCH(2); WIN_LAUNCH(1);
+#undef WIN_LAUNCH
+                LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
+                       dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
+                LAUNCH(ctx, "bg_rowsum_correct", k_rowsum_correct, dim3(nblk), dim3(256), 0, P->rowsum_base.as<double>(), ctx->rowsum.as<double>(), g,
+                       dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dCsum.as<double>());
+            } else {                                                   // no footprints: Bf is the centred video itself
+                CK(hipMemcpyAsync(ctx->cov.p, P->cov_base.p, (size_t)npairs * BLKPX * BLKPX * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                CK(hipMemcpyAsync(ctx->rowsum.p, P->rowsum_base.p, (size_t)nblk * BLKPX * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc;
         const int n = p + 1;

@@ -126,6 +126,11 @@ struct Patch {
     bool ysig_valid = false;
     bool res_ac = false, res_plain = false; int64_t res_ldc = 0;   // res_plain: Ysig came from cnmfe_residual itself (not the bg_ssub path)
     DevBuf resCnt, resK, resV, resCc;
+    // incremental ring regression (bg.hip): the block-pair covariance table and row sums of the centred VIDEO (no footprints subtracted),
+    // valid for one frame stride until the video changes
+    DevBuf cov_base, rowsum_base;
+    bool base_valid = false, derived = false;             // derived: a low-resolution patch of bg_ssub > 1 (its video is rebuilt every call)
+    int base_kstride = 0;
 };
 
 }  // namespace cnmfe
@@ -144,6 +149,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
     cnmfe::DevBuf rowsum;     // [blk][256] double
     cnmfe::DevBuf tmp[16];    // small scratch
+    cnmfe::DevBuf inc[6];     // incremental ring regression: block footprint lists, U~, trace sums
     cnmfe::DevBuf stage;      // upload staging
     std::map<std::string, int64_t> opts;
     int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }
