@@ -236,7 +236,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "r1_delta", "r1_probe", "gram_incremental", "debug", nullptr};
+    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "r1_delta", "r1_lazy", "r1_probe", "gram_incremental", "debug", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -498,6 +498,7 @@ int cnmfe_get_sn(cnmfe_ctx *ctx, int patch_id, float *sn_out) {
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
     if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    RET(residual_materialize(ctx, P));                       // a pending footprint term must be in Ysig for this consumer
     if (!sn_out) return fail(CNMFE_EINVAL, "null sn_out");
     CK(hipSetDevice(ctx->device));
     return sn_pixels_run(ctx, P, sn_out);
@@ -510,6 +511,7 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
     if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    RET(residual_materialize(ctx, P));                       // a pending footprint term must be in Ysig for this consumer
     if (algorithm < CNMFE_SPATIAL_HALS || algorithm > CNMFE_SPATIAL_NNLS) return fail(CNMFE_EINVAL, "unknown spatial algorithm %d", algorithm);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
@@ -557,6 +559,7 @@ int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
     if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    RET(residual_materialize(ctx, P));                       // a pending footprint term must be in Ysig for this consumer
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
     if ((!A_val && A_colptr[K] > 0) || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");

@@ -468,7 +468,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     const int64_t T = P->T, d = P->d, nnz = A_colptr[K];
     if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(A) too large");
     DevBuf &dC = ctx->tmp[0];
-    DevBuf dColptr, dErow, dAval, dU, dCraw, dNk, dNidx, dNval, dNptr, dAa, dLvl;
+    DevBuf dColptr, dErow, dAval, dU, dCraw, dNk, dNidx, dNval, dNptr, dAa, dLvl, dOvf;
     int64_t ldc;
     RET(upload_traces(ctx, dC, C_in, K, T, c_order, &ldc));
     RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
@@ -482,9 +482,26 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     const int64_t Tc = (T + 3) / 4;
     const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
     const int64_t tchunk = (Tc + nchunk - 1) / nchunk;                                              // in 4-frame groups
-    if (nnz > 0)
+    bool term_applied = false;
+    auto reproject = [&]() -> int {                             // fold the pending term into Ysig and project again
+        RET(residual_materialize(ctx, P));
+        CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
         LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
+        return 0;
+    };
+    if (nnz > 0) {
+        // a footprint term still pending on the residual enters through A' (W A)(C - mean C); if it cannot, it is folded into Ysig first
+        if (P->pend && (P->pend_ldc != ldc || (P->res_ac && P->res_ldc != ldc))) RET(residual_materialize(ctx, P));
+        LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
+               dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
+        RET(dOvf.ensure(64));
+        CK(hipMemsetAsync(dOvf.p, 0, 64, ctx->stream));
+        const int rc_ = residual_term_project(ctx, P, K, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(), dU.as<float>(), ldc, dOvf.as<int>());
+        if (rc_ < 0) return rc_;
+        if (rc_ > 0) RET(reproject());
+        else term_applied = P->pend;
+    }
     // T2: overlap graph + V values (neighbour lists include k itself: V(k,k) = aa(k))
     HostCSR csr; csc_to_csr(d, K, A_colptr, A_rowidx, A_val, csr);
     std::vector<char> nonempty(K, 0);
@@ -505,8 +522,11 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     LAUNCH(ctx, "temporal_ata_pairs", k_ata_pairs, dim3((nn + 255) / 256), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
            dNk.as<int>(), dNidx.as<int>(), nn, dNval.as<float>());
     std::vector<float> nval(nn);
+    int ovf = 0;
     CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (term_applied) CK(hipMemcpyAsync(&ovf, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
+    if (ovf) RET(reproject());                                  // a footprint near more than 512 traces: the list kernel gave up
     std::vector<float> aa(K);
     std::vector<char> upd(K);
     for (int k = 0; k < K; ++k) { aa[k] = nval[diag[k]]; upd[k] = aa[k] > 0.f; }                // ind_update = find(aa>0)  (:51)

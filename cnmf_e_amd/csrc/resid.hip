@@ -773,6 +773,96 @@ int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out
     return 0;
 }
 
+// Ysig += (pending term) - (applied term); the pending term becomes the applied one
+int residual_materialize(cnmfe_ctx *ctx, Patch *P) {
+    if (!P->pend) return 0;
+    if (!P->ysig_valid || !P->ysig.p) return fail(CNMFE_ESTATE, "pending footprint term without a resident residual");
+    if (P->pend_ac || P->res_ac) {
+        const int64_t nblk = (P->d + 255) / 256;
+        int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(P->Tc, (8192 + nblk - 1) / nblk));
+        const int64_t cseg = (P->Tc + nseg - 1) / nseg;
+        nseg = (P->Tc + cseg - 1) / cseg;
+        const dim3 grid((unsigned)nblk, (unsigned)nseg);
+#define DELTA_ARGS P->ysig.as<float4>(), P->d, P->Tc, cseg, P->pendCnt.as<int>(), P->pendK.as<int>(), P->pendV.as<float>(), P->pendCc.as<float>(), P->pend_ldc, \
+                   P->resCnt.as<int>(), P->resK.as<int>(), P->resV.as<float>(), P->resCc.as<float>(), P->res_ldc, (int)ctx->opt("r1_probe", 0)
+        if (P->pend_ac && P->res_ac) LAUNCH(ctx, "residual_delta", (k_residual_delta<true, true>), grid, dim3(256), 0, DELTA_ARGS);
+        else if (P->pend_ac)         LAUNCH(ctx, "residual_delta", (k_residual_delta<true, false>), grid, dim3(256), 0, DELTA_ARGS);
+        else                         LAUNCH(ctx, "residual_delta", (k_residual_delta<false, true>), grid, dim3(256), 0, DELTA_ARGS);
+#undef DELTA_ARGS
+    }
+    P->res_ac = P->pend_ac; P->res_ldc = P->pend_ldc; P->res_K = P->pend_K;
+    if (P->pend_ac) { P->resCnt.swap(P->pendCnt); P->resK.swap(P->pendK); P->resV.swap(P->pendV); P->resCc.swap(P->pendCc); }
+    P->pend = false;
+    return 0;
+}
+
+// U(k,:) += sign * sum_l M(k,l) Cc_l,  M(k,l) = sum_m A(m,k) (W A_term)(m,l): the footprint term of the residual seen through A'.
+// One workgroup per neuron k; deterministic (no floating-point atomics): the traces l that the rings of k's pixels touch are found with a
+// bitmap, listed in ascending order, and each M(k,l) is summed over k's pixels in storage order by one thread.
+constexpr int TERM_KMAX = 8192;
+__global__ void __launch_bounds__(256) k_term_project(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval, int64_t d,
+                                                      const int *__restrict__ cnt, const int *__restrict__ wk, const float *__restrict__ wv,
+                                                      const float *__restrict__ Cc, int64_t ldcc, int Kterm, float sign, float *__restrict__ U, int64_t ldu, int *__restrict__ overflow) {
+    __shared__ unsigned bm[TERM_KMAX / 32];
+    __shared__ int lst[512];
+    __shared__ float Mv[512];
+    __shared__ int nl_s;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int64_t e0 = colptr[k], e1 = colptr[k + 1];
+    if (e0 == e1) return;
+    for (int w = tid; w < TERM_KMAX / 32; w += 256) bm[w] = 0u;
+    __syncthreads();
+    for (int64_t e = e0 + tid; e < e1; e += 256) {
+        const int m = erow[e], n = cnt[m];
+        for (int j = 0; j < n; ++j) { const int l = wk[(int64_t)j * d + m]; atomicOr(&bm[l >> 5], 1u << (l & 31)); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int w = 0; w < (Kterm + 31) / 32; ++w) {
+            unsigned x = bm[w];
+            while (x) { if (n == 512) { *overflow = 1; break; } const int b = __ffs(x) - 1; x &= x - 1; lst[n++] = w * 32 + b; }
+        }
+        nl_s = n;
+    }
+    __syncthreads();
+    const int nl = nl_s;
+    for (int i = tid; i < nl; i += 256) {
+        const int l = lst[i];
+        float s = 0.f;
+        for (int64_t e = e0; e < e1; ++e) {
+            const int m = erow[e], n = cnt[m];
+            for (int j = 0; j < n; ++j) if (wk[(int64_t)j * d + m] == l) { s = fmaf(aval[e], wv[(int64_t)j * d + m], s); break; }
+        }
+        Mv[i] = sign * s;
+    }
+    __syncthreads();
+    float4 *urow = reinterpret_cast<float4 *>(U + (int64_t)k * ldu);
+    for (int64_t c = tid; c < (ldu >> 2); c += 256) {
+        float4 a4 = urow[c];
+        for (int i = 0; i < nl; ++i) {
+            const float w = Mv[i];
+            const float4 t = *reinterpret_cast<const float4 *>(Cc + (int64_t)lst[i] * ldcc + 4 * c);
+            a4.x = fmaf(w, t.x, a4.x); a4.y = fmaf(w, t.y, a4.y); a4.z = fmaf(w, t.z, a4.z); a4.w = fmaf(w, t.w, a4.w);
+        }
+        urow[c] = a4;
+    }
+}
+
+// A' Ysig for the residual the caller asked for: dU holds A' (resident Ysig); add the pending footprint term and take the applied one out
+int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu, int *dOverflow) {
+    if (!P->pend) return 0;
+    // more than 512 traces near one footprint, or trace ids beyond the bitmap: fold the term into Ysig instead (the caller re-projects)
+    if ((P->pend_ac && (P->pend_K > TERM_KMAX || P->pend_ldc != ldu)) || (P->res_ac && (P->res_K > TERM_KMAX || P->res_ldc != ldu))) return 1;
+    if (P->pend_ac)
+        LAUNCH(ctx, "temporal_term_project", k_term_project, dim3(K), dim3(256), 0, dColptr, dErow, dAval, P->d, P->pendCnt.as<int>(), P->pendK.as<int>(),
+               P->pendV.as<float>(), P->pendCc.as<float>(), P->pend_ldc, (int)P->pend_K, 1.f, dU, ldu, dOverflow);
+    if (P->res_ac)
+        LAUNCH(ctx, "temporal_term_project", k_term_project, dim3(K), dim3(256), 0, dColptr, dErow, dAval, P->d, P->resCnt.as<int>(), P->resK.as<int>(),
+               P->resV.as<float>(), P->resCc.as<float>(), P->res_ldc, (int)P->res_K, -1.f, dU, ldu, dOverflow);
+    return 0;
+}
+
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf) {
     const int64_t T = P->T;
@@ -808,24 +898,19 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)
     auto keep = [&]() {
         if (outbuf) return;
-        P->res_ac = has_ac; P->res_ldc = ldc; P->res_plain = true;
+        P->res_ac = has_ac; P->res_ldc = ldc; P->res_plain = true; P->res_K = Ksel; P->pend = false;
         if (has_ac) { P->resCnt.swap(dWaCnt); P->resK.swap(dWaK); P->resV.swap(dWaV); P->resCc.swap(dCc); }
     };
     if (delta) {
-        if (has_ac || P->res_ac) {
-            const int64_t nblk = (P->d + 255) / 256;
-            int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(P->Tc, (8192 + nblk - 1) / nblk));
-            const int64_t cseg = (P->Tc + nseg - 1) / nseg;
-            nseg = (P->Tc + cseg - 1) / cseg;
-            const dim3 grid((unsigned)nblk, (unsigned)nseg);
-#define DELTA_ARGS ysig.as<float4>(), P->d, P->Tc, cseg, dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dCc.as<float>(), ldc, \
-                   P->resCnt.as<int>(), P->resK.as<int>(), P->resV.as<float>(), P->resCc.as<float>(), P->res_ldc, (int)ctx->opt("r1_probe", 0)
-            if (has_ac && P->res_ac) LAUNCH(ctx, "residual_delta", (k_residual_delta<true, true>), grid, dim3(256), 0, DELTA_ARGS);
-            else if (has_ac)         LAUNCH(ctx, "residual_delta", (k_residual_delta<true, false>), grid, dim3(256), 0, DELTA_ARGS);
-            else                     LAUNCH(ctx, "residual_delta", (k_residual_delta<false, true>), grid, dim3(256), 0, DELTA_ARGS);
-#undef DELTA_ARGS
+        // lazy: keep the term pending; cnmfe_hals_temporal folds it in algebraically, anybody else materialises it
+        if (ctx->opt("r1_lazy", 1) != 0 && !Ysig_out) {
+            P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
+            if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); }
+            return 0;
         }
-        keep();
+        P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
+        if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); }
+        RET(residual_materialize(ctx, P));
         if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
         return 0;
     }

@@ -379,7 +379,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
         LAUNCH(ctx, "ssub_up_fused", k_up_fused, dim3((unsigned)ntile, (unsigned)nseg), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(), d1s, R->d_b,
                M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->nc, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(),
                dIc.as<int>(), dWc.as<float>(), ntr, M->Tc, cseg, M->ysig.as<float4>());
-        M->ysig_valid = true; M->res_plain = false;
+        M->ysig_valid = true; M->res_plain = false; M->pend = false;
         if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
         return 0;
     }
@@ -388,7 +388,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     LAUNCH(ctx, "ssub_up_rows_combine", k_up_rows_combine, dim3((unsigned)((M->d + 255) / 256), (unsigned)M->Tc), dim3(256), 0, ctx->up_tmp.as<float4>(), d1s,
            M->nc_b, M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(), tr.P,
            M->ysig.as<float4>());
-    M->ysig_valid = true; M->res_plain = false;
+    M->ysig_valid = true; M->res_plain = false; M->pend = false;
     if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
     return 0;
 }

@@ -368,15 +368,17 @@ class Sources2D:
         v, o = self.video, self.options
         # the block slices of the current A: prepared by the temporal update under its GPU work when A has not changed since
         cached = getattr(self, "_cur_blocks_src", None) is self.A
-        A_csr = self._cur_csr if cached else self.A.tocsr()
+        A_csr = self._cur_csr if cached and self._cur_csr is not None else None   # CSR of A: built only if some block needs row slicing
         infos = {}
         prefetched = False
-        self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update
+        self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update (None: built on demand)
         self._prev_blocks = {}                                             # (ind, A_block) per patch: what the temporal update's residual needs
         for idx in v.owned:
             if cached and idx in self._cur_blocks:
                 ind_nz, A_block = self._cur_blocks[idx]
             else:
+                if A_csr is None:
+                    A_csr = self.A.tocsr()
                 Ab = A_csr[v.block_pix[idx]]
                 ind_nz = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]   # :128
                 A_block = Ab[:, ind_nz].tocsc()                            # :129
@@ -408,9 +410,11 @@ class Sources2D:
     def _prev_csr_of(self):
         """A_prev in CSR; cached by update_background_parallel when A_prev is the A it fitted against"""
         if getattr(self, "_prev_csr_src", None) is not self.A_prev:
-            self._prev_csr = self.A_prev.tocsr()
+            self._prev_csr = None
             self._prev_csr_src = self.A_prev
             self._prev_blocks = {}
+        if self._prev_csr is None:
+            self._prev_csr = self.A_prev.tocsr()
         return self._prev_csr
 
     def _prev_block_of(self, idx):
@@ -566,21 +570,29 @@ class Sources2D:
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
             C_prev_b = self._rows(self.C_prev, indp) if indp.size else None
             launched = A_csr is None
+            whole = bp.size == v.d1 * v.d2                                 # this block is the whole field of view (then so is the patch): no row slicing
             if launched:
                 # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)
-                A_csr = self.A.tocsr()
-                self._cur_csr, self._cur_blocks, self._cur_blocks_src = A_csr, {}, self.A
-            Ab = A_csr[bp]
-            ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                              # :83
-            # the next background update fits against this same A (update_background_parallel.m:128-130): slice it now, under the sweep
-            self._cur_blocks[idx] = (ind, Ab[:, ind].tocsc())
+                A_csr = True if whole else self.A.tocsr()
+                self._cur_csr, self._cur_blocks, self._cur_blocks_src = (None if whole else A_csr), {}, self.A
+            if whole:
+                A_csc = self.A if sp.isspmatrix_csc(self.A) else self.A.tocsc()
+                ind = np.nonzero(np.asarray(A_csc.sum(axis=0)).ravel() > 0)[0]                       # :83
+                A_pp = A_csc if ind.size == K else A_csc[:, ind]
+                self._cur_blocks[idx] = (ind, A_pp)
+            else:
+                Ab = A_csr[bp]
+                ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                          # :83
+                # the next background update fits against this same A (update_background_parallel.m:128-130): slice it now, under the sweep
+                self._cur_blocks[idx] = (ind, Ab[:, ind].tocsc())
             if ind.size == 0:
                 continue                                                                              # :123
             if not launched:
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self._rows(self.C, ind)                                                        # :86
-            A_pp = A_csr[pp][:, ind].tocsc()                                                         # A_patch(ind_patch,:)
+            if not whole:
+                A_pp = A_csr[pp][:, ind].tocsc()                                                     # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175
                 C_raw_p, aa_p = self.engine.fast_temporal(v.pid[idx], A_pp)
             elif o.deconv_flag:                                                                       # :106-110

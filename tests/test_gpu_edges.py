@@ -208,6 +208,7 @@ def test_incremental_residual_equals_full_sweep(eng):
         scale = max(np.abs(x).max() for x in full)
         for a, b in zip(full, inc):
             assert np.abs(a - b).max() <= 2e-6 * scale
+        eng.set_option("r1_lazy", 0)                        # (lazy: the term would stay pending until somebody needs Ysig itself)
         eng.profile(True); eng.profile_reset()
         eng.residual(0, A, Cm)                              # delta (A' -> A)
         eng.fit_ring_model(0, A, Cm); eng.set_b0(0, eng.b0(0))      # new W, b0 (b0 rounded to fp32 so that the round trip below is exact)
@@ -220,4 +221,69 @@ def test_incremental_residual_equals_full_sweep(eng):
         y_ref = eng.residual(0, A[:, :3], Cm[:3], want=True)
         assert np.abs(y_after - y_ref).max() <= 2e-6 * scale
     finally:
-        eng.set_option("r1_delta", 1)
+        eng.set_option("r1_delta", 1); eng.set_option("r1_lazy", 1)
+
+
+def test_pending_footprint_term_through_hals_temporal(eng):
+    """r1_lazy (default): the second residual of an iteration leaves its footprint term pending; cnmfe_hals_temporal adds A' (W A)(C - mean C)
+    to A' Ysig instead of sweeping the video again, every other consumer folds the term into Ysig first"""
+    d1, d2, T, r = 44, 40, 128, 5
+    f, Y, video = _video(eng, d1, d2, T, 6, r, 13)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.fit_ring_model(0, A, Cm)
+    half = np.array([0, 2, 5])
+    def run(lazy):
+        eng.set_option("r1_lazy", lazy)
+        eng.set_b0(0, eng.b0(0))
+        eng.residual(0, A[:, half], Cm[half])               # sweep with a first term applied
+        eng.profile(True); eng.profile_reset()
+        eng.residual(0, A, Cm)                              # second residual: delta now (lazy = 0) or pending (lazy = 1)
+        c = eng.hals_temporal(0, A, Cm, 3)
+        n_delta = eng.profile_table().get("residual_delta", {"calls": 0})["calls"]
+        sn = eng.get_sn(0) if T >= 64 else None             # a consumer of Ysig itself: forces the fold
+        y = eng.residual(0, A, Cm, want=True)
+        eng.profile(False)
+        return c, n_delta, sn, y
+    try:
+        (c0, n0, sn0, y0), (c1, n1, sn1, y1) = run(0), run(1)
+        assert n0 == 1 and n1 == 0
+        for a, b in zip(c0, c1):
+            assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
+        assert np.allclose(sn0, sn1, rtol=1e-5)
+        assert np.abs(y0 - y1).max() <= 2e-6 * np.abs(y0).max()
+    finally:
+        eng.set_option("r1_lazy", 1)
+
+
+@pytest.mark.parametrize("T,r", [(96, 5), (9200, 5)])
+def test_incremental_gram_equals_direct_fp64(eng, T, r):
+    """The incremental ring regression (video table once + footprint corrections per fit) against the direct fp64 Gram of Bf, over a
+    sequence of fits with changing A, C -- including no footprints at all, a footprint set that shrinks, and (T = 9200 > 2 * 100 * p)
+    the frame stride 2 of fit_ring_model.m:84-87 on the second fit, which rebuilds the kept table for the new stride"""
+    d1, d2 = 40, 36
+    f, Y, video = _video(eng, d1, d2, T, 5, r, 11)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    seq = [(A, Cm), (A * 0.8, Cm * 1.2), (None, None), (A[:, :2].tocsc(), Cm[:2]), (A, Cm)]
+    def run(incr):
+        eng.set_option("gram_incremental", incr); eng.set_option("gram_mode", 3 if incr else 1)
+        eng.ring_init(0, r)
+        out = []
+        for Ai, Ci in seq:
+            _, info = eng.fit_ring_model(0, Ai, Ci)
+            out.append((eng.ring_csr(0).data.astype(np.float64), eng.b0(0).astype(np.float64), info["frame_stride"]))
+        return out
+    try:
+        eng.set_option("debug", 1)
+        direct, inc = run(0), run(1)
+        for (wd, bd, kd), (wi, bi, ki) in zip(direct, inc):
+            assert kd == ki
+            assert np.all(np.isfinite(wi))
+            assert np.linalg.norm(wi - wd) <= 2e-6 * np.linalg.norm(wd), np.linalg.norm(wi - wd) / np.linalg.norm(wd)
+            assert np.array_equal(bd, bi)
+        if T > 9000:
+            assert max(k for _, _, k in inc) == 2
+    finally:
+        eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)

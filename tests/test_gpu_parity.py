@@ -263,12 +263,13 @@ def test_method_level_iteration_parity(eng, alg):
         assert np.allclose(s.b0_new, o.b0_new, rtol=1e-4, atol=5e-2)
 
 
-@pytest.mark.parametrize("gram_mode", [1, 2, 3])
+@pytest.mark.parametrize("gram_mode", [1, 2, 3, 0])
 def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
-    """gram_mode 1 = fp64 matrix pipe, 2 = fp32 pipe with fp64 shadow accumulation; debug=1 NaN-poisons the
+    """gram_mode 1 = fp64 matrix pipe, 2 = fp32 pipe with fp64 shadow accumulation, 3 = split bf16 (all three: the direct Gram of Bf,
+    gram_incremental = 0); 0 here = the default incremental path (table of the video + footprint corrections).  debug=1 NaN-poisons the
     covariance table so that a lookup into a pruned (never computed) sub-tile cannot go unnoticed."""
     c = Case(eng, 70, 66, 160, 5, 15, 19, [35, 33])
-    eng.set_option("debug", 1); eng.set_option("gram_mode", gram_mode)
+    eng.set_option("debug", 1); eng.set_option("gram_mode", gram_mode or 3); eng.set_option("gram_incremental", 0 if gram_mode else 1)
     try:
         for idx in c.video.owned:
             pid = c.video.pid[idx]
@@ -281,9 +282,9 @@ def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
             W = eng.ring_csr(pid)
             assert np.all(np.isfinite(W.data))
             Wref = Wref.tocsr(); Wref.sort_indices()
-            assert rel(W.data, Wref.data) <= (1e-4 if gram_mode == 1 else 1e-3), rel(W.data, Wref.data)
+            assert rel(W.data, Wref.data) <= (1e-4 if gram_mode <= 1 else 1e-3), rel(W.data, Wref.data)
     finally:
-        eng.set_option("debug", 0); eng.set_option("gram_mode", 3)
+        eng.set_option("debug", 0); eng.set_option("gram_mode", 3); eng.set_option("gram_incremental", 1)
 
 
 def _deconv_case(eng, T=1500, K=5):
