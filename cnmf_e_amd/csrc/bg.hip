@@ -751,96 +751,135 @@ __global__ void __launch_bounds__(256) k_trace_subsum(const float *__restrict__ 
     if (threadIdx.x == 0) csum[blockIdx.x] = red[0];
 }
 
+// U(i,k) = sum_t Yc_i(t) Cc_k(t) for the 256 pixels of a block and the (<= 16 NT) traces on its list, plus G(k,l) = sum_t Cc_k Cc_l on the same
+// list: plain GEMMs on the fp64 matrix pipe with both operands read straight from global memory -- lane (fi, kq) of a 16x16x4 fragment wants
+// ONE float (pixel fi of a 4x4 patch / trace fi of a 16-trace group, frame kq of the chunk), and the 64 lanes of a pixel fragment cover four
+// full 64-byte segments of the 4-frame-interleaved video.  No LDS, no barriers; loads run two chunks ahead of the MFMAs.  One launch covers
+// all blocks (longest lists first) x frame segments; partial sums go to per-segment buffers that k_win_fix adds in a fixed order.
+// (A first version staged Z = Yc - 1/2 A Cc through LDS with two barriers per chunk and one launch per list length: 7.5 ms.)
 template <int NT>
-__global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, const int *__restrict__ arow, const int *__restrict__ acol,
-                                                  const float *__restrict__ aval, const float *__restrict__ Cc, int64_t ldc, int K, const int *__restrict__ lst_ptr,
-                                                  const int *__restrict__ lst_k, const short *__restrict__ slot_of, const int *__restrict__ blk_list, double *__restrict__ Ut) {
-    __shared__ __attribute__((aligned(16))) double Z[2][BLKPX][4];
-    __shared__ __attribute__((aligned(16))) float4 TR[2][NT * 16];
-    const int blk = blk_list[blockIdx.x];
-    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+__device__ __forceinline__ void win_body(const float4 *__restrict__ Y4, const BgGeom &g, const float *__restrict__ Cc, int64_t ldc, int blk, int l0, int nl,
+                                         const int *__restrict__ lst_k, int64_t c0, int64_t c1, double *__restrict__ Ut, double *__restrict__ Gb) {
     const int bi = blk % g.nbr, bj = blk / g.nbr;
-    const int tid = threadIdx.x, lp = tid;
-    const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
-    const int rb = bi * BLK + lr, cb = bj * BLK + lc;
-    const bool in = rb < g.nr_b && cb < g.nc_b;
-    const int64_t q = in ? (int64_t)cb * g.nr_b + rb : 0;
-    int e0 = 0, e1 = 0;
-    if (in) { e0 = arow[q]; e1 = arow[q + 1]; }
-    int sl[4]; float ha[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        sl[u] = 0; ha[u] = 0.f;
-        if (e0 + u < e1) { sl[u] = slot_of[(int64_t)blk * K + acol[e0 + u]]; ha[u] = 0.5f * aval[e0 + u]; }
-    }
-    const int kk = (tid < NT * 16 && tid < nl) ? lst_k[l0 + tid] : -1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kq = lane >> 4;
     const float *Ys = reinterpret_cast<const float *>(Y4);
-    auto loadY = [&](int64_t c) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!in) return v;
-        if (g.kstride == 1) { if (c < Tc) v = Y4[c * g.d_b + q]; return v; }
-        float *pv = &v.x;
+    const float *ya[4]; const float *tb[NT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int64_t tp = 4 * c + u; if (tp < g.Tp) { const int64_t t = tp * g.kstride; pv[u] = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)]; } }
-        return v;
+    for (int a = 0; a < 4; ++a) {
+        const int lp = (wave * 4 + a) * 16 + fi;
+        const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
+        const int rb = bi * BLK + lr, cb = bj * BLK + lc;
+        ya[a] = (rb < g.nr_b && cb < g.nc_b) ? Ys + ((int64_t)cb * g.nr_b + rb) * 4 : nullptr;
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) { const int sl = b * 16 + fi; tb[b] = sl < nl ? Cc + (int64_t)lst_k[l0 + sl] * ldc : nullptr; }
+    double4_t acc[4][NT], accg[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        accg[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    struct Frag { float y[4]; float t[NT]; };
+    auto load = [&](int64_t c) {
+        Frag f;
+        const int64_t tp = 4 * c + kq, t = tp * g.kstride;
+        const bool on = c < c1 && tp < g.Tp;
+        const int64_t yo = ((t >> 2) * g.d_b) * 4 + (t & 3);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) f.y[a] = (on && ya[a]) ? ya[a][yo] : 0.f;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) f.t[b] = (on && tb[b]) ? tb[b][t] : 0.f;
+        return f;
     };
-    auto loadT = [&](int64_t c) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < 0) return v;
-        const float *row = Cc + (int64_t)kk * ldc;
-        if (g.kstride == 1) return *reinterpret_cast<const float4 *>(row + 4 * c);        // rows are zero-padded to ldc
-        float *pv = &v.x;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int64_t tp = 4 * c + u; if (tp < g.Tp) pv[u] = row[tp * g.kstride]; }
-        return v;
-    };
-    const int64_t nchunk = (g.Tp + 3) >> 2;
-    double4_t acc[4][NT];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, kq = lane >> 4;
-    float4 yv = loadY(0), tv = loadT(0);
-    for (int64_t c = 0; c < nchunk; ++c) {
-        const int buf = (int)(c & 1);
-        if (tid < NT * 16) TR[buf][tid] = tv;
-        __syncthreads();                                     // traces of chunk c in place (and nobody is still reading this buffer: barrier B of c-1)
-        double z0 = yv.x, z1 = yv.y, z2 = yv.z, z3 = yv.w;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 t = TR[buf][sl[u]];
-            const double h = ha[u];
-            z0 -= h * (double)t.x; z1 -= h * (double)t.y; z2 -= h * (double)t.z; z3 -= h * (double)t.w;
-        }
-        for (int e = e0 + 4; e < e1; ++e) {
-            const float4 t = TR[buf][slot_of[(int64_t)blk * K + acol[e]]];
-            const double h = 0.5 * (double)aval[e];
-            z0 -= h * (double)t.x; z1 -= h * (double)t.y; z2 -= h * (double)t.z; z3 -= h * (double)t.w;
-        }
-        Z[buf][lp][0] = z0; Z[buf][lp][1] = z1; Z[buf][lp][2] = z2; Z[buf][lp][3] = z3;
-        if (c + 1 < nchunk) { yv = loadY(c + 1); tv = loadT(c + 1); }
-        __syncthreads();                                     // Z of chunk c in place
+    const bool gw = wave < NT;                              // wave w also owns row-group w of G
+    auto mm = [&](const Frag &f) {
         double bv[NT];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) bv[b] = (double)reinterpret_cast<const float *>(&TR[buf][b * 16 + fi])[kq];
+        for (int b = 0; b < NT; ++b) bv[b] = (double)f.t[b];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const double av = Z[buf][(wave * 4 + a) * 16 + fi][kq];
+            const double av = (double)f.y[a];
 #pragma unroll
             for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[b], acc[a][b], 0, 0, 0);
         }
+        if (gw) {
+            double gv = bv[0];
+#pragma unroll
+            for (int b = 1; b < NT; ++b) gv = wave == b ? bv[b] : gv;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) accg[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv, bv[b], accg[b], 0, 0, 0);
+        }
+    };
+    Frag f0 = load(c0), f1 = load(c0 + 1);                  // loads past the segment return zeros
+    for (int64_t c = c0; c < c1; c += 2) {
+        const Frag n0 = load(c + 2);
+        mm(f0);
+        const Frag n1 = load(c + 3);
+        mm(f1);
+        f0 = n0; f1 = n1;
     }
     // D layout (fp64 16x16): row = (lane>>4) + 4r, col = lane&15
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < NT; ++b) {
+        const int slot = b * 16 + fi;
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            const int slot = b * 16 + fi;
+        for (int a = 0; a < 4; ++a)
             if (slot < nl)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ut[(int64_t)(l0 + slot) * BLKPX + (wave * 4 + a) * 16 + kq + 4 * r] = acc[a][b][r];
-        }
+        if (gw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gb[(int64_t)blk * WIN_NLB * WIN_NLB + (wave * 16 + kq + 4 * r) * WIN_NLB + slot] = accg[b][r];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
+                                                  const int *__restrict__ lst_k, const int *__restrict__ blk_list, int nseg, double *__restrict__ Ut, int64_t ut_stride,
+                                                  double *__restrict__ Gb, int64_t gb_stride) {
+    const int blk = blk_list[blockIdx.x / nseg], seg = blockIdx.x % nseg;
+    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+    const int64_t nchunk = (g.Tp + 3) >> 2;
+    int64_t cseg = ((nchunk + nseg - 1) / nseg + 1) & ~int64_t(1);
+    const int64_t c0 = seg * cseg, c1 = c0 + cseg < nchunk ? c0 + cseg : nchunk;
+    double *ut = Ut + seg * ut_stride, *gb = Gb + seg * gb_stride;
+    switch ((nl + 15) >> 4) {
+        case 1: win_body<1>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        case 2: win_body<2>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        case 3: win_body<3>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        case 4: win_body<4>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        default: break;
+    }
+}
+
+// U~(i,k) = sum_seg U_seg(i,k) - 1/2 sum_{l at i} A_il sum_seg G_seg(l,k), written to segment 0
+__global__ void __launch_bounds__(256) k_win_fix(BgGeom g, int K, const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
+                                                 const int *__restrict__ lst_ptr, const short *__restrict__ slot_of, const int *__restrict__ blk_list, int nseg,
+                                                 double *__restrict__ Ut, int64_t ut_stride, const double *__restrict__ Gb, int64_t gb_stride) {
+    __shared__ double G[WIN_NLB * WIN_NLB];
+    const int blk = blk_list[blockIdx.x];
+    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+    const int lp = threadIdx.x;
+    const int nlp = ((nl + 15) >> 4) << 4;
+    for (int i = lp; i < nlp * WIN_NLB; i += 256) {
+        const int r = i / WIN_NLB, c = i % WIN_NLB;
+        double v = 0.0;
+        if (c < nlp) for (int sg = 0; sg < nseg; ++sg) v += Gb[sg * gb_stride + (int64_t)blk * WIN_NLB * WIN_NLB + r * WIN_NLB + c];
+        G[i] = v;
+    }
+    __syncthreads();
+    const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
+    const int rb = (blk % g.nbr) * BLK + lr, cb = (blk / g.nbr) * BLK + lc;
+    int e0 = 0, e1 = 0;
+    if (rb < g.nr_b && cb < g.nc_b) { const int64_t q = (int64_t)cb * g.nr_b + rb; e0 = arow[q]; e1 = arow[q + 1]; }
+    for (int s = 0; s < nl; ++s) {
+        double *u = Ut + (int64_t)(l0 + s) * BLKPX + lp;
+        double v = u[0];
+        for (int sg = 1; sg < nseg; ++sg) v += u[sg * ut_stride];
+        double w = 0.0;
+        for (int e = e0; e < e1; ++e) w += (double)aval[e] * G[(int)slot_of[(int64_t)blk * K + acol[e]] * WIN_NLB + s];
+        u[0] = v - 0.5 * w;
+    }
 }
 
 // cov(pair)(i,j) = base(pair)(i,j) - sum_{k at j} A_jk U~_a(k, i) - sum_{k at i} A_ik U~_b(k, j)  over the needed 16x16 sub-tiles
@@ -2027,24 +2066,29 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         }
         if (incr) {
             // ---- B2a': U~ on the blocks near footprints, then one sweep base -> cov ----
-            DevBuf &dLp = ctx->inc[0], &dLk = ctx->inc[1], &dSlot = ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5];
+            DevBuf &dLp = ctx->inc[0], &dLk = ctx->inc[1], &dSlot = ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5], &dGb = ctx->inc[6];
             RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
             if (has_a) {
-                std::vector<int> blall; int off_nt[5] = {0, 0, 0, 0, 0};
-                for (int t = 0; t < 4; ++t) { blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end()); off_nt[t + 1] = (int)blall.size(); }
+                std::vector<int> blall;
+                for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());      // longest lists first
                 RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
                 RET(to_dev(ctx, dLk, lst_k.data(), lst_k.size()));
                 RET(to_dev(ctx, dSlot, slot_of.data(), slot_of.size()));
                 RET(to_dev(ctx, dBl, blall.data(), blall.size()));
-                RET(dUt.ensure(std::max<size_t>(1, lst_k.size()) * BLKPX * sizeof(double)));
                 RET(dCsum.ensure((size_t)K * sizeof(double)));
                 CK(hipStreamSynchronize(ctx->stream));                 // the staging vectors above die with this scope
                 LAUNCH(ctx, "bg_trace_subsum", k_trace_subsum, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, g.Tp, g.kstride, dCsum.as<double>());
-#define WIN_LAUNCH(NT) if (off_nt[NT] > off_nt[NT - 1]) LAUNCH(ctx, "bg_win_proj", (k_win_proj<NT>), dim3((unsigned)(off_nt[NT] - off_nt[NT - 1])), dim3(256), 0, \
-                    P->Yc4.as<float4>(), P->Tc, g, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, (int)K, dLp.as<int>(), dLk.as<int>(), \
-                    dSlot.as<short>(), dBl.as<int>() + off_nt[NT - 1], dUt.as<double>())
-                WIN_LAUNCH(4); WIN_LAUNCH(3); WIN_LAUNCH(2); WIN_LAUNCH(1);
-#undef WIN_LAUNCH
+                {
+                    const int nb_ = (int)blall.size();
+                    const int nsg = std::max(1, std::min(8, (2048 + nb_ - 1) / std::max(1, nb_)));
+                    const int64_t ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX, gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
+                    RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
+                    RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
+                    LAUNCH(ctx, "bg_win_proj", k_win_proj, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
+                           dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+                    LAUNCH(ctx, "bg_win_fix", k_win_fix, dim3((unsigned)nb_), dim3(256), 0, g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(),
+                           dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+                }
                 LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
                        dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
                 LAUNCH(ctx, "bg_rowsum_correct", k_rowsum_correct, dim3(nblk), dim3(256), 0, P->rowsum_base.as<double>(), ctx->rowsum.as<double>(), g,

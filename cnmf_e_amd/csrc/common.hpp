@@ -153,7 +153,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
     cnmfe::DevBuf rowsum;     // [blk][256] double
     cnmfe::DevBuf tmp[16];    // small scratch
-    cnmfe::DevBuf inc[6];     // incremental ring regression: block footprint lists, U~, trace sums
+    cnmfe::DevBuf inc[7];     // incremental ring regression: block footprint lists, U~, trace sums
     cnmfe::DevBuf stage;      // upload staging
     std::map<std::string, int64_t> opts;
     int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }
