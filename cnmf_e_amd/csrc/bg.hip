@@ -1234,13 +1234,28 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
         const double *zrow = L + tri(n);
         double za = lane < n ? zrow[lane] : 0.0;
         double zb = lane + 64 < n ? zrow[lane + 64] : 0.0;
-        for (int j = n - 1; j >= 0; --j) {
-            const double *rj = L + tri(j);
-            const double zj = j < 64 ? readlane_f64(za, j) : readlane_f64(zb, j - 64);
-            const double wj = zj * rj[j];
-            if (lane == (j & 63)) { if (j < 64) za = wj; else zb = wj; }
-            if (lane < j) za -= rj[lane] * wj;
-            if (lane + 64 < j) zb -= rj[lane + 64] * wj;
+        // the rows of L a step needs do not depend on the running solution: four steps' worth of LDS reads are issued ahead of the
+        // four dependent readlane / multiply / fma steps (one LDS round trip per step sat on the chain before)
+        for (int jt = n - 1; jt >= 0; jt -= 4) {
+            double dj[4], ra_[4], rb_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jt - u;
+                const double *rj = L + tri(j >= 0 ? j : 0);
+                dj[u] = j >= 0 ? rj[j] : 0.0;
+                ra_[u] = (j >= 0 && lane < j) ? rj[lane] : 0.0;
+                rb_[u] = (j >= 0 && lane + 64 < j) ? rj[lane + 64] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jt - u;
+                if (j < 0) break;
+                const double zj = j < 64 ? readlane_f64(za, j) : readlane_f64(zb, j - 64);
+                const double wj = zj * dj[u];
+                if (lane == (j & 63)) { if (j < 64) za = wj; else zb = wj; }
+                za -= ra_[u] * wj;
+                zb -= rb_[u] * wj;
+            }
         }
         if (lane < p) W[(int64_t)lane * g.d + m] = nb[lane] >= 0 ? (float)za : 0.f;
         if (lane + 64 < p) W[(int64_t)(lane + 64) * g.d + m] = nb[lane + 64] >= 0 ? (float)zb : 0.f;   // intercept (index p) discarded (:107)
