@@ -62,8 +62,8 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--alg", default="hals", help="spatial algorithm: hals | hals_thresh | nnls")
     ap.add_argument("--deconv", action="store_true", help="deconv_flag=true (OASIS AR(1) FOOPSI inside the temporal sweep); reported separately")
@@ -221,6 +221,8 @@ def main():
                 "ms_per_launch": kern[dom]["ms_per_call"]}
     if roof.get("kernel", "").startswith("bg_gram"):
         roof["traffic"] = pmc_traffic("k_gram")
+    if roof.get("kernel") == "bg_ring_solve":
+        roof["traffic"] = pmc_traffic("k_ring_solve")
     r1r = r1_roof()
     if r1r is not None:
         r1r["traffic"] = pmc_traffic("k_residual", exclude="k_residual_delta")

@@ -14,7 +14,7 @@ for r in rows:
     else:
         other[0] += int(r["Calls"]); other[1] += float(r["TotalDurationNs"])
 with open(f"profiles/{rnd}/bench_c3_kernel_stats_{ver}.csv", "w") as g:
-    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline  (3 iterations traced; scripts/profile_round.sh)\n")
+    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline  (5 iterations traced, the first one includes the one-off table of the video: k_build_bf, k_rowsum, k_gram4<0>; scripts/profile_round.sh)\n")
     g.write("# kernel argument lists stripped; all non-engine kernels (torch synthetic-video generation, rocsparse/torch glue in synth + host logic) summed in the last row\n")
     g.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for s, c, t, a, mn, mx in sorted(out, key=lambda x: -x[2]):
@@ -25,5 +25,5 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     keep = [lines[0]] + [l for l in lines[1:] if "cnmfe::" in l]
     keep = [re.sub(r"\(cnmfe::[^\"]*|\((float|HIP|long|int|double|unsigned)[^\"]*", "", l) for l in keep]
     open(f"profiles/{rnd}/bench_c3_pmc_{c}_{ver}.csv", "w").write(
-        "# rocprofv3 --pmc %s --kernel-trace (own pass) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline; per-launch mean; counter unit KiB.  gfx950: FETCH_SIZE of 16-B/lane coalesced reads is reported at 1/2 (MI355X_MICROARCH.md, HBM section)\n" % c + "\n".join(keep) + "\n")
+        "# rocprofv3 --pmc %s --kernel-trace (own pass) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline; per-launch mean; counter unit KiB.  gfx950: FETCH_SIZE of 16-B/lane coalesced reads is reported at 1/2 (MI355X_MICROARCH.md, HBM section)\n" % c + "\n".join(keep) + "\n")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{rnd}/bench_c3_under_rocprof_{ver}.json")
