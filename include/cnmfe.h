@@ -103,7 +103,11 @@ int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0 /* d */);
  * (the outlier branch :50-56 is dead in every demo; anything else -> CNMFE_EUNSUPPORTED).
  * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels, info[3]=pmax (known before the heavy kernels start).
  * With b0_out == NULL the call returns while the Gram / solve kernels are still running on the context's stream; every later
- * call on this context is ordered behind them and reports their errors. */
+ * call on this context is ordered behind them and reports their errors.
+ * The first fit of a patch (and the first one after its frame stride k changes) also builds the block-pair covariance table of the
+ * resident VIDEO and keeps it with the patch (fp64, 58 bytes per block pixel and needed neighbour pair: 3.8 GB for 512 x 512,
+ * radius 15) until the next cnmfe_upload_block; later fits only add the footprint corrections (option "gram_incremental", default 1;
+ * 0 = the Gram of Y - A*C from scratch every call).  Results are the same regression either way. */
 int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
                          const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                          double thresh_outlier, int with_projection,
@@ -217,7 +221,9 @@ int cnmfe_profile_reset(cnmfe_ctx *ctx);
 int cnmfe_profile_count(cnmfe_ctx *ctx);
 int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *calls);
 int cnmfe_synchronize(cnmfe_ctx *ctx);
-/* tunables for A/B runs (name = "r1_variant", "gram_mode", ...); unknown names -> CNMFE_EINVAL */
+/* tunables for A/B runs; unknown names -> CNMFE_EINVAL.  r1_variant (R1 kernel), r1_delta / r1_lazy (incremental residual, see
+ * cnmfe_residual), gram_incremental (see cnmfe_fit_ring_model), gram_mode 1 | 2 | 3 = fp64 | fp32 | split-bf16 matrix pipe for the direct
+ * Gram, gram_kernel, gram_flush, solve_mode, tile_order, debug (1: NaN-poison never-computed table entries), *_probe (timing experiments) */
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus
