@@ -142,7 +142,12 @@ int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssu
  * A_prev is d_b x Ksel CSC (block rows), C_prev Ksel x T.  The result (d x T fp32,
  * frame-major) stays resident for the HALS/NNLS calls below; Ysig_out may be NULL, and then
  * the call returns with the sweep still running on the context's stream (all inputs have been
- * consumed; later calls on this context are stream-ordered behind it and report its errors). */
+ * consumed; later calls on this context are stream-ordered behind it and report its errors).
+ * Ysig stays resident PER PATCH.  While the video, W and b0 of the patch are unchanged, a further call only changes the footprint
+ * term (W*A_prev)*(C_prev - mean): the difference is folded into the resident Ysig in one streaming pass (option "r1_delta",
+ * default 1), or merely recorded (option "r1_lazy", default 1) -- cnmfe_hals_temporal[_deconv] then adds A'*(W*A_prev)*(C_prev - mean)
+ * to A'*Ysig without another pass over the video, every other consumer folds it in first.  The values any caller sees are those of
+ * the full expression above (up to fp32 rounding of the re-association). */
 int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_colptr,
                    const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                    float *Ysig_out, int out_memspace);
