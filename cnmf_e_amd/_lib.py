@@ -81,7 +81,7 @@ for _name, (_res, _args) in PROTOTYPES.items():
 # enums of include/cnmfe.h
 F32, F64, U16, U8, F16 = 0, 1, 2, 3, 4
 HOST, DEVICE = 0, 1
-COLMAJOR, ROWMAJOR, BOUND = 0, 1, 2
+COLMAJOR, ROWMAJOR, BOUND, BOUND_ROWS = 0, 1, 2, 3
 SPATIAL_HALS, SPATIAL_HALS_THRESH, SPATIAL_NNLS = 0, 1, 2
 
 

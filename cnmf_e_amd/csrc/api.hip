@@ -90,6 +90,12 @@ __global__ void k_transpose_out(const float *__restrict__ src, int64_t ldc, floa
     }
 }
 
+__global__ void __launch_bounds__(256) k_gather_rows(const float4 *__restrict__ src, int64_t ldc4, const int *__restrict__ idx, float4 *__restrict__ dst) {
+    const float4 *s = src + (int64_t)idx[blockIdx.x] * ldc4;
+    float4 *d = dst + (int64_t)blockIdx.x * ldc4;
+    for (int64_t c = threadIdx.x; c < ldc4; c += 256) d[c] = s[c];
+}
+
 int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_t T, int order, int64_t *ldc_out) {
     int64_t ldc = (T + 3) & ~int64_t(3);
     *ldc_out = ldc;
@@ -102,9 +108,20 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
         return 0;
     }
     if (!C) return fail(CNMFE_EINVAL, "null trace matrix");
+    if (order == CNMFE_BOUND_ROWS) {                       // K rows of the bound matrix, picked on the device
+        if (!ctx->bound_valid || ctx->bound_T != T) return fail(CNMFE_ESTATE, "no bound trace matrix with %lld frames (cnmfe_traces_bind)", (long long)T);
+        const int32_t *rows = reinterpret_cast<const int32_t *>(C);
+        for (int32_t k = 0; k < K; ++k)
+            if (rows[k] < 0 || rows[k] >= ctx->bound_K) return fail(CNMFE_EINVAL, "row %d of the bound trace matrix (%d rows) does not exist", rows[k], ctx->bound_K);
+        DevBuf &dIdx = ctx->tmp[15];
+        RET(to_dev(ctx, dIdx, rows, (size_t)K));
+        LAUNCH(ctx, "gather_rows", k_gather_rows, dim3((unsigned)K), dim3(256), 0, ctx->bound.as<float4>(), ldc >> 2, dIdx.as<int>(), dst.as<float4>());
+        CK(hipStreamSynchronize(ctx->stream));             // the caller's index array may go away after the call
+        return 0;
+    }
     CK(hipMemsetAsync(dst.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
     if (order == CNMFE_ROWMAJOR) {
-        CK(hipMemcpy2DAsync(dst.p, ldc * sizeof(float), C, T * sizeof(float), T * sizeof(float), K, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemcpy2DAsync(dst.p, ldc * sizeof(float), C, T * sizeof(float), T * sizeof(float), K, hipMemcpyDefault, ctx->stream));
     } else {
         RET(ctx->stage.ensure((size_t)K * T * sizeof(float)));
         CK(hipMemcpyAsync(ctx->stage.p, C, (size_t)K * T * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -116,7 +133,7 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
 
 int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int32_t K, int64_t T, int order) {
     if (K == 0 || !C) return 0;
-    if (order == CNMFE_BOUND) order = ctx->bound_order;        // outputs of a call on the bound matrix come back in ITS layout
+    if (order == CNMFE_BOUND || order == CNMFE_BOUND_ROWS) order = ctx->bound_order;   // outputs of a call on the bound matrix come back in ITS layout
     if (order == CNMFE_ROWMAJOR) {
         CK(hipMemcpy2DAsync(C, T * sizeof(float), dC, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->stream));
     } else {

@@ -41,17 +41,40 @@ def _traces(Cm, K, T):
     return Cm
 
 
+class BoundRows:
+    """C(ind, :) of a trace matrix, kept as (matrix, row indices): when the matrix is the one bound on the engine the rows are gathered
+    on the device (CNMFE_BOUND_ROWS); anywhere else it behaves like the array C[ind] (np.asarray)"""
+    def __init__(self, parent, ind):
+        self.parent = parent
+        self.ind = np.ascontiguousarray(ind, dtype=np.int32)
+        self.shape = (int(self.ind.size), int(parent.shape[1]))
+        self.dtype = parent.dtype
+        self.ndim = 2
+    def __array__(self, dtype=None, copy=None):
+        a = self.parent[self.ind]
+        return a if dtype is None else a.astype(dtype, copy=False)
+    def __len__(self):
+        return self.shape[0]
+    def __getitem__(self, key):
+        return np.asarray(self)[key]
+    def mean(self, *a, **k):
+        return np.asarray(self).mean(*a, **k)
+
+
 class Engine:
     # -- bound traces: obj.C is the same matrix for several calls of one iteration; bind_traces uploads it once and every
     # call that is handed THAT array object afterwards passes (NULL, CNMFE_BOUND).  The array must not be mutated in place
     # while it is bound (Sources2D replaces C, it never writes into it).
-    def bind_traces(self, Cm):
+    def bind_traces(self, Cm, device_ptr=None):
+        """device_ptr: address of a row-major fp32 DEVICE copy of Cm (e.g. the tensor an all-reduce just produced): the engine then binds
+        with a device-to-device copy; Cm stays the host-side identity of the bound matrix"""
         Cm = None if Cm is None or Cm.shape[0] == 0 else Cm
         if Cm is None or Cm.dtype != np.float32 or not Cm.flags["C_CONTIGUOUS"]:
             self._bound = None
             L.check(L.lib.cnmfe_traces_bind(self._ctx, 0, 0, None, L.ROWMAJOR))
             return
-        L.check(L.lib.cnmfe_traces_bind(self._ctx, Cm.shape[0], Cm.shape[1], _p(Cm, L.f32p), L.ROWMAJOR))
+        src = _p(Cm, L.f32p) if device_ptr is None else C.cast(int(device_ptr), L.f32p)
+        L.check(L.lib.cnmfe_traces_bind(self._ctx, Cm.shape[0], Cm.shape[1], src, L.ROWMAJOR))
         self._bound = Cm
 
     def _targs(self, Cm, K, T):
@@ -60,6 +83,8 @@ class Engine:
             return None, L.ROWMAJOR, None
         if Cm is getattr(self, "_bound", None) and Cm.shape == (K, T):
             return None, L.BOUND, None
+        if isinstance(Cm, BoundRows) and Cm.parent is getattr(self, "_bound", None) and Cm.shape == (K, T):
+            return C.cast(Cm.ind.ctypes.data, L.f32p), L.BOUND_ROWS, Cm.ind
         a = _traces(Cm, K, T)
         return _p(a, L.f32p), L.ROWMAJOR, a
 

@@ -22,7 +22,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import scipy.sparse as sp
 
-from .engine import Engine
+from .engine import BoundRows, Engine
 
 __all__ = ["Options", "PatchedVideo", "Sources2D", "distribute_geometry", "determine_search_location"]
 
@@ -240,13 +240,19 @@ class Sources2D:
 
     @staticmethod
     def _rows(Cm, ind):
-        """Cm(ind, :) -- the matrix itself when ind is every row (so that a bound trace matrix is recognised by identity)"""
-        return Cm if ind.size == Cm.shape[0] else Cm[ind]
+        """Cm(ind, :) -- the matrix itself when ind is every row (so that a bound trace matrix is recognised by identity), else a
+        (matrix, rows) pair that the engine resolves on the device when the matrix is the bound one"""
+        return Cm if ind.size == Cm.shape[0] else BoundRows(Cm, ind)
 
     def _bind_C(self):
         """one upload of obj.C per iteration instead of one per engine call (cnmfe_traces_bind)"""
         if hasattr(self.engine, "bind_traces"):
-            self.engine.bind_traces(self.C)
+            dev = getattr(self, "_C_dev", None)
+            self._C_dev = None
+            if dev is not None and dev[0] is self.C:
+                self.engine.bind_traces(self.C, device_ptr=dev[1].data_ptr())
+            else:
+                self.engine.bind_traces(self.C)
 
     def _residual(self, idx, A_prev_b, C_prev_b):
         """the background-subtraction expression of update_spatial_parallel.m:162-178 / update_temporal_parallel.m:149-165"""
@@ -319,7 +325,11 @@ class Sources2D:
         C_raw = buf[:, :T] / aa                                                                       # :280
         if not self.options.deconv_flag:
             C_raw = C_raw - C_raw.min(dim=1, keepdim=True).values                                     # :285
-        return C_raw.cpu().numpy()
+        C_raw = C_raw.contiguous()
+        host = C_raw.cpu().numpy()
+        if nccl and not self.options.deconv_flag:
+            self._C_dev = (host, C_raw)                                    # the next _bind_C binds device-to-device (no H2D of K x T)
+        return host
 
     def _update_b0_new(self):
         """obj.b0_new = Ymean - A*mean(C,2) (update_spatial_parallel.m:349).  Evaluated on first read from the

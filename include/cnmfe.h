@@ -48,13 +48,16 @@ enum { CNMFE_HOST = 0, CNMFE_DEVICE = 1 };
 /* memory order of a K x T trace matrix */
 enum { CNMFE_COLMAJOR = 0 /* MATLAB: element (k,t) at k + t*K */,
        CNMFE_ROWMAJOR = 1 /* numpy:  element (k,t) at k*T + t */,
-       CNMFE_BOUND = 2    /* the pointer is ignored: use the matrix bound with cnmfe_traces_bind */ };
+       CNMFE_BOUND = 2,   /* the pointer is ignored: use the matrix bound with cnmfe_traces_bind */
+       CNMFE_BOUND_ROWS = 3 /* the pointer is (const int32_t *) K ascending-or-not 0-based row indices into the bound matrix */ };
 
 /* Bind a K x T trace matrix to the context: one host-to-device transfer, after which every entry point that takes
  * (C, c_order) accepts (NULL, CNMFE_BOUND) for that same matrix (K and T must match) and copies it on the device.
  * obj.C is the same K x T matrix for the background fit, both residual sweeps and the temporal HALS of one iteration
  * (update_background_parallel.m:130, update_temporal_parallel.m:86,91): bind it once, upload it once.  Trace OUTPUTS of a call made
- * with CNMFE_BOUND use the layout the matrix was bound with.  K = 0 unbinds. */
+ * with CNMFE_BOUND use the layout the matrix was bound with.  K = 0 unbinds.  A call that works on a SUBSET of the neurons (a patch's
+ * C(ind,:), update_*_parallel.m) passes ((const float *)ind, CNMFE_BOUND_ROWS): the rows are gathered on the device, nothing crosses
+ * PCIe.  C may be a host or a device pointer (row-major device matrices bind with a device-to-device copy). */
 int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int c_order);
 /* spatial algorithm (options.spatial_algorithm, CNMFSetParms.m:117) */
 enum { CNMFE_SPATIAL_HALS = 0, CNMFE_SPATIAL_HALS_THRESH = 1, CNMFE_SPATIAL_NNLS = 2 };

@@ -287,3 +287,56 @@ def test_incremental_gram_equals_direct_fp64(eng, T, r):
             assert max(k for _, _, k in inc) == 2
     finally:
         eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
+
+
+def test_bound_rows_equal_uploaded_rows(eng):
+    """(ind, CNMFE_BOUND_ROWS): a subset of the bound trace matrix gathered on the device gives the same results as uploading C[ind];
+    an index outside the bound matrix is an error, not a read"""
+    from cnmf_e_amd import _lib as L
+    from cnmf_e_amd.engine import BoundRows
+    d1, d2, T, r = 36, 32, 96, 5
+    f, Y, video = _video(eng, d1, d2, T, 6, r, 21)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    ind = np.array([4, 1, 3])
+    eng.bind_traces(None)
+    eng.fit_ring_model(0, A[:, ind], Cm[ind]); W0 = eng.ring_csr(0).data.copy()
+    y0 = eng.residual(0, A[:, ind], Cm[ind], want=True)
+    c0 = eng.hals_temporal(0, A[:, ind], Cm[ind], 3)
+    eng.ring_init(0, r)
+    eng.bind_traces(Cm)
+    rows = BoundRows(Cm, ind)
+    assert np.array_equal(np.asarray(rows), Cm[ind])
+    eng.fit_ring_model(0, A[:, ind], rows); W1 = eng.ring_csr(0).data.copy()
+    y1 = eng.residual(0, A[:, ind], rows, want=True)
+    c1 = eng.hals_temporal(0, A[:, ind], rows, 3)
+    assert np.array_equal(W0, W1) and np.array_equal(y0, y1)
+    for a, b in zip(c0, c1):
+        assert np.array_equal(a, b)
+    bad = np.array([0, 6], np.int32)
+    with pytest.raises(L.CnmfeError):
+        L.check(L.lib.cnmfe_residual(eng._ctx, 0, 2, np.array([0, 1, 2], np.int64).ctypes.data_as(L.i64p), np.array([3, 5], np.int32).ctypes.data_as(L.i32p),
+                                     np.ones(2, np.float32).ctypes.data_as(L.f32p), bad.ctypes.data_as(L.f32p), L.BOUND_ROWS, None, L.HOST))
+    eng.bind_traces(None)
+
+
+def test_bind_traces_from_device_pointer(eng):
+    """cnmfe_traces_bind accepts a device pointer (the sharded temporal update binds the all-reduced C without a host round trip)"""
+    import torch
+    d1, d2, T, r = 36, 32, 100, 5
+    f, Y, video = _video(eng, d1, d2, T, 4, r, 23)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.bind_traces(None)
+    eng.fit_ring_model(0, A, Cm)
+    y0 = eng.residual(0, A, Cm, want=True)
+    t = torch.from_numpy(Cm).to("cuda:0").contiguous()
+    torch.cuda.synchronize()
+    eng.bind_traces(Cm, device_ptr=t.data_ptr())
+    eng.set_b0(0, eng.b0(0)); y_ref = eng.residual(0, A, Cm.copy(), want=True)     # (b0 now fp32-rounded: reference for the bound run)
+    eng.set_b0(0, eng.b0(0)); y1 = eng.residual(0, A, Cm, want=True)               # Cm is the bound identity -> (NULL, CNMFE_BOUND)
+    assert np.array_equal(y_ref, y1)
+    assert np.abs(y0 - y1).max() <= 1e-5 * np.abs(y0).max()
+    eng.bind_traces(None)
