@@ -61,6 +61,39 @@ class BoundRows:
         return np.asarray(self).mean(*a, **k)
 
 
+class DeviceTraces:
+    """A K x T fp32 trace matrix that lives in a torch DEVICE tensor (what the sharded temporal update's all-reduce produces).  It is bound on
+    the engine device-to-device, row subsets go through BoundRows, row means are taken on the device; a host copy is only made when
+    somebody actually reads the values (np.asarray), and then kept."""
+    def __init__(self, tensor):
+        self.tensor = tensor.contiguous()
+        self.shape = tuple(int(x) for x in tensor.shape)
+        self.dtype = np.dtype(np.float32)
+        self.ndim = 2
+        self.flags = {"C_CONTIGUOUS": True}
+        self._host = None
+    def host(self):
+        if self._host is None:
+            self._host = self.tensor.cpu().numpy()
+        return self._host
+    def __array__(self, dtype=None, copy=None):
+        a = self.host()
+        return a if dtype is None else a.astype(dtype, copy=False)
+    def __getitem__(self, key):
+        return self.host()[key]
+    def __len__(self):
+        return self.shape[0]
+    def mean(self, axis=None, dtype=None, **k):
+        import torch
+        if axis == 1 and self._host is None:
+            return self.tensor.to(torch.float64).mean(dim=1).cpu().numpy().astype(dtype or np.float64)
+        return self.host().mean(axis=axis, dtype=dtype, **k)
+    def copy(self):
+        return self.host().copy()
+    def data_ptr(self):
+        return self.tensor.data_ptr()
+
+
 class Engine:
     # -- bound traces: obj.C is the same matrix for several calls of one iteration; bind_traces uploads it once and every
     # call that is handed THAT array object afterwards passes (NULL, CNMFE_BOUND).  The array must not be mutated in place
@@ -69,6 +102,8 @@ class Engine:
         """device_ptr: address of a row-major fp32 DEVICE copy of Cm (e.g. the tensor an all-reduce just produced): the engine then binds
         with a device-to-device copy; Cm stays the host-side identity of the bound matrix"""
         Cm = None if Cm is None or Cm.shape[0] == 0 else Cm
+        if isinstance(Cm, DeviceTraces):
+            device_ptr = Cm.data_ptr()
         if Cm is None or Cm.dtype != np.float32 or not Cm.flags["C_CONTIGUOUS"]:
             self._bound = None
             L.check(L.lib.cnmfe_traces_bind(self._ctx, 0, 0, None, L.ROWMAJOR))

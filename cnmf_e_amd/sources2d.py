@@ -22,7 +22,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import scipy.sparse as sp
 
-from .engine import BoundRows, Engine
+from .engine import BoundRows, DeviceTraces, Engine
 
 __all__ = ["Options", "PatchedVideo", "Sources2D", "distribute_geometry", "determine_search_location"]
 
@@ -247,12 +247,7 @@ class Sources2D:
     def _bind_C(self):
         """one upload of obj.C per iteration instead of one per engine call (cnmfe_traces_bind)"""
         if hasattr(self.engine, "bind_traces"):
-            dev = getattr(self, "_C_dev", None)
-            self._C_dev = None
-            if dev is not None and dev[0] is self.C:
-                self.engine.bind_traces(self.C, device_ptr=dev[1].data_ptr())
-            else:
-                self.engine.bind_traces(self.C)
+            self.engine.bind_traces(self.C)
 
     def _residual(self, idx, A_prev_b, C_prev_b):
         """the background-subtraction expression of update_spatial_parallel.m:162-178 / update_temporal_parallel.m:149-165"""
@@ -325,11 +320,10 @@ class Sources2D:
         C_raw = buf[:, :T] / aa                                                                       # :280
         if not self.options.deconv_flag:
             C_raw = C_raw - C_raw.min(dim=1, keepdim=True).values                                     # :285
-        C_raw = C_raw.contiguous()
-        host = C_raw.cpu().numpy()
-        if nccl and not self.options.deconv_flag:
-            self._C_dev = (host, C_raw)                                    # the next _bind_C binds device-to-device (no H2D of K x T)
-        return host
+        if nccl and not self.options.deconv_flag and hasattr(self.engine, "bind_traces"):
+            torch.cuda.current_stream().synchronize()                      # the engine reads the tensor on its own stream
+            return DeviceTraces(C_raw)                                     # K x T stays on the device: bound device-to-device, host copy on demand
+        return C_raw.contiguous().cpu().numpy()
 
     def _update_b0_new(self):
         """obj.b0_new = Ymean - A*mean(C,2) (update_spatial_parallel.m:349).  Evaluated on first read from the
@@ -643,7 +637,7 @@ class Sources2D:
         else:
             if not sharded and single is None:
                 C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285 (sharded: done on the device)
-            self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
+            self.C_raw = C_raw if isinstance(C_raw, DeviceTraces) else np.ascontiguousarray(C_raw, dtype=np.float32)
             self.C = self.C_raw                                                                       # :286
             self._bind_C()
         self._update_b0_new()                                                                         # :291-295

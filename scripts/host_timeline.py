@@ -4,18 +4,25 @@ import argparse, os, sys, time, functools
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1)
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
 from cnmf_e_amd.engine import Engine
 from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-d1, d2, T, K, r, seed = 512, 512, 10000, 500, 15, 2
+d1, d2, T, K, r, seed = 512, 512 * a.npatch, 10000, 500 * a.npatch, 15, 2
 f = synth.make_factors(d1, d2, T, K, seed)
 Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
 eng = Engine(0)
-video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
-video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
+video = PatchedVideo(d1, d2, T, [512, 512], r, eng)
+if a.npatch == 1:
+    video.upload_block_device((0, 0), Yd.data_ptr())
+else:
+    del Yd
+    for idx in video.owned:
+        Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()
+        video.upload_block_device(idx, Yb.data_ptr()); del Yb
+Yd = None; torch.cuda.empty_cache()
 log = []
 import threading
 main = threading.get_ident()
@@ -31,11 +38,15 @@ for name in dir(Engine):
     setattr(Engine, name, wrap(fn, name))
 s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub), f.A_init, f.C_init, f.sn)
 marks = []
+import cProfile, pstats
+prof = cProfile.Profile() if a.cprofile else None
 for it in range(a.iters):
     torch.cuda.synchronize(); del log[:]; t0 = time.perf_counter()
+    if prof and it == a.iters - 1: prof.enable()
     s.update_background_parallel(); tb = time.perf_counter()
     s.update_spatial_parallel(); ts = time.perf_counter()
     s.update_temporal_parallel(); tt = time.perf_counter()
+    if prof and it == a.iters - 1: prof.disable()
     torch.cuda.synchronize(); te = time.perf_counter()
     print("iteration %d: %.1f ms" % (it, (te - t0) * 1e3), flush=True)
 print("last iteration: bg %.1f  spatial %.1f  temporal %.1f  drain %.1f  total %.1f ms" % ((tb - t0) * 1e3, (ts - tb) * 1e3, (tt - ts) * 1e3, (te - tt) * 1e3, (te - t0) * 1e3))
@@ -45,3 +56,6 @@ for name, a0, a1, on_main in log:
         print("      [thread] %-22s %.2f ms (at %.1f)" % (name, (a1 - a0) * 1e3, (a0 - t0) * 1e3)); continue
     print("%7.2f ms python | %-22s %7.2f ms in call (at %.1f)" % ((a0 - prev) * 1e3, name, (a1 - a0) * 1e3, (a0 - t0) * 1e3)); prev = a1
 print("%7.2f ms python tail" % ((tt - prev) * 1e3))
+
+if prof:
+    st = pstats.Stats(prof); st.sort_stats("tottime").print_stats(28)

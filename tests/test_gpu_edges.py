@@ -340,3 +340,29 @@ def test_bind_traces_from_device_pointer(eng):
     assert np.array_equal(y_ref, y1)
     assert np.abs(y0 - y1).max() <= 1e-5 * np.abs(y0).max()
     eng.bind_traces(None)
+
+
+def test_device_traces_handle(eng):
+    """DeviceTraces: a trace matrix that stays in a torch device tensor -- bound device-to-device, subsets via BoundRows, host copy on demand"""
+    import torch
+    from cnmf_e_amd.engine import BoundRows, DeviceTraces
+    d1, d2, T, r = 36, 32, 100, 5
+    f, Y, video = _video(eng, d1, d2, T, 5, r, 27)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.bind_traces(None)
+    eng.fit_ring_model(0, A, Cm); eng.set_b0(0, eng.b0(0))
+    y0 = eng.residual(0, A, Cm, want=True)
+    ind = np.array([0, 3, 4])
+    eng.set_b0(0, eng.b0(0)); y0s = eng.residual(0, A[:, ind], Cm[ind], want=True)
+    h = DeviceTraces(torch.from_numpy(Cm).to("cuda:0")); torch.cuda.synchronize()
+    eng.bind_traces(h)
+    assert h._host is None                                              # nothing downloaded so far
+    assert np.allclose(h.mean(axis=1, dtype=np.float64), Cm.mean(axis=1, dtype=np.float64), rtol=1e-6) and h._host is None
+    eng.set_b0(0, eng.b0(0)); y1 = eng.residual(0, A, h, want=True)
+    eng.set_b0(0, eng.b0(0)); y1s = eng.residual(0, A[:, ind], BoundRows(h, ind), want=True)
+    assert h._host is None
+    assert np.array_equal(y0, y1) and np.array_equal(y0s, y1s)
+    assert np.array_equal(np.asarray(h), Cm) and h._host is not None
+    eng.bind_traces(None)
