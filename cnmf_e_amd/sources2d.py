@@ -401,11 +401,10 @@ class Sources2D:
                 _, infos[idx] = self.engine.fit_ring_model_ssub(v.pid[idx], self.pid_fit[idx], self.pid_res[idx], self.ssub,
                                                                 A_block if A_block.shape[1] else None, C_block,
                                                                 o.thresh_outlier, o.bg_acceleration)
-        if self.dist is not None and v.world_size > 1:
-            self.b0_new = self.reconstruct_b0()                            # :315 (a collective when sharded: evaluate now, on every rank)
-        else:
-            self._b0_new_src = "b0"                                        # :315, evaluated on first read (b0 only changes in this method),
-            #                                                                so the call returns with the fit still running on the GPU
+        # :315, evaluated on first read (b0 only changes in this method), so the call returns with the fit still running on the GPU.
+        # Sharded: that first read is a collective (all-reduce of the stitched image) -- like every method of this class it must then be
+        # made by all ranks at the same point of the program; nobody reading it costs nothing (update_spatial_parallel replaces it).
+        self._b0_new_src = "b0"
         self.A_prev = self.A                                               # :316 (no copy needed: A, C are replaced, not mutated)
         self._prev_csr_src = self.A
         self.C_prev = self.C                                               # :317
@@ -550,11 +549,29 @@ class Sources2D:
         """all-gather of the per-rank rows of A (disjoint pixel sets, no reduction)."""
         if self.dist is None or self.video.world_size == 1:
             return A_
+        import torch
         import torch.distributed as td
         coo = A_.tocoo()
-        parts = [None] * self.video.world_size
-        td.all_gather_object(parts, (coo.row, coo.col, coo.data), group=self.dist)
-        r = np.concatenate([p[0] for p in parts]); c = np.concatenate([p[1] for p in parts]); d_ = np.concatenate([p[2] for p in parts])
+        nccl = td.get_backend(self.dist) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+        W = self.video.world_size
+        # two tensor collectives (sizes, then one padded int32 [3, nmax] block per rank: row, col, value bits) instead of pickled objects
+        n = torch.tensor([coo.nnz], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(W)]
+        td.all_gather(sizes, n, group=self.dist)
+        sizes = [int(x.item()) for x in sizes]
+        nmax = max(1, max(sizes))
+        buf = torch.zeros((3, nmax), dtype=torch.int32)
+        buf[0, :coo.nnz] = torch.from_numpy(coo.row.astype(np.int32))
+        buf[1, :coo.nnz] = torch.from_numpy(coo.col.astype(np.int32))
+        buf[2, :coo.nnz] = torch.from_numpy(np.ascontiguousarray(coo.data, dtype=np.float32).view(np.int32))
+        buf = buf.to(dev)
+        out = [torch.empty_like(buf) for _ in range(W)]
+        td.all_gather(out, buf, group=self.dist)
+        out = [o.cpu().numpy() for o in out]
+        r = np.concatenate([o[0, :m] for o, m in zip(out, sizes)]).astype(np.int64)
+        c = np.concatenate([o[1, :m] for o, m in zip(out, sizes)])
+        d_ = np.concatenate([np.ascontiguousarray(o[2, :m]).view(np.float32) for o, m in zip(out, sizes)])
         return sp.csc_matrix((d_, (r, c)), shape=A_.shape)
 
     # -- temporal -----------------------------------------------------------------------

@@ -10,11 +10,17 @@ import torch
 from cnmf_e_amd import synth
 from cnmf_e_amd.engine import Engine
 from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+group = None
+if world > 1:                                   # sharded run on ONE device (gloo): host-side costs of rank 0; kernel times are inflated by the shared GPU
+    import torch.distributed as td
+    td.init_process_group(backend="gloo"); group = td.group.WORLD
+    a.npatch = world
 d1, d2, T, K, r, seed = 512, 512 * a.npatch, 10000, 500 * a.npatch, 15, 2
 f = synth.make_factors(d1, d2, T, K, seed)
 Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
 eng = Engine(0)
-video = PatchedVideo(d1, d2, T, [512, 512], r, eng)
+video = PatchedVideo(d1, d2, T, [512, 512], r, eng, rank=rank, world_size=world)
 if a.npatch == 1:
     video.upload_block_device((0, 0), Yd.data_ptr())
 else:
@@ -36,7 +42,9 @@ for name in dir(Engine):
             log.append((name, t0, t1, threading.get_ident() == main)); return r_
         return w
     setattr(Engine, name, wrap(fn, name))
-s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub), f.A_init, f.C_init, f.sn)
+s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub), f.A_init, f.C_init, f.sn, dist_group=group)
+if rank != 0:
+    sys.stdout = open(os.devnull, 'w')
 marks = []
 import cProfile, pstats
 prof = cProfile.Profile() if a.cprofile else None
