@@ -134,29 +134,38 @@ struct Pools { double *v, *w; int *t, *l; int n; };
 // current pool list (v, w recomputed by the caller).  gl = g^l is carried multiplicatively.
 __device__ void oasis_seq(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, int warm) {
     const int nin = warm ? P.n : T;
-    // the stack is built in place: output index <= input index, so reading input i never sees an overwritten slot
+    // the stack is built in place: output index <= input index, so reading input i never sees an overwritten slot.
+    // This loop is one lane's dependent fp64 chain, so its length is what matters:
+    //  * the pool under the current one is mirrored in registers (pv, pw, pt, pl, pgl): the back-track test that follows every merge costs
+    //    no memory round trip (the stack lives in global memory; one dependent L2 read per sample made this loop 1 us per sample) and no
+    //    pow(); memory is read only after a back-track merge succeeded;
+    //  * the pool values v/w are compared cross-multiplied (weights are sums of g^2j > 0), which removes three fp64 divisions (~35
+    //    dependent instructions each) per sample: v_n/w_n >= (v/w) g^l + smin  <=>  v_n w >= (v g^l + smin w) w_n, and
+    //    v/w < max(v_p/w_p g^lp, 0) + smin  <=>  v w_p < (max(v_p g^lp, 0) + smin w_p) w.  (Same decisions as oasisAR1.m:64-65,83-85 up to
+    //    the last-bit rounding of either form.)
     double cv, cw, cgl; int ct, cl;
     if (warm) { cv = P.v[0]; cw = P.w[0]; ct = P.t[0]; cl = P.l[0]; cgl = pow(g, (double)cl); }
     else { cv = ((double)y[0] - bsub) - lam * (1 - g); if (T == 1) cv = ((double)y[0] - bsub) - lam; cw = 1.0; ct = 1; cl = 1; cgl = g; }
     int top = 0;                                  // number of pools already on the stack (below cur)
-    double crat = cv / cw;
+    double pv = 0, pw = 1, pgl = 1; int pt = 0, pl = 0;            // mirror of stack entry top-1 (valid when top > 0)
+    const double lam_in = lam * (1 - g);
     for (int i = 1; i < nin; ++i) {
         double nv, nw; int nt, nl; double ngl;
         if (warm) { nv = P.v[i]; nw = P.w[i]; nt = P.t[i]; nl = P.l[i]; ngl = pow(g, (double)nl); }
-        else { nv = ((double)y[i] - bsub) - (i == T - 1 ? lam : lam * (1 - g)); nw = 1.0; nt = i + 1; nl = 1; ngl = g; }
-        if (nv / nw >= crat * cgl + smin) {       // oasisAR1.m:64-65: no violation, advance
+        else { nv = ((double)y[i] - bsub) - (i == T - 1 ? lam : lam_in); nw = 1.0; nt = i + 1; nl = 1; ngl = g; }
+        if (nv * cw >= fma(smin, cw, cv * cgl) * nw) {                 // oasisAR1.m:64-65: no violation, advance
             P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl; ++top;
-            cv = nv; cw = nw; ct = nt; cl = nl; cgl = ngl; crat = cv / cw;
+            pv = cv; pw = cw; pt = ct; pl = cl; pgl = cgl;
+            cv = nv; cw = nw; ct = nt; cl = nl; cgl = ngl;
             continue;
         }
-        cv += nv * cgl; cw += nw * cgl * cgl; cl += nl; cgl *= ngl; crat = cv / cw;      // :74-76 merge
+        cv = fma(nv, cgl, cv); cw = fma(nw * cgl, cgl, cw); cl += nl; cgl *= ngl;       // :74-76 merge
         while (top > 0) {                          // :83-95 backtrack
-            const double pv = P.v[top - 1], pw = P.w[top - 1]; const int pl = P.l[top - 1];
-            const double pgl = pow(g, (double)pl);
-            const double lim = pv / pw * pgl;
-            if (!(crat < (lim > 0.0 ? lim : 0.0) + smin)) break;
-            cv = pv + cv * pgl; cw = pw + cw * pgl * pgl; ct = P.t[top - 1]; cl = pl + cl; cgl = pgl * cgl; crat = cv / cw;
+            const double lim = pv * pgl;
+            if (!(cv * pw < fma(smin, pw, lim > 0.0 ? lim : 0.0) * cw)) break;
+            cv = fma(cv, pgl, pv); cw = fma(cw * pgl, pgl, pw); ct = pt; cl = pl + cl; cgl = pgl * cgl;
             --top;
+            if (top > 0) { pv = P.v[top - 1]; pw = P.w[top - 1]; pt = P.t[top - 1]; pl = P.l[top - 1]; pgl = pow(g, (double)pl); }
         }
     }
     P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
