@@ -124,7 +124,7 @@ struct Patch {
     // footprint term (W*A)(C - mean C), whose applied instance is kept beside it (ELL rows + centred traces) -- see residual_run
     DevBuf ysig;
     bool ysig_valid = false;
-    bool res_ac = false, res_plain = false; int64_t res_ldc = 0;   // res_plain: Ysig came from cnmfe_residual itself (not the bg_ssub path)
+    bool res_ac = false; int res_kind = 0; int64_t res_ldc = 0;    // res_kind: who wrote Ysig and the term beside it: 1 = cnmfe_residual, 2 = cnmfe_residual_ssub (0: no term kept)
     DevBuf resCnt, resK, resV, resCc;
     // a footprint term asked for by the last cnmfe_residual but not yet folded into Ysig: cnmfe_hals_temporal only needs A' Ysig and adds
     // A' (W A)(C - mean C) algebraically (factor.hip), every other consumer calls residual_materialize first
@@ -147,6 +147,7 @@ struct cnmfe_ctx {
     // scratch shared by all patches of this context (sized for the largest)
     cnmfe::DevBuf bound;      // trace matrix bound with cnmfe_traces_bind (K x ldc fp32), passed as c_order = CNMFE_BOUND
     int32_t bound_K = 0; int64_t bound_T = 0; int bound_order = 1; bool bound_valid = false;
+    int64_t last_ldc = 0;     // row stride of the centred traces the last residual_run left in tmp[1]
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
@@ -176,7 +177,7 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only = 0);
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
-                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr);
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr, int tables_only = 0);
 int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out_memspace);
 int residual_materialize(cnmfe_ctx *ctx, Patch *P);       // fold a pending footprint term into the resident Ysig (no-op without one)
 int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu, int *dOverflow);   // 1: cannot be applied, materialise instead; *dOverflow set on the device if a footprint meets > 512 traces

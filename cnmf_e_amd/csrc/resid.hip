@@ -864,11 +864,11 @@ int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dC
 }
 
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
-                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf) {
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf, int tables_only) {
     const int64_t T = P->T;
     DevBuf &ysig = outbuf ? *outbuf : P->ysig;               // bg_ssub > 1 sweeps the low-resolution patch into its own buffer
     // the resident Ysig of this patch is still the residual under the current video, W and b0: only the footprint term changes
-    const bool delta = !outbuf && P->ysig_valid && P->res_plain && P->ysig.p && ctx->opt("r1_delta", 1) != 0;
+    const bool delta = !outbuf && P->ysig_valid && P->res_kind == 1 && P->ysig.p && ctx->opt("r1_delta", 1) != 0;
     RET(ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
            &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10], &dFlag = ctx->tmp[11];
@@ -895,10 +895,11 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         CK(hipStreamSynchronize(ctx->stream));
         if (flag) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than %d footprints of A_prev", WA_CAP);
     }
+    if (tables_only) { ctx->last_ldc = ldc; return 0; }       // bg_ssub: the caller only wants (W*A) and the centred traces (tmp[8..10], tmp[1])
     // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)
     auto keep = [&]() {
         if (outbuf) return;
-        P->res_ac = has_ac; P->res_ldc = ldc; P->res_plain = true; P->res_K = Ksel; P->pend = false;
+        P->res_ac = has_ac; P->res_ldc = ldc; P->res_kind = 1; P->res_K = Ksel; P->pend = false;
         if (has_ac) { P->resCnt.swap(dWaCnt); P->resK.swap(dWaK); P->resV.swap(dWaV); P->resCc.swap(dCc); }
     };
     if (delta) {
@@ -983,6 +984,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     }
     RET(rc);
     keep();
+    ctx->last_ldc = ldc;
     P->ysig_valid = true;
     if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
     // without an output buffer the call returns with the kernel in flight: every consumer of Ysig is an engine

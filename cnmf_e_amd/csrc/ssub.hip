@@ -335,6 +335,45 @@ int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, 
     return 0;
 }
 
+// (W A)(C - mean C) of the low-resolution sweep, seen from the full-resolution patch: up[(W A_low)] as ELL rows per patch pixel.
+// wa_up(i, l) = sum over the row / column taps of pixel i of w_r w_c wa_low(j(r,c), l).  One thread per patch pixel, its <= UP_CAP slots in LDS.
+constexpr int UP_CAP = 32;
+__global__ void __launch_bounds__(128) k_wa_upsample(int64_t d, int nr, int nr_b, int roff, int coff, int d1s, int64_t d_low, const int *__restrict__ ir,
+                                                     const float *__restrict__ wr, int Pr, const int *__restrict__ ic, const float *__restrict__ wc, int Pc,
+                                                     const int *__restrict__ cnt_l, const int *__restrict__ k_l, const float *__restrict__ v_l,
+                                                     int *__restrict__ cnt, int *__restrict__ kk, float *__restrict__ vv, int *__restrict__ overflow) {
+    __shared__ int tk[UP_CAP][128];
+    __shared__ float tv[UP_CAP][128];
+    const int64_t m = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (m >= d) return;
+    const int t = threadIdx.x;
+    const int rb = (int)(m % nr) + roff, cb = (int)(m / nr) + coff;
+    int n = 0;
+    for (int u = 0; u < Pc; ++u) {
+        const float wcu = wc[cb * Pc + u];
+        if (wcu == 0.f) continue;
+        const int jc = ic[cb * Pc + u];
+        for (int q = 0; q < Pr; ++q) {
+            const float w = wcu * wr[rb * Pr + q];
+            if (w == 0.f) continue;
+            const int64_t j = (int64_t)jc * d1s + ir[rb * Pr + q];
+            const int ne = cnt_l[j];
+            for (int e = 0; e < ne; ++e) {
+                const int k = k_l[(int64_t)e * d_low + j];
+                int s_ = 0;
+                while (s_ < n && tk[s_][t] != k) ++s_;
+                if (s_ == n) {
+                    if (n == UP_CAP) { *overflow = 1; continue; }
+                    tk[s_][t] = k; tv[s_][t] = 0.f; ++n;
+                }
+                tv[s_][t] = fmaf(w, v_l[(int64_t)e * d_low + j], tv[s_][t]);
+            }
+        }
+    }
+    cnt[m] = n;
+    for (int s_ = 0; s_ < n; ++s_) { kk[(int64_t)s_ * d + m] = tk[s_][t]; vv[(int64_t)s_ * d + m] = tv[s_][t]; }
+}
+
 int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int ssub, int32_t K, const int64_t *cp, const int32_t *ri,
                   const float *va, const float *C, int c_order, float *Ysig_out, int out_memspace) {
     int d1s, d2s; low_dims(M, ssub, d1s, d2s);
@@ -342,14 +381,51 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
     const bool has_a = K > 0 && cp[K] > 0;
     if (has_a) a_low(M, ssub, false, K, cp, ri, va, ocp, ori, ova);
-    // low-resolution sweep: ysig_low = down(Y') - W * (down(Y') - down(A_prev) (C - mean C))
-    RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low));
-    // upsample W*(...) to the block (imresize(Bf, [nr_block nc_block])) and combine on the patch pixels
+    // Ysig = [Y' + (Ymean - b0) - up(W down(Y'))] + up(W down(A_prev)) (C - mean C): while the video, W (of the residual patch) and b0 are
+    // unchanged a further call only changes the second bracket, exactly as in cnmfe_residual -- its full-resolution ELL form (k_wa_upsample)
+    // goes through the same pending-term / streaming-delta machinery (resid.hip), so the iteration does ONE low-resolution sweep + upsample.
+    const bool reuse = M->ysig_valid && M->res_kind == 2 && M->ysig.p && ctx->opt("r1_delta", 1) != 0;
+    RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, reuse ? 1 : 0));
+    const int64_t ldc_t = ctx->last_ldc;
+    DevBuf tCc;                                               // the centred traces of this call (tmp[1] is about to hold tap weights)
+    if (has_a) tCc.swap(ctx->tmp[1]);
     Taps tr = make_taps(d1s, M->nr_b, (double)M->nr_b / d1s, false), tc = make_taps(d2s, M->nc_b, (double)M->nc_b / d2s, false);
     DevBuf &dIr = ctx->tmp[0], &dWr = ctx->tmp[1], &dIc = ctx->tmp[2], &dWc = ctx->tmp[3], &dDlt = ctx->tmp[7];
     RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
     RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
-    CK(hipStreamSynchronize(ctx->stream));                    // the tap vectors die with this call
+    // the footprint term of this call at full resolution: into the pending (reuse) or the applied slot of the main patch
+    bool term_ok = true;
+    {
+        DevBuf &tCnt = reuse ? M->pendCnt : M->resCnt, &tK = reuse ? M->pendK : M->resK, &tV = reuse ? M->pendV : M->resV;
+        if (has_a) {
+            DevBuf &dFlag = ctx->tmp[11];
+            RET(tCnt.ensure((size_t)M->d * sizeof(int))); RET(tK.ensure((size_t)UP_CAP * M->d * sizeof(int))); RET(tV.ensure((size_t)UP_CAP * M->d * sizeof(float)));
+            RET(dFlag.ensure(64));
+            CK(hipMemsetAsync(dFlag.p, 0, 64, ctx->stream));
+            LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + 127) / 128)), dim3(128), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
+                   dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P, ctx->tmp[8].as<int>(), ctx->tmp[9].as<int>(), ctx->tmp[10].as<float>(),
+                   tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dFlag.as<int>());
+            int flag = 0;
+            CK(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            term_ok = flag == 0;                              // a pixel near more than UP_CAP footprints: no term kept, the next call sweeps again
+            (reuse ? M->pendCc : M->resCc).swap(tCc);
+        } else CK(hipStreamSynchronize(ctx->stream));         // the tap vectors die with this call
+        if (reuse && term_ok) {
+            M->pend = true; M->pend_ac = has_a; M->pend_ldc = ldc_t; M->pend_K = K;
+            if (ctx->opt("r1_lazy", 1) == 0 || Ysig_out) RET(residual_materialize(ctx, M));
+            if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
+            return 0;
+        }
+        if (reuse) {                                           // (overflow) fall back to the sweep: the tables are there, run it now
+            RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, 0));
+            RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
+            RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
+            CK(hipStreamSynchronize(ctx->stream));
+        }
+        M->res_ac = has_a && term_ok; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
+        M->res_kind = term_ok ? 2 : 0;
+    }
     const int64_t ntmp = (int64_t)d1s * M->nc_b;
     RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));
     RET(M->ysig.ensure((size_t)M->d * M->Tc * sizeof(float4)));
@@ -379,7 +455,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
         LAUNCH(ctx, "ssub_up_fused", k_up_fused, dim3((unsigned)ntile, (unsigned)nseg), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(), d1s, R->d_b,
                M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->nc, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(),
                dIc.as<int>(), dWc.as<float>(), ntr, M->Tc, cseg, M->ysig.as<float4>());
-        M->ysig_valid = true; M->res_plain = false; M->pend = false;
+        M->ysig_valid = true;
         if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
         return 0;
     }
@@ -388,7 +464,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     LAUNCH(ctx, "ssub_up_rows_combine", k_up_rows_combine, dim3((unsigned)((M->d + 255) / 256), (unsigned)M->Tc), dim3(256), 0, ctx->up_tmp.as<float4>(), d1s,
            M->nc_b, M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(), tr.P,
            M->ysig.as<float4>());
-    M->ysig_valid = true; M->res_plain = false; M->pend = false;
+    M->ysig_valid = true;
     if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
     return 0;
 }

@@ -509,3 +509,48 @@ def test_method_level_iteration_bg_ssub(eng):
         assert rel(Ag[same], Ar[same]) <= 2e-3, (it, rel(Ag[same], Ar[same]))
         s.update_temporal_parallel(); o.update_temporal_parallel()
         assert rel(s.C, o.C) <= 2e-3, (it, rel(s.C, o.C))
+
+
+def test_residual_ssub_footprint_term_reuse(eng):
+    """bg_ssub > 1: a second cnmfe_residual_ssub under the same W, b0 only changes up[(W down(A))](C - mean C); its full-resolution ELL form
+    goes through the pending-term / delta machinery of cnmfe_residual.  Every transition must agree with the full sweep + upsample, and
+    cnmfe_hals_temporal on a pending term with the materialised one."""
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2, T, K, r, ssub = 41, 38, 96, 6, 6, 2
+    f = synth.make_factors(d1, d2, T, K, 31, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    rr = -(-r // ssub)
+    pid, pres = 0, 3
+    eng.ring_init(pid, r); eng.patch_derive(pid, pres, ssub, "bicubic"); eng.ring_init(pres, rr)
+    rng = np.random.default_rng(5)
+    W0 = eng.ring_csr(pres)
+    eng.ring_set_values(pres, (W0.data * (1 + 0.3 * rng.standard_normal(W0.nnz))).astype(np.float32))
+    b0 = (500 + 20 * rng.standard_normal(d1 * d2)).astype(np.float32)
+    A = sp.csc_matrix(f.A_init.astype(np.float32)); Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    sel = [np.array([0, 2]), np.arange(K), np.arange(0), np.array([1, 3, 4, 5])]
+    def run(delta):
+        eng.set_option("r1_delta", delta)
+        eng.set_b0(pid, b0)                                  # invalidates: the first call is a sweep + upsample
+        return [eng.residual_ssub(pid, pres, ssub, A[:, s_] if len(s_) else None, Cm[s_] if len(s_) else None, want=True) for s_ in sel]
+    try:
+        full, inc = run(0), run(1)
+        scale = max(np.abs(x).max() for x in full)
+        for a_, b_ in zip(full, inc):
+            assert np.abs(a_ - b_).max() <= 3e-6 * scale
+        def temporal(lazy):
+            eng.set_option("r1_lazy", lazy); eng.set_b0(pid, b0)
+            eng.residual_ssub(pid, pres, ssub, A[:, :2], Cm[:2])
+            eng.profile(True); eng.profile_reset()
+            eng.residual_ssub(pid, pres, ssub, A, Cm)
+            c = eng.hals_temporal(pid, A, Cm, 3)
+            tab = eng.profile_table(); eng.profile(False)
+            return c, sum(v["calls"] for k_, v in tab.items() if k_ in ("ssub_up_fused", "ssub_up_cols", "residual_delta"))
+        (c0, n0), (c1, n1) = temporal(0), temporal(1)
+        assert n0 == 1 and n1 == 0                           # lazy: no pass over the video for the second residual
+        for a_, b_ in zip(c0, c1):
+            # (b0 is offset by ~500 here, so Ysig ~ 5e2 and its fp32 rounding, 3e-5 per element, is what the two associations differ by)
+            assert np.abs(a_ - b_).max() <= 1e-4 * max(1.0, np.abs(a_).max()), (np.abs(a_ - b_).max(), np.abs(a_).max())
+    finally:
+        eng.set_option("r1_delta", 1); eng.set_option("r1_lazy", 1)
