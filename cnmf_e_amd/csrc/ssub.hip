@@ -322,16 +322,17 @@ int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, 
              const float *C, int c_order, int with_projection, int64_t info[4]) {
     std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
     if (K > 0) a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
-    // W: fit_ring_model(imresize(Y - A*C, 1/s, 'nearest'), [], [], W_old, ...)  (update_background_parallel.m:224-227)
+    // b0 = mean(Y - A*C, 2) on the patch pixels (:222-223) = Ymean - A*mean(C): independent of W, so it goes first (a short, synchronous call)
+    RET(bg_fit_ring(ctx, M, K, cp, ri, va, C, c_order, with_projection, nullptr, nullptr, /*b0_only=*/1));
+    // W: fit_ring_model(imresize(Y - A*C, 1/s, 'nearest'), [], [], W_old, ...)  (update_background_parallel.m:224-227).  The call returns with the
+    // Gram / solve kernels in flight (its host staging has been consumed); the copy of W to the residual patch is ordered behind them.
     RET(bg_fit_ring(ctx, F, K, K > 0 ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, with_projection, nullptr, info, /*A = [] for ind_active*/ 2));
     if (R && R != F) {
         if (R->p != F->p || R->d != F->d) return fail(CNMFE_ESTATE, "fit / residual low-resolution patches have different rings");
         CK(hipMemcpyAsync(R->W.p, F->W.p, (size_t)F->p * F->d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         R->ysig_valid = false;
     }
-    // b0 = mean(Y - A*C, 2) on the patch pixels (:222-223) = Ymean - A*mean(C)
-    RET(bg_fit_ring(ctx, M, K, cp, ri, va, C, c_order, with_projection, nullptr, nullptr, /*b0_only=*/1));
-    CK(hipStreamSynchronize(ctx->stream));
+    M->ysig_valid = false;
     return 0;
 }
 

@@ -119,7 +119,9 @@ def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
     D, V = np.linalg.eigh(M)                                              # :74 ascending eigenvalues
     d11 = np.minimum(max_size ** 2, np.maximum(min_size ** 2, D[:, 0]))   # :81
     d22 = np.minimum(max_size ** 2, np.maximum(min_size ** 2, D[:, 1]))   # :82
-    R = int(np.ceil(dist * max_size)) + 1
+    # candidate window: the ellipse reaches dist*sqrt(d22) from the centre along its long axis (d22 <= max_size^2); sizing the window by the
+    # largest ellipse actually present instead of the largest possible one cuts the (K, W, W) arrays below ~3x for typical footprints
+    R = min(int(np.ceil(dist * max_size)), int(np.ceil(dist * np.sqrt(float(d22.max()) if K else 0.0)))) + 1
     off = np.arange(-R, R + 1)
     rows = np.floor(cmx)[:, None] + off[None, :]                           # (K, W) candidate rows (1-based)
     cols = np.floor(cmy)[:, None] + off[None, :]
