@@ -1843,7 +1843,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
     g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
     // ---- incremental Gram (k_win_proj / k_cov_correct above): per 16x16 block, the footprints with a pixel within two blocks of it ----
-    bool incr = ctx->opt("gram_incremental", 1) != 0 && ctx->opt("gram_kernel", 4) >= 4 && !(b0_only & 2) && !P->derived && K < 32768;
+    bool incr = ctx->opt("gram_incremental", 1) != 0 && ctx->opt("gram_kernel", 4) >= 4 && K < 32768;   // (derived low-resolution patches of bg_ssub included: their video is built once)
     std::vector<int> lst_ptr, lst_k, blk_nt[4];
     std::vector<short> slot_of;
     if (incr) {
