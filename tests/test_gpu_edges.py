@@ -366,3 +366,17 @@ def test_device_traces_handle(eng):
     assert np.array_equal(y0, y1) and np.array_equal(y0s, y1s)
     assert np.array_equal(np.asarray(h), Cm) and h._host is not None
     eng.bind_traces(None)
+
+
+def test_nccl_device_resident_traces():
+    """the sharded temporal update's device path on a real RCCL group (one rank): _stitch_distributed -> DeviceTraces -> device-to-device bind
+    -> a full iteration that never needs the host copy (scripts/nccl_smoke.py, in its own process: it owns a process group)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "nccl_smoke.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "host copy made: False" in out.stdout and "b0_new ok" in out.stdout
+    import re
+    errs = [float(x) for x in re.findall(r"= ([0-9.e+-]+)", out.stdout)]
+    assert errs and max(errs) < 1e-5
