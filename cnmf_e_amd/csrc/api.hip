@@ -584,6 +584,22 @@ int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     return fast_temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, c_order, C_raw_out, aa_out);
 }
 
+int cnmfe_compute_rss(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                      const float *C, int c_order, const float *b0_block, const float *b0_new, double *rss_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (P->res_kind != 1) return fail(CNMFE_EUNSUPPORTED, "compute_RSS needs the residual of cnmfe_residual (bg_ssub = 1)");
+    if (K < 0 || !b0_block || !b0_new || !rss_out) return fail(CNMFE_EINVAL, "bad K / null b0_block / b0_new / rss_out");
+    if (K > 0) {
+        RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
+        if ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C");
+    }
+    CK(hipSetDevice(ctx->device));
+    return rss_run(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, b0_block, b0_new, rss_out);
+}
+
 int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int c_order) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     ctx->bound_valid = false;

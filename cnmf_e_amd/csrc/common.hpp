@@ -125,11 +125,11 @@ struct Patch {
     DevBuf ysig;
     bool ysig_valid = false;
     bool res_ac = false; int res_kind = 0; int64_t res_ldc = 0;    // res_kind: who wrote Ysig and the term beside it: 1 = cnmfe_residual, 2 = cnmfe_residual_ssub (0: no term kept)
-    DevBuf resCnt, resK, resV, resCc;
+    DevBuf resCnt, resK, resV, resCc, resCm;              // resCm: the means the centred traces were taken about (fp64, per trace)
     // a footprint term asked for by the last cnmfe_residual but not yet folded into Ysig: cnmfe_hals_temporal only needs A' Ysig and adds
     // A' (W A)(C - mean C) algebraically (factor.hip), every other consumer calls residual_materialize first
     bool pend = false, pend_ac = false; int64_t pend_ldc = 0; int32_t pend_K = 0, res_K = 0;
-    DevBuf pendCnt, pendK, pendV, pendCc;
+    DevBuf pendCnt, pendK, pendV, pendCc, pendCm;
     // incremental ring regression (bg.hip): the block-pair covariance table and row sums of the centred VIDEO (no footprints subtracted),
     // valid for one frame stride until the video changes
     DevBuf cov_base, rowsum_base;
@@ -179,6 +179,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr, int tables_only = 0);
 int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out_memspace);
+int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+            const float *b0_block, const float *b0_new, double *rss_out);
 int residual_materialize(cnmfe_ctx *ctx, Patch *P);       // fold a pending footprint term into the resident Ysig (no-op without one)
 int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu, int *dOverflow);   // 1: cannot be applied, materialise instead; *dOverflow set on the device if a footprint meets > 512 traces
 int check_csc_pub(const char *what, int32_t ncol, int64_t nrow, const int64_t *colptr, const int32_t *rowidx);

@@ -168,6 +168,13 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         CHECK(cnmfe_fast_temporal(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), CNMFE_COLMAJOR, Cr.data(), aa.data()));
         pout[0] = to_double(Cr, A.K, (size_t)info_T);
         if (nout > 1) pout[1] = to_double(aa, A.K, 1);
+    } else if (!strcmp(cmd, "compute_rss")) {                // rss = cnmfe_mex('compute_rss', h, pid, A_patch, C, b0_block, b0_new_patch)   (Sources2D.m:1358-1510, one patch)
+        if (nin != 7) FAIL("compute_rss: 7 inputs required (h, pid, A, C, b0_block, b0_new)");
+        Csc A = csc_of(pin[3]);
+        std::vector<float> C = A.K ? f32_of(pin[4]) : std::vector<float>(), bb = f32_of(pin[5]), bn = f32_of(pin[6]);
+        double rss = 0.0;
+        CHECK(cnmfe_compute_rss(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, bb.data(), bn.data(), &rss));
+        pout[0] = mxCreateDoubleScalar(rss);
     } else if (!strcmp(cmd, "get_sn")) {                     // sn = cnmfe_mex('get_sn', h, pid, d)   (update_sn = true)
         if (nin != 4) FAIL("get_sn: 4 inputs required");
         size_t d = (size_t)mxGetScalar(pin[3]);

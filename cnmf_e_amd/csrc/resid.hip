@@ -791,7 +791,7 @@ int residual_materialize(cnmfe_ctx *ctx, Patch *P) {
 #undef DELTA_ARGS
     }
     P->res_ac = P->pend_ac; P->res_ldc = P->pend_ldc; P->res_K = P->pend_K;
-    if (P->pend_ac) { P->resCnt.swap(P->pendCnt); P->resK.swap(P->pendK); P->resV.swap(P->pendV); P->resCc.swap(P->pendCc); }
+    if (P->pend_ac) { P->resCnt.swap(P->pendCnt); P->resK.swap(P->pendK); P->resV.swap(P->pendV); P->resCc.swap(P->pendCc); P->resCm.swap(P->pendCm); }
     P->pend = false;
     return 0;
 }
@@ -863,6 +863,120 @@ int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dC
     return 0;
 }
 
+// ---- compute_RSS (Sources2D.m:1358-1510), ring model, bg_ssub = 1 ------------------------------------------------------------
+// E = Y(patch) - A C - (W (Y_block - b0_block - A_prev C_prev) + b0_new).  With the resident residual of (A_prev, C_prev),
+// Ysig = Yc + (Ymean - b0) - W Yc + (W A_prev)(C_prev - mean):  E = Ysig + kappa - A C,
+// kappa = b0 - b0_new - W (Ymean_block - b0_block) + (W A_prev) mean(C_prev)  -- a per-pixel constant (k_rss_const), so the sum of squares is
+// ONE streaming read of Ysig with the footprint rows A(m,:) applied through the wave-uniform trace lists of the delta kernel.
+__global__ void __launch_bounds__(256) k_rss_const(int64_t d, int nr, int nr_b, int nc_b, int roff, int coff, int p, const int *__restrict__ dr,
+                                                   const int *__restrict__ dc, const float *__restrict__ W, const float *__restrict__ ymean_f,
+                                                   const double *__restrict__ b0, const float *__restrict__ b0blk, const float *__restrict__ b0new,
+                                                   const int *__restrict__ cnt, const int *__restrict__ wk, const float *__restrict__ wv,
+                                                   const double *__restrict__ cm, float *__restrict__ kappa) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= d) return;
+    const int rbm = (int)(m % nr) + roff, cbm = (int)(m / nr) + coff;
+    double s = 0.0;
+    for (int i = 0; i < p; ++i) {
+        const float w = W[(int64_t)i * d + m];
+        const int rb = rbm + dr[i], cb = cbm + dc[i];
+        if (w == 0.f || rb < 0 || rb >= nr_b || cb < 0 || cb >= nc_b) continue;
+        const int64_t q = (int64_t)cb * nr_b + rb;
+        s += (double)w * ((double)ymean_f[q] - (double)b0blk[q]);
+    }
+    double t = 0.0;
+    if (cnt) { const int n = cnt[m]; for (int e = 0; e < n; ++e) t += (double)wv[(int64_t)e * d + m] * cm[wk[(int64_t)e * d + m]]; }
+    kappa[m] = (float)(b0[m] - (double)b0new[m] - s + t);
+}
+
+__global__ void __launch_bounds__(256) k_rss(const float4 *__restrict__ ysig4, int64_t d, int64_t T, int64_t Tc, int64_t cseg, const float *__restrict__ kappa,
+                                             const int *__restrict__ cnt, const int *__restrict__ ak, const float *__restrict__ av,
+                                             const float *__restrict__ C, int64_t ldc, double *__restrict__ partial) {
+    __shared__ double red[4];
+    const int64_t m0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = m0 < d;
+    const int64_t m = valid ? m0 : d - 1;
+    const int n = (cnt && valid) ? cnt[m] : 0;
+    int ke[DELTA_NE]; float ve[DELTA_NE];
+#pragma unroll
+    for (int e = 0; e < DELTA_NE; ++e) { ke[e] = 0; ve[e] = 0.f; if (e < n) { ke[e] = ak[(int64_t)e * d + m]; ve[e] = av[(int64_t)e * d + m]; } }
+    DeltaPlan pl; pl.nl = 0; pl.over = false;
+    if (cnt) delta_plan(n, ke, ve, ldc, -1.f, pl);
+    const float kap = valid ? kappa[m] : 0.f;
+    const int64_t c0 = (int64_t)blockIdx.y * cseg, c1 = c0 + cseg < Tc ? c0 + cseg : Tc;
+    double acc = 0.0;
+    for (int64_t c = c0; c < c1; ++c) {
+        float4 y = ysig4[c * d + m];
+        y.x += kap; y.y += kap; y.z += kap; y.w += kap;
+        if (!pl.over) {
+#pragma unroll
+            for (int j = 0; j < DELTA_NL; ++j)
+                if (j < pl.nl) {
+                    const float4 t = *reinterpret_cast<const float4 *>(C + pl.koff[j] + 4 * c);
+                    y.x = fmaf(pl.w[j], t.x, y.x); y.y = fmaf(pl.w[j], t.y, y.y); y.z = fmaf(pl.w[j], t.z, y.z); y.w = fmaf(pl.w[j], t.w, y.w);
+                }
+        } else {
+            for (int e = 0; e < n; ++e) {
+                const float w = -av[(int64_t)e * d + m];
+                const float4 t = *reinterpret_cast<const float4 *>(C + (int64_t)ak[(int64_t)e * d + m] * ldc + 4 * c);
+                y.x = fmaf(w, t.x, y.x); y.y = fmaf(w, t.y, y.y); y.z = fmaf(w, t.z, y.z); y.w = fmaf(w, t.w, y.w);
+            }
+        }
+        if (valid) {
+            const int64_t t0 = 4 * c;
+            acc += (double)y.x * y.x;
+            if (t0 + 1 < T) acc += (double)y.y * y.y;
+            if (t0 + 2 < T) acc += (double)y.z * y.z;
+            if (t0 + 3 < T) acc += (double)y.w * y.w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
+            const float *b0_block, const float *b0_new, double *rss_out) {
+    RET(residual_materialize(ctx, P));
+    const int64_t T = P->T, d = P->d;
+    DevBuf &dC = ctx->tmp[0], &dCnt = ctx->tmp[3], &dK = ctx->tmp[4], &dV = ctx->tmp[5], &dB0b = ctx->tmp[6], &dB0n = ctx->tmp[7], &dKap = ctx->tmp[12], &dPart = ctx->tmp[13];
+    const bool has_a = K > 0 && A_colptr[K] > 0;
+    int64_t ldc = 4;
+    std::vector<int> cnt; std::vector<int> ek; std::vector<float> ev;
+    if (has_a) {
+        RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
+        cnt.assign((size_t)d, 0);
+        for (int32_t k = 0; k < K; ++k) for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) cnt[A_rowidx[e]]++;
+        int cap = 1; for (int64_t m = 0; m < d; ++m) cap = std::max(cap, cnt[m]);
+        ek.assign((size_t)cap * d, 0); ev.assign((size_t)cap * d, 0.f);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int32_t k = 0; k < K; ++k)
+            for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) { const int64_t m = A_rowidx[e]; const int s_ = cnt[m]++; ek[(size_t)s_ * d + m] = k; ev[(size_t)s_ * d + m] = A_val[e]; }
+        RET(to_dev(ctx, dCnt, cnt.data(), cnt.size())); RET(to_dev(ctx, dK, ek.data(), ek.size())); RET(to_dev(ctx, dV, ev.data(), ev.size()));
+    }
+    RET(to_dev(ctx, dB0b, b0_block, (size_t)P->d_b)); RET(to_dev(ctx, dB0n, b0_new, (size_t)d));
+    RET(dKap.ensure((size_t)d * sizeof(float)));
+    LAUNCH(ctx, "rss_const", k_rss_const, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, d, P->nr, P->nr_b, P->nc_b, P->roff, P->coff, P->p, P->ring_dr.as<int>(),
+           P->ring_dc.as<int>(), P->W.as<float>(), P->ymean_f.as<float>(), P->b0.as<double>(), dB0b.as<float>(), dB0n.as<float>(),
+           P->res_ac ? P->resCnt.as<int>() : nullptr, P->resK.as<int>(), P->resV.as<float>(), P->resCm.as<double>(), dKap.as<float>());
+    const int64_t nblk = (d + 255) / 256;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(P->Tc, (8192 + nblk - 1) / nblk));
+    const int64_t cseg = (P->Tc + nseg - 1) / nseg;
+    nseg = (P->Tc + cseg - 1) / cseg;
+    RET(dPart.ensure((size_t)nblk * nseg * sizeof(double)));
+    LAUNCH(ctx, "rss_sweep", k_rss, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, P->ysig.as<float4>(), d, T, P->Tc, cseg, dKap.as<float>(),
+           has_a ? dCnt.as<int>() : nullptr, dK.as<int>(), dV.as<float>(), dC.as<float>(), ldc, dPart.as<double>());
+    std::vector<double> part((size_t)nblk * nseg);
+    CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (double v : part) s += v;                              // fixed order: reproducible
+    *rss_out = s;
+    return 0;
+}
+
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf, int tables_only) {
     const int64_t T = P->T;
@@ -900,17 +1014,17 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     auto keep = [&]() {
         if (outbuf) return;
         P->res_ac = has_ac; P->res_ldc = ldc; P->res_kind = 1; P->res_K = Ksel; P->pend = false;
-        if (has_ac) { P->resCnt.swap(dWaCnt); P->resK.swap(dWaK); P->resV.swap(dWaV); P->resCc.swap(dCc); }
+        if (has_ac) { P->resCnt.swap(dWaCnt); P->resK.swap(dWaK); P->resV.swap(dWaV); P->resCc.swap(dCc); P->resCm.swap(dCm); }
     };
     if (delta) {
         // lazy: keep the term pending; cnmfe_hals_temporal folds it in algebraically, anybody else materialises it
         if (ctx->opt("r1_lazy", 1) != 0 && !Ysig_out) {
             P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
-            if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); }
+            if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
             return 0;
         }
         P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
-        if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); }
+        if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
         RET(residual_materialize(ctx, P));
         if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
         return 0;

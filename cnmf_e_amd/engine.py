@@ -295,6 +295,18 @@ class Engine:
                                           _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Craw, aa
 
+    def compute_rss(self, pid, A_patch, C_patch, b0_block, b0_new_patch):
+        """RSS of one patch, compute_RSS (Sources2D.m:1358-1510): needs the resident residual of (A_prev, C_prev) on the block"""
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_patch, info["d"]) if A_patch is not None and A_patch.shape[1] else (0, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        cptr, cord, _keep = self._targs(C_patch, K, info["T"])
+        bb = np.ascontiguousarray(b0_block, dtype=np.float32).ravel(); bn = np.ascontiguousarray(b0_new_patch, dtype=np.float32).ravel()
+        if bb.size != info["d_b"] or bn.size != info["d"]:
+            raise ValueError("b0_block / b0_new have %d / %d entries, expected %d / %d" % (bb.size, bn.size, info["d_b"], info["d"]))
+        out = C.c_double(0.0)
+        L.check(L.lib.cnmfe_compute_rss(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord, _p(bb, L.f32p), _p(bn, L.f32p), C.byref(out)))
+        return float(out.value)
+
     @staticmethod
     def _dopts(deconv_options, maxIter=10):
         """deconv_options struct of demo_large_data_1p.m:38-43 -> cnmfe_deconv_opts"""

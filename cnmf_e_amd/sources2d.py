@@ -576,6 +576,30 @@ class Sources2D:
         d_ = np.concatenate([np.ascontiguousarray(o[2, :m]).view(np.float32) for o, m in zip(out, sizes)])
         return sp.csc_matrix((d_, (r, c)), shape=A_.shape)
 
+    # -- objective ----------------------------------------------------------------------
+    def compute_RSS(self):
+        """[RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, all frames.
+        Per patch the engine needs the residual of (A_prev, C_prev) on the block (:1427-1429, :1475) -- the one the temporal update asks for, so
+        right after update_temporal_parallel it is still resident (or pending) and this costs one read of Ysig per patch."""
+        self._need_data()
+        v = self.video
+        if self.ssub != 1:
+            raise NotImplementedError("compute_RSS is built for bg_ssub = 1")
+        b0_ = self.reconstruct_b0().reshape(-1, order="F")                                           # :1398 (a collective when sharded)
+        b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(-1, order="F")                   # :1399
+        A_csr = self.A.tocsr()
+        RSS = {}
+        for idx in v.owned:
+            pp, bp = v.patch_pix[idx], v.block_pix[idx]
+            ind = np.nonzero(np.asarray(A_csr[bp].sum(axis=0)).ravel() > 0)[0]                      # :1423
+            indp, A_prev_b = self._prev_block_of(idx)                                                # :1427-1428
+            self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
+            A_pp = A_csr[pp][:, ind].tocsc() if ind.size else None                                   # A_patch(ind_patch, :)  (:1467)
+            RSS[idx] = self.engine.compute_rss(v.pid[idx], A_pp, self._rows(self.C, ind) if ind.size else None, b0_[bp], b0_new_[pp])
+        total = float(self._allreduce(np.array([sum(RSS.values())], dtype=np.float64))[0])           # :1507-1508
+        self.P["RSS"] = total                                                                        # :1509
+        return total, RSS
+
     # -- temporal -----------------------------------------------------------------------
     def update_temporal_parallel(self, use_parallel=True, use_c_hat=True):
         """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295."""

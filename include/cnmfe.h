@@ -215,6 +215,15 @@ int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, in
                           const cnmfe_deconv_opts *opts, float *C_out, float *S_out,
                           float *kernel_pars_out, float *sn_out);
 
+/* ---- objective: [RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, one patch, all frames:
+ *   RSS = sum((Y(patch,:) - A(patch,:)*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)
+ * The resident residual of this patch must be the one of (A_prev, C_prev) = the block's neurons (cnmfe_residual; :1427-1429, :1475);
+ * with it RSS is one read of Ysig.  A: d x K CSC on the PATCH rows, C: K x T; b0_block: reconstruct_b0() on the block
+ * (d_b floats, column-major), b0_new: obj.b0_new on the patch (d floats). */
+int cnmfe_compute_rss(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                      const float *A_val, const float *C, int c_order, const float *b0_block, const float *b0_new,
+                      double *rss_out);
+
 /* ---- S6: post_process_spatial (connected = true, circular = false)
  * @Sources2D/post_process_spatial.m:19-32 -> endoscope/connectivity_constraint.m:1-18.
  * A is the whole-FOV d1*d2 x K CSC; keep[nnz] receives 1 for entries that survive. */

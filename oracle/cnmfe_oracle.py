@@ -675,6 +675,38 @@ class OracleSources2D:
         self.A_prev = self.A.copy()                          # :316
         self.C_prev = self.C.copy()                          # :317
 
+    # -- objective -------------------------------------------------------------------
+    def compute_RSS(self):
+        """[RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, all frames:
+        per patch  RSS = sum((Y(patch) - A*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)."""
+        if self.bg_ssub != 1:
+            raise NotImplementedError("compute_RSS is restated for bg_ssub = 1")
+        b0_ = self.reconstruct_b0()                                          # :1398
+        b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(self.d1, self.d2)   # :1399
+        RSS = {}
+        for idx in self._patches():
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            mask = self._mask(b)                                             # :1421-1422
+            ind = np.asarray((sp.csr_matrix(mask.astype(np.float64)) @ self.A).todense()).ravel() > 0        # :1423
+            A_b = self.A[mask, :][:, ind]; C_b = self.C[ind, :]               # :1424-1425
+            indp = np.asarray((sp.csr_matrix(mask.astype(np.float64)) @ self.A_prev).todense()).ravel() > 0  # :1427
+            A_pb = self.A_prev[mask, :][:, indp]; C_pb = self.C_prev[indp, :]  # :1428-1429
+            ip = ind_patch_mask(p, b)                                        # :1440-1443
+            Yb = np.asarray(self._block(b), dtype=np.float64)                 # :1447-1449
+            r0, r1, c0, c1 = [int(v) for v in b]
+            b0_ring = b0_[r0 - 1:r1, c0 - 1:c1].reshape(-1, order="F")        # :1453,1455
+            b0_new_patch = b0_new_[r0 - 1:r1, c0 - 1:c1].reshape(-1, order="F")[ip]   # :1454,1468
+            YmAC = Yb[ip, :] - (A_b[ip, :] @ C_b if A_b.shape[1] else 0.0)    # :1467
+            R = Yb - b0_ring[:, None]                                         # :1471
+            if A_pb.shape[1]:
+                R = R - A_pb @ C_pb
+            Bf = self.W[idx] @ R                                              # :1475
+            Ybg = Bf + b0_new_patch[:, None]                                  # :1487
+            RSS[idx] = float(np.sum((YmAC - Ybg) ** 2))                       # :1502
+        total = float(sum(RSS.values()))                                      # :1507-1508
+        self.RSS = total
+        return total, RSS
+
     # -- spatial -----------------------------------------------------------------
     def update_spatial_parallel(self, update_sn=False):
         """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""

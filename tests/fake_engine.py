@@ -54,6 +54,7 @@ class FakeEngine:
         q = self.p[pid]
         A = None if A_prev_block is None else sp.csc_matrix(A_prev_block).astype(np.float64)
         q["Ysig"] = orc.residual_ysig(q["Y"].T, A, C_prev, q["W"], q["b0"], q["ip"])
+        q["res_AC"] = (A, None if C_prev is None else np.asarray(C_prev, dtype=np.float64))
         return q["Ysig"].T if want else None
 
     def get_sn(self, pid):
@@ -71,6 +72,17 @@ class FakeEngine:
         else:
             out = orc.nnls_spatial(Y, A, C_patch, IND, param)
         return sp.csc_matrix(out)
+
+    def compute_rss(self, pid, A_patch, C_patch, b0_block, b0_new_patch):
+        q = self.p[pid]
+        ip = q["ip"]
+        Yb = q["Y"].T.astype(np.float64)
+        YmAC = Yb[ip] - (sp.csc_matrix(A_patch).astype(np.float64) @ np.asarray(C_patch, dtype=np.float64) if A_patch is not None and A_patch.shape[1] else 0.0)
+        R = Yb - np.asarray(b0_block, dtype=np.float64)[:, None]
+        Ap, Cp = q.get("res_AC", (None, None))
+        if Ap is not None and Ap.shape[1]:
+            R = R - Ap @ Cp
+        return float(np.sum((YmAC - (q["W"] @ R + np.asarray(b0_new_patch, dtype=np.float64)[:, None])) ** 2))
 
     def fast_temporal(self, pid, A_patch):
         aa, C_raw = orc.fast_temporal(self.p[pid]["Ysig"], sp.csc_matrix(A_patch).astype(np.float64))

@@ -554,3 +554,33 @@ def test_residual_ssub_footprint_term_reuse(eng):
             assert np.abs(a_ - b_).max() <= 1e-4 * max(1.0, np.abs(a_).max()), (np.abs(a_ - b_).max(), np.abs(a_).max())
     finally:
         eng.set_option("r1_delta", 1); eng.set_option("r1_lazy", 1)
+
+
+@pytest.mark.parametrize("pdims,T", [([22, 20], 303), (None, 300)])
+def test_compute_rss_parity(eng, pdims, T):
+    """compute_RSS (Sources2D.m:1358-1510) after each method of an iteration, 2x2 patches and one patch, T not a multiple of 4: the engine's
+    one-read formulation (resident / pending residual + per-pixel constant + footprint rows) against the oracle's literal one, engine and oracle
+    each on their own (parity-tested) state of the same iteration.  Tolerance: fp32 storage of Ysig and the 2e-3 agreement of the two states."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, K, r = 44, 40, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    pd_ = pdims or [d1, d2]
+    video = PatchedVideo(d1, d2, T, pd_, r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, pd_, r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
+    def check(tag):
+        got, per = s.compute_RSS(); ref, per_ref = o.compute_RSS()
+        assert abs(got - ref) <= 2e-5 * ref, (tag, got, ref)
+        for idx in video.owned:
+            assert abs(per[idx] - per_ref[idx]) <= 5e-5 * per_ref[idx], (tag, idx, per[idx], per_ref[idx])
+        return got
+    s.update_background_parallel(); o.update_background_parallel()
+    r0 = check("after background")
+    s.update_spatial_parallel(); o.update_spatial_parallel()
+    check("after spatial")
+    s.update_temporal_parallel(); o.update_temporal_parallel()
+    r1 = check("after temporal")                         # (the residual it needs is the temporal update's: pending, folded in by the engine)
+    assert r1 < r0
+    assert abs(s.P["RSS"] - r1) == 0
