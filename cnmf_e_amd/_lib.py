@@ -59,6 +59,7 @@ PROTOTYPES = {
     "cnmfe_update_spatial": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,
                                        i64p, i32p, f32p, C.c_int32, f32p]),
     "cnmfe_fast_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, C.c_int, f32p, f32p]),
+    "cnmfe_reconstruct_background": (C.c_int, [c_ctx, C.c_int, f32p, f32p, C.c_int64, C.c_int64, f32p, C.c_int]),
     "cnmfe_compute_rss": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, f32p, f32p, C.POINTER(C.c_double)]),
     "cnmfe_hals_temporal": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,
                                       f32p, f32p, f32p]),

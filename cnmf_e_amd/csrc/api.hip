@@ -600,6 +600,19 @@ int cnmfe_compute_rss(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_
     return rss_run(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, b0_block, b0_new, rss_out);
 }
 
+int cnmfe_reconstruct_background(cnmfe_ctx *ctx, int patch_id, const float *b0_block, const float *b0_new, int64_t frame0, int64_t nframes,
+                                  float *Ybg_out, int out_memspace) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (P->res_kind != 1) return fail(CNMFE_EUNSUPPORTED, "reconstruct_background needs the residual of cnmfe_residual (bg_ssub = 1)");
+    if (!b0_block || !b0_new || !Ybg_out) return fail(CNMFE_EINVAL, "null b0_block / b0_new / Ybg_out");
+    if (frame0 < 0 || nframes <= 0 || frame0 + nframes > P->T || nframes > 65535) return fail(CNMFE_EINVAL, "frames [%lld, %lld) outside [0, %lld) or more than 65535 at once", (long long)frame0, (long long)(frame0 + nframes), (long long)P->T);
+    CK(hipSetDevice(ctx->device));
+    return bg_reconstruct_run(ctx, P, b0_block, b0_new, frame0, nframes, Ybg_out, out_memspace);
+}
+
 int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int c_order) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     ctx->bound_valid = false;

@@ -181,6 +181,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
 int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out_memspace);
 int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
             const float *b0_block, const float *b0_new, double *rss_out);
+int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const float *b0_new, int64_t frame0, int64_t nframes, float *out, int out_memspace);
 int residual_materialize(cnmfe_ctx *ctx, Patch *P);       // fold a pending footprint term into the resident Ysig (no-op without one)
 int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu, int *dOverflow);   // 1: cannot be applied, materialise instead; *dOverflow set on the device if a footprint meets > 512 traces
 int check_csc_pub(const char *what, int32_t ncol, int64_t nrow, const int64_t *colptr, const int32_t *rowidx);

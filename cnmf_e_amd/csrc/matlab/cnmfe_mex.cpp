@@ -175,6 +175,14 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         double rss = 0.0;
         CHECK(cnmfe_compute_rss(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, bb.data(), bn.data(), &rss));
         pout[0] = mxCreateDoubleScalar(rss);
+    } else if (!strcmp(cmd, "reconstruct_background")) {     // Ybg = cnmfe_mex('reconstruct_background', h, pid, b0_block, b0_new_patch, frame0, nframes)   (Sources2D.m:1247-1355, one patch; d x nframes)
+        if (nin != 7) FAIL("reconstruct_background: 7 inputs required (h, pid, b0_block, b0_new, frame0, nframes)");
+        std::vector<float> bb = f32_of(pin[3]), bn = f32_of(pin[4]);
+        const int64_t f0 = (int64_t)mxGetScalar(pin[5]), nf = (int64_t)mxGetScalar(pin[6]);
+        if (nf <= 0) FAIL("reconstruct_background: nframes must be positive");
+        std::vector<float> out(bn.size() * (size_t)nf);
+        CHECK(cnmfe_reconstruct_background(c, pid, bb.data(), bn.data(), f0, nf, out.data(), CNMFE_HOST));
+        pout[0] = to_double(out, bn.size(), (size_t)nf);
     } else if (!strcmp(cmd, "get_sn")) {                     // sn = cnmfe_mex('get_sn', h, pid, d)   (update_sn = true)
         if (nin != 4) FAIL("get_sn: 4 inputs required");
         size_t d = (size_t)mxGetScalar(pin[3]);

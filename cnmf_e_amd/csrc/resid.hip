@@ -665,18 +665,21 @@ __global__ void __launch_bounds__(256) k_residual_delta(float4 *__restrict__ ysi
             nt4 *yp = reinterpret_cast<nt4 *>(ysig4 + c * d + m);
             const nt4 yv = __builtin_nontemporal_load(yp);
             float4 y = make_float4(yv.x, yv.y, yv.z, yv.w);
+            // the two terms are summed separately and their DIFFERENCE is added: asking again for the term Ysig already contains changes nothing
+            float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s2;
 #pragma unroll
             for (int j = 0; j < DELTA_NL; ++j)
                 if (HAS2 && j < nl2) {
                     const float4 t = *reinterpret_cast<const float4 *>(Cc2 + p2.koff[j] + 4 * c);         // wave-uniform address: a scalar load
-                    y.x = fmaf(p2.w[j], t.x, y.x); y.y = fmaf(p2.w[j], t.y, y.y); y.z = fmaf(p2.w[j], t.z, y.z); y.w = fmaf(p2.w[j], t.w, y.w);
+                    s2.x = fmaf(p2.w[j], t.x, s2.x); s2.y = fmaf(p2.w[j], t.y, s2.y); s2.z = fmaf(p2.w[j], t.z, s2.z); s2.w = fmaf(p2.w[j], t.w, s2.w);
                 }
 #pragma unroll
             for (int j = 0; j < DELTA_NL; ++j)
                 if (HAS1 && j < nl1) {
                     const float4 t = *reinterpret_cast<const float4 *>(Cc1 + p1.koff[j] + 4 * c);
-                    y.x = fmaf(p1.w[j], t.x, y.x); y.y = fmaf(p1.w[j], t.y, y.y); y.z = fmaf(p1.w[j], t.z, y.z); y.w = fmaf(p1.w[j], t.w, y.w);
+                    s1.x = fmaf(-p1.w[j], t.x, s1.x); s1.y = fmaf(-p1.w[j], t.y, s1.y); s1.z = fmaf(-p1.w[j], t.z, s1.z); s1.w = fmaf(-p1.w[j], t.w, s1.w);
                 }
+            y.x += s2.x - s1.x; y.y += s2.y - s1.y; y.z += s2.z - s1.z; y.w += s2.w - s1.w;
             if (valid) __builtin_nontemporal_store((nt4){y.x, y.y, y.z, y.w}, yp);
         }
         return;
@@ -688,28 +691,30 @@ __global__ void __launch_bounds__(256) k_residual_delta(float4 *__restrict__ ysi
     const int nm2 = __builtin_amdgcn_readfirstlane(x2), nm1 = __builtin_amdgcn_readfirstlane(x1);
     for (int64_t c = c0; c < c1; ++c) {
         float4 y = ysig4[c * d + m];
+        float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s2;
 #pragma unroll
         for (int e = 0; e < DELTA_NE; ++e)
             if (HAS2 && e < nm2) {
                 const float4 t = *reinterpret_cast<const float4 *>(Cc2 + (int64_t)ke2[e] * ldc2 + 4 * c);
-                y.x = fmaf(ve2[e], t.x, y.x); y.y = fmaf(ve2[e], t.y, y.y); y.z = fmaf(ve2[e], t.z, y.z); y.w = fmaf(ve2[e], t.w, y.w);
+                s2.x = fmaf(ve2[e], t.x, s2.x); s2.y = fmaf(ve2[e], t.y, s2.y); s2.z = fmaf(ve2[e], t.z, s2.z); s2.w = fmaf(ve2[e], t.w, s2.w);
             }
         for (int e = DELTA_NE; e < n2; ++e) {
             const float w = v2[(int64_t)e * d + m];
             const float4 t = *reinterpret_cast<const float4 *>(Cc2 + (int64_t)k2[(int64_t)e * d + m] * ldc2 + 4 * c);
-            y.x = fmaf(w, t.x, y.x); y.y = fmaf(w, t.y, y.y); y.z = fmaf(w, t.z, y.z); y.w = fmaf(w, t.w, y.w);
+            s2.x = fmaf(w, t.x, s2.x); s2.y = fmaf(w, t.y, s2.y); s2.z = fmaf(w, t.z, s2.z); s2.w = fmaf(w, t.w, s2.w);
         }
 #pragma unroll
         for (int e = 0; e < DELTA_NE; ++e)
             if (HAS1 && e < nm1) {
                 const float4 t = *reinterpret_cast<const float4 *>(Cc1 + (int64_t)ke1[e] * ldc1 + 4 * c);
-                y.x = fmaf(-ve1[e], t.x, y.x); y.y = fmaf(-ve1[e], t.y, y.y); y.z = fmaf(-ve1[e], t.z, y.z); y.w = fmaf(-ve1[e], t.w, y.w);
+                s1.x = fmaf(ve1[e], t.x, s1.x); s1.y = fmaf(ve1[e], t.y, s1.y); s1.z = fmaf(ve1[e], t.z, s1.z); s1.w = fmaf(ve1[e], t.w, s1.w);
             }
         for (int e = DELTA_NE; e < n1; ++e) {
-            const float w = -v1[(int64_t)e * d + m];
+            const float w = v1[(int64_t)e * d + m];
             const float4 t = *reinterpret_cast<const float4 *>(Cc1 + (int64_t)k1[(int64_t)e * d + m] * ldc1 + 4 * c);
-            y.x = fmaf(w, t.x, y.x); y.y = fmaf(w, t.y, y.y); y.z = fmaf(w, t.z, y.z); y.w = fmaf(w, t.w, y.w);
+            s1.x = fmaf(w, t.x, s1.x); s1.y = fmaf(w, t.y, s1.y); s1.z = fmaf(w, t.z, s1.z); s1.w = fmaf(w, t.w, s1.w);
         }
+        y.x += s2.x - s1.x; y.y += s2.y - s1.y; y.z += s2.z - s1.z; y.w += s2.w - s1.w;
         if (valid) ysig4[c * d + m] = y;
     }
 }
@@ -974,6 +979,39 @@ int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const 
     double s = 0.0;
     for (double v : part) s += v;                              // fixed order: reproducible
     *rss_out = s;
+    return 0;
+}
+
+// ---- reconstruct_background (Sources2D.m:1247-1355), ring model, bg_ssub = 1 --------------------------------------------------
+// Ybg = W (Y_block - b0_block - A_prev C_prev) + b0_new = Y(patch) - Ysig - kappa  with the resident residual of (A_prev, C_prev) and the
+// per-pixel constant kappa of compute_RSS: one streaming pass, frames [frame0, frame0 + nframes) written frame-major (d x nframes).
+__global__ void __launch_bounds__(256) k_bg_out(const float4 *__restrict__ yc4, int64_t d_b, int nr, int nr_b, int roff, int coff, const float4 *__restrict__ ysig4,
+                                                int64_t d, const float *__restrict__ ymean_f, const float *__restrict__ kappa, int64_t frame0, int64_t nframes,
+                                                float *__restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= d) return;
+    const int64_t q = (int64_t)((int)(m / nr) + coff) * nr_b + (int)(m % nr) + roff;
+    const float cst = ymean_f[q] - kappa[m];
+    const int64_t t = frame0 + blockIdx.y, c = t >> 2; const int u = (int)(t & 3);
+    const float y = reinterpret_cast<const float *>(yc4 + c * d_b + q)[u], s = reinterpret_cast<const float *>(ysig4 + c * d + m)[u];
+    out[(int64_t)blockIdx.y * d + m] = y - s + cst;
+}
+
+int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const float *b0_new, int64_t frame0, int64_t nframes, float *out, int out_memspace) {
+    RET(residual_materialize(ctx, P));
+    const int64_t d = P->d;
+    DevBuf &dB0b = ctx->tmp[6], &dB0n = ctx->tmp[7], &dKap = ctx->tmp[12];
+    RET(to_dev(ctx, dB0b, b0_block, (size_t)P->d_b)); RET(to_dev(ctx, dB0n, b0_new, (size_t)d));
+    RET(dKap.ensure((size_t)d * sizeof(float)));
+    LAUNCH(ctx, "rss_const", k_rss_const, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, d, P->nr, P->nr_b, P->nc_b, P->roff, P->coff, P->p, P->ring_dr.as<int>(),
+           P->ring_dc.as<int>(), P->W.as<float>(), P->ymean_f.as<float>(), P->b0.as<double>(), dB0b.as<float>(), dB0n.as<float>(),
+           P->res_ac ? P->resCnt.as<int>() : nullptr, P->resK.as<int>(), P->resV.as<float>(), P->resCm.as<double>(), dKap.as<float>());
+    float *dst = out;
+    if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)d * nframes * sizeof(float))); dst = ctx->stage.as<float>(); }
+    LAUNCH(ctx, "bg_reconstruct", k_bg_out, dim3((unsigned)((d + 255) / 256), (unsigned)nframes), dim3(256), 0, P->Yc4.as<float4>(), P->d_b, P->nr, P->nr_b, P->roff, P->coff,
+           P->ysig.as<float4>(), d, P->ymean_f.as<float>(), dKap.as<float>(), frame0, nframes, dst);
+    if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -295,6 +295,15 @@ class Engine:
                                           _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Craw, aa
 
+    def reconstruct_background(self, pid, b0_block, b0_new_patch, frame0=0, nframes=None):
+        """Ybg of one patch (Sources2D.m:1247-1355), frames [frame0, frame0 + nframes): (nframes, d) array; needs the resident residual of (A_prev, C_prev)"""
+        info = self._patch[pid]
+        nframes = info["T"] - frame0 if nframes is None else int(nframes)
+        bb = np.ascontiguousarray(b0_block, dtype=np.float32).ravel(); bn = np.ascontiguousarray(b0_new_patch, dtype=np.float32).ravel()
+        out = np.empty((nframes, info["d"]), dtype=np.float32)
+        L.check(L.lib.cnmfe_reconstruct_background(self._ctx, pid, _p(bb, L.f32p), _p(bn, L.f32p), int(frame0), nframes, _p(out, L.f32p), L.HOST))
+        return out
+
     def compute_rss(self, pid, A_patch, C_patch, b0_block, b0_new_patch):
         """RSS of one patch, compute_RSS (Sources2D.m:1358-1510): needs the resident residual of (A_prev, C_prev) on the block"""
         info = self._patch[pid]

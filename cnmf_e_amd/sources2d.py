@@ -600,6 +600,27 @@ class Sources2D:
         self.P["RSS"] = total                                                                        # :1509
         return total, RSS
 
+    def reconstruct_background(self, frame_range=None):
+        """Ybg = reconstruct_background(obj, frame_range)  (@Sources2D/Sources2D.m:1247-1355), ring model, bg_ssub = 1: d1 x d2 x T' (fp32) of the
+        owned patches (zeros elsewhere when sharded, like every per-patch output).  frame_range = (first, last), 1-based inclusive as in MATLAB."""
+        self._need_data()
+        v = self.video
+        if self.ssub != 1:
+            raise NotImplementedError("reconstruct_background is built for bg_ssub = 1")
+        T = self.C.shape[1]
+        f0, f1 = (1, T) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
+        b0_ = self.reconstruct_b0().reshape(-1, order="F")                                           # :1292
+        b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(-1, order="F")                   # :1293
+        Ybg = np.zeros((v.d1 * v.d2, f1 - f0 + 1), dtype=np.float32)                                 # :1297
+        for idx in v.owned:
+            pp, bp = v.patch_pix[idx], v.block_pix[idx]
+            indp, A_prev_b = self._prev_block_of(idx)                                                # :1317-1320
+            self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
+            for t0 in range(f0 - 1, f1, 4096):                                                       # (the ABI hands out at most 65535 frames per call)
+                n = min(4096, f1 - t0)
+                Ybg[pp, t0 - (f0 - 1):t0 - (f0 - 1) + n] = self.engine.reconstruct_background(v.pid[idx], b0_[bp], b0_new_[pp], t0, n).T
+        return Ybg.reshape(v.d1, v.d2, -1, order="F")
+
     # -- temporal -----------------------------------------------------------------------
     def update_temporal_parallel(self, use_parallel=True, use_c_hat=True):
         """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295."""

@@ -224,6 +224,12 @@ int cnmfe_compute_rss(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_
                       const float *A_val, const float *C, int c_order, const float *b0_block, const float *b0_new,
                       double *rss_out);
 
+/* Ybg = reconstruct_background(obj, frame_range)  (@Sources2D/Sources2D.m:1247-1355), ring model, bg_ssub = 1, one patch:
+ *   Ybg(patch, t) = W*(Y_block - b0_block - A_prev*C_prev)(:, t) + b0_new(patch),  t in [frame0, frame0 + nframes)
+ * from the resident residual of (A_prev, C_prev) as for cnmfe_compute_rss.  Ybg_out: d x nframes, frame-major, host or device. */
+int cnmfe_reconstruct_background(cnmfe_ctx *ctx, int patch_id, const float *b0_block, const float *b0_new,
+                                  int64_t frame0, int64_t nframes, float *Ybg_out, int out_memspace);
+
 /* ---- S6: post_process_spatial (connected = true, circular = false)
  * @Sources2D/post_process_spatial.m:19-32 -> endoscope/connectivity_constraint.m:1-18.
  * A is the whole-FOV d1*d2 x K CSC; keep[nnz] receives 1 for entries that survive. */

@@ -707,6 +707,31 @@ class OracleSources2D:
         self.RSS = total
         return total, RSS
 
+    def reconstruct_background(self):
+        """Ybg = reconstruct_background(obj)  (@Sources2D/Sources2D.m:1247-1355), ring model, bg_ssub = 1, all frames:
+        per patch  Ybg = W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch)  ->  d1 x d2 x T."""
+        if self.bg_ssub != 1:
+            raise NotImplementedError("reconstruct_background is restated for bg_ssub = 1")
+        b0_ = self.reconstruct_b0()                                          # :1292
+        b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(self.d1, self.d2)   # :1293
+        Ybg = np.zeros((self.d1, self.d2, self.T))                           # :1297
+        for idx in self._patches():
+            p, b = self.patch_pos[idx], self.block_pos[idx]
+            mask = self._mask(b)                                             # :1315-1316
+            indp = np.asarray((sp.csr_matrix(mask.astype(np.float64)) @ self.A_prev).todense()).ravel() > 0  # :1317
+            A_pb = self.A_prev[mask, :][:, indp]; C_pb = self.C_prev[indp, :]  # :1319-1320
+            Yb = np.asarray(self._block(b), dtype=np.float64)                 # :1303-1305
+            r0, r1, c0, c1 = [int(v) for v in b]
+            b0_ring = b0_[r0 - 1:r1, c0 - 1:c1].reshape(-1, order="F")        # :1308-1309
+            R = Yb - b0_ring[:, None]                                         # :1324
+            if A_pb.shape[1]:
+                R = R - A_pb @ C_pb
+            Bf = self.W[idx] @ R                                              # :1329
+            q0, q1, s0, s1 = [int(v) for v in p]
+            b0_patch = b0_new_[q0 - 1:q1, s0 - 1:s1].reshape(-1, order="F")   # :1311
+            Ybg[q0 - 1:q1, s0 - 1:s1, :] = (Bf + b0_patch[:, None]).reshape(q1 - q0 + 1, s1 - s0 + 1, self.T, order="F")   # :1330
+        return Ybg
+
     # -- spatial -----------------------------------------------------------------
     def update_spatial_parallel(self, update_sn=False):
         """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""

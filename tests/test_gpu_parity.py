@@ -584,3 +584,23 @@ def test_compute_rss_parity(eng, pdims, T):
     r1 = check("after temporal")                         # (the residual it needs is the temporal update's: pending, folded in by the engine)
     assert r1 < r0
     assert abs(s.P["RSS"] - r1) == 0
+
+
+def test_reconstruct_background_parity(eng):
+    """reconstruct_background (Sources2D.m:1247-1355) after a full iteration on 2x2 patches, all frames and a frame range, vs the oracle"""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 44, 40, 203, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
+    for step in ("update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
+        getattr(s, step)(); getattr(o, step)()
+    ref = o.reconstruct_background()
+    got = s.reconstruct_background()
+    assert got.shape == ref.shape
+    assert rel(got, ref) <= 2e-4, rel(got, ref)            # (W itself agrees to 2e-3 with the oracle's; Ybg is dominated by b0)
+    part = s.reconstruct_background((50, 120))
+    assert np.array_equal(part, got[:, :, 49:120])
