@@ -85,7 +85,8 @@ def test_ring_fit_satisfies_normal_equations_at_full_size(big):
         XX = X @ X.T
         w = torch.linalg.solve(XX + torch.eye(XX.shape[0], dtype=torch.float64, device="cuda") * torch.trace(XX) * 1e-5, X @ Bf[-1])
         w = w[:-1].cpu().numpy()
-        assert np.linalg.norm(w_gpu - w) / np.linalg.norm(w) <= 2e-3, (m, np.linalg.norm(w_gpu - w) / np.linalg.norm(w))
+        # (default path: fp64 table of the video + fp64 footprint corrections + fp64 Cholesky; what is left is the fp32 storage of W)
+        assert np.linalg.norm(w_gpu - w) / np.linalg.norm(w) <= 2e-5, (m, np.linalg.norm(w_gpu - w) / np.linalg.norm(w))
 
 
 def test_full_iteration_recovers_planted_model_and_reduces_rss(big):
@@ -121,3 +122,31 @@ def test_full_iteration_recovers_planted_model_and_reduces_rss(big):
     cors = [np.corrcoef(s.A[:, k].toarray().ravel(), f.A_true[:, k].toarray().ravel())[0, 1] for k in range(0, K, 25)]
     assert np.median(cors) > 0.97
     assert np.median([np.corrcoef(s.C[k], f.C_true[k])[0, 1] for k in range(0, K, 25)]) > 0.97
+
+
+def test_compute_rss_equals_the_literal_objective_at_full_size(big):
+    """compute_RSS (Sources2D.m:1358-1510) at full size: the engine's one-read evaluation (pending footprint term + per-pixel constant +
+    footprint rows) against the literal expression  sum((Y - A C - (W (Y - b0 - A_prev C_prev) + b0_new))^2)  evaluated with torch sparse
+    products in float64, frames in chunks -- this exercises the ring sweep, the pending-term fold and the RSS kernel together."""
+    torch, eng, Y, f, video = big["torch"], big["eng"], big["Y"], big["f"], big["video"]
+    from cnmf_e_amd.sources2d import Sources2D, Options
+    s = Sources2D(video, Options(ring_radius=R, spatial_algorithm="hals", maxIter=5), f.A_init, f.C_init, f.sn)
+    s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+    got, _ = s.compute_RSS()
+    W = s.get_W((0, 0))
+    dev = "cuda"
+    def sp_t(M):
+        M = M.tocoo()
+        return torch.sparse_coo_tensor(np.vstack([M.row, M.col]), M.data.astype(np.float64), M.shape, device=dev).coalesce()
+    Wt, At, Apt = sp_t(W), sp_t(s.A), sp_t(s.A_prev)
+    Ct = torch.from_numpy(np.asarray(s.C, dtype=np.float64)).to(dev); Cpt = torch.from_numpy(np.asarray(s.C_prev, dtype=np.float64)).to(dev)
+    b0 = torch.from_numpy(s.reconstruct_b0().reshape(-1, order="F").astype(np.float64)).to(dev)
+    b0n = torch.from_numpy(np.asarray(s.b0_new, dtype=np.float64).reshape(-1, order="F")).to(dev)
+    ref = 0.0
+    for t0 in range(0, T, 500):
+        Yc = Y[t0:t0 + 500].double().T                                           # d x chunk
+        Rm = Yc - b0[:, None] - torch.sparse.mm(Apt, Cpt[:, t0:t0 + 500])
+        E = Yc - torch.sparse.mm(At, Ct[:, t0:t0 + 500]) - (torch.sparse.mm(Wt, Rm) + b0n[:, None])
+        ref += float((E ** 2).sum())
+        del Yc, Rm, E
+    assert abs(got - ref) <= 2e-6 * ref, (got, ref)
