@@ -358,7 +358,7 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     LAUNCH(ctx, "ring_init", k_ring_init, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
            P->W.as<float>(), P->d, P->nr, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->prect[0], P->prect[2], P->d1, P->d2);
     CK(hipStreamSynchronize(ctx->stream));
-    P->ring_ready = true; P->ysig_valid = false;
+    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false;   // (the kept covariance table covers the sub-tiles THIS ring needs)
     return 0;
 }
 

@@ -380,3 +380,28 @@ def test_nccl_device_resident_traces():
     import re
     errs = [float(x) for x in re.findall(r"= ([0-9.e+-]+)", out.stdout)]
     assert errs and max(errs) < 1e-5
+
+
+def test_ring_change_rebuilds_the_kept_table(eng):
+    """cnmfe_ring_init with another ring (radius, num_neighbors) changes which covariance sub-tiles are needed: the table of the video kept by
+    the incremental fit must be rebuilt (debug = 1 NaN-poisons never-computed entries, so a stale table cannot go unnoticed)"""
+    d1, d2, T = 44, 40, 96
+    f, Y, video = _video(eng, d1, d2, T, 4, 5, 33)
+    A = f.A_init.tocsc().astype(np.float32); Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.set_option("debug", 1)
+    try:
+        out = {}
+        for incr in (0, 1):
+            eng.set_option("gram_incremental", incr); eng.set_option("gram_mode", 3 if incr else 1)
+            res = []
+            for r_, nn in ((5, None), (8, None), (8, 20), (5, None)):
+                eng.ring_init(0, r_, nn) if nn else eng.ring_init(0, r_)
+                eng.fit_ring_model(0, A, Cm)
+                w = eng.ring_csr(0).data.astype(np.float64)
+                assert np.all(np.isfinite(w))
+                res.append(w)
+            out[incr] = res
+        for a, b in zip(out[0], out[1]):
+            assert a.shape == b.shape and np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
+    finally:
+        eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
