@@ -39,7 +39,7 @@ def cpu_baseline(seconds_budget=30.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnmfe_oracle as orc
     from cnmf_e_amd import synth
-    d1, d2, T, r = 96, 96, 1500, 15
+    d1, d2, T, r = 128, 128, 3000, 15                  # ~12 s of host work on the GPU box
     K = max(2, int(round(500 * d1 * d2 / (512.0 * 512.0))))
     f = synth.make_factors(d1, d2, T, K, 9)
     Y = synth.make_video(f, np.float32)
