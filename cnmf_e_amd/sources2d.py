@@ -140,6 +140,43 @@ def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
     return IND
 
 
+def rows_of(A, lut, nloc, cols=None, span=None):
+    """A(rows, :) for the rows a lookup table selects (global pixel -> local row or -1; local order ascending with the global one), as
+    (ind, A(rows, ind)) in CSC with ind = the columns whose selected entries sum to > 0 (`sum(A(mask,:),1) > 0`, the reference's neuron
+    selection) -- or, with `cols` (ascending) given, A(rows, cols).  No CSR conversion and no per-row index array: columns that cannot reach
+    the rows (first / last stored row outside `span` = (lowest, highest) selected global row) are dropped in O(K), the rest costs O(their nnz)."""
+    A = A if sp.isspmatrix_csc(A) else sp.csc_matrix(A)
+    if not A.has_sorted_indices:
+        A = A.copy(); A.sort_indices()
+    K = A.shape[1]
+    if cols is None:
+        cnt_all = np.diff(A.indptr)
+        cand = np.nonzero(cnt_all > 0)[0]
+        if span is not None and cand.size:
+            first = A.indices[A.indptr[cand]]; last = A.indices[A.indptr[cand + 1] - 1]
+            cand = cand[(last >= span[0]) & (first <= span[1])]
+    else:
+        cand = np.asarray(cols, dtype=np.int64)
+        if cand.size and np.any(np.diff(cand) < 0):
+            raise ValueError("cols must be ascending")
+    S = A[:, cand] if cand.size != K else A                       # CSC column slice: O(nnz of the kept columns)
+    loc = lut[S.indices]
+    keep = loc >= 0
+    cid = np.repeat(np.arange(S.shape[1], dtype=np.int64), np.diff(S.indptr))
+    if cols is None:
+        csum = np.bincount(cid[keep], weights=S.data[keep], minlength=S.shape[1])
+        sub = np.nonzero(csum > 0)[0]
+        if sub.size != S.shape[1]:
+            colsel = np.zeros(S.shape[1], dtype=bool); colsel[sub] = True
+            keep &= colsel[cid]
+        ind = cand[sub]
+    else:
+        sub = np.arange(S.shape[1]); ind = cand
+    cnt = np.bincount(cid[keep], minlength=S.shape[1])[sub]
+    indptr = np.zeros(sub.size + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
+    M = sp.csc_matrix((S.data[keep], loc[keep].astype(np.int32), indptr), shape=(nloc, sub.size))
+    return ind, M
+
 # --------------------------------------------------------------------------------------
 # the blocked, GPU-resident video ( == mat_data + get_patch_data of the reference )
 # --------------------------------------------------------------------------------------
@@ -165,6 +202,7 @@ class PatchedVideo:
         self.block_pix = {idx: _rect_pixels(self.block_pos[idx], d1) for idx in self.order}
         self.ind_patch = {}
         self._halo = {}
+        self._lut = {}
         for idx in self.order:
             p, b = self.patch_pos[idx], self.block_pos[idx]
             mask = np.zeros((b[1] - b[0] + 1, b[3] - b[2] + 1), dtype=bool)
@@ -172,6 +210,18 @@ class PatchedVideo:
             self.ind_patch[idx] = np.nonzero(mask.reshape(-1, order="F"))[0]
         for idx in self.owned:
             engine.create_patch(self.pid[idx], self.patch_pos[idx], self.block_pos[idx], d1, d2, T)
+
+    def lut(self, idx, kind):
+        """(table, rows, (lowest, highest pixel)): global pixel -> row index inside the block / patch / halo of patch idx (-1 elsewhere), cached: lets `rows_of` slice a CSC matrix in
+        O(nnz) without a CSR conversion or an index array of block length (what grows with the FOV on every rank of a sharded run)"""
+        key = (idx, kind)
+        t = self._lut.get(key)
+        if t is None:
+            pix = self.block_pix[idx] if kind == "block" else self.patch_pix[idx] if kind == "patch" else self.halo_pix(idx)
+            t = np.full(self.d1 * self.d2, -1, dtype=np.int32)
+            t[pix] = np.arange(pix.size, dtype=np.int32)
+            t = self._lut[key] = (t, pix.size, (int(pix.min()), int(pix.max())) if pix.size else (0, -1))
+        return t
 
     def halo_pix(self, idx):
         """block pixels outside the patch (mask==1 in update_spatial_parallel.m:84-85), cached"""
@@ -239,6 +289,11 @@ class Sources2D:
     # -- accessors ------------------------------------------------------------------
     def get_W(self, idx):
         return self.engine.ring_csr(self.video.pid[idx] if self.ssub == 1 else self.pid_fit[idx])
+
+    def _slice(self, A, idx, kind, cols=None):
+        """(ind, A(pixels of idx's block / patch / halo, ind)): the reference's `mask` selections (update_*_parallel.m) without a CSR of A"""
+        t, n, span = self.video.lut(idx, kind)
+        return rows_of(A, t, n, cols=cols, span=span)
 
     @staticmethod
     def _rows(Cm, ind):
@@ -374,20 +429,14 @@ class Sources2D:
         v, o = self.video, self.options
         # the block slices of the current A: prepared by the temporal update under its GPU work when A has not changed since
         cached = getattr(self, "_cur_blocks_src", None) is self.A
-        A_csr = self._cur_csr if cached and self._cur_csr is not None else None   # CSR of A: built only if some block needs row slicing
         infos = {}
         prefetched = False
-        self._prev_csr = A_csr                                             # A_prev (set below) in CSR, reused by the spatial update (None: built on demand)
         self._prev_blocks = {}                                             # (ind, A_block) per patch: what the temporal update's residual needs
         for idx in v.owned:
             if cached and idx in self._cur_blocks:
                 ind_nz, A_block = self._cur_blocks[idx]
             else:
-                if A_csr is None:
-                    A_csr = self.A.tocsr()
-                Ab = A_csr[v.block_pix[idx]]
-                ind_nz = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]   # :128
-                A_block = Ab[:, ind_nz].tocsc()                            # :129
+                ind_nz, A_block = self._slice(self.A, idx, "block")       # :128-129
             C_block = self._rows(self.C, ind_nz)                           # :130
             self._prev_blocks[idx] = (ind_nz, A_block)
             # "stop updating B because A&C doesn't change in this area" (:188-199) is decided by the engine's
@@ -412,24 +461,15 @@ class Sources2D:
         self.C_prev = self.C                                               # :317
         return infos
 
-    def _prev_csr_of(self):
-        """A_prev in CSR; cached by update_background_parallel when A_prev is the A it fitted against"""
+    def _prev_block_of(self, idx):
+        """(ind, A_prev(block rows, ind)) for the neurons of A_prev that touch the block (update_temporal_parallel.m:90-91); cached by
+        update_background_parallel when A_prev is the A it fitted against"""
         if getattr(self, "_prev_csr_src", None) is not self.A_prev:
-            self._prev_csr = None
             self._prev_csr_src = self.A_prev
             self._prev_blocks = {}
-        if self._prev_csr is None:
-            self._prev_csr = self.A_prev.tocsr()
-        return self._prev_csr
-
-    def _prev_block_of(self, idx):
-        """(ind, A_prev(block rows, ind)) for the neurons of A_prev that touch the block (update_temporal_parallel.m:90-91)"""
-        Aprev_csr = self._prev_csr_of()
         hit = self._prev_blocks.get(idx)
         if hit is None:
-            Ab = Aprev_csr[self.video.block_pix[idx]]
-            ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]
-            hit = self._prev_blocks[idx] = (ind, Ab[:, ind].tocsc())
+            hit = self._prev_blocks[idx] = self._slice(self.A_prev, idx, "block")
         return hit
 
     def _first_run(self, idx):
@@ -445,29 +485,26 @@ class Sources2D:
         sn_new = np.zeros(v.d1 * v.d2, dtype=np.float64) if update_sn else None                  # :101-102
         if o.search_method != "ellipse":
             raise NotImplementedError("only search_method='ellipse' is built")
-        Aprev_csr = self._prev_csr_of()
         K = self.A.shape[1]
         rows, cols, vals = [], [], []
-        IND_csr = A_csr = None
+        IND = None
         for idx in v.owned:
             pp, bp, ip = v.patch_pix[idx], v.block_pix[idx], v.ind_patch[idx]
             # A_prev restricted to neurons that touch the HALO only (mask==1 after the patch is set to 2, :84-85,96)
             halo = v.halo_pix(idx)
             if halo.size:
-                indp = np.nonzero(np.asarray(Aprev_csr[halo].sum(axis=0)).ravel() > 0)[0]
+                indp, _ = self._slice(self.A_prev, idx, "halo")
             else:
                 indp = np.zeros(0, dtype=np.int64)
-            A_prev_b = Aprev_csr[bp][:, indp].tocsc() if indp.size else None                        # :97
+            A_prev_b = self._slice(self.A_prev, idx, "block", cols=indp)[1] if indp.size else None   # :97
             C_prev_b = self._rows(self.C_prev, indp) if indp.size else None                         # :98
-            launched = IND_csr is None
+            launched = IND is None
             if launched:
                 # the residual sweep (:162-166) does not depend on the search mask: start it (the call returns with
                 # the kernel in flight) and build IND (:66) on the host underneath it
                 self._residual(idx, A_prev_b, C_prev_b)
-                IND_csr = self._search_location_csr()
-                A_csr = self.A.tocsr()
-            INDp = IND_csr[pp]
-            ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]                          # :87
+                IND = self._search_location_csc()
+            ind, IND_patch = self._slice(IND, idx, "patch")                                          # :87, :89
             if ind.size == 0 and not update_sn:
                 continue                                                                             # :121-124
             if not launched:
@@ -478,8 +515,7 @@ class Sources2D:
                 sn_new[pp] = sn_patch
             if ind.size == 0:
                 continue                                                                             # :196-199
-            A_patch = A_csr[pp][:, ind].tocsc()                                                     # :88,199
-            IND_patch = INDp[:, ind].tocsc()                                                        # :89
+            A_patch = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # :88,199
             C_patch = self._rows(self.C, ind)                                                       # :91
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
             Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
@@ -511,14 +547,20 @@ class Sources2D:
         if getattr(self, "_pool", None) is None:
             self._pool = cf.ThreadPoolExecutor(max_workers=1)
         A = self.A
-        self._ind_future = (A, self._pool.submit(lambda: self._search_location_owned(A).tocsr()))
+        self._ind_future = (A, self._pool.submit(lambda: self._as_mask_csc(self._search_location_owned(A))))
 
-    def _search_location_csr(self):
+    @staticmethod
+    def _as_mask_csc(IND):
+        M = sp.csc_matrix(IND, dtype=np.float32)
+        M.sort_indices()
+        return M
+
+    def _search_location_csc(self):
         fut = getattr(self, "_ind_future", None)
         self._ind_future = None
         if fut is not None and fut[0] is self.A:
             return fut[1].result()
-        return self._search_location_owned().tocsr()
+        return self._as_mask_csc(self._search_location_owned())
 
     def _search_location_owned(self, A=None):
         """IND = determine_search_location(obj.A, ...) (:66), evaluated only for the neurons that can reach a patch
@@ -587,14 +629,13 @@ class Sources2D:
             raise NotImplementedError("compute_RSS is built for bg_ssub = 1")
         b0_ = self.reconstruct_b0().reshape(-1, order="F")                                           # :1398 (a collective when sharded)
         b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(-1, order="F")                   # :1399
-        A_csr = self.A.tocsr()
         RSS = {}
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
-            ind = np.nonzero(np.asarray(A_csr[bp].sum(axis=0)).ravel() > 0)[0]                      # :1423
+            ind, _ = self._slice(self.A, idx, "block")                                              # :1423
             indp, A_prev_b = self._prev_block_of(idx)                                                # :1427-1428
             self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
-            A_pp = A_csr[pp][:, ind].tocsc() if ind.size else None                                   # A_patch(ind_patch, :)  (:1467)
+            A_pp = self._slice(self.A, idx, "patch", cols=ind)[1] if ind.size else None              # A_patch(ind_patch, :)  (:1467)
             RSS[idx] = self.engine.compute_rss(v.pid[idx], A_pp, self._rows(self.C, ind) if ind.size else None, b0_[bp], b0_new_[pp])
         total = float(self._allreduce(np.array([sum(RSS.values())], dtype=np.float64))[0])           # :1507-1508
         self.P["RSS"] = total                                                                        # :1509
@@ -627,7 +668,7 @@ class Sources2D:
         self._need_data()
         v, o = self.video, self.options
         K, T = self.C.shape
-        A_csr = None
+        launched_any = False
         acc = None                                                         # sum over patches of aa .* C_raw  (:274)
         aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
         sharded = self.dist is not None and v.world_size > 1
@@ -637,30 +678,28 @@ class Sources2D:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
             C_prev_b = self._rows(self.C_prev, indp) if indp.size else None
-            launched = A_csr is None
+            launched = not launched_any
             whole = bp.size == v.d1 * v.d2                                 # this block is the whole field of view (then so is the patch): no row slicing
             if launched:
                 # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)
-                A_csr = True if whole else self.A.tocsr()
-                self._cur_csr, self._cur_blocks, self._cur_blocks_src = (None if whole else A_csr), {}, self.A
+                launched_any = True
+                self._cur_blocks, self._cur_blocks_src = {}, self.A
             if whole:
                 A_csc = self.A if sp.isspmatrix_csc(self.A) else self.A.tocsc()
                 ind = np.nonzero(np.asarray(A_csc.sum(axis=0)).ravel() > 0)[0]                       # :83
                 A_pp = A_csc if ind.size == K else A_csc[:, ind]
                 self._cur_blocks[idx] = (ind, A_pp)
             else:
-                Ab = A_csr[bp]
-                ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]                          # :83
-                # the next background update fits against this same A (update_background_parallel.m:128-130): slice it now, under the sweep
-                self._cur_blocks[idx] = (ind, Ab[:, ind].tocsc())
+                # (ind, A(block, ind)): also what the next background update fits against (update_background_parallel.m:128-130)
+                ind, A_blk = self._cur_blocks[idx] = self._slice(self.A, idx, "block")               # :83
             if ind.size == 0:
                 continue                                                                              # :123
             if not launched:
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self._rows(self.C, ind)                                                        # :86
             if not whole:
-                A_pp = A_csr[pp][:, ind].tocsc()                                                     # A_patch(ind_patch,:)
+                A_pp = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175
                 C_raw_p, aa_p = self.engine.fast_temporal(v.pid[idx], A_pp)
             elif o.deconv_flag:                                                                       # :106-110
