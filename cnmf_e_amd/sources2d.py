@@ -613,7 +613,7 @@ class Sources2D:
         out = [torch.empty_like(buf) for _ in range(W)]
         td.all_gather(out, buf, group=self.dist)
         out = [o.cpu().numpy() for o in out]
-        r = np.concatenate([o[0, :m] for o, m in zip(out, sizes)]).astype(np.int64)
+        r = np.concatenate([o[0, :m] for o, m in zip(out, sizes)])            # int32 row / column indices: the CSC build is index-bound
         c = np.concatenate([o[1, :m] for o, m in zip(out, sizes)])
         d_ = np.concatenate([np.ascontiguousarray(o[2, :m]).view(np.float32) for o, m in zip(out, sizes)])
         return sp.csc_matrix((d_, (r, c)), shape=A_.shape)
