@@ -45,6 +45,44 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return r;
 }
 
+// ---- order statistics without a sort -----------------------------------------------------------------------
+// The trace needs two adjacent order statistics twice (median of HALS_temporal.m:78, interpolated 15 % quantile of
+// foopsi_oasisAR1.m:93).  An MSD radix select on the order-preserving integer key of the floats finds the k-th smallest in four
+// 256-bin histogram passes over the LDS copy of the trace (a full bitonic sort of 16384 slots cost 0.67 ms per trace, a fifth
+// of the whole kernel); the (k+1)-th is the same value when the k-th is repeated often enough, else the smallest key above it.
+__device__ __forceinline__ unsigned fkey(float x) { const unsigned u = __float_as_uint(x); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ void select_pair(const float *y, int T, int k, int *hist /* 260 ints of LDS */, float &vk, float &vk1) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, known = 0;
+    int kk = k, cnt_eq = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < T; t += 256) { const unsigned key = fkey(y[t]); if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1); }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, b = 0;
+            for (; b < 255; ++b) { const int h = hist[b]; if (acc + h > kk) break; acc += h; }
+            hist[256] = b; hist[257] = kk - acc; hist[258] = hist[b];
+        }
+        __syncthreads();
+        prefix |= (unsigned)hist[256] << shift; known |= 255u << shift; kk = hist[257]; cnt_eq = hist[258];
+        __syncthreads();
+    }
+    vk = fkey_inv(prefix);
+    if (kk + 1 < cnt_eq) { vk1 = vk; return; }
+    unsigned mn = 0xffffffffu;
+    for (int t = tid; t < T; t += 256) { const unsigned key = fkey(y[t]); if (key > prefix && key < mn) mn = key; }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mn, o); mn = other < mn ? other : mn; }
+    if ((tid & 63) == 0) hist[tid >> 6] = (int)mn;
+    __syncthreads();
+    unsigned r = (unsigned)hist[0];
+    for (int w = 1; w < 4; ++w) r = (unsigned)hist[w] < r ? (unsigned)hist[w] : r;
+    __syncthreads();
+    vk1 = r == 0xffffffffu ? vk : fkey_inv(r);
+}
+
 // in-place radix-2 FFT of n complex points in LDS (re, im), 256 threads
 __device__ void fft_lds(float *re, float *im, int n, int logn) {
     const int tid = threadIdx.x;
@@ -132,8 +170,13 @@ struct Pools { double *v, *w; int *t, *l; int n; };
 
 // oasisAR1 on lane 0: left-to-right pool stack.  Input pools: singletons of (y - b) when `warm` is 0, else the
 // current pool list (v, w recomputed by the caller).  gl = g^l is carried multiplicatively.
-__device__ void oasis_seq(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, int warm) {
+template <bool warm>
+__device__ void oasis_seq_t(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, float *lds_scr, int nc) {
     const int nin = warm ? P.n : T;
+    // the lowest `nc` stack entries are mirrored in LDS (cold pass): the pool that comes to the top after a back-track merge is then
+    // re-read from LDS, not from global memory -- in a decaying transient every other sample takes that path (1 us per global round trip)
+    double *lv = reinterpret_cast<double *>(lds_scr), *lw = lv + nc;
+    int *lt = reinterpret_cast<int *>(lw + nc), *ll = lt + nc;
     // the stack is built in place: output index <= input index, so reading input i never sees an overwritten slot.
     // This loop is one lane's dependent fp64 chain, so its length is what matters:
     //  * the pool under the current one is mirrored in registers (pv, pw, pt, pl, pgl): the back-track test that follows every merge costs
@@ -149,12 +192,19 @@ __device__ void oasis_seq(const float *y, double bsub, int T, double g, double l
     int top = 0;                                  // number of pools already on the stack (below cur)
     double pv = 0, pw = 1, pgl = 1; int pt = 0, pl = 0;            // mirror of stack entry top-1 (valid when top > 0)
     const double lam_in = lam * (1 - g);
+    float ynext = (!warm && nin > 1) ? y[1] : 0.f;               // fresh samples are fetched one iteration ahead of their use
     for (int i = 1; i < nin; ++i) {
         double nv, nw; int nt, nl; double ngl;
         if (warm) { nv = P.v[i]; nw = P.w[i]; nt = P.t[i]; nl = P.l[i]; ngl = pow(g, (double)nl); }
-        else { nv = ((double)y[i] - bsub) - (i == T - 1 ? lam : lam_in); nw = 1.0; nt = i + 1; nl = 1; ngl = g; }
+        else {
+            const float yi = ynext;
+            ynext = y[i + 1 < nin ? i + 1 : i];
+            nv = ((double)yi - bsub) - (i == T - 1 ? lam : lam_in); nw = 1.0; nt = i + 1; nl = 1; ngl = g;
+        }
         if (nv * cw >= fma(smin, cw, cv * cgl) * nw) {                 // oasisAR1.m:64-65: no violation, advance
-            P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl; ++top;
+            P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
+            if (!warm && top < nc) { lv[top] = cv; lw[top] = cw; lt[top] = ct; ll[top] = cl; }
+            ++top;
             pv = cv; pw = cw; pt = ct; pl = cl; pgl = cgl;
             cv = nv; cw = nw; ct = nt; cl = nl; cgl = ngl;
             continue;
@@ -165,11 +215,67 @@ __device__ void oasis_seq(const float *y, double bsub, int T, double g, double l
             if (!(cv * pw < fma(smin, pw, lim > 0.0 ? lim : 0.0) * cw)) break;
             cv = fma(cv, pgl, pv); cw = fma(cw * pgl, pgl, pw); ct = pt; cl = pl + cl; cgl = pgl * cgl;
             --top;
-            if (top > 0) { pv = P.v[top - 1]; pw = P.w[top - 1]; pt = P.t[top - 1]; pl = P.l[top - 1]; pgl = pow(g, (double)pl); }
+            if (top > 0) {
+                if (!warm && top - 1 < nc) { pv = lv[top - 1]; pw = lw[top - 1]; pt = lt[top - 1]; pl = ll[top - 1]; }
+                else { pv = P.v[top - 1]; pw = P.w[top - 1]; pt = P.t[top - 1]; pl = P.l[top - 1]; }
+                pgl = pow(g, (double)pl);
+            }
         }
     }
     P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
     P.n = top + 1;
+}
+
+// The cold pass with lambda = 0 (the only lambda deconv_setup admits), written for the fewest instructions per sample: one lane of one
+// wave issues an instruction every ~8 clocks whatever its kind, so 60 instructions per sample (the generic loop above under a divergent
+// exec mask) are 0.24 us per sample = 2.4 ms per 10^4-frame trace.  Here
+//  * branch conditions go through a ballot, which tells the compiler they are wave-uniform: scalar branches, no exec-mask bookkeeping;
+//  * both thresholds are kept in the form they are compared in: thr = smin w + v g^l of the current pool (recomputed once per sample),
+//    plim = smin w_p + max(v_p g^lp, 0) of the pool under it (recomputed only when that pool changes; -inf on an empty stack, so no
+//    separate `top > 0` test);
+//  * the stack is mirrored in LDS together with g^l: a back-track merge costs one LDS round trip and no pow().
+// The comparisons are the ones of oasis_seq_t term by term (n_w = 1, lambda (1 - g) = 0), so the pools are identical.
+__device__ __forceinline__ bool wave_uniform(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }   // (lane 0 is the only active lane)
+__device__ void oasis_cold(const float *y, double bsub, int T, double g, double smin, Pools &P, float *lds_scr, int nc) {
+    double *lv = reinterpret_cast<double *>(lds_scr), *lw = lv + nc, *lg = lw + nc;          // 32 B per mirrored pool
+    int *lt = reinterpret_cast<int *>(lg + nc), *ll = lt + nc;
+    double cv = (double)y[0] - bsub, cw = 1.0, cgl = g;
+    int ct = 1, cl = 1, top = 0;
+    double thr = fma(smin, cw, cv * cgl);
+    double pv = 0, pw = 1, pgl = 1, plim = -INFINITY; int pt = 0, pl = 0;
+    float ynext = T > 1 ? y[1] : 0.f;
+    for (int i = 1; i < T; ++i) {
+        const double nv = (double)ynext - bsub;
+        ynext = y[i + 1 < T ? i + 1 : i];
+        if (wave_uniform(nv * cw >= thr)) {                              // oasisAR1.m:64-65: no violation, push the current pool
+            P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
+            if (top < nc) { lv[top] = cv; lw[top] = cw; lg[top] = cgl; lt[top] = ct; ll[top] = cl; }
+            ++top;
+            pv = cv; pw = cw; pt = ct; pl = cl; pgl = cgl;
+            { const double lim = pv * pgl; plim = fma(smin, pw, lim > 0.0 ? lim : 0.0); }
+            cv = nv; cw = 1.0; ct = i + 1; cl = 1; cgl = g;
+        } else {
+            cv = fma(nv, cgl, cv); cw = fma(cgl, cgl, cw); cl += 1; cgl *= g;              // :74-76 merge
+            while (wave_uniform(cv * pw < plim * cw)) {                  // :83-95 back-track
+                cv = fma(cv, pgl, pv); cw = fma(cw * pgl, pgl, pw); ct = pt; cl = pl + cl; cgl = pgl * cgl;
+                --top;
+                if (top > 0) {
+                    if (top - 1 < nc) { pv = lv[top - 1]; pw = lw[top - 1]; pgl = lg[top - 1]; pt = lt[top - 1]; pl = ll[top - 1]; }
+                    else { pv = P.v[top - 1]; pw = P.w[top - 1]; pt = P.t[top - 1]; pl = P.l[top - 1]; pgl = pow(g, (double)pl); }
+                    const double lim = pv * pgl; plim = fma(smin, pw, lim > 0.0 ? lim : 0.0);
+                } else plim = -INFINITY;
+            }
+        }
+        thr = fma(smin, cw, cv * cgl);
+    }
+    P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
+    P.n = top + 1;
+}
+
+__device__ __forceinline__ void oasis_seq(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, int warm, float *lds_scr, int nc) {
+    if (warm) oasis_seq_t<true>(y, bsub, T, g, lam, smin, P, lds_scr, 0);
+    else if (lam == 0.0) oasis_cold(y, bsub, T, g, smin, P, lds_scr, (nc * 24) / 32);
+    else oasis_seq_t<false>(y, bsub, T, g, lam, smin, P, lds_scr, nc);   // (the cold pass is the long one: no per-sample `warm` tests in it)
 }
 
 // split the pools into tasks of <= 64 samples (lane 0)
@@ -219,7 +325,8 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     const int tid = threadIdx.x, T = c.T;
     const int slot = blockIdx.x, k = io.list[slot];
     float *y = sm;                                  // T raw samples (fp32), persistent
-    float *scr = sm + ((T + 3) & ~3);               // scratch: sort buffer P2 | FFT re, im (2*nfft)
+    float *scr = sm + ((T + 3) & ~3);               // scratch: sort buffer P2 | FFT re, im (2*nfft) | top of the OASIS pool stack
+    const int nc_pools = (int)(((size_t)max(max(c.P2, 2 * c.nfft), T) * sizeof(float)) / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
     Pools P; P.v = io.pv + base; P.w = io.pw + base; P.t = io.pt + base; P.l = io.pl + base; P.n = 0;
     double *num = io.pnum + base;                   // per-pool numerators
@@ -247,28 +354,20 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         for (int t = tid; t < T; t += 256) { ck[t] = 0.f; io.S[(int64_t)k * io.ldc + t] = 0.f; if (io.Craw) io.Craw[(int64_t)k * io.ldc + t] = 0.f; }
         return;
     }
-    // ---- bitonic sort of a copy (median of HALS_temporal.m:78, quantile of foopsi_oasisAR1.m:93) ----
-    for (int i = tid; i < c.P2; i += 256) scr[i] = i < T ? y[i] : INFINITY;
-    __syncthreads();
-    for (int kk = 2; kk <= c.P2; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < c.P2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const float a = scr[i], b = scr[ixj];
-                    const bool up = (i & kk) == 0;
-                    if ((a > b) == up) { scr[i] = b; scr[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    // ---- median (HALS_temporal.m:78) and 15 % quantile (foopsi_oasisAR1.m:93) of the raw trace ----
     double bsub = 0.0;                               // everything subtracted from the raw trace so far
-    const double q15pos = 0.15 * T - 0.5;
-    double q15;
-    { const int qi = (int)floor(q15pos);
-      q15 = q15pos <= 0 ? (double)scr[0] : (q15pos >= T - 1 ? (double)scr[T - 1] : (double)scr[qi] + (q15pos - qi) * ((double)scr[qi + 1] - (double)scr[qi])); }
+    double q15 = 0.0;
+    if (c.optimize_b) {
+        const double q15pos = 0.15 * T - 0.5;
+        const int qi = q15pos <= 0 ? 0 : (q15pos >= T - 1 ? T - 1 : (int)floor(q15pos));
+        float v0, v1;
+        select_pair(y, T, qi, reinterpret_cast<int *>(scr), v0, v1);
+        q15 = (q15pos <= 0 || q15pos >= T - 1) ? (double)v0 : (double)v0 + (q15pos - qi) * ((double)v1 - (double)v0);
+    }
     if (c.hals) {
-        const float med = 0.5f * (scr[(T - 1) / 2] + scr[T / 2]);
+        float m0, m1;
+        select_pair(y, T, (T - 1) / 2, reinterpret_cast<int *>(scr), m0, m1);
+        const float med = 0.5f * (m0 + ((T & 1) ? m0 : m1));
         double s = 0, n = 0;
         for (int t = tid; t < T; t += 256) if (y[t] < med) { s += y[t]; n += 1; }
         s = block_sum(s, red); n = block_sum(n, red);
@@ -301,7 +400,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     double b = c.optimize_b ? (q15 - bsub) : 0.0;    // :93 quantile(y, .15) of the baseline-subtracted trace
     int optimize_g = c.optimize_g;
     int ntask = 0;
-    if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+    if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0, scr, nc_pools); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
     __syncthreads();
     P.n = sh_i[0]; ntask = sh_i[1];
     const int niter = c.optimize_b ? c.maxIter : (optimize_g ? 1 : 0);
@@ -322,7 +421,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
             const double sn2 = get_sn(y, c, scr, scr + c.nfft, red);
             const double g2 = est_g(y, bsub, T, sn2, red);
             if (g2 >= -1.0) g = g2;
-            if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+            if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0, scr, nc_pools); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
             __syncthreads();
             P.n = sh_i[0]; ntask = sh_i[1];
             break;
@@ -380,7 +479,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, num);
         for (int p = tid; p < P.n; p += 256) { P.v[p] = num[p]; P.w[p] = hh_of(glast, P.l[p]); }
         __syncthreads();
-        if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 1); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+        if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 1, scr, nc_pools); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
         __syncthreads();
         P.n = sh_i[0]; ntask = sh_i[1];
         if (fabs(g - g0) / g0 < 1e-3) optimize_g = 0;            // :110-112
