@@ -272,10 +272,93 @@ __device__ void oasis_cold(const float *y, double bsub, int T, double g, double 
     P.n = top + 1;
 }
 
+// The same pass on the 64 lanes of wave 0.  Almost every sample of a real trace takes the "merge into the current pool" path (a 10^4-frame
+// trace ends with ~10^2 pools), and a run of merges has a closed form: after j merges onto the pool (v, w, g^l)
+//     v_j = v + g^l sum_{m<j} y_m g^m,      w_j = w + g^2l sum_{m<j} g^2m,      g^l_j = g^l g^j,
+// so one wave-wide prefix sum gives the state in front of each of the next 64 samples as if all earlier ones had merged; every lane then
+// evaluates both tests of its sample (push: oasisAR1.m:64-65; back-track after the merge: :83-85) and the first lane whose test fires
+// ends the run.  The samples before it are merged exactly as computed, the event itself (a push, or the back-track loop) is handled
+// on uniform values by all lanes, and the next block starts behind it.  Where events are dense (blocks that end within a few samples)
+// the pass drops to the one-sample step for a stretch, so it is never much slower than oasis_cold.  The run's sums are accumulated
+// in a different order than the sample-by-sample fma chain (relative differences of 1e-16 in v); the tests are otherwise the same.
+__device__ void oasis_cold_wave(const float *y, double bsub, int T, double g, double smin, Pools &P, float *lds_scr, int nc) {
+    const int lane = threadIdx.x;                                           // called by tid < 64
+    double *lv = reinterpret_cast<double *>(lds_scr), *lw = lv + nc, *lg = lw + nc;
+    int *lt = reinterpret_cast<int *>(lg + nc), *ll = lt + nc;
+    double gm = 1.0, qm = 0.0;                                               // g^lane, sum_{m<lane} g^2m
+    { const double g2 = g * g; double q = 1.0; for (int m = 0; m < lane; ++m) { gm *= g; qm += q; q *= g2; } }
+    double cv = (double)y[0] - bsub, cw = 1.0, cgl = g;
+    int ct = 1, cl = 1, top = 0;
+    double pv = 0, pw = 1, pgl = 1, plim = -INFINITY; int pt = 0, pl = 0;
+    auto push = [&](double nv, int tn) {                                    // current pool onto the stack, sample nv opens the next one
+        if (lane == 0) {
+            P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
+            if (top < nc) { lv[top] = cv; lw[top] = cw; lg[top] = cgl; lt[top] = ct; ll[top] = cl; }
+        }
+        ++top;
+        pv = cv; pw = cw; pt = ct; pl = cl; pgl = cgl;
+        { const double lim = pv * pgl; plim = fma(smin, pw, lim > 0.0 ? lim : 0.0); }
+        cv = nv; cw = 1.0; ct = tn; cl = 1; cgl = g;
+    };
+    auto backtrack = [&]() {
+        while (wave_uniform(cv * pw < plim * cw)) {
+            cv = fma(cv, pgl, pv); cw = fma(cw * pgl, pgl, pw); ct = pt; cl = pl + cl; cgl = pgl * cgl;
+            --top;
+            if (top > 0) {
+                if (top - 1 < nc) { pv = lv[top - 1]; pw = lw[top - 1]; pgl = lg[top - 1]; pt = lt[top - 1]; pl = ll[top - 1]; }
+                else { pv = P.v[top - 1]; pw = P.w[top - 1]; pt = P.t[top - 1]; pl = P.l[top - 1]; pgl = pow(g, (double)pl); }
+                const double lim = pv * pgl; plim = fma(smin, pw, lim > 0.0 ? lim : 0.0);
+            } else plim = -INFINITY;
+        }
+    };
+    int i = 1, credit = 0;
+    while (i < T) {
+        if (credit > 0) {                                                   // one-sample step (dense events)
+            const double nv = (double)y[i] - bsub;
+            if (wave_uniform(nv * cw >= fma(smin, cw, cv * cgl))) push(nv, i + 1);
+            else { cv = fma(nv, cgl, cv); cw = fma(cgl, cgl, cw); cl += 1; cgl *= g; backtrack(); }
+            ++i; --credit;
+            continue;
+        }
+        const int idx = i + lane;
+        const bool in = idx < T;
+        const double nv = in ? (double)y[idx] - bsub : 0.0;
+        double sc = nv * gm;                                                // inclusive scan of y_m g^m
+        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(sc, o); if (lane >= o) sc += up; }
+        double ex = __shfl_up(sc, 1); if (lane == 0) ex = 0.0;
+        const double gl_j = cgl * gm;                                        // state in front of this lane's sample
+        const double v_j = fma(cgl, ex, cv), w_j = fma(cgl * cgl, qm, cw);
+        const bool ev_push = in && (nv * w_j >= fma(smin, w_j, v_j * gl_j));
+        const double v_n = fma(nv, gl_j, v_j), w_n = fma(gl_j, gl_j, w_j), gl_n = gl_j * g;     // ... and behind it, merged
+        const bool ev_back = in && !ev_push && (v_n * pw < plim * w_n);
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(ev_push || ev_back || !in);
+        const unsigned long long pushes = __builtin_amdgcn_ballot_w64(ev_push);
+        const int j = stop ? __builtin_ctzll(stop) : 64;                    // samples i .. i+j-1 merge
+        if (j == 64) { cv = __shfl(v_n, 63); cw = __shfl(w_n, 63); cgl = __shfl(gl_n, 63); cl += 64; i += 64; continue; }
+        if (i + j >= T) { cv = __shfl(v_j, j); cw = __shfl(w_j, j); cgl = __shfl(gl_j, j); cl += j; i += j; continue; }   // ran off the trace
+        if ((pushes >> j) & 1) {                                            // the state the firing lane tested is the one that is kept
+            cv = __shfl(v_j, j); cw = __shfl(w_j, j); cgl = __shfl(gl_j, j); cl += j;
+            push(__shfl(nv, j), i + j + 1);
+        } else {
+            cv = __shfl(v_n, j); cw = __shfl(w_n, j); cgl = __shfl(gl_n, j); cl += j + 1;
+            backtrack();
+        }
+        i += j + 1;
+        if (j < 6) credit = 24;
+    }
+    if (lane == 0) { P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl; }
+    P.n = top + 1;
+}
+
 __device__ __forceinline__ void oasis_seq(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, int warm, float *lds_scr, int nc) {
     if (warm) oasis_seq_t<true>(y, bsub, T, g, lam, smin, P, lds_scr, 0);
     else if (lam == 0.0) oasis_cold(y, bsub, T, g, smin, P, lds_scr, (nc * 24) / 32);
     else oasis_seq_t<false>(y, bsub, T, g, lam, smin, P, lds_scr, nc);   // (the cold pass is the long one: no per-sample `warm` tests in it)
+}
+// the pass from singleton pools: wave 0 enters
+__device__ __forceinline__ void oasis_first(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, float *lds_scr, int nc24) {
+    if (lam == 0.0) { oasis_cold_wave(y, bsub, T, g, smin, P, lds_scr, (nc24 * 24) / 32); return; }
+    if (threadIdx.x == 0) oasis_seq_t<false>(y, bsub, T, g, lam, smin, P, lds_scr, nc24);
 }
 
 // split the pools into tasks of <= 64 samples (lane 0)
@@ -400,7 +483,8 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     double b = c.optimize_b ? (q15 - bsub) : 0.0;    // :93 quantile(y, .15) of the baseline-subtracted trace
     int optimize_g = c.optimize_g;
     int ntask = 0;
-    if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0, scr, nc_pools); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+    if (tid < 64) oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools);
+    if (tid == 0) { sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
     __syncthreads();
     P.n = sh_i[0]; ntask = sh_i[1];
     const int niter = c.optimize_b ? c.maxIter : (optimize_g ? 1 : 0);
@@ -421,7 +505,8 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
             const double sn2 = get_sn(y, c, scr, scr + c.nfft, red);
             const double g2 = est_g(y, bsub, T, sn2, red);
             if (g2 >= -1.0) g = g2;
-            if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 0, scr, nc_pools); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+            if (tid < 64) oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools);
+            if (tid == 0) { sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
             __syncthreads();
             P.n = sh_i[0]; ntask = sh_i[1];
             break;
