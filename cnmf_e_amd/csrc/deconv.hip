@@ -83,22 +83,20 @@ __device__ void select_pair(const float *y, int T, int k, int *hist /* 260 ints 
     vk1 = r == 0xffffffffu ? vk : fkey_inv(r);
 }
 
-// in-place radix-2 FFT of n complex points in LDS (re, im), 256 threads
-__device__ void fft_lds(float *re, float *im, int n, int logn) {
+// in-place radix-2 FFT of n complex points in LDS (re, im), 256 threads; the input is already in bit-reversed order and
+// tw[k] = exp(-2 pi i k / n), k < n/4, is a table (a sincospif per butterfly was most of the transform's time); the second quarter
+// of the circle is -i times the first
+__device__ void fft_lds(float *re, float *im, const float2 *tw, int n, int logn) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 256) {                       // bit reversal
-        const int j = (int)(__brev((unsigned)i) >> (32 - logn));
-        if (j > i) { float t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
-    }
-    __syncthreads();
     for (int s = 1; s <= logn; ++s) {
-        const int half = 1 << (s - 1);
+        const int half = 1 << (s - 1), tstep = n >> s;
         for (int b = tid; b < n / 2; b += 256) {
-            const int grp = b / half, pos = b % half;
-            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
-            float sn_, cs_;
-            sincospif(-(float)pos / (float)half, &sn_, &cs_);
-            const float xr = re[i1] * cs_ - im[i1] * sn_, xi = re[i1] * sn_ + im[i1] * cs_;
+            const int pos = b & (half - 1);
+            const int i0 = ((b >> (s - 1)) << s) + pos, i1 = i0 + half;
+            const int tk = pos * tstep;
+            float2 w = tw[tk & (n / 4 - 1)];
+            if (tk >= n / 4) w = make_float2(w.y, -w.x);
+            const float xr = re[i1] * w.x - im[i1] * w.y, xi = re[i1] * w.y + im[i1] * w.x;
             const float ur = re[i0], ui = im[i0];
             re[i0] = ur + xr; im[i0] = ui + xi; re[i1] = ur - xr; im[i1] = ui - xi;
         }
@@ -106,10 +104,16 @@ __device__ void fft_lds(float *re, float *im, int n, int logn) {
     }
 }
 
-// GetSn(y): Welch PSD (Hamming L, 50 % overlap, nfft) averaged as exp(mean(log(psd/2))) over 0.25 <= f <= 0.5
-__device__ double get_sn(const float *y, const DeconvCfg &c, float *re, float *im, double *red) {
+// GetSn(y, [0.25 0.5], 'logmexp'): Welch PSD (pwelch defaults: Hamming window of floor(T/4.5) samples, 50 % overlap, nfft =
+// max(256, nextpow2(L))), noise = sqrt(exp(mean(log(psd/2)))) over the upper half band.  scr = re | im | twiddles (nfft/2 floats) | window (nfft floats, only
+// with `wintab`; k_sn_pixels does without to keep two workgroups per CU).
+// Two real segments ride one complex transform (z = a + i b): the Welch sum only needs |A_k|^2 + |B_k|^2 = (|Z_k|^2 + |Z_{n-k}|^2) / 2,
+// and the same expression is |A_k|^2 for an unpaired last segment (b = 0).
+__device__ double get_sn(const float *y, const DeconvCfg &c, float *scr, double *red, bool wintab) {
     const int tid = threadIdx.x;
     const int nfft = c.nfft, L = c.L, step = c.L - c.nov;
+    float *re = scr, *im = scr + nfft, *win = scr + 2 * nfft + nfft / 2;
+    float2 *tw = reinterpret_cast<float2 *>(scr + 2 * nfft);
     int logn = 0; while ((1 << logn) < nfft) ++logn;
     const int k0 = (nfft + 3) / 4, k1 = nfft / 2;              // bins with 0.25 <= k/nfft <= 0.5
     const int nb = k1 - k0 + 1;
@@ -118,18 +122,24 @@ __device__ double get_sn(const float *y, const DeconvCfg &c, float *re, float *i
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) acc[i] = 0.f;
     double w2 = 0;
-    for (int i = tid; i < L; i += 256) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; }
+    for (int i = tid; i < L; i += 256) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; if (wintab) win[i] = (float)w; }
+    for (int k = tid; k < nfft / 4; k += 256) { float sn_, cs_; sincospif(-(float)k / (float)(nfft / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
     w2 = block_sum(w2, red);
-    for (int sg = 0; sg < c.nseg; ++sg) {
+    for (int sg = 0; sg < c.nseg; sg += 2) {
+        const bool two = sg + 1 < c.nseg;
         for (int i = tid; i < nfft; i += 256) {
-            float v = 0.f;
-            if (i < L) v = y[sg * step + i] * (float)(0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)));
-            re[i] = v; im[i] = 0.f;
+            float va = 0.f, vb = 0.f;
+            if (i < L) { const float w = wintab ? win[i] : (float)(0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1))); va = y[sg * step + i] * w; if (two) vb = y[(sg + 1) * step + i] * w; }
+            const int j = (int)(__brev((unsigned)i) >> (32 - logn));
+            re[j] = va; im[j] = vb;
         }
         __syncthreads();
-        fft_lds(re, im, nfft, logn);
+        fft_lds(re, im, tw, nfft, logn);
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i) { const int k = k0 + tid + i * 256; if (k <= k1) acc[i] += re[k] * re[k] + im[k] * im[k]; }
+        for (int i = 0; i < MAXB; ++i) {
+            const int k = k0 + tid + i * 256;
+            if (k <= k1) acc[i] += 0.5f * ((re[k] * re[k] + im[k] * im[k]) + (re[nfft - k] * re[nfft - k] + im[nfft - k] * im[nfft - k]));
+        }
         __syncthreads();
     }
     double ls = 0;
@@ -272,6 +282,37 @@ __device__ void oasis_cold(const float *y, double bsub, int T, double g, double 
     P.n = top + 1;
 }
 
+// The warm-started pass (foopsi_oasisAR1.m:155-161 hands update_g's pools back to oasisAR1) with its input pools staged in LDS by the
+// whole workgroup -- v, w, t, l and g^l per pool, 32 B each -- so that lane 0 neither waits for a global load nor evaluates a pow() per pool
+// (90 us per pass for ~10^2 pools).  Same tests as oasis_seq_t<true>; the stack is written to P as there.
+__device__ void oasis_warm(int nin, double g, double smin, Pools &P, const double *sv, const double *sw, const double *sg, const int *st, const int *sl) {
+    double cv = sv[0], cw = sw[0], cgl = sg[0];
+    int ct = st[0], cl = sl[0], top = 0;
+    double pv = 0, pw = 1, pgl = 1, plim = -INFINITY; int pt = 0, pl = 0;
+    for (int i = 1; i < nin; ++i) {
+        const double nv = sv[i], nw = sw[i], ngl = sg[i];
+        const int nt = st[i], nl = sl[i];
+        if (wave_uniform(nv * cw >= fma(smin, cw, cv * cgl) * nw)) {
+            P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl; ++top;
+            pv = cv; pw = cw; pt = ct; pl = cl; pgl = cgl;
+            { const double lim = pv * pgl; plim = fma(smin, pw, lim > 0.0 ? lim : 0.0); }
+            cv = nv; cw = nw; ct = nt; cl = nl; cgl = ngl;
+            continue;
+        }
+        cv = fma(nv, cgl, cv); cw = fma(nw * cgl, cgl, cw); cl += nl; cgl *= ngl;
+        while (wave_uniform(cv * pw < plim * cw)) {
+            cv = fma(cv, pgl, pv); cw = fma(cw * pgl, pgl, pw); ct = pt; cl = pl + cl; cgl = pgl * cgl;
+            --top;
+            if (top > 0) {
+                pv = P.v[top - 1]; pw = P.w[top - 1]; pt = P.t[top - 1]; pl = P.l[top - 1]; pgl = pow(g, (double)pl);
+                const double lim = pv * pgl; plim = fma(smin, pw, lim > 0.0 ? lim : 0.0);
+            } else plim = -INFINITY;
+        }
+    }
+    P.v[top] = cv; P.w[top] = cw; P.t[top] = ct; P.l[top] = cl;
+    P.n = top + 1;
+}
+
 // The same pass on the 64 lanes of wave 0.  Almost every sample of a real trace takes the "merge into the current pool" path (a 10^4-frame
 // trace ends with ~10^2 pools), and a run of merges has a closed form: after j merges onto the pool (v, w, g^l)
 //     v_j = v + g^l sum_{m<j} y_m g^m,      w_j = w + g^2l sum_{m<j} g^2m,      g^l_j = g^l g^j,
@@ -359,16 +400,27 @@ __device__ __forceinline__ void oasis_seq(const float *y, double bsub, int T, do
 __device__ __forceinline__ void oasis_first(const float *y, double bsub, int T, double g, double lam, double smin, Pools &P, float *lds_scr, int nc24) {
     if (lam == 0.0) { oasis_cold_wave(y, bsub, T, g, smin, P, lds_scr, (nc24 * 24) / 32); return; }
     if (threadIdx.x == 0) oasis_seq_t<false>(y, bsub, T, g, lam, smin, P, lds_scr, nc24);
+    P.n = __shfl(P.n, 0);
 }
 
-// split the pools into tasks of <= 64 samples (lane 0)
+// split the pools into tasks of <= 64 samples: wave 0, 64 pools per round, task slots from a wave prefix sum of the per-pool counts
+// (one lane walking the pool list paid a dependent global load per pool: 65 us for 115 pools)
 __device__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
+    const int lane = threadIdx.x;                                           // called by tid < 64 with P.n uniform
+    __threadfence_block();                                                  // lane 0 wrote the pools
     int nt = 0;
-    for (int p = 0; p < P.n; ++p)
-        for (int off = 0; off < P.l[p]; off += 64) {
-            io.tk_pool[base2 + nt] = p; io.tk_off[base2 + nt] = off;
-            io.tk_len[base2 + nt] = P.l[p] - off < 64 ? P.l[p] - off : 64; ++nt;
+    for (int p0 = 0; p0 < P.n; p0 += 64) {
+        const int p = p0 + lane;
+        const int l = p < P.n ? P.l[p] : 0;
+        const int k = (l + 63) >> 6;
+        int inc = k;
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        int at = nt + inc - k;
+        for (int off = 0; off < l; off += 64, ++at) {
+            io.tk_pool[base2 + at] = p; io.tk_off[base2 + at] = off; io.tk_len[base2 + at] = l - off < 64 ? l - off : 64;
         }
+        nt += __shfl(inc, 63);
+    }
     return nt;
 }
 
@@ -387,8 +439,9 @@ __device__ void pool_numerators(const float *y, double bsub, double lam, double 
     for (int k = tid; k < ntask; k += 256) {
         if (io.tk_off[base2 + k] != 0) continue;                 // first task of its pool sums the pool's tasks in order
         const int p = io.tk_pool[base2 + k];
+        const int nk = (P.l[p] + 63) >> 6;                       // (its task count from the pool length: no load-dependent loop exit)
         double s = 0;
-        for (int q = k; q < ntask && io.tk_pool[base2 + q] == p; ++q) s += io.tk_val[base2 + q];
+        for (int q = 0; q < nk; ++q) s += io.tk_val[base2 + k + q];
         num[p] = s;
     }
     __syncthreads();
@@ -408,8 +461,8 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     const int tid = threadIdx.x, T = c.T;
     const int slot = blockIdx.x, k = io.list[slot];
     float *y = sm;                                  // T raw samples (fp32), persistent
-    float *scr = sm + ((T + 3) & ~3);               // scratch: sort buffer P2 | FFT re, im (2*nfft) | top of the OASIS pool stack
-    const int nc_pools = (int)(((size_t)max(max(c.P2, 2 * c.nfft), T) * sizeof(float)) / 24);
+    float *scr = sm + ((T + 3) & ~3);               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
+    const int nc_pools = (int)(((size_t)max(max(c.P2, 4 * c.nfft), T) * sizeof(float)) / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
     Pools P; P.v = io.pv + base; P.w = io.pw + base; P.t = io.pt + base; P.l = io.pl + base; P.n = 0;
     double *num = io.pnum + base;                   // per-pool numerators
@@ -458,7 +511,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     }
     __syncthreads();
     // ---- noise level (GetSn on the raw trace: HALS_temporal.m:79, deconvTemporal.m:45) ----
-    const double sn = get_sn(y, c, scr, scr + c.nfft, red);
+    const double sn = get_sn(y, c, scr, red, true);
     // ---- time constant (deconvolveCa.m:73-89) ----
     double g = (double)io.pars[k];
     if (g == 0.0) {
@@ -483,8 +536,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     double b = c.optimize_b ? (q15 - bsub) : 0.0;    // :93 quantile(y, .15) of the baseline-subtracted trace
     int optimize_g = c.optimize_g;
     int ntask = 0;
-    if (tid < 64) oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools);
-    if (tid == 0) { sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+    if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
     __syncthreads();
     P.n = sh_i[0]; ntask = sh_i[1];
     const int niter = c.optimize_b ? c.maxIter : (optimize_g ? 1 : 0);
@@ -502,11 +554,10 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         if (!optimize_g) break;                      // :113-115
         const double g0 = g;
         if (g > c.gmax) {                            // :104-108
-            const double sn2 = get_sn(y, c, scr, scr + c.nfft, red);
+            const double sn2 = get_sn(y, c, scr, red, true);
             const double g2 = est_g(y, bsub, T, sn2, red);
             if (g2 >= -1.0) g = g2;
-            if (tid < 64) oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools);
-            if (tid == 0) { sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+            if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
             __syncthreads();
             P.n = sh_i[0]; ntask = sh_i[1];
             break;
@@ -562,9 +613,23 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         g = xf;
         // warm-started pools: v = yp' * h(g), w = cumsum(h_last.^2)(l) with h_last from the LAST rss_g call (:155-161, sic)
         pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, num);
-        for (int p = tid; p < P.n; p += 256) { P.v[p] = num[p]; P.w[p] = hh_of(glast, P.l[p]); }
+        const int ncap = nc_pools * 24 / 32;
+        const bool staged = P.n <= ncap;
+        double *sv = reinterpret_cast<double *>(scr), *sw = sv + ncap, *sg = sw + ncap;
+        int *st = reinterpret_cast<int *>(sg + ncap), *sl = st + ncap;
+        for (int p = tid; p < P.n; p += 256) {
+            const int l = P.l[p];
+            const double v = num[p], w = hh_of(glast, l);
+            P.v[p] = v; P.w[p] = w;
+            if (staged) { sv[p] = v; sw[p] = w; sg[p] = pow(g, (double)l); st[p] = P.t[p]; sl[p] = l; }
+        }
         __syncthreads();
-        if (tid == 0) { oasis_seq(y, bsub + b, T, g, lam, smin, P, 1, scr, nc_pools); sh_i[0] = P.n; sh_i[1] = build_tasks(P, io, base2); }
+        if (tid < 64) {
+            if (tid == 0) { if (staged) oasis_warm(P.n, g, smin, P, sv, sw, sg, st, sl); else oasis_seq(y, bsub + b, T, g, lam, smin, P, 1, scr, nc_pools); }
+            P.n = __shfl(P.n, 0);
+            const int nt = build_tasks(P, io, base2);
+            if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; }
+        }
         __syncthreads();
         P.n = sh_i[0]; ntask = sh_i[1];
         if (fabs(g - g0) / g0 < 1e-3) optimize_g = 0;            // :110-112
@@ -610,7 +675,7 @@ __global__ void __launch_bounds__(256) k_sn_pixels(DeconvCfg c, const float4 *__
     float *y = lds, *scr = lds + Tal;
     for (int q = tid; q < (T + 3) / 4; q += 256) *reinterpret_cast<float4 *>(y + 4 * q) = ysig4[(int64_t)q * d + m];
     __syncthreads();
-    const double v = get_sn(y, c, scr, scr + c.nfft, red);
+    const double v = get_sn(y, c, scr, red, false);
     if (tid == 0) sn[m] = (float)v;
 }
 
@@ -622,7 +687,7 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
     c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
     c.nseg = (int)((T - c.nov) / (c.L - c.nov));
-    const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft) * sizeof(float);
+    const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
     if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the GetSn kernel's LDS", (long long)T);
     if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     DevBuf &dSn = ctx->tmp[14];
@@ -649,7 +714,7 @@ int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg 
     c.smin_opt = o->smin; c.lam = o->lambda; c.gmax = exp(-1.0 / (o->max_tau > 0 ? o->max_tau : 100.0));
     c.hals = in_sweep; c.last = 0;
     if (o->lambda != 0.0) return fail(CNMFE_EUNSUPPORTED, "lambda != 0 is not built");
-    size_t scr = std::max<size_t>((size_t)c.P2, 2 * (size_t)c.nfft);
+    size_t scr = std::max<size_t>((size_t)c.P2, 4 * (size_t)c.nfft);
     scr = std::max<size_t>(scr, (size_t)T);
     shmem = ((((size_t)T + 3) & ~size_t(3)) + scr) * sizeof(float);
     if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the deconvolution kernel's LDS", (long long)T);
