@@ -424,25 +424,31 @@ __device__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
     return nt;
 }
 
-// per-pool numerators num_p = sum_j yp(t_p + j) g^j, deterministic (task partials, then a per-pool ordered sum)
+// per-pool numerators num_p = sum_j yp(t_p + j) g^j, deterministic (task partials, then a per-pool ordered sum), and -- when hh is
+// given -- the denominators hh_p = sum_{j<l_p} g^2j = cumsum(h.*h)(l_p) of foopsi_oasisAR1.m:166-174 from the same sweep.  tkv (2 doubles per
+// task), num and hh are flat pointers: k_deconv places them in LDS when the pool list is short enough (a Brent step is then not three
+// global-memory round trips long), else in the global scratch.
 __device__ void pool_numerators(const float *y, double bsub, double lam, double g, const Pools &P, const DeconvIO &io, int64_t base2,
-                                int ntask, double *num /* >= P.n, global */) {
+                                int ntask, double *tkv, double *num, double *hh) {
     const int tid = threadIdx.x;
+    double g64 = g; for (int i = 0; i < 6; ++i) g64 *= g64;       // g^64: a task starts at a multiple of 64 samples into its pool
     for (int k = tid; k < ntask; k += 256) {
         const int p = io.tk_pool[base2 + k], off = io.tk_off[base2 + k], len = io.tk_len[base2 + k];
         const int t0 = P.t[p] - 1 + off;
-        double gj = pow(g, (double)off), s = 0;
-        for (int j = 0; j < len; ++j) { s += (((double)y[t0 + j] - bsub) - lam * (1 - g)) * gj; gj *= g; }
-        io.tk_val[base2 + k] = s;
+        double gj = 1.0, s = 0, h2 = 0;
+        { double bs = g64; for (int e = off >> 6; e; e >>= 1) { if (e & 1) gj *= bs; bs *= bs; } }
+        for (int j = 0; j < len; ++j) { s += (((double)y[t0 + j] - bsub) - lam * (1 - g)) * gj; h2 = fma(gj, gj, h2); gj *= g; }
+        tkv[2 * k] = s; tkv[2 * k + 1] = h2;
     }
     __syncthreads();
     for (int k = tid; k < ntask; k += 256) {
         if (io.tk_off[base2 + k] != 0) continue;                 // first task of its pool sums the pool's tasks in order
         const int p = io.tk_pool[base2 + k];
         const int nk = (P.l[p] + 63) >> 6;                       // (its task count from the pool length: no load-dependent loop exit)
-        double s = 0;
-        for (int q = 0; q < nk; ++q) s += io.tk_val[base2 + k + q];
+        double s = 0, h2 = 0;
+        for (int q = 0; q < nk; ++q) { s += tkv[2 * (k + q)]; h2 += tkv[2 * (k + q) + 1]; }
         num[p] = s;
+        if (hh) hh[p] = h2;
     }
     __syncthreads();
 }
@@ -462,10 +468,22 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     const int slot = blockIdx.x, k = io.list[slot];
     float *y = sm;                                  // T raw samples (fp32), persistent
     float *scr = sm + ((T + 3) & ~3);               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
-    const int nc_pools = (int)(((size_t)max(max(c.P2, 4 * c.nfft), T) * sizeof(float)) / 24);
+    const size_t scr_bytes = (size_t)max(max(c.P2, 4 * c.nfft), T) * sizeof(float);
+    const int nc_pools = (int)(scr_bytes / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
     Pools P; P.v = io.pv + base; P.w = io.pw + base; P.t = io.pt + base; P.l = io.pl + base; P.n = 0;
-    double *num = io.pnum + base;                   // per-pool numerators
+    // per-task partial sums, per-pool numerators and denominators of update_g: the tail of scr when 48 B per pool (32 for the staged warm
+    // pass at its head) and 16 B per task fit, else the global scratch (then without the denominators: hh_of() per pool)
+    double *tkv = io.tk_val + 2 * base2, *num = io.pnum + base, *hhs = nullptr;          // (tk_val: 4 T doubles per slot, two per task)
+    bool in_lds = false;
+    int ntask = 0;
+    auto place = [&]() {                            // after every build_tasks: P.n and ntask changed
+        in_lds = (size_t)48 * P.n + (size_t)16 * ntask <= scr_bytes;
+        if (in_lds) {
+            double *end = reinterpret_cast<double *>(reinterpret_cast<char *>(scr) + scr_bytes);
+            tkv = end - 2 * ntask; num = tkv - P.n; hhs = num - P.n;
+        } else { tkv = io.tk_val + 2 * base2; num = io.pnum + base; hhs = nullptr; }
+    };
 
     // ---- raw trace into LDS; HALS: ck_raw = C(k,:) + (U(k,:) - V(k,:)*C)/aa(k)  (HALS_temporal.m:62) ----
     float *ck = io.C + (int64_t)k * io.ldc;
@@ -535,10 +553,9 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     // ---- foopsi_oasisAR1.m:82-117 ----
     double b = c.optimize_b ? (q15 - bsub) : 0.0;    // :93 quantile(y, .15) of the baseline-subtracted trace
     int optimize_g = c.optimize_g;
-    int ntask = 0;
     if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
     __syncthreads();
-    P.n = sh_i[0]; ntask = sh_i[1];
+    P.n = sh_i[0]; ntask = sh_i[1]; place();
     const int niter = c.optimize_b ? c.maxIter : (optimize_g ? 1 : 0);
     for (int it = 0; it < niter; ++it) {
         // sum of the current solution: c(t) = max(0, v/w) g^j on each pool
@@ -559,7 +576,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
             if (g2 >= -1.0) g = g2;
             if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
             __syncthreads();
-            P.n = sh_i[0]; ntask = sh_i[1];
+            P.n = sh_i[0]; ntask = sh_i[1]; place();
             break;
         }
         // ---- update_g (:122-180): Brent's fminbnd of rss(g) on [0,1] ----
@@ -567,9 +584,9 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         for (int t = tid; t < T; t += 256) { const double v = (double)y[t] - (bsub + b); sumy2 += v * v; }
         sumy2 = block_sum(sumy2, red);
         auto rss = [&](double gg) -> double {
-            pool_numerators(y, bsub + b, lam, gg, P, io, base2, ntask, num);
+            pool_numerators(y, bsub + b, lam, gg, P, io, base2, ntask, tkv, num, hhs);
             double s = 0;
-            for (int p = tid; p < P.n; p += 256) { const double nm = num[p]; if (nm > 0) s += nm * nm / hh_of(gg, P.l[p]); }
+            for (int p = tid; p < P.n; p += 256) { const double nm = num[p]; if (nm > 0) s += nm * nm / (hhs ? hhs[p] : hh_of(gg, P.l[p])); }
             s = block_sum(s, red);
             return sumy2 - s;                        // ||y - c||^2 with c = max(num/hh, 0) h on every pool (lam = 0 form)
         };
@@ -612,14 +629,13 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         }
         g = xf;
         // warm-started pools: v = yp' * h(g), w = cumsum(h_last.^2)(l) with h_last from the LAST rss_g call (:155-161, sic)
-        pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, num);
-        const int ncap = nc_pools * 24 / 32;
-        const bool staged = P.n <= ncap;
-        double *sv = reinterpret_cast<double *>(scr), *sw = sv + ncap, *sg = sw + ncap;
-        int *st = reinterpret_cast<int *>(sg + ncap), *sl = st + ncap;
+        pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, tkv, num, nullptr);       // (hhs keeps the LAST rss_g call's sums)
+        const bool staged = in_lds;
+        double *sv = reinterpret_cast<double *>(scr), *sw = sv + P.n, *sg = sw + P.n;
+        int *st = reinterpret_cast<int *>(sg + P.n), *sl = st + P.n;
         for (int p = tid; p < P.n; p += 256) {
             const int l = P.l[p];
-            const double v = num[p], w = hh_of(glast, l);
+            const double v = num[p], w = hhs ? hhs[p] : hh_of(glast, l);
             P.v[p] = v; P.w[p] = w;
             if (staged) { sv[p] = v; sw[p] = w; sg[p] = pow(g, (double)l); st[p] = P.t[p]; sl[p] = l; }
         }
@@ -631,7 +647,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
             if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; }
         }
         __syncthreads();
-        P.n = sh_i[0]; ntask = sh_i[1];
+        P.n = sh_i[0]; ntask = sh_i[1]; place();
         if (fabs(g - g0) / g0 < 1e-3) optimize_g = 0;            // :110-112
         if (!c.optimize_b) break;
     }
@@ -727,7 +743,7 @@ int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const
     RET(s.pv.ensure((size_t)n * T * 8)); RET(s.pw.ensure((size_t)n * T * 8));
     RET(s.pt.ensure((size_t)n * T * 4)); RET(s.pl.ensure((size_t)n * T * 4));
     RET(s.tkp.ensure((size_t)n * 2 * T * 4)); RET(s.tko.ensure((size_t)n * 2 * T * 4)); RET(s.tkl.ensure((size_t)n * 2 * T * 4));
-    RET(s.tkv.ensure((size_t)n * 2 * T * 8)); RET(s.pnum.ensure((size_t)n * T * 8));
+    RET(s.tkv.ensure((size_t)n * 4 * T * 8)); RET(s.pnum.ensure((size_t)n * T * 8));
     io.list = d_list;
     io.pv = s.pv.as<double>(); io.pw = s.pw.as<double>(); io.pt = s.pt.as<int>(); io.pl = s.pl.as<int>();
     io.tk_pool = s.tkp.as<int>(); io.tk_off = s.tko.as<int>(); io.tk_len = s.tkl.as<int>(); io.tk_val = s.tkv.as<double>(); io.pnum = s.pnum.as<double>();

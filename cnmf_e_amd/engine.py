@@ -326,13 +326,16 @@ class Engine:
         return L.DeconvOpts(1, 1, float(o["smin"]), float(o.get("lambda", 0.0)), float(o["max_tau"]),
                             int(bool(o["optimize_b"])), int(bool(o["optimize_pars"])), int(o.get("maxIter", maxIter)))
 
-    def hals_temporal_deconv(self, pid, A_patch, C_patch, maxIter, deconv_options, kernel_pars=None):
+    def hals_temporal_deconv(self, pid, A_patch, C_patch, maxIter, deconv_options, kernel_pars=None, want_all=True):
         """[C, C_raw, results_deconv] = HALS_temporal(Y, A, C, maxIter, deconv_options): returns
-        (C, C_raw, S, sn, kernel_pars, aa)."""
+        (C, C_raw, S, sn, kernel_pars, aa).  want_all=False skips the download of C and S (update_temporal_parallel.m:106-110
+        only keeps C_raw and aa; two K x T copies over PCIe otherwise)."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_patch, info["d"])
         Cm = _traces(C_patch, K, info["T"])
-        Cout = np.empty_like(Cm); Craw = np.empty_like(Cm); S = np.empty_like(Cm)
+        Craw = np.empty_like(Cm)
+        Cout = np.empty_like(Cm) if want_all else None
+        S = np.empty_like(Cm) if want_all else None
         aa = np.empty(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
         pars = np.zeros(K, dtype=np.float32) if kernel_pars is None else np.ascontiguousarray(kernel_pars, dtype=np.float32).copy()
         opts = self._dopts(deconv_options)
@@ -341,9 +344,12 @@ class Engine:
                                                  _p(S, L.f32p), _p(sn, L.f32p), _p(aa, L.f32p)))
         return Cout, Craw, S, sn, pars, aa
 
-    def deconv_temporal(self, C_raw, deconv_options):
-        """obj.deconvTemporal(): returns (C, C_raw, S, kernel_pars, sn)"""
-        Craw = np.ascontiguousarray(C_raw, dtype=np.float32).copy()
+    def deconv_temporal(self, C_raw, deconv_options, overwrite=False):
+        """obj.deconvTemporal(): returns (C, C_raw, S, kernel_pars, sn).  The ABI updates C_raw in place (ck_raw - b); overwrite=True
+        lets it do that to the caller's array (when that is a C-contiguous float32 one) instead of to a copy."""
+        Craw = np.ascontiguousarray(C_raw, dtype=np.float32)
+        if Craw is C_raw and not overwrite:
+            Craw = Craw.copy()
         K, T = Craw.shape
         Cout = np.empty_like(Craw); S = np.empty_like(Craw)
         pars = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)

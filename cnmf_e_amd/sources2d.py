@@ -412,6 +412,11 @@ class Sources2D:
             return self.C_raw.copy()
         v = self.video
         rows = np.arange(K)[v.rank::v.world_size] if (self.dist is not None and v.world_size > 1) else np.arange(K)
+        if rows.size == K:                                               # not sharded: no row gather / scatter of K x T arrays on the host
+            C, Craw, S, kp, sn = self.engine.deconv_temporal(self.C_raw, self.options.deconv_options, overwrite=True)
+            self.C, self.C_raw, self.S = C, Craw, S
+            self.P["kernel_pars"], self.P["neuron_sn"] = kp, sn
+            return C
         C = np.zeros_like(self.C_raw); Craw = np.zeros_like(self.C_raw); S = np.zeros_like(self.C_raw)
         kp = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
         if rows.size:
@@ -703,15 +708,15 @@ class Sources2D:
             if not use_c_hat:                                                                         # :174-175
                 C_raw_p, aa_p = self.engine.fast_temporal(v.pid[idx], A_pp)
             elif o.deconv_flag:                                                                       # :106-110
-                _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options)
+                _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options, want_all=False)
             else:
                 _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False)   # :180-181
             if sharded:
                 pieces.append((ind, C_raw_p, aa_p))                        # scattered and weighted on the collective's device
                 continue
-            if len(v.owned) == 1 and ind.size == K and use_c_hat and not o.deconv_flag:
-                # one patch sees every neuron: aa.*C_raw./aa (:274-280) is C_raw itself, rows with aa = 0 are zero, and HALS_temporal
-                # already subtracted each row's minimum (HALS_temporal.m:64-68), so :285 changes nothing
+            if len(v.owned) == 1 and ind.size == K and use_c_hat:
+                # one patch sees every neuron: aa.*C_raw./aa (:274-280) is C_raw itself, rows with aa = 0 are zero, and (without
+                # deconvolution) HALS_temporal already subtracted each row's minimum (HALS_temporal.m:64-68), so :285 changes nothing
                 C_raw_p[aa_p == 0] = 0
                 single = C_raw_p
                 continue
