@@ -313,6 +313,30 @@ __device__ void oasis_warm(int nin, double g, double smin, Pools &P, const doubl
     P.n = top + 1;
 }
 
+// wave64 inclusive prefix sum of doubles on the DPP path: four row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31
+// carry the row totals across (lanes without a source add 0).  Six ds_bpermute round trips of a shuffle-based scan are ~1500 clocks, this is ~150.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_scan_incl(double x) {
+    x += dpp_take<0x111, 0xf>(x);      // row_shr:1
+    x += dpp_take<0x112, 0xf>(x);      // row_shr:2
+    x += dpp_take<0x114, 0xf>(x);      // row_shr:4
+    x += dpp_take<0x118, 0xf>(x);      // row_shr:8
+    x += dpp_take<0x142, 0xa>(x);      // row_bcast:15 into rows 1 and 3
+    x += dpp_take<0x143, 0xc>(x);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ double lane_of(double x, int j) {                // x of lane j, j wave-uniform
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), j), hi = __builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // The same pass on the 64 lanes of wave 0.  Almost every sample of a real trace takes the "merge into the current pool" path (a 10^4-frame
 // trace ends with ~10^2 pools), and a run of merges has a closed form: after j merges onto the pool (v, w, g^l)
 //     v_j = v + g^l sum_{m<j} y_m g^m,      w_j = w + g^2l sum_{m<j} g^2m,      g^l_j = g^l g^j,
@@ -364,9 +388,8 @@ __device__ void oasis_cold_wave(const float *y, double bsub, int T, double g, do
         const int idx = i + lane;
         const bool in = idx < T;
         const double nv = in ? (double)y[idx] - bsub : 0.0;
-        double sc = nv * gm;                                                // inclusive scan of y_m g^m
-        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(sc, o); if (lane >= o) sc += up; }
-        double ex = __shfl_up(sc, 1); if (lane == 0) ex = 0.0;
+        const double xs = nv * gm;
+        const double ex = dpp_take<0x138, 0xf>(wave_scan_incl(xs));         // exclusive scan of y_m g^m (wave_shr:1; lane 0 takes 0)
         const double gl_j = cgl * gm;                                        // state in front of this lane's sample
         const double v_j = fma(cgl, ex, cv), w_j = fma(cgl * cgl, qm, cw);
         const bool ev_push = in && (nv * w_j >= fma(smin, w_j, v_j * gl_j));
@@ -374,14 +397,14 @@ __device__ void oasis_cold_wave(const float *y, double bsub, int T, double g, do
         const bool ev_back = in && !ev_push && (v_n * pw < plim * w_n);
         const unsigned long long stop = __builtin_amdgcn_ballot_w64(ev_push || ev_back || !in);
         const unsigned long long pushes = __builtin_amdgcn_ballot_w64(ev_push);
-        const int j = stop ? __builtin_ctzll(stop) : 64;                    // samples i .. i+j-1 merge
-        if (j == 64) { cv = __shfl(v_n, 63); cw = __shfl(w_n, 63); cgl = __shfl(gl_n, 63); cl += 64; i += 64; continue; }
-        if (i + j >= T) { cv = __shfl(v_j, j); cw = __shfl(w_j, j); cgl = __shfl(gl_j, j); cl += j; i += j; continue; }   // ran off the trace
+        const int j = __builtin_amdgcn_readfirstlane(stop ? __builtin_ctzll(stop) : 64);                    // samples i .. i+j-1 merge
+        if (j == 64) { cv = lane_of(v_n, 63); cw = lane_of(w_n, 63); cgl = lane_of(gl_n, 63); cl += 64; i += 64; continue; }
+        if (i + j >= T) { cv = lane_of(v_j, j); cw = lane_of(w_j, j); cgl = lane_of(gl_j, j); cl += j; i += j; continue; }   // ran off the trace
         if ((pushes >> j) & 1) {                                            // the state the firing lane tested is the one that is kept
-            cv = __shfl(v_j, j); cw = __shfl(w_j, j); cgl = __shfl(gl_j, j); cl += j;
-            push(__shfl(nv, j), i + j + 1);
+            cv = lane_of(v_j, j); cw = lane_of(w_j, j); cgl = lane_of(gl_j, j); cl += j;
+            push(lane_of(nv, j), i + j + 1);
         } else {
-            cv = __shfl(v_n, j); cw = __shfl(w_n, j); cgl = __shfl(gl_n, j); cl += j + 1;
+            cv = lane_of(v_n, j); cw = lane_of(w_n, j); cgl = lane_of(gl_n, j); cl += j + 1;
             backtrack();
         }
         i += j + 1;
