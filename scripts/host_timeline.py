@@ -4,7 +4,7 @@ import argparse, os, sys, time, functools
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)")
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -42,7 +42,7 @@ for name in dir(Engine):
             log.append((name, t0, t1, threading.get_ident() == main)); return r_
         return w
     setattr(Engine, name, wrap(fn, name))
-s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub), f.A_init, f.C_init, f.sn, dist_group=group)
+s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub, deconv_flag=a.deconv), f.A_init, f.C_init, f.sn, dist_group=group)
 if rank != 0:
     sys.stdout = open(os.devnull, 'w')
 marks = []
