@@ -405,3 +405,48 @@ def test_ring_change_rebuilds_the_kept_table(eng):
             assert a.shape == b.shape and np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
     finally:
         eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
+
+
+def _ar1_traces(K, T, g=0.95, sn=0.3, seed=5, rate=0.01, amp=1.5):
+    rng = np.random.default_rng(seed)
+    Y = np.zeros((K, T), np.float32)
+    for k in range(K):
+        s = (rng.random(T) < rate) * amp
+        c = np.zeros(T)
+        for t in range(T):
+            c[t] = (g * c[t - 1] if t else 0.0) + s[t]
+        Y[k] = c + 0.5 + sn * rng.standard_normal(T)
+    return Y
+
+
+@pytest.mark.parametrize("T", [3999, 4096])
+def test_deconv_many_pools_takes_the_global_fallbacks(eng, T):
+    """smin = 0 (non-negativity only): a noisy trace keeps ~T/3 pools, far more than the LDS mirror of the pool stack, the LDS copies of the
+    update_g sums and the staged warm pass hold at this T, so k_deconv runs its global-memory fallbacks and the dense-event (one-sample)
+    stretches of the wave pass.  With smin = 0 the problem is convex and the active set unique: the oracle's c is matched closely.
+    Odd T also exercises the unpaired last Welch segment and the order statistics at odd length."""
+    import oasis_oracle as oo
+    Y = _ar1_traces(3, T)
+    opts = dict(type="ar1", method="foopsi", smin=0.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+    Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
+    Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Y.astype(np.float64), smin=0.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+    assert np.allclose(sng, snr, rtol=2e-4)
+    assert np.allclose(parsg, parsr, atol=2e-3), (parsg, parsr)
+    for k in range(Y.shape[0]):
+        assert (Sr[k] > 0).sum() > 480                                        # the regime the test is about (LDS holds <= ~250 / 512 pools here)
+        assert rel(Cg[k], Cr[k]) <= 5e-3, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 5e-3
+        assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 0.03 * (Sr[k] > 0).sum()
+
+
+def test_deconv_without_the_optimisation_loops(eng):
+    """optimize_pars = optimize_b = false: one cold pass per trace, nothing else (deconvolveCa.m:120-122 with both flags off)"""
+    import oasis_oracle as oo
+    Y = _ar1_traces(4, 2500, seed=9)
+    opts = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=False, optimize_b=False, max_tau=100.0)
+    Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
+    Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Y.astype(np.float64), smin=-5.0, optimize_pars=False, optimize_b=False, max_tau=100.0)
+    assert np.allclose(sng, snr, rtol=2e-4) and np.allclose(parsg, parsr, atol=1e-5)
+    for k in range(Y.shape[0]):
+        assert rel(Cg[k], Cr[k]) <= 1e-2, (k, rel(Cg[k], Cr[k]))
+        assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 2
