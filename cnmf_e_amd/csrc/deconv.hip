@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     const int slot = blockIdx.x, k = io.list[slot];
     float *y = sm;                                  // T raw samples (fp32), persistent
     float *scr = sm + ((T + 3) & ~3);               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
-    const size_t scr_bytes = (size_t)max(max(c.P2, 4 * c.nfft), T) * sizeof(float);
+    const size_t scr_bytes = (size_t)max(4 * c.nfft, (T + 3) & ~3) * sizeof(float);
     const int nc_pools = (int)(scr_bytes / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
     Pools P; P.v = io.pv + base; P.w = io.pw + base; P.t = io.pt + base; P.l = io.pl + base; P.n = 0;
@@ -727,7 +727,7 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
     c.nseg = (int)((T - c.nov) / (c.L - c.nov));
     const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
-    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the GetSn kernel's LDS", (long long)T);
+    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the GetSn kernel's LDS (trace + Welch transform in 160 KB: T <= 20400)", (long long)T);
     if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     DevBuf &dSn = ctx->tmp[14];
     RET(dSn.ensure((size_t)P->d * sizeof(float)));
@@ -753,10 +753,9 @@ int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg 
     c.smin_opt = o->smin; c.lam = o->lambda; c.gmax = exp(-1.0 / (o->max_tau > 0 ? o->max_tau : 100.0));
     c.hals = in_sweep; c.last = 0;
     if (o->lambda != 0.0) return fail(CNMFE_EUNSUPPORTED, "lambda != 0 is not built");
-    size_t scr = std::max<size_t>((size_t)c.P2, 4 * (size_t)c.nfft);
-    scr = std::max<size_t>(scr, (size_t)T);
+    const size_t scr = std::max<size_t>(4 * (size_t)c.nfft, ((size_t)T + 3) & ~size_t(3));     // FFT + tables | output staging; pool mirrors use what there is
     shmem = ((((size_t)T + 3) & ~size_t(3)) + scr) * sizeof(float);
-    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the deconvolution kernel's LDS", (long long)T);
+    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the deconvolution kernel's LDS (trace + Welch transform in 160 KB: T <= 18436)", (long long)T);
     return 0;
 }
 

@@ -450,3 +450,17 @@ def test_deconv_without_the_optimisation_loops(eng):
     for k in range(Y.shape[0]):
         assert rel(Cg[k], Cr[k]) <= 1e-2, (k, rel(Cg[k], Cr[k]))
         assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 2
+
+
+def test_deconv_long_trace_fits_lds(eng):
+    """T = 18000: trace (72 KB) + scratch (72 KB) is the largest image the kernel takes; a longer trace is refused with EUNSUPPORTED."""
+    import oasis_oracle as oo
+    from cnmf_e_amd._lib import CnmfeError
+    Y = _ar1_traces(2, 18000, seed=21, rate=0.004)
+    opts = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+    Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
+    Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Y[:1].astype(np.float64), smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+    assert np.allclose(sng[0], snr[0], rtol=2e-4) and abs(parsg[0] - parsr[0]) < 2e-3
+    assert rel(Cg[0], Cr[0]) <= 2e-2
+    with pytest.raises(CnmfeError):
+        eng.deconv_temporal(np.zeros((1, 20000), np.float32), opts)
