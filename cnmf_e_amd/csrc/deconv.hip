@@ -16,6 +16,7 @@ namespace cnmfe {
 
 struct DeconvCfg {
     int T, P2, nfft, L, nov, nseg;     // trace length, pow2 >= T, Welch geometry
+    int ylong;                         // the trace lives in global memory (k_deconv<true>)
     int maxIter;                       // foopsi iterations (20 inside HALS_temporal, 10 in deconvTemporal)
     int optimize_b, optimize_g;
     double smin_opt, lam, gmax;
@@ -32,6 +33,7 @@ struct DeconvIO {
     int *tk_pool, *tk_off, *tk_len;    // task scratch, 2*T per trace slot
     double *tk_val;
     double *pnum;                      // per-pool numerators, T per trace slot
+    float *ybuf, *obuf;                // long traces only: the raw trace and the output staging, Tal floats per trace slot each
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red) {
@@ -483,15 +485,21 @@ __device__ __forceinline__ double hh_of(double g, int l) {       // cumsum(h.*h)
     return s;
 }
 
+// LONG: the trace does not fit LDS beside the Welch transform (T > 18436) -- it and the output staging live in a per-slot global buffer
+// (L2-resident: a few hundred KB per workgroup) and LDS only holds the scratch.  Same code; every access to y goes through a pointer whose
+// address space the compiler infers per instantiation.
+template <bool LONG>
 __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double red[8];
     __shared__ int sh_i[4];
     const int tid = threadIdx.x, T = c.T;
     const int slot = blockIdx.x, k = io.list[slot];
-    float *y = sm;                                  // T raw samples (fp32), persistent
-    float *scr = sm + ((T + 3) & ~3);               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
-    const size_t scr_bytes = (size_t)max(4 * c.nfft, (T + 3) & ~3) * sizeof(float);
+    const int Tal = (T + 3) & ~3;
+    float *y = LONG ? io.ybuf + (int64_t)blockIdx.x * Tal : sm;          // T raw samples (fp32), persistent
+    float *scr = LONG ? sm : sm + Tal;               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
+    const size_t scr_bytes = (size_t)(LONG ? 4 * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
+    float *ostage = LONG ? io.obuf + (int64_t)blockIdx.x * Tal : scr;   // the solution c(t), before it is written out
     const int nc_pools = (int)(scr_bytes / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
     Pools P; P.v = io.pv + base; P.w = io.pw + base; P.t = io.pt + base; P.l = io.pl + base; P.n = 0;
@@ -683,21 +691,21 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         const double r = P.v[p] / P.w[p];
         double gj = pow(g, (double)off) * (r > 0 ? r : 0.0);
         const int t0 = P.t[p] - 1 + off;
-        for (int j = 0; j < len; ++j) { double cv = gj; if (!(cv == cv) || isinf(cv)) cv = 0.0; scr[t0 + j] = (float)cv; sabs += fabs(cv); gj *= g; }
+        for (int j = 0; j < len; ++j) { double cv = gj; if (!(cv == cv) || isinf(cv)) cv = 0.0; ostage[t0 + j] = (float)cv; sabs += fabs(cv); gj *= g; }
     }
     sabs = block_sum(sabs, red);
     __syncthreads();
     const double btot = bsub + b;                     // HALS: ck_raw - b - tmp_options.b ; deconvTemporal: ck_raw - options.b
     for (int t = tid; t < T; t += 256) {
         const float raw = (float)((double)y[t] - btot);
-        ck[t] = sabs == 0.0 ? raw : scr[t];
+        ck[t] = sabs == 0.0 ? raw : ostage[t];
         if (wr) { so[t] = 0.f; io.Craw[(int64_t)k * io.ldc + t] = raw; }
     }
     __syncthreads();
     if (wr)
         for (int p = 1 + tid; p < P.n; p += 256) {    // s(t_p) = c(t_p) - g c(t_p - 1) at pool starts
             const int t0 = P.t[p] - 1;
-            so[t0] = (float)((double)scr[t0] - g * (double)scr[t0 - 1]);
+            so[t0] = (float)((double)ostage[t0] - g * (double)ostage[t0 - 1]);
         }
     if (tid == 0) { io.pars[k] = (float)g; io.sn_out[k] = (float)sn; io.b_out[k] = (float)b; }
 }
@@ -738,12 +746,12 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
-struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list; };
+struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf; };
 
 int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg &c, size_t &shmem) {
     if (!o) return fail(CNMFE_EINVAL, "null deconvolution options");
     if (o->type != 1 || o->method != 1) return fail(CNMFE_EUNSUPPORTED, "only type 'ar1' / method 'foopsi' is built (demo_large_data_1p.m:38-43)");
-    if (T < 64 || T > 32768) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= 32768 frames (got %lld)", (long long)T);
+    if (T < 64 || T > 36868) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= 36868 frames (got %lld)", (long long)T);
     c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
     c.L = (int)(T / 4.5); c.nov = c.L / 2;
     c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
@@ -755,7 +763,12 @@ int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg 
     if (o->lambda != 0.0) return fail(CNMFE_EUNSUPPORTED, "lambda != 0 is not built");
     const size_t scr = std::max<size_t>(4 * (size_t)c.nfft, ((size_t)T + 3) & ~size_t(3));     // FFT + tables | output staging; pool mirrors use what there is
     shmem = ((((size_t)T + 3) & ~size_t(3)) + scr) * sizeof(float);
-    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames does not fit the deconvolution kernel's LDS (trace + Welch transform in 160 KB: T <= 18436)", (long long)T);
+    c.ylong = 0;
+    if (shmem > 160 * 1024 - 256) {                  // long recording: trace and output staging in global memory, LDS = the scratch alone
+        c.ylong = 1;
+        shmem = 4 * (size_t)c.nfft * sizeof(float);
+        if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames: the Welch transform (nfft = %d) does not fit the deconvolution kernel's LDS (T <= 36868)", (long long)T, c.nfft);
+    }
     return 0;
 }
 
@@ -769,8 +782,17 @@ int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const
     io.list = d_list;
     io.pv = s.pv.as<double>(); io.pw = s.pw.as<double>(); io.pt = s.pt.as<int>(); io.pl = s.pl.as<int>();
     io.tk_pool = s.tkp.as<int>(); io.tk_off = s.tko.as<int>(); io.tk_len = s.tkl.as<int>(); io.tk_val = s.tkv.as<double>(); io.pnum = s.pnum.as<double>();
-    if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv, dim3(n), dim3(256), shmem, c, io);
+    io.ybuf = io.obuf = nullptr;
+    if (c.ylong) {
+        const size_t Tal = ((size_t)T + 3) & ~size_t(3);
+        RET(s.ybuf.ensure((size_t)n * Tal * 4)); RET(s.obuf.ensure((size_t)n * Tal * 4));
+        io.ybuf = s.ybuf.as<float>(); io.obuf = s.obuf.as<float>();
+        if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<true>, dim3(n), dim3(256), shmem, c, io);
+        return 0;
+    }
+    if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<false>, dim3(n), dim3(256), shmem, c, io);
     return 0;
 }
 
