@@ -739,6 +739,10 @@ __global__ void __launch_bounds__(512) k_gram5(const float *__restrict__ bf, int
 // (256 px) x (footprints near it, <= 64) x T' GEMM on the fp64 pipe, 0.1-0.2 TFLOP instead of 9.6 -- and one sweep over the table.
 // Everything is fp64 (exact fp32 products, fp64 sums): the difference of the two large terms keeps ~1e-13 relative accuracy.
 constexpr int WIN_NLB = 64;
+#ifndef WIN_AHEAD_N
+#define WIN_AHEAD_N 2
+#endif
+constexpr int WIN_AHEAD = WIN_AHEAD_N;
 
 // csum[k] = sum over the used frames of Cc_k  (the ones-row of X: rowsum(Bf) = rowsum(Yc) - A csum)
 __global__ void __launch_bounds__(256) k_trace_subsum(const float *__restrict__ Cc, int64_t ldc, int64_t Tp, int kstride, double *__restrict__ csum) {
@@ -811,13 +815,19 @@ __device__ __forceinline__ void win_body(const float4 *__restrict__ Y4, const Bg
             for (int b = 0; b < NT; ++b) accg[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv, bv[b], accg[b], 0, 0, 0);
         }
     };
-    Frag f0 = load(c0), f1 = load(c0 + 1);                  // loads past the segment return zeros
-    for (int64_t c = c0; c < c1; c += 2) {
-        const Frag n0 = load(c + 2);
-        mm(f0);
-        const Frag n1 = load(c + 3);
-        mm(f1);
-        f0 = n0; f1 = n1;
+    // loads run WIN_AHEAD chunks in front of the MFMAs; loads past the segment return zeros.  (Measured at H: 2 ahead 5.5 ms, 3 ahead 5.4 ms,
+    // 6 ahead 6.0 ms -- each extra chunk costs 18 VGPRs and beyond 256 the kernel drops to one wave per SIMD; with lists of ~48 traces the
+    // 13 fp64 MFMAs per chunk and wave are ~4 ms of matrix-pipe time at the clock this kernel runs at, so latency is not what is left.)
+    Frag f[WIN_AHEAD];
+#pragma unroll
+    for (int d = 0; d < WIN_AHEAD; ++d) f[d] = load(c0 + d);
+    for (int64_t c = c0; c < c1; c += WIN_AHEAD) {
+#pragma unroll
+        for (int d = 0; d < WIN_AHEAD; ++d) {
+            const Frag nx = load(c + WIN_AHEAD + d);
+            mm(f[d]);
+            f[d] = nx;
+        }
     }
     // D layout (fp64 16x16): row = (lane>>4) + 4r, col = lane&15
 #pragma unroll
