@@ -313,6 +313,30 @@ class Sources2D:
         else:
             self.engine.residual_ssub(self.video.pid[idx], self.pid_res[idx], self.ssub, A_prev_b, C_prev_b)
 
+    def init_residual(self, idx):
+        """@Sources2D/initComponents_residual_parallel.m:106-121,186-217 (ring model): the video greedyROI_endoscope searches for missed
+        neurons in patch `idx` -- the block's neurons subtracted, then the ring background,
+            Ypatch = Y(ind_patch,:) - A*C - W*(Y - A*C) - (b0 - W*mean(Y - A*C, 2))       (:199,:206; the imresize form :209-217 for bg_ssub > 1).
+        The sweep over the video is cnmfe_residual[_ssub] with the block's current neurons (it leaves that residual resident, like
+        the call of a temporal update would); the footprints' own A(patch,:)*C is a sparse product on the exported copy.  Returns a
+        (T, d_patch) float32 array (frame-major == the reference's d x T in MATLAB order).  greedyROI_endoscope itself is host code
+        outside this engine (initialisation is out of scope)."""
+        self._need_data()
+        v = self.video
+        ind, A_blk = self._slice(self.A, idx, "block")                                               # :116-117
+        C_blk = self._rows(self.C, ind) if ind.size else None                                        # :120
+        pid = v.pid[idx]
+        if self.ssub == 1:
+            out = self.engine.residual(pid, A_blk if ind.size else None, C_blk, want=True)
+        else:
+            out = self.engine.residual_ssub(pid, self.pid_res[idx], self.ssub, A_blk if ind.size else None, C_blk, want=True)
+        if ind.size:
+            A_pp = self._slice(self.A, idx, "patch", cols=ind)[1].tocsr()
+            Cb = np.asarray(C_blk, dtype=np.float32)
+            for t0 in range(0, out.shape[0], 2048):                                                  # :199, on the patch rows
+                out[t0:t0 + 2048] -= (A_pp @ Cb[:, t0:t0 + 2048]).T
+        return out
+
     def get_b0(self, idx):
         return self.engine.b0(self.video.pid[idx])
 

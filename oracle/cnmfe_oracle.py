@@ -783,6 +783,23 @@ class OracleSources2D:
             self.A @ self.C.mean(axis=1)).reshape(d1, d2, order="F")        # :349
 
     # -- temporal ----------------------------------------------------------------
+    def init_residual(self, idx):
+        """@Sources2D/initComponents_residual_parallel.m:106-121,186-217 (ring model): the video greedyROI_endoscope searches for missed
+        neurons in one patch -- the block's neurons subtracted, then the ring background: Ypatch = Y(ind_patch,:) - A*C - W*(Y - A*C) -
+        (b0 - W*mean(Y - A*C, 2)) (bg_ssub = 1, :206), the imresize form for bg_ssub > 1 (:209-217).  Returns d_patch x T (float64)."""
+        p, b = self.patch_pos[idx], self.block_pos[idx]
+        mb = self._mask(b)
+        ind = np.nonzero(np.asarray(self.A[mb, :].sum(axis=0)).ravel() > 0)[0]             # :116
+        A_b = self.A[mb, :][:, ind]                                                         # :117
+        C_b = self.C[ind, :]                                                                # :120
+        ip = ind_patch_mask(p, b)
+        Yb = self._block(b)
+        # :199 subtracts A*C from the whole block first; _residual's Y(ind_patch,:) - W*(Y - A*C) - ... keeps the neurons in its first term
+        Ysig = self._residual(Yb, A_b, C_b, idx, ip, b)
+        if ind.size:
+            Ysig = Ysig - np.asarray(A_b[ip, :] @ C_b)
+        return Ysig
+
     def update_temporal_parallel(self, use_c_hat=True):
         """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295 (no deconv)."""
         K, T = self.C.shape

@@ -604,3 +604,35 @@ def test_reconstruct_background_parity(eng):
     assert rel(got, ref) <= 2e-4, rel(got, ref)            # (W itself agrees to 2e-3 with the oracle's; Ybg is dominated by b0)
     part = s.reconstruct_background((50, 120))
     assert np.array_equal(part, got[:, :, 49:120])
+
+
+@pytest.mark.parametrize("bg_ssub", [1, 2])
+def test_init_residual_parity(eng, bg_ssub):
+    """initComponents_residual_parallel.m:106-121,186-217 (ring branch): the per-patch video the residual initialisation searches,
+    Y - A*C - ring background, after a full iteration on 2x2 patches, vs the oracle.  The residual holds only noise and what the
+    model missed, so it is compared on the scale of the noise; a planted neuron that A does not know must survive in it."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 44, 40, 203, 6, (5 if bg_ssub == 1 else 10)
+    f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    A0, C0 = f.A_init.tocsc()[:, :K - 1], f.C_init[:K - 1]                      # the model misses the last neuron
+    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3, bg_ssub=bg_ssub), A0, C0, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, A0.astype(np.float32), C0, f.sn, maxIter=3, bg_ssub=bg_ssub)
+    for step in ("update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
+        getattr(s, step)(); getattr(o, step)()
+    o.A = s.A.astype(np.float64); o.C = np.asarray(s.C, dtype=np.float64)       # same model on both sides: the expression is what is compared
+    for idx in video.owned:
+        o.W[idx] = s.get_W(idx).astype(np.float64); o.b0[idx] = np.asarray(s.get_b0(idx), dtype=np.float64)
+    worst = 0.0
+    for idx in video.owned:
+        got = s.init_residual(idx).T.astype(np.float64)                          # d_patch x T
+        ref = o.init_residual(idx)
+        assert got.shape == ref.shape
+        worst = max(worst, np.abs(got - ref).max() / ref.std())
+    assert worst <= 2e-4, worst                                                  # fp32 storage of the residual against the float64 expression
+    k = K - 1                                                                     # the neuron the model does not know is still in the residual
+    idx = max(video.owned, key=lambda i: np.asarray(abs(f.A_true.tocsc()[:, k][video.patch_pix[i]]).sum()))
+    px = int(np.argmax(np.asarray(f.A_true.tocsc()[:, k].todense()).ravel()[video.patch_pix[idx]]))
+    assert np.corrcoef(s.init_residual(idx)[:, px], f.C_true[k])[0, 1] > 0.8

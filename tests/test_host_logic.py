@@ -117,3 +117,24 @@ def test_compute_rss_host_logic_with_fake_engine():
         getattr(s, step)(); getattr(o, step)()
         got, _ = s.compute_RSS(); ref, _ = o.compute_RSS()
         assert abs(got - ref) <= 1e-6 * ref, (step, got, ref)
+
+
+def test_init_residual_host_logic_with_fake_engine():
+    """Sources2D.init_residual (block's neurons, patch rows, A*C on the exported copy) against the oracle's restatement of
+    initComponents_residual_parallel.m:106-121,186-217, on the NumPy fake engine"""
+    from fake_engine import FakeEngine
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 30, 28, 60, 4, 5
+    f = synth.make_factors(d1, d2, T, K, 7, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    eng = FakeEngine()
+    video = PatchedVideo(d1, d2, T, [15, 14], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=2), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [15, 14], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=2)
+    for step in ("update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
+        getattr(s, step)(); getattr(o, step)()
+    for idx in video.owned:
+        got = np.asarray(s.init_residual(idx), dtype=np.float64).T
+        ref = o.init_residual(idx)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), idx
