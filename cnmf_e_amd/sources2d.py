@@ -240,6 +240,51 @@ class PatchedVideo:
     def upload_block_device(self, idx, dev_ptr):
         self.engine.upload_block_device(self.pid[idx], dev_ptr, self.T)
 
+    # -- data plane: what distribute_data.m:56-173 + get_patch_data.m:50-93 do for the reference (blocks with their halo out of the recording).
+    # The recording is read ONCE, in frame chunks; every owned block of a chunk goes up in the file's own element type (uint8/uint16/float16/
+    # float32/float64: cnmfe_upload_block converts on the device) -- there is no blocked intermediate file.
+    def upload_from_images(self, frames, chunk=256):
+        """frames: an array (T, d1, d2) or any iterable of T images of shape (d1, d2) -- rows x columns as MATLAB's Y(:,:,t), e.g. TIFF pages.
+        Pixels are re-ordered to the column-major order of the reference (pixel = (c-1)*d1 + r) chunk by chunk."""
+        t0, buf = 0, []
+        def flush():
+            nonlocal t0, buf
+            if len(buf) == 0:
+                return
+            arr = np.stack(buf) if not isinstance(buf, np.ndarray) else buf
+            if arr.shape[1:] != (self.d1, self.d2):
+                raise ValueError("frames are %s, the field of view is (%d, %d)" % (arr.shape[1:], self.d1, self.d2))
+            cm = arr.transpose(0, 2, 1).reshape(arr.shape[0], self.d1 * self.d2)        # column-major pixel order
+            for idx in self.owned:
+                self.engine.upload_block(self.pid[idx], cm[:, self.block_pix[idx]], t0)
+            t0 += arr.shape[0]; buf = []
+        if isinstance(frames, np.ndarray) and frames.ndim == 3:
+            for s0 in range(0, frames.shape[0], chunk):
+                buf = frames[s0:s0 + chunk]; flush()
+        else:
+            for im in frames:
+                buf.append(np.asarray(im))
+                if len(buf) == chunk:
+                    flush()
+            flush()
+        if t0 != self.T:
+            raise ValueError("the recording has %d frames, the patches were created for %d" % (t0, self.T))
+
+    def upload_from_tiff(self, path, chunk=256):
+        """a multi-page TIFF (what the reference's demos ship and tif2mat.m / bigread2.m read), one page per frame"""
+        from PIL import Image, ImageSequence
+        with Image.open(path) as im:
+            self.upload_from_images((np.asarray(page) for page in ImageSequence.Iterator(im)), chunk)
+
+    def upload_from_raw(self, path, dtype, offset=0, order="F", chunk=256):
+        """a flat binary recording of T frames (np.memmap, nothing is read twice): order='F' = MATLAB's fwrite of a d1 x d2 x T array (pixels
+        column-major inside a frame), order='C' = row-major frames (rows x columns, e.g. numpy's tofile of a (T, d1, d2) array)."""
+        mm = np.memmap(path, dtype=np.dtype(dtype), mode="r", offset=offset, shape=(self.T, self.d1 * self.d2))
+        if order == "F":
+            self.upload_from_full(mm, chunk)
+        else:
+            self.upload_from_images(mm.reshape(self.T, self.d1, self.d2), chunk)
+
 
 # --------------------------------------------------------------------------------------
 # Sources2D

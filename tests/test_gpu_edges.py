@@ -467,3 +467,25 @@ def test_deconv_long_traces(eng, T):
     assert abs((Sg[0] > 0).sum() - (Sr[0] > 0).sum()) <= max(2, 0.05 * (Sr[0] > 0).sum())
     with pytest.raises(CnmfeError):
         eng.deconv_temporal(np.zeros((1, 40000), np.float32), opts)
+
+
+def test_data_plane_uint16_tiff_to_device(eng, tmp_path):
+    """a uint16 multi-page TIFF goes up block by block in its own element type (converted on the device); the resident blocks are the
+    ones upload_from_full of the float video gives: same Ymean, same residual export"""
+    from PIL import Image
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2, T, r = 40, 36, 130, 5
+    rng = np.random.default_rng(11)
+    vol = rng.integers(100, 3000, size=(T, d1, d2)).astype(np.uint16)
+    tif = str(tmp_path / "rec.tif")
+    pages = [Image.fromarray(vol[t]) for t in range(T)]
+    pages[0].save(tif, save_all=True, append_images=pages[1:])
+    v = PatchedVideo(d1, d2, T, [20, 18], r, eng)
+    v.upload_from_tiff(tif, chunk=32)
+    Y_td = vol.transpose(0, 2, 1).reshape(T, d1 * d2).astype(np.float64)
+    for idx in v.owned:
+        ym = eng.ymean(v.pid[idx])
+        assert np.allclose(ym, Y_td[:, v.block_pix[idx]].mean(axis=0), rtol=1e-6)
+        eng.ring_init(v.pid[idx], r)
+        out = eng.residual(v.pid[idx], None, None, want=True)                   # fresh ring (uniform mean), b0 = 0
+        assert out.shape == (T, v.patch_pix[idx].size) and np.isfinite(out).all()

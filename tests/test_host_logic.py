@@ -138,3 +138,38 @@ def test_init_residual_host_logic_with_fake_engine():
         got = np.asarray(s.init_residual(idx), dtype=np.float64).T
         ref = o.init_residual(idx)
         assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), idx
+
+
+def test_data_plane_readers_match_upload_from_full(tmp_path):
+    """upload_from_images / upload_from_tiff / upload_from_raw hand every block the same frames as upload_from_full (the reference's
+    distribute_data + get_patch_data: blocks with halo, MATLAB pixel order), in the file's element type"""
+    from PIL import Image
+    from fake_engine import FakeEngine
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2, T, r = 18, 14, 23, 3
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 4000, size=(T, d1, d2)).astype(np.uint16)             # frames as images (rows x columns)
+    Y_td = vol.transpose(0, 2, 1).reshape(T, d1 * d2)                            # MATLAB d x T, transposed: pixels column-major
+
+    def blocks(loader):
+        eng = FakeEngine()
+        v = PatchedVideo(d1, d2, T, [9, 7], r, eng)
+        loader(v)
+        return {idx: eng.p[v.pid[idx]]["Y"].copy() for idx in v.owned}
+
+    ref = blocks(lambda v: v.upload_from_full(Y_td, chunk=5))
+    tif = str(tmp_path / "rec.tif")
+    pages = [Image.fromarray(vol[t]) for t in range(T)]
+    pages[0].save(tif, save_all=True, append_images=pages[1:])
+    rawF, rawC = str(tmp_path / "rec_f.bin"), str(tmp_path / "rec_c.bin")
+    Y_td.tofile(rawF); vol.tofile(rawC)
+    for name, got in (("images", blocks(lambda v: v.upload_from_images(vol, chunk=7))),
+                      ("iterable", blocks(lambda v: v.upload_from_images(iter(vol), chunk=4))),
+                      ("tiff", blocks(lambda v: v.upload_from_tiff(tif, chunk=6))),
+                      ("raw F", blocks(lambda v: v.upload_from_raw(rawF, np.uint16, chunk=8))),
+                      ("raw C", blocks(lambda v: v.upload_from_raw(rawC, np.uint16, order="C", chunk=8)))):
+        assert set(got) == set(ref), name
+        for idx in ref:
+            assert np.array_equal(np.asarray(got[idx], dtype=np.float64), np.asarray(ref[idx], dtype=np.float64)), (name, idx)
+    with pytest.raises(ValueError):
+        blocks(lambda v: v.upload_from_images(vol[:-1]))
