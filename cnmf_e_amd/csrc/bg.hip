@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) k_gram3(const float *__restrict__ bf, 
 // Bf is stored [block][frame/4][256][4] (like the resident video): a lane's A (or B) fragment for ALL FOUR
 // k-steps of a 16-frame stage is ONE conflict-free ds_read_b128 (lane (l&15, l>>4) reads quad-row l>>4: MFMA m
 // contracts frames {4*(l>>4) + m}), at lane base + a per-slot scalar tile offset.
-constexpr int G4_NBUF = 4, G4_STAGE_F = 2 * GK * 128, G4_MAXSLOT = 16;
+constexpr int G4_NBUF = 4, G4_STAGE_F = 2 * GK * 128;
 
 struct G4Wave {                       // per-wave constants of a work item (all wave-uniform except lbase, vo0, vo1)
     const float *gA, *gB;
@@ -1092,7 +1092,6 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
         nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
     }
     __syncthreads();
-    auto rsum = [&](int rb, int cb) { return rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + lp_of(rb & 15, cb & 15)]; };
     // ---- assemble the packed triangle ----
     // The p ring neighbours and the centre (node p) lie within a 31x31 window = at most 3x3 16x16 blocks.  The
     // pair-table indirection of cov_lookup is resolved once per block pair (81 lookups, PT in LDS); every entry of the

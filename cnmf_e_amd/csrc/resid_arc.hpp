@@ -36,7 +36,7 @@ template <int R> constexpr ArcTab<R> make_arcs() {
     for (int i = 0; i < ring.n; ++i) {
         const int dr = ring.dr[i], dc = ring.dc[i];
         const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
-        int a;
+        int a = 0;
         if (adc > adr) a = dc < 0 ? 0 : 1;
         else if (adr > adc) a = dr < 0 ? 2 : 3;
         else a = (dc < 0 && dr < 0) ? 0 : (dc > 0 && dr > 0) ? 1 : (dr < 0 ? 2 : 3);
