@@ -329,13 +329,15 @@ def test_hals_temporal_deconv_parity(eng):
         assert np.corrcoef(Cg[k], c.f.C_true[k])[0, 1] > 0.95
 
 
-def test_method_level_iteration_with_deconvolution(eng):
-    """deconv_flag=true through Sources2D.update_temporal_parallel: runs, recovers the planted traces, S is sparse."""
+@pytest.mark.parametrize("patch_dims", [[22, 20], [44, 40]])
+def test_method_level_iteration_with_deconvolution(eng, patch_dims):
+    """deconv_flag=true through Sources2D.update_temporal_parallel: runs, recovers the planted traces, S is sparse.  One patch over the whole
+    field of view takes the no-stitch shortcut (no K x T gathers on the host), 2 x 2 patches the weighted stitch of :269-280."""
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
     d1, d2, T, K, r = 44, 40, 1000, 6, 5
     f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
-    video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
+    video = PatchedVideo(d1, d2, T, patch_dims, r, eng)
     video.upload_from_full(Y)
     s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=2, deconv_flag=True), f.A_init, f.C_init, f.sn)
     s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
