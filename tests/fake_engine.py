@@ -57,6 +57,23 @@ class FakeEngine:
         q["res_AC"] = (A, None if C_prev is None else np.asarray(C_prev, dtype=np.float64))
         return q["Ysig"].T if want else None
 
+    @staticmethod
+    def _dopt(deconv_options):
+        o = dict(smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+        o.update({k: v for k, v in (deconv_options or {}).items() if k in o})
+        return o
+
+    def hals_temporal_deconv(self, pid, A_patch, C_patch, maxIter, deconv_options, kernel_pars=None, want_all=True):
+        import oasis_oracle as oo
+        A = sp.csc_matrix(A_patch).astype(np.float64)
+        Cn, Craw, S, sn, kp = oo.HALS_temporal_deconv(self.p[pid]["Ysig"], A, np.asarray(C_patch, dtype=np.float64), maxIter, **self._dopt(deconv_options))
+        aa = np.asarray(A.multiply(A).sum(axis=0)).ravel()
+        return Cn, Craw, S, sn, np.array([0.0 if g is None else g for g in kp]), aa
+
+    def deconv_temporal(self, C_raw, deconv_options, overwrite=False):
+        import oasis_oracle as oo
+        return oo.deconvTemporal(np.asarray(C_raw, dtype=np.float64), **self._dopt(deconv_options))
+
     def get_sn(self, pid):
         import oasis_oracle as oo
         return np.array([oo.GetSn(row) for row in self.p[pid]["Ysig"]], dtype=np.float32)

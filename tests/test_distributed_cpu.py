@@ -61,3 +61,42 @@ def test_two_rank_sharded_iteration_matches_single_process(tmp_path, update_sn):
     assert np.allclose(got["A"], o.A.toarray(), rtol=1e-4, atol=1e-6)
     assert np.allclose(got["C"], o.C, rtol=1e-4, atol=1e-4)
     assert np.allclose(got["b0_new"], o.b0_new, rtol=1e-5, atol=1e-2)
+
+
+def _deconv_run(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    group = None
+    if world > 1:
+        import torch.distributed as td
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        td.init_process_group("gloo", rank=rank, world_size=world)
+        group = td.group.WORLD
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    from fake_engine import FakeEngine
+    d1, d2, T, K, r = 30, 28, 160, 4, 5
+    f = synth.make_factors(d1, d2, T, K, 7, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [15, 14], r, FakeEngine(), rank=rank, world_size=world)
+    video.upload_from_full(Y.astype(np.float64))
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=2, deconv_flag=True), f.A_init, f.C_init, f.sn, dist_group=group)
+    s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+    res = dict(C=np.asarray(s.C), C_raw=np.asarray(s.C_raw), S=np.asarray(s.S), kp=np.asarray(s.P["kernel_pars"]), sn=np.asarray(s.P["neuron_sn"]))
+    if world > 1:
+        if rank == 0:
+            np.savez(out, **res)
+        td.barrier(); td.destroy_process_group()
+    return res
+
+
+def test_two_rank_sharded_deconvolution_matches_single_process(tmp_path):
+    """deconv_flag=true over 2 ranks: the per-patch HALS+OASIS sweeps, the all-reduce stitch of C_raw (:269-280) and deconvTemporal with its
+    rows sharded over the ranks give what one process gives"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_deconv_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    ref = _deconv_run(0, 1, 0, None)
+    for k in ("C", "C_raw", "S", "kp", "sn"):
+        assert np.allclose(got[k], ref[k], rtol=1e-6, atol=1e-6), k
+    assert (ref["S"] > 0).any()
