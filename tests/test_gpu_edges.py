@@ -489,3 +489,19 @@ def test_data_plane_uint16_tiff_to_device(eng, tmp_path):
         eng.ring_init(v.pid[idx], r)
         out = eng.residual(v.pid[idx], None, None, want=True)                   # fresh ring (uniform mean), b0 = 0
         assert out.shape == (T, v.patch_pix[idx].size) and np.isfinite(out).all()
+
+
+def test_deconv_degenerate_traces_terminate_with_finite_output(eng):
+    """all-zero, constant, single-spike and monotone traces: no stable AR(1) estimate / zero noise level / NaN intermediates must neither hang
+    the per-trace kernel nor leak NaN or Inf into C and S (deconvolveCa.m:84-89,206)"""
+    T = 400
+    Y = np.zeros((5, T), np.float32)
+    Y[1] = 3.25
+    Y[2, 100] = 10.0
+    Y[3] = np.linspace(0, 5, T, dtype=np.float32)
+    Y[4] = _ar1_traces(1, T, seed=2)[0]
+    opts = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+    Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
+    for a in (Cg, Crawg, Sg, parsg, sng):
+        assert np.isfinite(a).all()
+    assert np.all(Sg >= 0) and (Sg[4] > 0).any()
