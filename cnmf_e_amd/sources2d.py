@@ -314,6 +314,9 @@ class Sources2D:
         self.P = {"sn": np.asarray(sn, dtype=np.float32).reshape(-1).copy(), "Ymean": {}}
         self._b0_new_val = None; self._b0_new_src = None
         self.dist = dist_group
+        # test hook: take the collective (sharded) branches even with one rank, so that a single-GPU box can run the all-gather of A, the
+        # device-side stitch of C_raw and the lazy all-reduces over RCCL exactly as an N-rank job does (scripts/nccl_smoke.py)
+        self.force_collectives = False
         self._bind_C()
         self.ssub = int(options.bg_ssub)
         npatch = len(video.order)
@@ -408,7 +411,7 @@ class Sources2D:
         return self._ymean_full
 
     def _allreduce(self, arr):
-        if self.dist is None or self.video.world_size == 1:
+        if self.dist is None or (self.video.world_size == 1 and not self.force_collectives):
             return arr
         import torch
         import torch.distributed as td
@@ -665,7 +668,7 @@ class Sources2D:
 
     def _gather_sparse(self, A_):
         """all-gather of the per-rank rows of A (disjoint pixel sets, no reduction)."""
-        if self.dist is None or self.video.world_size == 1:
+        if self.dist is None or (self.video.world_size == 1 and not self.force_collectives):
             return A_
         import torch
         import torch.distributed as td
@@ -745,7 +748,7 @@ class Sources2D:
         launched_any = False
         acc = None                                                         # sum over patches of aa .* C_raw  (:274)
         aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
-        sharded = self.dist is not None and v.world_size > 1
+        sharded = self.dist is not None and (v.world_size > 1 or self.force_collectives)
         pieces = []
         single = None
         for idx in v.owned:

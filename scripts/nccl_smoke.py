@@ -49,4 +49,19 @@ for s in (ref, dev):
 print("iteration on the device-resident C: max |dC| / max|C| = %.2e, host copy made: %s" % (np.abs(np.asarray(dev.C) - np.asarray(ref.C)).max() / np.abs(np.asarray(ref.C)).max(), C_dev._host is not None))
 b = dev.b0_new
 print("b0_new ok", b.shape)
+# the collective branches of the three methods themselves, taken with one rank (force_collectives): all-gather of A over RCCL, device-side
+# stitch + all-reduce of C_raw, lazy all-reduces of b0 / Ymean -- two full iterations against the plain single-rank run
+ref2 = build(); frc = build(); frc.force_collectives = True
+for it in range(2):
+    for s in (ref2, frc):
+        s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+assert isinstance(frc.C, DeviceTraces), type(frc.C)
+eA = abs(frc.A - ref2.A).max() / abs(ref2.A).max()
+eC = np.abs(np.asarray(frc.C) - np.asarray(ref2.C)).max() / np.abs(np.asarray(ref2.C)).max()
+eb = np.abs(frc.b0_new - ref2.b0_new).max() / np.abs(ref2.b0_new).max()
+print("forced collectives, 2 iterations: max |dA| %.2e  |dC| %.2e  |db0_new| %.2e (relative)" % (eA, eC, eb))
+assert eA < 1e-4 and eC < 1e-4 and eb < 1e-4
+rss_f, _ = frc.compute_RSS(); rss_r, _ = ref2.compute_RSS()
+assert abs(rss_f - rss_r) <= 1e-4 * rss_r, (rss_f, rss_r)
+print("compute_RSS ok", rss_f)
 td.destroy_process_group()
