@@ -1,6 +1,7 @@
 """Builds libcnmfe_hip.so (gfx950) in-tree with hipcc.  `python -m cnmf_e_amd.build [--force]`."""
 from __future__ import annotations
 
+import glob
 import os
 import subprocess
 import sys
@@ -31,7 +32,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "cnmfe.h")]
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "cnmfe.h")]   # every header: resid_arc.hpp, ring_solve.hpp hold whole kernels
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

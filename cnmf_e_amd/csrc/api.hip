@@ -185,6 +185,24 @@ int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first) {
     return 0;
 }
 
+int ctx_errflag(cnmfe_ctx *ctx, int **dflag) {
+    if (!ctx->errflag.p) {
+        RET(ctx->errflag.ensure(sizeof(int)));
+        CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->stream));
+    }
+    *dflag = ctx->errflag.as<int>();
+    return 0;
+}
+int ctx_check_errflag(cnmfe_ctx *ctx) {
+    if (!ctx->errflag.p) return 0;
+    int h = 0;
+    CK(hipMemcpyAsync(&h, ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (!h) return 0;
+    CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->stream));
+    return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
+}
+
 // ring offsets: get_nhood.m:1-25, then sorted by (dc, dr) == MATLAB sparse column order
 static void ring_offsets(int radius, int k, std::vector<int32_t> &dr, std::vector<int32_t> &dc) {
     dr.clear(); dc.clear();
@@ -248,7 +266,7 @@ void cnmfe_destroy(cnmfe_ctx *ctx) {
 int cnmfe_synchronize(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_check_errflag(ctx);
 }
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
@@ -276,6 +294,8 @@ int cnmfe_patch_create(cnmfe_ctx *ctx, int patch_id, const int32_t pr[4], const 
     P->d = (int64_t)P->nr * P->nc; P->d_b = (int64_t)P->nr_b * P->nc_b;
     int rc = P->Y.ensure((size_t)P->d_b * T * sizeof(float));
     if (rc) { delete P; return rc; }
+    if (hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * T * sizeof(float), ctx->stream) != hipSuccess) { delete P; return fail(CNMFE_EHIP, "hipMemsetAsync of the upload staging failed"); }
+    P->frame_seen.assign((size_t)T, 0);
     P->Tc = (T + 3) / 4;
     ctx->patches[patch_id] = P;
     return 0;
@@ -290,10 +310,14 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     size_t esz = dtype == CNMFE_F32 ? 4 : dtype == CNMFE_F64 ? 8 : dtype == CNMFE_U16 ? 2 : dtype == CNMFE_U8 ? 1 : dtype == CNMFE_F16 ? 2 : 0;
     if (!esz) return fail(CNMFE_EINVAL, "unknown dtype %d", dtype);
     if (memspace != CNMFE_HOST && memspace != CNMFE_DEVICE) return fail(CNMFE_EINVAL, "unknown memspace %d", memspace);
-    if (!P->Y.p) {                                   // a re-upload after the block was finalised: start over
+    if (!P->Y.p) {                                   // a re-upload after the block was finalised: start over with a zeroed staging copy
         RET(P->Y.ensure((size_t)P->d_b * P->T * sizeof(float)));
+        CK(hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * P->T * sizeof(float), ctx->stream));
         P->frames_uploaded = 0;
+        P->frame_seen.assign((size_t)P->T, 0);
     }
+    for (int64_t t = t0; t < t0 + nt; ++t)           // every frame arrives exactly once: a repeated or overlapping chunk is a caller error, not a silent overwrite
+        if (P->frame_seen[(size_t)t]) return fail(CNMFE_EINVAL, "frame %lld of patch %d was already uploaded (chunks must not overlap; re-create the patch to replace its video)", (long long)t, patch_id);
     float *dst = P->Y.as<float>() + t0 * P->d_b;
     int64_t n = nt * P->d_b;
     if (dtype == CNMFE_F32) {
@@ -320,6 +344,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
         }
     }
     CK(hipStreamSynchronize(ctx->stream));
+    std::fill(P->frame_seen.begin() + t0, P->frame_seen.begin() + t0 + nt, (uint8_t)1);
     P->frames_uploaded += nt;
     P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false;
     return 0;
@@ -342,14 +367,20 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
     if (radius < 1 || radius > 64) return fail(CNMFE_EINVAL, "ring radius %d out of range", radius);
     CK(hipSetDevice(ctx->device));
-    ring_offsets(radius, num_neighbors, P->dr, P->dc);
-    P->p = (int32_t)P->dr.size(); P->radius = radius;
-    if (P->p > PMAX_RING) return fail(CNMFE_EUNSUPPORTED, "ring with %d neighbours exceeds the supported %d", P->p, PMAX_RING);
+    // validate on locals first: a rejected call leaves the patch's ring (offsets, p, W) exactly as it was
+    std::vector<int32_t> ndr, ndc;
+    ring_offsets(radius, num_neighbors, ndr, ndc);
+    const int32_t np_ = (int32_t)ndr.size();
+    if (np_ < 1) return fail(CNMFE_EINVAL, "ring of radius %d has no neighbours", radius);
+    if (np_ > PMAX_RING) return fail(CNMFE_EUNSUPPORTED, "ring with %d neighbours exceeds the supported %d", np_, PMAX_RING);
+    if (radius > 24) return fail(CNMFE_EUNSUPPORTED, "ring radius %d: the block-pair covariance table of the ring regression covers radii <= 24", radius);
     // every in-FOV ring neighbour of a patch pixel must be inside the block
     int h = radius;
     if ((P->prect[0] - P->brect[0] < std::min(h, P->prect[0] - 1)) || (P->brect[1] - P->prect[1] < std::min(h, P->d1 - P->prect[1])) ||
         (P->prect[2] - P->brect[2] < std::min(h, P->prect[2] - 1)) || (P->brect[3] - P->prect[3] < std::min(h, P->d2 - P->prect[3])))
         return fail(CNMFE_EINVAL, "block halo is narrower than the ring radius %d", radius);
+    P->ring_ready = false;                                  // from here on a failure leaves "no ring", never a mismatched one
+    P->dr.swap(ndr); P->dc.swap(ndc); P->p = np_; P->radius = radius;
     RET(to_dev(ctx, P->ring_dr, P->dr.data(), P->dr.size()));
     RET(to_dev(ctx, P->ring_dc, P->dc.data(), P->dc.size()));
     RET(P->W.ensure((size_t)P->p * P->d * sizeof(float)));

@@ -135,255 +135,14 @@ __global__ void __launch_bounds__(256) k_rowsum(const float *__restrict__ bf, in
 }
 
 // ---- B2a: block-sparse SYRK on the matrix pipe ------------------------------------------------------
-// One workgroup = one 128x128 quadrant of one 256x256 block-pair covariance, 4 waves x 16 MFMA sub-tiles
-// (16x16x4: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]).  K (=frames) advances 16 per LDS stage, fp32 tiles
-// [16][128] with the row stride padded to 144 floats so the four k-rows of a fragment hit different
-// bank halves; the next stage's global loads are register-prefetched under the MFMAs.
-constexpr int GK = 16, GLD = 144;
+// One workgroup = one 128x128 quadrant of one 256x256 block-pair covariance (16x16x4 MFMA: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]);
+// K (= frames) advances GK = 16 per LDS stage.
+constexpr int GK = 16;
 
-// ---- B2a v2: pruned block-sparse SYRK, fp64 pipe or fp32 pipe with fp64 shadow accumulation ----------
-// Work items are 128x128 quadrants of block pairs that contain at least one needed 16x16 sub-tile
-// (needmask[rel][patch_i] bit patch_j; a sub-tile is needed iff some pixel pair in it can be two ring
-// neighbours of one centre, or a centre and its ring neighbour).  F32: v_mfma_f32_16x16x4_f32 runs at
-// twice the fp64 rate; every 32 frames the fp32 accumulators are added into fp64 shadows, so the
-// rounding of a partial sum never sees more than 32 terms.
-template <bool F32>
-__global__ void __launch_bounds__(256, 2) k_gram2(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
-                                                  const int *__restrict__ work, int nwork, const unsigned short *__restrict__ needmask,
-                                                  int flush_every, double *__restrict__ cov) {
-    __shared__ __attribute__((aligned(16))) float sA[2][GK * GLD];
-    __shared__ __attribute__((aligned(16))) float sB[2][GK * GLD];
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
-    if (bid >= nwork) return;
-    const int wk = work[bid];
-    const int pair = wk >> 2, quad = wk & 3;
-    const int ih = quad & 1, jh = quad >> 1;
-    const int4 pr = pairs[pair];
-    const float *gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 128;
-    const float *gB = bf + ((int64_t)pr.y * Tpad) * BLKPX + jh * 128;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // The quadrant is an 8x8 grid of 16x16 sub-tiles.  Wave w owns 16 of them, slot s -> (i = s>>1,
-    // j = ((w+i)&3) + 4*(s&1)): a diagonal interleave, so the banded set of NEEDED sub-tiles is split
-    // evenly over the four waves (a 2x2 wave grid would leave corner waves idle behind the barrier).
-    unsigned need = 0;
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx) {
-        const int i = sidx >> 1, j = ((wave + i) & 3) + 4 * (sidx & 1);
-        need |= ((needmask[pr.z * 16 + ih * 8 + i] >> (jh * 8 + j)) & 1u) << sidx;
-    }
-    need = __builtin_amdgcn_readfirstlane(need);
-    const int lr = tid >> 5, lc = (tid & 31) * 4;
-    float4 ra0, ra1, rb0, rb1;
-    auto gload = [&](int64_t t0) {
-        ra0 = *reinterpret_cast<const float4 *>(gA + (t0 + lr) * BLKPX + lc);
-        ra1 = *reinterpret_cast<const float4 *>(gA + (t0 + lr + 8) * BLKPX + lc);
-        rb0 = *reinterpret_cast<const float4 *>(gB + (t0 + lr) * BLKPX + lc);
-        rb1 = *reinterpret_cast<const float4 *>(gB + (t0 + lr + 8) * BLKPX + lc);
-    };
-    auto sstore = [&](int buf) {
-        *reinterpret_cast<float4 *>(&sA[buf][lr * GLD + lc]) = ra0;
-        *reinterpret_cast<float4 *>(&sA[buf][(lr + 8) * GLD + lc]) = ra1;
-        *reinterpret_cast<float4 *>(&sB[buf][lr * GLD + lc]) = rb0;
-        *reinterpret_cast<float4 *>(&sB[buf][(lr + 8) * GLD + lc]) = rb1;
-    };
-    double4_t acc[16];
-    float4_t facc[16];
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx) { acc[sidx] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sidx] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
-
-    const int nst = (int)(Tpad / GK);
-    gload(0); sstore(0);
-    __syncthreads();
-    const int fl = lane & 15, fk = lane >> 4;
-    int since = 0;
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nst) gload((int64_t)(st + 1) * GK);
-        if (need) {
-#pragma unroll
-            for (int kk = 0; kk < GK; kk += 4) {
-                const float *rowA = &sA[buf][(kk + fk) * GLD + fl];
-                const float *rowB = &sB[buf][(kk + fk) * GLD + fl];
-                // all 8 + 8 fragments first (unconditional, one latency), then the needed MFMAs back to back;
-                // slot (i, h) reads b fragment q = (i&3) + 4h, which is sub-tile column j = ((wave + i) & 3) + 4h
-                float a[8], bq[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = rowA[i * 16];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bq[q] = rowB[(((wave + (q & 3)) & 3) + 4 * (q >> 2)) * 16];
-#pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx)
-                    if ((need >> sidx) & 1u) {
-                        const float b = bq[((sidx >> 1) & 3) + 4 * (sidx & 1)];
-                        if (F32) facc[sidx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sidx >> 1], b, facc[sidx], 0, 0, 0);
-                        else acc[sidx] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[sidx >> 1], (double)b, acc[sidx], 0, 0, 0);
-                    }
-            }
-            if (F32 && (++since == flush_every || st + 1 == nst)) {   // fold the fp32 partial sums into the fp64 shadows
-                since = 0;
-#pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx)
-                    if ((need >> sidx) & 1u) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[sidx][r] += (double)facc[sidx][r];
-                        facc[sidx] = (float4_t){0.f, 0.f, 0.f, 0.f};
-                    }
-            }
-        }
-        if (st + 1 < nst) sstore(buf ^ 1);
-        __syncthreads();
-    }
-    double *out = cov + (int64_t)pair * BLKPX * BLKPX;
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx)
-        if ((need >> sidx) & 1u) {
-            const int i = sidx >> 1, j = ((wave + i) & 3) + 4 * (sidx & 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // D layouts: fp32 16x16 -> row = (lane>>4)*4 + r ; fp64 16x16 -> row = (lane>>4) + 4*r
-                const int rr = F32 ? ((lane >> 4) * 4 + r) : ((lane >> 4) + 4 * r);
-                out[(int64_t)(ih * 128 + i * 16 + rr) * BLKPX + jh * 128 + j * 16 + fl] = acc[sidx][r];
-            }
-        }
-}
-
-// ---- B2a v3: the same work items, operands staged by LDS-DMA ------------------------------------------
-// k_gram2 is bound by the latency x concurrency of its panel stream (one 16 KB stage per workgroup in flight,
-// ~8 MB chip-wide, 2.9 TB/s at ~2.8 us): its 247 VGPRs leave no room for deeper register staging.  Here the
-// stages go global -> LDS directly (global_load_lds_dwordx4, no VGPRs), GR_NBUF-1 stages ahead.  The DMA writes
-// LDS lane-linearly, so the row padding of v2 is replaced by a swizzle applied on the GLOBAL side: LDS row f
-// (frame) holds pixel (c ^ 16*(f&1)) at column c, which sends the four k-rows of an MFMA fragment to
-// alternating bank halves exactly like the 144-float stride did, and keeps every 512-B frame row coalesced.
-// The asm loads are invisible to hipcc's waitcnt bookkeeping: completion is counted by hand (vmcnt), then a raw
-// s_barrier publishes the stage; loads past the last stage are clamped, not skipped, so the count is uniform.
-constexpr int GR_NBUF = 4, GR_STAGE_F = 2 * GK * 128;          // floats per stage: A half + B half, [16][128] each
-
-
-template <bool F32>
-__global__ void __launch_bounds__(256, 2) k_gram3(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
-                                                  const int *__restrict__ work, int nwork, const unsigned short *__restrict__ needmask,
-                                                  int flush_every, double *__restrict__ cov) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];       // the ONLY LDS object (a second one de-pipelines the DMA)
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
-    if (bid >= nwork) return;
-    const int wk = work[bid];
-    const int pair = wk >> 2, quad = wk & 3;
-    const int ih = quad & 1, jh = quad >> 1;
-    const int4 pr = pairs[pair];
-    const float *gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 128;
-    const float *gB = bf + ((int64_t)pr.y * Tpad) * BLKPX + jh * 128;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned need = 0;
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx) {
-        const int i = sidx >> 1, j = ((wave + i) & 3) + 4 * (sidx & 1);
-        need |= ((needmask[pr.z * 16 + ih * 8 + i] >> (jh * 8 + j)) & 1u) << sidx;
-    }
-    need = __builtin_amdgcn_readfirstlane(need);
-    const bool probe = (flush_every >> 16) != 0; flush_every &= 0xffff;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
-    // DMA geometry: one wave-instruction = 64 lanes x 16 B = two frame rows of a 128-pixel half.  Wave w moves
-    // frame pairs w and w+4 of both halves.  Lane: row fr = lane>>5, 4-pixel group g = lane&31, swizzled source.
-    const int fr = lane >> 5, gq = lane & 31;
-    const unsigned vo0 = (unsigned)(((2 * wave + fr) * BLKPX + ((gq ^ (4 * fr)) * 4)) * 4);
-    const unsigned vo1 = vo0 + 8u * BLKPX * 4u;
-    const unsigned dA0 = lds0 + (unsigned)wave * 1024u, dA1 = dA0 + 4096u, dB0 = dA0 + 8192u, dB1 = dA0 + 12288u;
-    const int nst = (int)(Tpad / GK);
-    auto issue = [&](int st) {
-        int sc = st < nst ? st : nst - 1;                               // clamp: keeps the vmcnt arithmetic uniform
-        if (probe) sc = 0;                                              // A/B probe: every stage re-reads stage 0 (no fabric traffic)
-        const float *sa = gA + (int64_t)sc * GK * BLKPX, *sb = gB + (int64_t)sc * GK * BLKPX;
-        const unsigned bo = (unsigned)(st & (GR_NBUF - 1)) * (GR_STAGE_F * 4u);
-        glds16(sa, vo0, dA0 + bo); glds16(sa, vo1, dA1 + bo);
-        glds16(sb, vo0, dB0 + bo); glds16(sb, vo1, dB1 + bo);
-    };
-    double4_t acc[16];
-    float4_t facc[16];
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx) { acc[sidx] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sidx] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
-    const int fl = lane & 15, fk = lane >> 4, par = fk & 1;
-    // fragment read bases (floats): row fk, column (tile ^ par)*16 + fl  ->  even/odd tile pointers
-    const int rbase = fk * 128 + fl;
-    const int aE = rbase + (par ? 16 : 0), aO = rbase + (par ? 0 : 16);
-    int bo8[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int j = ((wave + (q & 3)) & 3) + 4 * (q >> 2);
-        bo8[q] = GK * 128 + rbase + ((j ^ par) * 16);
-    }
-#pragma unroll
-    for (int s0 = 0; s0 < GR_NBUF - 1; ++s0) issue(s0);
-    int since = 0;
-    for (int st = 0; st < nst; ++st) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * (GR_NBUF - 2)) : "memory");    // this wave's part of stage st has landed
-        __builtin_amdgcn_s_barrier();                                                // ... and everybody else's; buffer st-1 is free
-        asm volatile("" ::: "memory");
-        issue(st + GR_NBUF - 1);
-        if (need) {
-            const float *sb_ = smem + (st & (GR_NBUF - 1)) * GR_STAGE_F;
-            // fragments of k-step kk+4 are issued before the MFMAs of k-step kk; the empty asm makes the current
-            // 16 fragments "used" at this point, so hipcc cannot sink each ds_read next to its (conditional) MFMA
-            // and wait out one LDS latency per sub-tile (it did: 16 x lgkmcnt(0) in the first k-step)
-            float fr_[2][16];
-            auto ldfrag = [&](float *f, int kk) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] = sb_[kk * 128 + ((i & 1) ? aO : aE) + (i & ~1) * 16];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) f[8 + q] = sb_[kk * 128 + bo8[q]];
-            };
-            ldfrag(fr_[0], 0);
-#pragma unroll
-            for (int kk = 0; kk < GK; kk += 4) {
-                float *f = fr_[(kk >> 2) & 1];
-                if (kk + 4 < GK) ldfrag(fr_[((kk >> 2) + 1) & 1], kk + 4);
-                asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
-                                  "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
-#pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx)
-                    if ((need >> sidx) & 1u) {
-                        const float b = f[8 + ((sidx >> 1) & 3) + 4 * (sidx & 1)];
-                        if (F32) facc[sidx] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[sidx >> 1], b, facc[sidx], 0, 0, 0);
-                        else acc[sidx] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)f[sidx >> 1], (double)b, acc[sidx], 0, 0, 0);
-                    }
-            }
-            if (F32 && (++since == flush_every || st + 1 == nst)) {
-                since = 0;
-#pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx)
-                    if ((need >> sidx) & 1u) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[sidx][r] += (double)facc[sidx][r];
-                        facc[sidx] = (float4_t){0.f, 0.f, 0.f, 0.f};
-                    }
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the clamped tail loads before the LDS is released
-    double *out = cov + (int64_t)pair * BLKPX * BLKPX;
-#pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx)
-        if ((need >> sidx) & 1u) {
-            const int i = sidx >> 1, j = ((wave + i) & 3) + 4 * (sidx & 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = F32 ? ((lane >> 4) * 4 + r) : ((lane >> 4) + 4 * r);
-                out[(int64_t)(ih * 128 + i * 16 + rr) * BLKPX + jh * 128 + j * 16 + fl] = acc[sidx][r];
-            }
-        }
-}
-
-// ---- B2a v4: dense tile slots --------------------------------------------------------------------------
-// v2/v3 run at 77 TF/s although neither the fabric (probe: every stage re-reading stage 0 changes nothing) nor
-// the LDS latency bounds them: a wave owns a FIXED 16-slot pattern of the quadrant and tests `need` per slot, and
-// hipcc turns that into two scalar branches per MFMA -- the issue stream, not the matrix pipe, is saturated, and
-// the four waves of a workgroup are unevenly loaded (84 %).  Here the host lists the needed 16x16 sub-tiles of
+// ---- dense tile slots ----------------------------------------------------------------------------------
+// A first version gave every wave a FIXED 16-slot pattern of the quadrant with a `need` test per slot: hipcc turned that into two
+// scalar branches per MFMA -- the issue stream, not the matrix pipe, was saturated (77 TF/s), and the four waves of a workgroup were
+// unevenly loaded (84 %).  Here the host lists the needed 16x16 sub-tiles of
 // every (displacement class, quadrant); tile t of an item goes to wave t%4, slot t/4, so slots are dense, the
 // waves are balanced to within one tile, and the stage body is straight-line code instantiated per slot count.
 // Bf is stored [block][frame/4][256][4] (like the resident video): a lane's A (or B) fragment for ALL FOUR
@@ -943,112 +702,13 @@ __global__ void __launch_bounds__(256) k_rowsum_correct(const double *__restrict
 
 // ---- helpers on the covariance table ----------------------------------------------------------------
 struct CovTab {
-    const double *cov; const int *pair_of;   // pair_of[blk*NREL + rel] or -1
+    const double *cov; const int *pair_of;   // pair_of[blk*nrel + rel] or -1
     int nbr, nbc;
+    int maxd, nrel;                          // largest block displacement between two ring pixels of one centre (2: radius <= 16, 3: <= 24); nrel_of(maxd)
 };
-// canonical displacement index: dC in {0,1,2}; dC==0 -> dR in {0,1,2} (0..2); dC==1 -> dR in -2..2 (3..7); dC==2 -> (8..12)
-__device__ __forceinline__ int rel_index(int dR, int dC) { return dC == 0 ? dR : (dC == 1 ? 5 + dR : 10 + dR); }
-// Cov(a,b) for block pixels a=(ra,ca), b=(rb,cb) (block coordinates)
-__device__ __forceinline__ double cov_lookup(const CovTab &t, int ra, int ca, int rb, int cb) {
-    int ia = ra >> 4, ja = ca >> 4, ib = rb >> 4, jb = cb >> 4;
-    int dR = ib - ia, dC = jb - ja;
-    if (dC < 0 || (dC == 0 && dR < 0)) {          // swap so that the displacement is canonical
-        int t0;
-        t0 = ra; ra = rb; rb = t0; t0 = ca; ca = cb; cb = t0;
-        t0 = ia; ia = ib; ib = t0; t0 = ja; ja = jb; jb = t0;
-        dR = -dR; dC = -dC;
-    }
-    const int pidx = t.pair_of[(ja * t.nbr + ia) * NREL + rel_index(dR, dC)];
-    int la = lp_of(ra & 15, ca & 15), lb = lp_of(rb & 15, cb & 15);
-    if (dR == 0 && dC == 0 && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }   // self pair: upper patch triangle only
-    return t.cov[((int64_t)pidx * BLKPX + la) * BLKPX + lb];
-}
-
-// ---- B2b: per-pixel assemble + ridge + Cholesky solve (one 64-lane workgroup per pixel) ----------
-// Packed lower triangle in LDS (fp64).  Neighbours outside the FOV keep a unit diagonal / zero RHS so
-// the system size is always n = p+1; they are excluded from the trace and get weight 0.
-__global__ void __launch_bounds__(64) k_ring_solve(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
-                                                   const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
-                                                   float *__restrict__ W) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int p = g.p, n = p + 1;
-    double *L = sm;                               // n(n+1)/2 packed, row i at i(i+1)/2
-    double *rhs = sm + (n * (n + 1)) / 2;         // n
-    int *nb = reinterpret_cast<int *>(rhs + n);   // n: packed (rb | cb<<16) or -1 if the neighbour is outside the FOV
-    const int64_t m = blockIdx.x;
-    if (active && !active[m]) return;
-    const int lane = threadIdx.x;
-    const int prow = (int)(m % g.nr), pcol = (int)(m / g.nr);
-    const int rbm = prow + g.roff, cbm = pcol + g.coff;          // centre in block coords
-    for (int i = lane; i < p; i += 64) {
-        const int rb = rbm + dr[i], cb = cbm + dc[i];
-        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;        // absolute 1-based
-        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
-    }
-    __syncthreads();
-    // assemble: rows 0..p-1 ring neighbours, row p = ones
-    for (int i = 0; i < n; ++i) {
-        const int ni = i < p ? nb[i] : 0;
-        for (int j = lane; j <= i; j += 64) {
-            double v;
-            if (i < p) {
-                const int nj = nb[j];
-                if (ni < 0 || nj < 0) v = (i == j) ? 1.0 : 0.0;
-                else v = cov_lookup(tab, ni & 0xffff, ni >> 16, nj & 0xffff, nj >> 16);
-            } else if (j < p) {
-                const int nj = nb[j];
-                v = nj < 0 ? 0.0 : rowsum[(((nj >> 16) >> 4) * g.nbr + ((nj & 0xffff) >> 4)) * BLKPX + lp_of((nj & 0xffff) & 15, (nj >> 16) & 15)];
-            } else v = (double)g.Tp;
-            L[(i * (i + 1)) / 2 + j] = v;
-        }
-        if (lane == 0) {
-            double y;
-            if (i < p) y = ni < 0 ? 0.0 : cov_lookup(tab, ni & 0xffff, ni >> 16, rbm, cbm);
-            else y = rowsum[((cbm >> 4) * g.nbr + (rbm >> 4)) * BLKPX + lp_of(rbm & 15, cbm & 15)];
-            rhs[i] = y;
-        }
-    }
-    __syncthreads();
-    // ridge: lambda = 1e-5 * trace over real rows (fit_ring_model.m:106)
-    double tr = 0;
-    for (int i = lane; i < n; i += 64) if (i == p || nb[i] >= 0) tr += L[(i * (i + 1)) / 2 + i];
-    for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-    const double lam = tr * 1e-5;
-    for (int i = lane; i < n; i += 64) if (i == p || nb[i] >= 0) L[(i * (i + 1)) / 2 + i] += lam;
-    __syncthreads();
-    // right-looking Cholesky, lane-per-row
-    for (int j = 0; j < n; ++j) {
-        const double djj = sqrt(L[(j * (j + 1)) / 2 + j]);
-        __syncthreads();
-        if (lane == 0) L[(j * (j + 1)) / 2 + j] = djj;
-        const double inv = 1.0 / djj;
-        for (int i = j + 1 + lane; i < n; i += 64) L[(i * (i + 1)) / 2 + j] *= inv;
-        __syncthreads();
-        for (int i = j + 1 + lane; i < n; i += 64) {
-            const double lij = L[(i * (i + 1)) / 2 + j];
-            double *row = L + (i * (i + 1)) / 2;
-            for (int k = j + 1; k <= i; ++k) row[k] -= lij * L[(k * (k + 1)) / 2 + j];
-        }
-        __syncthreads();
-    }
-    // forward substitution L z = rhs (column sweep), then back substitution L^T w = z
-    for (int j = 0; j < n; ++j) {
-        if (lane == 0) rhs[j] /= L[(j * (j + 1)) / 2 + j];
-        __syncthreads();
-        const double zj = rhs[j];
-        for (int i = j + 1 + lane; i < n; i += 64) rhs[i] -= L[(i * (i + 1)) / 2 + j] * zj;
-        __syncthreads();
-    }
-    for (int j = n - 1; j >= 0; --j) {
-        if (lane == 0) rhs[j] /= L[(j * (j + 1)) / 2 + j];
-        __syncthreads();
-        const double wj = rhs[j];
-        for (int i = lane; i < j; i += 64) rhs[i] -= L[(j * (j + 1)) / 2 + i] * wj;
-        __syncthreads();
-    }
-    for (int i = lane; i < p; i += 64) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)rhs[i] : 0.f;   // intercept rhs[p] is discarded (:107)
-}
-
+// canonical displacement index: dC in 0..maxd; dC == 0 -> dR in 0..maxd (0..maxd); dC >= 1 -> dR in -maxd..maxd.  maxd = 2: 13 classes (0..2, 3..7, 8..12)
+__host__ __device__ __forceinline__ int rel_index(int dR, int dC, int maxd) { return dC == 0 ? dR : (maxd + 1) + (dC - 1) * (2 * maxd + 1) + dR + maxd; }
+__host__ __device__ __forceinline__ int nrel_of(int maxd) { return (maxd + 1) + maxd * (2 * maxd + 1); }
 // ---- B2b v2: panel-blocked Cholesky, 256 threads per pixel ------------------------------------------
 // The system is augmented with the right-hand side as row n of the packed lower triangle, so the
 // factorisation leaves z = L^-1 g in that row (forward substitution for free).  Per panel of PW
@@ -1074,7 +734,7 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 
 __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
                                                      const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
-                                                     float *__restrict__ W, int probe) {
+                                                     float *__restrict__ W, int *__restrict__ errflag, int probe) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = g.p, n = p + 1, na = n + 1;
     double *L = sm;                                   // rows 0..n packed; row n = [g ; unused]
@@ -1106,8 +766,10 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
         if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
             int dR = ib - ia, dC = jb - ja, sw = 0;
             if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
-            const int pidx = tab.pair_of[(ja * tab.nbr + ia) * NREL + rel_index(dR, dC)];
-            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
+            if (dC <= tab.maxd && dR <= tab.maxd && dR >= -tab.maxd) {
+                const int pidx = tab.pair_of[(ja * tab.nbr + ia) * tab.nrel + rel_index(dR, dC, tab.maxd)];
+                code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
+            }
         }
         pt[q] = code;
     }
@@ -1143,7 +805,8 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
                     else if (j == p) src[u] = &rowsum[((cbm >> 4) * g.nbr + (rbm >> 4)) * BLKPX + lp_of(rbm & 15, cbm & 15)];
                 }
                 if (na_ >= 0) {
-                    const int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
+                    int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
+                    if (code < 0) { atomicOr(errflag, 1); code = 0; }      // a needed block pair is not in the table: reported by the host, never indexed
                     int la = na_ & 255, lb = nb_ & 255;
                     if (code & 2) { const int t0 = la; la = lb; lb = t0; }
                     if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }   // self pair: upper patch triangle only
@@ -1273,492 +936,9 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
     }
 }
 
-// ---- B2b v3 (experimental, solve_mode=3; NOT the default) -----------------------------------------------
-// Correct (same parity tests as v2) but slower: 34 ms vs 23 ms at 512x512, p=96.  The matrix of one pixel is 72 KB
-// whether it sits in LDS (v2: 3 workgroups per CU) or in registers (here: 253 VGPR+AGPR, 2 workgroups per CU), so the
-// register-resident form buys no occupancy, and its 16x16 diagonal factor + explicit inverse (wave 0, ~1500
-// instructions per block) is a longer serial chain than v2's 8-column register panel.  Kept for the MFMA trailing
-// update (the part that does work), which is the piece to graft onto v2's LDS layout.
-// ---- B2b v3: the normal equations of one pixel as MFMA accumulator tiles ----------------------------------
-// v2 keeps the packed triangle in LDS (41 KB: 3 workgroups per CU) and every phase is a chain of LDS round trips
-// with multi-way bank conflicts on the triangle (probes: assembly 3, panel 6, trailing update 8.6, back substitution
-// 4 ms).  Here the matrix lives in REGISTERS as 16x16 fp64 tiles in v_mfma_f64_16x16x4 accumulator layout, split
-// over the four waves by row block; LDS only carries the current block column.
-//   unknowns 0..p (p neighbours + intercept) padded with identity to 112 = 7 row blocks; the right-hand side is an
-//   8th row block (row 0 real), so it is eliminated by the same TRSM/update code and ends up as z = L^-1 g.
-//   step kb: owners publish block column kb -> wave 0 factors the 16x16 diagonal tile and inverts it (registers,
-//   lane = row, v_readlane broadcasts) -> every owner: L(I,kb) = A(I,kb) * Linv^T on the MFMA pipe -> trailing
-//   update A(I,J) -= L(I,kb) L(J,kb)^T, 4 MFMAs per tile.  Back substitution by row blocks with the stored inverses.
-constexpr int S3_NU = 7, S3_NB = 8, S3_LD = 17, S3_TILE = 16 * S3_LD, S3_NSLOT = 11;
-
-__device__ __forceinline__ double4_t s3_mfma(double a, double b, double4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-
-__global__ void __launch_bounds__(256) k_ring_solve3(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
-                                                     const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
-                                                     float *__restrict__ W) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int p = g.p;
-    double *panel = sm;                                   // S3_NB tiles [16][S3_LD]: block column kb (A, then L)
-    double *linv = panel + S3_NB * S3_TILE;               // S3_NU tiles: inverse of every diagonal factor
-    double *zv = linv + S3_NU * S3_TILE;                  // 128: z = L^-1 g
-    double *av = zv + 128;                                // 128: accumulated L^T w of the blocks below
-    double *wv = av + 128;                                // 128: solution
-    double *sc = wv + 128;                                // 8 scalars
-    int *nb = reinterpret_cast<int *>(sc + 8);            // p neighbour codes
-    int *node = nb + p;                                   // p+1 node codes
-    int *pt = node + p + 1;                               // nbw^4 block-pair codes
-    const int64_t m = blockIdx.x;
-    if (active && !active[m]) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lc = lane & 15, lg = lane >> 4;             // accumulator layout: element r of a tile is (row lg + 4r, col lc)
-    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
-    for (int i = tid; i < p; i += 256) {
-        const int rb = rbm + dr[i], cb = cbm + dc[i];
-        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
-    }
-    if (tid < 8) sc[tid] = 0.0;
-    for (int i = tid; i < 128; i += 256) { av[i] = 0.0; zv[i] = 0.0; wv[i] = 0.0; }
-    __syncthreads();
-    const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;
-    const int nbw = g.nbw, nb2 = nbw * nbw;
-    for (int q = tid; q < nb2 * nb2; q += 256) {
-        const int a = q / nb2, b = q % nb2;
-        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
-        int code = -1;
-        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
-            int dR = ib - ia, dC = jb - ja, sw = 0;
-            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
-            const int pidx = tab.pair_of[(ja * tab.nbr + ia) * NREL + rel_index(dR, dC)];
-            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
-        }
-        pt[q] = code;
-    }
-    for (int i = tid; i <= p; i += 256) {
-        const int c = i < p ? nb[i] : (rbm | (cbm << 16));
-        int nc = -1;
-        if (c >= 0) { const int rb = c & 0xffff, cb = c >> 16; nc = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15); }
-        node[i] = nc;
-    }
-    __syncthreads();
-    // covariance of two nodes (block-local codes), through the block-pair table
-    auto cov_ptr = [&](int na_, int nb_) -> const double * {
-        const int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
-        int la = na_ & 255, lb = nb_ & 255;
-        if (code & 2) { const int t0 = la; la = lb; lb = t0; }
-        if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }
-        return tab.cov + ((int64_t)(code >> 2) * BLKPX + la) * BLKPX + lb;
-    };
-    auto rs_ptr = [&](int c) -> const double * {           // rowsum of a block pixel code (rb | cb << 16)
-        const int rb = c & 0xffff, cb = c >> 16;
-        return &rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + lp_of(rb & 15, cb & 15)];
-    };
-    // element (i, j) of the augmented system: i in 0..111 unknown rows (i > p: identity padding), i >= 112: rhs block
-    auto elem = [&](int i, int j, double &val) -> const double * {
-        val = 0.0;
-        if (i >= 16 * S3_NU) {                             // right-hand side X*y' (fit_ring_model.m:104), row 0 of block 7
-            if (i != 16 * S3_NU) return nullptr;
-            if (j < p) return (node[j] >= 0) ? cov_ptr(node[j], node[p]) : nullptr;
-            if (j == p) return rs_ptr(rbm | (cbm << 16));
-            return nullptr;
-        }
-        if (i < j) { const int t0 = i; i = j; j = t0; }
-        if (i > p) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
-        if (i == p) {                                      // the row of ones (:101)
-            if (j == p) { val = (double)g.Tp; return nullptr; }
-            return nb[j] >= 0 ? rs_ptr(nb[j]) : nullptr;
-        }
-        if (node[i] < 0 || node[j] < 0) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
-        return cov_ptr(node[i], node[j]);
-    };
-    // tile slots of this wave: row blocks Ia = 7 - wave (slots 0..6, J = slot) and Ib = wave (slots 7..10, J = slot - 7)
-    const int Ia = 7 - wave, Ib = wave;
-    auto slotI = [&](int s_) { return s_ < 7 ? Ia : Ib; };
-    auto slotJ = [&](int s_) { return s_ < 7 ? s_ : s_ - 7; };
-    auto slotOn = [&](int s_) { return s_ < 7 ? (s_ <= (Ia < 6 ? Ia : 6)) : (s_ - 7 <= Ib); };
-    double4_t acc[S3_NSLOT];
-#pragma unroll
-    for (int s_ = 0; s_ < S3_NSLOT; ++s_) {
-        acc[s_] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        if (slotOn(s_)) {
-            const int I = slotI(s_), J = slotJ(s_);
-            const double *ptr[4]; double v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ptr[r] = elem(16 * I + lg + 4 * r, 16 * J + lc, v[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (ptr[r]) v[r] = *ptr[r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s_][r] = v[r];
-        }
-    }
-    // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
-    {
-        double tr = 0.0;
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * slotI(s_) + lg + 4 * r;
-                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) tr += acc[s_][r];
-                }
-            }
-        for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-        if (lane == 0) atomicAdd(&sc[0], tr);
-        __syncthreads();
-        const double lam = sc[0] * 1e-5;
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * slotI(s_) + lg + 4 * r;
-                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) acc[s_][r] += lam;
-                }
-            }
-    }
-    // fragment of an LDS tile X for MFMA k-step mq: X[lc][4*mq + lg]  (serves as A operand of X*Y^T and as B operand of Y*X^T)
-    auto frag = [&](const double *X, int mq) { return X[lc * S3_LD + 4 * mq + lg]; };
-    // ---- blocked Cholesky over the unknown blocks ----
-    for (int kb = 0; kb < S3_NU; ++kb) {
-        // a. publish block column kb
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotJ(s_) == kb) {
-                double *X = panel + slotI(s_) * S3_TILE;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * S3_LD + lc] = acc[s_][r];
-            }
-        __syncthreads();
-        // c. wave 0: Cholesky of the diagonal tile and its inverse (lane = row lc; the four lane groups work in lockstep)
-        if (wave == 0) {
-            const double *X = panel + kb * S3_TILE;
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = X[lc * S3_LD + c];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const double piv = readlane_f64(a[c], c);
-                const double inv = rsqrt_f64(piv);
-                a[c] = lc == c ? piv * inv : a[c] * inv;                  // column c of L (rows above the diagonal are junk, never used)
-#pragma unroll
-                for (int c2 = c + 1; c2 < 16; ++c2) {
-                    const double l2 = readlane_f64(a[c], c2);              // L[c2][c]
-                    a[c2] = fma(-a[c], l2, a[c2]);
-                }
-            }
-            // inverse: lane lc computes COLUMN lc of Linv by forward substitution: x_r = (d_{r,lc} - sum_{q<r} L[r][q] x_q) / L[r][r]
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double s_ = (r == lc) ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < r; ++q) s_ = fma(-readlane_f64(a[q], r), x[q], s_);      // L[r][q] lives in lane r, register q
-                const double dinv = 1.0 / readlane_f64(a[r], r);
-                x[r] = (r < lc) ? 0.0 : s_ * dinv;
-            }
-            if (lg == 0) {
-                double *Li = linv + kb * S3_TILE;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Li[r * S3_LD + lc] = x[r];                     // Linv[r][lc]
-            }
-        }
-        __syncthreads();
-        // e. L(I,kb) = A(I,kb) * Linv^T for the blocks below the diagonal (and the right-hand side block)
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotJ(s_) == kb && slotI(s_) > kb) {
-                double *X = panel + slotI(s_) * S3_TILE;
-                const double *Li = linv + kb * S3_TILE;
-                double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq) t = s3_mfma(frag(X, mq), frag(Li, mq), t);
-                acc[s_] = t;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * S3_LD + lc] = t[r];
-            }
-        __syncthreads();
-        // g. trailing update A(I,J) -= L(I,kb) * L(J,kb)^T
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotJ(s_) > kb) {
-                const double *XI = panel + slotI(s_) * S3_TILE, *XJ = panel + slotJ(s_) * S3_TILE;
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq) acc[s_] = s3_mfma(-frag(XI, mq), frag(XJ, mq), acc[s_]);
-            }
-        __syncthreads();
-    }
-    // ---- z = row 0 of the right-hand side block ----
-    if (wave == 0 && lg == 0) {
-#pragma unroll
-        for (int s_ = 0; s_ < 7; ++s_) zv[16 * s_ + lc] = acc[s_][0];
-    }
-    __syncthreads();
-    // ---- back substitution L^T w = z by row blocks, bottom up ----
-    for (int kb = S3_NU - 1; kb >= 0; --kb) {
-        if (wave == 0) {                                   // w_kb = Linv_kk^T (z_kb - acc_kb): lane lc -> entry lc
-            const double *Li = linv + kb * S3_TILE;
-            double w_ = 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w_ = fma(Li[r * S3_LD + lc], zv[16 * kb + r] - av[16 * kb + r], w_);
-            if (lg == 0) wv[16 * kb + lc] = w_;
-        }
-        __syncthreads();
-        // acc_J += L(kb,J)^T w_kb for J < kb: the owner of row block kb holds those tiles
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotI(s_) == kb && slotJ(s_) < kb) {
-                double q = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) q = fma(acc[s_][r], wv[16 * kb + lg + 4 * r], q);
-                q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-                if (lg == 0) av[16 * slotJ(s_) + lc] += q;
-            }
-        __syncthreads();
-    }
-    for (int i = tid; i < p; i += 256) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)wv[i] : 0.f;   // intercept (index p) discarded (:107)
-}
-
-// ---- B2b v4 (experimental, solve_mode=4; NOT the default): v2's 8-column register panel on v3's register-resident
-// trailing matrix.  Correct, 41 ms vs v2's 23 ms: 208 VGPR+AGPR -> 2 workgroups per CU, three barriers per 8-column panel,
-// and the tile publish / read-back round trips make the per-pixel chain (160 k clk) longer than v2's (134 k clk at 3 per CU).
-// Probes: assembly straight into accumulator tiles 9 ms (v2: 3), panel loop 27 ms (panel factor 11), back substitution 6 ms.
-__global__ void __launch_bounds__(256) k_ring_solve4(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
-                                                     const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
-                                                     float *__restrict__ W, int probe) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int p = g.p;
-    double *panel = sm;                                   // S3_NB tiles [16][S3_LD]: block column kb (A, then L)
-    double *linv = panel + S3_NB * S3_TILE;               // S3_NU tiles: inverse of every diagonal factor
-    double *zv = linv + S3_NU * S3_TILE;                  // 128: z = L^-1 g
-    double *av = zv + 128;                                // 128: accumulated L^T w of the blocks below
-    double *wv = av + 128;                                // 128: solution
-    double *sc = wv + 128;                                // 8 scalars
-    double *dinv = sc + 8;                                // 128: 1 / L(j,j)
-    int *nb = reinterpret_cast<int *>(dinv + 128);        // p neighbour codes
-    int *node = nb + p;                                   // p+1 node codes
-    int *pt = node + p + 1;                               // nbw^4 block-pair codes
-    const int64_t m = blockIdx.x;
-    if (active && !active[m]) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lc = lane & 15, lg = lane >> 4;             // accumulator layout: element r of a tile is (row lg + 4r, col lc)
-    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
-    for (int i = tid; i < p; i += 256) {
-        const int rb = rbm + dr[i], cb = cbm + dc[i];
-        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
-    }
-    if (tid < 8) sc[tid] = 0.0;
-    for (int i = tid; i < 128; i += 256) { av[i] = 0.0; zv[i] = 0.0; wv[i] = 0.0; }
-    __syncthreads();
-    const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;
-    const int nbw = g.nbw, nb2 = nbw * nbw;
-    for (int q = tid; q < nb2 * nb2; q += 256) {
-        const int a = q / nb2, b = q % nb2;
-        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
-        int code = -1;
-        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
-            int dR = ib - ia, dC = jb - ja, sw = 0;
-            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
-            const int pidx = tab.pair_of[(ja * tab.nbr + ia) * NREL + rel_index(dR, dC)];
-            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
-        }
-        pt[q] = code;
-    }
-    for (int i = tid; i <= p; i += 256) {
-        const int c = i < p ? nb[i] : (rbm | (cbm << 16));
-        int nc = -1;
-        if (c >= 0) { const int rb = c & 0xffff, cb = c >> 16; nc = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15); }
-        node[i] = nc;
-    }
-    __syncthreads();
-    // covariance of two nodes (block-local codes), through the block-pair table
-    auto cov_ptr = [&](int na_, int nb_) -> const double * {
-        const int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
-        int la = na_ & 255, lb = nb_ & 255;
-        if (code & 2) { const int t0 = la; la = lb; lb = t0; }
-        if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }
-        return tab.cov + ((int64_t)(code >> 2) * BLKPX + la) * BLKPX + lb;
-    };
-    auto rs_ptr = [&](int c) -> const double * {           // rowsum of a block pixel code (rb | cb << 16)
-        const int rb = c & 0xffff, cb = c >> 16;
-        return &rowsum[((cb >> 4) * g.nbr + (rb >> 4)) * BLKPX + lp_of(rb & 15, cb & 15)];
-    };
-    // element (i, j) of the augmented system: i in 0..111 unknown rows (i > p: identity padding), i >= 112: rhs block
-    auto elem = [&](int i, int j, double &val) -> const double * {
-        val = 0.0;
-        if (i >= 16 * S3_NU) {                             // right-hand side X*y' (fit_ring_model.m:104), row 0 of block 7
-            if (i != 16 * S3_NU) return nullptr;
-            if (j < p) return (node[j] >= 0) ? cov_ptr(node[j], node[p]) : nullptr;
-            if (j == p) return rs_ptr(rbm | (cbm << 16));
-            return nullptr;
-        }
-        if (i < j) { const int t0 = i; i = j; j = t0; }
-        if (i > p) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
-        if (i == p) {                                      // the row of ones (:101)
-            if (j == p) { val = (double)g.Tp; return nullptr; }
-            return nb[j] >= 0 ? rs_ptr(nb[j]) : nullptr;
-        }
-        if (node[i] < 0 || node[j] < 0) { val = (i == j) ? 1.0 : 0.0; return nullptr; }
-        return cov_ptr(node[i], node[j]);
-    };
-    // tile slots of this wave: row blocks Ia = 7 - wave (slots 0..6, J = slot) and Ib = wave (slots 7..10, J = slot - 7)
-    const int Ia = 7 - wave, Ib = wave;
-    auto slotI = [&](int s_) { return s_ < 7 ? Ia : Ib; };
-    auto slotJ = [&](int s_) { return s_ < 7 ? s_ : s_ - 7; };
-    auto slotOn = [&](int s_) { return s_ < 7 ? (s_ <= (Ia < 6 ? Ia : 6)) : (s_ - 7 <= Ib); };
-    double4_t acc[S3_NSLOT];
-#pragma unroll
-    for (int s_ = 0; s_ < S3_NSLOT; ++s_) {
-        acc[s_] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        if (slotOn(s_)) {
-            const int I = slotI(s_), J = slotJ(s_);
-            const double *ptr[4]; double v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ptr[r] = elem(16 * I + lg + 4 * r, 16 * J + lc, v[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (ptr[r]) v[r] = *ptr[r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s_][r] = v[r];
-        }
-    }
-    // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
-    {
-        double tr = 0.0;
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * slotI(s_) + lg + 4 * r;
-                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) tr += acc[s_][r];
-                }
-            }
-        for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-        if (lane == 0) atomicAdd(&sc[0], tr);
-        __syncthreads();
-        const double lam = sc[0] * 1e-5;
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * slotI(s_) + lg + 4 * r;
-                    if (lg + 4 * r == lc && (i == p || (i < p && nb[i] >= 0))) acc[s_][r] += lam;
-                }
-            }
-    }
-    // ---- right-looking Cholesky by 8-column panels: the matrix stays in the accumulator tiles, LDS carries the panel ----
-    constexpr int PS = 9;                                  // panel row stride (doubles): pan[row][0..7]
-    double *pan = panel;                                   // 128 rows
-    for (int pp = 0; pp < ((probe & 2) ? 0 : 2 * S3_NU); ++pp) {
-        const int kb = pp >> 1, h = pp & 1, j0 = 8 * pp;
-        // a. owners publish columns j0..j0+7 (their tile column kb, half h), all rows of their tiles
-        if ((lc >> 3) == h) {
-#pragma unroll
-            for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-                if (slotOn(s_) && slotJ(s_) == kb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pan[(16 * slotI(s_) + lg + 4 * r) * PS + (lc & 7)] = acc[s_][r];
-                }
-        }
-        __syncthreads();
-        // c. wave 0 factors the panel in registers (lane = row j0+lane and j0+lane+64), exactly like k_ring_solve2
-        if (wave == 0 && !(probe & 8)) {
-            const int ra = j0 + lane, rb = j0 + lane + 64;
-            double a[PW], b[PW];
-#pragma unroll
-            for (int jj = 0; jj < PW; ++jj) {
-                a[jj] = (ra < 128 && j0 + jj <= ra) ? pan[ra * PS + jj] : 0.0;
-                b[jj] = (rb < 128) ? pan[rb * PS + jj] : 0.0;
-            }
-#pragma unroll
-            for (int jj = 0; jj < PW; ++jj) {
-                const double piv = readlane_f64(a[jj], jj);
-                const double inv = rsqrt_f64(piv);
-                if (lane == jj) { a[jj] = piv * inv; dinv[j0 + jj] = inv; } else if (lane > jj) a[jj] *= inv;
-                b[jj] *= inv;
-#pragma unroll
-                for (int c = jj + 1; c < PW; ++c) {
-                    const double lcj = readlane_f64(a[jj], c);
-                    if (lane >= c) a[c] -= a[jj] * lcj;
-                    b[c] -= b[jj] * lcj;
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < PW; ++jj) {
-                if (ra < 128 && j0 + jj <= ra) pan[ra * PS + jj] = a[jj];
-                if (rb < 128) pan[rb * PS + jj] = b[jj];
-            }
-        }
-        __syncthreads();
-        // e1. the factored columns go back into their tiles
-        if ((lc >> 3) == h) {
-#pragma unroll
-            for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-                if (slotOn(s_) && slotJ(s_) == kb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[s_][r] = pan[(16 * slotI(s_) + lg + 4 * r) * PS + (lc & 7)];
-                }
-        }
-        // e2. trailing update A(I,J) -= P_I P_J^T (rank 8: two MFMAs) on everything right of the panel
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && (slotJ(s_) > kb || (slotJ(s_) == kb && h == 0))) {
-                const double *PI = pan + (16 * slotI(s_) + lc) * PS + lg, *PJ = pan + (16 * slotJ(s_) + lc) * PS + lg;
-                const bool keep = !(slotJ(s_) == kb && lc < 8);          // columns of the panel itself are finished
-#pragma unroll
-                for (int mq = 0; mq < 2; ++mq) {
-                    const double bv = keep ? PJ[4 * mq] : 0.0;
-                    acc[s_] = s3_mfma(-PI[4 * mq], bv, acc[s_]);
-                }
-            }
-        __syncthreads();
-    }
-    // ---- diagonal tiles to LDS (for the block back substitution), z = row 0 of the right-hand side block ----
-    double *dt = linv;
-#pragma unroll
-    for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-        if (slotOn(s_) && slotI(s_) == slotJ(s_) && slotI(s_) < S3_NU) {
-            double *X = dt + slotI(s_) * S3_TILE;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * S3_LD + lc] = acc[s_][r];
-        }
-    if (wave == 0 && lg == 0) {
-#pragma unroll
-        for (int s_ = 0; s_ < 7; ++s_) zv[16 * s_ + lc] = acc[s_][0];
-    }
-    __syncthreads();
-    // ---- back substitution L^T w = z by row blocks, bottom up ----
-    for (int kb = S3_NU - 1; kb >= ((probe & 4) ? S3_NU : 0); --kb) {
-        if (wave == 0) {                                   // within the block: 16 steps, lane lc holds entry lc (replicated over lg)
-            const double *X = dt + kb * S3_TILE;
-            double t = zv[16 * kb + lc] - av[16 * kb + lc];
-#pragma unroll
-            for (int c = 15; c >= 0; --c) {
-                const double wc = readlane_f64(t, c) * dinv[16 * kb + c];
-                if (lc == c) t = wc;
-                else if (lc < c) t = fma(-X[c * S3_LD + lc], wc, t);
-            }
-            if (lg == 0) wv[16 * kb + lc] = t;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s_ = 0; s_ < S3_NSLOT; ++s_)
-            if (slotOn(s_) && slotI(s_) == kb && slotJ(s_) < kb) {
-                double q = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) q = fma(acc[s_][r], wv[16 * kb + lg + 4 * r], q);
-                q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-                if (lg == 0) av[16 * slotJ(s_) + lc] += q;
-            }
-        __syncthreads();
-    }
-    for (int i = tid; i < p; i += 256) W[(int64_t)i * g.d + m] = nb[i] >= 0 ? (float)wv[i] : 0.f;   // intercept (index p) discarded (:107)
-}
-
+}  // namespace cnmfe
+#include "ring_solve.hpp"
+namespace cnmfe {
 
 // pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60) and the first-run test on row 1 (:25)
 __global__ void k_count_pos(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
@@ -1854,7 +1034,14 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.Tp = (T + kstride - 1) / kstride;                   // numel(1:k:T)
     g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
     // ---- incremental Gram (k_win_proj / k_cov_correct above): per 16x16 block, the footprints with a pixel within two blocks of it ----
-    bool incr = ctx->opt("gram_incremental", 1) != 0 && ctx->opt("gram_kernel", 4) >= 4 && K < 32768;   // (derived low-resolution patches of bg_ssub included: their video is built once)
+    g.p_radius = 0;
+    for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
+    g.nbw = ((2 * g.p_radius) >> 4) + 2;
+    g.p = p;
+    // two ring pixels of one centre are up to 2*p_radius apart along an axis: their 16x16 blocks up to maxd apart (2 for radius <= 16, 3 up to 24)
+    const int maxd = (2 * g.p_radius + 15) >> 4, nrel = nrel_of(maxd);
+    if (maxd > 3 || g.nbw > 4) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: ring offsets up to %d pixels (the block-pair table covers <= 24)", g.p_radius);
+    bool incr = ctx->opt("gram_incremental", 1) != 0 && K < 32768;   // (derived low-resolution patches of bg_ssub included: their video is built once)
     std::vector<int> lst_ptr, lst_k, blk_nt[4];
     std::vector<short> slot_of;
     if (incr) {
@@ -1868,8 +1055,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 if (own[b_] != k) { own[b_] = k; mark.push_back(b_); }
             }
             for (int b_ : mark)
-                for (int dj = -2; dj <= 2; ++dj)
-                    for (int di = -2; di <= 2; ++di) {
+                for (int dj = -maxd; dj <= maxd; ++dj)
+                    for (int di = -maxd; di <= maxd; ++di) {
                         const int i2 = b_ % g.nbr + di, j2 = b_ / g.nbr + dj;
                         if (i2 < 0 || i2 >= g.nbr || j2 < 0 || j2 >= g.nbc) continue;
                         const int nb_ = j2 * g.nbr + i2;
@@ -1887,12 +1074,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         }
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
-    g.bf4 = incr ? 1 : (ctx->opt("gram_kernel", 4) >= 4 ? (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1) : 0);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
+    g.bf4 = incr ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
-    g.p_radius = 0;
-    for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
-    g.nbw = ((2 * g.p_radius) >> 4) + 2;
-    g.p = p;
     const int nblk = g.nbr * g.nbc;
 
     // ---- ind_active (:25-29) ----
@@ -1918,39 +1101,42 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
            has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCm.as<double>(), P->b0.as<double>());
 
     if (nactive > 0) {
-        // ---- pair list: blocks that hold ring pixels of some patch pixel, displacement within +-2 ----
-        // a block is "touched" if it lies within one block of a block containing patch pixels
+        // ---- pair list: blocks that hold ring pixels of some patch pixel (or patch pixels), displacement within +-maxd ----
         std::vector<char> touched(nblk, 0);
         {
-            int pi0 = P->roff / BLK, pi1 = (P->roff + P->nr - 1) / BLK, pj0 = P->coff / BLK, pj1 = (P->coff + P->nc - 1) / BLK;
-            for (int j = std::max(0, pj0 - 1); j <= std::min(g.nbc - 1, pj1 + 1); ++j)
-                for (int i = std::max(0, pi0 - 1); i <= std::min(g.nbr - 1, pi1 + 1); ++i) touched[j * g.nbr + i] = 1;
+            const int pi0 = std::max(0, P->roff - g.p_radius) / BLK, pi1 = std::min(P->nr_b - 1, P->roff + P->nr - 1 + g.p_radius) / BLK;
+            const int pj0 = std::max(0, P->coff - g.p_radius) / BLK, pj1 = std::min(P->nc_b - 1, P->coff + P->nc - 1 + g.p_radius) / BLK;
+            for (int j = pj0; j <= pj1; ++j)
+                for (int i = pi0; i <= pi1; ++i) touched[j * g.nbr + i] = 1;
         }
-        std::vector<int4> pairs; std::vector<int> pair_of((size_t)nblk * NREL, -1);
+        std::vector<int4> pairs; std::vector<int> pair_of((size_t)nblk * nrel, -1);
         for (int j = 0; j < g.nbc; ++j)
             for (int i = 0; i < g.nbr; ++i) {
                 if (!touched[j * g.nbr + i]) continue;
-                for (int dC = 0; dC <= 2; ++dC)
-                    for (int dR = (dC == 0 ? 0 : -2); dR <= 2; ++dR) {
+                for (int dC = 0; dC <= maxd; ++dC)
+                    for (int dR = (dC == 0 ? 0 : -maxd); dR <= maxd; ++dR) {
                         int i2 = i + dR, j2 = j + dC;
                         if (i2 < 0 || i2 >= g.nbr || j2 >= g.nbc || !touched[j2 * g.nbr + i2]) continue;
-                        int rel = dC == 0 ? dR : (dC == 1 ? 5 + dR : 10 + dR);
-                        pair_of[(size_t)(j * g.nbr + i) * NREL + rel] = (int)pairs.size();
+                        const int rel = rel_index(dR, dC, maxd);
+                        pair_of[(size_t)(j * g.nbr + i) * nrel + rel] = (int)pairs.size();
                         pairs.push_back(make_int4(j * g.nbr + i, j2 * g.nbr + i2, rel, 0));
                     }
             }
         const int npairs = (int)pairs.size();
         // needed 16x16 sub-tiles: displacement set D = (O - O) u O u -O of the ring offsets O
-        const int DM = 2 * 32 + 1;
+        const int DB = 2 * g.p_radius, DM = 2 * DB + 1;
         std::vector<char> Dm((size_t)DM * DM, 0);
-        auto dset = [&](int dr, int dc) { if (dr >= -32 && dr <= 32 && dc >= -32 && dc <= 32) Dm[(size_t)(dr + 32) * DM + dc + 32] = 1; };
+        auto dset = [&](int dr, int dc) { if (dr >= -DB && dr <= DB && dc >= -DB && dc <= DB) Dm[(size_t)(dr + DB) * DM + dc + DB] = 1; };
         for (int a = 0; a < p; ++a) {
             dset(P->dr[a], P->dc[a]); dset(-P->dr[a], -P->dc[a]);
             for (int b = 0; b < p; ++b) dset(P->dr[b] - P->dr[a], P->dc[b] - P->dc[a]);
         }
-        std::vector<unsigned short> needmask(NREL * 16, 0);
-        for (int rel = 0; rel < NREL; ++rel) {
-            const int dC = rel < 3 ? 0 : (rel < 8 ? 1 : 2), dR = rel < 3 ? rel : (rel < 8 ? rel - 5 : rel - 10);
+        std::vector<int> rel_dR(nrel), rel_dC(nrel);
+        for (int dC = 0; dC <= maxd; ++dC)
+            for (int dR = (dC == 0 ? 0 : -maxd); dR <= maxd; ++dR) { rel_dR[rel_index(dR, dC, maxd)] = dR; rel_dC[rel_index(dR, dC, maxd)] = dC; }
+        std::vector<unsigned short> needmask((size_t)nrel * 16, 0);
+        for (int rel = 0; rel < nrel; ++rel) {
+            const int dC = rel_dC[rel], dR = rel_dR[rel];
             for (int pi = 0; pi < 16; ++pi)
                 for (int pj = 0; pj < 16; ++pj) {
                     if (rel == 0 && pi > pj) continue;       // self pair: upper patch triangle (cov_lookup swaps)
@@ -1959,7 +1145,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                     for (int x = -3; x <= 3 && !nd; ++x)
                         for (int y = -3; y <= 3; ++y) {
                             const int ddr = rj - ri + x, ddc = cj - ci + y;
-                            if (ddr >= -32 && ddr <= 32 && ddc >= -32 && ddc <= 32 && Dm[(size_t)(ddr + 32) * DM + ddc + 32]) { nd = true; break; }
+                            if (ddr >= -DB && ddr <= DB && ddc >= -DB && ddc <= DB && Dm[(size_t)(ddr + DB) * DM + ddc + DB]) { nd = true; break; }
                         }
                     if (nd) needmask[rel * 16 + pi] |= (unsigned short)(1u << pj);
                 }
@@ -1994,9 +1180,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
         if (half_items) {
             // tile lists per (displacement class, row half): i | j << 4 with i < 8 (rows of the half), j < 16
-            std::vector<int> tcnt(NREL * 2, 0);
-            std::vector<int> tlist((size_t)NREL * 2 * G4Half::LIST, 0);
-            for (int rel = 0; rel < NREL; ++rel)
+            std::vector<int> tcnt((size_t)nrel * 2, 0);
+            std::vector<int> tlist((size_t)nrel * 2 * G4Half::LIST, 0);
+            for (int rel = 0; rel < nrel; ++rel)
                 for (int ih = 0; ih < 2; ++ih) {
                     int n = 0;
                     for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j)
@@ -2005,11 +1191,11 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 }
             RET(to_dev(ctx, dTcnt, tcnt.data(), tcnt.size()));
             RET(to_dev(ctx, dTl, tlist.data(), tlist.size()));
-        } else if (g.bf4) {
+        } else {
             // tile lists per (displacement class, quadrant): needed 16x16 sub-tiles as i | j << 4 (quadrant coordinates)
-            std::vector<int> tcnt(NREL * 4, 0);
-            std::vector<int> tlist((size_t)NREL * 4 * 64, 0);
-            for (int rel = 0; rel < NREL; ++rel)
+            std::vector<int> tcnt((size_t)nrel * 4, 0);
+            std::vector<int> tlist((size_t)nrel * 4 * 64, 0);
+            for (int rel = 0; rel < nrel; ++rel)
                 for (int q = 0; q < 4; ++q) {
                     const int ih = q & 1, jh = q >> 1;
                     int n = 0;
@@ -2043,7 +1229,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         if (g.bf4 != 2)
             LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, rsT.as<double>(), g.bf4);
 
-        if (g.bf4) {
+        {
             const size_t shmem = (size_t)G4_NBUF * G4_STAGE_F * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
@@ -2068,26 +1254,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             else
                 LAUNCH(ctx, "bg_gram_f64", k_gram4<0>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), 0, covT.as<double>());
-        } else if (ctx->opt("gram_kernel", 4) == 3) {
-            const size_t shmem = (size_t)GR_NBUF * GR_STAGE_F * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                CK(hipFuncSetAttribute((const void *)k_gram3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                CK(hipFuncSetAttribute((const void *)k_gram3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                attr_set = true;
-            }
-            if (f32s)
-                LAUNCH(ctx, "bg_gram_f32s", k_gram3<true>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16), covT.as<double>());
-            else
-                LAUNCH(ctx, "bg_gram_f64", k_gram3<false>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dNeed.as<unsigned short>(), 0, covT.as<double>());
-        } else if (f32s)
-            LAUNCH(ctx, "bg_gram_f32s", k_gram2<true>, dim3(nwg), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                   dNeed.as<unsigned short>(), (int)ctx->opt("gram_flush", 4), covT.as<double>());
-        else
-            LAUNCH(ctx, "bg_gram_f64", k_gram2<false>, dim3(nwg), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                   dNeed.as<unsigned short>(), 0, covT.as<double>());
+        }
         if (incr) { P->base_valid = true; P->base_kstride = kstride; }
         }
         if (incr) {
@@ -2125,32 +1292,31 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
         }
         // ---- B2b ----
-        CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc;
+        CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
         const int n = p + 1;
-        if (ctx->opt("solve_mode", 2) == 4 && n <= 16 * S3_NU) {
-            size_t shmem = ((size_t)(S3_NB + S3_NU) * S3_TILE + 4 * 128 + 8) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
-            shmem = (shmem + 15) & ~size_t(15);
-            LAUNCH(ctx, "bg_ring_solve", k_ring_solve4, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>(), (int)ctx->opt("solve_probe", 0));
-        } else if (ctx->opt("solve_mode", 2) == 3 && n <= 16 * S3_NU) {
-            size_t shmem = ((size_t)(S3_NB + S3_NU) * S3_TILE + 3 * 128 + 8) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
-            shmem = (shmem + 15) & ~size_t(15);
-            LAUNCH(ctx, "bg_ring_solve", k_ring_solve3, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
-        } else if (ctx->opt("solve_mode", 2) >= 2 && n + 1 <= 128) {
+        int *dErr = nullptr;
+        RET(ctx_errflag(ctx, &dErr));
+        const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();
+        const int probe = (int)ctx->opt("solve_probe", 0);
+        const int nt = (p + 15) / 16;
+        if (ctx->opt("solve_mode", 5) >= 5 && nt >= 1 && nt <= 8) {
+            // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp)
+#define RS5_CASE(NT_) case NT_: if (unrolled) LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_, false>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
+                                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); \
+                      else LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_, true>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
+                                  P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); break;
+            const bool unrolled = ctx->opt("solve_mode", 5) == 6;
+            switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
+#undef RS5_CASE
+        } else if (n + 1 <= 130) {
+            // panel-blocked Cholesky out of LDS, one 256-thread workgroup per pixel (solve_mode = 2: kept for A/B runs)
             const int na = n + 1;
             size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
             shmem = (shmem + 15) & ~size_t(15);
             if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             LAUNCH(ctx, "bg_ring_solve", k_ring_solve2, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>(), (int)ctx->opt("solve_probe", 0));
-        } else {
-            size_t shmem = ((size_t)(n * (n + 1)) / 2 + n) * sizeof(double) + (size_t)n * sizeof(int);
-            shmem = (shmem + 15) & ~size_t(15);
-            if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            LAUNCH(ctx, "bg_ring_solve_v1", k_ring_solve, dim3((unsigned)P->d), dim3(64), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-                   ctx->rowsum.as<double>(), first_run ? nullptr : dActive.as<unsigned char>(), P->W.as<float>());
-        }
+                   ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe);
+        } else return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
     }
     if (b0_out) {
         std::vector<double> tmp(P->d);

@@ -81,7 +81,6 @@ struct Profiler {
 constexpr int PMAX_RING = 128;    // max ring neighbours supported (r=18 -> 120)
 constexpr int BLK = 16;           // 16x16-pixel covariance blocks
 constexpr int BLKPX = BLK * BLK;
-constexpr int NREL = 13;          // canonical block displacements for the block-sparse SYRK
 
 // ---- sparse helpers (host) ------------------------------------------------------
 struct HostCSR { std::vector<int64_t> rowptr; std::vector<int32_t> col; std::vector<float> val; std::vector<int32_t> src; };
@@ -111,7 +110,8 @@ struct Patch {
     DevBuf ymean_d;                    // d_b double
     DevBuf ymean_f;                    // d_b float
     bool ymean_valid = false;
-    int64_t frames_uploaded = 0;
+    int64_t frames_uploaded = 0;       // distinct frames that have arrived
+    std::vector<uint8_t> frame_seen;   // T flags: a frame counts once, overlapping or repeated chunks are rejected (cnmfe_upload_block)
     // ring
     int32_t radius = 0, p = 0;         // p ring offsets
     std::vector<int32_t> dr, dc;       // ring offsets, (dc, dr)-sorted == MATLAB find() order
@@ -156,6 +156,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf tmp[16];    // small scratch
     cnmfe::DevBuf inc[7];     // incremental ring regression: block footprint lists, U~, trace sums
     cnmfe::DevBuf stage;      // upload staging
+    cnmfe::DevBuf errflag;    // one int, set by kernels that meet a state the host-side set-up should have excluded (checked at the next sync)
     std::map<std::string, int64_t> opts;
     int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }
     ~cnmfe_ctx();
@@ -211,4 +212,6 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P);
 int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
 int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean);
+int ctx_errflag(cnmfe_ctx *ctx, int **dflag);            // the device error word (allocated and cleared on first use)
+int ctx_check_errflag(cnmfe_ctx *ctx);                   // after a stream sync: CNMFE_ESTATE if a kernel raised it (and clears it)
 }  // namespace cnmfe

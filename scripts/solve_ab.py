@@ -1,0 +1,37 @@
+"""A/B of the ring-regression solve kernels on one patch: python scripts/solve_ab.py --cfg c3 [--modes 2,5,6] [--probes 0,1,2,4]
+Every mode fits the same first-run problem (ring re-initialised before each fit), so the W of the modes are comparable entry by entry."""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="2,5,6"); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0)
+a = ap.parse_args()
+import torch
+from cnmf_e_amd import synth
+from cnmf_e_amd.engine import Engine
+from cnmf_e_amd.sources2d import PatchedVideo
+CFG = {"c2": (256, 256, 3000, 200, 15, 1), "c3": (512, 512, 10000, 500, 15, 2), "small": (128, 128, 1000, 30, 15, 4)}
+d1, d2, T, K, r, seed = CFG[a.cfg]
+r = a.radius or r
+f = synth.make_factors(d1, d2, T, K, seed)
+Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
+eng = Engine(0)
+video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
+eng.profile(True)
+Ws = {}
+for mode in [int(x) for x in a.modes.split(",")]:
+    for probe in [int(x) for x in a.probes.split(",")]:
+        eng.ring_init(0, r)
+        eng.set_option("solve_mode", mode); eng.set_option("solve_probe", probe); eng.profile_reset()
+        _, info = eng.fit_ring_model(0, f.A_init.astype(np.float32), f.C_init)
+        eng.synchronize()
+        tab = eng.profile_table()
+        print("solve_mode %d probe %d: bg_ring_solve %.3f ms   (%s)" % (mode, probe, tab["bg_ring_solve"]["total_ms"] / tab["bg_ring_solve"]["calls"], info), flush=True)
+        if probe == 0:
+            Ws[mode] = eng.ring_csr(0).data.copy()
+ks = list(Ws)
+for k in ks[1:]:
+    dW = np.abs(Ws[k] - Ws[ks[0]])
+    print("max |W_%d - W_%d| / max|W| = %.3e   (rms %.3e, nan %d)" % (k, ks[0], dW.max() / np.abs(Ws[ks[0]]).max(), np.sqrt((dW ** 2).mean()), int(np.isnan(Ws[k]).sum())))
