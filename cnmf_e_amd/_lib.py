@@ -11,12 +11,31 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcnmfe_hip.so")
 
-if not os.path.exists(LIB_PATH):
-    raise ImportError(
-        "cnmf_e_amd: %s not found -- the HIP engine is mandatory (no CPU fallback). "
-        "Run `python -m cnmf_e_amd.build` (needs hipcc)." % LIB_PATH)
 
-lib = C.CDLL(LIB_PATH)
+class _Lib:
+    """The shared library, loaded and bound at first attribute access (Engine.__init__ is the first user).  Importing the package on a
+    checkout without the .so therefore works for the host logic (sources2d on a test double); anything that touches the engine raises --
+    there is still no CPU fallback."""
+    _dll = None
+
+    def _load(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "cnmf_e_amd: %s not found -- the HIP engine is mandatory (no CPU fallback). "
+                "Run `python -m cnmf_e_amd.build` (needs hipcc)." % LIB_PATH)
+        dll = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(dll, name)          # AttributeError here == missing export
+            fn.restype = res
+            fn.argtypes = args
+        _Lib._dll = dll
+        return dll
+
+    def __getattr__(self, name):
+        return getattr(_Lib._dll or self._load(), name)
+
+
+lib = _Lib()
 
 c_ctx = C.c_void_p
 i32p = C.POINTER(C.c_int32)
@@ -74,11 +93,6 @@ PROTOTYPES = {
     "cnmfe_synchronize": (C.c_int, [c_ctx]),
     "cnmfe_set_option": (C.c_int, [c_ctx, C.c_char_p, C.c_int64]),
 }
-
-for _name, (_res, _args) in PROTOTYPES.items():
-    _fn = getattr(lib, _name)          # AttributeError here == missing export
-    _fn.restype = _res
-    _fn.argtypes = _args
 
 # enums of include/cnmfe.h
 F32, F64, U16, U8, F16 = 0, 1, 2, 3, 4

@@ -13,11 +13,11 @@
 // Every ring pair of every patch pixel lies within +-2 blocks, so B2a computes each needed
 // covariance exactly once (symmetric pairs once) instead of once per centre pixel.
 #include "common.hpp"
+#include "ring_solve_core.hpp"
 #include <type_traits>
 
 namespace cnmfe {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // local pixel index inside a 16x16 block: 4x4-pixel patches (patch = (r>>2) + 4*(c>>2)), 16 pixels per patch.
@@ -722,15 +722,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
-// 1/sqrt(x) in fp64: hardware seed (v_rsq_f64, ~2^-26) + two Newton steps.  The library sqrt + divide of the
-// pivot cost ~100 fp64 instructions per column on the critical path of wave 0 (97 columns per pixel).
-__device__ __forceinline__ double rsqrt_f64(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
+__device__ __forceinline__ double rsqrt_f64(double x) { return rs_rsqrt(x); }
 
 __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
                                                      const double *__restrict__ rowsum, const unsigned char *__restrict__ active,

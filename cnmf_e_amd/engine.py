@@ -348,8 +348,11 @@ class Engine:
         """obj.deconvTemporal(): returns (C, C_raw, S, kernel_pars, sn).  The ABI updates C_raw in place (ck_raw - b); overwrite=True
         lets it do that to the caller's array (when that is a C-contiguous float32 one) instead of to a copy."""
         Craw = np.ascontiguousarray(C_raw, dtype=np.float32)
-        if Craw is C_raw and not overwrite:
-            Craw = Craw.copy()
+        if not overwrite or not isinstance(C_raw, np.ndarray) or not np.shares_memory(Craw, C_raw):
+            # in-place only on the caller's own plain array when it asked for it; anything else (a DeviceTraces' cached host copy, a view
+            # np.ascontiguousarray passed through) gets a private copy, so the write never lands in memory somebody else still reads
+            if np.shares_memory(Craw, np.asarray(C_raw)):
+                Craw = Craw.copy()
         K, T = Craw.shape
         Cout = np.empty_like(Craw); S = np.empty_like(Craw)
         pars = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)

@@ -485,9 +485,14 @@ class Sources2D:
         v = self.video
         rows = np.arange(K)[v.rank::v.world_size] if (self.dist is not None and v.world_size > 1) else np.arange(K)
         if rows.size == K:                                               # not sharded: no row gather / scatter of K x T arrays on the host
-            C, Craw, S, kp, sn = self.engine.deconv_temporal(self.C_raw, self.options.deconv_options, overwrite=True)
+            # the ABI writes ck_raw - b into C_raw in place: only a PRIVATE plain array may be handed over -- with deconv_flag = false C_raw
+            # is the same object as C / C_prev (and the engine's bound matrix), and a DeviceTraces' host cache must not diverge from its tensor
+            private = (isinstance(self.C_raw, np.ndarray) and self.C_raw is not self.C and self.C_raw is not self.C_prev
+                       and self.C_raw is not getattr(self.engine, "_bound", None))
+            C, Craw, S, kp, sn = self.engine.deconv_temporal(self.C_raw, self.options.deconv_options, overwrite=private)
             self.C, self.C_raw, self.S = C, Craw, S
             self.P["kernel_pars"], self.P["neuron_sn"] = kp, sn
+            self._bind_C()
             return C
         C = np.zeros_like(self.C_raw); Craw = np.zeros_like(self.C_raw); S = np.zeros_like(self.C_raw)
         kp = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
@@ -497,6 +502,7 @@ class Sources2D:
             C, Craw, S, kp, sn = (self._allreduce(x) for x in (C, Craw, S, kp, sn))
         self.C, self.C_raw, self.S = C, Craw, S
         self.P["kernel_pars"], self.P["neuron_sn"] = kp, sn
+        self._bind_C()
         return C
 
     # -- background -------------------------------------------------------------------
@@ -508,6 +514,7 @@ class Sources2D:
         cached = getattr(self, "_cur_blocks_src", None) is self.A
         infos = {}
         prefetched = False
+        flag_first = self._first_run()                                     # :143, from patch 1 for EVERY patch (a collective when sharded)
         self._prev_blocks = {}                                             # (ind, A_block) per patch: what the temporal update's residual needs
         for idx in v.owned:
             if cached and idx in self._cur_blocks:
@@ -518,7 +525,7 @@ class Sources2D:
             self._prev_blocks[idx] = (ind_nz, A_block)
             # "stop updating B because A&C doesn't change in this area" (:188-199) is decided by the engine's
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
-            if A_block.shape[1] == 0 and not self._first_run(idx):
+            if A_block.shape[1] == 0 and not flag_first:
                 continue
             if not prefetched:                                             # host thread under the first blocking (GIL-free) fit call
                 self._prefetch_search_location(); prefetched = True
@@ -549,10 +556,16 @@ class Sources2D:
             hit = self._prev_blocks[idx] = self._slice(self.A_prev, idx, "block")
         return hit
 
-    def _first_run(self, idx):
-        """flag_first = (length(unique(W{1}(1,:)))==2)  (update_background_parallel.m:143); the same value test,
-        evaluated on this patch's own W{m} so that sharded ranks need no broadcast of patch 1."""
-        return self.engine.ring_first_run(self.video.pid[idx] if self.ssub == 1 else self.pid_fit[idx])
+    def _first_run(self):
+        """flag_first = (length(unique(W{1}(1,:)))==2)  (update_background_parallel.m:143): the value test on patch 1's W decides the
+        "nothing changed here, keep W" skip (:188-199) of EVERY patch.  Sharded: the rank that owns patch 1 evaluates it, one
+        all-reduce of a flag hands it to the others (fit_ring_model's own first-run test, :25, stays per patch inside the engine)."""
+        v = self.video
+        idx1 = v.order[0]
+        flag = 0.0
+        if idx1 in v.owned:
+            flag = float(self.engine.ring_first_run(v.pid[idx1] if self.ssub == 1 else self.pid_fit[idx1]))
+        return bool(self._allreduce(np.array([flag], dtype=np.float64))[0] > 0)
 
     # -- spatial ----------------------------------------------------------------------
     def update_spatial_parallel(self, use_parallel=True, update_sn=False):
