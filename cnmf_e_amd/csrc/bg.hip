@@ -1297,7 +1297,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                                                         P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); \
                       else LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_, true>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
                                   P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); break;
-            const bool unrolled = ctx->opt("solve_mode", 5) == 6;
+            const bool unrolled = ctx->opt("solve_mode", 5) != 6;      // 5 (default): everything unrolled; 6: the block columns in a real loop (smaller code, more spills: slower)
             switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
 #undef RS5_CASE
         } else if (n + 1 <= 130) {

@@ -22,19 +22,19 @@ k_ring_solve5(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__res
     const int p = g.p;
     const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
     const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;      // arithmetic shift: floor
-    const int nbw = g.nbw, nb2 = nbw * nbw;
+    // the window is at most 4 x 4 blocks (host check): window block = wr + 4 wc whatever its real width, so every index below is a shift
     for (int a = lane; a <= N; a += 64) {
         int code = -1;
         if (a < p || a == N) {
             const int rb = a < p ? rbm + dr[a] : rbm, cb = a < p ? cbm + dc[a] : cbm;
             const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-            if (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) code = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15);
+            if (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) code = ((((rb >> 4) - br0) + 4 * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15);
         }
         s_node[a] = code;
     }
-    for (int q = lane; q < nb2 * nb2; q += 64) {
-        const int a = q / nb2, b = q % nb2;
-        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
+    for (int q = lane; q < 256; q += 64) {
+        const int a = q >> 4, b = q & 15;
+        int ia = br0 + (a & 3), ja = bc0 + (a >> 2), ib = br0 + (b & 3), jb = bc0 + (b >> 2);
         int code = -1;
         if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
             int dR = ib - ia, dC = jb - ja, sw = 0;
@@ -50,10 +50,13 @@ k_ring_solve5(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__res
     int bad = 0;
     // address of Cov(node na, node nb) in the table (both nodes exist)
     auto cov_ptr = [&](int na, int nb) -> const double * {
-        const int code = s_pt[(na >> 8) * nb2 + (nb >> 8)];
+        // (self pairs: upper patch triangle only.  Mirroring them in the table to drop this case distinction was measured: 0.7 ms SLOWER at
+        //  512 x 512 -- both orientations of a pair then miss the cache separately)
+        const int code = s_pt[((na >> 8) << 4) + (nb >> 8)];
         bad |= code < 0;
-        int la = na & 255, lb = nb & 255;
-        const bool flip = ((code & 2) != 0) != (((code & 1) != 0) && (((code & 2) ? lb : la) >> 4) > (((code & 2) ? la : lb) >> 4));
+        const int la = na & 255, lb = nb & 255;
+        const bool sw = (code & 2) != 0;
+        const bool flip = sw != (((code & 1) != 0) && ((sw ? lb : la) >> 4) > ((sw ? la : lb) >> 4));
         const int x = flip ? lb : la, y = flip ? la : lb;
         return tab.cov + ((int64_t)(code < 0 ? 0 : code >> 2) * BLKPX + x) * BLKPX + y;
     };
@@ -62,7 +65,7 @@ k_ring_solve5(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__res
         const int na = s_node[a], nc = s_node[N];
         double uv = 0.0, gv = 0.0;
         if (na >= 0 && !(probe & 1)) {
-            const int ab = ((na >> 8) % nbw + br0) + ((na >> 8) / nbw + bc0) * g.nbr;
+            const int ab = (((na >> 8) & 3) + br0) + ((na >> 10) + bc0) * g.nbr;
             uv = rowsum[(int64_t)ab * BLKPX + (na & 255)];
             gv = *cov_ptr(na, nc);
         }

@@ -129,9 +129,10 @@ __device__ __forceinline__ void rs_put_diag(const double4_t &D, double *s_blk, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = D[r];
 }
-// LOOP = true: the block columns run in a REAL loop -- one copy of the 16x16 diagonal step (11 KB of code; unrolled, the NT = 6 kernel is
-// 94 KB, more than the instruction cache two CUs share), the tile indices stay compile-time inside the arms of an if-chain on k.
-// LOOP = false: everything unrolled (no arm selection, fewer spills, 1.8x the code).  cnmfe_set_option("solve_mode", 5 | 6).
+// LOOP = false (default): the block columns are unrolled, every tile index a compile-time constant; the NT = 6 kernel is 87 KB of code.
+// LOOP = true (cnmfe_set_option("solve_mode", 6)): the block columns run in a real loop with ONE copy of the 16x16 diagonal step and the
+// tile indices compile-time inside the arms of an if-chain on k: 53 KB (the instruction cache two CUs share holds 64 KB), but hipcc then
+// spills ~200 tile registers around the loop -- measured at 512 x 512, p = 96: 10.6 ms against 8.5 ms unrolled.
 template <int NT, int K>
 __device__ __forceinline__ void rs_step_k(double4_t (&T)[(NT * (NT + 1)) / 2], int k, const double4_t &X1, double *s_blk, int c, int rq) {
     if constexpr (K < NT) {
