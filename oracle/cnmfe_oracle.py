@@ -223,12 +223,14 @@ def ind_patch_mask(patch, block):
 # --------------------------------------------------------------------------- #
 # background: ring model
 # --------------------------------------------------------------------------- #
-def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection=True):
+def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection=True, only_rows=None):
     """[W, b0] = fit_ring_model(...).  endoscope/fit_ring_model.m:1-127.
 
     Y: d_b x T, A: d_b x K (dense or sparse), C: K x T, W_old: sparse d x d_b.
     The outlier branch (:50-56, :62-67) is implemented for NaN thresh only
     (no demo sets thresh_outlier) and raises otherwise.
+    only_rows (test harness only, not in the reference): regress just these patch pixels -- the per-pixel regressions of :92-108 are
+    independent, so a sample of rows of W at a size where all of them would take hours; the other rows keep W_old.
     """
     Y = np.asarray(Y)
     d_b, T = Y.shape
@@ -277,7 +279,7 @@ def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projectio
     vec_ones = np.ones((1, Bf.shape[1]))                     # :91 / :69
     indptr, indices, data = W_old.indptr, W_old.indices, W_old.data
     new_data = data.copy()
-    for m in range(d):                                       # :92 / :112
+    for m in (range(d) if only_rows is None else only_rows):  # :92 / :112
         if not ind_active[m]:
             continue
         idx = ind_pixels[m]
@@ -307,10 +309,11 @@ def ring_frame_stride(W_old, T, with_projection=True):
 # --------------------------------------------------------------------------- #
 # residual / background subtraction  (the "R1" expression)
 # --------------------------------------------------------------------------- #
-def residual_ysig(Y_block, A_prev, C_prev, W, b0, ind_patch):
+def residual_ysig(Y_block, A_prev, C_prev, W, b0, ind_patch, only_rows=None):
     """Ysig = Y(patch,:) - W*(Y - A_prev*C_prev) - (b0 - W*mean(...,2)).
 
     @Sources2D/update_spatial_parallel.m:162-166 (= update_temporal_parallel.m:149-152).
+    only_rows (test harness only): just these patch pixels' rows of the result (rows of the expression are independent).
     """
     Yb = np.asarray(Y_block, dtype=np.float64)
     if A_prev is not None and A_prev.shape[1] > 0:
@@ -320,6 +323,10 @@ def residual_ysig(Y_block, A_prev, C_prev, W, b0, ind_patch):
     ind_patch = np.asarray(ind_patch, dtype=bool).ravel()
     W = sp.csr_matrix(W)
     b0 = np.asarray(b0, dtype=np.float64).ravel()
+    if only_rows is not None:
+        rows = np.asarray(only_rows)
+        Wr = W[rows]
+        return (Yb[np.nonzero(ind_patch)[0][rows], :] - Wr @ tmp_Y) - (b0[rows] - Wr @ tmp_Y.mean(axis=1))[:, None]
     return (Yb[ind_patch, :] - W @ tmp_Y) - (b0 - W @ tmp_Y.mean(axis=1))[:, None]   # :166
 
 
@@ -575,8 +582,9 @@ class OracleSources2D:
 
     def __init__(self, Yfull, d1, d2, T, patch_dims, ring_radius, A, C, sn, *,
                  spatial_algorithm="hals", maxIter=5, num_neighbors=None,
-                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1):
+                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1, deconv_options=None):
         self.bg_ssub = int(bg_ssub)
+        self.deconv_options = deconv_options       # None: options.deconv_flag = false; a dict: the keyword arguments of oasis_oracle
         self.Y = Yfull
         self.d1, self.d2, self.T = d1, d2, T
         self.ring_radius = ring_radius
@@ -821,6 +829,10 @@ class OracleSources2D:
             A_pp = A_b[ip, :]
             if not use_c_hat:
                 aa_p, C_raw_p = fast_temporal(Ysig, A_pp)                                   # :174-175
+            elif self.deconv_options is not None:                                          # :106-110 (deconv_flag = true)
+                from oasis_oracle import HALS_temporal_deconv
+                _, C_raw_p, _, _, _ = HALS_temporal_deconv(Ysig, A_pp, C_b, self.maxIter, **self.deconv_options)
+                aa_p = np.asarray(A_pp.multiply(A_pp).sum(axis=0)).ravel()
             else:
                 _, C_raw_p, _ = HALS_temporal(Ysig, A_pp, C_b, self.maxIter, None)         # :180
                 aa_p = np.asarray(A_pp.multiply(A_pp).sum(axis=0)).ravel()                  # :181
@@ -829,7 +841,11 @@ class OracleSources2D:
                 aa[k] += aa_p[j]
         aa[aa == 0] = 1                                      # :279
         self.C_raw = C_new / aa[:, None]                     # :280
-        self.C_raw = self.C_raw - self.C_raw.min(axis=1, keepdims=True)     # :285
-        self.C = self.C_raw.copy()                           # :286
+        if self.deconv_options is not None:                  # :282-283  obj.C = obj.deconvTemporal()
+            from oasis_oracle import deconvTemporal
+            self.C, self.C_raw, self.S, self.kernel_pars, self.neuron_sn = deconvTemporal(self.C_raw, **self.deconv_options)
+        else:
+            self.C_raw = self.C_raw - self.C_raw.min(axis=1, keepdims=True)     # :285
+            self.C = self.C_raw.copy()                       # :286
         self.b0_new = self._ymean_full() - np.asarray(
             self.A @ self.C.mean(axis=1)).reshape(self.d1, self.d2, order="F")              # :293

@@ -13,8 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def rel(a, b):
-    return np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(np.linalg.norm(b), 1e-30)
+from parity_util import rel
 
 
 def _oracle_iteration(z):
@@ -63,15 +62,15 @@ def test_engine_matches_iteration_fixture():
         s.update_background_parallel()
         for idx in video.owned:
             Wg = s.get_W(idx).toarray()
-            assert rel(Wg, z["W_%d_%d" % idx]) <= 2e-3            # fp32 products + fp64 shadow accumulation
+            assert rel(Wg, z["W_%d_%d" % idx]) <= 5e-7            # observed 3e-8 (fp64 table + fp64 solve, W stored in fp32)
         s.update_spatial_parallel()
         Ag, Ar = s.A.toarray(), z["A_after_spatial"]
-        assert ((Ag != 0) != (Ar != 0)).sum() <= max(3, 0.02 * (Ar != 0).sum())
+        assert ((Ag != 0) != (Ar != 0)).sum() == 0
         same = (Ag != 0) == (Ar != 0)
-        assert rel(Ag[same], Ar[same]) <= 2e-3
+        assert rel(Ag[same], Ar[same]) <= 3e-6
         s.update_temporal_parallel()
-        assert rel(s.C, z["C_after_temporal"]) <= 2e-3
-        assert np.allclose(s.b0_new, z["b0_new"], rtol=1e-4, atol=5e-2)
+        assert rel(s.C, z["C_after_temporal"]) <= 1e-6
+        assert np.allclose(s.b0_new, z["b0_new"], rtol=1e-6, atol=2e-4)
     finally:
         eng.close()
 
@@ -85,6 +84,6 @@ def test_engine_matches_oasis_fixture():
         C, Craw, S, kp, sn = eng.deconv_temporal(z["y"], dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0))
         assert np.max(np.abs(sn - z["sn"]) / z["sn"]) <= 2e-4
         assert np.max(np.abs(kp - z["g"])) <= 2e-3
-        assert rel(C, z["c"]) <= 2e-2                              # fp32 pools vs float64; Brent's search amplifies the difference
+        assert rel(C, z["c"]) <= 2.5e-3                              # fp32 pools vs float64; Brent's search amplifies the difference
     finally:
         eng.close()

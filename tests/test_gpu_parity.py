@@ -1,9 +1,9 @@
 """GPU parity: the HIP engine (through the C ABI) against the float64 CPU oracle on the same seeded inputs.
 
-Tolerances (fp32 engine vs float64 oracle):
-  Ysig, U-derived quantities, C : rel Frobenius <= 1e-4
-  W values                     : rel Frobenius <= 1e-3  (ridge-regularised (p+1)x(p+1) solves, fp32 video)
-  A after thresholding         : identical support except where |a - thr| is within 1e-4 relative of the threshold
+Tolerances (fp32 engine vs float64 oracle).  SURVEY.md 8(c) asks for Ysig / U / C <= 1e-4, W <= 1e-3 and identical supports off the
+threshold; the bounds below are set at <= 10x what the engine achieves on MI355X (recorded per call site by parity_util.rel into
+gpurun_out/parity_observed.json): 1e-7..3e-7 for A, C, Ysig, 3e-8..2e-7 for W (fp64 covariance table + fp64
+solve, fp32 storage), exact supports; only the OASIS traces (a discrete active-set method) sit at 1e-3.
 """
 import numpy as np
 import scipy.sparse as sp
@@ -15,9 +15,7 @@ from cnmf_e_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def rel(a, b):
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+from parity_util import rel
 
 
 @pytest.fixture(scope="module")
@@ -115,7 +113,7 @@ def test_residual_parity(eng, r, dims, pdims, T, with_ac):
         got = eng.residual(pid, A_b, C_b, want=True)                       # (T, d)
         ref = orc.residual_ysig(c.block(idx), A_b.astype(np.float64) if with_ac else None, C_b, Wv, b0.astype(np.float64), c.ipmask(idx))
         assert got.shape == ref.T.shape
-        assert rel(got.T, ref) <= 1e-4, rel(got.T, ref)
+        assert rel(got.T, ref) <= 1e-6, rel(got.T, ref)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11])
@@ -153,8 +151,8 @@ def test_fit_ring_model_parity(eng, r, dims, pdims, T):
             W = eng.ring_csr(pid)
             Wref = Wref.tocsr(); Wref.sort_indices()
             assert np.array_equal(W.indices, Wref.indices)
-            assert rel(W.data, Wref.data) <= 1e-3, (run, rel(W.data, Wref.data))
-            assert np.allclose(b0, b0ref, rtol=1e-6, atol=1e-3)
+            assert rel(W.data, Wref.data) <= 5e-7, (run, rel(W.data, Wref.data))
+            assert np.allclose(b0, b0ref, rtol=1e-6, atol=2e-4)
             # what matters downstream: the reconstructed fluctuating background W*Bf
             W_old = Wref
 
@@ -192,9 +190,9 @@ def test_update_spatial_parity(eng, alg, dims, pdims):
             ref = orc.nnls_spatial(ysig, A_p, C_p, INDp, 20)
         mism = (got != 0) != (ref != 0)
         # support may differ only for entries sitting on the threshold / on the nonnegativity boundary
-        assert mism.sum() <= max(2, 0.01 * (ref != 0).sum()), mism.sum()
+        assert mism.sum() == 0, mism.sum()
         ok = ~mism
-        assert rel(got[ok], ref[ok]) <= 2e-4, rel(got[ok], ref[ok])
+        assert rel(got[ok], ref[ok]) <= 3e-6, rel(got[ok], ref[ok])
 
 
 @pytest.mark.parametrize("dims,pdims", [((40, 36), None), ((44, 40), [22, 20])])
@@ -212,8 +210,8 @@ def test_hals_temporal_parity(eng, dims, pdims):
         Cg, Crawg, aa = eng.hals_temporal(pid, A_p, C_p, 5)
         Cr, Crawr, _ = orc.HALS_temporal(ysig, A_p.astype(np.float64), C_p, 5, None)
         assert np.allclose(aa, np.asarray(A_p.multiply(A_p).sum(axis=0)).ravel(), rtol=1e-5)
-        assert rel(Cg, Cr) <= 1e-4, rel(Cg, Cr)
-        assert rel(Crawg, Crawr) <= 1e-4
+        assert rel(Cg, Cr) <= 2e-6, rel(Cg, Cr)
+        assert rel(Crawg, Crawr) <= 2e-6
 
 
 def test_post_process_spatial_parity(eng):
@@ -250,17 +248,17 @@ def test_method_level_iteration_parity(eng, alg):
         s.update_background_parallel(); o.update_background_parallel()
         for idx in video.owned:
             Wg = s.get_W(idx); Wr = sp.csr_matrix(o.W[idx]); Wr.sort_indices()
-            assert rel(Wg.data, Wr.data) <= 2e-3, (it, rel(Wg.data, Wr.data))
-        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-5, atol=1e-2)
+            assert rel(Wg.data, Wr.data) <= 2e-6, (it, rel(Wg.data, Wr.data))
+        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-6, atol=2e-4)
         s.update_spatial_parallel(); o.update_spatial_parallel()
         Ag, Ar = s.A.toarray(), o.A.toarray()
         mism = ((Ag != 0) != (Ar != 0)).sum()
-        assert mism <= max(3, 0.02 * (Ar != 0).sum()), (it, mism)
+        assert mism == 0, (it, mism)
         same = (Ag != 0) == (Ar != 0)
-        assert rel(Ag[same], Ar[same]) <= 2e-3, (it, rel(Ag[same], Ar[same]))
+        assert rel(Ag[same], Ar[same]) <= 2e-6, (it, rel(Ag[same], Ar[same]))
         s.update_temporal_parallel(); o.update_temporal_parallel()
-        assert rel(s.C, o.C) <= 2e-3, (it, rel(s.C, o.C))
-        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-4, atol=5e-2)
+        assert rel(s.C, o.C) <= 2e-6, (it, rel(s.C, o.C))
+        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-6, atol=2e-4)
 
 
 @pytest.mark.parametrize("gram_mode", [1, 2, 3, 0])
@@ -282,7 +280,7 @@ def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
             W = eng.ring_csr(pid)
             assert np.all(np.isfinite(W.data))
             Wref = Wref.tocsr(); Wref.sort_indices()
-            assert rel(W.data, Wref.data) <= (1e-4 if gram_mode <= 1 else 1e-3), rel(W.data, Wref.data)
+            assert rel(W.data, Wref.data) <= (2e-6 if gram_mode <= 1 else 2e-4), rel(W.data, Wref.data)
     finally:
         eng.set_option("debug", 0); eng.set_option("gram_mode", 3); eng.set_option("gram_incremental", 1)
 
@@ -309,10 +307,10 @@ def test_deconv_temporal_parity(eng):
     assert np.allclose(sng, snr, rtol=2e-4)
     assert np.allclose(parsg, parsr, atol=2e-3), (parsg, parsr)
     for k in range(Cg.shape[0]):
-        assert rel(Cg[k], Cr[k]) <= 2e-2, (k, rel(Cg[k], Cr[k]))
-        assert rel(Crawg[k], Crawr[k]) <= 1e-2
+        assert rel(Cg[k], Cr[k]) <= 1.2e-2, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 7e-3
         eg, er = np.nonzero(Sg[k] > 0)[0], np.nonzero(Sr[k] > 0)[0]
-        assert abs(len(eg) - len(er)) <= max(2, 0.05 * len(er)), (k, len(eg), len(er))
+        assert abs(len(eg) - len(er)) <= 2, (k, len(eg), len(er))
 
 
 def test_hals_temporal_deconv_parity(eng):
@@ -324,8 +322,8 @@ def test_hals_temporal_deconv_parity(eng):
     assert np.allclose(sng, snr, rtol=1e-3)
     assert np.allclose(parsg, np.array(parsr, dtype=np.float64), atol=3e-3), (parsg, parsr)
     for k in range(Cg.shape[0]):
-        assert rel(Cg[k], Cr[k]) <= 3e-2, (k, rel(Cg[k], Cr[k]))
-        assert rel(Crawg[k], Crawr[k]) <= 2e-2, (k, rel(Crawg[k], Crawr[k]))
+        assert rel(Cg[k], Cr[k]) <= 1.3e-2, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 7e-3, (k, rel(Crawg[k], Crawr[k]))
         assert np.corrcoef(Cg[k], c.f.C_true[k])[0, 1] > 0.95
 
 
@@ -381,9 +379,9 @@ def test_method_level_update_sn(eng):
     assert not np.allclose(s.P["sn"], np.asarray(f.sn).reshape(-1))      # it really was re-estimated
     Ag, Ar = s.A.toarray(), o.A.toarray()
     mism = ((Ag != 0) != (Ar != 0)).sum()
-    assert mism <= max(3, 0.02 * (Ar != 0).sum()), mism
+    assert mism == 0, mism
     same = (Ag != 0) == (Ar != 0)
-    assert rel(Ag[same], Ar[same]) <= 2e-3
+    assert rel(Ag[same], Ar[same]) <= 1e-6
 
 
 def test_fast_temporal_parity(eng):
@@ -397,7 +395,7 @@ def test_fast_temporal_parity(eng):
     Craw, aa = eng.fast_temporal(pid, A)
     aa_ref, Craw_ref = orc.fast_temporal(Ysig, A.astype(np.float64))
     assert np.allclose(aa, aa_ref, rtol=1e-6) and aa[-1] == 0 and not Craw[-1].any()
-    assert rel(Craw, Craw_ref) <= 1e-5
+    assert rel(Craw, Craw_ref) <= 6e-7
     d1, d2, T, K, r = 44, 40, 300, 6, 5
     f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
@@ -407,7 +405,7 @@ def test_fast_temporal_parity(eng):
     o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
     s.update_background_parallel(); o.update_background_parallel()
     s.update_temporal_parallel(use_c_hat=False); o.update_temporal_parallel(use_c_hat=False)
-    assert rel(s.C, o.C) <= 1e-3, rel(s.C, o.C)
+    assert rel(s.C, o.C) <= 1e-6, rel(s.C, o.C)
 
 
 @pytest.mark.parametrize("variant", [10, 11])
@@ -482,7 +480,7 @@ def test_residual_ssub_parity(eng, dims, pdims, ssub, r):
         got = eng.residual_ssub(pid, pres, ssub, A_b, f.C_init, want=True).T.astype(np.float64)       # d x T
         ip = np.zeros(bp.size, dtype=bool); ip[video.ind_patch[idx]] = True
         ref = orc.residual_ysig_ssub(Y[:, bp].T.astype(np.float64), A_b.astype(np.float64), f.C_init, Wl, b0.astype(np.float64), ip, nrb, ncb, ssub)
-        assert rel(got, ref) <= 3e-6, (idx, rel(got, ref))
+        assert rel(got, ref) <= 3e-7, (idx, rel(got, ref))
 
 
 def test_method_level_iteration_bg_ssub(eng):
@@ -501,16 +499,16 @@ def test_method_level_iteration_bg_ssub(eng):
         for idx in video.owned:
             Wg = s.get_W(idx); Wr = sp.csr_matrix(o.W[idx]); Wr.sort_indices()
             assert Wg.shape == Wr.shape
-            assert rel(Wg.data, Wr.data) <= 2e-3, (it, rel(Wg.data, Wr.data))
-        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-5, atol=1e-2)
+            assert rel(Wg.data, Wr.data) <= 1e-6, (it, rel(Wg.data, Wr.data))
+        assert np.allclose(s.b0_new, o.b0_new, rtol=1e-6, atol=2e-4)
         s.update_spatial_parallel(); o.update_spatial_parallel()
         Ag, Ar = s.A.toarray(), o.A.toarray()
         mism = ((Ag != 0) != (Ar != 0)).sum()
-        assert mism <= max(3, 0.02 * (Ar != 0).sum()), (it, mism)
+        assert mism == 0, (it, mism)
         same = (Ag != 0) == (Ar != 0)
-        assert rel(Ag[same], Ar[same]) <= 2e-3, (it, rel(Ag[same], Ar[same]))
+        assert rel(Ag[same], Ar[same]) <= 2e-6, (it, rel(Ag[same], Ar[same]))
         s.update_temporal_parallel(); o.update_temporal_parallel()
-        assert rel(s.C, o.C) <= 2e-3, (it, rel(s.C, o.C))
+        assert rel(s.C, o.C) <= 2e-6, (it, rel(s.C, o.C))
 
 
 def test_residual_ssub_footprint_term_reuse(eng):
@@ -603,7 +601,7 @@ def test_reconstruct_background_parity(eng):
     ref = o.reconstruct_background()
     got = s.reconstruct_background()
     assert got.shape == ref.shape
-    assert rel(got, ref) <= 2e-4, rel(got, ref)            # (W itself agrees to 2e-3 with the oracle's; Ybg is dominated by b0)
+    assert rel(got, ref) <= 5e-7, rel(got, ref)            # (W itself agrees to 2e-3 with the oracle's; Ybg is dominated by b0)
     part = s.reconstruct_background((50, 120))
     assert np.array_equal(part, got[:, :, 49:120])
 
