@@ -118,3 +118,232 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
             assert obs["kp_%d" % it] <= 4e-4 * tl
         e = float(np.abs(got["b0new_t_%d" % it] - ref["b0new_t_%d" % it]).max()); obs["b0new_t_%d" % it] = e
         assert e <= (0.1 if deconv else 1e-4), (name, it, e)
+
+
+# ======================================================================================================================================
+# BASELINE configurations at FULL size.  The float64 oracle cannot run them whole (hours), but every stage is a set of independent
+# per-pixel or per-patch problems, so it is run on SAMPLES: rows of W (the per-pixel regressions), rows of the background-subtracted
+# video, rows of the spatial update, one patch's temporal update -- each from the same inputs the engine had.
+# ======================================================================================================================================
+import cnmfe_oracle as orc
+
+
+class BigCase:
+    """a full-size configuration resident on the GPU, with host copies of the blocks of the patches the oracle samples"""
+
+    def __init__(self, eng, d1, d2, T, K, r, seed, patch_dims, sample_patches, upload_dtype="f32", rank=0, world=1, **opts):
+        import torch
+        from cnmf_e_amd import synth, _lib
+        from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+        self.torch = torch
+        self.f = f = synth.make_factors(d1, d2, T, K, seed)
+        self.video = v = PatchedVideo(d1, d2, T, patch_dims, r, eng, rank=rank, world_size=world)
+        self.Yb = {}
+        for idx in v.owned:
+            Yd = synth.make_video_device(f, "cuda:0", pixels=v.block_pix[idx])
+            if upload_dtype == "f16":
+                Yd = Yd.to(torch.float16)
+            torch.cuda.synchronize()
+            eng.upload_block_device(v.pid[idx], Yd.data_ptr(), T, dtype=_lib.F16 if upload_dtype == "f16" else _lib.F32)
+            if idx in sample_patches:
+                self.Yb[idx] = Yd.float().cpu().numpy().T.copy()                      # d_b x T float32, exactly what the engine holds
+            del Yd
+        torch.cuda.empty_cache()
+        self.s = Sources2D(v, Options(ring_radius=r, maxIter=5, **opts), f.A_init, f.C_init, f.sn)
+        self.rs, self.cs = orc.get_nhood(r)
+        self.d1, self.d2, self.T, self.r = d1, d2, T, r
+        self.rng = np.random.default_rng(99)
+
+    def ip(self, idx):
+        m = np.zeros(self.video.block_pix[idx].size, dtype=bool); m[self.video.ind_patch[idx]] = True
+        return m
+
+    def block_neurons(self, A, idx, pix=None):
+        """(ind, A(pix, ind)) with ind = neurons that have mass on the block (the reference's `mask` selection)"""
+        Ab = sp.csc_matrix(A).tocsr()[self.video.block_pix[idx] if pix is None else pix]
+        ind = np.nonzero(np.asarray(Ab.sum(axis=0)).ravel() > 0)[0]
+        return ind, sp.csc_matrix(Ab[:, ind]).astype(np.float64)
+
+    def check_background(self, idx, A, C, W_old, nrows, obs, tag):
+        """sampled rows of the freshly fitted W{idx} and b0{idx} against fit_ring_model (fit_ring_model.m:1-127) on the same inputs"""
+        v, s = self.video, self.s
+        ind, A_blk = self.block_neurons(A, idx)
+        rows = np.sort(self.rng.choice(v.patch_pix[idx].size, size=nrows, replace=False))
+        Wr, b0r = orc.fit_ring_model(self.Yb[idx], A_blk if ind.size else None, np.asarray(C)[ind] if ind.size else None, W_old, np.nan, None, self.ip(idx), True, only_rows=rows)
+        Wg = s.get_W(idx); Wr = sp.csr_matrix(Wr); Wr.sort_indices()
+        eW = rel(Wg[rows].data, Wr[rows].data)
+        eb = float(np.abs(s.get_b0(idx) - b0r).max())
+        obs[tag + "_W_rows"] = eW; obs[tag + "_b0"] = eb
+        assert eW <= 2e-6 and eb <= 5e-4, (tag, eW, eb)
+        return Wg
+
+    def check_residual(self, idx, A, C, nrows, obs, tag):
+        """sampled rows of Y - A C - ring background (initComponents_residual_parallel.m:199-206 == the R1 expression with the block's neurons)"""
+        v, s = self.video, self.s
+        ind, A_blk = self.block_neurons(A, idx)
+        rows = np.sort(self.rng.choice(v.patch_pix[idx].size, size=nrows, replace=False))
+        got = s.init_residual(idx)[:, rows].T
+        Cb = np.asarray(C, dtype=np.float64)[ind]
+        ref = orc.residual_ysig(self.Yb[idx], A_blk, Cb, s.get_W(idx), s.get_b0(idx).astype(np.float64), self.ip(idx), only_rows=rows)
+        ref = ref - np.asarray(A_blk[np.nonzero(self.ip(idx))[0][rows]] @ Cb)
+        e = rel(got, ref); obs[tag + "_resid_rows"] = e
+        assert e <= 2e-4, (tag, e)          # a unit-variance residual of fp32 numbers ~1.5e3 (ulp 1.2e-4): observed 2e-5..4e-5
+
+    def check_spatial(self, idx, A_before, C, A_prev, C_prev, nrows, obs, tag):
+        """sampled rows of the spatial update of patch idx (HALS_spatial.m:26-45 on Ysig with the halo-only A_prev of update_spatial_parallel.m:83-98)"""
+        v, s = self.video, self.s
+        pp, bp = v.patch_pix[idx], v.block_pix[idx]
+        rows = np.sort(self.rng.choice(pp.size, size=nrows, replace=False))
+        halo = np.setdiff1d(bp, pp)
+        indp = np.nonzero(np.asarray(sp.csc_matrix(A_prev).tocsr()[halo].sum(axis=0)).ravel() > 0)[0]
+        A_prev_b = sp.csc_matrix(sp.csc_matrix(A_prev).tocsr()[bp][:, indp]).astype(np.float64)
+        Ysig = orc.residual_ysig(self.Yb[idx], A_prev_b, np.asarray(C_prev, dtype=np.float64)[indp], s.get_W(idx), s.get_b0(idx).astype(np.float64), self.ip(idx), only_rows=rows)
+        IND = orc.determine_search_location(sp.csc_matrix(A_before).astype(np.float64), self.d1, self.d2)
+        INDp = sp.csc_matrix(IND).tocsr()[pp]
+        ind = np.nonzero(np.asarray(INDp.sum(axis=0)).ravel() > 0)[0]
+        A_pp = sp.csc_matrix(A_before).tocsr()[pp[rows]][:, ind].toarray().astype(np.float64)
+        ref = orc.HALS_spatial(Ysig, A_pp, np.asarray(C, dtype=np.float64)[ind], INDp[rows][:, ind].toarray(), 3)
+        got = s.A_raw.tocsr()[pp[rows]][:, ind].toarray()
+        assert np.array_equal(got != 0, ref != 0), (tag, int(((got != 0) != (ref != 0)).sum()))
+        e = rel(got, ref); obs[tag + "_A_rows"] = e
+        assert e <= 2e-6, (tag, e)
+
+    def check_temporal_patch(self, idx, obs, tag, deconv=False, maxIter=5):
+        """the temporal update of ONE patch through the engine-level call against HALS_temporal.m on the engine's exported Ysig (R1 itself is
+        checked on sampled rows above; here the 16384 x T product A' Ysig, A'A and the Gauss-Seidel sweeps at full length)"""
+        v, s = self.video, self.s
+        pp, bp = v.patch_pix[idx], v.block_pix[idx]
+        ind, A_blk = self.block_neurons(s.A, idx)
+        indp, A_prev_b = self.block_neurons(s.A_prev, idx)
+        Ysig = s.engine.residual(v.pid[idx], A_prev_b.astype(np.float32), np.asarray(s.C_prev)[indp], want=True).T.astype(np.float64)
+        A_pp = sp.csc_matrix(sp.csc_matrix(s.A).tocsr()[pp][:, ind]).astype(np.float32)
+        Cp = np.ascontiguousarray(np.asarray(s.C)[ind], dtype=np.float32)
+        if not deconv:
+            Cg, Crawg, aa = s.engine.hals_temporal(v.pid[idx], A_pp, Cp, maxIter)
+            Cr, Crawr, _ = orc.HALS_temporal(Ysig, A_pp.astype(np.float64), Cp, maxIter, None)
+            e = max(rel(Cg, Cr), rel(Crawg, Crawr)); obs[tag + "_C_patch"] = e
+            assert e <= 5e-6, (tag, e)
+        else:
+            import oasis_oracle as oo
+            Cg, Crawg, Sg, sng, parsg, aa = s.engine.hals_temporal_deconv(v.pid[idx], A_pp, Cp, maxIter, None)
+            Cr, Crawr, Sr, snr, parsr = oo.HALS_temporal_deconv(Ysig, A_pp.astype(np.float64), Cp, maxIter)
+            live = np.nonzero(aa > 0)[0]
+            ec = [rel(Cg[k], Cr[k]) for k in live]; er = [rel(Crawg[k], Crawr[k]) for k in live]
+            obs[tag + "_deconv_C_patch"] = dict(max=max(ec), median=float(np.median(ec)), raw_max=max(er), n=len(live))
+            assert np.allclose(sng[live], snr[live], rtol=5e-4)
+            assert max(ec) <= 3e-2 and np.median(ec) <= 2e-3 and max(er) <= 2e-2, (tag, max(ec), float(np.median(ec)), max(er))
+            for k in live:
+                assert abs(int((Sg[k] > 0).sum()) - int((Sr[k] > 0).sum())) <= max(2, 0.05 * (Sr[k] > 0).sum())
+
+
+def _recovery(s, f):
+    """correlation of the updated traces with the planted ones (neurons with a real footprint)"""
+    C = np.asarray(s.C); ok = np.nonzero(np.asarray(s.A.sum(axis=0)).ravel() > 0)[0]
+    cc = [np.corrcoef(C[k], f.C_true[k])[0, 1] for k in ok if C[k].std() > 0]
+    return float(np.median(cc)), float(np.min(cc))
+
+
+def _need_big_gpu():
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs a 128+ GB GPU")
+
+
+@pytest.fixture
+def own_engine():
+    """a context of its own per full-size configuration: its blocks (tens of GB) are released when the test ends"""
+    from cnmf_e_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_c2_full_size(own_engine, observed):
+    """BASELINE configs[1]: 256 x 256 x 3000, K = 200, r = 15, one patch -- two iterations, sampled-oracle checks of every stage"""
+    obs = observed.setdefault("c2_full", {})
+    c = BigCase(own_engine, 256, 256, 3000, 200, 15, 1, [256, 256], {(0, 0)}, spatial_algorithm="hals")
+    s, idx = c.s, (0, 0)
+    W_old = orc.build_ring_W(c.video.patch_pos[idx], c.video.block_pos[idx], 256, 256, c.rs, c.cs)
+    rss = []
+    for it in range(2):
+        A0, C0 = s.A.copy(), np.asarray(s.C).copy()
+        info = s.update_background_parallel()
+        assert info[idx]["first_run"] == (it == 0)
+        W_old = c.check_background(idx, A0, C0, W_old, 96, obs, "it%d" % it)
+        c.check_residual(idx, A0, C0, 256, obs, "it%d" % it)
+        s.update_spatial_parallel()
+        c.check_spatial(idx, A0, C0, s.A_prev, s.C_prev, 512, obs, "it%d" % it)
+        s.update_temporal_parallel()
+        c.check_temporal_patch(idx, obs, "it%d" % it)
+        rss.append(s.compute_RSS()[0])
+    med, mn = _recovery(s, c.f)
+    obs["recovery_median_min"] = [med, mn]; obs["rss"] = rss
+    assert med > 0.98 and rss[1] <= rss[0] * (1 + 1e-6), (med, mn, rss)
+
+
+def test_c4_sixteen_patches_on_one_gpu(own_engine, observed):
+    """BASELINE configs[3] on ONE GPU: 512 x 512 x 10000, K = 500, 4 x 4 patches of distribute_data.m:56-79,165-171 (16 resident blocks), two
+    iterations; an interior and a corner patch are checked stage by stage against the oracle on samples"""
+    _need_big_gpu()
+    obs = observed.setdefault("c4_16_patches", {})
+    sample = {(1, 1), (3, 0)}
+    c = BigCase(own_engine, 512, 512, 10000, 500, 15, 2, [128, 128], sample, spatial_algorithm="hals")
+    s, v = c.s, c.video
+    assert (v.nr_patch, v.nc_patch) == (4, 4) and list(v.block_pos[(1, 1)]) == [113, 272, 113, 272] and list(v.patch_pos[(3, 0)]) == [385, 512, 1, 128]
+    W_old = {idx: orc.build_ring_W(v.patch_pos[idx], v.block_pos[idx], 512, 512, c.rs, c.cs) for idx in sample}
+    rss = []
+    for it in range(2):
+        A0, C0 = s.A.copy(), np.asarray(s.C).copy()
+        s.update_background_parallel()
+        for idx in sorted(sample):
+            W_old[idx] = c.check_background(idx, A0, C0, W_old[idx], 64, obs, "it%d_%d%d" % (it, idx[0], idx[1]))
+            c.check_residual(idx, A0, C0, 128, obs, "it%d_%d%d" % (it, idx[0], idx[1]))
+        s.update_spatial_parallel()
+        for idx in sorted(sample):
+            c.check_spatial(idx, A0, C0, s.A_prev, s.C_prev, 384, obs, "it%d_%d%d" % (it, idx[0], idx[1]))
+        s.update_temporal_parallel()
+        if it == 0:
+            c.check_temporal_patch((1, 1), obs, "it0_11")
+        rss.append(s.compute_RSS()[0])
+    med, mn = _recovery(s, c.f)
+    obs["recovery_median_min"] = [med, mn]; obs["rss"] = rss
+    assert np.all(np.asarray(s.C) >= 0) and med > 0.98 and rss[1] <= rss[0] * (1 + 1e-6), (med, mn, rss)
+
+
+def test_c5_one_rank_shard(own_engine, observed):
+    """BASELINE configs[4], the shard of rank 0 of 8: 1024 x 1024 x 20000 fp16 video, K = 2000, 8 x 8 patches -> 8 resident blocks uploaded as
+    fp16; deconv_flag = true (T = 20000 takes the LONG deconvolution kernel) and update_sn = true (per-pixel GetSn at T = 20000)."""
+    _need_big_gpu()
+    obs = observed.setdefault("c5_shard", {})
+    sample = {(0, 3)}
+    c = BigCase(own_engine, 1024, 1024, 20000, 2000, 15, 3, [128, 128], sample, upload_dtype="f16", rank=0, world=8,
+                spatial_algorithm="hals", deconv_flag=True)
+    s, v = c.s, c.video
+    assert len(v.owned) == 8 and (0, 3) in v.owned
+    idx = (0, 3)
+    W_old = orc.build_ring_W(v.patch_pos[idx], v.block_pos[idx], 1024, 1024, c.rs, c.cs)
+    A0, C0 = s.A.copy(), np.asarray(s.C).copy()
+    info = s.update_background_parallel()
+    assert info[idx]["frame_stride"] == 2                        # T = 20000 > 100 * pmax: the fit subsamples (fit_ring_model.m:84-87)
+    c.check_background(idx, A0, C0, W_old, 48, obs, "it0")
+    c.check_residual(idx, A0, C0, 96, obs, "it0")
+    s.update_spatial_parallel(update_sn=True)
+    # GetSn of sampled pixels of the patch (update_spatial_parallel.m:191-194) against the oracle on the oracle's own Ysig rows
+    import oasis_oracle as oo
+    pp, bp = v.patch_pix[idx], v.block_pix[idx]
+    rows = np.sort(c.rng.choice(pp.size, size=48, replace=False))
+    halo = np.setdiff1d(bp, pp)
+    indp = np.nonzero(np.asarray(sp.csc_matrix(s.A_prev).tocsr()[halo].sum(axis=0)).ravel() > 0)[0]
+    A_prev_b = sp.csc_matrix(sp.csc_matrix(s.A_prev).tocsr()[bp][:, indp]).astype(np.float64)
+    Ysig = orc.residual_ysig(c.Yb[idx], A_prev_b, np.asarray(s.C_prev, dtype=np.float64)[indp], s.get_W(idx), s.get_b0(idx).astype(np.float64), c.ip(idx), only_rows=rows)
+    sn_ref = np.array([oo.GetSn(y) for y in Ysig])
+    e = float(np.max(np.abs(s.P["sn"][pp[rows]] - sn_ref) / sn_ref)); obs["sn_rows"] = e
+    assert e <= 5e-4, e
+    c.check_temporal_patch(idx, obs, "it0", deconv=True, maxIter=2)
+    s.update_temporal_parallel()
+    C = np.asarray(s.C)
+    owned_neurons = np.nonzero(np.asarray(sp.csc_matrix(s.A).tocsr()[np.concatenate([v.patch_pix[i] for i in v.owned])].sum(axis=0)).ravel() > 0)[0]
+    assert np.all(np.isfinite(C)) and owned_neurons.size > 100        # (C may dip below 0 where deconvolution returns an all-zero trace: ck = ck_raw, deconvTemporal.m:53-55)
+    cc = [np.corrcoef(C[k], c.f.C_true[k])[0, 1] for k in owned_neurons if C[k].std() > 0]
+    obs["recovery_median"] = float(np.median(cc))
+    assert np.median(cc) > 0.9, np.median(cc)
