@@ -2,11 +2,14 @@
 """bench.py -- CNMF-E iterations/s (background + spatial + temporal) on MI355X.
 
 One "step" = Sources2D.update_background_parallel + update_spatial_parallel + update_temporal_parallel
-(demos/demo_large_data_1p.m:199-201) on synthetic data already resident in HBM.
-N=1: BASELINE.json configs[2] (headline): 512x512x10000 fp32, K=500, ring_radius=15, 1 patch.
-N>1: weak scaling -- the FOV grows to 512 x (512*N) (1 x N patches of 512x512, 500 neurons each); every
-rank owns one patch (with its ring halo) and the temporal update does one RCCL all-reduce of the
-[K x T] stitch (update_temporal_parallel.m:269-280).  value = patch-iterations per second over all ranks.
+(demos/demo_large_data_1p.m:199-201) on synthetic data already resident in HBM; value = whole-FOV iterations per second.
+N=1 (default --config c3): BASELINE.json configs[2] (headline): 512x512x10000 fp32, K=500, ring_radius=15, 1 patch.
+N>1 (default --config c4): BASELINE.json configs[3]: the SAME 512x512x10000, K=500 video cut into the 4 x 4 patches of
+distribute_data.m:56-79,165-171 (blocks = patches + ring halo), patches round-robin over the ranks (strong scaling: the total work is
+fixed); spatial rows are all-gathered, the temporal update does one RCCL all-reduce of the [K x T] stitch
+(update_temporal_parallel.m:269-280).  `--config c4 --gpus 1` runs all 16 patches on one GPU.
+--weak: the round-1 grown-FOV mode (512 x 512N, one 512x512 patch and 500 neurons per rank; value = patch-iterations/s).
+--demo-sequence: the calls demo_large_data_1p.m:142-211 makes on this path, from a fresh upload, as seconds per recording.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -26,7 +29,10 @@ CONFIGS = {
     "c3": (512, 512, 10000, 500, 15, 2),     # BASELINE.json configs[2] (headline)
     "c2": (256, 256, 3000, 200, 15, 1),      # BASELINE.json configs[1]
     "tiny": (96, 96, 600, 18, 15, 5),
+    "c4": (512, 512, 10000, 500, 15, 2),     # BASELINE.json configs[3]: c3's video, 4 x 4 patches sharded over the ranks
+    "c4tiny": (96, 96, 600, 18, 15, 5),      # (test size of the c4 code path: 2 x 2 patches of 48 x 48)
 }
+PATCHES = {"c4": [128, 128], "c4tiny": [48, 48]}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (157.3 TF), spec
 F32_MFMA_PEAK_TF = 157.3
@@ -64,7 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3")
+    ap.add_argument("--config", default=None, help="c3 (default at 1 GPU) | c4 (default at N > 1) | c2 | tiny | c4tiny")
+    ap.add_argument("--weak", action="store_true", help="grown-FOV weak scaling (512 x 512N, one patch per rank) instead of the sharded 4 x 4 patches")
+    ap.add_argument("--demo-sequence", action="store_true", help="time the call sequence of demo_large_data_1p.m:142-211 from a fresh upload")
     ap.add_argument("--alg", default="hals", help="spatial algorithm: hals | hals_thresh | nnls")
     ap.add_argument("--deconv", action="store_true", help="deconv_flag=true (OASIS AR(1) FOOPSI inside the temporal sweep); reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,11 +105,18 @@ def main():
     from cnmf_e_amd.engine import Engine
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
 
+    if a.config is None:
+        a.config = "c3" if (world == 1 or a.weak) else "c4"
+    sharded_fov = a.config in PATCHES                         # one FOV cut into patches that are sharded over the ranks (strong scaling)
+    if sharded_fov and a.weak:
+        raise SystemExit("--weak grows the FOV of a one-patch configuration; %s is a patched FOV" % a.config)
+    if world > 1 and not sharded_fov and not a.weak:
+        raise SystemExit("--gpus %d needs a patched configuration (c4) or --weak" % world)
     d1, d2p, T, Kp, r, seed = CONFIGS[a.config]
-    d2, K = d2p * world, Kp * world
+    d2, K = (d2p, Kp) if sharded_fov else (d2p * world, Kp * world)
     f = synth.make_factors(d1, d2, T, K, seed)
     eng = Engine(local)
-    video = PatchedVideo(d1, d2, T, [d1, d2p], r, eng, rank=rank, world_size=world)
+    video = PatchedVideo(d1, d2, T, PATCHES[a.config] if sharded_fov else [d1, d2p], r, eng, rank=rank, world_size=world)
     for idx in video.owned:                                   # synthesise each owned block directly in HBM
         Yb = synth.make_video_device(f, "cuda:%d" % local, pixels=video.block_pix[idx])
         torch.cuda.synchronize()
@@ -124,6 +139,27 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    if a.demo_sequence:
+        # demo_large_data_1p.m:142-211 on this path: background; spatial (update_sn); temporal x2; spatial_algorithm = 'nnls'; background;
+        # spatial; temporal; and the K-changed branch (:205-209) spatial; temporal  --  2 background + 3 spatial + 4 temporal updates
+        fence()
+        t0 = time.perf_counter()
+        s.update_background_parallel(); s.update_spatial_parallel(update_sn=True)
+        s.update_temporal_parallel(); s.update_temporal_parallel()
+        s.options.spatial_algorithm = "nnls"
+        i2 = s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+        s.update_spatial_parallel(); s.update_temporal_parallel()
+        fence()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            tab = eng.profile_table()
+            print(json.dumps({"metric": "cnmfe_demo_sequence_seconds", "value": dt, "unit": "s per recording", "n_gpus": world, "higher_is_better": False,
+                              "config": {"workload": "%s: %dx%dx%d, K=%d, %d patches" % (a.config, d1, d2, T, K, len(video.order)),
+                                         "sequence": "bg, spatial(update_sn), temporal, temporal, [nnls] bg, spatial, temporal, spatial, temporal (demo_large_data_1p.m:142-211), fresh upload"},
+                              "second_fit": {k: int(v) if not isinstance(v, bool) else v for k, v in (i2.get(video.owned[0]) or {}).items()},
+                              "kernels_ms_total": {k: round(v["total_ms"], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["total_ms"]) if v["total_ms"] > 0.05}}))
+        eng.close()
+        return
     fence()
     tw0 = time.perf_counter()
     for _ in range(a.warmup):
@@ -146,7 +182,7 @@ def main():
     if rank != 0:
         return
     n_patches = video.nr_patch * video.nc_patch
-    value = n_patches * a.steps / dt
+    value = (n_patches if a.weak else 1) * a.steps / dt          # whole-FOV iterations/s (weak mode: patch-iterations/s, every patch a full 512 x 512 FOV)
     tab = eng.profile_table()
     kern = {k: {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / a.steps,
                 "ms_per_step": v["total_ms"] / a.steps} for k, v in tab.items() if v["calls"]}
@@ -154,13 +190,13 @@ def main():
     # ---- roofline of the dominant kernel; algorithmic work per launch from SURVEY.md section 8(d) ----
     P = {idx: video.patch_pix[idx].size for idx in video.owned}
     B = {idx: video.block_pix[idx].size for idx in video.owned}
-    idx0 = video.owned[0]
-    d, d_b, p = P[idx0], B[idx0], 96 if r == 15 else None
+    # per LAUNCH: a kernel runs once per owned patch, ms_per_call averages over them -- so do the algorithmic bytes / flops
+    d, d_b, p = sum(P.values()) / float(len(P)), sum(B.values()) / float(len(B)), 96 if r == 15 else None
     roof = None
     def r1_roof():
         if "residual_r1" not in kern or a.bg_ssub != 1:         # bg_ssub > 1: the sweep runs on the low-resolution patch, a different kernel mix
             return None
-        bytes_r1 = 4.0 * d_b * T + 4.0 * d * T + 8.0 * d * p + 4.0 * Kp * T       # read Y + write Ysig + W + C
+        bytes_r1 = 4.0 * d_b * T + 4.0 * d * T + 8.0 * d * p + 4.0 * (Kp if not sharded_fov else Kp * d_b / float(d1 * d2)) * T       # read Y + write Ysig + W + C
         ms = kern["residual_r1"]["ms_per_call"]
         return {"bound": "hbm", "achieved": bytes_r1 / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_r1 / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "residual_r1", "ms_per_launch": ms,
@@ -192,6 +228,21 @@ def main():
                 return None
             tot += mult * 1024.0 * sum(float(r_["value_per_launch_KiB"]) for r_ in rows) / len(rows)
         return tot
+    def solve_roof():
+        # per active pixel: gather the (p+1)x(p+1) Gram + RHS from the table, ridge, Cholesky, two triangular solves -- all fp64
+        if "bg_ring_solve" not in kern:
+            return None
+        n = (p or 96) + 1
+        infos = [i_ for i_ in (last.get("bg") or {}).values()]
+        n_act = (sum(int(i_.get("n_active", 0)) for i_ in infos) / float(max(1, len(infos)))) or d      # per launch = per fitted patch
+        ms = kern["bg_ring_solve"]["ms_per_call"]
+        fl = n_act * 2.0 * (n ** 3 / 3.0 + 2.0 * n * n)
+        return {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / F64_MFMA_PEAK_TF, "traffic": None,
+                "kernel": "bg_ring_solve", "ms_per_launch": ms, "algorithmic_flops_per_launch": fl,
+                "note": "fp64 Cholesky + substitutions of %d independent %dx%d systems per launch (one per active pixel: 2(n^3/3 + 2n^2) flops each), priced against "
+                        "the fp64 peak (78.6 TFLOP/s, matrix and vector pipes alike).  One wave per pixel, the matrix in MFMA accumulator tiles "
+                        "(v_mfma_f64_16x16x4); the 16x16 diagonal steps, the table gather and the substitutions run on the vector pipe and bound the kernel -- DESIGN.md section 3"
+                        % (int(n_act), n, n)}
     if dom.startswith("bg_gram"):
         roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else (BF16_MFMA_PEAK_TF if "bf16" in dom else F32_MFMA_PEAK_TF))
         if "bf16" in dom:
@@ -207,16 +258,7 @@ def main():
         roof = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
                 "kernel": dom, "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     elif dom == "bg_ring_solve":
-        # per active pixel: assemble the (p+1)x(p+1) Gram + RHS from the table, ridge, Cholesky, two triangular solves -- all fp64
-        n = (p or 96) + 1
-        n_act = sum(int(i_.get("n_active", 0)) for i_ in (last.get("bg") or {}).values()) or d
-        ms = kern[dom]["ms_per_call"]
-        fl = n_act * 2.0 * (n ** 3 / 3.0 + 2.0 * n * n)
-        roof = {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / F64_MFMA_PEAK_TF, "traffic": None,
-                "kernel": dom, "ms_per_launch": ms, "algorithmic_flops_per_launch": fl,
-                "note": "fp64 Cholesky of %d independent %dx%d systems (one per active pixel), priced against the fp64 peak of the chip (78.6 TFLOP/s, matrix "
-                        "and vector pipes alike); the kernel runs the panel on the vector pipe out of LDS and is bound by the serial pivot chain and "
-                        "LDS read-modify-write of the packed triangle, not by arithmetic -- DESIGN.md section 3" % (n_act, n, n)}
+        roof = solve_roof()
     else:
         roof = {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": dom,
                 "ms_per_launch": kern[dom]["ms_per_call"]}
@@ -237,19 +279,24 @@ def main():
                "traffic": pmc_traffic("k_residual_delta"), "kernel": "residual_delta", "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     out = {
         "metric": "cnmfe_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak" if a.weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
-                               "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub),
+        "config": {"workload": ("%s: %dx%dx%d fp32 video, K=%d, ring_radius=%d, %dx%d patches of distribute_data.m (%d resident blocks per GPU), "
+                                "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2, T, K, r, video.nr_patch, video.nc_patch, len(video.owned), a.alg, "true" if a.deconv else "false", a.bg_ssub))
+                               if not a.weak else
+                               ("%s (weak): %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
+                                "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub)),
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
-                   "parallelism": "patch-parallel x%d" % world},
+                   "parallelism": "patches round-robin over %d rank(s)" % world},
         "roofline": roof,
         "roofline_r1": r1r,
+        "roofline_solve": solve_roof(),
         "roofline_r1_delta": dlr,
         "first_iteration": {"ms": warm_ms if a.warmup else None,
                             "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},
                             "note": "the first background fit of a patch also builds the block-pair covariance table of the video on the fp64 matrix pipe (kept until the "
                                     "video or the frame stride changes); it falls into the warm-up step(s), `--warmup 0` puts it inside the timed region"},
+        "kernel_sum_ms_per_step": round(sum(v["ms_per_step"] for v in kern.values()), 3),
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "kernel_calls_per_step": {k: round(v["calls_per_step"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] > 0.5},
     }

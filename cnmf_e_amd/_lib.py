@@ -86,6 +86,11 @@ PROTOTYPES = {
                                              C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p, f32p, f32p]),
     "cnmfe_deconv_temporal": (C.c_int, [c_ctx, C.c_int32, C.c_int64, f32p, C.c_int, C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p]),
     "cnmfe_post_process_spatial": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, f32p, u8p]),
+    "cnmfe_stitch_begin": (C.c_int, [c_ctx, C.c_int32, C.c_int64]),
+    "cnmfe_stitch_add": (C.c_int, [c_ctx, C.c_int32, i32p]),
+    "cnmfe_stitch_buffer": (C.c_int, [c_ctx, C.POINTER(f32p), i64p]),
+    "cnmfe_stitch_finish": (C.c_int, [c_ctx, C.c_int, f32p, C.c_int]),
+    "cnmfe_stitch_temporal": (C.c_int, [C.POINTER(c_ctx), C.c_int, C.c_int, f32p, C.c_int]),
     "cnmfe_profile_enable": (C.c_int, [c_ctx, C.c_int]),
     "cnmfe_profile_reset": (C.c_int, [c_ctx]),
     "cnmfe_profile_count": (C.c_int, [c_ctx]),

@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <dlfcn.h>
 
 namespace cnmfe {
 thread_local char g_err[1024] = "";
@@ -203,6 +204,63 @@ int ctx_check_errflag(cnmfe_ctx *ctx) {
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
 }
 
+// ---- T5: stitch accumulator (update_temporal_parallel.m:264-280) ------------------------------------------------------------------
+// acc[row][t] += aa_m(j) * C_raw_m(j, t), row = ind_m[j]; the weight sum lives in column ld - 4 of the same row
+__global__ void __launch_bounds__(256) k_stitch_add(const float *__restrict__ craw, int64_t ldc, const float *__restrict__ aa, const int *__restrict__ ind,
+                                                    float *__restrict__ acc, int64_t ld, int64_t T) {
+    const int j = blockIdx.y;
+    const float w = aa[j];
+    float *row = acc + (int64_t)ind[j] * ld;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < T) row[t] += w * craw[(int64_t)j * ldc + t];
+    if (t == 0) row[ld - 4] += w;
+}
+// one workgroup per row: C_raw(k,:) = acc(k,:) / max(aa, (aa == 0)) (:279-280), minus its minimum if asked (:285); written to the bound trace matrix
+__global__ void __launch_bounds__(256) k_stitch_finish(const float *__restrict__ acc, int64_t ld, int64_t T, int subtract_min, float *__restrict__ out, int64_t ldc) {
+    const int k = blockIdx.x;
+    const float *row = acc + (int64_t)k * ld;
+    float w = row[ld - 4];
+    if (w == 0.f) w = 1.f;
+    float mn = INFINITY;
+    for (int64_t t = threadIdx.x; t < T; t += 256) mn = fminf(mn, row[t] / w);
+    __shared__ float red[256];
+    red[threadIdx.x] = mn; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    const float sub = subtract_min ? red[0] : 0.f;
+    for (int64_t t = threadIdx.x; t < ldc; t += 256) out[(int64_t)k * ldc + t] = t < T ? row[t] / w - sub : 0.f;
+}
+
+// RCCL, resolved at first use (single-process multi-GPU stitch only): the library is optional for single-GPU hosts
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr; int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int load() {
+        if (h) return 0;
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return fail(CNMFE_EUNSUPPORTED, "cnmfe_stitch_temporal over several GPUs needs RCCL (librccl.so not found: %s)", dlerror());
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll"); AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy"); GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!CommInitAll || !AllReduce || !GroupStart || !GroupEnd || !CommDestroy) { h = nullptr; return fail(CNMFE_EUNSUPPORTED, "librccl.so lacks the ncclCommInitAll / ncclAllReduce / ncclGroup* symbols"); }
+        return 0;
+    }
+};
+static Rccl g_rccl;
+static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order) {
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
+    const int32_t K = ctx->stitch_K; const int64_t T = ctx->stitch_T, ldc = (T + 3) & ~int64_t(3);
+    CK(hipSetDevice(ctx->device));
+    RET(ctx->bound.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
+    if (K > 0) LAUNCH(ctx, "stitch_finish", k_stitch_finish, dim3((unsigned)K), dim3(256), 0, ctx->stitch.as<float>(), ctx->stitch_ld, T, subtract_min, ctx->bound.as<float>(), ldc);
+    ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = (c_order == CNMFE_COLMAJOR) ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR; ctx->bound_valid = K > 0;
+    ctx->stitch_open = false;
+    if (C_raw_out) RET(download_traces(ctx, ctx->bound.as<float>(), ldc, C_raw_out, K, T, c_order == CNMFE_COLMAJOR ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR));
+    return 0;
+}
+
 // ring offsets: get_nhood.m:1-25, then sorted by (dc, dr) == MATLAB sparse column order
 static void ring_offsets(int radius, int k, std::vector<int32_t> &dr, std::vector<int32_t> &dc) {
     dr.clear(); dc.clear();
@@ -234,6 +292,7 @@ static void ring_offsets(int radius, int k, std::vector<int32_t> &dr, std::vecto
 using namespace cnmfe;
 
 cnmfe_ctx::~cnmfe_ctx() {
+    if (rccl_comm && g_rccl.CommDestroy) { (void)hipSetDevice(device); g_rccl.CommDestroy(rccl_comm); rccl_comm = nullptr; }
     for (auto &kv : patches) delete kv.second;
     prof.drain();
     if (stream) (void)hipStreamDestroy(stream);
@@ -610,7 +669,7 @@ int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *
     RET(residual_materialize(ctx, P));                       // a pending footprint term must be in Ysig for this consumer
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
-    if ((!A_val && A_colptr[K] > 0) || !C_raw_out) return fail(CNMFE_EINVAL, "null A_val / C_raw_out");
+    if (!A_val && A_colptr[K] > 0) return fail(CNMFE_EINVAL, "null A_val");
     CK(hipSetDevice(ctx->device));
     return fast_temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, c_order, C_raw_out, aa_out);
 }
@@ -642,6 +701,89 @@ int cnmfe_reconstruct_background(cnmfe_ctx *ctx, int patch_id, const float *b0_b
     if (frame0 < 0 || nframes <= 0 || frame0 + nframes > P->T || nframes > 65535) return fail(CNMFE_EINVAL, "frames [%lld, %lld) outside [0, %lld) or more than 65535 at once", (long long)frame0, (long long)(frame0 + nframes), (long long)P->T);
     CK(hipSetDevice(ctx->device));
     return bg_reconstruct_run(ctx, P, b0_block, b0_new, frame0, nframes, Ybg_out, out_memspace);
+}
+
+int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (K < 0 || T <= 0) return fail(CNMFE_EINVAL, "bad K / T");
+    CK(hipSetDevice(ctx->device));
+    const int64_t ld = ((T + 3) & ~int64_t(3)) + 4;
+    RET(ctx->stitch.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float)));
+    CK(hipMemsetAsync(ctx->stitch.p, 0, (size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float), ctx->stream));
+    ctx->stitch_K = K; ctx->stitch_T = T; ctx->stitch_ld = ld; ctx->stitch_open = true;
+    return 0;
+}
+
+int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
+    if (K_m == 0) return 0;
+    if (K_m < 0 || !ind_m) return fail(CNMFE_EINVAL, "bad K_m / null ind_m");
+    if (!ctx->last_t_valid || ctx->last_t_K != K_m || ctx->last_t_T != ctx->stitch_T)
+        return fail(CNMFE_ESTATE, "no temporal result of %d rows x %lld frames on the device (the last cnmfe_hals_temporal / cnmfe_fast_temporal call)", K_m, (long long)ctx->stitch_T);
+    std::vector<char> seen((size_t)ctx->stitch_K, 0);
+    for (int32_t j = 0; j < K_m; ++j) {
+        if (ind_m[j] < 0 || ind_m[j] >= ctx->stitch_K) return fail(CNMFE_EINVAL, "row %d outside the %d-row accumulator", ind_m[j], ctx->stitch_K);
+        if (seen[ind_m[j]]) return fail(CNMFE_EINVAL, "row %d listed twice", ind_m[j]);
+        seen[ind_m[j]] = 1;
+    }
+    CK(hipSetDevice(ctx->device));
+    RET(to_dev(ctx, ctx->scr[23], ind_m, (size_t)K_m));
+    LAUNCH(ctx, "stitch_add", k_stitch_add, dim3((unsigned)((ctx->stitch_T + 255) / 256), (unsigned)K_m), dim3(256), 0, ctx->last_craw.as<float>(), ctx->last_t_ldc,
+           ctx->last_aa.as<float>(), ctx->scr[23].as<int>(), ctx->stitch.as<float>(), ctx->stitch_ld, ctx->stitch_T);
+    CK(hipStreamSynchronize(ctx->stream));                 // ind_m is the caller's
+    ctx->last_t_valid = false;
+    return 0;
+}
+
+int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld) {
+    if (!ctx || !dev_acc || !ld) return fail(CNMFE_EINVAL, "null argument");
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
+    CK(hipSetDevice(ctx->device));
+    CK(hipStreamSynchronize(ctx->stream));                 // the caller's collective runs on ITS stream: everything added so far must have landed
+    *dev_acc = ctx->stitch.as<float>(); *ld = ctx->stitch_ld;
+    return 0;
+}
+
+int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    return stitch_finish_one(ctx, subtract_min, C_raw_out, c_order);
+}
+
+int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order) {
+    if (!ctxs || n <= 0) return fail(CNMFE_EINVAL, "no contexts");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->stitch_open) return fail(CNMFE_ESTATE, "context %d: cnmfe_stitch_begin has not been called", i);
+        if (ctxs[i]->stitch_K != ctxs[0]->stitch_K || ctxs[i]->stitch_T != ctxs[0]->stitch_T) return fail(CNMFE_EINVAL, "context %d accumulates a different K x T", i);
+        for (int j = 0; j < i; ++j) if (ctxs[j]->device == ctxs[i]->device) return fail(CNMFE_EINVAL, "contexts %d and %d share GPU %d (one context per GPU)", j, i, ctxs[i]->device);
+    }
+    // n == 1 still goes through RCCL when the communicator exists or CNMFE_STITCH_RCCL=1 asks for it (a 1-GPU box exercising the multi-GPU path)
+    const char *force = getenv("CNMFE_STITCH_RCCL");
+    if (n > 1 || (force && force[0] == '1')) {
+        RET(g_rccl.load());
+        bool have = true;
+        for (int i = 0; i < n; ++i) have = have && ctxs[i]->rccl_comm && ctxs[i]->rccl_n == n && ctxs[i]->rccl_rank == i;
+        if (!have) {
+            std::vector<int> devs(n); std::vector<void *> comms(n, nullptr);
+            for (int i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; if (ctxs[i]->rccl_comm) { g_rccl.CommDestroy(ctxs[i]->rccl_comm); ctxs[i]->rccl_comm = nullptr; } }
+            const int rc = g_rccl.CommInitAll(comms.data(), n, devs.data());
+            if (rc != 0) return fail(CNMFE_EHIP, "ncclCommInitAll over %d GPU(s) failed: %s", n, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+            for (int i = 0; i < n; ++i) { ctxs[i]->rccl_comm = comms[i]; ctxs[i]->rccl_n = n; ctxs[i]->rccl_rank = i; }
+        }
+        const size_t count = (size_t)ctxs[0]->stitch_K * (size_t)ctxs[0]->stitch_ld;
+        if (count) {
+            int rc = g_rccl.GroupStart();
+            for (int i = 0; i < n && rc == 0; ++i) {
+                CK(hipSetDevice(ctxs[i]->device));
+                rc = g_rccl.AllReduce(ctxs[i]->stitch.p, ctxs[i]->stitch.p, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, ctxs[i]->rccl_comm, ctxs[i]->stream);
+            }
+            const int rc2 = g_rccl.GroupEnd();
+            if (rc != 0 || rc2 != 0) return fail(CNMFE_EHIP, "ncclAllReduce of the stitch accumulator failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "?");
+        }
+    }
+    for (int i = 0; i < n; ++i) RET(stitch_finish_one(ctxs[i], subtract_min, i == 0 ? C_raw_out : nullptr, c_order));
+    for (int i = 0; i < n; ++i) { CK(hipSetDevice(ctxs[i]->device)); CK(hipStreamSynchronize(ctxs[i]->stream)); }
+    return 0;
 }
 
 int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int c_order) {

@@ -137,6 +137,9 @@ struct Patch {
     int base_kstride = 0;
 };
 
+// device scratch of the OASIS kernels (deconv.hip): pool / task tables, grown on demand and kept with the context
+struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf; };
+
 }  // namespace cnmfe
 
 struct cnmfe_ctx {
@@ -156,6 +159,18 @@ struct cnmfe_ctx {
     cnmfe::DevBuf tmp[16];    // small scratch
     cnmfe::DevBuf inc[7];     // incremental ring regression: block footprint lists, U~, trace sums
     cnmfe::DevBuf stage;      // upload staging
+    // per-call device scratch of the factor updates (factor.hip, deconv.hip): grown on demand, NEVER freed between calls -- a hipMalloc /
+    // hipFree pair per buffer and call cost more than the small kernels they serve, and hipFree drains the device
+    cnmfe::DevBuf scr[24];
+    cnmfe::DeconvScratch dscr;
+    // the traces the last cnmfe_hals_temporal[_deconv] / cnmfe_fast_temporal left on the device (C_raw rows, row stride last_t_ldc, and aa): what
+    // cnmfe_stitch_add folds into the stitch accumulator without a host round trip
+    cnmfe::DevBuf last_craw, last_aa;
+    int32_t last_t_K = 0; int64_t last_t_ldc = 0, last_t_T = 0; bool last_t_valid = false;
+    // overlap-region stitch of update_temporal_parallel.m:264-280: acc[k][0..T) = sum_m aa_m(k) C_raw_m(k,:), acc[k][ld-1..] ... see cnmfe_stitch_begin
+    cnmfe::DevBuf stitch;     // K rows of stitch_ld floats: [0, T) the weighted sum, column stitch_ld - 4 the sum of the weights
+    int32_t stitch_K = 0; int64_t stitch_T = 0, stitch_ld = 0; bool stitch_open = false;
+    void *rccl_comm = nullptr; int rccl_rank = 0, rccl_n = 0;          // single-process multi-GPU stitch (cnmfe_stitch_temporal)
     cnmfe::DevBuf errflag;    // one int, set by kernels that meet a state the host-side set-up should have excluded (checked at the next sync)
     std::map<std::string, int64_t> opts;
     int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }

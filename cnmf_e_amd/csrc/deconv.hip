@@ -746,7 +746,6 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
-struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf; };
 
 int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg &c, size_t &shmem) {
     if (!o) return fail(CNMFE_EINVAL, "null deconvolution options");
@@ -801,7 +800,7 @@ int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64
                            const int *dNptr, const int *dNidx, const float *dNval, const float *dAa, float *dPars, float *dSn) {
     DeconvCfg c; size_t shmem;
     RET(deconv_setup(dopts, T, 1, c, shmem));
-    DeconvScratch scr; DevBuf dB;
+    DeconvScratch &scr = ctx->dscr; DevBuf &dB = ctx->scr[20];
     RET(dB.ensure((size_t)K * sizeof(float)));
     DeconvIO io;
     io.C = dC; io.Craw = dCraw; io.S = dS; io.ldc = ldc; io.U = dU; io.nptr = dNptr; io.nidx = dNidx; io.nval = dNval; io.aa = dAa;
@@ -819,7 +818,8 @@ int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_ord
                    float *C_out, float *S_out, float *pars_out, float *sn_out) {
     DeconvCfg c; size_t shmem;
     RET(deconv_setup(opts, T, 0, c, shmem));
-    DevBuf dCraw, dC, dS, dPars, dSn, dB, dList; DeconvScratch scr;
+    DevBuf *S_ = ctx->scr;
+    DevBuf &dCraw = S_[0], &dC = S_[1], &dS = S_[2], &dPars = S_[3], &dSn = S_[4], &dB = S_[20], &dList = S_[5]; DeconvScratch &scr = ctx->dscr;
     int64_t ldc;
     RET(upload_traces(ctx, dCraw, C_raw, K, T, c_order, &ldc));
     RET(dC.ensure((size_t)K * ldc * sizeof(float))); RET(dS.ensure((size_t)K * ldc * sizeof(float)));

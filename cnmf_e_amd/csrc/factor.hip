@@ -347,7 +347,8 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     if (nnz == 0) return 0;
     if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(IND) too large");
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2];
-    DevBuf dColptr, dErow, dEcol, dRptr, dRcol, dRsrc, dAval, dU, dPart, dV, dPairs, dSn, dLvl;
+    DevBuf *S_ = ctx->scr;
+    DevBuf &dColptr = S_[0], &dErow = S_[1], &dEcol = S_[2], &dRptr = S_[3], &dRcol = S_[4], &dRsrc = S_[5], &dAval = S_[6], &dU = S_[7], &dPart = S_[8], &dV = S_[9], &dPairs = S_[10], &dSn = S_[11], &dLvl = S_[12];
     int64_t ldc;
     RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
     RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
@@ -442,7 +443,8 @@ int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colp
         }
         aa[k] = (float)s; inv[k] = s > 0.0 ? (float)(1.0 / s) : 0.f;
     }
-    DevBuf dColptr, dErow, dAval, dU, dInv;
+    DevBuf *S_ = ctx->scr;
+    DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dU = ctx->last_craw, &dInv = S_[13];
     const int64_t ldc = (T + 3) & ~int64_t(3);
     RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
     RET(to_dev(ctx, dErow, A_rowidx, (size_t)nnz));
@@ -457,6 +459,8 @@ int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colp
         LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
     LAUNCH(ctx, "temporal_scale_rows", k_scale_rows, dim3((unsigned)((T + 255) / 256), (unsigned)K), dim3(256), 0, dU.as<float>(), ldc, T, dInv.as<float>());
+    RET(to_dev(ctx, ctx->last_aa, aa.data(), (size_t)K));
+    ctx->last_t_K = K; ctx->last_t_ldc = ldc; ctx->last_t_T = T; ctx->last_t_valid = true;      // for cnmfe_stitch_add
     RET(download_traces(ctx, dU.as<float>(), ldc, C_raw_out, K, T, c_order));
     if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));
     return 0;
@@ -468,7 +472,9 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     const int64_t T = P->T, d = P->d, nnz = A_colptr[K];
     if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(A) too large");
     DevBuf &dC = ctx->tmp[0];
-    DevBuf dColptr, dErow, dAval, dU, dCraw, dNk, dNidx, dNval, dNptr, dAa, dLvl, dOvf;
+    DevBuf *S_ = ctx->scr;
+    DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dU = S_[7], &dCraw = ctx->last_craw, &dNk = S_[14], &dNidx = S_[15], &dNval = S_[16], &dNptr = S_[17], &dAa = ctx->last_aa, &dLvl = S_[12], &dOvf = S_[18];
+    ctx->last_t_valid = false;
     int64_t ldc;
     RET(upload_traces(ctx, dC, C_in, K, T, c_order, &ldc));
     RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
@@ -542,7 +548,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
                 LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
                        dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dU.as<float>(), dC.as<float>(), dCraw.as<float>(), ldc, T);
     } else {
-        DevBuf dS, dPars, dSn;
+        DevBuf &dS = S_[19], &dPars = S_[21], &dSn = S_[22];
         RET(dS.ensure((size_t)K * ldc * sizeof(float)));
         CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));                 // S = zeros(K,T)  (:55)
         RET(to_dev(ctx, dPars, kernel_pars, (size_t)K));
@@ -555,10 +561,11 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
     }
+    ctx->last_t_K = K; ctx->last_t_ldc = ldc; ctx->last_t_T = T; ctx->last_t_valid = true;      // C_raw rows + aa stay on the device for cnmfe_stitch_add
     RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));
     RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw_out, K, T, c_order));
     if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));
-    CK(hipStreamSynchronize(ctx->stream));
+    if (C_out || C_raw_out) CK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -579,7 +586,8 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
             return fail(CNMFE_EUNSUPPORTED, "footprint %d spans %dx%d pixels; post-processing supports %dx%d", k, h - 4, w - 4, PP_MAX - 4, PP_MAX - 4);
         box[k] = make_int4(rmin - 2, cmin - 2, h, w);
     }
-    DevBuf dColptr, dErow, dAval, dBox, dKeep;
+    DevBuf *S_ = ctx->scr;
+    DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dBox = S_[13], &dKeep = S_[14];
     RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
     RET(to_dev(ctx, dErow, A_rowidx, (size_t)nnz));
     RET(to_dev(ctx, dAval, A_val, (size_t)nnz));

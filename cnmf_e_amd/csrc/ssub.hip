@@ -388,10 +388,13 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     const bool reuse = M->ysig_valid && M->res_kind == 2 && M->ysig.p && ctx->opt("r1_delta", 1) != 0;
     RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, reuse ? 1 : 0));
     const int64_t ldc_t = ctx->last_ldc;
-    DevBuf tCc;                                               // the centred traces of this call (tmp[1] is about to hold tap weights)
+    // the centred traces of this call move to the patch (pendCc / resCc) and the buffer the patch held before comes back as tmp[1]: a swap
+    // both ways, no hipMalloc / hipFree per call (the guard hands the leftover buffer back on every exit path)
+    struct GiveBack { DevBuf b; DevBuf &home; ~GiveBack() { if (b.p && !home.p) b.swap(home); } } gb{DevBuf(), ctx->tmp[1]};
+    DevBuf &tCc = gb.b;
     if (has_a) tCc.swap(ctx->tmp[1]);
     Taps tr = make_taps(d1s, M->nr_b, (double)M->nr_b / d1s, false), tc = make_taps(d2s, M->nc_b, (double)M->nc_b / d2s, false);
-    DevBuf &dIr = ctx->tmp[0], &dWr = ctx->tmp[1], &dIc = ctx->tmp[2], &dWc = ctx->tmp[3], &dDlt = ctx->tmp[7];
+    DevBuf &dIr = ctx->tmp[0], &dWr = ctx->scr[21], &dIc = ctx->tmp[2], &dWc = ctx->tmp[3], &dDlt = ctx->tmp[7];
     RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
     RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
     // the footprint term of this call at full resolution: into the pending (reuse) or the applied slot of the main patch

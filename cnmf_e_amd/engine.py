@@ -273,24 +273,26 @@ class Engine:
                                            _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), _p(out, L.f32p)))
         return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
 
-    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True):
+    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True, want_raw=True):
         """[C, C_raw] = HALS_temporal(Ysig, A, C, maxIter); want_C=False skips the download of C (the caller of
-        update_temporal_parallel.m:180 only keeps C_raw)."""
+        update_temporal_parallel.m:180 only keeps C_raw), want_raw=False that of C_raw too: it stays on the device for stitch_add."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_patch, info["d"])
         T = info["T"]
         cptr, cord, _keep = self._targs(C_patch, K, T)
         Cout = np.empty((K, T), dtype=np.float32) if want_C else None
-        Craw = np.empty((K, T), dtype=np.float32); aa = np.empty(K, dtype=np.float32)
+        Craw = np.empty((K, T), dtype=np.float32) if want_raw else None
+        aa = np.empty(K, dtype=np.float32)
         L.check(L.lib.cnmfe_hals_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                           int(maxIter), _p(Cout, L.f32p), _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Cout, Craw, aa
 
-    def fast_temporal(self, pid, A_patch):
+    def fast_temporal(self, pid, A_patch, want_raw=True):
         """[aa, C_raw] = fast_temporal(Ysig, A) (update_temporal_parallel.m:314-337); returns (C_raw, aa)"""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_patch, info["d"])
-        Craw = np.empty((K, info["T"]), dtype=np.float32); aa = np.empty(K, dtype=np.float32)
+        Craw = np.empty((K, info["T"]), dtype=np.float32) if want_raw else None
+        aa = np.empty(K, dtype=np.float32)
         L.check(L.lib.cnmfe_fast_temporal(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), L.ROWMAJOR,
                                           _p(Craw, L.f32p), _p(aa, L.f32p)))
         return Craw, aa
@@ -326,6 +328,46 @@ class Engine:
         return L.DeconvOpts(1, 1, float(o["smin"]), float(o.get("lambda", 0.0)), float(o["max_tau"]),
                             int(bool(o["optimize_b"])), int(bool(o["optimize_pars"])), int(o.get("maxIter", maxIter)))
 
+    # ---- the overlap-region stitch on the device (update_temporal_parallel.m:264-286; cnmfe_stitch_* in include/cnmfe.h) ----
+    def stitch_begin(self, K, T):
+        L.check(L.lib.cnmfe_stitch_begin(self._ctx, int(K), int(T)))
+        self._stitch_shape = (int(K), int(T))
+
+    def stitch_add(self, ind):
+        """rows `ind` of the accumulator += aa .* C_raw of the temporal call just made (its result is still on the device)"""
+        ind = np.ascontiguousarray(ind, dtype=np.int32)
+        L.check(L.lib.cnmfe_stitch_add(self._ctx, ind.size, _p(ind, L.i32p)))
+
+    def stitch_allreduce(self, group):
+        """one process per GPU: the all-reduce of the accumulators over the torch.distributed group, in place on the device buffer
+        (nccl == RCCL over xGMI).  gloo (CPU test hook with every rank on one device) goes through a host copy."""
+        import torch
+        import torch.distributed as td
+        ptr = L.f32p(); ld = C.c_int64()
+        L.check(L.lib.cnmfe_stitch_buffer(self._ctx, C.byref(ptr), C.byref(ld)))
+        K, _ = self._stitch_shape
+        n = K * ld.value
+        if n == 0:
+            return
+
+        class _View:                                                    # zero-copy torch view of the engine's accumulator
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (C.cast(ptr, C.c_void_p).value, False), "version": 2}
+        t = torch.as_tensor(_View(), device="cuda")
+        if td.get_backend(group) == "nccl":
+            td.all_reduce(t, group=group)
+        else:
+            h = t.cpu(); td.all_reduce(h, group=group); t.copy_(h)
+        torch.cuda.current_stream().synchronize()                       # the engine continues on its own stream
+
+    def stitch_finish(self, subtract_min, want=True):
+        """C_raw = acc ./ aa (aa == 0 -> 1), minus the row minima without deconvolution (:279-286); the result becomes the engine's bound
+        trace matrix, and the returned host copy its identity: passing THAT array to later calls costs no upload"""
+        K, T = self._stitch_shape
+        out = np.empty((K, T), dtype=np.float32) if want else None
+        L.check(L.lib.cnmfe_stitch_finish(self._ctx, int(bool(subtract_min)), _p(out, L.f32p), L.ROWMAJOR))
+        self._bound = out if (want and K > 0) else None
+        return out
+
     def hals_temporal_deconv(self, pid, A_patch, C_patch, maxIter, deconv_options, kernel_pars=None, want_all=True):
         """[C, C_raw, results_deconv] = HALS_temporal(Y, A, C, maxIter, deconv_options): returns
         (C, C_raw, S, sn, kernel_pars, aa).  want_all=False skips the download of C and S (update_temporal_parallel.m:106-110
@@ -333,7 +375,7 @@ class Engine:
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_patch, info["d"])
         Cm = _traces(C_patch, K, info["T"])
-        Craw = np.empty_like(Cm)
+        Craw = np.empty_like(Cm) if want_all is not None else None      # want_all=None: nothing but aa comes back (C_raw stays on the device for stitch_add)
         Cout = np.empty_like(Cm) if want_all else None
         S = np.empty_like(Cm) if want_all else None
         aa = np.empty(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)

@@ -428,32 +428,6 @@ class Sources2D:
             self._cmean_of = self.C
         return self._cmean_val
 
-    def _stitch_distributed(self, pieces, K, T):
-        """C_raw(k,:) = sum_m aa_m(k) C_raw_m(k,:) / sum_m aa_m(k)  (update_temporal_parallel.m:269-280) with ONE
-        all-reduce of [acc ; aa] over the process group.  The per-patch rows are weighted and scattered on the device
-        the collective runs on, and so are the division and (without deconvolution) the row-minimum subtraction (:285)."""
-        import torch
-        import torch.distributed as td
-        nccl = td.get_backend(self.dist) == "nccl"
-        dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-        buf = torch.zeros((K, T + 1), dtype=torch.float32, device=dev)
-        for ind, C_raw_p, aa_p in pieces:
-            it = torch.from_numpy(np.ascontiguousarray(ind, dtype=np.int64)).to(dev)
-            w = torch.from_numpy(np.ascontiguousarray(aa_p, dtype=np.float32)).to(dev)
-            rows = torch.from_numpy(np.ascontiguousarray(C_raw_p, dtype=np.float32)).to(dev)
-            buf[:, :T].index_add_(0, it, rows * w[:, None])                                          # :274
-            buf[:, T].index_add_(0, it, w)                                                           # :275
-        td.all_reduce(buf, group=self.dist)
-        aa = buf[:, T:T + 1].clone()
-        aa[aa == 0] = 1                                                                               # :279
-        C_raw = buf[:, :T] / aa                                                                       # :280
-        if not self.options.deconv_flag:
-            C_raw = C_raw - C_raw.min(dim=1, keepdim=True).values                                     # :285
-        if nccl and not self.options.deconv_flag and hasattr(self.engine, "bind_traces"):
-            torch.cuda.current_stream().synchronize()                      # the engine reads the tensor on its own stream
-            return DeviceTraces(C_raw)                                     # K x T stays on the device: bound device-to-device, host copy on demand
-        return C_raw.contiguous().cpu().numpy()
-
     def _update_b0_new(self):
         """obj.b0_new = Ymean - A*mean(C,2) (update_spatial_parallel.m:349).  Evaluated on first read from the
         (A, C) of this moment -- both are replaced, never mutated, so holding the references is a snapshot."""
@@ -494,12 +468,15 @@ class Sources2D:
             self.P["kernel_pars"], self.P["neuron_sn"] = kp, sn
             self._bind_C()
             return C
-        C = np.zeros_like(self.C_raw); Craw = np.zeros_like(self.C_raw); S = np.zeros_like(self.C_raw)
-        kp = np.zeros(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
+        # rows k = rank mod world on this rank; ONE collective over the packed [C | C_raw | S | kernel_pars | sn] rows (3T + 2 floats per neuron)
+        T = self.C_raw.shape[1]
+        pack = np.zeros((K, 3 * T + 2), dtype=np.float32)
         if rows.size:
-            C[rows], Craw[rows], S[rows], kp[rows], sn[rows] = self.engine.deconv_temporal(self.C_raw[rows], self.options.deconv_options)
-        if rows.size != K:
-            C, Craw, S, kp, sn = (self._allreduce(x) for x in (C, Craw, S, kp, sn))
+            c_, r_, s_, k_, n_ = self.engine.deconv_temporal(np.asarray(self.C_raw)[rows], self.options.deconv_options)
+            pack[rows, :T], pack[rows, T:2 * T], pack[rows, 2 * T:3 * T], pack[rows, 3 * T], pack[rows, 3 * T + 1] = c_, r_, s_, k_, n_
+        pack = self._allreduce(pack)
+        C, Craw, S = (np.ascontiguousarray(pack[:, i * T:(i + 1) * T]) for i in range(3))
+        kp, sn = pack[:, 3 * T].copy(), pack[:, 3 * T + 1].copy()
         self.C, self.C_raw, self.S = C, Craw, S
         self.P["kernel_pars"], self.P["neuron_sn"] = kp, sn
         self._bind_C()
@@ -625,8 +602,22 @@ class Sources2D:
         self.A_raw = A_
         if o.spatial_constraints.get("circular", False):
             raise NotImplementedError("circular_constraints is off by default and not built")
-        self.A = self.engine.post_process_spatial(A_, v.d1, v.d2) if o.spatial_constraints.get("connected", True) else A_   # :341
+        self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                              # :341
         self._update_b0_new()                                                                        # :347-351
+
+    def _post_process(self, A_):
+        """obj.post_process_spatial() (:341) works on whole footprints, which only exist after the gather; sharded, every rank then takes the
+        columns k = rank mod world and the processed columns are gathered again (disjoint columns: the same all-gather of triplets)"""
+        v = self.video
+        if self.dist is None or (v.world_size == 1 and not self.force_collectives):
+            return self.engine.post_process_spatial(A_, v.d1, v.d2)
+        K = A_.shape[1]
+        mine = np.arange(v.rank, K, v.world_size)
+        sub = self.engine.post_process_spatial(A_[:, mine], v.d1, v.d2).tocoo() if mine.size else sp.coo_matrix((A_.shape[0], 0), dtype=np.float32)
+        part = sp.csc_matrix((sub.data, (sub.row, mine[sub.col])), shape=A_.shape) if mine.size else sp.csc_matrix(A_.shape, dtype=np.float32)
+        out = self._gather_sparse(part)
+        out.sort_indices()
+        return out
 
     def _prefetch_search_location(self):
         """The search mask of the NEXT spatial update depends on A only, which the background update leaves alone: build it
@@ -754,16 +745,16 @@ class Sources2D:
 
     # -- temporal -----------------------------------------------------------------------
     def update_temporal_parallel(self, use_parallel=True, use_c_hat=True):
-        """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295."""
+        """@Sources2D/update_temporal_parallel.m:62-94,112-186,264-295.  The per-patch traces never leave the device: every patch's
+        aa .* C_raw is added to the engine's stitch accumulator (:269-278), sharded runs all-reduce that buffer in place (the
+        overlap-region stitch, ONE collective), and :279-286 run on the device; one K x T copy comes back for obj.C_raw / obj.C."""
         self._need_data()
         v, o = self.video, self.options
+        eng = self.engine
         K, T = self.C.shape
         launched_any = False
-        acc = None                                                         # sum over patches of aa .* C_raw  (:274)
-        aa_tot = np.zeros(K, dtype=np.float64)                             # sum over patches of aa          (:275)
         sharded = self.dist is not None and (v.world_size > 1 or self.force_collectives)
-        pieces = []
-        single = None
+        eng.stitch_begin(K, T)
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
@@ -791,46 +782,19 @@ class Sources2D:
             if not whole:
                 A_pp = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175
-                C_raw_p, aa_p = self.engine.fast_temporal(v.pid[idx], A_pp)
+                eng.fast_temporal(v.pid[idx], A_pp, want_raw=False)
             elif o.deconv_flag:                                                                       # :106-110
-                _, C_raw_p, _, _, _, aa_p = self.engine.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options, want_all=False)
+                eng.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options, want_all=None)
             else:
-                _, C_raw_p, aa_p = self.engine.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False)   # :180-181
-            if sharded:
-                pieces.append((ind, C_raw_p, aa_p))                        # scattered and weighted on the collective's device
-                continue
-            if len(v.owned) == 1 and ind.size == K and use_c_hat:
-                # one patch sees every neuron: aa.*C_raw./aa (:274-280) is C_raw itself, rows with aa = 0 are zero, and (without
-                # deconvolution) HALS_temporal already subtracted each row's minimum (HALS_temporal.m:64-68), so :285 changes nothing
-                C_raw_p[aa_p == 0] = 0
-                single = C_raw_p
-                continue
-            contrib = C_raw_p * aa_p[:, None].astype(np.float32)                                     # :274
-            if acc is None and ind.size == K:
-                acc = contrib                                              # first patch sees every neuron: no scatter-add needed
-            else:
-                if acc is None:
-                    acc = np.zeros((K, T), dtype=np.float32)
-                acc[ind] += contrib
-            aa_tot[ind] += aa_p                                                                      # :275
-        if sharded:                                                        # the overlap-region stitch: ONE all-reduce
-            C_raw = self._stitch_distributed(pieces, K, T)
-        elif single is not None:
-            C_raw = single
-        else:
-            if acc is None:
-                acc = np.zeros((K, T), dtype=np.float32)
-            aa_tot[aa_tot == 0] = 1                                                                   # :279
-            C_raw = acc
-            C_raw /= aa_tot[:, None].astype(np.float32)                                              # :280
+                eng.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False, want_raw=False)  # :180-181
+            eng.stitch_add(ind)                                                                       # :274-275
+        if sharded:                                                        # the overlap-region stitch: ONE all-reduce, in place on the device
+            eng.stitch_allreduce(self.dist)
+        C_raw = eng.stitch_finish(subtract_min=not o.deconv_flag)                                     # :279-280, :285
         if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
-            self.C_raw = np.ascontiguousarray(C_raw, dtype=np.float32)
+            self.C_raw = C_raw
             self.C = self.deconvTemporal()
-            self._bind_C()
         else:
-            if not sharded and single is None:
-                C_raw -= C_raw.min(axis=1, keepdims=True)                                            # :285 (sharded: done on the device)
-            self.C_raw = C_raw if isinstance(C_raw, DeviceTraces) else np.ascontiguousarray(C_raw, dtype=np.float32)
-            self.C = self.C_raw                                                                       # :286
-            self._bind_C()
+            self.C_raw = C_raw
+            self.C = self.C_raw                                                                       # :286 (already the engine's bound matrix)
         self._update_b0_new()                                                                         # :291-295

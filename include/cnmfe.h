@@ -177,14 +177,15 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
 /* ---- fast_temporal (use_c_hat = false)                @Sources2D/update_temporal_parallel.m:174-175,314-337
  *   tmp_A = A .* (A ./ max(A,[],1) >= 0.5);  aa = sum(tmp_A.^2,1);  C_raw = (tmp_A' * Ysig) ./ aa'
  * (rows with aa == 0 are 0 and report aa = 0).  A is d x K CSC over PATCH rows; Ysig = the resident
- * residual of this patch.  C_raw_out K x T, aa_out K floats (may be NULL). */
+ * residual of this patch.  C_raw_out K x T (NULL: keep the result on the device for cnmfe_stitch_add), aa_out K floats (may be NULL). */
 int cnmfe_fast_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
                         const int32_t *A_rowidx, const float *A_val, int c_order,
                         float *C_raw_out, float *aa_out);
 
 /* ---- T1-T3: [C, C_raw, ~, ~] = HALS_temporal(Y, A, C, maxIter, [])   utilities/HALS_temporal.m:1-119
  * (no-deconvolution branch :64-68).  Y = resident Ysig.  A d x K CSC over PATCH rows.
- * Outputs in c_order; aa_out[k] = sum(A(:,k).^2) (update_temporal_parallel.m:181). */
+ * Outputs in c_order (each may be NULL: C_raw and aa also stay on the device for cnmfe_stitch_add); aa_out[k] = sum(A(:,k).^2)
+ * (update_temporal_parallel.m:181). */
 int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
                         const int32_t *A_rowidx, const float *A_val, const float *C_in, int c_order,
                         int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out);
@@ -214,6 +215,27 @@ int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const in
 int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order,
                           const cnmfe_deconv_opts *opts, float *C_out, float *S_out,
                           float *kernel_pars_out, float *sn_out);
+
+/* ---- T5: the overlap-region stitch of the temporal update, on the device
+ * @Sources2D/update_temporal_parallel.m:264-280:
+ *     C_new(ind_m, :) += aa_m .* C_raw_m;  aa(ind_m) += aa_m   over the patches m;   C_raw = C_new ./ aa  (aa == 0 -> 1);
+ *     without deconvolution  C_raw = C_raw - min(C_raw, [], 2),  C = C_raw   (:285-286)
+ * cnmfe_hals_temporal[_deconv] / cnmfe_fast_temporal leave their C_raw rows and aa on the device (their host outputs may be NULL); the
+ * stitch accumulates them there, so the K_m x T pieces never cross PCIe:
+ *   cnmfe_stitch_begin(ctx, K, T)             zero the accumulator: K rows of (T + weight) floats
+ *   cnmfe_stitch_add(ctx, K_m, ind_m)         after each patch's temporal call: rows ind_m (0-based, distinct) += aa_m .* C_raw_m
+ *   cnmfe_stitch_temporal(ctxs, n, ...)       the exchange + :279-286.  n contexts of ONE process (one per GPU, each holding the sum over its own
+ *                                             patches): RCCL all-reduce (sum) of the accumulators over xGMI, in place; every context then
+ *                                             divides, subtracts the row minima if asked, and BINDS the result as its trace matrix
+ *                                             (cnmfe_traces_bind semantics, row-major): the next background / spatial update reads it with
+ *                                             (NULL, CNMFE_BOUND).  C_raw_out (K x T, c_order; may be NULL) receives a host copy from ctxs[0].
+ *   one process PER GPU (torch.distributed, MPI): cnmfe_stitch_buffer hands out the accumulator's device address for the caller's own
+ *   all-reduce (count = K * ld floats), cnmfe_stitch_finish does :279-286 + bind on this context. */
+int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T);
+int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m);
+int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld);
+int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order);
+int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order);
 
 /* ---- objective: [RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, one patch, all frames:
  *   RSS = sum((Y(patch,:) - A(patch,:)*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)

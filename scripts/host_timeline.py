@@ -4,7 +4,7 @@ import argparse, os, sys, time, functools
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)")
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--patch", type=int, default=512, help="patch side (128: the 4 x 4 patches of BASELINE configs[3] on the 512 x 512 FOV)"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -20,8 +20,8 @@ d1, d2, T, K, r, seed = 512, 512 * a.npatch, 10000, 500 * a.npatch, 15, 2
 f = synth.make_factors(d1, d2, T, K, seed)
 Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
 eng = Engine(0)
-video = PatchedVideo(d1, d2, T, [512, 512], r, eng, rank=rank, world_size=world)
-if a.npatch == 1:
+video = PatchedVideo(d1, d2, T, [a.patch, a.patch], r, eng, rank=rank, world_size=world)
+if a.npatch == 1 and a.patch == 512:
     video.upload_block_device((0, 0), Yd.data_ptr())
 else:
     del Yd

@@ -68,6 +68,7 @@ class FakeEngine:
         A = sp.csc_matrix(A_patch).astype(np.float64)
         Cn, Craw, S, sn, kp = oo.HALS_temporal_deconv(self.p[pid]["Ysig"], A, np.asarray(C_patch, dtype=np.float64), maxIter, **self._dopt(deconv_options))
         aa = np.asarray(A.multiply(A).sum(axis=0)).ravel()
+        self._last = (Craw, aa)
         return Cn, Craw, S, sn, np.array([0.0 if g is None else g for g in kp]), aa
 
     def deconv_temporal(self, C_raw, deconv_options, overwrite=False):
@@ -101,14 +102,40 @@ class FakeEngine:
             R = R - Ap @ Cp
         return float(np.sum((YmAC - (q["W"] @ R + np.asarray(b0_new_patch, dtype=np.float64)[:, None])) ** 2))
 
-    def fast_temporal(self, pid, A_patch):
+    def fast_temporal(self, pid, A_patch, want_raw=True):
         aa, C_raw = orc.fast_temporal(self.p[pid]["Ysig"], sp.csc_matrix(A_patch).astype(np.float64))
+        self._last = (C_raw, aa)
         return C_raw, aa
 
-    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True):
+    def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True, want_raw=True):
         A = sp.csc_matrix(A_patch).astype(np.float64)
         C, C_raw, _ = orc.HALS_temporal(self.p[pid]["Ysig"], A, C_patch, maxIter, None)
-        return C, C_raw, np.asarray(A.multiply(A).sum(axis=0)).ravel()
+        aa = np.asarray(A.multiply(A).sum(axis=0)).ravel()
+        self._last = (C_raw, aa)
+        return C, C_raw, aa
+
+    # the stitch accumulator of the real engine (cnmfe_stitch_*), on the host
+    def stitch_begin(self, K, T):
+        self._acc = np.zeros((K, T + 1))
+
+    def stitch_add(self, ind):
+        C_raw, aa = self._last
+        self._acc[ind, :-1] += C_raw * aa[:, None]                       # update_temporal_parallel.m:274
+        self._acc[ind, -1] += aa                                        # :275
+
+    def stitch_allreduce(self, group):
+        import torch
+        import torch.distributed as td
+        t = torch.from_numpy(self._acc)
+        td.all_reduce(t, group=group)
+
+    def stitch_finish(self, subtract_min, want=True):
+        aa = self._acc[:, -1:].copy()
+        aa[aa == 0] = 1                                                  # :279
+        C_raw = self._acc[:, :-1] / aa                                   # :280
+        if subtract_min:
+            C_raw = C_raw - C_raw.min(axis=1, keepdims=True)             # :285
+        return np.ascontiguousarray(C_raw, dtype=np.float32)
 
     def post_process_spatial(self, A_full, d1, d2):
         A = sp.csc_matrix(A_full).toarray().astype(np.float64)

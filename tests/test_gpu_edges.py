@@ -504,3 +504,47 @@ def test_deconv_degenerate_traces_terminate_with_finite_output(eng):
     for a in (Cg, Crawg, Sg, parsg, sng):
         assert np.isfinite(a).all()
     assert np.all(Sg >= 0) and (Sg[4] > 0).any()
+
+
+def test_stitch_temporal_through_the_abi_with_rccl(eng, monkeypatch):
+    """cnmfe_stitch_begin / _add / _temporal (update_temporal_parallel.m:264-286): two patches' traces accumulated on the device, the exchange
+    taken through RCCL itself (ncclCommInitAll + ncclAllReduce on this one GPU: CNMFE_STITCH_RCCL=1), division, row minima, binding --
+    against the NumPy statement of the same lines; then the bound result is usable as (NULL, CNMFE_BOUND)."""
+    import ctypes as C
+    from cnmf_e_amd import _lib as L
+    from cnmf_e_amd.sources2d import PatchedVideo
+    monkeypatch.setenv("CNMFE_STITCH_RCCL", "1")
+    d1, d2, T, K, r = 44, 40, 300, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 31, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [22, 40], r, eng)                 # two patches stacked vertically
+    video.upload_from_full(Y)
+    acc = np.zeros((K, T)); aat = np.zeros(K)
+    L.check(L.lib.cnmfe_stitch_begin(eng._ctx, K, T))
+    for idx in video.owned:
+        pid = video.pid[idx]
+        eng.ring_init(pid, r)
+        eng.fit_ring_model(pid, None, None)
+        eng.residual(pid, None, None)
+        A_p = f.A_init.tocsr()[video.patch_pix[idx]].tocsc().astype(np.float32)
+        ind = np.nonzero(np.asarray(A_p.sum(axis=0)).ravel() > 0)[0]
+        _, Craw, aa = eng.hals_temporal(pid, A_p[:, ind], f.C_init[ind], 3, want_C=False)      # (host copy only for the reference below)
+        eng.stitch_add(ind)
+        acc[ind] += Craw.astype(np.float64) * aa[:, None]; aat[ind] += aa
+    aat[aat == 0] = 1
+    ref = acc / aat[:, None]
+    ref = ref - ref.min(axis=1, keepdims=True)
+    out = np.empty((K, T), dtype=np.float32)
+    ctxs = (L.c_ctx * 1)(eng._ctx)
+    L.check(L.lib.cnmfe_stitch_temporal(ctxs, 1, 1, out.ctypes.data_as(L.f32p), L.ROWMAJOR))
+    assert rel(out, ref) <= 1e-6, rel(out, ref)
+    # the stitched matrix is now the context's bound trace matrix
+    pid = video.pid[video.owned[0]]
+    A_p = f.A_init.tocsr()[video.patch_pix[video.owned[0]]].tocsc().astype(np.float32)
+    eng._bound = out
+    c_bound = eng.hals_temporal(pid, A_p, out, 2)
+    eng.bind_traces(None)
+    c_plain = eng.hals_temporal(pid, A_p, out.copy(), 2)
+    assert np.array_equal(c_bound[1], c_plain[1])
+    with pytest.raises(L.CnmfeError):
+        eng.stitch_add(np.arange(2))                                     # no open accumulator any more
