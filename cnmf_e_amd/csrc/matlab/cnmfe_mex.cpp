@@ -1,224 +1,347 @@
-// cnmfe_mex.cpp -- thin MEX gateway over the C ABI of include/cnmfe.h.
+// cnmfe_mex.cpp -- thin MEX gateway over the C ABI of include/cnmfe.h (one command string per entry point).
 //
-// NOT compiled in this repository's CI: it needs MATLAB's mex.h / matrix.h.  Build where MATLAB is installed:
-//     mex -O -largeArrayDims cnmfe_mex.cpp -I../include -L../cnmf_e_amd -lcnmfe_hip
-// House conventions follow the reference's own MEX (ca_source_extraction/utilities/graph_conn_comp_mex.cpp:38-64):
-// argument checks first, mexErrMsgIdAndTxt on failure, outputs allocated with mxCreate*, inputs never written.
+// Build where MATLAB is installed (not built in this repository: the image has no MATLAB; tests/test_host_logic.py only syntax-checks this
+// file against the stub headers in tests/mex_stub/):
+//     mex -O -largeArrayDims cnmfe_mex.cpp -I../../../include -L../.. -lcnmfe_hip
+// House conventions follow the reference's own MEX (ca_source_extraction/utilities/graph_conn_comp_mex.cpp:38-64, 88, 115): argument checks
+// first, mexErrMsgIdAndTxt on failure, outputs allocated with mxCreate*, inputs never written, scratch from mxMalloc.
 //
-//   h = cnmfe_mex('create', device)
-//   cnmfe_mex('patch', h, pid, patch_pos, block_pos, d1, d2, T)          % distribute_data.m:165-171 rectangles
-//   cnmfe_mex('upload', h, pid, Yblock, t0)                               % Yblock: d_b x nt, any numeric class
-//   cnmfe_mex('ring_init', h, pid, radius, num_neighbors)
-//   [b0, info] = cnmfe_mex('fit_ring', h, pid, A_block, C_block, with_projection)   % fit_ring_model.m:1
-//   Ysig = cnmfe_mex('residual', h, pid, A_prev_block, C_prev)            % update_spatial_parallel.m:162-166
-//   A = cnmfe_mex('spatial', h, pid, alg, A_patch, C_patch, IND_patch, sn, param)   % HALS_spatial*.m / nnls_spatial.m
-//   [C, C_raw, aa] = cnmfe_mex('temporal', h, pid, A_patch, C_patch, maxIter)       % HALS_temporal.m:1
-//   keep = cnmfe_mex('postprocess', h, A, d1, d2)                         % post_process_spatial.m:19-32
-//   [W, b0] = cnmfe_mex('get_ring', h, pid)
-//   cnmfe_mex('destroy', h)
+// mexErrMsgIdAndTxt does not return (it long-jumps out of the MEX function), so NO C++ object with a destructor is alive at any point that can
+// fail: every temporary is mxMalloc memory, which MATLAB releases itself when a MEX function exits through an error.
+//
+//   h = cnmfe_mex('create', device)                                        cnmfe_mex('destroy', h)
+//   cnmfe_mex('patch', h, pid, patch_pos, block_pos, d1, d2, T)            distribute_data.m:165-171 rectangles
+//   cnmfe_mex('upload', h, pid, Yblock, t0)                                Yblock: d_b x nt of class single / double / uint16 / uint8
+//   cnmfe_mex('ring_init', h, pid, radius, num_neighbors)                  get_nhood.m + initComponents_parallel.m:213-236
+//   [Wt, b0] = cnmfe_mex('get_ring', h, pid, d, d_b)                       W{m}.' (d_b x d sparse) and b0{m}
+//   cnmfe_mex('set_ring', h, pid, Wt, b0)                                  put a W{m}, b0{m} of an earlier session back on the device
+//   f = cnmfe_mex('first_run', h, pid)                                     update_background_parallel.m:143
+//   cnmfe_mex('bind_traces', h, C)                                         obj.C once per iteration; later C arguments may be int32 ROW INDICES into it
+//   info = cnmfe_mex('fit_ring', h, pid, A_block, C_or_rows, with_projection)             fit_ring_model.m:1
+//   info = cnmfe_mex('fit_ring_ssub', h, pid, fit_pid, res_pid, bg_ssub, A_block, C_or_rows, with_projection)
+//   cnmfe_mex('derive', h, pid, new_pid, bg_ssub, 'nearest' | 'bicubic')
+//   cnmfe_mex('residual', h, pid, A_prev_block, C_or_rows)                 update_spatial_parallel.m:162-166 (result stays on the device)
+//   cnmfe_mex('residual_ssub', h, pid, res_pid, bg_ssub, A_prev_block, C_or_rows)
+//   sn = cnmfe_mex('get_sn', h, pid, d)                                    update_sn = true
+//   A = cnmfe_mex('spatial', h, pid, alg, A_patch, C_or_rows, IND_patch, sn, param)       HALS_spatial*.m / nnls_spatial.m
+//   [C, C_raw, aa] = cnmfe_mex('temporal', h, pid, A_patch, C_or_rows, maxIter)           HALS_temporal.m:1 (fewer outputs: fewer downloads)
+//   [C, C_raw, S, pars, sn, aa] = cnmfe_mex('temporal_deconv', h, pid, A, C, maxIter, smin, max_tau, pars)
+//   [C_raw, aa] = cnmfe_mex('fast_temporal', h, pid, A, T)
+//   cnmfe_mex('stitch_begin', h, K, T);  cnmfe_mex('stitch_add', h, ind)   update_temporal_parallel.m:269-278, on the device
+//   C_raw = cnmfe_mex('stitch_temporal', hs, subtract_min, K, T)           :279-286 over the contexts hs (one per GPU; RCCL all-reduce)
+//   [C, C_raw, S, pars, sn] = cnmfe_mex('deconv_temporal', h, C_raw, smin, max_tau)       deconvTemporal.m:29-105
+//   rss = cnmfe_mex('compute_rss', h, pid, A_patch, C_or_rows, b0_block, b0_new_patch)
+//   Ybg = cnmfe_mex('reconstruct_background', h, pid, b0_block, b0_new_patch, frame0, nframes)
+//   keep = cnmfe_mex('postprocess', h, A, d1, d2)                          post_process_spatial.m:19-32 (connected)
 #include "mex.h"
 #include "matrix.h"
 #include <string.h>
 #include <stdint.h>
-#include <vector>
 #include "cnmfe.h"
 
-static std::vector<cnmfe_ctx *> g_ctx;
-static void at_exit() { for (auto c : g_ctx) if (c) cnmfe_destroy(c); g_ctx.clear(); }
+#define MAX_CTX 64
+static cnmfe_ctx *g_ctx[MAX_CTX];
+static int g_nctx = 0;
+static void at_exit(void) { for (int i = 0; i < g_nctx; ++i) if (g_ctx[i]) { cnmfe_destroy(g_ctx[i]); g_ctx[i] = NULL; } g_nctx = 0; }
 #define FAIL(...) mexErrMsgIdAndTxt("cnmfe_mex:error", __VA_ARGS__)
 #define CHECK(rc) do { if ((rc) != 0) FAIL("%s", cnmfe_last_error()); } while (0)
 
 static cnmfe_ctx *ctx_of(const mxArray *h) {
-    size_t i = (size_t)mxGetScalar(h);
-    if (i < 1 || i > g_ctx.size() || !g_ctx[i - 1]) FAIL("invalid context handle");
+    const double v = mxGetScalar(h);
+    const int i = (int)v;
+    if (i < 1 || i > g_nctx || !g_ctx[i - 1]) FAIL("invalid context handle");
     return g_ctx[i - 1];
 }
-// sparse double (CSC) -> ABI arrays (int64 colptr, int32 rowidx, float val)
-struct Csc { std::vector<int64_t> cp; std::vector<int32_t> ri; std::vector<float> v; int32_t K; };
-static Csc csc_of(const mxArray *A) {
-    Csc o;
-    if (mxIsEmpty(A)) { o.K = 0; o.cp.assign(1, 0); return o; }
-    mxArray *S = nullptr; const mxArray *src = A;
-    if (!mxIsSparse(A)) { mxArray *in = const_cast<mxArray *>(A); mexCallMATLAB(1, &S, 1, &in, "sparse"); src = S; }
+// ---- plain-data views of MATLAB arrays (all storage mxMalloc'ed) ----
+typedef struct { int32_t K; int64_t nnz; int64_t *cp; int32_t *ri; float *v; } Csc;
+static Csc csc_of(const mxArray *A) {                       // sparse / full, double / logical -> int64 colptr, int32 rowidx, float values
+    Csc o; o.K = 0; o.nnz = 0; o.ri = NULL; o.v = NULL;
+    if (mxIsEmpty(A)) { o.cp = (int64_t *)mxCalloc(1, sizeof(int64_t)); return o; }
+    mxArray *S = NULL; const mxArray *src = A;
+    if (!mxIsSparse(A)) { mxArray *in = (mxArray *)A; if (mexCallMATLAB(1, &S, 1, &in, "sparse")) FAIL("sparse() failed"); src = S; }
+    if (!mxIsDouble(src) && !mxIsLogical(src)) FAIL("sparse matrices must be double or logical");
     o.K = (int32_t)mxGetN(src);
     const mwIndex *jc = mxGetJc(src), *ir = mxGetIr(src);
-    o.cp.assign(jc, jc + o.K + 1);
-    mwIndex nnz = jc[o.K];
-    o.ri.resize(nnz); o.v.resize(nnz);
-    if (mxIsLogical(src)) { for (mwIndex e = 0; e < nnz; ++e) { o.ri[e] = (int32_t)ir[e]; o.v[e] = 1.f; } }
-    else { const double *pr = mxGetPr(src); for (mwIndex e = 0; e < nnz; ++e) { o.ri[e] = (int32_t)ir[e]; o.v[e] = (float)pr[e]; } }
+    o.nnz = (int64_t)jc[o.K];
+    o.cp = (int64_t *)mxMalloc(((size_t)o.K + 1) * sizeof(int64_t));
+    o.ri = (int32_t *)mxMalloc(((size_t)o.nnz + 1) * sizeof(int32_t));
+    o.v = (float *)mxMalloc(((size_t)o.nnz + 1) * sizeof(float));
+    for (int32_t k = 0; k <= o.K; ++k) o.cp[k] = (int64_t)jc[k];
+    if (mxIsLogical(src)) { for (int64_t e = 0; e < o.nnz; ++e) { o.ri[e] = (int32_t)ir[e]; o.v[e] = 1.f; } }
+    else { const double *pr = mxGetPr(src); for (int64_t e = 0; e < o.nnz; ++e) { o.ri[e] = (int32_t)ir[e]; o.v[e] = (float)pr[e]; } }
     if (S) mxDestroyArray(S);
     return o;
 }
-static std::vector<float> f32_of(const mxArray *M) {
-    size_t n = mxGetNumberOfElements(M);
-    std::vector<float> o(n);
-    if (mxIsSingle(M)) memcpy(o.data(), mxGetData(M), n * sizeof(float));
+static float *f32_of(const mxArray *M, size_t *n_out) {     // single / double -> float copy
+    const size_t n = mxGetNumberOfElements(M);
+    float *o = (float *)mxMalloc((n + 1) * sizeof(float));
+    if (mxIsSingle(M)) memcpy(o, mxGetData(M), n * sizeof(float));
     else if (mxIsDouble(M)) { const double *p = mxGetPr(M); for (size_t i = 0; i < n; ++i) o[i] = (float)p[i]; }
     else FAIL("expected a single or double array");
+    if (n_out) *n_out = n;
     return o;
 }
-static mxArray *to_double(const std::vector<float> &v, size_t r, size_t c) {
+// a trace argument: a K x T single / double matrix (column-major, uploaded) or an int32 vector of 1-based rows of the bound matrix
+typedef struct { const float *ptr; int order; } Traces;
+static Traces traces_of(const mxArray *C, int32_t K) {
+    Traces t; t.ptr = NULL; t.order = CNMFE_COLMAJOR;
+    if (K == 0) return t;
+    if (mxIsInt32(C)) {
+        if ((int32_t)mxGetNumberOfElements(C) != K) FAIL("row list has %d entries for %d footprints", (int)mxGetNumberOfElements(C), (int)K);
+        int32_t *rows = (int32_t *)mxMalloc((size_t)K * sizeof(int32_t));
+        const int32_t *src = (const int32_t *)mxGetData(C);
+        for (int32_t k = 0; k < K; ++k) rows[k] = src[k] - 1;
+        t.ptr = (const float *)rows; t.order = CNMFE_BOUND_ROWS;
+        return t;
+    }
+    if ((int32_t)mxGetM(C) != K) FAIL("trace matrix has %d rows for %d footprints", (int)mxGetM(C), (int)K);
+    t.ptr = f32_of(C, NULL);
+    return t;
+}
+static mxArray *to_double(const float *v, size_t r, size_t c) {
     mxArray *o = mxCreateDoubleMatrix(r, c, mxREAL);
     double *p = mxGetPr(o);
-    for (size_t i = 0; i < v.size(); ++i) p[i] = v[i];
+    for (size_t i = 0; i < r * c; ++i) p[i] = v[i];
     return o;
+}
+static mxArray *info_of(const int64_t info[4]) {
+    mxArray *o = mxCreateDoubleMatrix(1, 4, mxREAL);
+    for (int i = 0; i < 4; ++i) mxGetPr(o)[i] = (double)info[i];
+    return o;
+}
+static void deconv_opts_of(cnmfe_deconv_opts *o, double smin, double max_tau) {
+    memset(o, 0, sizeof(*o));
+    o->type = 1; o->method = 1; o->smin = smin; o->max_tau = max_tau; o->optimize_b = 1; o->optimize_pars = 1; o->maxIter = 10;
 }
 
 void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
     if (nin < 1 || !mxIsChar(pin[0])) FAIL("first argument must be a command string");
-    char cmd[32]; mxGetString(pin[0], cmd, sizeof(cmd));
+    char cmd[40];
+    if (mxGetString(pin[0], cmd, sizeof(cmd))) FAIL("command string too long");
     mexAtExit(at_exit);
     if (!strcmp(cmd, "create")) {
+        if (g_nctx >= MAX_CTX) FAIL("too many contexts");
         cnmfe_ctx *c = cnmfe_create(nin > 1 ? (int)mxGetScalar(pin[1]) : 0);
         if (!c) FAIL("%s", cnmfe_last_error());
-        g_ctx.push_back(c);
-        pout[0] = mxCreateDoubleScalar((double)g_ctx.size());
+        g_ctx[g_nctx++] = c;
+        pout[0] = mxCreateDoubleScalar((double)g_nctx);
         return;
     }
     if (nin < 2) FAIL("missing context handle");
+    if (!strcmp(cmd, "stitch_temporal")) {                      // C_raw = cnmfe_mex('stitch_temporal', hs, subtract_min, K, T)   (single, K x T)
+        if (nin != 5) FAIL("stitch_temporal: 5 inputs required (hs, subtract_min, K, T)");
+        const int n = (int)mxGetNumberOfElements(pin[1]);
+        if (n < 1 || n > MAX_CTX) FAIL("stitch_temporal: 1..%d context handles", MAX_CTX);
+        cnmfe_ctx *cs[MAX_CTX];
+        const double *hv = mxGetPr(pin[1]);
+        for (int i = 0; i < n; ++i) { const int k = (int)hv[i]; if (k < 1 || k > g_nctx || !g_ctx[k - 1]) FAIL("invalid context handle"); cs[i] = g_ctx[k - 1]; }
+        const size_t K = (size_t)mxGetScalar(pin[3]), T = (size_t)mxGetScalar(pin[4]);
+        pout[0] = mxCreateNumericMatrix(K, T, mxSINGLE_CLASS, mxREAL);
+        CHECK(cnmfe_stitch_temporal(cs, n, mxGetScalar(pin[2]) != 0, nout > 0 ? (float *)mxGetData(pout[0]) : NULL, CNMFE_COLMAJOR));
+        return;
+    }
     cnmfe_ctx *c = ctx_of(pin[1]);
-    if (!strcmp(cmd, "destroy")) { size_t i = (size_t)mxGetScalar(pin[1]); cnmfe_destroy(c); g_ctx[i - 1] = nullptr; return; }
+    if (!strcmp(cmd, "destroy")) { const int i = (int)mxGetScalar(pin[1]); cnmfe_destroy(c); g_ctx[i - 1] = NULL; return; }
+    if (!strcmp(cmd, "bind_traces")) {
+        if (nin != 3) FAIL("bind_traces: 3 inputs required");
+        if (mxIsEmpty(pin[2])) { CHECK(cnmfe_traces_bind(c, 0, 0, NULL, CNMFE_COLMAJOR)); return; }
+        float *Cm = f32_of(pin[2], NULL);
+        CHECK(cnmfe_traces_bind(c, (int32_t)mxGetM(pin[2]), (int64_t)mxGetN(pin[2]), Cm, CNMFE_COLMAJOR));
+        return;
+    }
+    if (!strcmp(cmd, "stitch_begin")) {
+        if (nin != 4) FAIL("stitch_begin: 4 inputs required (h, K, T)");
+        CHECK(cnmfe_stitch_begin(c, (int32_t)mxGetScalar(pin[2]), (int64_t)mxGetScalar(pin[3])));
+        return;
+    }
+    if (!strcmp(cmd, "stitch_add")) {                           // ind: 1-based rows (double or int32)
+        if (nin != 3) FAIL("stitch_add: 3 inputs required (h, ind)");
+        const size_t n = mxGetNumberOfElements(pin[2]);
+        int32_t *ind = (int32_t *)mxMalloc((n + 1) * sizeof(int32_t));
+        if (mxIsInt32(pin[2])) { const int32_t *s = (const int32_t *)mxGetData(pin[2]); for (size_t i = 0; i < n; ++i) ind[i] = s[i] - 1; }
+        else if (mxIsDouble(pin[2])) { const double *s = mxGetPr(pin[2]); for (size_t i = 0; i < n; ++i) ind[i] = (int32_t)s[i] - 1; }
+        else FAIL("stitch_add: ind must be double or int32");
+        CHECK(cnmfe_stitch_add(c, (int32_t)n, ind));
+        return;
+    }
+    if (!strcmp(cmd, "deconv_temporal")) {                      // [C, C_raw, S, pars, sn] = cnmfe_mex('deconv_temporal', h, C_raw, smin, max_tau)
+        if (nin != 5) FAIL("deconv_temporal: 5 inputs required");
+        const size_t K = mxGetM(pin[2]), T = mxGetN(pin[2]);
+        float *Cr = f32_of(pin[2], NULL);
+        cnmfe_deconv_opts o; deconv_opts_of(&o, mxGetScalar(pin[3]), mxGetScalar(pin[4]));
+        float *Co = (float *)mxMalloc((K * T + 1) * sizeof(float)), *S = (float *)mxMalloc((K * T + 1) * sizeof(float));
+        float *kp = (float *)mxMalloc((K + 1) * sizeof(float)), *sn = (float *)mxMalloc((K + 1) * sizeof(float));
+        CHECK(cnmfe_deconv_temporal(c, (int32_t)K, (int64_t)T, Cr, CNMFE_COLMAJOR, &o, Co, S, kp, sn));
+        pout[0] = to_double(Co, K, T);
+        if (nout > 1) pout[1] = to_double(Cr, K, T);
+        if (nout > 2) pout[2] = to_double(S, K, T);
+        if (nout > 3) pout[3] = to_double(kp, K, 1);
+        if (nout > 4) pout[4] = to_double(sn, K, 1);
+        return;
+    }
     if (!strcmp(cmd, "postprocess")) {
         if (nin != 5) FAIL("postprocess: 5 inputs required");
         Csc A = csc_of(pin[2]);
-        std::vector<uint8_t> keep(A.v.size());
-        CHECK(cnmfe_post_process_spatial(c, (int32_t)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), A.K, A.cp.data(), A.ri.data(), A.v.data(), keep.data()));
-        pout[0] = mxCreateLogicalMatrix(keep.size(), 1);
+        uint8_t *keep = (uint8_t *)mxCalloc((size_t)A.nnz + 1, 1);
+        CHECK(cnmfe_post_process_spatial(c, (int32_t)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), A.K, A.cp, A.ri, A.v, keep));
+        pout[0] = mxCreateLogicalMatrix((size_t)A.nnz, 1);
         mxLogical *k = mxGetLogicals(pout[0]);
-        for (size_t i = 0; i < keep.size(); ++i) k[i] = keep[i] != 0;
+        for (int64_t i = 0; i < A.nnz; ++i) k[i] = keep[i] != 0;
         return;
     }
     if (nin < 3) FAIL("missing patch id");
     const int pid = (int)mxGetScalar(pin[2]);
     if (!strcmp(cmd, "patch")) {
         if (nin != 8) FAIL("patch: 8 inputs required");
+        if (mxGetNumberOfElements(pin[3]) != 4 || mxGetNumberOfElements(pin[4]) != 4) FAIL("patch: positions are [r0 r1 c0 c1]");
         int32_t pr[4], br[4];
         for (int i = 0; i < 4; ++i) { pr[i] = (int32_t)mxGetPr(pin[3])[i]; br[i] = (int32_t)mxGetPr(pin[4])[i]; }
         CHECK(cnmfe_patch_create(c, pid, pr, br, (int32_t)mxGetScalar(pin[5]), (int32_t)mxGetScalar(pin[6]), (int64_t)mxGetScalar(pin[7])));
     } else if (!strcmp(cmd, "upload")) {
         if (nin != 5) FAIL("upload: 5 inputs required");
         const mxArray *Y = pin[3];
-        int dt = mxIsSingle(Y) ? CNMFE_F32 : mxIsDouble(Y) ? CNMFE_F64 : mxIsUint16(Y) ? CNMFE_U16 : mxIsUint8(Y) ? CNMFE_U8 : -1;
+        const int dt = mxIsSingle(Y) ? CNMFE_F32 : mxIsDouble(Y) ? CNMFE_F64 : mxIsUint16(Y) ? CNMFE_U16 : mxIsUint8(Y) ? CNMFE_U8 : -1;
         if (dt < 0) FAIL("upload: unsupported class %s", mxGetClassName(Y));
         CHECK(cnmfe_upload_block(c, pid, mxGetData(Y), dt, CNMFE_HOST, (int64_t)mxGetScalar(pin[4]), (int64_t)mxGetN(Y)));
     } else if (!strcmp(cmd, "ring_init")) {
+        if (nin < 4) FAIL("ring_init: radius required");
         CHECK(cnmfe_ring_init(c, pid, (int32_t)mxGetScalar(pin[3]), nin > 4 && !mxIsEmpty(pin[4]) ? (int32_t)mxGetScalar(pin[4]) : 0));
+    } else if (!strcmp(cmd, "first_run")) {
+        int f = 0;
+        CHECK(cnmfe_ring_first_run(c, pid, &f));
+        pout[0] = mxCreateLogicalScalar(f != 0);
     } else if (!strcmp(cmd, "fit_ring")) {
         if (nin != 6) FAIL("fit_ring: 6 inputs required");
         Csc A = csc_of(pin[3]);
-        std::vector<float> C = A.K ? f32_of(pin[4]) : std::vector<float>();
-        int64_t nnz; int32_t p; CHECK(cnmfe_ring_nnz(c, pid, &nnz, &p));
+        Traces Cm = traces_of(pin[4], A.K);
         int64_t info[4];
-        // d is not known here without a query; b0 is fetched through get_ring
-        CHECK(cnmfe_fit_ring_model(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR,
-                                   mxGetNaN(), mxGetScalar(pin[5]) != 0, nullptr, info));
-        pout[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
-        for (int i = 0; i < 4; ++i) mxGetPr(pout[0])[i] = (double)info[i];
+        CHECK(cnmfe_fit_ring_model(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, mxGetNaN(), mxGetScalar(pin[5]) != 0, NULL, info));
+        pout[0] = info_of(info);
     } else if (!strcmp(cmd, "residual")) {
         if (nin != 5) FAIL("residual: 5 inputs required");
         Csc A = csc_of(pin[3]);
-        std::vector<float> C = A.K ? f32_of(pin[4]) : std::vector<float>();
-        CHECK(cnmfe_residual(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, nullptr, CNMFE_HOST));
+        Traces Cm = traces_of(pin[4], A.K);
+        CHECK(cnmfe_residual(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, NULL, CNMFE_HOST));
     } else if (!strcmp(cmd, "spatial")) {
         if (nin != 9) FAIL("spatial: 9 inputs required");
-        char alg[16]; mxGetString(pin[3], alg, sizeof(alg));
-        int a = !strcmp(alg, "hals") ? CNMFE_SPATIAL_HALS : !strcmp(alg, "hals_thresh") ? CNMFE_SPATIAL_HALS_THRESH : CNMFE_SPATIAL_NNLS;
+        char alg[16];
+        if (mxGetString(pin[3], alg, sizeof(alg))) FAIL("spatial: bad algorithm name");
+        const int a = !strcmp(alg, "hals") ? CNMFE_SPATIAL_HALS : !strcmp(alg, "hals_thresh") ? CNMFE_SPATIAL_HALS_THRESH : !strcmp(alg, "nnls") ? CNMFE_SPATIAL_NNLS : -1;
+        if (a < 0) FAIL("spatial: unknown algorithm '%s'", alg);
+        if (!mxIsSparse(pin[6])) FAIL("spatial: IND must be sparse");
         Csc A = csc_of(pin[4]), IND = csc_of(pin[6]);
-        std::vector<float> C = f32_of(pin[5]), sn = mxIsEmpty(pin[7]) ? std::vector<float>() : f32_of(pin[7]);
-        std::vector<float> out(IND.v.size());
-        CHECK(cnmfe_update_spatial(c, pid, a, A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, IND.cp.data(), IND.ri.data(),
-                                   sn.empty() ? nullptr : sn.data(), (int32_t)mxGetScalar(pin[8]), out.data()));
-        pout[0] = mxCreateSparse(mxGetM(pin[6]), IND.K, out.size(), mxREAL);       // same pattern as IND
-        memcpy(mxGetJc(pout[0]), mxGetJc(pin[6]), (IND.K + 1) * sizeof(mwIndex));
-        memcpy(mxGetIr(pout[0]), mxGetIr(pin[6]), out.size() * sizeof(mwIndex));
-        for (size_t i = 0; i < out.size(); ++i) mxGetPr(pout[0])[i] = out[i];
+        Traces Cm = traces_of(pin[5], A.K);
+        float *sn = mxIsEmpty(pin[7]) ? NULL : f32_of(pin[7], NULL);
+        float *out = (float *)mxCalloc((size_t)IND.nnz + 1, sizeof(float));
+        CHECK(cnmfe_update_spatial(c, pid, a, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, IND.cp, IND.ri, sn, (int32_t)mxGetScalar(pin[8]), out));
+        pout[0] = mxCreateSparse(mxGetM(pin[6]), (size_t)IND.K, (size_t)IND.nnz > 0 ? (size_t)IND.nnz : 1, mxREAL);       // same pattern as IND
+        memcpy(mxGetJc(pout[0]), mxGetJc(pin[6]), ((size_t)IND.K + 1) * sizeof(mwIndex));
+        memcpy(mxGetIr(pout[0]), mxGetIr(pin[6]), (size_t)IND.nnz * sizeof(mwIndex));
+        for (int64_t i = 0; i < IND.nnz; ++i) mxGetPr(pout[0])[i] = out[i];
     } else if (!strcmp(cmd, "temporal")) {
         if (nin != 6) FAIL("temporal: 6 inputs required");
         Csc A = csc_of(pin[3]);
-        std::vector<float> C = f32_of(pin[4]);
-        size_t K = mxGetM(pin[4]), T = mxGetN(pin[4]);
-        std::vector<float> Co(K * T), Cr(K * T), aa(K);
-        CHECK(cnmfe_hals_temporal(c, pid, (int32_t)K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR,
-                                  (int32_t)mxGetScalar(pin[5]), Co.data(), Cr.data(), aa.data()));
-        pout[0] = to_double(Co, K, T);
+        Traces Cm = traces_of(pin[4], A.K);
+        const size_t K = (size_t)A.K, T = mxIsInt32(pin[4]) ? 0 : mxGetN(pin[4]);
+        if (nout > 0 && T == 0) FAIL("temporal: outputs need the trace matrix itself (row lists carry no T); use the stitch commands instead");
+        float *Co = nout > 0 ? (float *)mxMalloc((K * T + 1) * sizeof(float)) : NULL, *Cr = nout > 1 ? (float *)mxMalloc((K * T + 1) * sizeof(float)) : NULL;
+        float *aa = (float *)mxMalloc((K + 1) * sizeof(float));
+        CHECK(cnmfe_hals_temporal(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, (int32_t)mxGetScalar(pin[5]), Co, Cr, aa));
+        if (nout > 0) pout[0] = to_double(Co, K, T);
         if (nout > 1) pout[1] = to_double(Cr, K, T);
         if (nout > 2) pout[2] = to_double(aa, K, 1);
-    } else if (!strcmp(cmd, "temporal_deconv")) {            // [C, C_raw, S, pars, sn, aa] = cnmfe_mex('temporal_deconv', h, pid, A, C, maxIter, smin, max_tau)
-        if (nin != 8) FAIL("temporal_deconv: 8 inputs required");
+    } else if (!strcmp(cmd, "temporal_deconv")) {
+        if (nin != 9) FAIL("temporal_deconv: 9 inputs required (h, pid, A, C, maxIter, smin, max_tau, pars)");
         Csc A = csc_of(pin[3]);
-        std::vector<float> C = f32_of(pin[4]);
-        size_t K = mxGetM(pin[4]), T = mxGetN(pin[4]);
-        cnmfe_deconv_opts o; memset(&o, 0, sizeof(o));
-        o.type = 1; o.method = 1; o.smin = mxGetScalar(pin[6]); o.max_tau = mxGetScalar(pin[7]); o.optimize_b = 1; o.optimize_pars = 1; o.maxIter = 10;
-        std::vector<float> Co(K * T), Cr(K * T), S(K * T), kp(K), sn(K), aa(K);
-        CHECK(cnmfe_hals_temporal_deconv(c, pid, (int32_t)K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR,
-                                         (int32_t)mxGetScalar(pin[5]), &o, Co.data(), Cr.data(), S.data(), kp.data(), sn.data(), aa.data()));
-        pout[0] = to_double(Co, K, T);
+        const size_t K = (size_t)A.K, T = mxGetN(pin[4]);
+        if (mxIsInt32(pin[4])) FAIL("temporal_deconv: pass the trace matrix itself");
+        Traces Cm = traces_of(pin[4], A.K);
+        cnmfe_deconv_opts o; deconv_opts_of(&o, mxGetScalar(pin[6]), mxGetScalar(pin[7]));
+        float *kp = (float *)mxCalloc(K + 1, sizeof(float));
+        if (!mxIsEmpty(pin[8])) { size_t n; float *p0 = f32_of(pin[8], &n); if (n != K) FAIL("temporal_deconv: pars must have K entries"); memcpy(kp, p0, K * sizeof(float)); }
+        float *Co = nout > 0 ? (float *)mxMalloc((K * T + 1) * sizeof(float)) : NULL, *Cr = nout > 1 ? (float *)mxMalloc((K * T + 1) * sizeof(float)) : NULL;
+        float *S = nout > 2 ? (float *)mxMalloc((K * T + 1) * sizeof(float)) : NULL;
+        float *sn = (float *)mxMalloc((K + 1) * sizeof(float)), *aa = (float *)mxMalloc((K + 1) * sizeof(float));
+        CHECK(cnmfe_hals_temporal_deconv(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, (int32_t)mxGetScalar(pin[5]), &o, kp, Co, Cr, S, sn, aa));
+        if (nout > 0) pout[0] = to_double(Co, K, T);
         if (nout > 1) pout[1] = to_double(Cr, K, T);
         if (nout > 2) pout[2] = to_double(S, K, T);
         if (nout > 3) pout[3] = to_double(kp, K, 1);
         if (nout > 4) pout[4] = to_double(sn, K, 1);
         if (nout > 5) pout[5] = to_double(aa, K, 1);
-    } else if (!strcmp(cmd, "fast_temporal")) {              // [C_raw, aa] = cnmfe_mex('fast_temporal', h, pid, A, T)   (use_c_hat = false)
+    } else if (!strcmp(cmd, "fast_temporal")) {
         if (nin != 5) FAIL("fast_temporal: 5 inputs required (h, pid, A, T)");
         Csc A = csc_of(pin[3]);
-        int64_t info_T = (int64_t)mxGetScalar(pin[4]);
-        std::vector<float> Cr((size_t)A.K * info_T), aa(A.K);
-        CHECK(cnmfe_fast_temporal(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), CNMFE_COLMAJOR, Cr.data(), aa.data()));
-        pout[0] = to_double(Cr, A.K, (size_t)info_T);
-        if (nout > 1) pout[1] = to_double(aa, A.K, 1);
-    } else if (!strcmp(cmd, "compute_rss")) {                // rss = cnmfe_mex('compute_rss', h, pid, A_patch, C, b0_block, b0_new_patch)   (Sources2D.m:1358-1510, one patch)
+        const size_t K = (size_t)A.K, T = (size_t)mxGetScalar(pin[4]);
+        float *Cr = nout > 0 ? (float *)mxMalloc((K * T + 1) * sizeof(float)) : NULL, *aa = (float *)mxMalloc((K + 1) * sizeof(float));
+        CHECK(cnmfe_fast_temporal(c, pid, A.K, A.cp, A.ri, A.v, CNMFE_COLMAJOR, Cr, aa));
+        if (nout > 0) pout[0] = to_double(Cr, K, T);
+        if (nout > 1) pout[1] = to_double(aa, K, 1);
+    } else if (!strcmp(cmd, "compute_rss")) {
         if (nin != 7) FAIL("compute_rss: 7 inputs required (h, pid, A, C, b0_block, b0_new)");
         Csc A = csc_of(pin[3]);
-        std::vector<float> C = A.K ? f32_of(pin[4]) : std::vector<float>(), bb = f32_of(pin[5]), bn = f32_of(pin[6]);
+        Traces Cm = traces_of(pin[4], A.K);
+        float *bb = f32_of(pin[5], NULL), *bn = f32_of(pin[6], NULL);
         double rss = 0.0;
-        CHECK(cnmfe_compute_rss(c, pid, A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, bb.data(), bn.data(), &rss));
+        CHECK(cnmfe_compute_rss(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, bb, bn, &rss));
         pout[0] = mxCreateDoubleScalar(rss);
-    } else if (!strcmp(cmd, "reconstruct_background")) {     // Ybg = cnmfe_mex('reconstruct_background', h, pid, b0_block, b0_new_patch, frame0, nframes)   (Sources2D.m:1247-1355, one patch; d x nframes)
+    } else if (!strcmp(cmd, "reconstruct_background")) {
         if (nin != 7) FAIL("reconstruct_background: 7 inputs required (h, pid, b0_block, b0_new, frame0, nframes)");
-        std::vector<float> bb = f32_of(pin[3]), bn = f32_of(pin[4]);
+        size_t nb = 0, nn = 0;
+        float *bb = f32_of(pin[3], &nb), *bn = f32_of(pin[4], &nn);
         const int64_t f0 = (int64_t)mxGetScalar(pin[5]), nf = (int64_t)mxGetScalar(pin[6]);
         if (nf <= 0) FAIL("reconstruct_background: nframes must be positive");
-        std::vector<float> out(bn.size() * (size_t)nf);
-        CHECK(cnmfe_reconstruct_background(c, pid, bb.data(), bn.data(), f0, nf, out.data(), CNMFE_HOST));
-        pout[0] = to_double(out, bn.size(), (size_t)nf);
-    } else if (!strcmp(cmd, "get_sn")) {                     // sn = cnmfe_mex('get_sn', h, pid, d)   (update_sn = true)
+        pout[0] = mxCreateNumericMatrix(nn, (size_t)nf, mxSINGLE_CLASS, mxREAL);
+        CHECK(cnmfe_reconstruct_background(c, pid, bb, bn, f0, nf, (float *)mxGetData(pout[0]), CNMFE_HOST));
+    } else if (!strcmp(cmd, "get_sn")) {
         if (nin != 4) FAIL("get_sn: 4 inputs required");
-        size_t d = (size_t)mxGetScalar(pin[3]);
-        std::vector<float> sn(d);
-        CHECK(cnmfe_get_sn(c, pid, sn.data()));
+        const size_t d = (size_t)mxGetScalar(pin[3]);
+        float *sn = (float *)mxMalloc((d + 1) * sizeof(float));
+        CHECK(cnmfe_get_sn(c, pid, sn));
         pout[0] = to_double(sn, d, 1);
-    } else if (!strcmp(cmd, "derive")) {                     // cnmfe_mex('derive', h, pid, new_pid, bg_ssub, 'nearest'|'bicubic')
+    } else if (!strcmp(cmd, "derive")) {
         if (nin != 6) FAIL("derive: 6 inputs required");
-        char md[16]; mxGetString(pin[5], md, sizeof(md));
+        char md[16];
+        if (mxGetString(pin[5], md, sizeof(md))) FAIL("derive: bad mode");
         CHECK(cnmfe_patch_derive(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), !strcmp(md, "nearest") ? CNMFE_DERIVE_NEAREST : CNMFE_DERIVE_BICUBIC));
-    } else if (!strcmp(cmd, "fit_ring_ssub")) {              // info = cnmfe_mex('fit_ring_ssub', h, pid, fit_pid, res_pid, bg_ssub, A, C, with_projection)
+    } else if (!strcmp(cmd, "fit_ring_ssub")) {
         if (nin != 9) FAIL("fit_ring_ssub: 9 inputs required");
         Csc A = csc_of(pin[6]);
-        std::vector<float> C = A.K ? f32_of(pin[7]) : std::vector<float>();
+        Traces Cm = traces_of(pin[7], A.K);
         int64_t info[4];
-        CHECK(cnmfe_fit_ring_model_ssub(c, pid, (int)mxGetScalar(pin[3]), (int)mxGetScalar(pin[4]), (int32_t)mxGetScalar(pin[5]), A.K, A.cp.data(),
-                                        A.ri.data(), A.v.data(), C.data(), CNMFE_COLMAJOR, mxGetNaN(), mxGetScalar(pin[8]) != 0, info));
-        pout[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
-        for (int i = 0; i < 4; ++i) mxGetPr(pout[0])[i] = (double)info[i];
-    } else if (!strcmp(cmd, "residual_ssub")) {              // cnmfe_mex('residual_ssub', h, pid, res_pid, bg_ssub, A_prev, C_prev)
+        CHECK(cnmfe_fit_ring_model_ssub(c, pid, (int)mxGetScalar(pin[3]), (int)mxGetScalar(pin[4]), (int32_t)mxGetScalar(pin[5]), A.K, A.cp, A.ri, A.v,
+                                        Cm.ptr, Cm.order, mxGetNaN(), mxGetScalar(pin[8]) != 0, info));
+        pout[0] = info_of(info);
+    } else if (!strcmp(cmd, "residual_ssub")) {
         if (nin != 7) FAIL("residual_ssub: 7 inputs required");
         Csc A = csc_of(pin[5]);
-        std::vector<float> C = A.K ? f32_of(pin[6]) : std::vector<float>();
-        CHECK(cnmfe_residual_ssub(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), A.K, A.cp.data(), A.ri.data(), A.v.data(), C.data(),
-                                  CNMFE_COLMAJOR, nullptr, CNMFE_HOST));
+        Traces Cm = traces_of(pin[6], A.K);
+        CHECK(cnmfe_residual_ssub(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, NULL, CNMFE_HOST));
     } else if (!strcmp(cmd, "get_ring")) {
-        int64_t nnz; int32_t p; CHECK(cnmfe_ring_nnz(c, pid, &nnz, &p));
-        // rows = patch pixels: recovered from the CSR row pointer length the caller passes as pin[3] = d, pin[4] = d_b
-        size_t d = (size_t)mxGetScalar(pin[3]), d_b = (size_t)mxGetScalar(pin[4]);
-        std::vector<int64_t> rp(d + 1); std::vector<int32_t> col(nnz); std::vector<float> val(nnz), b0(d);
-        CHECK(cnmfe_ring_get_csr(c, pid, rp.data(), col.data(), val.data()));
-        CHECK(cnmfe_b0_get(c, pid, b0.data()));
-        // CSR (d x d_b) == CSC of the transpose: build W' (d_b x d) directly, the caller transposes
-        pout[0] = mxCreateSparse(d_b, d, nnz, mxREAL);
+        if (nin != 5) FAIL("get_ring: 5 inputs required (h, pid, d, d_b)");
+        int64_t nnz; int32_t p;
+        CHECK(cnmfe_ring_nnz(c, pid, &nnz, &p));
+        const size_t d = (size_t)mxGetScalar(pin[3]), d_b = (size_t)mxGetScalar(pin[4]);
+        int64_t *rp = (int64_t *)mxMalloc((d + 1) * sizeof(int64_t));
+        int32_t *col = (int32_t *)mxMalloc(((size_t)nnz + 1) * sizeof(int32_t));
+        float *val = (float *)mxMalloc(((size_t)nnz + 1) * sizeof(float)), *b0 = (float *)mxMalloc((d + 1) * sizeof(float));
+        CHECK(cnmfe_ring_get_csr(c, pid, rp, col, val));
+        CHECK(cnmfe_b0_get(c, pid, b0));
+        // CSR (d x d_b) == CSC of the transpose: W' (d_b x d) directly, the caller transposes
+        pout[0] = mxCreateSparse(d_b, d, (size_t)nnz > 0 ? (size_t)nnz : 1, mxREAL);
         for (size_t i = 0; i <= d; ++i) mxGetJc(pout[0])[i] = (mwIndex)rp[i];
         for (int64_t e = 0; e < nnz; ++e) { mxGetIr(pout[0])[e] = (mwIndex)col[e]; mxGetPr(pout[0])[e] = val[e]; }
         if (nout > 1) pout[1] = to_double(b0, d, 1);
+    } else if (!strcmp(cmd, "set_ring")) {                      // Wt = W{m}.' with the ring's own pattern (what get_ring returned)
+        if (nin != 5) FAIL("set_ring: 5 inputs required (h, pid, Wt, b0)");
+        int64_t nnz; int32_t p;
+        CHECK(cnmfe_ring_nnz(c, pid, &nnz, &p));
+        if (!mxIsSparse(pin[3]) || (int64_t)mxGetJc(pin[3])[mxGetN(pin[3])] != nnz) FAIL("set_ring: Wt must be sparse with the ring's %lld entries", (long long)nnz);
+        float *val = (float *)mxMalloc(((size_t)nnz + 1) * sizeof(float));
+        const double *pr = mxGetPr(pin[3]);
+        for (int64_t e = 0; e < nnz; ++e) val[e] = (float)pr[e];
+        CHECK(cnmfe_ring_set_values(c, pid, val));
+        float *b0 = f32_of(pin[4], NULL);
+        CHECK(cnmfe_b0_set(c, pid, b0));
     } else FAIL("unknown command '%s'", cmd);
 }

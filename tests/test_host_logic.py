@@ -173,3 +173,33 @@ def test_data_plane_readers_match_upload_from_full(tmp_path):
             assert np.array_equal(np.asarray(got[idx], dtype=np.float64), np.asarray(ref[idx], dtype=np.float64)), (name, idx)
     with pytest.raises(ValueError):
         blocks(lambda v: v.upload_from_images(vol[:-1]))
+
+
+def test_mex_gateway_compiles_against_stub():
+    """cnmf_e_amd/csrc/matlab/cnmfe_mex.cpp is type-checked against include/cnmfe.h and stub MEX headers (tests/mex_stub: declarations only);
+    the gateway must not hold C++ objects across mexErrMsgIdAndTxt (which long-jumps): no STL anywhere in it."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "cnmf_e_amd", "csrc", "matlab", "cnmfe_mex.cpp")
+    text = open(src).read()
+    assert "std::" not in text and "#include <vector>" not in text and "#include <string>" not in text
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    out = subprocess.run([cxx, "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "tests", "mex_stub"),
+                          "-I", os.path.join(root, "include"), src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_matlab_host_speaks_the_gateways_commands():
+    """every cnmfe_mex('command', ...) in the MATLAB host files is a command the gateway dispatches, and the three drop-in methods exist"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mdir = os.path.join(root, "cnmf_e_amd", "csrc", "matlab")
+    gateway = set(re.findall(r'strcmp\(cmd, "(\w+)"\)', open(os.path.join(mdir, "cnmfe_mex.cpp")).read()))
+    used = set()
+    mfiles = [os.path.join(dp, f) for dp, _, fs in os.walk(mdir) for f in fs if f.endswith(".m")]
+    for fn in mfiles:
+        used |= set(re.findall(r"cnmfe_mex\('(\w+)'", open(fn).read()))
+    assert used and used <= gateway, used - gateway
+    for name in ("update_background_parallel.m", "update_spatial_parallel.m", "update_temporal_parallel.m"):
+        assert os.path.exists(os.path.join(mdir, "@Sources2D", name))
