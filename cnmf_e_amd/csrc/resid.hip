@@ -105,6 +105,8 @@ struct R1Args {
     float4 *Ysig4;                   // output, [T/4][d] float4
     int ntile_r;
     const int *tile_map;         // dispatch slot -> tile_r | tile_c << 16 (XCD-compact order, built on the host)
+    int probe;                   // timing ablations of the arc-DMA kernel (option r1_probe): 1 no DMA after the first chunk, 2 no ring product,
+                                 // 4 no partial-sum exchange, 8 no store.  Results are garbage with any bit set.
 };
 
 constexpr int R1_TKMAX = 64;                // traces staged per tile and chunk (one DMA instruction)
@@ -161,6 +163,15 @@ __device__ __forceinline__ float4 ld4_off(const float4 *base, uint32_t byteoff) 
 }
 __device__ __forceinline__ void st4_off(float4 *base, uint32_t byteoff, float4 v) {
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + byteoff) = v;
+}
+
+// write-through store that DROPS the line from the XCD's L2 (sc1; MI355X_MICROARCH.md, stores of each flavour): Ysig is written once and read
+// by later kernels -- kept in L2 it only evicts the halo lines neighbouring tiles are about to re-read (TCC hit rate of the sweep: 56 %).
+// Inline asm: invisible to hipcc's vmcnt bookkeeping -- only for kernels that count vmcnt by hand (the LDS-DMA ones do).
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_off_wt(float4 *base, uint32_t byteoff, float4 v) {
+    const f4v_t x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(byteoff), "v"(x), "s"(base) : "memory");
 }
 
 // waves/SIMD the register allocator must leave room for: weights (P VGPRs) + working registers
@@ -536,15 +547,15 @@ static int launch_r1_dma(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid
 // once and served from that XCD's L2 afterwards: the fabric-side read amplification is the halo'd area of the
 // *union* of those 32 tiles over its own area.  order 1 therefore hands every XCD compact, near-square groups
 // of 32 tiles (super-tiles); order 0 is the plain column-major strip.
-static int build_tile_map(cnmfe_ctx *ctx, DevBuf &buf, int ntr, int ntc, int TR, int TC, int h, int order) {
+static int build_tile_map(cnmfe_ctx *ctx, DevBuf &buf, int ntr, int ntc, int TR, int TC, int h, int order, int per_xcd = 32) {
     const int n = ntr * ntc;
     std::vector<int32_t> logical; logical.reserve(n);
     if (order == 0) {
         for (int c = 0; c < ntc; ++c) for (int r = 0; r < ntr; ++r) logical.push_back(r | (c << 16));
     } else {
-        int sr = 32, sc = 1; double best = 1e300;
-        for (int a2 = 1; a2 <= 32; a2 *= 2) {
-            const int b2 = 32 / a2;
+        int sr = per_xcd, sc = 1; double best = 1e300;          // per_xcd workgroups of an XCD are resident together (32 CUs x workgroups per CU)
+        for (int a2 = 1; a2 <= per_xcd; a2 *= 2) {
+            const int b2 = per_xcd / a2;
             const double area = (double)(std::min(a2, ntr) * TR + 2 * h) * (std::min(b2, ntc) * TC + 2 * h);
             if (area < best) { best = area; sr = a2; sc = b2; }
         }
@@ -734,6 +745,7 @@ static int launch_r1(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid) {
 
 }  // namespace cnmfe
 #include "resid_arc.hpp"
+#include "resid_quad.hpp"
 namespace cnmfe {
 
 template <int R>
@@ -745,6 +757,7 @@ static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac
         if (variant == 8) return launch_r1_arc<R, 4, 0, 2>(ctx, a, has_ac, ntile_c, nseg);   // 2 chunks in flight
         if (variant == 9) return launch_r1_arc<R, 4, 0, 3>(ctx, a, has_ac, ntile_c, nseg);   // 3 chunks in flight
         if (variant == 11) return launch_r1_arc_dma<R>(ctx, a, has_ac, ntile_c, nseg);         // arc roles on LDS-DMA staging
+        if (variant == 12) return launch_r1_quad<R>(ctx, a, ntile_c, nseg);                    // the four roles inside one wave, two workgroups per CU
     }
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
@@ -763,6 +776,7 @@ static void tile_shape(int variant, int &TR, int &TC) {
     if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2 || variant == 10) { TR = 32; TC = 16; }
     else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
     else if ((variant >= 5 && variant <= 9) || variant == 11) { TR = ARC_TR; TC = ARC_TC; }
+    else if (variant == 12) { TR = QD_T; TC = QD_T; }
 }
 
 // the ABI hands Ysig out frame-major (d x T column-major); resident it is 4-frame interleaved
@@ -1074,12 +1088,13 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
     int variant = (int)ctx->opt("r1_variant", 11);
     const int h = P->radius;
+    if (variant == 12 && (has_ac || h != 15)) variant = 11;   // quad roles (resid_quad.hpp; measured slower, kept for A/B): radius 15, no footprint term inside the sweep
     bool full_ring = true;
     { int n = 0;
       for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
-    if (h == 18 && ((variant >= 5 && variant <= 9) || variant == 11)) variant = 10;   // arc kernels: radius 15 only (ds_read immediates)
+    if (h == 18 && ((variant >= 5 && variant <= 9) || variant >= 11)) variant = 10;   // arc kernels: radius 15 only (ds_read immediates)
     // the low-resolution rings of bg_ssub = 2, 3 (ceil(15/2) = 8, ceil(18/2) = 9, ceil(15/3) = 5, ceil(18/3) = 6): LDS-DMA kernel only
     const bool small_special = full_ring && (h == 5 || h == 6 || h == 8 || h == 9) && variant >= 0;
     if (small_special) variant = 10;
@@ -1098,16 +1113,18 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     a.wa_v = has_ac ? dWaV.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
     a.Ysig4 = ysig.as<float4>();
     a.ntile_r = (P->nr + TR - 1) / TR;
+    a.probe = (int)ctx->opt("r1_probe", 0);
     const int ntile_c = (P->nc + TC - 1) / TC;
     const int64_t ntiles = (int64_t)a.ntile_r * ntile_c;
     // enough workgroups to fill 256 CUs several times over; segments are a multiple of 4 frames
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((T + 255) / 256, (4096 + ntiles - 1) / ntiles));
+    if (ctx->opt("r1_nseg", 0) > 0) nseg = std::min<int64_t>(ctx->opt("r1_nseg", 0), (T + 3) / 4);      // (experiments: force the number of frame segments)
     int64_t tseg = ((T + nseg - 1) / nseg + 3) & ~int64_t(3);
     nseg = (T + tseg - 1) / tseg;
     a.tseg = tseg;
     int rc;
     if (special) {
-        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
+        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1), variant == 12 ? 64 : 32));
         a.tile_map = dOffs.as<int>();
         CK(hipStreamSynchronize(ctx->stream));           // the host-side staging vectors die with this call; the stream is near-idle here
         const dim3 gridd((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
