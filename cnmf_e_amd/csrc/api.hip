@@ -576,16 +576,26 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     Patch *P = get_patch(ctx, patch_id);
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
-    if (!(thresh_outlier != thresh_outlier))
-        return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 outlier branch is not built)");
     RET(check_csc("A", K, P->d_b, A_colptr, A_rowidx));
     if (K > 0 && ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND))) return fail(CNMFE_EINVAL, "null A_val / C");
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, P));
     int64_t dummy[4];
-    int rc = bg_fit_ring(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, b0_out, info ? info : dummy);
+    int rc = bg_fit_ring(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, b0_out, info ? info : dummy, 0, thresh_outlier);
     P->ysig_valid = false;
     return rc;
+}
+
+int cnmfe_set_noise(cnmfe_ctx *ctx, int patch_id, const float *sn_block) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (!sn_block) return fail(CNMFE_EINVAL, "null sn_block");
+    CK(hipSetDevice(ctx->device));
+    RET(to_dev(ctx, P->sn_b, sn_block, (size_t)P->d_b));
+    CK(hipStreamSynchronize(ctx->stream));
+    P->sn_ready = true;
+    return 0;
 }
 
 int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,

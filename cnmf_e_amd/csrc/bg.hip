@@ -972,8 +972,66 @@ __global__ void k_b0(const double *__restrict__ ymean, BgGeom g, const int *__re
     b0[m] = v;
 }
 
+// ---- outlier branch (fit_ring_model.m:50-56): Bf_old = W_old*Bf; entries of the patch rows above Bf_old + thresh*sn take the value of
+// Bf_old.  Bf_old is formed from the unmodified Bf (the reference computes it before touching tmp_Bf), so the clipped rows go to a
+// second buffer.  One thread per (patch pixel, 4 frames); cnt[t] = sum(ind_outlier(:, t)) feeds the frame selection of :62-67.
+__device__ __forceinline__ int64_t bf4_index(const BgGeom &g, int rb, int cb, int64_t c) {
+    return ((int64_t)((cb >> 4) * g.nbr + (rb >> 4)) * (g.Tpad >> 2) + c) * BLKPX + lp_of(rb & 15, cb & 15);
+}
+__global__ void __launch_bounds__(256) k_outlier_clip(const float4 *__restrict__ bf, float4 *__restrict__ bf2, BgGeom g, const int *__restrict__ dr,
+                                                      const int *__restrict__ dc, const float *__restrict__ W, const float *__restrict__ sn_b,
+                                                      double thresh, int *__restrict__ cnt) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (m >= g.d) return;
+    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
+    double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    for (int i = 0; i < g.p; ++i) {
+        const float w = W[(int64_t)i * g.d + m];
+        if (w == 0.f) continue;                                   // outside the FOV (or an exact zero: no term either way)
+        const float4 v = bf[bf4_index(g, rbm + dr[i], cbm + dc[i], c)];
+        o0 += (double)w * v.x; o1 += (double)w * v.y; o2 += (double)w * v.z; o3 += (double)w * v.w;
+    }
+    const int64_t at = bf4_index(g, rbm, cbm, c);
+    float4 y = bf[at];
+    const double lim = thresh * (double)sn_b[(int64_t)cbm * g.nr_b + rbm];
+    const int64_t t = c * 4;
+    if (t < g.T && (double)y.x > o0 + lim) { y.x = (float)o0; atomicAdd(&cnt[t], 1); }
+    if (t + 1 < g.T && (double)y.y > o1 + lim) { y.y = (float)o1; atomicAdd(&cnt[t + 1], 1); }
+    if (t + 2 < g.T && (double)y.z > o2 + lim) { y.z = (float)o2; atomicAdd(&cnt[t + 2], 1); }
+    if (t + 3 < g.T && (double)y.w > o3 + lim) { y.w = (float)o3; atomicAdd(&cnt[t + 3], 1); }
+    bf2[at] = y;
+}
+// Bf = Bf(:, ind_frames) (:66): frame j of the destination is frame sel[j] of the source; frames past nsel are zero padding
+__global__ void __launch_bounds__(256) k_select_frames(const float *__restrict__ src, int64_t Tpad_src, float *__restrict__ dst, int64_t Tpad_dst,
+                                                       const int *__restrict__ sel, int64_t nsel) {
+    const int64_t blk = blockIdx.x, lp = threadIdx.x;
+    for (int64_t c = blockIdx.y; c < (Tpad_dst >> 2); c += gridDim.y) {
+        float v[4];
+        for (int i = 0; i < 4; ++i) {
+            const int64_t j = c * 4 + i;
+            float x = 0.f;
+            if (j < nsel) { const int64_t t = sel[j]; x = src[((blk * (Tpad_src >> 2) + (t >> 2)) * BLKPX + lp) * 4 + (t & 3)]; }
+            v[i] = x;
+        }
+        reinterpret_cast<float4 *>(dst)[(blk * (Tpad_dst >> 2) + c) * BLKPX + lp] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+// quantile(x, q) of the Statistics Toolbox as documented: the sorted values are the (0.5/n), (1.5/n), ... quantiles, linear
+// interpolation between them, the extremes outside
+static double matlab_quantile(std::vector<int> x, double q) {
+    std::sort(x.begin(), x.end());
+    const int64_t n = (int64_t)x.size();
+    const double r = q * (double)n + 0.5;                 // 1-based fractional rank
+    if (r <= 1.0) return x[0];
+    if (r >= (double)n) return x[n - 1];
+    const int64_t lo = (int64_t)std::floor(r);
+    return x[lo - 1] + (r - (double)lo) * (double)(x[lo] - x[lo - 1]);
+}
+
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
-                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only) {
+                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only, double thresh_outlier) {
+    const bool outl = thresh_outlier == thresh_outlier;      // ~isnan(thresh_outlier), :50
+    if (outl && !P->sn_ready && !(b0_only & 1)) return fail(CNMFE_ESTATE, "fit_ring_model with thresh_outlier needs the noise levels of the block (cnmfe_set_noise)");
     const int64_t T = P->T;
     const int p = P->p;
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
@@ -1018,6 +1076,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         kstride = (int)(T / nk);
         if (kstride < 1) kstride = 1;
     }
+    // with a threshold the frames are SELECTED instead (:62-67) and nmax = nnz(ind_frames) = size(Bf, 2) makes k = 1 at :84-85
+    // (also when nmax >= T, where nk = min(T, nmax) = T)
+    if (outl) kstride = 1;
     BgGeom g;
     g.nr = P->nr; g.nc = P->nc; g.nr_b = P->nr_b; g.nc_b = P->nc_b; g.roff = P->roff; g.coff = P->coff;
     g.r0_abs = P->brect[0]; g.c0_abs = P->brect[2]; g.d1 = P->d1; g.d2 = P->d2;
@@ -1033,7 +1094,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     // two ring pixels of one centre are up to 2*p_radius apart along an axis: their 16x16 blocks up to maxd apart (2 for radius <= 16, 3 up to 24)
     const int maxd = (2 * g.p_radius + 15) >> 4, nrel = nrel_of(maxd);
     if (maxd > 3 || g.nbw > 4) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: ring offsets up to %d pixels (the block-pair table covers <= 24)", g.p_radius);
-    bool incr = ctx->opt("gram_incremental", 1) != 0 && K < 32768;   // (derived low-resolution patches of bg_ssub included: their video is built once)
+    bool incr = !outl && ctx->opt("gram_incremental", 1) != 0 && K < 32768;   // the clipped Bf is not linear in the video: direct Gram   // (derived low-resolution patches of bg_ssub included: their video is built once)
     std::vector<int> lst_ptr, lst_k, blk_nt[4];
     std::vector<short> slot_of;
     if (incr) {
@@ -1066,7 +1127,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         }
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
-    g.bf4 = incr ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
+    g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
     const int nblk = g.nbr * g.nbc;
 
@@ -1203,7 +1264,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         CK(hipStreamSynchronize(ctx->stream));
         // incremental: the table of the video alone is built once (fp64 pipe) and kept with the patch; later fits skip B1 / B2a entirely
         DevBuf &covT = incr ? P->cov_base : ctx->cov, &rsT = incr ? P->rowsum_base : ctx->rowsum;
-        const bool f32s = !incr && ctx->opt("gram_mode", 3) >= 2;
+        const bool f32s = !incr && !outl && ctx->opt("gram_mode", 3) >= 2;     // outlier branch: exact fp64 products of the fp32 Bf
         const bool has_a_bf = has_a && !incr;
         if (incr) {
             RET(P->cov_base.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
@@ -1218,6 +1279,33 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         if (g.bf4 == 2) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->stream));
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());
+        if (outl) {
+            // ---- :50-56 clip, :60-67 frame selection ----
+            const size_t bfbytes = (size_t)nblk * g.Tpad * BLKPX * sizeof(float);
+            RET(ctx->bf2.ensure(bfbytes));
+            RET(ctx->outl_cnt.ensure((size_t)T * sizeof(int)));
+            CK(hipMemcpyAsync(ctx->bf2.p, ctx->bf.p, bfbytes, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemsetAsync(ctx->outl_cnt.p, 0, (size_t)T * sizeof(int), ctx->stream));
+            LAUNCH(ctx, "bg_outlier_clip", k_outlier_clip, dim3((unsigned)((P->d + 255) / 256), (unsigned)(g.Tpad >> 2)), dim3(256), 0, ctx->bf.as<float4>(),
+                   ctx->bf2.as<float4>(), g, P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->W.as<float>(), P->sn_b.as<float>(), thresh_outlier,
+                   ctx->outl_cnt.as<int>());
+            std::vector<int> sel;
+            const int64_t nmax = (int64_t)pmax * 100;                       // :61
+            if (nmax < T) {                                                 // :62
+                std::vector<int> cnt((size_t)T);
+                CK(hipMemcpyAsync(cnt.data(), ctx->outl_cnt.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                const double qv = matlab_quantile(cnt, (double)nmax / (double)T);   // :64
+                for (int64_t t = 0; t < T; ++t) if ((double)cnt[t] <= qv) sel.push_back((int)t);
+            } else for (int64_t t = 0; t < T; ++t) sel.push_back((int)t);
+            const int64_t Tpad_src = g.Tpad;
+            g.Tp = (int64_t)sel.size();
+            g.Tpad = (g.Tp + GK - 1) / GK * GK;
+            RET(to_dev(ctx, ctx->outl_sel, sel.data(), sel.size()));
+            LAUNCH(ctx, "bg_select_frames", k_select_frames, dim3(nblk, (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, g.Tpad >> 2))), dim3(256), 0,
+                   ctx->bf2.as<float>(), Tpad_src, ctx->bf.as<float>(), g.Tpad, ctx->outl_sel.as<int>(), g.Tp);
+            CK(hipStreamSynchronize(ctx->stream));                           // `sel` is staged from this scope
+        }
         if (g.bf4 != 2)
             LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, rsT.as<double>(), g.bf4);
 

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <cmath>
 #include <map>
 #include <algorithm>
 #include "../../include/cnmfe.h"
@@ -119,6 +120,8 @@ struct Patch {
     DevBuf W;                          // p x d fp32, offset-major; 0 where the neighbour is outside the FOV
     DevBuf b0;                         // d fp64 (kept in double on the device; the ABI converts)
     bool ring_ready = false;
+    DevBuf sn_b;                       // d_b fp32 noise levels of the block pixels (cnmfe_set_noise): only the outlier branch of the ring fit reads them
+    bool sn_ready = false;
     // the background-subtracted video of this patch, Ysig4[ceil(T/4)][d] float4, as left by the last cnmfe_residual; valid until the
     // video, W or b0 change.  It stays resident per patch: a further cnmfe_residual under the same W, b0 differs from it only by the
     // footprint term (W*A)(C - mean C), whose applied instance is kept beside it (ELL rows + centred traces) -- see residual_run
@@ -154,6 +157,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
+    cnmfe::DevBuf bf2, outl_cnt, outl_sel;   // outlier branch of the ring fit: clipped copy of bf, outliers per frame, kept frames
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
     cnmfe::DevBuf rowsum;     // [blk][256] double
     cnmfe::DevBuf tmp[16];    // small scratch
@@ -191,7 +195,7 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
 
 // implemented in the kernel translation units
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
-                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only = 0);
+                const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only = 0, double thresh_outlier = NAN);
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr, int tables_only = 0);
 int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out_memspace);

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(128) k_hals_spatial(const int *__restrict__ lv
 }
 
 // ---- S4: nnls_spatial.m:26-38 + nnls() :41-109, one thread per pixel, fp64 --------------------------
-constexpr int NN_MAX = 16;
+constexpr int NN_MAX = 32;   // most passive variables (maxN) the kernel is instantiated for; the number of masks over a pixel is unbounded
 __device__ inline bool solve_small(int n, double *M /* n x n row-major, destroyed */, double *b /* in: rhs, out: x */) {
     for (int c = 0; c < n; ++c) {
         int piv = c; double best = fabs(M[c * n + c]);
@@ -90,6 +90,10 @@ __device__ inline bool solve_small(int n, double *M /* n x n row-major, destroye
     return true;
 }
 
+// One outer pass adds at most one variable to the passive set (:84-85) and there are at most maxN passes (:76), so s has at most maxN
+// entries that were ever non-zero: the thread keeps s, b and the passive flag for those "touched" entries only (sorted by position in the
+// pixel's row, which is the order of A(P,P) at :93) and reads everything else -- b from U, the Gram entries from V -- where it lies.
+template <int CAP>
 __global__ void __launch_bounds__(64) k_nnls_spatial(int64_t d, const int *__restrict__ rptr, const int *__restrict__ rcol, const int *__restrict__ rsrc,
                                                      const float *__restrict__ U, const float *__restrict__ V, int K, int maxN, double tol,
                                                      float *__restrict__ Aval) {
@@ -97,33 +101,38 @@ __global__ void __launch_bounds__(64) k_nnls_spatial(int64_t d, const int *__res
     if (m >= d) return;
     const int r0 = rptr[m], n = rptr[m + 1] - r0;
     if (n <= 0) return;
-    double G[NN_MAX * NN_MAX], b[NN_MAX], s[NN_MAX], mu[NN_MAX], Ms[NN_MAX * NN_MAX];
-    bool P[NN_MAX];
-    int idx[NN_MAX];
-    for (int i = 0; i < n; ++i) {
-        b[i] = (double)U[rsrc[r0 + i]];
-        for (int j = 0; j < n; ++j) G[i * n + j] = (double)V[(int64_t)rcol[r0 + i] * K + rcol[r0 + j]];
-        s[i] = 0.0; mu[i] = 0.0;
-    }
+    int tpos[CAP], tcol[CAP], idx[CAP];
+    double ts[CAP], tb[CAP], mu[CAP], Ms[CAP * CAP];
+    bool P[CAP];
+    int nt = 0;
     for (int it = 0; it < maxN; ++it) {                                      // :76
-        double lmax = -1e300; int imax = 0;
+        double lmax = -1e300; int imax = 0, icol = 0; double ib = 0.0;
         for (int i = 0; i < n; ++i) {
-            double l = b[i];
-            for (int j = 0; j < n; ++j) l -= G[i * n + j] * s[j];            // :77
-            P[i] = s[i] > 0.0;                                               // :78
-            if (l > lmax) { lmax = l; imax = i; }                            // first maximum
+            const int ci = rcol[r0 + i];
+            const double bi = (double)U[rsrc[r0 + i]];
+            double l = bi;
+            for (int a = 0; a < nt; ++a) l -= (double)V[(int64_t)ci * K + tcol[a]] * ts[a];   // :77 (the untouched s are exact zeros)
+            if (l > lmax) { lmax = l; imax = i; icol = ci; ib = bi; }        // first maximum
         }
         if (lmax < tol) break;                                               // :80
-        P[imax] = true;                                                      // :85
-        int np = 0; for (int i = 0; i < n; ++i) np += P[i];
+        int np = 0, at = -1;
+        for (int a = 0; a < nt; ++a) { P[a] = ts[a] > 0.0; if (tpos[a] == imax) at = a; }   // :78
+        if (at < 0) {                                                        // keep the touched list in row order
+            at = nt;
+            while (at > 0 && tpos[at - 1] > imax) { tpos[at] = tpos[at - 1]; tcol[at] = tcol[at - 1]; ts[at] = ts[at - 1]; tb[at] = tb[at - 1]; P[at] = P[at - 1]; --at; }
+            tpos[at] = imax; tcol[at] = icol; ts[at] = 0.0; tb[at] = ib; ++nt;
+        }
+        P[at] = true;                                                        // :85
+        for (int a = 0; a < nt; ++a) np += P[a];
         if (np > maxN) break;                                                // :86
         bool have_mu = false;
+        int q = 0;
         while (np > 0) {                                                     // :90
-            int q = 0;
-            for (int i = 0; i < n; ++i) if (P[i]) idx[q++] = i;
-            for (int a = 0; a < q; ++a) { mu[a] = b[idx[a]]; for (int c = 0; c < q; ++c) Ms[a * q + c] = G[idx[a] * n + idx[c]]; }
+            q = 0;
+            for (int a = 0; a < nt; ++a) if (P[a]) idx[q++] = a;
+            for (int a = 0; a < q; ++a) { mu[a] = tb[idx[a]]; for (int c = 0; c < q; ++c) Ms[a * q + c] = (double)V[(int64_t)tcol[idx[a]] * K + tcol[idx[c]]]; }
             if (!solve_small(q, Ms, mu)) {                                   // catch branch :94-96
-                for (int a = 0; a < q; ++a) { mu[a] = b[idx[a]]; for (int c = 0; c < q; ++c) Ms[a * q + c] = G[idx[a] * n + idx[c]] + (a == c ? tol : 0.0); }
+                for (int a = 0; a < q; ++a) { mu[a] = tb[idx[a]]; for (int c = 0; c < q; ++c) Ms[a * q + c] = (double)V[(int64_t)tcol[idx[a]] * K + tcol[idx[c]]] + (a == c ? tol : 0.0); }
                 solve_small(q, Ms, mu);
             }
             have_mu = true;
@@ -131,15 +140,16 @@ __global__ void __launch_bounds__(64) k_nnls_spatial(int64_t d, const int *__res
             for (int a = 0; a < q; ++a) all_pos = all_pos && (mu[a] > tol);
             if (all_pos) break;                                              // :98
             double amin = 1e300;
-            for (int a = 0; a < q; ++a) if (!(mu[a] > tol)) { double v = s[idx[a]] / (s[idx[a]] - mu[a]); if (v < amin) amin = v; }   // :102-104
-            for (int a = 0; a < q; ++a) s[idx[a]] += amin * (mu[a] - s[idx[a]]);   // :105
+            for (int a = 0; a < q; ++a) if (!(mu[a] > tol)) { double v = ts[idx[a]] / (ts[idx[a]] - mu[a]); if (v < amin) amin = v; }   // :102-104
+            for (int a = 0; a < q; ++a) ts[idx[a]] += amin * (mu[a] - ts[idx[a]]);   // :105
             np = 0;
-            for (int i = 0; i < n; ++i) { if (s[i] < tol) P[i] = false; np += P[i]; }   // :106
+            for (int a = 0; a < nt; ++a) { if (ts[a] < tol) P[a] = false; np += P[a]; }   // :106
             have_mu = false;
         }
-        if (have_mu) { int q = 0; for (int i = 0; i < n; ++i) if (P[i]) s[i] = mu[q++]; }   // :109
+        if (have_mu) for (int a = 0; a < q; ++a) ts[idx[a]] = mu[a];         // :109
     }
-    for (int i = 0; i < n; ++i) Aval[rsrc[r0 + i]] = (float)s[i];
+    for (int i = 0; i < n; ++i) Aval[rsrc[r0 + i]] = 0.f;
+    for (int a = 0; a < nt; ++a) Aval[rsrc[r0 + tpos[a]]] = (float)ts[a];
 }
 
 // ---- T1: U(k,t) = sum_e A(e) * Ysig(m_e, t)  (HALS_temporal.m:48) --------------------------------------
@@ -364,10 +374,8 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
         }
     }
     HostCSR csr; csc_to_csr(d, K, IND_colptr, IND_rowidx, nullptr, csr);
-    int maxrow = 0;
-    for (int64_t m = 0; m < d; ++m) maxrow = std::max<int>(maxrow, (int)(csr.rowptr[m + 1] - csr.rowptr[m]));
-    if (algorithm == CNMFE_SPATIAL_NNLS && maxrow > NN_MAX)
-        return fail(CNMFE_EUNSUPPORTED, "a pixel lies in %d search masks; the NNLS kernel supports %d", maxrow, NN_MAX);
+    if (algorithm == CNMFE_SPATIAL_NNLS && ((int)param > NN_MAX || (int)param < 1))
+        return fail(CNMFE_EUNSUPPORTED, "maxN = %d; the NNLS kernel holds 1..%d passive variables", (int)param, NN_MAX);
     std::vector<int32_t> rptr(csr.rowptr.begin(), csr.rowptr.end());
     RET(to_dev(ctx, dColptr, IND_colptr, (size_t)K + 1));
     RET(to_dev(ctx, dErow, IND_rowidx, (size_t)nnz));
@@ -393,8 +401,11 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     CK(hipMemsetAsync(dV.p, 0, (size_t)K * K * sizeof(float), ctx->stream));
     LAUNCH(ctx, "spatial_pair_gram", k_pair_gram, dim3((unsigned)g.pairs.size()), dim3(256), 0, dCc.as<float>(), ldc, T, dPairs.as<int2>(), K, dV.as<float>());
     if (algorithm == CNMFE_SPATIAL_NNLS) {
-        LAUNCH(ctx, "spatial_nnls", k_nnls_spatial, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, d, dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(),
-               dU.as<float>(), dV.as<float>(), K, (int)param, 1e-4, dAval.as<float>());
+        const int maxN = (int)param;
+#define NNLS_GO(CAP) LAUNCH(ctx, "spatial_nnls", k_nnls_spatial<CAP>, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, d, dRptr.as<int>(), dRcol.as<int>(), \
+                            dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K, maxN, 1e-4, dAval.as<float>())
+        if (maxN <= 8) NNLS_GO(8); else if (maxN <= 20) NNLS_GO(20); else NNLS_GO(32);
+#undef NNLS_GO
     } else {
         std::vector<int> flat; std::vector<int> off;
         for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }

@@ -319,14 +319,15 @@ static void a_low(const Patch *S, int ssub, bool nearest, int32_t K, const int64
 }
 
 int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, const int64_t *cp, const int32_t *ri, const float *va,
-             const float *C, int c_order, int with_projection, int64_t info[4]) {
+             const float *C, int c_order, int with_projection, int64_t info[4], double thresh_outlier) {
     std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
     if (K > 0) a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
     // b0 = mean(Y - A*C, 2) on the patch pixels (:222-223) = Ymean - A*mean(C): independent of W, so it goes first (a short, synchronous call)
     RET(bg_fit_ring(ctx, M, K, cp, ri, va, C, c_order, with_projection, nullptr, nullptr, /*b0_only=*/1));
     // W: fit_ring_model(imresize(Y - A*C, 1/s, 'nearest'), [], [], W_old, ...)  (update_background_parallel.m:224-227).  The call returns with the
     // Gram / solve kernels in flight (its host staging has been consumed); the copy of W to the residual patch is ordered behind them.
-    RET(bg_fit_ring(ctx, F, K, K > 0 ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, with_projection, nullptr, info, /*A = [] for ind_active*/ 2));
+    RET(bg_fit_ring(ctx, F, K, K > 0 ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, with_projection, nullptr, info, /*A = [] for ind_active*/ 2,
+                    thresh_outlier));          // sn of the low-resolution block: cnmfe_set_noise on the fit patch (update_background_parallel.m:137)
     if (R && R != F) {
         if (R->p != F->p || R->d != F->d) return fail(CNMFE_ESTATE, "fit / residual low-resolution patches have different rings");
         CK(hipMemcpyAsync(R->W.p, F->W.p, (size_t)F->p * F->d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
@@ -495,11 +496,10 @@ int cnmfe_fit_ring_model_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int r
     Patch *M = get_patch(ctx, patch_id), *F = get_patch(ctx, fit_patch), *R = get_patch(ctx, res_patch);
     if (!M || !F || !R) return fail(CNMFE_ESTATE, "patch %d / %d / %d not created", patch_id, fit_patch, res_patch);
     if (!F->ring_ready || !R->ring_ready || !M->ring_ready) return fail(CNMFE_ESTATE, "rings not initialised");
-    if (thresh_outlier == thresh_outlier) return fail(CNMFE_EUNSUPPORTED, "thresh_outlier must be NaN (fit_ring_model.m:50-56 is not built)");
     if (K < 0) return fail(CNMFE_EINVAL, "K=%d", K);
     if (K > 0) { RET(check_csc_pub("A", K, M->d_b, A_colptr, A_rowidx)); if ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C"); }
     CK(hipSetDevice(ctx->device));
-    return ssub_fit(ctx, M, F, R, ssub, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, info);
+    return ssub_fit(ctx, M, F, R, ssub, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, info, thresh_outlier);
 }
 
 int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssub, int32_t Ksel, const int64_t *A_colptr,

@@ -197,6 +197,12 @@ class Engine:
         b0 = np.ascontiguousarray(b0, dtype=np.float32)
         L.check(L.lib.cnmfe_b0_set(self._ctx, pid, _p(b0, L.f32p)))
 
+    def set_noise(self, pid, sn_block):
+        """sn of the block pixels (update_background_parallel.m:131,137); read by the outlier branch of fit_ring_model only"""
+        sn_block = np.ascontiguousarray(sn_block, dtype=np.float32).ravel()
+        assert sn_block.size == self._patch[pid]["d_b"], (sn_block.size, self._patch[pid]["d_b"])
+        L.check(L.lib.cnmfe_set_noise(self._ctx, pid, _p(sn_block, L.f32p)))
+
     # ---- kernels ----------------------------------------------------------------
     def fit_ring_model(self, pid, A_block, C_block, thresh_outlier=float("nan"), with_projection=True, want_b0=True):
         """[W, b0] = fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection); W stays resident."""

@@ -87,6 +87,15 @@ def distribute_geometry(d1, d2, patch_dims, w_overlap):
     return (nrp, ncp), patch_pos, block_pos
 
 
+def nearest_rows(n, s):
+    """0-based input rows that imresize(., 1/s, 'nearest') keeps along a dimension of length n (box kernel on u = x*s + 0.5*(1 - s), taps
+    mirrored at the border; the same selection the engine's cnmfe_patch_derive makes): ceil(n/s) of them"""
+    x = np.arange(1, -(-n // s) + 1, dtype=np.float64)
+    ind = np.floor(x * s + 0.5 * (1 - s) + 0.5).astype(np.int64)          # 1-based
+    ind = np.where(ind > n, 2 * n + 1 - ind, ind)
+    return ind - 1
+
+
 def _rect_pixels(rect, d1):
     """global column-major pixel indices of a rectangle, in the rectangle's own column-major order"""
     r0, r1, c0, c1 = [int(v) for v in rect]
@@ -506,6 +515,15 @@ class Sources2D:
                 continue
             if not prefetched:                                             # host thread under the first blocking (GIL-free) fit call
                 self._prefetch_search_location(); prefetched = True
+            if not np.isnan(o.thresh_outlier):                             # :131-138: sn of the block, resized for bg_ssub > 1
+                sn_block = np.asarray(self.P["sn"], dtype=np.float32).ravel()[v.block_pix[idx]]
+                if self.ssub == 1:
+                    self.engine.set_noise(v.pid[idx], sn_block)
+                else:
+                    b = v.block_pos[idx]
+                    nr_b, nc_b = int(b[1] - b[0] + 1), int(b[3] - b[2] + 1)
+                    low = sn_block.reshape(nr_b, nc_b, order="F")[np.ix_(nearest_rows(nr_b, self.ssub), nearest_rows(nc_b, self.ssub))] * self.ssub
+                    self.engine.set_noise(self.pid_fit[idx], low.reshape(-1, order="F"))
             if self.ssub == 1:
                 _, infos[idx] = self.engine.fit_ring_model(v.pid[idx], A_block if A_block.shape[1] else None, C_block,
                                                            o.thresh_outlier, o.bg_acceleration, want_b0=False)   # :218

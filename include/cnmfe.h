@@ -102,8 +102,10 @@ int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0 /* d */);
 /* ---- B1/B2: [W, b0] = fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projection)
  * endoscope/fit_ring_model.m:1-127.  Y = the resident block, W_old = the resident W{m}
  * (first-run detection by value inspection of row 1, :25; ind_active, :28; frame stride k,
- * :60,84-87).  A is d_b x K CSC (block rows), C is K x T.  thresh_outlier must be NaN
- * (the outlier branch :50-56 is dead in every demo; anything else -> CNMFE_EUNSUPPORTED).
+ * :60,84-87).  A is d_b x K CSC (block rows), C is K x T.  thresh_outlier = NaN is what every demo runs.  A finite value takes the
+ * outlier branch (:50-56: entries of the patch rows above W_old*Bf + thresh_outlier*sn are replaced by W_old*Bf; :62-67: only the frames
+ * with at most the nmax/T quantile of outliers are regressed on) -- it needs the noise levels of the block (cnmfe_set_noise, else
+ * CNMFE_ESTATE) and computes the Gram of the clipped residual directly (the kept video table does not apply); info[1] is 1 then.
  * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels, info[3]=pmax (known before the heavy kernels start).
  * With b0_out == NULL the call returns while the Gram / solve kernels are still running on the context's stream; every later
  * call on this context is ordered behind them and reports their errors.
@@ -115,6 +117,10 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
                          const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                          double thresh_outlier, int with_projection,
                          float *b0_out /* d or NULL */, int64_t info[4]);
+
+/* sn of the BLOCK pixels of a patch (obj.P.sn(logical(mask)), update_background_parallel.m:131; for a low-resolution fit patch of
+ * bg_ssub > 1 the resized values of :137).  Only the outlier branch of the ring fit reads them. */
+int cnmfe_set_noise(cnmfe_ctx *ctx, int patch_id, const float *sn_block /* d_b */);
 
 /* ---- bg_ssub > 1: the ring model on a spatially downsampled block
  * W lives on the ceil(nr_b/s) x ceil(nc_b/s) grid with ring radius ceil(r/s)  (@Sources2D/initComponents_parallel.m:214,237-251).

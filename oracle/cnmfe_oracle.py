@@ -227,8 +227,7 @@ def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projectio
     """[W, b0] = fit_ring_model(...).  endoscope/fit_ring_model.m:1-127.
 
     Y: d_b x T, A: d_b x K (dense or sparse), C: K x T, W_old: sparse d x d_b.
-    The outlier branch (:50-56, :62-67) is implemented for NaN thresh only
-    (no demo sets thresh_outlier) and raises otherwise.
+    With a finite thresh_outlier the outlier branch (:50-56) and the frame selection (:62-67) run (no demo sets it).
     only_rows (test harness only, not in the reference): regress just these patch pixels -- the per-pixel regressions of :92-108 are
     independent, so a sample of rows of W at a size where all of them would take hours; the other rows keep W_old.
     """
@@ -262,11 +261,21 @@ def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projectio
     Cc = C - Cmean[:, None]                                  # :46
     Bf = Yc - A @ Cc                                         # :47
 
-    if not np.isnan(thresh_outlier):
-        raise NotImplementedError("outlier branch (fit_ring_model.m:50-56) not restated")
+    outl = not np.isnan(thresh_outlier)
+    if outl:                                                 # :50
+        Bf_old = W_old @ Bf                                  # :51
+        tmp_Bf = Bf[ind_patch, :]                            # :52
+        ind_outlier = tmp_Bf > Bf_old + thresh_outlier * np.asarray(sn, dtype=np.float64).reshape(-1, 1)   # :53
+        tmp_Bf[ind_outlier] = Bf_old[ind_outlier]            # :54
+        Bf[ind_patch, :] = tmp_Bf                            # :55
 
     pmax = int(np.max(np.asarray((W_old > 0).sum(axis=1)).ravel()))          # :60
     nmax = pmax * 100                                        # :61
+    if outl and nmax < T:                                    # :62
+        temp = ind_outlier.sum(axis=0)                       # :63 (column sums: outliers per frame)
+        ind_frames = temp <= matlab_quantile(temp, nmax / T)  # :64
+        nmax = int(ind_frames.sum())                         # :65
+        Bf = Bf[:, ind_frames]                               # :66
     ind_pixels = np.nonzero(ind_patch)[0]                    # :71
     d = ind_pixels.size
     W = W_old.copy().tolil()
@@ -295,6 +304,21 @@ def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projectio
         new_data[pos] = w[:-1] + 1e-100                      # :107
     W = sp.csr_matrix((new_data, indices.copy(), indptr.copy()), shape=W_old.shape)
     return W, b0
+
+
+def matlab_quantile(x, p):
+    """quantile(x, p) of the Statistics Toolbox for a vector (a MathWorks function, not in the repository; restated from its documented
+    definition: the sorted values are the 0.5/n, 1.5/n, ..., (n-0.5)/n quantiles, linear interpolation between them, the minimum /
+    maximum outside).  Used at fit_ring_model.m:64.  PARITY UNPINNED."""
+    x = np.sort(np.asarray(x, dtype=np.float64).ravel())
+    n = x.size
+    r = p * n + 0.5                                          # 1-based fractional rank
+    if r <= 1:
+        return x[0]
+    if r >= n:
+        return x[-1]
+    lo = int(np.floor(r))
+    return x[lo - 1] + (r - lo) * (x[lo] - x[lo - 1])
 
 
 def ring_frame_stride(W_old, T, with_projection=True):
@@ -582,8 +606,9 @@ class OracleSources2D:
 
     def __init__(self, Yfull, d1, d2, T, patch_dims, ring_radius, A, C, sn, *,
                  spatial_algorithm="hals", maxIter=5, num_neighbors=None,
-                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1, deconv_options=None):
+                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1, deconv_options=None, thresh_outlier=np.nan):
         self.bg_ssub = int(bg_ssub)
+        self.thresh_outlier = thresh_outlier
         self.deconv_options = deconv_options       # None: options.deconv_flag = false; a dict: the keyword arguments of oasis_oracle
         self.Y = Yfull
         self.d1, self.d2, self.T = d1, d2, T
@@ -670,7 +695,7 @@ class OracleSources2D:
             Yb = self._block(b)                              # :208
             sn_patch = self.sn.reshape(-1, order="F")[mask][ip]
             if self.bg_ssub == 1:
-                self.W[idx], self.b0[idx] = fit_ring_model(Yb, A_block, C_block, self.W[idx], np.nan,
+                self.W[idx], self.b0[idx] = fit_ring_model(Yb, A_block, C_block, self.W[idx], self.thresh_outlier,
                                                            sn_patch, ip, self.bg_acceleration)   # :218
             else:                                            # :219-230
                 nr_b, nc_b = int(b[1] - b[0] + 1), int(b[3] - b[2] + 1)
@@ -678,7 +703,10 @@ class OracleSources2D:
                 self.b0[idx] = temp.mean(axis=1)[ip]                                                            # :222-223
                 low = imresize_scale(temp.reshape(nr_b, nc_b, self.T, order="F"), 1.0 / self.bg_ssub, "nearest")  # :224
                 low = low.reshape(-1, self.T, order="F")
-                self.W[idx], _ = fit_ring_model(low, None, None, self.W[idx], np.nan, None, None, self.bg_acceleration)   # :227
+                sn_low = imresize_scale(self.sn.reshape(-1, order="F")[mask].reshape(nr_b, nc_b, order="F"), 1.0 / self.bg_ssub,
+                                        "nearest") * self.bg_ssub                                              # :137
+                self.W[idx], _ = fit_ring_model(low, None, None, self.W[idx], self.thresh_outlier, sn_low.reshape(-1, order="F"), None,
+                                                self.bg_acceleration)                                          # :227
         self.b0_new = self.reconstruct_b0()                  # :315
         self.A_prev = self.A.copy()                          # :316
         self.C_prev = self.C.copy()                          # :317

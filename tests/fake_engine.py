@@ -43,10 +43,14 @@ class FakeEngine:
     def b0(self, pid):
         return self.p[pid]["b0"]
 
+    def set_noise(self, pid, sn_block):
+        self.p[pid]["sn_b"] = np.asarray(sn_block, dtype=np.float64).ravel()
+
     def fit_ring_model(self, pid, A_block, C_block, thresh_outlier=float("nan"), with_projection=True, want_b0=True):
         q = self.p[pid]
         A = None if A_block is None else sp.csc_matrix(A_block).astype(np.float64)
-        W, b0 = orc.fit_ring_model(q["Y"].T, A, C_block, q["W"], thresh_outlier, None, q["ip"], with_projection)
+        W, b0 = orc.fit_ring_model(q["Y"].T, A, C_block, q["W"], thresh_outlier,
+                                   q["sn_b"][q["ip"]] if "sn_b" in q else None, q["ip"], with_projection)
         q["W"], q["b0"] = W.tocsr(), b0
         return b0, {}
 

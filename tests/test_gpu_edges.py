@@ -546,3 +546,80 @@ def test_stitch_temporal_through_the_abi_with_rccl(eng, monkeypatch):
     assert np.array_equal(c_bound[1], c_plain[1])
     with pytest.raises(L.CnmfeError):
         eng.stitch_add(np.arange(2))                                     # no open accumulator any more
+
+
+@pytest.mark.parametrize("maxN", [3, 20, 27])
+def test_nnls_crowded_pixels(eng, maxN):
+    """nnls_spatial.m:35-37 puts no bound on how many search masks cover a pixel; only the passive set is bounded (maxIter = maxN, :76,:86).
+    30 neurons share one neighbourhood, so the central pixels lie in up to 30 masks (more than the demo's maxN = 20)."""
+    import cnmfe_oracle as orc
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2, T, K, r = 32, 32, 500, 30, 5
+    rng = np.random.default_rng(41)
+    f = synth.make_factors(d1, d2, T, K, 41, gSig=2.5, gSiz=11, min_sep=1)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    pid = video.pid[video.order[0]]
+    eng.ring_init(pid, r)
+    eng.fit_ring_model(pid, None, None)
+    ysig = eng.residual(pid, None, None, want=True).T.astype(np.float64)
+    yy, xx = np.mgrid[:d1, :d2]
+    IND = np.zeros((d1 * d2, K), bool)
+    for k in range(K):                                    # a disc of radius 9..12 around a centre near the middle of the FOV
+        cy, cx = rng.uniform(12, 20, 2)
+        IND[:, k] = (((yy - cy) ** 2 + (xx - cx) ** 2) <= rng.uniform(9, 12) ** 2).ravel(order="F")
+    assert IND.sum(axis=1).max() > 20
+    INDs = sp.csc_matrix(IND)
+    C = f.C_true.astype(np.float32) if hasattr(f, "C_true") else f.C_init
+    A0 = sp.csc_matrix((d1 * d2, K), dtype=np.float32)
+    got = eng.update_spatial(pid, "nnls", A0, C, INDs, f.sn, maxN).toarray()
+    ref = orc.nnls_spatial(ysig, A0, C, INDs, maxN)
+    assert ((ref != 0).sum(axis=1) <= maxN).all()
+    # a variable that leaves the passive set keeps s + a*(mu - s) with a = s/(s - mu) (:102-106): zero up to rounding, i.e. 0 or ~1e-17 of the
+    # pixel's weights depending on the order of operations -- the only entries whose support may differ
+    mism = (got != 0) != (ref != 0)
+    assert np.all(np.abs(np.where(mism, got, 0)) + np.abs(np.where(mism, ref, 0)) <= 1e-9 * np.abs(ref).max()), np.abs(got - ref)[mism].max()
+    assert mism.sum() <= 0.01 * (ref != 0).sum(), mism.sum()
+    assert rel(got, ref) <= 5e-6, rel(got, ref)
+
+
+@pytest.mark.parametrize("pdims,r,T,thr", [(None, 4, 3072, 1.5), ([24, 40], 5, 1024, 0.5), (None, 7, 1024, 2.0)])
+def test_outlier_branch_with_exact_decisions(eng, pdims, r, T, thr):
+    """fit_ring_model.m:50-67 (thresh_outlier not NaN): clip the patch rows of Bf at W_old*Bf + thresh*sn, keep the frames with few outliers.
+    The `>` of :53 is a discrete decision, so this video is built to make the engine's fp32 Bf EXACT (8-bit integers, T a multiple of 1024:
+    the pixel means and the centred values fit a float32 mantissa; no footprints) -- every decision then matches the float64 oracle and W
+    agrees as tightly as in the linear branch.  Case 1 selects frames (24 offsets -> nmax = 2400 < T), the others keep them all; case 2 has
+    patches smaller than their blocks (ind_patch).  Two fits: ring pattern as W_old, then the fitted weights as W_old."""
+    import cnmfe_oracle as orc
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2 = 48, 40
+    rng = np.random.default_rng(5)
+    base = rng.integers(100, 200, (1, d1 * d2))
+    drift = (40 * np.sin(np.arange(T) / 37.0)[:, None] * rng.uniform(0.5, 1.5, (1, d1 * d2))).astype(np.int64)
+    Y = (base + drift + rng.integers(0, 60, (T, d1 * d2))).astype(np.float32)
+    Y[rng.random((T, d1 * d2)) < 0.02] += 90.0                              # sparse positive events: what the branch is meant to clip
+    assert Y.min() >= 0 and Y.max() < 512 and T % 1024 == 0
+    sn = rng.uniform(5.0, 15.0, d1 * d2).astype(np.float32)
+    video = PatchedVideo(d1, d2, T, pdims or [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    for idx in video.order:
+        pid, bp = video.pid[idx], video.block_pix[idx]
+        ip = np.zeros(bp.size, dtype=bool); ip[video.ind_patch[idx]] = True
+        eng.ring_init(pid, r)
+        eng.set_noise(pid, sn[bp])
+        Yb = Y[:, bp].T.astype(np.float64)
+        for fit in range(2):
+            W_old = eng.ring_csr(pid)
+            _, info = eng.fit_ring_model(pid, None, None, thresh_outlier=thr)
+            assert info["frame_stride"] == 1 and info["first_run"] == (fit == 0)
+            Wr, b0r = orc.fit_ring_model(Yb, None, None, W_old, thr, sn[bp][ip], ip, True)
+            Wg = eng.ring_csr(pid); Wr = sp.csr_matrix(Wr); Wr.sort_indices()
+            assert np.array_equal(Wg.indices, Wr.indices)
+            e = rel(Wg.data, Wr.data)
+            assert e <= 2e-6, (idx, fit, e)
+    with pytest.raises(Exception, match="cnmfe_set_noise"):                 # a fresh patch without noise levels: CNMFE_ESTATE
+        v2 = PatchedVideo(d1, d2, T, [d1, d2], r, eng); v2.upload_from_full(Y)
+        eng.ring_init(v2.pid[v2.order[0]], r)
+        eng.fit_ring_model(v2.pid[v2.order[0]], None, None, thresh_outlier=thr)

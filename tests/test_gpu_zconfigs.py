@@ -40,7 +40,8 @@ def _support_report(Ag, Ar, thr=None):
     return int(mism.sum()), int(off.sum()), rel(Ag[both], Ar[both]), int(nr.sum())
 
 
-@pytest.mark.parametrize("name", ["m128_hals", "m128_hals_thresh", "m128_nnls", "m128_ssub2", "m128_deconv", "m128_2x2", "m96_r18", "c2_crop64"])
+@pytest.mark.parametrize("name", ["m128_hals", "m128_hals_thresh", "m128_nnls", "m128_ssub2", "m128_deconv", "m128_2x2", "m96_r18", "c2_crop64",
+                                  "m64_outlier", "m64_outlier_all", "m64_outlier_ssub2"])
 def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
     cfg = oj.JOBS[name]
@@ -48,7 +49,8 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
     T, r = cfg["T"], cfg["r"]
     video = PatchedVideo(d1, d2, T, cfg.get("patch") or [d1, d2], r, eng)
     video.upload_from_full(Y)
-    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=cfg["alg"], maxIter=5, bg_ssub=cfg.get("bg_ssub", 1), deconv_flag=bool(cfg.get("deconv"))), A, C, sn)
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=cfg["alg"], maxIter=5, bg_ssub=cfg.get("bg_ssub", 1), deconv_flag=bool(cfg.get("deconv")),
+                                  thresh_outlier=cfg.get("thresh_outlier", float("nan"))), A, C, sn)
     first = video.order[0]
     rows = oj.sample_rows(cfg, video.patch_pix[first].size)
     got = {}
@@ -71,13 +73,26 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
     # Tolerances = <= 10x the errors observed on MI355X (gpurun_out/parity_observed.json), far inside SURVEY 8(c)'s
     # 1e-3 (W) / 1e-4 (Ysig, U, C).  With deconv_flag the first iteration's traces already differ by the discrete OASIS decisions (worst trace
     # 1.6e-3, median 5e-5), and everything the second iteration computes inherits that: `loose` scales its tolerances.
+    # With thresh_outlier the fit starts with a DISCRETE decision per entry of Bf (fit_ring_model.m:53, `>` against W_old*Bf + thresh*sn).  The
+    # engine's centred video is fp32 (|error| ~ 3e-5 on values ~1e3), so a handful of the d*T comparisons fall the other way; each moves one
+    # entry of Bf by ~thresh*sn, i.e. the covariances of that pixel by ~thresh/T relative, and with them the rows of W whose ring holds it.
+    # So: most weights agree like everywhere else (one flipped entry reaches the p + 1 rows around it), the rest within a few thresh/T;
+    # later stages inherit that.  tests/test_gpu_edges.py::test_outlier_branch_with_exact_decisions pins the branch itself on a video whose
+    # fp32 representation is exact.
+    outl = "thresh_outlier" in cfg
     for it in range(cfg["iters"]):
-        loose = 1e4 if (deconv and it) else 1.0
+        loose = 1e4 if (deconv and it) else 1e3 if outl else 1.0
         # ---- background ----
         for idx in video.order:
             k = "W_%d_%d_%d" % (it, idx[0], idx[1])
             e = rel(got[k], ref[k]); obs[k] = e
-            assert got[k].shape == ref[k].shape and e <= 2e-6 * loose, (name, k, e)
+            assert got[k].shape == ref[k].shape
+            if outl:
+                ee = np.abs(got[k] - ref[k]) / np.abs(ref[k]).max()
+                frac = float((ee > 2e-6 * (1 if not it else 50)).mean()); obs[k + "_frac_off"] = frac
+                assert frac <= 0.25 and e <= 10 * cfg["thresh_outlier"] / T, (name, k, frac, e)
+                continue
+            assert e <= 2e-6 * loose, (name, k, e)
             k = "b0_%d_%d_%d" % (it, idx[0], idx[1])
             e = float(np.abs(got[k] - ref[k]).max()); obs[k] = e
             assert e <= 5e-4 * min(loose, 100), (name, k, e)              # b0 ~ 1e3 stored in fp32: 6e-5 is one ulp
@@ -103,7 +118,7 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
         if not deconv:
             for k in ("C_%d" % it, "C_raw_%d" % it):
                 e = rel(got[k], ref[k]); obs[k] = e
-                assert e <= 5e-6, (name, k, e)
+                assert e <= 5e-6 * min(loose, 100), (name, k, e)
         else:
             # OASIS is a discrete active-set method: a pool boundary may move by a frame when a comparison falls within fp32 rounding
             er = [rel(got["C_raw_%d" % it][j], ref["C_raw_%d" % it][j]) for j in range(C.shape[0])]
