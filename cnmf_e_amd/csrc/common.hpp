@@ -156,6 +156,8 @@ struct cnmfe_ctx {
     int64_t last_ldc = 0;     // row stride of the centred traces the last residual_run left in tmp[1]
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
+    cnmfe::DevBuf bgs_r, bgs_b, bgs_upr, bgs_upc;   // bg_ssub > 1, reconstruct_background / compute_RSS: R_low, W*R_low, replication maps
+    int bgs_patch = -1, bgs_d1s = 0; int64_t bgs_dF = 0;   // the patch bgs_b belongs to (cnmfe_background_ssub)
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
     cnmfe::DevBuf bf2, outl_cnt, outl_sel;   // outlier branch of the ring fit: clipped copy of bf, outliers per frame, kept frames
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)

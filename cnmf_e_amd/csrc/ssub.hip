@@ -321,6 +321,7 @@ static void a_low(const Patch *S, int ssub, bool nearest, int32_t K, const int64
 int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, const int64_t *cp, const int32_t *ri, const float *va,
              const float *C, int c_order, int with_projection, int64_t info[4], double thresh_outlier) {
     std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
+    ctx->bgs_patch = -1;                                   // W changes: a kept W*R_low (cnmfe_background_ssub) is stale
     if (K > 0) a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
     // b0 = mean(Y - A*C, 2) on the patch pixels (:222-223) = Ymean - A*mean(C): independent of W, so it goes first (a short, synchronous call)
     RET(bg_fit_ring(ctx, M, K, cp, ri, va, C, c_order, with_projection, nullptr, nullptr, /*b0_only=*/1));
@@ -474,6 +475,174 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     return 0;
 }
 
+
+// ---- reconstruct_background / compute_RSS with bg_ssub > 1 (Sources2D.m:1325-1334, :1479-1486) -------------------------------------
+// Unlike the update methods (bicubic), these two resize with 'nearest' both ways:
+//   Bf = up( W * down(Y_block - b0_block - A_prev*C_prev) ),  down = pixel selection, up = pixel replication,
+// so on the fit patch (whose resident video IS down(Y - Ymean)) it is three plain kernels: R_low = Yc_F + (Ymean - b0_block)[sel] -
+// down(A_prev)*C_prev, B_low = W*R_low, and a sweep of the patch pixels that looks its low pixel up.  B_low stays with the context until
+// the next call; neither function is on the path of the iteration.
+__global__ void __launch_bounds__(256) k_bgs_rlow(const float4 *__restrict__ ycF, int64_t dF, const float *__restrict__ ymeanF, const float *__restrict__ b0low,
+                                                  const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
+                                                  const float *__restrict__ C, int64_t ldc, float4 *__restrict__ R) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (q >= dF) return;
+    float4 v = ycF[c * dF + q];
+    const float k = ymeanF[q] - b0low[q];
+    v.x += k; v.y += k; v.z += k; v.w += k;
+    if (arow)
+        for (int e = arow[q]; e < arow[q + 1]; ++e) {
+            const float a = aval[e];
+            const float4 t = *reinterpret_cast<const float4 *>(C + (int64_t)acol[e] * ldc + 4 * c);
+            v.x = fmaf(-a, t.x, v.x); v.y = fmaf(-a, t.y, v.y); v.z = fmaf(-a, t.z, v.z); v.w = fmaf(-a, t.w, v.w);
+        }
+    R[c * dF + q] = v;
+}
+__global__ void __launch_bounds__(256) k_bgs_wr(const float4 *__restrict__ R, int64_t dF, int d1s, int d2s, int p, const int *__restrict__ dr, const int *__restrict__ dc,
+                                                const float *__restrict__ W, float4 *__restrict__ B) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (m >= dF) return;
+    const int r0 = (int)(m % d1s), c0 = (int)(m / d1s);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int i = 0; i < p; ++i) {
+        const float w = W[(int64_t)i * dF + m];
+        const int rr = r0 + dr[i], cc = c0 + dc[i];
+        if (w == 0.f || rr < 0 || rr >= d1s || cc < 0 || cc >= d2s) continue;
+        const float4 v = R[c * dF + (int64_t)cc * d1s + rr];
+        a0 += (double)w * v.x; a1 += (double)w * v.y; a2 += (double)w * v.z; a3 += (double)w * v.w;
+    }
+    B[c * dF + m] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+}
+__global__ void __launch_bounds__(256) k_bgs_out(const float4 *__restrict__ B, int64_t dF, int d1s, const int *__restrict__ upr, const int *__restrict__ upc,
+                                                 int64_t d, int nr, int roff, int coff, const float *__restrict__ b0new, int64_t frame0, float *__restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= d) return;
+    const int64_t u = (int64_t)upc[(int)(m / nr) + coff] * d1s + upr[(int)(m % nr) + roff];
+    const int64_t t = frame0 + blockIdx.y;
+    out[(int64_t)blockIdx.y * d + m] = reinterpret_cast<const float *>(B + (t >> 2) * dF + u)[t & 3] + b0new[m];
+}
+// sum((Y(patch) - A*C - (Bf + b0_new)).^2): one thread per patch pixel and segment of frames
+__global__ void __launch_bounds__(256) k_bgs_rss(const float4 *__restrict__ B, int64_t dF, int d1s, const int *__restrict__ upr, const int *__restrict__ upc,
+                                                 const float4 *__restrict__ ycM, int64_t d_b, int nr_b, const float *__restrict__ ymeanM, int64_t d, int nr, int roff, int coff,
+                                                 const float *__restrict__ b0new, const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
+                                                 const float *__restrict__ C, int64_t ldc, int64_t T, int64_t Tc, int64_t cseg, double *__restrict__ partial) {
+    __shared__ double red[4];
+    const int64_t m0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = m0 < d;
+    const int64_t m = valid ? m0 : d - 1;
+    const int rb = (int)(m % nr) + roff, cb = (int)(m / nr) + coff;
+    const int64_t q = (int64_t)cb * nr_b + rb, u = (int64_t)upc[cb] * d1s + upr[rb];
+    const float k = ymeanM[q] - b0new[m];
+    const int e0 = arow ? arow[m] : 0, e1 = arow ? arow[m + 1] : 0;
+    const int64_t c0 = (int64_t)blockIdx.y * cseg, c1 = c0 + cseg < Tc ? c0 + cseg : Tc;
+    double acc = 0.0;
+    for (int64_t c = c0; c < c1; ++c) {
+        const float4 y = ycM[c * d_b + q], b = B[c * dF + u];
+        float4 r = make_float4(y.x + k - b.x, y.y + k - b.y, y.z + k - b.z, y.w + k - b.w);
+        for (int e = e0; e < e1; ++e) {
+            const float a = aval[e];
+            const float4 t = *reinterpret_cast<const float4 *>(C + (int64_t)acol[e] * ldc + 4 * c);
+            r.x = fmaf(-a, t.x, r.x); r.y = fmaf(-a, t.y, r.y); r.z = fmaf(-a, t.z, r.z); r.w = fmaf(-a, t.w, r.w);
+        }
+        if (valid) {
+            const int64_t t0 = 4 * c;
+            acc += (double)r.x * r.x;
+            if (t0 + 1 < T) acc += (double)r.y * r.y;
+            if (t0 + 2 < T) acc += (double)r.z * r.z;
+            if (t0 + 3 < T) acc += (double)r.w * r.w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+static std::vector<int> nearest_sel(const Taps &t) {          // the one source index a 'nearest' tap row keeps
+    std::vector<int> s((size_t)t.n_out, 0);
+    for (int o = 0; o < t.n_out; ++o) for (int i = 0; i < t.P; ++i) if (t.w[(size_t)o * t.P + i] != 0.f) s[o] = t.idx[(size_t)o * t.P + i];
+    return s;
+}
+
+int ssub_background(cnmfe_ctx *ctx, Patch *M, int pid, Patch *F, int ssub, int32_t K, const int64_t *cp, const int32_t *ri, const float *va,
+                    const float *C, int c_order, const float *b0_block) {
+    int d1s, d2s; low_dims(M, ssub, d1s, d2s);
+    if (F->d1 != d1s || F->d2 != d2s || F->T != M->T) return fail(CNMFE_ESTATE, "the fit patch is not the low-resolution patch of patch %d", pid);
+    ctx->bgs_patch = -1;
+    const int64_t dF = F->d;
+    DevBuf &dC = ctx->tmp[0], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5], &dB0 = ctx->tmp[6];
+    const bool has_a = K > 0 && cp[K] > 0;
+    int64_t ldc = 4;
+    if (has_a) {
+        std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
+        a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
+        RET(upload_traces(ctx, dC, C, K, M->T, c_order, &ldc));
+        HostCSR csr; csc_to_csr(dF, K, ocp.data(), ori.data(), ova.data(), csr);
+        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
+        RET(to_dev(ctx, dArow, rp.data(), rp.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    const std::vector<int> sr = nearest_sel(make_taps(M->nr_b, d1s, 1.0 / ssub, true)), sc = nearest_sel(make_taps(M->nc_b, d2s, 1.0 / ssub, true));
+    std::vector<float> b0low((size_t)dF);
+    for (int co = 0; co < d2s; ++co) for (int ro = 0; ro < d1s; ++ro) b0low[(size_t)co * d1s + ro] = b0_block[(size_t)sc[co] * M->nr_b + sr[ro]];
+    RET(to_dev(ctx, dB0, b0low.data(), b0low.size()));
+    // up = imresize(., [nr_block nc_block], 'nearest'): the low pixel every block row / column replicates (:1329, :1483)
+    const std::vector<int> ur = nearest_sel(make_taps(d1s, M->nr_b, (double)M->nr_b / d1s, true)), uc = nearest_sel(make_taps(d2s, M->nc_b, (double)M->nc_b / d2s, true));
+    RET(to_dev(ctx, ctx->bgs_upr, ur.data(), ur.size())); RET(to_dev(ctx, ctx->bgs_upc, uc.data(), uc.size()));
+    RET(ctx->bgs_r.ensure((size_t)dF * F->Tc * sizeof(float4))); RET(ctx->bgs_b.ensure((size_t)dF * F->Tc * sizeof(float4)));
+    dim3 grid((unsigned)((dF + 255) / 256), (unsigned)F->Tc);
+    LAUNCH(ctx, "bgs_rlow", k_bgs_rlow, grid, dim3(256), 0, F->Yc4.as<float4>(), dF, F->ymean_f.as<float>(), dB0.as<float>(), has_a ? dArow.as<int>() : nullptr,
+           dAcol.as<int>(), dAval.as<float>(), dC.as<float>(), ldc, ctx->bgs_r.as<float4>());
+    LAUNCH(ctx, "bgs_wr", k_bgs_wr, grid, dim3(256), 0, ctx->bgs_r.as<float4>(), dF, d1s, d2s, F->p, F->ring_dr.as<int>(), F->ring_dc.as<int>(), F->W.as<float>(),
+           ctx->bgs_b.as<float4>());
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->bgs_patch = pid; ctx->bgs_d1s = d1s; ctx->bgs_dF = dF;
+    return 0;
+}
+
+int ssub_bg_out(cnmfe_ctx *ctx, Patch *M, const float *b0_new, int64_t frame0, int64_t nframes, float *out, int out_memspace) {
+    DevBuf &dB0n = ctx->tmp[7];
+    RET(to_dev(ctx, dB0n, b0_new, (size_t)M->d));
+    float *dst = out;
+    if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)M->d * nframes * sizeof(float))); dst = ctx->stage.as<float>(); }
+    LAUNCH(ctx, "bgs_out", k_bgs_out, dim3((unsigned)((M->d + 255) / 256), (unsigned)nframes), dim3(256), 0, ctx->bgs_b.as<float4>(), ctx->bgs_dF, ctx->bgs_d1s,
+           ctx->bgs_upr.as<int>(), ctx->bgs_upc.as<int>(), M->d, M->nr, M->roff, M->coff, dB0n.as<float>(), frame0, dst);
+    if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)M->d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ssub_rss(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *cp, const int32_t *ri, const float *va, const float *C, int c_order, const float *b0_new,
+             double *rss_out) {
+    DevBuf &dC = ctx->tmp[0], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5], &dB0n = ctx->tmp[7], &dPart = ctx->tmp[13];
+    const bool has_a = K > 0 && cp[K] > 0;
+    int64_t ldc = 4;
+    if (has_a) {
+        RET(upload_traces(ctx, dC, C, K, M->T, c_order, &ldc));
+        HostCSR csr; csc_to_csr(M->d, K, cp, ri, va, csr);
+        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
+        RET(to_dev(ctx, dArow, rp.data(), rp.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    RET(to_dev(ctx, dB0n, b0_new, (size_t)M->d));
+    const int64_t nblk = (M->d + 255) / 256;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(M->Tc, (8192 + nblk - 1) / nblk));
+    const int64_t cseg = (M->Tc + nseg - 1) / nseg;
+    nseg = (M->Tc + cseg - 1) / cseg;
+    RET(dPart.ensure((size_t)nblk * nseg * sizeof(double)));
+    LAUNCH(ctx, "bgs_rss", k_bgs_rss, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, ctx->bgs_b.as<float4>(), ctx->bgs_dF, ctx->bgs_d1s, ctx->bgs_upr.as<int>(),
+           ctx->bgs_upc.as<int>(), M->Yc4.as<float4>(), M->d_b, M->nr_b, M->ymean_f.as<float>(), M->d, M->nr, M->roff, M->coff, dB0n.as<float>(),
+           has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dC.as<float>(), ldc, M->T, M->Tc, cseg, dPart.as<double>());
+    std::vector<double> part((size_t)nblk * nseg);
+    CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    double s_ = 0.0;
+    for (double v : part) s_ += v;
+    *rss_out = s_;
+    return 0;
+}
+
 }  // namespace cnmfe
 
 using namespace cnmfe;
@@ -513,4 +682,40 @@ int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssu
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, M));
     return ssub_residual(ctx, M, patch_id, R, res_patch, ssub, Ksel, A_colptr, A_rowidx, A_val, C, c_order, Ysig_out, out_memspace);
+}
+
+int cnmfe_background_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int32_t ssub, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                          const float *A_val, const float *C, int c_order, const float *b0_block) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *M = get_patch(ctx, patch_id), *F = get_patch(ctx, fit_patch);
+    if (!M || !F) return fail(CNMFE_ESTATE, "patch %d / %d not created", patch_id, fit_patch);
+    if (!F->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", fit_patch);
+    if (K < 0 || !b0_block) return fail(CNMFE_EINVAL, "K=%d / null b0_block", K);
+    if (K > 0) { RET(check_csc_pub("A_prev", K, M->d_b, A_colptr, A_rowidx)); if ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C"); }
+    CK(hipSetDevice(ctx->device));
+    RET(ensure_ymean(ctx, M));
+    return ssub_background(ctx, M, patch_id, F, ssub, K, A_colptr, A_rowidx, A_val, C, c_order, b0_block);
+}
+
+int cnmfe_reconstruct_background_ssub(cnmfe_ctx *ctx, int patch_id, const float *b0_new, int64_t frame0, int64_t nframes, float *Ybg_out, int out_memspace) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *M = get_patch(ctx, patch_id);
+    if (!M) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->bgs_patch != patch_id) return fail(CNMFE_ESTATE, "cnmfe_background_ssub has not been run for patch %d", patch_id);
+    if (!b0_new || !Ybg_out) return fail(CNMFE_EINVAL, "null b0_new / Ybg_out");
+    if (frame0 < 0 || nframes <= 0 || frame0 + nframes > M->T || nframes > 65535) return fail(CNMFE_EINVAL, "frames [%lld, %lld) outside [0, %lld) or more than 65535 at once", (long long)frame0, (long long)(frame0 + nframes), (long long)M->T);
+    CK(hipSetDevice(ctx->device));
+    return ssub_bg_out(ctx, M, b0_new, frame0, nframes, Ybg_out, out_memspace);
+}
+
+int cnmfe_compute_rss_ssub(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C,
+                           int c_order, const float *b0_new, double *rss_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *M = get_patch(ctx, patch_id);
+    if (!M) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (ctx->bgs_patch != patch_id) return fail(CNMFE_ESTATE, "cnmfe_background_ssub has not been run for patch %d", patch_id);
+    if (K < 0 || !b0_new || !rss_out) return fail(CNMFE_EINVAL, "bad K / null b0_new / rss_out");
+    if (K > 0) { RET(check_csc_pub("A", K, M->d, A_colptr, A_rowidx)); if ((!A_val && A_colptr[K] > 0) || (!C && c_order != CNMFE_BOUND)) return fail(CNMFE_EINVAL, "null A_val / C"); }
+    CK(hipSetDevice(ctx->device));
+    return ssub_rss(ctx, M, K, A_colptr, A_rowidx, A_val, C, c_order, b0_new, rss_out);
 }

@@ -324,6 +324,34 @@ class Engine:
         L.check(L.lib.cnmfe_compute_rss(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord, _p(bb, L.f32p), _p(bn, L.f32p), C.byref(out)))
         return float(out.value)
 
+    # -- the same two with bg_ssub > 1 ('nearest' resizes, Sources2D.m:1325-1334,1479-1486) --
+    def background_ssub(self, pid, fit_pid, ssub, A_prev_block, C_prev, b0_block):
+        """W * imresize(Y_block - b0_block - A_prev*C_prev, 1/s, 'nearest') on the fit patch, kept on the device for the two readers below"""
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_prev_block, info["d_b"]) if A_prev_block is not None and A_prev_block.shape[1] else (0, None, None, None)
+        cptr, cord, _keep = self._targs(C_prev, K, info["T"])
+        bb = np.ascontiguousarray(b0_block, dtype=np.float32).ravel()
+        if bb.size != info["d_b"]:
+            raise ValueError("b0_block has %d entries, expected %d" % (bb.size, info["d_b"]))
+        L.check(L.lib.cnmfe_background_ssub(self._ctx, pid, fit_pid, int(ssub), K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord, _p(bb, L.f32p)))
+
+    def reconstruct_background_ssub(self, pid, b0_new_patch, frame0=0, nframes=None):
+        info = self._patch[pid]
+        nframes = info["T"] - frame0 if nframes is None else int(nframes)
+        bn = np.ascontiguousarray(b0_new_patch, dtype=np.float32).ravel()
+        out = np.empty((nframes, info["d"]), dtype=np.float32)
+        L.check(L.lib.cnmfe_reconstruct_background_ssub(self._ctx, pid, _p(bn, L.f32p), int(frame0), nframes, _p(out, L.f32p), L.HOST))
+        return out
+
+    def compute_rss_ssub(self, pid, A_patch, C_patch, b0_new_patch):
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_patch, info["d"]) if A_patch is not None and A_patch.shape[1] else (0, None, None, None)
+        cptr, cord, _keep = self._targs(C_patch, K, info["T"])
+        bn = np.ascontiguousarray(b0_new_patch, dtype=np.float32).ravel()
+        out = C.c_double(0.0)
+        L.check(L.lib.cnmfe_compute_rss_ssub(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord, _p(bn, L.f32p), C.byref(out)))
+        return float(out.value)
+
     @staticmethod
     def _dopts(deconv_options, maxIter=10):
         """deconv_options struct of demo_large_data_1p.m:38-43 -> cnmfe_deconv_opts"""

@@ -42,6 +42,10 @@ class Options:
     background_model: str = "ring"   # demo_large_data_1p.m:54
     spatial_algorithm: str = "hals"  # :117  ('hals' | 'hals_thresh' | 'nnls')
     search_method: str = "ellipse"   # :48
+    se: object = "disk4"             # strel('disk', 4, 0): element of the 'dilate' search; None = [] -> strel('disk', bSiz, 0)
+    bSiz: int = 3                    # :35
+    nb: int = 1                      # :23 (threshold_components leaves the last nb columns alone)
+    nrgthr: float = 0.99             # :56
     min_size: float = 3.0            # :51
     max_size: float = 8.0            # :52
     dist: float = 3.0                # :53
@@ -568,8 +572,8 @@ class Sources2D:
         self._need_data()
         v, o = self.video, self.options
         sn_new = np.zeros(v.d1 * v.d2, dtype=np.float64) if update_sn else None                  # :101-102
-        if o.search_method != "ellipse":
-            raise NotImplementedError("only search_method='ellipse' is built")
+        if o.search_method not in ("ellipse", "dilate"):
+            raise NotImplementedError("search_method must be 'ellipse' or 'dilate'")
         K = self.A.shape[1]
         rows, cols, vals = [], [], []
         IND = None
@@ -618,9 +622,10 @@ class Sources2D:
         A_.eliminate_zeros()
         A_.sort_indices()
         self.A_raw = A_
-        if o.spatial_constraints.get("circular", False):
-            raise NotImplementedError("circular_constraints is off by default and not built")
-        self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                              # :341
+        self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                              # :341, :24-26
+        if o.spatial_constraints.get("circular", False):                                            # post_process_spatial.m:28-30
+            from . import hostops
+            self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)
         self._update_b0_new()                                                                        # :347-351
 
     def _post_process(self, A_):
@@ -668,6 +673,13 @@ class Sources2D:
         v, o = self.video, self.options
         A = self.A if A is None else A
         K = A.shape[1]
+        if o.search_method == "dilate":
+            # update_spatial_parallel.m:56 copies the options BEFORE :63-65 clears obj.options.se: this call still uses the old element and
+            # the next one strel('disk', bSiz, 0) (determine_search_location.m:42-44).  Host work on every rank (off in every demo).
+            from . import hostops
+            se, o.se = o.se, None
+            se = hostops.strel_disk(4) if isinstance(se, str) else hostops.strel_disk(o.bSiz) if se is None else se
+            return hostops.search_location_dilate(A, v.d1, v.d2, se, o.nb, o.nrgthr)
         if v.world_size == 1:
             return determine_search_location(A, v.d1, v.d2, o.min_size, o.max_size, o.dist)
         A = A.tocsc()
@@ -719,13 +731,11 @@ class Sources2D:
 
     # -- objective ----------------------------------------------------------------------
     def compute_RSS(self):
-        """[RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, all frames.
+        """[RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, all frames.
         Per patch the engine needs the residual of (A_prev, C_prev) on the block (:1427-1429, :1475) -- the one the temporal update asks for, so
         right after update_temporal_parallel it is still resident (or pending) and this costs one read of Ysig per patch."""
         self._need_data()
         v = self.video
-        if self.ssub != 1:
-            raise NotImplementedError("compute_RSS is built for bg_ssub = 1")
         b0_ = self.reconstruct_b0().reshape(-1, order="F")                                           # :1398 (a collective when sharded)
         b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(-1, order="F")                   # :1399
         RSS = {}
@@ -733,20 +743,23 @@ class Sources2D:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             ind, _ = self._slice(self.A, idx, "block")                                              # :1423
             indp, A_prev_b = self._prev_block_of(idx)                                                # :1427-1428
-            self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
             A_pp = self._slice(self.A, idx, "patch", cols=ind)[1] if ind.size else None              # A_patch(ind_patch, :)  (:1467)
+            if self.ssub != 1:                                                                       # :1479-1486 ('nearest' both ways)
+                self.engine.background_ssub(v.pid[idx], self.pid_fit[idx], self.ssub, A_prev_b if indp.size else None,
+                                            self._rows(self.C_prev, indp) if indp.size else None, b0_[bp])
+                RSS[idx] = self.engine.compute_rss_ssub(v.pid[idx], A_pp, self._rows(self.C, ind) if ind.size else None, b0_new_[pp])
+                continue
+            self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
             RSS[idx] = self.engine.compute_rss(v.pid[idx], A_pp, self._rows(self.C, ind) if ind.size else None, b0_[bp], b0_new_[pp])
         total = float(self._allreduce(np.array([sum(RSS.values())], dtype=np.float64))[0])           # :1507-1508
         self.P["RSS"] = total                                                                        # :1509
         return total, RSS
 
     def reconstruct_background(self, frame_range=None):
-        """Ybg = reconstruct_background(obj, frame_range)  (@Sources2D/Sources2D.m:1247-1355), ring model, bg_ssub = 1: d1 x d2 x T' (fp32) of the
+        """Ybg = reconstruct_background(obj, frame_range)  (@Sources2D/Sources2D.m:1247-1355), ring model: d1 x d2 x T' (fp32) of the
         owned patches (zeros elsewhere when sharded, like every per-patch output).  frame_range = (first, last), 1-based inclusive as in MATLAB."""
         self._need_data()
         v = self.video
-        if self.ssub != 1:
-            raise NotImplementedError("reconstruct_background is built for bg_ssub = 1")
         T = self.C.shape[1]
         f0, f1 = (1, T) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
         b0_ = self.reconstruct_b0().reshape(-1, order="F")                                           # :1292
@@ -755,10 +768,17 @@ class Sources2D:
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :1317-1320
-            self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
+            if self.ssub != 1:                                                                       # :1325-1334
+                self.engine.background_ssub(v.pid[idx], self.pid_fit[idx], self.ssub, A_prev_b if indp.size else None,
+                                            self._rows(self.C_prev, indp) if indp.size else None, b0_[bp])
+            else:
+                self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None)
             for t0 in range(f0 - 1, f1, 4096):                                                       # (the ABI hands out at most 65535 frames per call)
                 n = min(4096, f1 - t0)
-                Ybg[pp, t0 - (f0 - 1):t0 - (f0 - 1) + n] = self.engine.reconstruct_background(v.pid[idx], b0_[bp], b0_new_[pp], t0, n).T
+                if self.ssub != 1:
+                    Ybg[pp, t0 - (f0 - 1):t0 - (f0 - 1) + n] = self.engine.reconstruct_background_ssub(v.pid[idx], b0_new_[pp], t0, n).T
+                else:
+                    Ybg[pp, t0 - (f0 - 1):t0 - (f0 - 1) + n] = self.engine.reconstruct_background(v.pid[idx], b0_[bp], b0_new_[pp], t0, n).T
         return Ybg.reshape(v.d1, v.d2, -1, order="F")
 
     # -- temporal -----------------------------------------------------------------------

@@ -258,6 +258,18 @@ int cnmfe_compute_rss(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_
 int cnmfe_reconstruct_background(cnmfe_ctx *ctx, int patch_id, const float *b0_block, const float *b0_new,
                                   int64_t frame0, int64_t nframes, float *Ybg_out, int out_memspace);
 
+/* The same two with bg_ssub > 1 (Sources2D.m:1325-1334 and :1479-1486), where both resizes are 'nearest':
+ *   Bf = imresize( W * imresize(Y_block - b0_block - A_prev*C_prev, 1/s, 'nearest'), [nr_block nc_block], 'nearest' )(patch)
+ * cnmfe_background_ssub forms W * imresize(...) on the fit patch (the low-resolution patch that holds W; A_prev: d_b x K CSC on the BLOCK rows
+ * of patch_id, C_prev: K x T) and keeps it with the context until the next call of it, the next cnmfe_fit_ring_model_ssub or the next upload;
+ * the other two then read it:  Ybg(patch, t) = Bf(:, t) + b0_new  and  RSS = sum((Y(patch,:) - A*C - Ybg).^2)  (A: d x K CSC on the patch rows). */
+int cnmfe_background_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int32_t ssub, int32_t K, const int64_t *A_colptr,
+                          const int32_t *A_rowidx, const float *A_val, const float *C, int c_order, const float *b0_block /* d_b */);
+int cnmfe_reconstruct_background_ssub(cnmfe_ctx *ctx, int patch_id, const float *b0_new /* d */, int64_t frame0, int64_t nframes,
+                                       float *Ybg_out /* d x nframes, frame-major */, int out_memspace);
+int cnmfe_compute_rss_ssub(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
+                           const float *A_val, const float *C, int c_order, const float *b0_new /* d */, double *rss_out);
+
 /* ---- S6: post_process_spatial (connected = true, circular = false)
  * @Sources2D/post_process_spatial.m:19-32 -> endoscope/connectivity_constraint.m:1-18.
  * A is the whole-FOV d1*d2 x K CSC; keep[nnz] receives 1 for entries that survive. */

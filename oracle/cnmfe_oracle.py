@@ -581,16 +581,161 @@ def connectivity_constraint(img, thr=0.01, sz=5):
     return img
 
 
-def post_process_spatial(A_img):
-    """@Sources2D/post_process_spatial.m:19-32 with the default constraints (connected only).
+def post_process_spatial(A_img, connected=True, circular=False):
+    """@Sources2D/post_process_spatial.m:19-32 (defaults: connected only).
 
     A_img: d1 x d2 x K.  Returns d x K (column-major flattening).
     """
     d1, d2, K = A_img.shape
     out = np.zeros((d1 * d2, K))
     for m in range(K):
-        out[:, m] = connectivity_constraint(A_img[:, :, m]).reshape(-1, order="F")
+        ai = np.asarray(A_img[:, :, m], dtype=np.float64)
+        if connected:
+            ai = connectivity_constraint(ai)                 # :24-26
+        if circular:
+            ai = circular_constraints(ai)                    # :28-30
+        out[:, m] = ai.reshape(-1, order="F")
     return out
+
+
+# --------------------------------------------------------------------------- #
+# optional branches: search_method = 'dilate' and spatial_constraints.circular.  Written with explicit shifts and a flood fill (no
+# scipy.ndimage), so that the product's scipy.ndimage versions (cnmf_e_amd/hostops.py) are checked against an independent statement of the
+# toolbox rules: medfilt2 pads with zeros; imdilate pads with -Inf, imerode with +Inf; strel('disk', R, 0) is the exact disc.
+# Toolbox functions are not in the repository: PARITY UNPINNED for them (DESIGN.md).
+# --------------------------------------------------------------------------- #
+def _shifted(img, dy, dx, fill):
+    """out[y, x] = img[y + dy, x + dx], `fill` outside"""
+    out = np.full(img.shape, fill, dtype=img.dtype)
+    n0, n1 = img.shape
+    ys, ye = max(0, -dy), min(n0, n0 - dy)
+    xs, xe = max(0, -dx), min(n1, n1 - dx)
+    if ys < ye and xs < xe:
+        out[ys:ye, xs:xe] = img[ys + dy:ye + dy, xs + dx:xe + dx]
+    return out
+
+
+def _se_offsets(se):
+    se = np.asarray(se, dtype=bool)
+    cy, cx = se.shape[0] // 2, se.shape[1] // 2              # strel origin: floor((size + 1) / 2), 1-based
+    return [(int(y) - cy, int(x) - cx) for y, x in zip(*np.nonzero(se))]
+
+
+def _bw_dilate(bw, se):
+    out = np.zeros(bw.shape, dtype=bool)
+    for dy, dx in _se_offsets(se):
+        out |= _shifted(bw, -dy, -dx, False)                 # reflection of the element; symmetric elements only matter here
+    return out
+
+
+def _bw_erode(bw, se):
+    out = np.ones(bw.shape, dtype=bool)
+    for dy, dx in _se_offsets(se):
+        out &= _shifted(bw, dy, dx, True)
+    return out
+
+
+def _medfilt3(img):
+    """medfilt2(img) / medfilt2(img, [3 3])"""
+    st = np.stack([_shifted(img, dy, dx, 0.0) for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
+    return np.sort(st, axis=0)[4]
+
+
+def _flood_label(bw, conn):
+    """bwlabel(bw, 4) / bwlabeln(bw, 8): labels in column-major scan order of the first pixel of each component"""
+    n0, n1 = bw.shape
+    lab = np.zeros(bw.shape, dtype=np.int64)
+    nb = [(-1, 0), (1, 0), (0, -1), (0, 1)] + ([(-1, -1), (-1, 1), (1, -1), (1, 1)] if conn == 8 else [])
+    cur = 0
+    for x in range(n1):
+        for y in range(n0):
+            if bw[y, x] and not lab[y, x]:
+                cur += 1
+                lab[y, x] = cur
+                stack = [(y, x)]
+                while stack:
+                    a, b = stack.pop()
+                    for dy, dx in nb:
+                        u, w = a + dy, b + dx
+                        if 0 <= u < n0 and 0 <= w < n1 and bw[u, w] and not lab[u, w]:
+                            lab[u, w] = cur
+                            stack.append((u, w))
+    return lab, cur
+
+
+def strel_disk(radius):
+    r = int(radius)
+    return np.array([[(x * x + y * y) <= radius * radius for x in range(-r, r + 1)] for y in range(-r, r + 1)])
+
+
+def threshold_components(A, d1, d2, nb=1, nrgthr=0.99):
+    """utilities/threshold_components.m:20-62 with medw = [3 3], clos_op = strel('square', 3) (CNMFSetParms.m defaults)."""
+    A = np.asarray(A.toarray() if sp.issparse(A) else A, dtype=np.float64)
+    d, nr = A.shape
+    Ath = np.zeros((d, nr))
+    Ath[:, nr - nb:] = A[:, nr - nb:]                        # :22
+    sq = np.ones((3, 3), dtype=bool)
+    for i in range(nr - nb):                                 # :25
+        A_temp = _medfilt3(A[:, i].reshape(d1, d2, order="F")).reshape(-1, order="F")     # :26-30
+        e = A_temp ** 2
+        ind = np.argsort(e, kind="stable")                   # :31
+        temp = np.cumsum(e[ind])                             # :32
+        ff = np.nonzero(temp > (1 - nrgthr) * temp[-1])[0]   # :33
+        BW = np.zeros(d, dtype=bool)
+        if ff.size:
+            BW[ind[ff[0]:]] = True                           # :35
+        BW = _bw_erode(_bw_dilate(BW.reshape(d1, d2, order="F"), sq), sq)                 # :37 imclose
+        L, NUM = _flood_label(BW, 8)                         # :39
+        if NUM > 0:
+            nrg = [float((A_temp[(L == l).reshape(-1, order="F")] ** 2).sum()) for l in range(1, NUM + 1)]   # :42-45
+            sel = (L == 1 + int(np.argmax(nrg))).reshape(-1, order="F")                   # :46-47
+            Ath[sel, i] = A_temp[sel]                        # :50,56
+    return Ath
+
+
+def determine_search_location_dilate(A, d1, d2, se, nb=1, nrgthr=0.99):
+    """'dilate' method.  utilities/determine_search_location.m:51-56,89-98."""
+    A = np.array(A.toarray() if sp.issparse(A) else A, dtype=np.float64)
+    d, nr = A.shape
+    ind_empty = A.sum(axis=0) == 0                           # :52
+    A[0, ind_empty] = 1                                      # :54
+    Ath = threshold_components(A, d1, d2, nb, nrgthr)        # :90
+    IND = np.zeros((d, nr), dtype=bool)
+    for i in range(nr):                                      # :91
+        img = Ath[:, i].reshape(d1, d2, order="F")
+        # grey dilation by a flat element (max over the neighbourhood, -Inf outside), then > 0
+        st = np.stack([_shifted(img, -dy, -dx, -np.inf) for dy, dx in _se_offsets(se)], axis=0)
+        IND[:, i] = (st.max(axis=0) > 0).reshape(-1, order="F")   # :92-93
+    IND[:, ind_empty] = False                                # :98
+    return IND
+
+
+def circular_constraints(img):
+    """endoscope/circular_constraints.m:8-55."""
+    img = np.array(img, dtype=np.float64, copy=True)
+    tmp1, tmp2 = np.nonzero(img)                             # :8
+    if tmp1.size == 0:
+        return img                                           # :9-11
+    rmin, rmax, cmin, cmax = tmp1.min(), tmp1.max(), tmp2.min(), tmp2.max()
+    nr, nc = img.shape
+    if rmax - rmin < 1 or cmax - cmin < 1:                   # :17-19
+        return img
+    if not (rmin == 0 and rmax == nr - 1 and cmin == 0 and cmax == nc - 1):   # :21 / :52-54
+        img[rmin:rmax + 1, cmin:cmax + 1] = circular_constraints(img[rmin:rmax + 1, cmin:cmax + 1])
+        return img
+    flat = img.reshape(-1, order="F")
+    ind_max = int(np.argmax(flat)); vmax = flat[ind_max]     # :30
+    y0, x0 = ind_max % nr + 1, ind_max // nr + 1             # :31
+    x, y = np.meshgrid(np.arange(1, nc + 1), np.arange(1, nr + 1))           # :32
+    fx = np.empty_like(img); fy = np.empty_like(img)         # :33 [fx, fy] = gradient(img)
+    fx[:, 1:-1] = (img[:, 2:] - img[:, :-2]) / 2; fx[:, 0] = img[:, 1] - img[:, 0]; fx[:, -1] = img[:, -1] - img[:, -2]
+    fy[1:-1, :] = (img[2:, :] - img[:-2, :]) / 2; fy[0, :] = img[1, :] - img[0, :]; fy[-1, :] = img[-1, :] - img[-2, :]
+    ind = ((fx * (x0 - x) + fy * (y0 - y)) < 0) & (img < vmax / 3)           # :34
+    img[ind] = 0                                             # :35
+    l, _ = _flood_label(img != 0, 4)                         # :39
+    keep = _bw_dilate(l == l[y0 - 1, x0 - 1], np.ones((3, 3), dtype=bool))   # :40
+    img[~keep] = 0                                           # :41
+    return _medfilt3(img)                                    # :42
 
 
 # --------------------------------------------------------------------------- #
@@ -606,8 +751,13 @@ class OracleSources2D:
 
     def __init__(self, Yfull, d1, d2, T, patch_dims, ring_radius, A, C, sn, *,
                  spatial_algorithm="hals", maxIter=5, num_neighbors=None,
-                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1, deconv_options=None, thresh_outlier=np.nan):
+                 min_size=3, max_size=8, dist=3, bg_acceleration=True, bg_ssub=1, deconv_options=None, thresh_outlier=np.nan,
+                 search_method="ellipse", se="default", bSiz=3, nb=1, nrgthr=0.99, connected=True, circular=False):
         self.bg_ssub = int(bg_ssub)
+        # options of the 'dilate' search (CNMFSetParms.m: se = strel('disk', 4, 0), bSiz = 3, nb = 1, nrgthr = 0.99) and of post_process_spatial
+        self.search_method = search_method
+        self.se = strel_disk(4) if isinstance(se, str) else se
+        self.bSiz, self.nb, self.nrgthr, self.connected, self.circular = bSiz, nb, nrgthr, connected, circular
         self.thresh_outlier = thresh_outlier
         self.deconv_options = deconv_options       # None: options.deconv_flag = false; a dict: the keyword arguments of oasis_oracle
         self.Y = Yfull
@@ -654,6 +804,18 @@ class OracleSources2D:
             return residual_ysig(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip)
         return residual_ysig_ssub(Yb, A_prev_b, C_prev_b, self.W[idx], self.b0[idx], ip,
                                   int(b[1] - b[0] + 1), int(b[3] - b[2] + 1), self.bg_ssub)
+
+    def _ring_background(self, idx, R, b, ip):
+        """W*R on the patch rows; with bg_ssub > 1 through imresize 'nearest' both ways (Sources2D.m:1325-1334 == :1479-1486)"""
+        if self.bg_ssub == 1:
+            return self.W[idx] @ R
+        nr_b, nc_b = int(b[1] - b[0] + 1), int(b[3] - b[2] + 1)
+        T = R.shape[1]
+        temp = imresize_scale(R.reshape(nr_b, nc_b, T, order="F"), 1.0 / self.bg_ssub, "nearest")     # :1327-1328
+        d1s, d2s = temp.shape[:2]                                                                       # :1326
+        Bf = (self.W[idx] @ temp.reshape(-1, T, order="F")).reshape(d1s, d2s, T, order="F")             # :1329
+        Bf = imresize_size(Bf, [nr_b, nc_b], "nearest")                                                 # :1330
+        return Bf.reshape(-1, T, order="F")[ip]                                                         # :1331-1332
 
     def _patches(self):
         # MATLAB linear order over the nr_patch x nc_patch cell: rows fastest
@@ -715,8 +877,6 @@ class OracleSources2D:
     def compute_RSS(self):
         """[RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, all frames:
         per patch  RSS = sum((Y(patch) - A*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)."""
-        if self.bg_ssub != 1:
-            raise NotImplementedError("compute_RSS is restated for bg_ssub = 1")
         b0_ = self.reconstruct_b0()                                          # :1398
         b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(self.d1, self.d2)   # :1399
         RSS = {}
@@ -736,7 +896,7 @@ class OracleSources2D:
             R = Yb - b0_ring[:, None]                                         # :1471
             if A_pb.shape[1]:
                 R = R - A_pb @ C_pb
-            Bf = self.W[idx] @ R                                              # :1475
+            Bf = self._ring_background(idx, R, b, ip)                         # :1475 / :1479-1486
             Ybg = Bf + b0_new_patch[:, None]                                  # :1487
             RSS[idx] = float(np.sum((YmAC - Ybg) ** 2))                       # :1502
         total = float(sum(RSS.values()))                                      # :1507-1508
@@ -746,8 +906,6 @@ class OracleSources2D:
     def reconstruct_background(self):
         """Ybg = reconstruct_background(obj)  (@Sources2D/Sources2D.m:1247-1355), ring model, bg_ssub = 1, all frames:
         per patch  Ybg = W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch)  ->  d1 x d2 x T."""
-        if self.bg_ssub != 1:
-            raise NotImplementedError("reconstruct_background is restated for bg_ssub = 1")
         b0_ = self.reconstruct_b0()                                          # :1292
         b0_new_ = np.asarray(self.b0_new, dtype=np.float64).reshape(self.d1, self.d2)   # :1293
         Ybg = np.zeros((self.d1, self.d2, self.T))                           # :1297
@@ -762,7 +920,7 @@ class OracleSources2D:
             R = Yb - b0_ring[:, None]                                         # :1324
             if A_pb.shape[1]:
                 R = R - A_pb @ C_pb
-            Bf = self.W[idx] @ R                                              # :1329
+            Bf = self._ring_background(idx, R, b, ind_patch_mask(p, b))        # :1324 / :1325-1334
             q0, q1, s0, s1 = [int(v) for v in p]
             b0_patch = b0_new_[q0 - 1:q1, s0 - 1:s1].reshape(-1, order="F")   # :1311
             Ybg[q0 - 1:q1, s0 - 1:s1, :] = (Bf + b0_patch[:, None]).reshape(q1 - q0 + 1, s1 - s0 + 1, self.T, order="F")   # :1330
@@ -772,7 +930,14 @@ class OracleSources2D:
     def update_spatial_parallel(self, update_sn=False):
         """@Sources2D/update_spatial_parallel.m:61-100,116-216,320-351."""
         d1, d2 = self.d1, self.d2
-        IND = determine_search_location(self.A, d1, d2, **self.search)     # :66
+        if self.search_method == "dilate":
+            # :56 copies the options struct BEFORE :63-65 clears obj.options.se, so this call still sees the old element; the cleared one
+            # (-> strel('disk', bSiz, 0), determine_search_location.m:42-44) is what the NEXT call sees
+            se = self.se
+            self.se = None                                                   # :64
+            IND = determine_search_location_dilate(self.A, d1, d2, strel_disk(self.bSiz) if se is None else se, self.nb, self.nrgthr)
+        else:
+            IND = determine_search_location(self.A, d1, d2, **self.search)     # :66
         K = self.A.shape[1]
         A_ = np.zeros((d1 * d2, K))
         Aprev_dense_any = self.A_prev
@@ -814,7 +979,7 @@ class OracleSources2D:
         if update_sn:
             self.sn = sn_new.reshape(np.shape(self.sn), order="F") if np.ndim(self.sn) == 2 else sn_new   # :336-337
         A_img = A_.reshape(d1, d2, K, order="F")
-        self.A = sp.csc_matrix(post_process_spatial(A_img))  # :341
+        self.A = sp.csc_matrix(post_process_spatial(A_img, self.connected, self.circular))  # :341
         self.b0_new = self._ymean_full() - np.asarray(
             self.A @ self.C.mean(axis=1)).reshape(d1, d2, order="F")        # :349
 

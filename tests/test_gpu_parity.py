@@ -556,20 +556,22 @@ def test_residual_ssub_footprint_term_reuse(eng):
         eng.set_option("r1_delta", 1); eng.set_option("r1_lazy", 1)
 
 
-@pytest.mark.parametrize("pdims,T", [([22, 20], 303), (None, 300)])
-def test_compute_rss_parity(eng, pdims, T):
+@pytest.mark.parametrize("pdims,T,bg_ssub", [([22, 20], 303, 1), (None, 300, 1), ([22, 20], 303, 2), (None, 202, 3)])
+def test_compute_rss_parity(eng, pdims, T, bg_ssub):
     """compute_RSS (Sources2D.m:1358-1510) after each method of an iteration, 2x2 patches and one patch, T not a multiple of 4: the engine's
     one-read formulation (resident / pending residual + per-pixel constant + footprint rows) against the oracle's literal one, engine and oracle
-    each on their own (parity-tested) state of the same iteration.  Tolerance: fp32 storage of Ysig and the 2e-3 agreement of the two states."""
+    each on their own (parity-tested) state of the same iteration.  Tolerance: fp32 storage of Ysig and the 2e-3 agreement of the two states.
+    bg_ssub > 1: the 'nearest' form of Sources2D.m:1479-1486 (W on the low-resolution block, pixel selection down, replication up)."""
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-    d1, d2, K, r = 44, 40, 6, 5
+    d1, d2, K = 44, 40, 6
+    r = 5 * bg_ssub
     f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
     pd_ = pdims or [d1, d2]
     video = PatchedVideo(d1, d2, T, pd_, r, eng)
     video.upload_from_full(Y)
-    s = Sources2D(video, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn)
-    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, pd_, r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3, bg_ssub=bg_ssub), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, pd_, r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3, bg_ssub=bg_ssub)
     def check(tag):
         got, per = s.compute_RSS(); ref, per_ref = o.compute_RSS()
         assert abs(got - ref) <= 2e-5 * ref, (tag, got, ref)
@@ -586,16 +588,19 @@ def test_compute_rss_parity(eng, pdims, T):
     assert abs(s.P["RSS"] - r1) == 0
 
 
-def test_reconstruct_background_parity(eng):
-    """reconstruct_background (Sources2D.m:1247-1355) after a full iteration on 2x2 patches, all frames and a frame range, vs the oracle"""
+@pytest.mark.parametrize("bg_ssub", [1, 2, 3])
+def test_reconstruct_background_parity(eng, bg_ssub):
+    """reconstruct_background (Sources2D.m:1247-1355; :1325-1334 for bg_ssub > 1) after a full iteration on 2x2 patches, all frames and a frame
+    range, vs the oracle"""
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-    d1, d2, T, K, r = 44, 40, 203, 6, 5
+    d1, d2, T, K = 44, 40, 203, 6
+    r = 5 * bg_ssub
     f = synth.make_factors(d1, d2, T, K, 23, gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
     video = PatchedVideo(d1, d2, T, [22, 20], r, eng)
     video.upload_from_full(Y)
-    s = Sources2D(video, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn)
-    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=3, bg_ssub=bg_ssub), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [22, 20], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=3, bg_ssub=bg_ssub)
     for step in ("update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
         getattr(s, step)(); getattr(o, step)()
     ref = o.reconstruct_background()

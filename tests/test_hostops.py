@@ -1,0 +1,85 @@
+"""search_method = 'dilate' (determine_search_location.m:89-98 + threshold_components.m) and spatial_constraints.circular
+(circular_constraints.m): the product's scipy.ndimage implementation (cnmf_e_amd/hostops.py) against the oracle's explicit-shift /
+flood-fill restatement, function by function and through two iterations of the three update methods (NumPy fake engine)."""
+import numpy as np
+import scipy.sparse as sp
+import pytest
+
+import cnmfe_oracle as orc
+from cnmf_e_amd import hostops, synth
+
+
+def _footprints(d1, d2, K, seed):
+    """blobs with specks, a second lobe, holes and a neuron at the FOV border: everything the morphology has to decide about"""
+    rng = np.random.default_rng(seed)
+    f = synth.make_factors(d1, d2, 10, K, seed, gSig=2.0, gSiz=9, min_sep=4)
+    A = f.A_true.toarray().astype(np.float64)
+    for k in range(K):
+        pix = rng.integers(0, d1 * d2, 8)
+        A[pix, k] += rng.uniform(0.02, 0.5, 8)
+        nz = np.nonzero(A[:, k])[0]
+        A[rng.choice(nz, min(3, nz.size), replace=False), k] = 0.0
+    A[:, 1] += 0.7 * np.roll(A[:, 0], 3 * d1 + 2)
+    yy, xx = np.mgrid[:d1, :d2]
+    A[:, 2] = np.exp(-((yy - 0.5) ** 2 + (xx - 1.0) ** 2) / 8.0).reshape(-1, order="F") * (rng.random(d1 * d2) > 0.1)
+    A[:, 3] = 0.0                                                          # an empty component
+    return A
+
+
+@pytest.mark.parametrize("seed,dims", [(1, (40, 36)), (2, (31, 45))])
+def test_threshold_components_and_dilate_match_oracle(seed, dims):
+    d1, d2 = dims
+    A = _footprints(d1, d2, 7, seed)
+    for nb in (1, 0):
+        got = hostops.threshold_components(sp.csc_matrix(A), d1, d2, nb=nb).toarray()
+        ref = orc.threshold_components(A, d1, d2, nb=nb)
+        assert np.array_equal(got, ref)
+    assert np.array_equal(hostops.strel_disk(4), orc.strel_disk(4)) and hostops.strel_disk(3).sum() == 29
+    for se in (orc.strel_disk(4), orc.strel_disk(3), np.ones((3, 3), bool)):
+        got = hostops.search_location_dilate(sp.csc_matrix(A), d1, d2, se).toarray()
+        ref = orc.determine_search_location_dilate(A, d1, d2, se)
+        assert np.array_equal(got, ref)
+        assert not ref[:, 3].any() and ref[:, 0].sum() > (A[:, 0] > 0).sum() * 0.8     # the empty column stays empty, the others grow
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_circular_constraints_match_oracle(seed):
+    d1, d2 = 40, 36
+    A = _footprints(d1, d2, 7, seed)
+    changed = 0
+    for k in range(A.shape[1]):
+        img = A[:, k].reshape(d1, d2, order="F")
+        got = hostops.circular_constraints(img)
+        ref = orc.circular_constraints(img)
+        assert np.array_equal(got, ref), k
+        changed += int(not np.array_equal(ref, img))
+    assert changed >= 5
+    line = np.zeros((d1, d2)); line[7, 3:9] = 1.0                          # a one-pixel-high bounding box is returned as it is (:17-19)
+    assert np.array_equal(hostops.circular_constraints(line), line) and np.array_equal(orc.circular_constraints(line), line)
+    cols = hostops.circular_constraints_columns(sp.csc_matrix(A.astype(np.float32)), d1, d2).toarray()
+    ref = np.stack([orc.circular_constraints(A.astype(np.float32)[:, k].reshape(d1, d2, order="F")).reshape(-1, order="F") for k in range(A.shape[1])], axis=1)
+    assert np.allclose(cols, ref, rtol=1e-6, atol=0)
+
+
+def test_methods_with_dilate_and_circular_match_oracle():
+    """two iterations of update_{background,spatial,temporal}_parallel with search_method = 'dilate' (first call: strel('disk', 4, 0),
+    second: strel('disk', bSiz, 0) -- update_spatial_parallel.m:56,63-65) and circular = true, on the NumPy fake engine"""
+    from fake_engine import FakeEngine
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 36, 32, 80, 5, 5
+    f = synth.make_factors(d1, d2, T, K, 11, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    eng = FakeEngine()
+    video = PatchedVideo(d1, d2, T, [18, 16], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, maxIter=2, search_method="dilate", bSiz=2,
+                                 spatial_constraints={"circular": True, "connected": True}), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [18, 16], r, f.A_init.astype(np.float32), f.C_init, f.sn, maxIter=2,
+                            search_method="dilate", bSiz=2, circular=True)
+    for it in range(2):
+        for step in ("update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
+            getattr(s, step)(); getattr(o, step)()
+        Ag, Ar = s.A.toarray(), o.A.toarray()
+        assert np.array_equal(Ag != 0, Ar != 0), it
+        assert np.abs(Ag - Ar).max() <= 1e-5 * np.abs(Ar).max() and np.abs(np.asarray(s.C) - o.C).max() <= 1e-5 * np.abs(o.C).max(), it
+    assert s.options.se is None and o.se is None
