@@ -621,6 +621,16 @@ int cnmfe_get_sn(cnmfe_ctx *ctx, int patch_id, float *sn_out) {
     return sn_pixels_run(ctx, P, sn_out);
 }
 
+int cnmfe_estimate_noise(cnmfe_ctx *ctx, int patch_id, int64_t nframes, float *sn_block_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (!sn_block_out) return fail(CNMFE_EINVAL, "null sn_block_out");
+    CK(hipSetDevice(ctx->device));
+    RET(ensure_ymean(ctx, P));
+    return sn_video_run(ctx, P, nframes, sn_block_out);
+}
+
 int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K, const int64_t *A_colptr,
                          const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx, const float *sn, int32_t param, float *A_out) {

@@ -231,6 +231,7 @@ int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_ord
 int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, uint8_t *keep);
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P);
+int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out);
 int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
 int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean);
 int ctx_errflag(cnmfe_ctx *ctx, int **dflag);            // the device error word (allocated and cleared on first use)

@@ -745,6 +745,42 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     return 0;
 }
 
+// ---- P.sn = estimate_noise(obj) (Sources2D.m:328-379, method 'psd'): GetSn of the first frames of the RAW video, per block pixel ------
+// The resident video is centred, so the pixel mean goes back in (pwelch does not detrend: what the mean leaks through the Hamming window
+// into [0.25, 0.5] is part of the reference's number).
+__global__ void __launch_bounds__(256) k_sn_video(DeconvCfg c, const float4 *__restrict__ yc4, int64_t d_b, const float *__restrict__ ymean_f, float *__restrict__ sn) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red[4];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, T = c.T;
+    const int Tal = (T + 3) & ~3;
+    float *y = lds, *scr = lds + Tal;
+    const float mu = ymean_f[q];
+    for (int i = tid; i < (T + 3) / 4; i += 256) { const float4 v = yc4[(int64_t)i * d_b + q]; *reinterpret_cast<float4 *>(y + 4 * i) = make_float4(v.x + mu, v.y + mu, v.z + mu, v.w + mu); }
+    __syncthreads();
+    const double v = get_sn(y, c, scr, red, false);
+    if (tid == 0) sn[q] = (float)v;
+}
+
+int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out) {
+    const int64_t T = nframes;
+    if (T < 64 || T > P->T) return fail(CNMFE_EUNSUPPORTED, "estimate_noise on the device supports 64 <= frames <= T (got %lld of %lld)", (long long)T, (long long)P->T);
+    DeconvCfg c{};
+    c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
+    c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
+    c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
+    c.nseg = (int)((T - c.nov) / (c.L - c.nov));
+    const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
+    if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "%lld frames do not fit the GetSn kernel's LDS (trace + Welch transform in 160 KB: <= 20400)", (long long)T);
+    if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_video, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    DevBuf &dSn = ctx->tmp[14];
+    RET(dSn.ensure((size_t)P->d_b * sizeof(float)));
+    LAUNCH(ctx, "estimate_noise", k_sn_video, dim3((unsigned)P->d_b), dim3(256), shmem, c, P->Yc4.as<float4>(), P->d_b, P->ymean_f.as<float>(), dSn.as<float>());
+    CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d_b * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------
 
 int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg &c, size_t &shmem) {

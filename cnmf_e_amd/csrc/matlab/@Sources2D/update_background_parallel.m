@@ -13,9 +13,7 @@ function update_background_parallel(obj, use_parallel)
     if ~strcmpi(obj.options.background_model, 'ring')
         error('cnmfe:model', 'the MI355X engine implements the ring background model; got ''%s''', obj.options.background_model);
     end
-    if ~isnan(obj.options.thresh_outlier)
-        error('cnmfe:outlier', 'thresh_outlier must be NaN (the outlier branch of fit_ring_model is not built)');
-    end
+    thr = obj.options.thresh_outlier;                    % NaN in every demo; a finite value takes fit_ring_model's outlier branch
     if nargin < 2, use_parallel = true; end  %#ok<NASGU>
     eng = cnmfe_handle(obj);
     d1 = eng.dims(1);  d2 = eng.dims(2);
@@ -38,10 +36,20 @@ function update_background_parallel(obj, use_parallel)
             continue;                                    % nothing changed in this area: W{m}, b0{m} stay
         end
         rows = int32(ind(:));
+        if ~isnan(thr)                                   % sn of the block (reference :131-138; resized for bg_ssub > 1)
+            blk = eng.block_pos{m};
+            sn_blk = obj.P.sn(blk(1):blk(2), blk(3):blk(4));
+            if s == 1
+                cnmfe_mex('set_noise', h, eng.pid(m), sn_blk(:));
+            else
+                sn_low = imresize(sn_blk, 1/s, 'nearest') * s;
+                cnmfe_mex('set_noise', h, eng.pid_fit(m), sn_low(:));
+            end
+        end
         if s == 1
-            cnmfe_mex('fit_ring', h, eng.pid(m), Ablk(:, ind), rows, accel);
+            cnmfe_mex('fit_ring', h, eng.pid(m), Ablk(:, ind), rows, accel, thr);
         else
-            cnmfe_mex('fit_ring_ssub', h, eng.pid(m), eng.pid_fit(m), eng.pid_res(m), s, Ablk(:, ind), rows, accel);
+            cnmfe_mex('fit_ring_ssub', h, eng.pid(m), eng.pid_fit(m), eng.pid_res(m), s, Ablk(:, ind), rows, accel, thr);
         end
     end
 

@@ -23,6 +23,8 @@
 //   cnmfe_mex('residual', h, pid, A_prev_block, C_or_rows)                 update_spatial_parallel.m:162-166 (result stays on the device)
 //   cnmfe_mex('residual_ssub', h, pid, res_pid, bg_ssub, A_prev_block, C_or_rows)
 //   sn = cnmfe_mex('get_sn', h, pid, d)                                    update_sn = true
+//   cnmfe_mex('set_noise', h, pid, sn_block);  sn_block = cnmfe_mex('estimate_noise', h, pid, d_b, nframes)
+//   cnmfe_mex('background_ssub', ...), cnmfe_mex('compute_rss_ssub', ...), cnmfe_mex('reconstruct_background_ssub', ...)   bg_ssub > 1
 //   A = cnmfe_mex('spatial', h, pid, alg, A_patch, C_or_rows, IND_patch, sn, param)       HALS_spatial*.m / nnls_spatial.m
 //   [C, C_raw, aa] = cnmfe_mex('temporal', h, pid, A_patch, C_or_rows, maxIter)           HALS_temporal.m:1 (fewer outputs: fewer downloads)
 //   [C, C_raw, S, pars, sn, aa] = cnmfe_mex('temporal_deconv', h, pid, A, C, maxIter, smin, max_tau, pars)
@@ -211,11 +213,11 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         CHECK(cnmfe_ring_first_run(c, pid, &f));
         pout[0] = mxCreateLogicalScalar(f != 0);
     } else if (!strcmp(cmd, "fit_ring")) {
-        if (nin != 6) FAIL("fit_ring: 6 inputs required");
+        if (nin != 6 && nin != 7) FAIL("fit_ring: 6 or 7 inputs required (h, pid, A, C, with_projection[, thresh_outlier])");
         Csc A = csc_of(pin[3]);
         Traces Cm = traces_of(pin[4], A.K);
         int64_t info[4];
-        CHECK(cnmfe_fit_ring_model(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, mxGetNaN(), mxGetScalar(pin[5]) != 0, NULL, info));
+        CHECK(cnmfe_fit_ring_model(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, nin > 6 ? mxGetScalar(pin[6]) : mxGetNaN(), mxGetScalar(pin[5]) != 0, NULL, info));
         pout[0] = info_of(info);
     } else if (!strcmp(cmd, "residual")) {
         if (nin != 5) FAIL("residual: 5 inputs required");
@@ -293,6 +295,35 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         if (nf <= 0) FAIL("reconstruct_background: nframes must be positive");
         pout[0] = mxCreateNumericMatrix(nn, (size_t)nf, mxSINGLE_CLASS, mxREAL);
         CHECK(cnmfe_reconstruct_background(c, pid, bb, bn, f0, nf, (float *)mxGetData(pout[0]), CNMFE_HOST));
+    } else if (!strcmp(cmd, "set_noise")) {                    // cnmfe_mex('set_noise', h, pid, sn_block): read by the outlier branch of the ring fit
+        if (nin != 4) FAIL("set_noise: 4 inputs required");
+        CHECK(cnmfe_set_noise(c, pid, f32_of(pin[3], NULL)));
+    } else if (!strcmp(cmd, "estimate_noise")) {               // sn_block = cnmfe_mex('estimate_noise', h, pid, d_b, nframes)   Sources2D.m:328-379 per pixel
+        if (nin != 5) FAIL("estimate_noise: 5 inputs required");
+        const size_t db = (size_t)mxGetScalar(pin[3]);
+        float *sn = (float *)mxMalloc((db + 1) * sizeof(float));
+        CHECK(cnmfe_estimate_noise(c, pid, (int64_t)mxGetScalar(pin[4]), sn));
+        pout[0] = to_double(sn, db, 1);
+    } else if (!strcmp(cmd, "background_ssub")) {              // cnmfe_mex('background_ssub', h, pid, fit_pid, bg_ssub, A_prev_block, C_or_rows, b0_block)
+        if (nin != 8) FAIL("background_ssub: 8 inputs required");
+        Csc A = csc_of(pin[5]);
+        Traces Cm = traces_of(pin[6], A.K);
+        CHECK(cnmfe_background_ssub(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, f32_of(pin[7], NULL)));
+    } else if (!strcmp(cmd, "compute_rss_ssub")) {             // rss = cnmfe_mex('compute_rss_ssub', h, pid, A_patch, C_or_rows, b0_new_patch)
+        if (nin != 6) FAIL("compute_rss_ssub: 6 inputs required");
+        Csc A = csc_of(pin[3]);
+        Traces Cm = traces_of(pin[4], A.K);
+        double rss = 0.0;
+        CHECK(cnmfe_compute_rss_ssub(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, f32_of(pin[5], NULL), &rss));
+        pout[0] = mxCreateDoubleScalar(rss);
+    } else if (!strcmp(cmd, "reconstruct_background_ssub")) {  // Ybg = cnmfe_mex('reconstruct_background_ssub', h, pid, b0_new_patch, frame0, nframes)
+        if (nin != 6) FAIL("reconstruct_background_ssub: 6 inputs required");
+        size_t nn = 0;
+        float *bn = f32_of(pin[3], &nn);
+        const int64_t f0 = (int64_t)mxGetScalar(pin[4]), nf = (int64_t)mxGetScalar(pin[5]);
+        if (nf <= 0) FAIL("reconstruct_background_ssub: nframes must be positive");
+        pout[0] = mxCreateNumericMatrix(nn, (size_t)nf, mxSINGLE_CLASS, mxREAL);
+        CHECK(cnmfe_reconstruct_background_ssub(c, pid, bn, f0, nf, (float *)mxGetData(pout[0]), CNMFE_HOST));
     } else if (!strcmp(cmd, "get_sn")) {
         if (nin != 4) FAIL("get_sn: 4 inputs required");
         const size_t d = (size_t)mxGetScalar(pin[3]);
@@ -305,12 +336,12 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         if (mxGetString(pin[5], md, sizeof(md))) FAIL("derive: bad mode");
         CHECK(cnmfe_patch_derive(c, pid, (int)mxGetScalar(pin[3]), (int32_t)mxGetScalar(pin[4]), !strcmp(md, "nearest") ? CNMFE_DERIVE_NEAREST : CNMFE_DERIVE_BICUBIC));
     } else if (!strcmp(cmd, "fit_ring_ssub")) {
-        if (nin != 9) FAIL("fit_ring_ssub: 9 inputs required");
+        if (nin != 9 && nin != 10) FAIL("fit_ring_ssub: 9 or 10 inputs required");
         Csc A = csc_of(pin[6]);
         Traces Cm = traces_of(pin[7], A.K);
         int64_t info[4];
         CHECK(cnmfe_fit_ring_model_ssub(c, pid, (int)mxGetScalar(pin[3]), (int)mxGetScalar(pin[4]), (int32_t)mxGetScalar(pin[5]), A.K, A.cp, A.ri, A.v,
-                                        Cm.ptr, Cm.order, mxGetNaN(), mxGetScalar(pin[8]) != 0, info));
+                                        Cm.ptr, Cm.order, nin > 9 ? mxGetScalar(pin[9]) : mxGetNaN(), mxGetScalar(pin[8]) != 0, info));
         pout[0] = info_of(info);
     } else if (!strcmp(cmd, "residual_ssub")) {
         if (nin != 7) FAIL("residual_ssub: 7 inputs required");

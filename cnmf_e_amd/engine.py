@@ -197,6 +197,14 @@ class Engine:
         b0 = np.ascontiguousarray(b0, dtype=np.float32)
         L.check(L.lib.cnmfe_b0_set(self._ctx, pid, _p(b0, L.f32p)))
 
+    def estimate_noise(self, pid, nframes=None):
+        """GetSn of the first `nframes` (default min(T, 3000), Sources2D.m:333-335) frames of the raw video, per block pixel"""
+        info = self._patch[pid]
+        n = min(info["T"], 3000) if nframes is None else int(nframes)
+        out = np.empty(info["d_b"], dtype=np.float32)
+        L.check(L.lib.cnmfe_estimate_noise(self._ctx, pid, n, _p(out, L.f32p)))
+        return out
+
     def set_noise(self, pid, sn_block):
         """sn of the block pixels (update_background_parallel.m:131,137); read by the outlier branch of fit_ring_model only"""
         sn_block = np.ascontiguousarray(sn_block, dtype=np.float32).ravel()

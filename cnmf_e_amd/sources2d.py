@@ -100,6 +100,24 @@ def nearest_rows(n, s):
     return ind - 1
 
 
+def storage_block_index(d, patch_idx, w_overlap):
+    """block_idx_r / block_idx_c of distribute_data.m:91-97: the cut lines of the blocks the reference stores the video in"""
+    idx = np.concatenate([np.asarray(patch_idx) - 1 - w_overlap, np.asarray(patch_idx) + w_overlap])
+    return np.unique(np.clip(idx, 1, d))
+
+
+def estimate_noise_image(sn_pix, block_idx_r, block_idx_c):
+    """Sources2D.m:361-376 given the per-pixel estimates: the reference evaluates storage block [r0 r1] x [c0 c1] INCLUDING the row r1 it
+    shares with the next block, then drops row END-1 (not the shared one) of every block but the last, likewise for columns.  Net effect:
+    row b - 1 of the image holds the estimate of row b for every interior cut line b -- reproduced as it is."""
+    out = np.array(sn_pix, copy=True)
+    for b in np.asarray(block_idx_r)[1:-1]:
+        out[b - 2, :] = out[b - 1, :]
+    for b in np.asarray(block_idx_c)[1:-1]:
+        out[:, b - 2] = out[:, b - 1]
+    return out
+
+
 def _rect_pixels(rect, d1):
     """global column-major pixel indices of a rectangle, in the rectangle's own column-major order"""
     r0, r1, c0, c1 = [int(v) for v in rect]
@@ -404,6 +422,24 @@ class Sources2D:
     def _need_data(self):
         if self.video is None:
             raise RuntimeError("No data file selected")                   # update_spatial_parallel.m:13-38
+
+    def estimate_noise(self, frame_range=None):
+        """obj.P.sn = obj.estimate_noise(frame_range, 'psd')  (Sources2D.m:328-379): GetSn per pixel on the device (every owned patch evaluates its
+        block, the patch part is kept), then the storage-block bookkeeping of :361-376.  frame_range = (1, n): the first n frames."""
+        self._need_data()
+        v = self.video
+        n = None if frame_range is None else int(frame_range[1]) - int(frame_range[0]) + 1
+        if frame_range is not None and int(frame_range[0]) != 1:
+            raise NotImplementedError("estimate_noise reads the frames from the first one on (the reference's default is [1, min(T, 3000)])")
+        out = np.zeros(v.d1 * v.d2, dtype=np.float64)
+        for idx in v.owned:
+            out[v.patch_pix[idx]] = self.engine.estimate_noise(v.pid[idx], n)[v.ind_patch[idx]]
+        out = self._allreduce(out).reshape(v.d1, v.d2, order="F")
+        pr = np.array([int(v.patch_pos[(m, 0)][0]) for m in range(v.nr_patch)] + [v.d1])       # patch_idx_r / patch_idx_c of distribute_data.m:57-79
+        pc = np.array([int(v.patch_pos[(0, j)][2]) for j in range(v.nc_patch)] + [v.d2])
+        sn = estimate_noise_image(out, storage_block_index(v.d1, pr, v.w_overlap), storage_block_index(v.d2, pc, v.w_overlap))
+        self.P["sn"] = sn.reshape(-1, order="F").astype(np.float32)
+        return sn
 
     def reconstruct_b0(self):
         """Sources2D.m:1153-1190: stitch b0{m} into a d1 x d2 image (owned patches; all-reduced if sharded)."""

@@ -118,6 +118,12 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
                          double thresh_outlier, int with_projection,
                          float *b0_out /* d or NULL */, int64_t info[4]);
 
+/* P.sn: sn = estimate_noise(obj, frame_range, 'psd')  (@Sources2D/Sources2D.m:328-379 -> OASIS_matlab/functions/GetSn.m:19-46) for the block
+ * pixels of a patch: the Welch estimate of the first `nframes` frames (the reference's default is min(T, 3000)) of the resident RAW video
+ * (pixel mean included, as pwelch sees it).  The per-storage-block bookkeeping of :361-375 (row / column end-1 of every block but the
+ * last is dropped) is index arithmetic on the assembled image and stays with the host (sources2d.estimate_noise_image). */
+int cnmfe_estimate_noise(cnmfe_ctx *ctx, int patch_id, int64_t nframes, float *sn_block_out /* d_b */);
+
 /* sn of the BLOCK pixels of a patch (obj.P.sn(logical(mask)), update_background_parallel.m:131; for a low-resolution fit patch of
  * bg_ssub > 1 the resized values of :137).  Only the outlier branch of the ring fit reads them. */
 int cnmfe_set_noise(cnmfe_ctx *ctx, int patch_id, const float *sn_block /* d_b */);

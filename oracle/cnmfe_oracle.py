@@ -787,6 +787,35 @@ class OracleSources2D:
             self.Ymean[idx] = self._block(p).astype(np.float64).mean(axis=1)  # P.Ymean (:338-339)
         self.b0_new = None
 
+    def estimate_noise(self, frame_range=None):
+        """sn = estimate_noise(obj, frame_range, 'psd')  (@Sources2D/Sources2D.m:328-379), literally: GetSn on every storage block of
+        distribute_data.m:91-97 (neighbouring blocks share their cut line), row / column end-1 of every block but the last removed, cell2mat."""
+        from oasis_oracle import GetSn
+        T = self.T
+        f0, f1 = (1, min(T, 3000)) if frame_range is None else frame_range                     # :333-335
+        nr, nc = self.patch_pos.shape
+        w = self.ring_radius
+        pr = np.array([int(self.patch_pos[m, 0][0]) for m in range(nr)] + [self.d1]); pc = np.array([int(self.patch_pos[0, j][2]) for j in range(nc)] + [self.d2])
+        bir = np.unique(np.clip(np.concatenate([pr - 1 - w, pr + w]), 1, self.d1))             # distribute_data.m:91-97
+        bic = np.unique(np.clip(np.concatenate([pc - 1 - w, pc + w]), 1, self.d2))
+        nrb, ncb = bir.size - 1, bic.size - 1
+        rows = []
+        for m in range(nrb):
+            cols = []
+            for n in range(ncb):
+                r0, r1, c0, c1 = bir[m], bir[m + 1], bic[n], bic[n + 1]                        # :362-365
+                Yp = np.asarray(self.Y[r0 - 1:r1, c0 - 1:c1, f0 - 1:f1], dtype=np.float64)      # :366-367
+                tmp = np.array([[GetSn(Yp[i, j]) for j in range(Yp.shape[1])] for i in range(Yp.shape[0])])   # :368
+                if m != nrb - 1:
+                    tmp = np.delete(tmp, tmp.shape[0] - 2, axis=0)                              # :369-371
+                if n != ncb - 1:
+                    tmp = np.delete(tmp, tmp.shape[1] - 2, axis=1)                              # :372-374
+                cols.append(tmp)
+            rows.append(np.hstack(cols))
+        sn = np.vstack(rows)                                                                    # :378
+        assert sn.shape == (self.d1, self.d2)
+        return sn
+
     # -- helpers ------------------------------------------------------------
     def _block(self, pos):
         r0, r1, c0, c1 = [int(v) for v in pos]

@@ -641,3 +641,27 @@ def test_init_residual_parity(eng, bg_ssub):
     idx = max(video.owned, key=lambda i: np.asarray(abs(f.A_true.tocsc()[:, k][video.patch_pix[i]]).sum()))
     px = int(np.argmax(np.asarray(f.A_true.tocsc()[:, k].todense()).ravel()[video.patch_pix[idx]]))
     assert np.corrcoef(s.init_residual(idx)[:, px], f.C_true[k])[0, 1] > 0.8
+
+
+@pytest.mark.parametrize("pdims,T,nfr", [([22, 20], 300, None), (None, 403, 250), ([22, 20], 3100, None)])
+def test_estimate_noise_parity(eng, pdims, T, nfr):
+    """P.sn = estimate_noise(obj) (Sources2D.m:328-379): GetSn of the first min(T, 3000) (or nfr) frames of the raw video per pixel on the
+    device + the storage-block bookkeeping of :361-376 (row / column end-1 of a block dropped instead of the shared one), against the oracle's
+    literal block loop.  The third case is longer than 3000 frames (only the first 3000 count)."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, K, r = 44, 40, 6, 5
+    f = synth.make_factors(d1, d2, T, K, 29, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    pd_ = pdims or [d1, d2]
+    video = PatchedVideo(d1, d2, T, pd_, r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r), f.A_init, f.C_init, f.sn)
+    o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, pd_, r, f.A_init.astype(np.float32), f.C_init, f.sn)
+    fr = None if nfr is None else (1, nfr)
+    got = s.estimate_noise(fr); ref = o.estimate_noise(fr)
+    assert got.shape == ref.shape == (d1, d2)
+    e = np.abs(got - ref).max() / np.abs(ref).max()
+    assert e <= 2e-5, e
+    assert np.array_equal(s.P["sn"], got.reshape(-1, order="F").astype(np.float32))
+    if pdims is not None:                                   # the bookkeeping is visible: row b - 1 repeats row b at the interior cut lines
+        assert np.array_equal(got[4], got[5]) and not np.array_equal(got[3], got[4])
