@@ -117,8 +117,7 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
         DevBuf &dIdx = ctx->tmp[15];
         RET(to_dev(ctx, dIdx, rows, (size_t)K));
         LAUNCH(ctx, "gather_rows", k_gather_rows, dim3((unsigned)K), dim3(256), 0, ctx->bound.as<float4>(), ldc >> 2, dIdx.as<int>(), dst.as<float4>());
-        CK(hipStreamSynchronize(ctx->stream));             // the caller's index array may go away after the call
-        return 0;
+        return 0;                                          // (the index array went through the pinned arena: the caller may drop it)
     }
     CK(hipMemsetAsync(dst.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
     if (order == CNMFE_ROWMAJOR) {
@@ -129,6 +128,7 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
         dim3 g((unsigned)((T + 31) / 32), (unsigned)((K + 31) / 32)), b(32, 8);
         LAUNCH(ctx, "transpose_in", k_transpose_in, g, b, 0, ctx->stage.as<float>(), dst.as<float>(), K, T, ldc);
     }
+    CK(hipStreamSynchronize(ctx->stream));                 // the caller's matrix was read in place: it is free again when this returns
     return 0;
 }
 
@@ -165,16 +165,19 @@ int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
     return 0;
 }
 
-// length(unique(W_old(1,:)))==2 on row 1 of the resident W, implicit zeros of the sparse row included
-int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first) {
-    const int p = P->p;
-    std::vector<float> row0(p);
-    CK(hipMemcpy2DAsync(row0.data(), sizeof(float), P->W.p, P->d * sizeof(float), sizeof(float), p, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+// pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60)
+__global__ void k_ring_pmax(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (m < d) for (int i = 0; i < p; ++i) c += W[(int64_t)i * d + m] > 0.f;
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(c, o); c = v > c ? v : c; }
+    if ((threadIdx.x & 63) == 0) atomicMax(pmax, c);
+}
+static bool first_run_of_row(const Patch *P, const float *row0) {
     std::vector<float> u;
     const int r = P->prect[0], c = P->prect[2];
     int nvalid = 0;
-    for (int i = 0; i < p; ++i) {
+    for (int i = 0; i < P->p; ++i) {
         const int rr = r + P->dr[i], cc = c + P->dc[i];
         if (rr < 1 || rr > P->d1 || cc < 1 || cc > P->d2) continue;
         ++nvalid; u.push_back(row0[i]);
@@ -182,10 +185,32 @@ int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first) {
     if (nvalid < P->d_b) u.push_back(0.f);
     std::sort(u.begin(), u.end());
     u.erase(std::unique(u.begin(), u.end()), u.end());
-    *first = u.size() == 2;
+    return u.size() == 2;
+}
+// pinned layout: int pmax | float row1[p]
+int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P) {
+    const size_t bytes = 64 + (size_t)P->p * sizeof(float);
+    if (!P->stat_host) CK(hipHostMalloc(&P->stat_host, bytes, hipHostMallocDefault));
+    if (!P->stat_ev) CK(hipEventCreateWithFlags(&P->stat_ev, hipEventDisableTiming));
+    RET(P->stat_dev.ensure(64));
+    CK(hipMemsetAsync(P->stat_dev.p, 0, 64, ctx->stream));
+    LAUNCH(ctx, "ring_pmax", k_ring_pmax, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->W.as<float>(), P->d, P->p, P->stat_dev.as<int>());
+    CK(hipMemcpyAsync(P->stat_host, P->stat_dev.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpy2DAsync((char *)P->stat_host + 64, sizeof(float), P->W.p, P->d * sizeof(float), sizeof(float), P->p, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipEventRecord(P->stat_ev, ctx->stream));
+    P->stat_valid = true;
+    return 0;
+}
+int ring_stats_get(cnmfe_ctx *ctx, Patch *P, int *pmax, bool *first) {
+    if (!P->stat_valid) RET(ring_stats_enqueue(ctx, P));      // W came from somewhere else (ring_init, cnmfe_ring_set_csr): evaluate now
+    CK(hipEventSynchronize(P->stat_ev));
+    if (pmax) *pmax = *reinterpret_cast<const int *>(P->stat_host);
+    if (first) *first = first_run_of_row(P, reinterpret_cast<const float *>((const char *)P->stat_host + 64));
     return 0;
 }
 
+// length(unique(W_old(1,:)))==2 on row 1 of the resident W, implicit zeros of the sparse row included
+int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first) { return ring_stats_get(ctx, P, nullptr, first); }
 int ctx_errflag(cnmfe_ctx *ctx, int **dflag) {
     if (!ctx->errflag.p) {
         RET(ctx->errflag.ensure(sizeof(int)));
@@ -312,6 +337,7 @@ cnmfe_ctx *cnmfe_create(int device) {
     cnmfe_ctx *ctx = new cnmfe_ctx();
     ctx->device = device;
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -330,7 +356,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "r1_delta", "r1_lazy", "r1_probe", "r1_nseg", "gram_incremental", "debug", nullptr};
+    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "r1_delta", "r1_lazy", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -448,6 +474,8 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     LAUNCH(ctx, "ring_init", k_ring_init, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
            P->W.as<float>(), P->d, P->nr, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->prect[0], P->prect[2], P->d1, P->d2);
     CK(hipStreamSynchronize(ctx->stream));
+    P->stat_valid = false;
+    if (P->stat_host) { (void)hipHostFree(P->stat_host); P->stat_host = nullptr; }      // sized by the number of ring offsets
     P->ring_ready = true; P->ysig_valid = false; P->base_valid = false;   // (the kept covariance table covers the sub-tiles THIS ring needs)
     return 0;
 }
@@ -513,6 +541,7 @@ int cnmfe_ring_set_values(cnmfe_ctx *ctx, int patch_id, const float *val) {
     }
     CK(hipMemcpyAsync(P->W.p, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
+    P->stat_valid = false;
     P->ysig_valid = false;
     return 0;
 }
@@ -751,7 +780,7 @@ int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m) {
     RET(to_dev(ctx, ctx->scr[23], ind_m, (size_t)K_m));
     LAUNCH(ctx, "stitch_add", k_stitch_add, dim3((unsigned)((ctx->stitch_T + 255) / 256), (unsigned)K_m), dim3(256), 0, ctx->last_craw.as<float>(), ctx->last_t_ldc,
            ctx->last_aa.as<float>(), ctx->scr[23].as<int>(), ctx->stitch.as<float>(), ctx->stitch_ld, ctx->stitch_T);
-    CK(hipStreamSynchronize(ctx->stream));                 // ind_m is the caller's
+    // (ind_m went through the pinned arena; the call returns with the accumulation queued behind the patch's HALS sweeps)
     ctx->last_t_valid = false;
     return 0;
 }

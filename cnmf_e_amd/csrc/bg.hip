@@ -1030,6 +1030,7 @@ static double matlab_quantile(std::vector<int> x, double q) {
 
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only, double thresh_outlier) {
+    HostTrace ht(ctx, "fit_ring");
     const bool outl = thresh_outlier == thresh_outlier;      // ~isnan(thresh_outlier), :50
     if (outl && !P->sn_ready && !(b0_only & 1)) return fail(CNMFE_ESTATE, "fit_ring_model with thresh_outlier needs the noise levels of the block (cnmfe_set_noise)");
     const int64_t T = P->T;
@@ -1050,6 +1051,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
     }
+    ht.mark("traces + A csr");
     if (b0_only & 1) {                                    // bg_ssub > 1: b0 = mean(Y - A*C, 2) on the patch (update_background_parallel.m:222-223)
         BgGeom g0{};
         g0.nr = P->nr; g0.nc = P->nc; g0.nr_b = P->nr_b; g0.nc_b = P->nc_b; g0.roff = P->roff; g0.coff = P->coff; g0.d = P->d; g0.d_b = P->d_b;
@@ -1060,15 +1062,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         return 0;
     }
     // ---- first-run test (:25): row 1 of W_old has exactly two distinct values (0 and 1/count) ----
+    // Both questions about W_old were answered behind the call that produced it (ring_stats_enqueue): no drain of the stream here, so with
+    // several patches per context the host sets up patch m + 1 while the GPU still solves patch m.
     bool first_run = false;
-    RET(ring_first_run(ctx, P, &first_run));
+    int pmax = 0;
+    RET(ring_stats_get(ctx, P, &pmax, &first_run));
     RET(dMisc.ensure(64));
-    CK(hipMemsetAsync(dMisc.p, 0, 64, ctx->stream));
-    LAUNCH(ctx, "bg_count_pos", k_count_pos, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->W.as<float>(), P->d, p, dMisc.as<int>());
-    int h_misc[2] = {0, 0};
-    CK(hipMemcpyAsync(h_misc, dMisc.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    const int pmax = h_misc[0];
+    ht.mark("first_run + pmax");
     int kstride = 1;
     if (with_projection) {                                // :84-87
         int64_t nk = std::min<int64_t>(T, (int64_t)pmax * 100);
@@ -1127,6 +1127,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         }
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
+    ht.mark("footprint block lists");
     g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
     const int nblk = g.nbr * g.nbc;
@@ -1145,15 +1146,16 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         CK(hipMemsetAsync(dMisc.p, 0, 64, ctx->stream));
         LAUNCH(ctx, "bg_active", k_active, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->W.as<float>(), g,
                P->ring_dr.as<int>(), P->ring_dc.as<int>(), dAsum.as<float>(), dActive.as<unsigned char>(), dMisc.as<int>());
-        CK(hipMemcpyAsync(h_misc, dMisc.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        nactive = h_misc[0];
+        // the count is only reported (info[2]): it lands in pinned memory and is read if the call ends with a drain anyway (b0_out)
+        CK(hipMemcpyAsync((char *)P->stat_host + 8, dMisc.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        nactive = -1;
     }
     // ---- b0 (:44) ----
     LAUNCH(ctx, "bg_b0", k_b0, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->ymean_d.as<double>(), g,
            has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCm.as<double>(), P->b0.as<double>());
 
-    if (nactive > 0) {
+    ht.mark("ind_active + b0");
+    {   // (pixels that are not active keep their weights: the solve kernel skips them; a patch without any costs the sweep of its tables)
         // ---- pair list: blocks that hold ring pixels of some patch pixel (or patch pixels), displacement within +-maxd ----
         std::vector<char> touched(nblk, 0);
         {
@@ -1222,6 +1224,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 if (any) work.push_back(pp * 4 + q);
             }
         const int nwork = (int)work.size();
+    ht.mark("pair / need / work tables");
         DevBuf &dWork = ctx->tmp[11], &dNeed = ctx->tmp[7];
         RET(to_dev(ctx, dPairs, pairs.data(), pairs.size()));
         RET(to_dev(ctx, dPairOf, pair_of.data(), pair_of.size()));
@@ -1259,9 +1262,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             RET(to_dev(ctx, dTcnt, tcnt.data(), tcnt.size()));
             RET(to_dev(ctx, dTl, tlist.data(), tlist.size()));
         }
-        // every host-side staging vector of this call has been consumed once the stream drains here -- and nothing heavy is queued
-        // yet: the three big launches below go out back to back, and without an output request the call returns with them in flight
-        CK(hipStreamSynchronize(ctx->stream));
+        // (every table above went through the pinned arena: no drain here, the big launches below queue behind whatever the stream still holds)
+        ht.mark("tile lists + uploads (sync)");
         // incremental: the table of the video alone is built once (fp64 pipe) and kept with the patch; later fits skip B1 / B2a entirely
         DevBuf &covT = incr ? P->cov_base : ctx->cov, &rsT = incr ? P->rowsum_base : ctx->rowsum;
         const bool f32s = !incr && !outl && ctx->opt("gram_mode", 3) >= 2;     // outlier branch: exact fp64 products of the fp32 Bf
@@ -1349,7 +1351,6 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 RET(to_dev(ctx, dSlot, slot_of.data(), slot_of.size()));
                 RET(to_dev(ctx, dBl, blall.data(), blall.size()));
                 RET(dCsum.ensure((size_t)K * sizeof(double)));
-                CK(hipStreamSynchronize(ctx->stream));                 // the staging vectors above die with this scope
                 LAUNCH(ctx, "bg_trace_subsum", k_trace_subsum, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, g.Tp, g.kstride, dCsum.as<double>());
                 {
                     const int nb_ = (int)blall.size();
@@ -1371,6 +1372,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 CK(hipMemcpyAsync(ctx->rowsum.p, P->rowsum_base.p, (size_t)nblk * BLKPX * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             }
         }
+        ht.mark("base / correction launches");
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
         const int n = p + 1;
@@ -1398,11 +1400,14 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                    ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe);
         } else return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
     }
+    RET(ring_stats_enqueue(ctx, P));                         // what the NEXT fit of this patch asks of the W being written now
+    ht.mark("solve launch");
     if (b0_out) {
         std::vector<double> tmp(P->d);
         CK(hipMemcpyAsync(tmp.data(), P->b0.p, P->d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         for (int64_t i = 0; i < P->d; ++i) b0_out[i] = (float)tmp[i];
+        if (nactive < 0) nactive = *reinterpret_cast<const int *>((const char *)P->stat_host + 8);
     }
     // without b0_out the call returns with the fit in flight (every later engine call is stream-ordered behind it)
     if (info) { info[0] = first_run ? 1 : 0; info[1] = kstride; info[2] = nactive; info[3] = pmax; }

@@ -7,6 +7,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <cstring>
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <algorithm>
@@ -138,6 +140,10 @@ struct Patch {
     DevBuf cov_base, rowsum_base;
     bool base_valid = false, derived = false;             // derived: a low-resolution patch of bg_ssub > 1 (its video is rebuilt every call)
     int base_kstride = 0;
+    // what the next fit asks of W before it can queue anything (pmax of fit_ring_model.m:60, row 1 for the first-run test of :25), copied to
+    // pinned memory behind the fit that produced W: the next fit reads it without draining the stream (ring_stats_*, api.hip)
+    DevBuf stat_dev; void *stat_host = nullptr; hipEvent_t stat_ev = nullptr; bool stat_valid = false;
+    ~Patch() { if (stat_host) (void)hipHostFree(stat_host); if (stat_ev) (void)hipEventDestroy(stat_ev); }
 };
 
 // device scratch of the OASIS kernels (deconv.hip): pool / task tables, grown on demand and kept with the context
@@ -145,9 +151,41 @@ struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, yb
 
 }  // namespace cnmfe
 
+namespace cnmfe {
+// Pinned staging for the small host -> device uploads of a call (index lists, CSR arrays, tables).  to_dev() copies the caller's data into
+// the arena and enqueues the transfer from there, so (a) the source may go away as soon as to_dev returns and (b) the call does not have to
+// drain the stream for that -- the host prepares the next patch while the GPU still works on this one.  Two halves: before allocating in a
+// half again, the host waits for the event that marks the last transfer enqueued out of it.
+struct PinArena {
+    char *p = nullptr; size_t cap = 0, off = 0; int half = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr}; bool ev_set[2] = {false, false};
+    int init(size_t bytes) {
+        if (p) return 0;
+        if (hipHostMalloc((void **)&p, bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; return -1; }
+        cap = bytes;
+        for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+        return 0;
+    }
+    // nullptr: the request does not fit half the arena (the caller copies straight from its buffer and waits)
+    void *take(size_t n, hipStream_t st) {
+        n = (n + 255) & ~size_t(255);
+        if (!p || n > cap / 2) return nullptr;
+        const size_t end = (size_t)(half + 1) * (cap / 2);
+        if (off + n > end) {
+            (void)hipEventRecord(ev[half], st); ev_set[half] = true;
+            half ^= 1; off = (size_t)half * (cap / 2);
+            if (ev_set[half]) (void)hipEventSynchronize(ev[half]);
+        }
+        void *r = p + off; off += n; return r;
+    }
+    ~PinArena() { if (p) (void)hipHostFree(p); for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]); }
+};
+}  // namespace cnmfe
+
 struct cnmfe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    cnmfe::PinArena pin;
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)
@@ -184,11 +222,30 @@ struct cnmfe_ctx {
 };
 
 namespace cnmfe {
+// option "host_trace" = 1: wall-clock marks of the host-side phases of a call on stderr (scripts/host_timeline.py)
+struct HostTrace {
+    bool on; const char *name; std::chrono::steady_clock::time_point t0, last;
+    HostTrace(cnmfe_ctx *ctx, const char *n) : on(ctx->opt("host_trace", 0) != 0), name(n) { if (on) t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host_trace] %s: %-28s %8.3f ms (at %8.3f)\n", name, what, std::chrono::duration<double, std::milli>(t - last).count(),
+                std::chrono::duration<double, std::milli>(t - t0).count());
+        last = t;
+    }
+};
 inline Patch *get_patch(cnmfe_ctx *ctx, int id) { auto it = ctx->patches.find(id); return it == ctx->patches.end() ? nullptr : it->second; }
 // upload a host vector to a DevBuf on the context stream
 template <class T> inline int to_dev(cnmfe_ctx *ctx, DevBuf &b, const T *h, size_t n) {
     RET(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
-    if (n) CK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (!n) return 0;
+    if (void *st = ctx->pin.take(n * sizeof(T), ctx->stream)) {             // staged: `h` is free again when this returns
+        memcpy(st, h, n * sizeof(T));
+        CK(hipMemcpyAsync(b.p, st, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    CK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));                                   // too large for the arena: straight from the caller's buffer
     return 0;
 }
 // [k][t] row-major fp32 copy of a K x T matrix given in `order`; device result has row stride ldc (multiple of 4)
@@ -233,6 +290,8 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P);
 int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out);
 int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
+int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P);                    // after W changed on the stream: count + row 1 to pinned memory, event
+int ring_stats_get(cnmfe_ctx *ctx, Patch *P, int *pmax, bool *first); // waits for that event only (falls back to a fresh evaluation)
 int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean);
 int ctx_errflag(cnmfe_ctx *ctx, int **dflag);            // the device error word (allocated and cleared on first use)
 int ctx_check_errflag(cnmfe_ctx *ctx);                   // after a stream sync: CNMFE_ESTATE if a kernel raised it (and clears it)

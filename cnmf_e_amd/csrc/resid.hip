@@ -1126,7 +1126,6 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     if (special) {
         RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1), variant == 12 ? 64 : 32));
         a.tile_map = dOffs.as<int>();
-        CK(hipStreamSynchronize(ctx->stream));           // the host-side staging vectors die with this call; the stream is near-idle here
         const dim3 gridd((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
         if (h == 15) rc = launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg);
         else if (h == 18) rc = launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);

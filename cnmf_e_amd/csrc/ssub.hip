@@ -332,6 +332,7 @@ int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, 
     if (R && R != F) {
         if (R->p != F->p || R->d != F->d) return fail(CNMFE_ESTATE, "fit / residual low-resolution patches have different rings");
         CK(hipMemcpyAsync(R->W.p, F->W.p, (size_t)F->p * F->d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        R->stat_valid = false;
         R->ysig_valid = false;
     }
     M->ysig_valid = false;

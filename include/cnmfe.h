@@ -106,7 +106,9 @@ int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0 /* d */);
  * outlier branch (:50-56: entries of the patch rows above W_old*Bf + thresh_outlier*sn are replaced by W_old*Bf; :62-67: only the frames
  * with at most the nmax/T quantile of outliers are regressed on) -- it needs the noise levels of the block (cnmfe_set_noise, else
  * CNMFE_ESTATE) and computes the Gram of the clipped residual directly (the kept video table does not apply); info[1] is 1 then.
- * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels, info[3]=pmax (known before the heavy kernels start).
+ * info[0]=first_run, info[1]=frame stride k, info[2]=#active pixels (-1 when the call returns without waiting for the device -- b0_out ==
+ * NULL on a later run), info[3]=pmax.  Nothing about W_old is asked of the device at call time: pmax and row 1 were copied to pinned memory
+ * behind the call that wrote W, so a fit does not drain the stream before it queues its kernels.
  * With b0_out == NULL the call returns while the Gram / solve kernels are still running on the context's stream; every later
  * call on this context is ordered behind them and reports their errors.
  * The first fit of a patch (and the first one after its frame stride k changes) also builds the block-pair covariance table of the

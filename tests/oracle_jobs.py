@@ -26,9 +26,10 @@ JOBS = {
     "m128_2x2": dict(d1=128, d2=128, T=3000, K=31, r=15, seed=9, alg="hals", patch=[64, 64], iters=2),
     "m96_r18": dict(d1=96, d2=96, T=1500, K=16, r=18, seed=11, alg="hals", iters=2),
     # outlier branch of fit_ring_model (:50-67; dead in every demo): with frame selection (24 ring offsets -> nmax = 2400 < T), without
-    # (nmax >= T), and through the low-resolution fit of bg_ssub = 2
-    "m64_outlier": dict(d1=64, d2=64, T=3000, K=8, r=4, seed=13, alg="hals", thresh_outlier=3.0, iters=2),
-    "m64_outlier_all": dict(d1=64, d2=64, T=1200, K=8, r=7, seed=14, alg="hals", thresh_outlier=2.5, iters=2),
+    # (nmax >= T), and through the low-resolution fit of bg_ssub = 2.  The first two meet a few fp32-flipped `>` decisions (see the test): one
+    # iteration only, a second one starts from weights that already differ by ~thresh/T and decides differently in many more places
+    "m64_outlier": dict(d1=64, d2=64, T=3000, K=8, r=4, seed=13, alg="hals", thresh_outlier=3.0, iters=1),
+    "m64_outlier_all": dict(d1=64, d2=64, T=1200, K=8, r=7, seed=14, alg="hals", thresh_outlier=2.5, iters=1),
     "m64_outlier_ssub2": dict(d1=64, d2=64, T=3000, K=8, r=8, seed=15, alg="hals", bg_ssub=2, thresh_outlier=3.0, iters=2),
     # BASELINE configs[1] (C2: 256 x 256 x 3000, K = 200, seed 1): a 64 x 64 window of the same video
     "c2_crop64": dict(d1=256, d2=256, T=3000, K=200, r=15, seed=1, alg="hals", crop=(96, 96, 64), iters=2),
