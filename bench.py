@@ -234,7 +234,10 @@ def main():
             return None
         n = (p or 96) + 1
         infos = [i_ for i_ in (last.get("bg") or {}).values()]
-        n_act = (sum(int(i_.get("n_active", 0)) for i_ in infos) / float(max(1, len(infos)))) or d      # per launch = per fitted patch
+        # per launch = per fitted patch; the engine reports -1 when it did not wait for the count (asynchronous fit): then every patch pixel
+        # (at the headline configuration 245152 of the 262144 are active: the ratio below is then 7 % high)
+        acts = [int(i_.get("n_active", -1)) for i_ in infos]
+        n_act = (sum(acts) / float(len(acts))) if acts and min(acts) >= 0 else d / float(max(1, len(video.owned)))
         ms = kern["bg_ring_solve"]["ms_per_call"]
         fl = n_act * 2.0 * (n ** 3 / 3.0 + 2.0 * n * n)
         return {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / F64_MFMA_PEAK_TF, "traffic": None,

@@ -72,6 +72,10 @@ PROTOTYPES = {
     "cnmfe_reconstruct_background_ssub": (C.c_int, [c_ctx, C.c_int, f32p, C.c_int64, C.c_int64, f32p, C.c_int]),
     "cnmfe_compute_rss_ssub": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, f32p, C.POINTER(C.c_double)]),
     "cnmfe_estimate_noise": (C.c_int, [c_ctx, C.c_int, C.c_int64, f32p]),
+    "cnmfe_stitch_finish_async": (C.c_int, [c_ctx, C.c_int, f32p]),
+    "cnmfe_stitch_wait": (C.c_int, [c_ctx]),
+    "cnmfe_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "cnmfe_host_free": (None, [C.c_void_p]),
     "cnmfe_set_noise": (C.c_int, [c_ctx, C.c_int, f32p]),
     "cnmfe_patch_derive": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, C.c_int]),
     "cnmfe_fit_ring_model_ssub": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,

@@ -274,14 +274,29 @@ struct Rccl {
     }
 };
 static Rccl g_rccl;
-static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order) {
+static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order, bool async_copy = false) {
     if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
     const int32_t K = ctx->stitch_K; const int64_t T = ctx->stitch_T, ldc = (T + 3) & ~int64_t(3);
     CK(hipSetDevice(ctx->device));
     RET(ctx->bound.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
+    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last download still reads `bound`
     if (K > 0) LAUNCH(ctx, "stitch_finish", k_stitch_finish, dim3((unsigned)K), dim3(256), 0, ctx->stitch.as<float>(), ctx->stitch_ld, T, subtract_min, ctx->bound.as<float>(), ldc);
     ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = (c_order == CNMFE_COLMAJOR) ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR; ctx->bound_valid = K > 0;
     ctx->stitch_open = false;
+    if (C_raw_out && async_copy && K > 0) {
+        // the copy goes out on its own stream behind an event: the compute stream is free for the next call's kernels at once
+        if (!ctx->copy_stream) {
+            CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            CK(hipEventCreateWithFlags(&ctx->ev_bound_ready, hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&ctx->ev_copy_done, hipEventDisableTiming));
+        }
+        CK(hipEventRecord(ctx->ev_bound_ready, ctx->stream));
+        CK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_bound_ready, 0));
+        CK(hipMemcpy2DAsync(C_raw_out, T * sizeof(float), ctx->bound.p, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->copy_stream));
+        CK(hipEventRecord(ctx->ev_copy_done, ctx->copy_stream));
+        ctx->copy_pending = true;
+        return 0;
+    }
     if (C_raw_out) RET(download_traces(ctx, ctx->bound.as<float>(), ldc, C_raw_out, K, T, c_order == CNMFE_COLMAJOR ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR));
     return 0;
 }
@@ -320,6 +335,9 @@ cnmfe_ctx::~cnmfe_ctx() {
     if (rccl_comm && g_rccl.CommDestroy) { (void)hipSetDevice(device); g_rccl.CommDestroy(rccl_comm); rccl_comm = nullptr; }
     for (auto &kv : patches) delete kv.second;
     prof.drain();
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    if (ev_bound_ready) (void)hipEventDestroy(ev_bound_ready);
+    if (ev_copy_done) (void)hipEventDestroy(ev_copy_done);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -351,6 +369,7 @@ void cnmfe_destroy(cnmfe_ctx *ctx) {
 int cnmfe_synchronize(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) CK(hipStreamSynchronize(ctx->copy_stream));
     return ctx_check_errflag(ctx);
 }
 
@@ -798,6 +817,25 @@ int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int 
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     return stitch_finish_one(ctx, subtract_min, C_raw_out, c_order);
 }
+
+int cnmfe_stitch_finish_async(cnmfe_ctx *ctx, int subtract_min, float *C_raw_pinned) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (!C_raw_pinned) return fail(CNMFE_EINVAL, "null C_raw_pinned");
+    return stitch_finish_one(ctx, subtract_min, C_raw_pinned, CNMFE_ROWMAJOR, true);
+}
+
+int cnmfe_stitch_wait(cnmfe_ctx *ctx) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (ctx->ev_copy_done && ctx->copy_stream) CK(hipStreamSynchronize(ctx->copy_stream));
+    return 0;
+}
+
+void *cnmfe_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(CNMFE_EHIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void cnmfe_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order) {
     if (!ctxs || n <= 0) return fail(CNMFE_EINVAL, "no contexts");

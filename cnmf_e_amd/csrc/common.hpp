@@ -186,6 +186,8 @@ struct cnmfe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     cnmfe::PinArena pin;
+    hipStream_t copy_stream = nullptr;                     // device -> pinned host downloads that should not hold up the compute stream
+    hipEvent_t ev_bound_ready = nullptr, ev_copy_done = nullptr; bool copy_pending = false;
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)

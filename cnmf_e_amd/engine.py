@@ -94,7 +94,74 @@ class DeviceTraces:
         return self.tensor.data_ptr()
 
 
+class LazyHostTraces:
+    """The K x T result of the temporal update as the host sees it: the engine keeps the matrix bound on the device (that is what the next
+    background / spatial / temporal calls read) and streams a copy into pinned host memory on a second stream; the first time somebody
+    READS the values (np.asarray, indexing, mean) this object waits for that copy -- never for the compute stream.  Identity of the bound
+    matrix like any array returned by stitch_finish."""
+    def __init__(self, eng, K, T):
+        self._eng = eng
+        self.shape = (int(K), int(T)); self.dtype = np.dtype(np.float32); self.ndim = 2
+        self.flags = {"C_CONTIGUOUS": True}
+        self._nbytes = max(1, K * T) * 4
+        self._ptr = eng._pinned_take(self._nbytes)
+        self._arr = np.ctypeslib.as_array(C.cast(self._ptr, L.f32p), shape=(max(1, K * T),))[:K * T].reshape(K, T)
+        self._ready = False
+    def host(self):
+        if not self._ready:
+            L.check(L.lib.cnmfe_stitch_wait(self._eng._ctx))
+            self._ready = True
+        return self._arr
+    def __array__(self, dtype=None, copy=None):
+        a = self.host()
+        return a if dtype is None else a.astype(dtype, copy=False)
+    def __getitem__(self, key):
+        return self.host()[key]
+    def __len__(self):
+        return self.shape[0]
+    def mean(self, *a, **k):
+        return self.host().mean(*a, **k)
+    def copy(self):
+        return self.host().copy()
+    def astype(self, *a, **k):
+        return self.host().astype(*a, **k)
+    def __getattr__(self, name):                      # everything else an ndarray has (.T, .sum, .max, ...): the host copy's
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.host(), name)
+    def __del__(self):
+        try:
+            if not self._ready:
+                L.lib.cnmfe_stitch_wait(self._eng._ctx)          # the copy may still be writing into the buffer
+            self._eng._pinned_give(self._ptr, self._nbytes)
+        except Exception:
+            pass
+
+
+for _op in ("add", "sub", "mul", "truediv", "radd", "rsub", "rmul", "rtruediv", "lt", "le", "gt", "ge", "eq", "ne", "neg", "abs", "matmul", "rmatmul"):
+    setattr(LazyHostTraces, "__%s__" % _op, (lambda op: lambda self, *a: getattr(self.host(), "__%s__" % op)(*a))(_op))
+LazyHostTraces.__hash__ = object.__hash__
+
+
 class Engine:
+    supports_lazy_traces = True
+    # pinned buffers of LazyHostTraces, recycled by size (page-locking 20 MB costs milliseconds)
+    def _pinned_take(self, nbytes):
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        lst = pool.get(nbytes)
+        if lst:
+            return lst.pop()
+        p = L.lib.cnmfe_host_alloc(nbytes)
+        if not p:
+            raise L.CnmfeError(L.lib.cnmfe_last_error().decode("utf-8", "replace"))
+        return p
+    def _pinned_give(self, ptr, nbytes):
+        pool = self.__dict__.get("_pinned_pool")
+        if pool is None or getattr(self, "_ctx", None) is None:
+            L.lib.cnmfe_host_free(ptr)
+        else:
+            pool.setdefault(nbytes, []).append(ptr)
+
     # -- bound traces: obj.C is the same matrix for several calls of one iteration; bind_traces uploads it once and every
     # call that is handed THAT array object afterwards passes (NULL, CNMFE_BOUND).  The array must not be mutated in place
     # while it is bound (Sources2D replaces C, it never writes into it).
@@ -134,6 +201,9 @@ class Engine:
         if getattr(self, "_ctx", None):
             L.lib.cnmfe_destroy(self._ctx)
             self._ctx = None
+            for lst in self.__dict__.pop("_pinned_pool", {}).values():
+                for ptr in lst:
+                    L.lib.cnmfe_host_free(ptr)
 
     def __del__(self):
         try:
@@ -405,6 +475,11 @@ class Engine:
         """C_raw = acc ./ aa (aa == 0 -> 1), minus the row minima without deconvolution (:279-286); the result becomes the engine's bound
         trace matrix, and the returned host copy its identity: passing THAT array to later calls costs no upload"""
         K, T = self._stitch_shape
+        if want == "lazy" and K > 0:
+            out = LazyHostTraces(self, K, T)
+            L.check(L.lib.cnmfe_stitch_finish_async(self._ctx, int(bool(subtract_min)), C.cast(out._ptr, L.f32p)))
+            self._bound = out
+            return out
         out = np.empty((K, T), dtype=np.float32) if want else None
         L.check(L.lib.cnmfe_stitch_finish(self._ctx, int(bool(subtract_min)), _p(out, L.f32p), L.ROWMAJOR))
         self._bound = out if (want and K > 0) else None

@@ -612,6 +612,7 @@ class Sources2D:
             raise NotImplementedError("search_method must be 'ellipse' or 'dilate'")
         K = self.A.shape[1]
         rows, cols, vals = [], [], []
+        whole_result = None
         IND = None
         for idx in v.owned:
             pp, bp, ip = v.patch_pix[idx], v.block_pix[idx], v.ind_patch[idx]
@@ -645,10 +646,15 @@ class Sources2D:
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
             Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                               sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
+            if pp.size == v.d1 * v.d2 and ind.size == K:
+                whole_result = Anew                                                                  # one patch over the whole FOV, every neuron: already A_
+                continue
             coo = Anew.tocoo()
             rows.append(pp[coo.row]); cols.append(ind[coo.col]); vals.append(coo.data)             # :324-334 (patches are disjoint)
         d = v.d1 * v.d2
-        if rows:
+        if whole_result is not None:
+            A_ = whole_result
+        elif rows:
             A_ = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(d, K))
         else:
             A_ = sp.csc_matrix((d, K), dtype=np.float32)
@@ -864,7 +870,10 @@ class Sources2D:
             eng.stitch_add(ind)                                                                       # :274-275
         if sharded:                                                        # the overlap-region stitch: ONE all-reduce, in place on the device
             eng.stitch_allreduce(self.dist)
-        C_raw = eng.stitch_finish(subtract_min=not o.deconv_flag)                                     # :279-280, :285
+        # without deconvolution nobody needs the values on the host right away: the engine keeps the matrix bound and streams a copy into pinned
+        # memory behind the kernels (LazyHostTraces); the next background fit is set up while the temporal sweep is still running
+        lazy = (not o.deconv_flag) and getattr(eng, "supports_lazy_traces", False)
+        C_raw = eng.stitch_finish(subtract_min=not o.deconv_flag, want="lazy" if lazy else True)       # :279-280, :285
         if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
             self.C_raw = C_raw
             self.C = self.deconvTemporal()

@@ -250,6 +250,13 @@ int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m);
 int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld);
 int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order);
 int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order);
+/* cnmfe_stitch_finish without the wait: the host copy (row-major K x T) is written by a second stream into PINNED memory (cnmfe_host_alloc) and is
+ * complete after cnmfe_synchronize(ctx); the call itself returns at once, so the caller can set up the next background fit -- which takes the
+ * traces from the device binding this call leaves -- while the temporal kernels and the download are still running. */
+int cnmfe_stitch_finish_async(cnmfe_ctx *ctx, int subtract_min, float *C_raw_pinned);
+int cnmfe_stitch_wait(cnmfe_ctx *ctx);         /* waits for the downloads of cnmfe_stitch_finish_async only (not for the compute stream) */
+void *cnmfe_host_alloc(size_t bytes);          /* page-locked host memory (NULL + cnmfe_last_error on failure) */
+void cnmfe_host_free(void *p);
 
 /* ---- objective: [RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, one patch, all frames:
  *   RSS = sum((Y(patch,:) - A(patch,:)*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)

@@ -65,7 +65,9 @@ def pytest_sessionfinish(session, exitstatus):
             _observed["rel_by_call_site"] = parity_util.RECORD
     except Exception:
         pass
+    gpu_run = any(item.get_closest_marker("gpu") for item in getattr(session, "items", []))
     if _observed and os.path.isdir(out):
         import json
-        with open(os.path.join(out, "parity_observed.json"), "w") as fh:
+        # (a CPU-only session must not overwrite the record of the last GPU session)
+        with open(os.path.join(out, "parity_observed.json" if gpu_run else "parity_observed_cpu.json"), "w") as fh:
             json.dump(_observed, fh, indent=1, sort_keys=True)

@@ -101,7 +101,7 @@ def test_full_iteration_recovers_planted_model_and_reduces_rss(big):
         At = torch.sparse_coo_tensor(np.vstack(s.A.tocoo().coords), s.A.tocoo().data.astype(np.float32), s.A.shape, device="cuda")
         # constant per-pixel offsets are excluded: the residual kernel uses b0 of the last BACKGROUND update, while the
         # temporal update shifts every trace to min 0 (b0_new absorbs that only at the next background update)
-        Ct = torch.from_numpy(s.C).cuda()
+        Ct = torch.from_numpy(np.asarray(s.C)).cuda()
         s1 = torch.zeros(D1 * D2, dtype=torch.float64, device="cuda"); s2 = 0.0
         for t0 in range(0, T, 1000):
             res = (out[t0:t0 + 1000] - torch.sparse.mm(At, Ct[:, t0:t0 + 1000]).T).double()
