@@ -73,6 +73,7 @@ PROTOTYPES = {
     "cnmfe_compute_rss_ssub": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, f32p, C.POINTER(C.c_double)]),
     "cnmfe_estimate_noise": (C.c_int, [c_ctx, C.c_int, C.c_int64, f32p]),
     "cnmfe_stitch_finish_async": (C.c_int, [c_ctx, C.c_int, f32p]),
+    "cnmfe_update_spatial_fetch": (C.c_int, [c_ctx, f32p, C.c_int64]),
     "cnmfe_stitch_wait": (C.c_int, [c_ctx]),
     "cnmfe_host_alloc": (C.c_void_p, [C.c_size_t]),
     "cnmfe_host_free": (None, [C.c_void_p]),

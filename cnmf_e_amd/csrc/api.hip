@@ -691,11 +691,18 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
     RET(check_csc("IND", K, P->d, IND_colptr, IND_rowidx));
-    if ((!C && c_order != CNMFE_BOUND) || !A_out) return fail(CNMFE_EINVAL, "null C / A_out");
+    if (!C && c_order != CNMFE_BOUND) return fail(CNMFE_EINVAL, "null C");
     if (algorithm == CNMFE_SPATIAL_HALS_THRESH && !sn) return fail(CNMFE_EINVAL, "HALS_THRESH needs sn");
     if (param <= 0) return fail(CNMFE_EINVAL, "maxIter/maxN must be positive");
     CK(hipSetDevice(ctx->device));
     return spatial_run(ctx, P, algorithm, K, A_colptr, A_rowidx, A_val, C, c_order, IND_colptr, IND_rowidx, sn, param, A_out);
+}
+
+int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (!A_out && nnz) return fail(CNMFE_EINVAL, "null A_out");
+    CK(hipSetDevice(ctx->device));
+    return spatial_fetch(ctx, A_out, nnz);
 }
 
 int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,

@@ -186,6 +186,7 @@ struct cnmfe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     cnmfe::PinArena pin;
+    int64_t spatial_nnz = -1;                              // values of the last cnmfe_update_spatial still in scr[6] (deferred fetch)
     hipStream_t copy_stream = nullptr;                     // device -> pinned host downloads that should not hold up the compute stream
     hipEvent_t ev_bound_ready = nullptr, ev_copy_done = nullptr; bool copy_pending = false;
     cnmfe::Profiler prof;
@@ -291,6 +292,7 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
                  const float *A_val, uint8_t *keep);
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P);
 int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out);
+int spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz);
 int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
 int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P);                    // after W changed on the stream: count + row 1 to pinned memory, event
 int ring_stats_get(cnmfe_ctx *ctx, Patch *P, int *pmax, bool *first); // waits for that event only (falls back to a fresh evaluation)

@@ -354,6 +354,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
                 const float *A_val, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
                 const float *sn, int32_t param, float *A_out) {
     const int64_t T = P->T, d = P->d, nnz = IND_colptr[K];
+    ctx->spatial_nnz = nnz == 0 ? 0 : -1;
     if (nnz == 0) return 0;
     if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(IND) too large");
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2];
@@ -416,7 +417,16 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
                        dColptr.as<int64_t>(), dErow.as<int>(), dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K,
                        dSn.as<float>(), algorithm == CNMFE_SPATIAL_HALS_THRESH ? 1 : 0, dAval.as<float>());
     }
+    ctx->spatial_nnz = nnz;                                  // the result stays in scr[6] until the next spatial update (cnmfe_update_spatial_fetch)
+    if (!A_out) return 0;                                    // deferred: the caller does other host work under the sweeps and fetches afterwards
     CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
+    if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
+    if (nnz) CK(hipMemcpyAsync(A_out, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -340,8 +340,9 @@ class Engine:
         L.check(L.lib.cnmfe_get_sn(self._ctx, pid, _p(out, L.f32p)))
         return out
 
-    def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3):
-        """Returns the updated A as a CSC matrix with exactly IND's pattern (explicit zeros kept)."""
+    def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3, defer=False):
+        """Returns the updated A as a CSC matrix with exactly IND's pattern (explicit zeros kept).  defer=True returns a callable instead that
+        fetches it: the sweeps are queued, the caller does other host work under them and calls it afterwards (before the next spatial update)."""
         info = self._patch[pid]
         alg = {"hals": L.SPATIAL_HALS, "hals_thresh": L.SPATIAL_HALS_THRESH, "nnls": L.SPATIAL_NNLS}[algorithm]
         K, cp, ri, va = _csc(A_patch, info["d"])
@@ -354,7 +355,12 @@ class Engine:
         snf = np.ascontiguousarray(sn, dtype=np.float32).ravel() if sn is not None else None
         out = np.zeros(icp[-1], dtype=np.float32)
         L.check(L.lib.cnmfe_update_spatial(self._ctx, pid, alg, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
-                                           _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), _p(out, L.f32p)))
+                                           _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), None if defer else _p(out, L.f32p)))
+        if defer:
+            def fetch():
+                L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
+                return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
+            return fetch
         return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
 
     def hals_temporal(self, pid, A_patch, C_patch, maxIter=5, want_C=True, want_raw=True):

@@ -385,8 +385,10 @@ class Sources2D:
         if hasattr(self.engine, "bind_traces"):
             self.engine.bind_traces(self.C)
 
-    def _residual(self, idx, A_prev_b, C_prev_b):
-        """the background-subtraction expression of update_spatial_parallel.m:162-178 / update_temporal_parallel.m:149-165"""
+    def _residual(self, idx, A_prev_b, C_prev_b, tag=None):
+        """the background-subtraction expression of update_spatial_parallel.m:162-178 / update_temporal_parallel.m:149-165.
+        tag: who asked (see _temporal_residual_early); any other request replaces it"""
+        self.__dict__.setdefault("_resid_tag", {})[idx] = tag
         if self.ssub == 1:
             self.engine.residual(self.video.pid[idx], A_prev_b, C_prev_b)
         else:
@@ -553,6 +555,7 @@ class Sources2D:
             # first-run test on W{m}(1,:) exactly like :143; an empty A_block on a later run keeps W, b0.
             if A_block.shape[1] == 0 and not flag_first:
                 continue
+            getattr(self, "_resid_tag", {}).pop(idx, None)                 # W, b0 of this patch change: its resident residual goes with them
             if not prefetched:                                             # host thread under the first blocking (GIL-free) fit call
                 self._prefetch_search_location(); prefetched = True
             if not np.isnan(o.thresh_outlier):                             # :131-138: sn of the block, resized for bg_ssub > 1
@@ -579,6 +582,18 @@ class Sources2D:
         self._prev_csr_src = self.A
         self.C_prev = self.C                                               # :317
         return infos
+
+    def _temporal_residual_early(self, idx):
+        """update_temporal_parallel.m:149-152 asks for the residual of (A_prev, C_prev) on the block -- both known since the background update.
+        The engine only RECORDS that request while the resident Ysig still serves the spatial update (pending footprint term), so
+        the host-side part of it is done here, under the spatial sweeps that were just queued; the temporal update then finds it in place."""
+        indp, A_prev_b = self._prev_block_of(idx)
+        self._residual(idx, A_prev_b if indp.size else None, self._rows(self.C_prev, indp) if indp.size else None,
+                       tag=("temporal", self.A_prev, self.C_prev))
+
+    def _temporal_residual_done(self, idx):
+        t = getattr(self, "_resid_tag", {}).get(idx)
+        return t is not None and t[0] == "temporal" and t[1] is self.A_prev and t[2] is self.C_prev
 
     def _prev_block_of(self, idx):
         """(ind, A_prev(block rows, ind)) for the neurons of A_prev that touch the block (update_temporal_parallel.m:90-91); cached by
@@ -644,8 +659,14 @@ class Sources2D:
             A_patch = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # :88,199
             C_patch = self._rows(self.C, ind)                                                       # :91
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
-            Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
-                                              sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
+            if getattr(self.engine, "supports_lazy_traces", False):
+                fetch = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
+                                                   sn_patch if o.spatial_algorithm == "hals_thresh" else None, param, defer=True)
+                self._temporal_residual_early(idx)                       # host work under the sweeps
+                Anew = fetch()
+            else:
+                Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
+                                                  sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
             if pp.size == v.d1 * v.d2 and ind.size == K:
                 whole_result = Anew                                                                  # one patch over the whole FOV, every neuron: already A_
                 continue
@@ -843,7 +864,8 @@ class Sources2D:
             whole = bp.size == v.d1 * v.d2                                 # this block is the whole field of view (then so is the patch): no row slicing
             if launched:
                 # the sweep (:149-152) only needs (A_prev, C_prev): start it, slice the current A underneath it
-                self._residual(idx, A_prev_b if indp.size else None, C_prev_b)
+                if not self._temporal_residual_done(idx):
+                    self._residual(idx, A_prev_b if indp.size else None, C_prev_b)
                 launched_any = True
                 self._cur_blocks, self._cur_blocks_src = {}, self.A
             if whole:
@@ -856,7 +878,7 @@ class Sources2D:
                 ind, A_blk = self._cur_blocks[idx] = self._slice(self.A, idx, "block")               # :83
             if ind.size == 0:
                 continue                                                                              # :123
-            if not launched:
+            if not launched and not self._temporal_residual_done(idx):
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self._rows(self.C, ind)                                                        # :86
             if not whole:

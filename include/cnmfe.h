@@ -181,12 +181,15 @@ int cnmfe_get_sn(cnmfe_ctx *ctx, int patch_id, float *sn_out);
  * Y = the resident Ysig of this patch (cnmfe_residual must have been called).
  * A is d x K CSC over PATCH rows, IND (active_pixel) d x K CSC pattern, sn d floats
  * (HALS_THRESH only).  param = maxIter (HALS*) or maxN (NNLS).  The result has exactly
- * the IND pattern: A_out[nnz(IND)] in IND's CSC order (entries may be 0). */
+ * the IND pattern: A_out[nnz(IND)] in IND's CSC order (entries may be 0).
+ * A_out == NULL defers the download: the call returns with the sweeps queued and cnmfe_update_spatial_fetch(ctx, A_out, nnz(IND)) collects the
+ * values later (valid until the next spatial update of this context) -- the host mirror sets up the temporal update's residual in between. */
 int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
                          const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                          const float *C, int c_order,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx,
                          const float *sn, int32_t param, float *A_out);
+int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz);
 
 /* ---- fast_temporal (use_c_hat = false)                @Sources2D/update_temporal_parallel.m:174-175,314-337
  *   tmp_A = A .* (A ./ max(A,[],1) >= 0.5);  aa = sum(tmp_A.^2,1);  C_raw = (tmp_A' * Ysig) ./ aa'
