@@ -1,8 +1,8 @@
 """Idle gaps of the GPU between consecutive kernels of one iteration, from a rocprofv3 --kernel-trace CSV: python scripts/gap_analysis.py <kernel_trace.csv> [n_last_kernels]"""
 import csv, sys
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))), key=lambda x: x[0])
-# last iteration = from the last-but-one k_count_pos (first kernel of a background fit) to the last one
-idx = [i for i, r in enumerate(rows) if "k_count_pos" in r[2]]
+# one iteration = from one k_ring_pmax (the kernel a background fit ends with) to the next
+idx = [i for i, r in enumerate(rows) if "k_ring_pmax" in r[2]]
 a, b = idx[-2], idx[-1]
 it = rows[a:b]
 span = (it[-1][1] - it[0][0]) / 1e6
