@@ -15,7 +15,8 @@ group = None
 if world > 1:                                   # sharded run on ONE device (gloo): host-side costs of rank 0; kernel times are inflated by the shared GPU
     import torch.distributed as td
     td.init_process_group(backend="gloo"); group = td.group.WORLD
-    a.npatch = world
+    if a.patch == 512:
+        a.npatch = world                        # weak: the FOV grows with the ranks; with --patch 128 the 4 x 4 patches of the fixed FOV are sharded (c4)
 d1, d2, T, K, r, seed = 512, 512 * a.npatch, 10000, 500 * a.npatch, 15, 2
 f = synth.make_factors(d1, d2, T, K, seed)
 Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
