@@ -623,3 +623,38 @@ def test_outlier_branch_with_exact_decisions(eng, pdims, r, T, thr):
         v2 = PatchedVideo(d1, d2, T, [d1, d2], r, eng); v2.upload_from_full(Y)
         eng.ring_init(v2.pid[v2.order[0]], r)
         eng.fit_ring_model(v2.pid[v2.order[0]], None, None, thresh_outlier=thr)
+
+
+def test_lazy_traces_keep_their_iteration(eng):
+    """The temporal update hands C back as a LazyHostTraces (device binding + copy into pinned memory on a second stream).  Two runs in lockstep on
+    two contexts: one reads C after every iteration, the other keeps the lazy objects of three iterations unread until the very end -- each must
+    still hold ITS iteration's values (own pinned buffer; the next stitch waits for the copy before it overwrites the bound matrix)."""
+    from cnmf_e_amd.engine import Engine, LazyHostTraces
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    from cnmf_e_amd import synth
+    d1, d2, T, K, r = 40, 36, 300, 5, 5
+    f = synth.make_factors(d1, d2, T, K, 31, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    eng2 = Engine(0)
+    try:
+        runs = []
+        for e in (eng, eng2):
+            v = PatchedVideo(d1, d2, T, [20, 18], r, e)
+            v.upload_from_full(Y)
+            runs.append(Sources2D(v, Options(ring_radius=r, maxIter=3), f.A_init, f.C_init, f.sn))
+        eager, lazy, kept = [], runs[1], []
+        for it in range(3):
+            for s in runs:
+                s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+            eager.append(np.asarray(runs[0].C).copy())
+            assert isinstance(lazy.C, LazyHostTraces) and not lazy.C._ready
+            kept.append(lazy.C)
+        for it in range(3):
+            assert np.array_equal(np.asarray(kept[it]), eager[it]), it
+        assert not np.array_equal(eager[0], eager[2])
+        # arithmetic / reductions / indexing go through the host copy
+        c = kept[2]
+        assert c.shape == eager[2].shape and np.allclose(c.mean(axis=1), eager[2].mean(axis=1)) and np.array_equal(c[1], eager[2][1])
+        assert np.array_equal(c - eager[2], np.zeros_like(eager[2])) and float(c.max()) == float(eager[2].max())
+    finally:
+        eng2.close()
