@@ -201,6 +201,28 @@ def main():
         return {"bound": "hbm", "achieved": bytes_r1 / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_r1 / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "residual_r1", "ms_per_launch": ms,
                 "algorithmic_bytes_per_launch": bytes_r1}
+    def proj_roofs():
+        """the two projection kernels (north_star's "residual projections"): S1 U = Ysig*C' on the search mask (HALS_spatial.m:27-32) and T1
+        U = A'*Ysig (HALS_temporal.m:48).  Algorithmic bytes = the rows of Ysig a launch needs, once (pixels under the mask / under a footprint,
+        x T x 4) + the K x T traces read (S1) or written (T1) + the mask / footprint entries; whole-FOV single patch only."""
+        if world != 1 or len(video.owned) != 1 or a.bg_ssub != 1:
+            return None
+        out = {}
+        try:
+            Acsc = s.A.tocsc()
+            IND = s._search_location_owned(Acsc)
+            npix = {"spatial_proj_U": int(np.unique(IND.indices).size), "temporal_proj_U": int(np.unique(Acsc.indices).size)}
+            nnz = {"spatial_proj_U": int(IND.nnz), "temporal_proj_U": int(Acsc.nnz)}
+        except Exception:
+            return None
+        for name in ("spatial_proj_U", "temporal_proj_U"):
+            if name not in kern:
+                continue
+            by = 4.0 * npix[name] * T + 4.0 * K * T + 8.0 * nnz[name]
+            ms = kern[name]["ms_per_call"]
+            out[name] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": name, "ms_per_launch": ms, "algorithmic_bytes_per_launch": by, "pixels_read": npix[name], "entries": nnz[name]}
+        return out or None
     def gram_roof(name, peak):
         ms = kern[name]["ms_per_call"]
         flops_ref = 2.0 * d * (p + 1) ** 2 * T / 2.0        # SURVEY 8(d) B2: the reference's per-pixel Gram, symmetric count, first run (T' = T)
@@ -295,6 +317,7 @@ def main():
         "roofline_r1": r1r,
         "roofline_solve": solve_roof(),
         "roofline_r1_delta": dlr,
+        "roofline_projections": proj_roofs(),
         "first_iteration": {"ms": warm_ms if a.warmup else None,
                             "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},
                             "note": "the first background fit of a patch also builds the block-pair covariance table of the video on the fp64 matrix pipe (kept until the "
