@@ -1046,8 +1046,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
         RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
         csc_to_csr(P->d_b, K, A_colptr, A_rowidx, A_val, csr);
-        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
-        RET(to_dev(ctx, dArow, rp.data(), rp.size()));
+        RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
     }

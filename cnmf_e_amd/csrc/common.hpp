@@ -86,17 +86,17 @@ constexpr int BLK = 16;           // 16x16-pixel covariance blocks
 constexpr int BLKPX = BLK * BLK;
 
 // ---- sparse helpers (host) ------------------------------------------------------
-struct HostCSR { std::vector<int64_t> rowptr; std::vector<int32_t> col; std::vector<float> val; std::vector<int32_t> src; };
+struct HostCSR { std::vector<int32_t> rowptr;   /* nnz < 2^31 everywhere (checked by the callers): the device wants 32-bit row pointers anyway */ std::vector<int32_t> col; std::vector<float> val; std::vector<int32_t> src; };
 // CSC (ncol columns, nrow rows) -> CSR with `src` = index into the CSC arrays
 inline void csc_to_csr(int64_t nrow, int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, HostCSR &out) {
     int64_t nnz = colptr[ncol];
     out.rowptr.assign(nrow + 1, 0); out.col.resize(nnz); out.val.resize(nnz); out.src.resize(nnz);
     for (int64_t e = 0; e < nnz; ++e) out.rowptr[rowidx[e] + 1]++;
     for (int64_t r = 0; r < nrow; ++r) out.rowptr[r + 1] += out.rowptr[r];
-    std::vector<int64_t> cur(out.rowptr.begin(), out.rowptr.end() - 1);
+    std::vector<int32_t> cur(out.rowptr.begin(), out.rowptr.end() - 1);
     for (int32_t k = 0; k < ncol; ++k)
         for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
-            int64_t pos = cur[rowidx[e]]++; out.col[pos] = k; out.val[pos] = val ? val[e] : 1.0f; out.src[pos] = (int32_t)e;
+            int32_t pos = cur[rowidx[e]]++; out.col[pos] = k; out.val[pos] = val ? val[e] : 1.0f; out.src[pos] = (int32_t)e;
         }
 }
 

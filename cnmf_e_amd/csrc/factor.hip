@@ -360,6 +360,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2];
     DevBuf *S_ = ctx->scr;
     DevBuf &dColptr = S_[0], &dErow = S_[1], &dEcol = S_[2], &dRptr = S_[3], &dRcol = S_[4], &dRsrc = S_[5], &dAval = S_[6], &dU = S_[7], &dPart = S_[8], &dV = S_[9], &dPairs = S_[10], &dSn = S_[11], &dLvl = S_[12];
+    HostTrace ht(ctx, "spatial");
     int64_t ldc;
     RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
     RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
@@ -374,10 +375,12 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
             if (a < ae && A_rowidx[a] == IND_rowidx[e] && algorithm != CNMFE_SPATIAL_NNLS) aval[e] = A_val[a];
         }
     }
+    ht.mark("traces + A on the mask");
     HostCSR csr; csc_to_csr(d, K, IND_colptr, IND_rowidx, nullptr, csr);
+    ht.mark("csr of the mask");
     if (algorithm == CNMFE_SPATIAL_NNLS && ((int)param > NN_MAX || (int)param < 1))
         return fail(CNMFE_EUNSUPPORTED, "maxN = %d; the NNLS kernel holds 1..%d passive variables", (int)param, NN_MAX);
-    std::vector<int32_t> rptr(csr.rowptr.begin(), csr.rowptr.end());
+    const std::vector<int32_t> &rptr = csr.rowptr;
     RET(to_dev(ctx, dColptr, IND_colptr, (size_t)K + 1));
     RET(to_dev(ctx, dErow, IND_rowidx, (size_t)nnz));
     RET(to_dev(ctx, dEcol, ecol.data(), (size_t)nnz));
@@ -394,9 +397,11 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, P->ysig.as<float4>(), d, T,
            dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
     LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
+    ht.mark("uploads + projection launch");
     // S2 on the co-occurrence pairs
     std::vector<char> include(K, 1);
     PairGraph g; build_graph(K, csr, d, include, g);
+    ht.mark("graph");
     RET(to_dev(ctx, dPairs, g.pairs.data(), g.pairs.size()));
     RET(dV.ensure((size_t)K * K * sizeof(float)));
     CK(hipMemsetAsync(dV.p, 0, (size_t)K * K * sizeof(float), ctx->stream));
@@ -417,6 +422,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
                        dColptr.as<int64_t>(), dErow.as<int>(), dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K,
                        dSn.as<float>(), algorithm == CNMFE_SPATIAL_HALS_THRESH ? 1 : 0, dAval.as<float>());
     }
+    ht.mark("sweep launches");
     ctx->spatial_nnz = nnz;                                  // the result stays in scr[6] until the next spatial update (cnmfe_update_spatial_fetch)
     if (!A_out) return 0;                                    // deferred: the caller does other host work under the sweeps and fetches afterwards
     CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -496,6 +502,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     DevBuf *S_ = ctx->scr;
     DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dU = S_[7], &dCraw = ctx->last_craw, &dNk = S_[14], &dNidx = S_[15], &dNval = S_[16], &dNptr = S_[17], &dAa = ctx->last_aa, &dLvl = S_[12], &dOvf = S_[18];
     ctx->last_t_valid = false;
+    HostTrace ht(ctx, "temporal");
     int64_t ldc;
     RET(upload_traces(ctx, dC, C_in, K, T, c_order, &ldc));
     RET(to_dev(ctx, dColptr, A_colptr, (size_t)K + 1));
@@ -529,6 +536,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         if (rc_ > 0) RET(reproject());
         else term_applied = P->pend;
     }
+    ht.mark("uploads + projection launch");
     // T2: overlap graph + V values (neighbour lists include k itself: V(k,k) = aa(k))
     HostCSR csr; csc_to_csr(d, K, A_colptr, A_rowidx, A_val, csr);
     std::vector<char> nonempty(K, 0);
@@ -548,21 +556,31 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     RET(dNval.ensure((size_t)std::max(1, nn) * sizeof(float)));
     LAUNCH(ctx, "temporal_ata_pairs", k_ata_pairs, dim3((nn + 255) / 256), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
            dNk.as<int>(), dNidx.as<int>(), nn, dNval.as<float>());
+    // T3's level schedule only needs WHICH neurons are updated (ind_update = find(aa > 0), :51): aa(k) = sum of squares of column k is positive
+    // exactly when some stored value squares to a non-zero float, so the schedule is built here, under the projection kernel, instead of
+    // after the wait for the device's A'A
+    std::vector<char> upd(K, 0);
+    for (int k = 0; k < K; ++k)
+        for (int64_t e = A_colptr[k]; e < A_colptr[k + 1] && !upd[k]; ++e) upd[k] = A_val[e] * A_val[e] > 0.f;
+    build_graph(K, csr, d, upd, g);
+    std::vector<int> flat, off;
+    for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
+    RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
+    ht.mark("csr + graph + lists + levels");
     std::vector<float> nval(nn);
     int ovf = 0;
     CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (term_applied) CK(hipMemcpyAsync(&ovf, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
+    ht.mark("wait for A'A (sync)");
     if (ovf) RET(reproject());                                  // a footprint near more than 512 traces: the list kernel gave up
     std::vector<float> aa(K);
-    std::vector<char> upd(K);
-    for (int k = 0; k < K; ++k) { aa[k] = nval[diag[k]]; upd[k] = aa[k] > 0.f; }                // ind_update = find(aa>0)  (:51)
+    for (int k = 0; k < K; ++k) {
+        aa[k] = nval[diag[k]];
+        if ((aa[k] > 0.f) != (upd[k] != 0)) return fail(CNMFE_EHIP, "temporal update: aa(%d) = %g disagrees with the host-side test of its column", k, (double)aa[k]);
+    }
     RET(to_dev(ctx, dAa, aa.data(), aa.size()));
-    // T3: level schedule over the neurons that are updated
-    build_graph(K, csr, d, upd, g);
-    std::vector<int> flat, off;
-    for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
-    RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
+    ht.mark("level schedule");
     if (!dopts) {
         for (int it = 0; it < maxIter; ++it)
             for (size_t l = 0; l < g.levels.size(); ++l)

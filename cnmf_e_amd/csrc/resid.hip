@@ -1044,8 +1044,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         RET(upload_traces(ctx, dC, C, Ksel, T, c_order, &ldc));
         RET(center_traces(ctx, dC.as<float>(), ldc, Ksel, T, dCc, dCm));
         HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
-        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
-        RET(to_dev(ctx, dArow, rp.data(), rp.size()));
+        RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
         RET(dWaCnt.ensure(P->d * sizeof(int)));

@@ -580,8 +580,7 @@ int ssub_background(cnmfe_ctx *ctx, Patch *M, int pid, Patch *F, int ssub, int32
         a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
         RET(upload_traces(ctx, dC, C, K, M->T, c_order, &ldc));
         HostCSR csr; csc_to_csr(dF, K, ocp.data(), ori.data(), ova.data(), csr);
-        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
-        RET(to_dev(ctx, dArow, rp.data(), rp.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+        RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
         CK(hipStreamSynchronize(ctx->stream));
     }
     const std::vector<int> sr = nearest_sel(make_taps(M->nr_b, d1s, 1.0 / ssub, true)), sc = nearest_sel(make_taps(M->nc_b, d2s, 1.0 / ssub, true));
@@ -622,8 +621,7 @@ int ssub_rss(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *cp, const int32
     if (has_a) {
         RET(upload_traces(ctx, dC, C, K, M->T, c_order, &ldc));
         HostCSR csr; csc_to_csr(M->d, K, cp, ri, va, csr);
-        std::vector<int32_t> rp(csr.rowptr.begin(), csr.rowptr.end());
-        RET(to_dev(ctx, dArow, rp.data(), rp.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+        RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
         CK(hipStreamSynchronize(ctx->stream));
     }
     RET(to_dev(ctx, dB0n, b0_new, (size_t)M->d));

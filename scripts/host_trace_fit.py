@@ -1,4 +1,4 @@
-"""Host-side phases of cnmfe_fit_ring_model at the headline size (option host_trace): python scripts/host_trace_fit.py [--patch 128]"""
+"""Host-side phases of the fit / spatial / temporal calls at the headline size (option host_trace): python scripts/host_trace_fit.py [--patch 128]"""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +21,7 @@ for it in range(3):
     if it == 2:
         torch.cuda.synchronize(); eng.set_option("host_trace", 1)
     s.update_background_parallel()
+    s.update_spatial_parallel(); s.update_temporal_parallel()
     if it == 2:
         eng.set_option("host_trace", 0)
-    s.update_spatial_parallel(); s.update_temporal_parallel()
 torch.cuda.synchronize()
