@@ -74,6 +74,7 @@ PROTOTYPES = {
     "cnmfe_estimate_noise": (C.c_int, [c_ctx, C.c_int, C.c_int64, f32p]),
     "cnmfe_stitch_finish_async": (C.c_int, [c_ctx, C.c_int, f32p]),
     "cnmfe_update_spatial_fetch": (C.c_int, [c_ctx, f32p, C.c_int64]),
+    "cnmfe_update_spatial_fetch_connected": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, f32p, u8p]),
     "cnmfe_stitch_wait": (C.c_int, [c_ctx]),
     "cnmfe_host_alloc": (C.c_void_p, [C.c_size_t]),
     "cnmfe_host_free": (None, [C.c_void_p]),

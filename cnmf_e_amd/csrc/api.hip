@@ -705,6 +705,16 @@ int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
     return spatial_fetch(ctx, A_out, nnz);
 }
 
+int cnmfe_update_spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                                         float *A_out, uint8_t *keep_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (K <= 0 || d1 <= 0 || d2 <= 0) return fail(CNMFE_EINVAL, "bad K / d1 / d2");
+    RET(check_csc("IND", K, (int64_t)d1 * d2, IND_colptr, IND_rowidx));
+    if (IND_colptr[K] && (!A_out || !keep_out)) return fail(CNMFE_EINVAL, "null A_out / keep_out");
+    CK(hipSetDevice(ctx->device));
+    return spatial_fetch_connected(ctx, d1, d2, K, IND_colptr, IND_rowidx, A_out, keep_out);
+}
+
 int cnmfe_hals_temporal(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                         const float *A_val, const float *C_in, int c_order, int32_t maxIter,
                         float *C_out, float *C_raw_out, float *aa_out) {

@@ -293,6 +293,7 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P);
 int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out);
 int spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz);
+int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx, float *A_out, uint8_t *keep);
 int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
 int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P);                    // after W changed on the stream: count + row 1 to pinned memory, event
 int ring_stats_get(cnmfe_ctx *ctx, Patch *P, int *pmax, bool *first); // waits for that event only (falls back to a fresh evaluation)

@@ -608,6 +608,47 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     return 0;
 }
 
+static int postproc_boxes(int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, std::vector<int4> &box);
+
+// The connectivity constraint on the result of a deferred spatial update WHERE IT LIES (scr[0], scr[1], scr[6]: the mask's CSC pattern and the new
+// values, explicit zeros included -- they are zero pixels of the footprint image either way): valid when the patch is the whole field of view, so
+// that patch rows are FOV pixels.  One wait, one download of values + keep flags; no second upload of A.
+int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx, float *A_out, uint8_t *keep) {
+    const int64_t nnz = IND_colptr[K];
+    if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
+    if (nnz == 0) return 0;
+    std::vector<int4> box;
+    RET(postproc_boxes(d1, d2, K, IND_colptr, IND_rowidx, box));
+    DevBuf *S_ = ctx->scr;
+    DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dBox = S_[13], &dKeep = S_[14];
+    RET(to_dev(ctx, dBox, box.data(), box.size()));
+    RET(dKeep.ensure((size_t)nnz));
+    CK(hipMemsetAsync(dKeep.p, 0, (size_t)nnz, ctx->stream));
+    LAUNCH(ctx, "spatial_connectivity", k_connectivity, dim3(K), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
+           dBox.as<int4>(), d1, d2, dKeep.as<unsigned char>());
+    CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int postproc_boxes(int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, std::vector<int4> &box) {
+    box.assign(K, make_int4(0, 0, 0, 0));
+    for (int k = 0; k < K; ++k) {
+        int rmin = d1, rmax = -1, cmin = d2, cmax = -1;
+        for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
+            int r = A_rowidx[e] % d1, c = A_rowidx[e] / d1;
+            rmin = std::min(rmin, r); rmax = std::max(rmax, r); cmin = std::min(cmin, c); cmax = std::max(cmax, c);
+        }
+        if (rmax < 0) continue;
+        int h = rmax - rmin + 5, w = cmax - cmin + 5;
+        if (h > PP_MAX || w > PP_MAX)
+            return fail(CNMFE_EUNSUPPORTED, "footprint %d spans %dx%d pixels; post-processing supports %dx%d", k, h - 4, w - 4, PP_MAX - 4, PP_MAX - 4);
+        box[k] = make_int4(rmin - 2, cmin - 2, h, w);
+    }
+    return 0;
+}
+
 int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, uint8_t *keep) {
     const int64_t nnz = A_colptr[K];

@@ -357,9 +357,18 @@ class Engine:
         L.check(L.lib.cnmfe_update_spatial(self._ctx, pid, alg, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                            _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), None if defer else _p(out, L.f32p)))
         if defer:
-            def fetch():
-                L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
-                return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
+            def fetch(connected_fov=None):
+                """connected_fov = (d1, d2): the patch is the whole field of view -- also apply the connectivity constraint on the device and
+                return (A_raw, A) instead of A_raw"""
+                if connected_fov is None:
+                    L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
+                    return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
+                keep = np.zeros(out.size, dtype=np.uint8)
+                L.check(L.lib.cnmfe_update_spatial_fetch_connected(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
+                                                                   _p(out, L.f32p), _p(keep, L.u8p)))
+                A_raw = sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
+                A_pp = sp.csc_matrix((out * keep, iri.copy(), icp.copy()), shape=(info["d"], K))
+                return A_raw, A_pp
             return fetch
         return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
 

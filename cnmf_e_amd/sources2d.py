@@ -627,7 +627,7 @@ class Sources2D:
             raise NotImplementedError("search_method must be 'ellipse' or 'dilate'")
         K = self.A.shape[1]
         rows, cols, vals = [], [], []
-        whole_result = None
+        whole_result = whole_pp = None
         IND = None
         for idx in v.owned:
             pp, bp, ip = v.patch_pix[idx], v.block_pix[idx], v.ind_patch[idx]
@@ -663,7 +663,12 @@ class Sources2D:
                 fetch = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                                    sn_patch if o.spatial_algorithm == "hals_thresh" else None, param, defer=True)
                 self._temporal_residual_early(idx)                       # host work under the sweeps
-                Anew = fetch()
+                whole = pp.size == v.d1 * v.d2 and ind.size == K
+                if whole and o.spatial_constraints.get("connected", True) and (self.dist is None or (v.world_size == 1 and not self.force_collectives)):
+                    # one patch = the field of view: post_process_spatial's connectivity constraint (:341) runs on the result where it lies
+                    Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2))
+                else:
+                    Anew = fetch()
             else:
                 Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                                   sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
@@ -685,7 +690,11 @@ class Sources2D:
         A_.eliminate_zeros()
         A_.sort_indices()
         self.A_raw = A_
-        self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                              # :341, :24-26
+        if whole_pp is not None:
+            whole_pp.eliminate_zeros(); whole_pp.sort_indices()
+            self.A = whole_pp                                                                        # :341, done with the fetch
+        else:
+            self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                          # :341, :24-26
         if o.spatial_constraints.get("circular", False):                                            # post_process_spatial.m:28-30
             from . import hostops
             self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)

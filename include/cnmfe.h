@@ -190,6 +190,11 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx,
                          const float *sn, int32_t param, float *A_out);
 int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz);
+/* the same fetch with post_process_spatial's connectivity constraint (cnmfe_post_process_spatial below) applied to the result where it lies on the
+ * device: for a patch that IS the d1 x d2 field of view (patch rows = FOV pixels), IND = the mask the deferred update ran on.  A_out = the raw update
+ * (obj.A before post-processing), keep_out[e] = 1 where entry e survives. */
+int cnmfe_update_spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                                         float *A_out, uint8_t *keep_out);
 
 /* ---- fast_temporal (use_c_hat = false)                @Sources2D/update_temporal_parallel.m:174-175,314-337
  *   tmp_A = A .* (A ./ max(A,[],1) >= 0.5);  aa = sum(tmp_A.^2,1);  C_raw = (tmp_A' * Ysig) ./ aa'
