@@ -757,6 +757,7 @@ static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac
         if (variant == 8) return launch_r1_arc<R, 4, 0, 2>(ctx, a, has_ac, ntile_c, nseg);   // 2 chunks in flight
         if (variant == 9) return launch_r1_arc<R, 4, 0, 3>(ctx, a, has_ac, ntile_c, nseg);   // 3 chunks in flight
         if (variant == 11) return launch_r1_arc_dma<R>(ctx, a, has_ac, ntile_c, nseg);         // arc roles on LDS-DMA staging
+        if (variant == 13) return launch_r1_arc_dma1<R>(ctx, a, ntile_c, nseg);                // arc roles, one barrier per chunk (keeper role finishes chunk c-1 under chunk c)
         if (variant == 12) return launch_r1_quad<R>(ctx, a, ntile_c, nseg);                    // the four roles inside one wave, two workgroups per CU
     }
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
@@ -775,7 +776,7 @@ static void tile_shape(int variant, int &TR, int &TC) {
     TR = 16; TC = 16;
     if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2 || variant == 10) { TR = 32; TC = 16; }
     else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
-    else if ((variant >= 5 && variant <= 9) || variant == 11) { TR = ARC_TR; TC = ARC_TC; }
+    else if ((variant >= 5 && variant <= 9) || variant == 11 || variant == 13) { TR = ARC_TR; TC = ARC_TC; }
     else if (variant == 12) { TR = QD_T; TC = QD_T; }
 }
 
@@ -1085,8 +1086,9 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
            P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
 
     // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
-    int variant = (int)ctx->opt("r1_variant", 11);
+    int variant = (int)ctx->opt("r1_variant", 13);
     const int h = P->radius;
+    if (variant == 13 && (has_ac || h != 15)) variant = 11;   // one-barrier arc kernel: no footprint term inside the sweep
     if (variant == 12 && (has_ac || h != 15)) variant = 11;   // quad roles (resid_quad.hpp; measured slower, kept for A/B): radius 15, no footprint term inside the sweep
     bool full_ring = true;
     { int n = 0;

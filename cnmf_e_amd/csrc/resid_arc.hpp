@@ -496,6 +496,158 @@ __global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma(R1Args a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- r1_variant 13: the same roles with ONE barrier per chunk -----------------------------------------------------------------------------
+// In k_residual_arc_dma every chunk ends with a serial tail behind the second barrier (read the four partial sums, add the centre term, store,
+// wait) during which nothing else runs.  Here the partial sums are double-buffered and the bottom arc's threads (role 3) are the KEEPERS of their
+// four pixels: their own partial and the centre values of chunk c stay in registers, the other three roles' partials go to part[c & 1], and the keeper
+// finishes chunk c inside the interval in which everybody computes chunk c + 1.  One barrier per chunk (halo landed = previous partials complete);
+// the store's latency overlaps the other waves' ring products.  No footprint-term flavour (the caller falls back to variant 11 for it).
+template <int R, int ARC_D = 4>
+__global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma1(R1Args a) {
+    constexpr int P = 4;
+    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC, NT = NC, NWV = NT / 64;
+    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
+    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;
+    constexpr int NHp = HRp * HC;
+    constexpr int NIT = (NHp + NT - 1) / NT, NHs = NIT * NT;
+    constexpr int NA = ArcConst<R>::tab.n[0];
+    static_assert(ArcConst<R>::tab.n[1] == NA && ArcConst<R>::tab.n[2] == NA && ArcConst<R>::tab.n[3] == NA && NA % 2 == 0, "arcs must be balanced");
+    constexpr int NW = NA / 2;
+    constexpr int TRp = TR + 1, NCp = TRp * TC;
+    constexpr int NBUF = 2, PARTN = 2 * NCp + NC;                      // roles 0, 1 (column stride TR + 1), role 2
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHs] | part[2][PARTN]
+    float4 *halo = lds, *part = lds + NBUF * NHs;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tmap = a.tile_map[blockIdx.x];
+    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
+    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
+    constexpr int TPR = NC / P;
+    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;
+    int cr[P], cc[P];
+    int hbase;
+    if (role < 2) {
+        const int c = rt & 31, g = rt >> 5;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
+        hbase = c * HRp + g * P;
+    } else {
+        const int q = rt >> 4, i = rt & 15;
+        const int sq = (q * P * HRp) & 15;
+        const int r = (i - sq) & 15;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
+        hbase = q * P * HRp + r;
+    }
+    f2 wp[P][NW];
+    uint32_t fmb[P]; float dl[P]; bool fv[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
+        fv[j] = pr < a.nr && pc < a.nc;
+        const int64_t m = fv[j] ? (int64_t)pc * a.nr + pr : 0;
+        const uint32_t mb = (uint32_t)m * 4u;
+        fmb[j] = mb; dl[j] = ld_off(a.dlt, mb);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int i0, i1;
+            if (role == 0) { i0 = ArcConst<R>::tab.ring[0][2 * k]; i1 = ArcConst<R>::tab.ring[0][2 * k + 1]; }
+            else if (role == 1) { i0 = ArcConst<R>::tab.ring[1][2 * k]; i1 = ArcConst<R>::tab.ring[1][2 * k + 1]; }
+            else if (role == 2) { i0 = ArcConst<R>::tab.ring[2][2 * k]; i1 = ArcConst<R>::tab.ring[2][2 * k + 1]; }
+            else { i0 = ArcConst<R>::tab.ring[3][2 * k]; i1 = ArcConst<R>::tab.ring[3][2 * k + 1]; }
+            wp[j][k].x = ld_off(a.W + (int64_t)i0 * a.d, mb);
+            wp[j][k].y = ld_off(a.W + (int64_t)i1 * a.d, mb);
+        }
+    }
+    uint32_t qoff[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int idx = (j * NWV + wave) * 64 + lane;
+        const int hr = idx % HRp, hc = idx / HRp;
+        int rb = hr0 + hr, cb = hc0 + (hc < HC ? hc : HC - 1);
+        rb = rb < 0 ? 0 : (rb >= a.nr_b ? a.nr_b - 1 : rb);
+        cb = cb < 0 ? 0 : (cb >= a.nc_b ? a.nc_b - 1 : cb);
+        qoff[j] = (uint32_t)(cb * a.nr_b + rb) * 16u;
+    }
+    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds;
+    const unsigned lds0 = ldsA + (unsigned)wave * 1024u;
+    const int64_t cbeg = ((int64_t)blockIdx.y * a.tseg) >> 2;
+    const int64_t tend = (int64_t)blockIdx.y * a.tseg + a.tseg < a.T ? (int64_t)blockIdx.y * a.tseg + a.tseg : a.T;
+    const int64_t cend = (tend + 3) >> 2;
+    const int probe = __builtin_amdgcn_readfirstlane(a.probe);
+    auto issue = [&](int64_t c) {
+        if ((probe & 1) && c > cbeg + 1) return;
+        const int64_t cx = c < cend ? c : cend - 1;
+        const float4 *y4 = a.Y4 + cx * a.d_b;
+        const int b = (int)((c - cbeg) & 1);
+        const unsigned dst = lds0 + (unsigned)b * (unsigned)(NHs * 16);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) glds16(y4, qoff[j], dst + (unsigned)(j * NWV) * 1024u);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(cbeg);
+    f2 keep[P][2];                                                    // keeper: its own partial of the previous chunk
+    float4 cvs[P];                                                    //         and the centre values of that chunk
+#pragma unroll
+    for (int j = 0; j < P; ++j) { keep[j][0] = (f2){0.f, 0.f}; keep[j][1] = (f2){0.f, 0.f}; cvs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int64_t c = cbeg; c <= cend; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's part of halo(c) (and the keeper's stores of chunk c-2)
+        __builtin_amdgcn_s_barrier();                                 // halo(c) complete; the partial sums of chunk c-1 complete
+        asm volatile("" ::: "memory");
+        if (c < cend) issue(c + 1);                                   // into the buffer of chunk c-1: everybody is done with it
+        const int cb_ = (int)((c - cbeg) & 1);
+        if (role == 3 && c > cbeg) {                                  // finish chunk c-1
+            const float4 *pb = part + (cb_ ^ 1) * PARTN;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int cv_ = cc[j] * TRp + cr[j], ci = cc[j] * TR + cr[j];
+                const float4 p0 = pb[cv_], p1 = pb[NCp + cv_], p2 = pb[2 * NCp + ci];
+                const float4 cv = cvs[j];
+                const float4 yo = make_float4(cv.x + dl[j] - ((p0.x + p1.x) + (p2.x + keep[j][0].x)), cv.y + dl[j] - ((p0.y + p1.y) + (p2.y + keep[j][0].y)),
+                                              cv.z + dl[j] - ((p0.z + p1.z) + (p2.z + keep[j][1].x)), cv.w + dl[j] - ((p0.w + p1.w) + (p2.w + keep[j][1].y)));
+                if (fv[j] && !(probe & 8)) st4_off(a.Ysig4 + (c - 1) * a.d, fmb[j] * 4u, yo);
+            }
+        }
+        if (c == cend) break;
+        const float4 *hb = halo + cb_ * NHs + hbase;
+        f2 acc[P][2];
+#pragma unroll
+        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
+        if (probe & 2) { }
+        else if (role == 0) arc_product<R, 0, P, HRp, NW, ARC_D>(hb, wp, acc);
+        else if (role == 1) arc_product<R, 1, P, HRp, NW, ARC_D>(hb, wp, acc);
+        else if (role == 2) arc_product<R, 2, P, HRp, NW, ARC_D>(hb, wp, acc);
+        else arc_product<R, 3, P, HRp, NW, ARC_D>(hb, wp, acc);
+        if (role == 3) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                keep[j][0] = acc[j][0]; keep[j][1] = acc[j][1];
+                cvs[j] = halo[cb_ * NHs + (cc[j] + R) * HRp + (cr[j] + R)];
+            }
+        } else {
+            float4 *pw = part + cb_ * PARTN;
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                pw[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + cc[j] * TR + cr[j]] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // partial sums written / centre values read before the next barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int R>
+static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int64_t nseg) {
+    constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1, NT = ARC_TR * ARC_TC;
+    constexpr int NIT = (HRp * HC + NT - 1) / NT;
+    constexpr size_t shmem = (2 * (size_t)NIT * NT + 2 * (2 * (size_t)(ARC_TR + 1) * ARC_TC + (size_t)ARC_TR * ARC_TC)) * sizeof(float4);
+    static_assert(shmem <= 160 * 1024, "arc DMA kernel (one barrier) exceeds LDS");
+    static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
+    dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
+    CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R>), grid, dim3(NT), shmem, a);
+    return 0;
+}
+
 template <int R>
 static int launch_r1_arc_dma(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
     constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1, NT = ARC_TR * ARC_TC;

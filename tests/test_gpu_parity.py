@@ -124,11 +124,35 @@ def test_residual_variants_agree(eng, variant):
     eng.ring_set_values(0, (W0.data * (1 + 0.5 * rng.standard_normal(W0.nnz))).astype(np.float32))
     eng.set_b0(0, np.full(W0.shape[0], 990.0, dtype=np.float32))
     A_b = c.f.A_init.tocsc().astype(np.float32)
-    eng.set_option("r1_variant", -1)          # generic kernel
-    base = eng.residual(0, A_b, c.f.C_init, want=True)
-    eng.set_option("r1_variant", variant)
-    got = eng.residual(0, A_b, c.f.C_init, want=True)
-    eng.set_option("r1_variant", 10)
+    eng.set_option("r1_delta", 0)             # every call a full sweep (with the default, the second call would only fold a zero difference in)
+    try:
+        eng.set_option("r1_variant", -1)      # generic kernel
+        base = eng.residual(0, A_b, c.f.C_init, want=True)
+        eng.set_option("r1_variant", variant)
+        got = eng.residual(0, A_b, c.f.C_init, want=True)
+    finally:
+        eng.set_option("r1_variant", 13); eng.set_option("r1_delta", 1)
+    assert rel(got, base) <= 2e-6, rel(got, base)
+
+
+@pytest.mark.parametrize("variant", [10, 11, 12, 13])
+@pytest.mark.parametrize("T", [24, 53, 1030])
+def test_residual_variants_without_footprint_term(eng, variant, T):
+    """the kernels that have no A_prev flavour of their own (12: quad roles, 13: one barrier per chunk) and the defaults, on a FOV that is not a
+    multiple of the tile, frame counts that are not a multiple of 4 and span several frame segments; no footprints, so nothing falls back"""
+    c = Case(eng, 80, 72, T, 4, 15, 3)
+    rng = np.random.default_rng(5)
+    W0 = c.W0((0, 0)).tocsr(); W0.sort_indices()
+    eng.ring_set_values(0, (W0.data * (1 + 0.5 * rng.standard_normal(W0.nnz))).astype(np.float32))
+    eng.set_b0(0, np.full(W0.shape[0], 990.0, dtype=np.float32))
+    eng.set_option("r1_delta", 0)
+    try:
+        eng.set_option("r1_variant", -1)
+        base = eng.residual(0, None, None, want=True)
+        eng.set_option("r1_variant", variant)
+        got = eng.residual(0, None, None, want=True)
+    finally:
+        eng.set_option("r1_variant", 13); eng.set_option("r1_delta", 1)
     assert rel(got, base) <= 2e-6, rel(got, base)
 
 
@@ -426,11 +450,14 @@ def test_residual_dma_many_footprints(eng, variant):
                 rows.append((c0 + dc) * 80 + r0 + dr); cols.append(k); vals.append(rng.random() + 0.1)
     A_b = sp.csc_matrix((np.array(vals, np.float32), (rows, cols)), shape=(d, K)); A_b.sum_duplicates()
     Cm = rng.random((K, 24)).astype(np.float32) * 5
-    eng.set_option("r1_variant", -1)
-    base = eng.residual(0, A_b, Cm, want=True)
-    eng.set_option("r1_variant", variant)
-    got = eng.residual(0, A_b, Cm, want=True)
-    eng.set_option("r1_variant", 10)
+    eng.set_option("r1_delta", 0)
+    try:
+        eng.set_option("r1_variant", -1)
+        base = eng.residual(0, A_b, Cm, want=True)
+        eng.set_option("r1_variant", variant)
+        got = eng.residual(0, A_b, Cm, want=True)
+    finally:
+        eng.set_option("r1_variant", 13); eng.set_option("r1_delta", 1)
     assert rel(got, base) <= 2e-6, rel(got, base)
 
 
