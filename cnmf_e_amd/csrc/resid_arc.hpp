@@ -643,8 +643,17 @@ static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int6
     static_assert(shmem <= 160 * 1024, "arc DMA kernel (one barrier) exceeds LDS");
     static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
-    CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R>), grid, dim3(NT), shmem, a);
+    const int arcd = (int)ctx->opt("r1_arc_d", 4);                     // LDS reads in flight ahead of their FMAs (experiments: 6, 8)
+    if (arcd == 6) {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R, 6>), grid, dim3(NT), shmem, a);
+    } else if (arcd == 8) {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R, 8>), grid, dim3(NT), shmem, a);
+    } else {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R>), grid, dim3(NT), shmem, a);
+    }
     return 0;
 }
 

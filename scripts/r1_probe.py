@@ -3,7 +3,7 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--probes", default="0,1,2,3,4,6,7,8,15"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--variant", type=int, default=11); ap.add_argument("--d1", type=int, default=512); ap.add_argument("--d2", type=int, default=512); ap.add_argument("--nseg", type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument("--probes", default="0,1,2,3,4,6,7,8,15"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--variant", type=int, default=11); ap.add_argument("--d1", type=int, default=512); ap.add_argument("--d2", type=int, default=512); ap.add_argument("--nseg", type=int, default=0); ap.add_argument("--arcd", type=int, default=4)
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -16,7 +16,7 @@ eng = Engine(0)
 video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
 video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
 eng.ring_init(0, r)
-eng.set_option("r1_delta", 0); eng.set_option("r1_variant", a.variant); eng.set_option("r1_nseg", a.nseg)
+eng.set_option("r1_delta", 0); eng.set_option("r1_variant", a.variant); eng.set_option("r1_nseg", a.nseg); eng.set_option("r1_arc_d", a.arcd)
 eng.residual(0, None, None)
 eng.profile(True)
 for pr in [int(x) for x in a.probes.split(",")]:
