@@ -93,12 +93,17 @@ __device__ inline bool solve_small(int n, double *M /* n x n row-major, destroye
 // One outer pass adds at most one variable to the passive set (:84-85) and there are at most maxN passes (:76), so s has at most maxN
 // entries that were ever non-zero: the thread keeps s, b and the passive flag for those "touched" entries only (sorted by position in the
 // pixel's row, which is the order of A(P,P) at :93) and reads everything else -- b from U, the Gram entries from V -- where it lies.
+// `rows`: the pixels this launch solves.  The per-thread arrays (CAP^2 doubles) live in scratch memory, which the runtime sizes per DISPATCH as
+// bytes per lane x the waves the grid can have in flight: one launch of the CAP = 20 instantiation over all 262144 pixels asks for 2 GB of it (and
+// the first such launch of a process stalls for ~0.9 s while it is mapped).  So the pixels are split by the number of masks over them: n <= 4 (the
+// bulk; 4 x 4 systems stay in registers), n <= 8, and the few crowded ones, each list through the smallest instantiation that holds min(n, maxN).
 template <int CAP>
-__global__ void __launch_bounds__(64) k_nnls_spatial(int64_t d, const int *__restrict__ rptr, const int *__restrict__ rcol, const int *__restrict__ rsrc,
-                                                     const float *__restrict__ U, const float *__restrict__ V, int K, int maxN, double tol,
-                                                     float *__restrict__ Aval) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= d) return;
+__global__ void __launch_bounds__(64) k_nnls_spatial(const int *__restrict__ rows, int nrows, const int *__restrict__ rptr, const int *__restrict__ rcol,
+                                                     const int *__restrict__ rsrc, const float *__restrict__ U, const float *__restrict__ V, int K, int maxN,
+                                                     double tol, float *__restrict__ Aval) {
+    const int64_t ridx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ridx >= nrows) return;
+    const int64_t m = rows[ridx];
     const int r0 = rptr[m], n = rptr[m + 1] - r0;
     if (n <= 0) return;
     int tpos[CAP], tcol[CAP], idx[CAP];
@@ -408,9 +413,20 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     LAUNCH(ctx, "spatial_pair_gram", k_pair_gram, dim3((unsigned)g.pairs.size()), dim3(256), 0, dCc.as<float>(), ldc, T, dPairs.as<int2>(), K, dV.as<float>());
     if (algorithm == CNMFE_SPATIAL_NNLS) {
         const int maxN = (int)param;
-#define NNLS_GO(CAP) LAUNCH(ctx, "spatial_nnls", k_nnls_spatial<CAP>, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, d, dRptr.as<int>(), dRcol.as<int>(), \
-                            dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K, maxN, 1e-4, dAval.as<float>())
-        if (maxN <= 8) NNLS_GO(8); else if (maxN <= 20) NNLS_GO(20); else NNLS_GO(32);
+        std::vector<int> rows[3];                               // by min(n, maxN): <= 4, <= 8, more
+        for (int64_t m = 0; m < d; ++m) {
+            const int n = std::min<int>(csr.rowptr[m + 1] - csr.rowptr[m], maxN);
+            if (n > 0) rows[n <= 4 ? 0 : n <= 8 ? 1 : 2].push_back((int)m);
+        }
+        DevBuf &dRows = S_[19];
+        std::vector<int> all; int off3[4] = {0, 0, 0, 0};
+        for (int g_ = 0; g_ < 3; ++g_) { all.insert(all.end(), rows[g_].begin(), rows[g_].end()); off3[g_ + 1] = (int)all.size(); }
+        RET(to_dev(ctx, dRows, all.data(), all.size()));
+#define NNLS_GO(CAP, G) do { if (off3[G + 1] > off3[G]) { LAUNCH(ctx, "spatial_nnls", k_nnls_spatial<CAP>, dim3((unsigned)((off3[G + 1] - off3[G] + 63) / 64)), dim3(64), 0, \
+                            dRows.as<int>() + off3[G], off3[G + 1] - off3[G], dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K, \
+                            maxN, 1e-4, dAval.as<float>()); } } while (0)
+        NNLS_GO(4, 0); NNLS_GO(8, 1);
+        if (maxN <= 20) { NNLS_GO(20, 2); } else { NNLS_GO(32, 2); }
 #undef NNLS_GO
     } else {
         std::vector<int> flat; std::vector<int> off;
