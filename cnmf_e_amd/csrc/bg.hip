@@ -932,15 +932,6 @@ __global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const
 #include "ring_solve.hpp"
 namespace cnmfe {
 
-// pmax = max_i #{j : W(i,j) > 0}  (fit_ring_model.m:60) and the first-run test on row 1 (:25)
-__global__ void k_count_pos(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
-    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int c = 0;
-    if (m < d) for (int i = 0; i < p; ++i) c += W[(int64_t)i * d + m] > 0.f;
-    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(c, o); c = v > c ? v : c; }
-    if ((threadIdx.x & 63) == 0) atomicMax(pmax, c);
-}
-
 // ind_active = abs(W_old)*sum(A,2) > 0  (fit_ring_model.m:28)
 __global__ void k_active(const float *__restrict__ W, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
                          const float *__restrict__ asum, unsigned char *__restrict__ active, int *__restrict__ nactive) {

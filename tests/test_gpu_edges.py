@@ -1,6 +1,7 @@
 """Edge cases of the hot path on the GPU: empty / ragged inputs, argument and state errors of the C ABI
 (the reference has no tests of its own -- SURVEY.md section 4 -- so these follow its code paths: isempty(A) in
 fit_ring_model.m:14-16, patches without neurons in update_*_parallel.m:121-124,123, num_neighbors in get_nhood.m:17-25)."""
+import ctypes as C
 import os
 import sys
 
@@ -124,8 +125,26 @@ def test_abi_state_and_argument_errors(eng):
         eng.hals_temporal(0, A, f.C_init, 2)
     with pytest.raises(L.CnmfeError):                      # unknown patch, straight at the C ABI
         L.check(L.lib.cnmfe_residual(eng._ctx, 7, 0, None, None, None, None, L.ROWMAJOR, None, L.HOST))
-    with pytest.raises(L.CnmfeError):                      # the outlier branch of fit_ring_model is not built: must be NaN
+    with pytest.raises(L.CnmfeError, match="cnmfe_set_noise"):      # the outlier branch needs the noise levels of the block first
         eng.fit_ring_model(0, A, f.C_init, thresh_outlier=3.0)
+    with pytest.raises(L.CnmfeError, match="deferred"):             # nothing to fetch: no deferred spatial update on this context
+        out = np.zeros(4, np.float32)
+        L.check(L.lib.cnmfe_update_spatial_fetch(eng._ctx, out.ctypes.data_as(L.f32p), 4))
+    with pytest.raises(L.CnmfeError, match="stitch_begin"):         # finish without begin (sync and async flavours)
+        L.check(L.lib.cnmfe_stitch_finish(eng._ctx, 1, None, L.ROWMAJOR))
+    p_ = L.lib.cnmfe_host_alloc(1 << 16)
+    assert p_
+    try:
+        with pytest.raises(L.CnmfeError, match="stitch_begin"):
+            L.check(L.lib.cnmfe_stitch_finish_async(eng._ctx, 1, C.cast(p_, L.f32p)))
+    finally:
+        L.lib.cnmfe_host_free(p_)
+    L.check(L.lib.cnmfe_stitch_wait(eng._ctx))                      # nothing in flight: returns at once
+    with pytest.raises(L.CnmfeError, match="cnmfe_background_ssub"):    # the bg_ssub objective without its preparation
+        rss = C.c_double()
+        L.check(L.lib.cnmfe_compute_rss_ssub(eng._ctx, 0, 0, None, None, None, None, L.ROWMAJOR, np.zeros(d1 * d2, np.float32).ctypes.data_as(L.f32p), C.byref(rss)))
+    with pytest.raises(L.CnmfeError):                               # estimate_noise over more frames than the video has
+        eng.estimate_noise(0, T + 1)
     cp = np.array([0, 2], np.int64); ri = np.array([5, 3], np.int32); va = np.ones(2, np.float32)     # rows of a column not ascending
     Cm = np.zeros((1, T), np.float32)
     with pytest.raises(L.CnmfeError):
