@@ -669,7 +669,9 @@ __global__ void __launch_bounds__(256) k_cov_correct(const double *__restrict__ 
     };
     const double *bp = base + (int64_t)pair * BLKPX * BLKPX;
     double *cp = cov + (int64_t)pair * BLKPX * BLKPX;
-    for (int pi = 0; pi < 16; ++pi) {
+    // gridDim.y workgroups share a pair (its 16 row patches split evenly): a small patch has too few pairs to fill the chip with one each
+    const int pi0 = (int)blockIdx.y * (16 / (int)gridDim.y), pi1 = pi0 + 16 / (int)gridDim.y;
+    for (int pi = pi0; pi < pi1; ++pi) {
         const unsigned mask = needmask[rel * 16 + pi];
         if (!mask) continue;
         const int ilp = pi * 16 + ty;
@@ -1344,7 +1346,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 LAUNCH(ctx, "bg_trace_subsum", k_trace_subsum, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, g.Tp, g.kstride, dCsum.as<double>());
                 {
                     const int nb_ = (int)blall.size();
-                    const int nsg = std::max(1, std::min(8, (2048 + nb_ - 1) / std::max(1, nb_)));
+                    // frame segments per block: enough workgroups to fill the chip; small patches (few blocks) get more, shorter segments
+                    const int nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
                     const int64_t ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX, gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
                     RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
                     RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
@@ -1353,7 +1356,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                     LAUNCH(ctx, "bg_win_fix", k_win_fix, dim3((unsigned)nb_), dim3(256), 0, g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(),
                            dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
                 }
-                LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
+                const int csplit = npairs >= 8192 ? 1 : npairs >= 4096 ? 2 : 4;      // (small patches: a pair's sweep is a long serial loop, one workgroup per pair leaves the chip idle)
+                LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs, (unsigned)csplit), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
                        dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
                 LAUNCH(ctx, "bg_rowsum_correct", k_rowsum_correct, dim3(nblk), dim3(256), 0, P->rowsum_base.as<double>(), ctx->rowsum.as<double>(), g,
                        dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dCsum.as<double>());
