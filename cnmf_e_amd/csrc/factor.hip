@@ -200,32 +200,37 @@ __global__ void k_ata_pairs(const int64_t *__restrict__ colptr, const int *__res
 }
 
 // ---- T3: one Gauss-Seidel level of HALS_temporal (no-deconvolution branch :62-68) --------------------
-__global__ void __launch_bounds__(256) k_hals_temporal(const int *__restrict__ lvl, const int *__restrict__ nptr, const int *__restrict__ nidx,
-                                                       const float *__restrict__ nval, const float *__restrict__ aa, const float *__restrict__ U,
-                                                       float *__restrict__ C, float *__restrict__ Craw, int64_t ldc, int64_t T) {
-    const int k = lvl[blockIdx.x];
+__device__ __forceinline__ void hals_temporal_one(int k, const int *__restrict__ nptr, const int *__restrict__ nidx, const float *__restrict__ nval,
+                                                  const float *__restrict__ aa, const float *__restrict__ U, float *C, float *Craw, int64_t ldc, int64_t T, float *red) {
     const float a = aa[k];
     float *ck = C + (int64_t)k * ldc;
     const float *uk = U + (int64_t)k * ldc;
     const int n0 = nptr[k], n1 = nptr[k + 1];
     float mn = INFINITY;
-    for (int64_t t = threadIdx.x; t < T; t += 256) {
+    const int nt = (int)blockDim.x;
+    for (int64_t t = threadIdx.x; t < T; t += nt) {
         float vc = 0.f;
         for (int j = n0; j < n1; ++j) vc = fmaf(nval[j], C[(int64_t)nidx[j] * ldc + t], vc);    // V(k,:)*C
         const float v = ck[t] + (uk[t] - vc) / a;                                                  // :62
         Craw[(int64_t)k * ldc + t] = v;
         mn = fminf(mn, v);
     }
-    __shared__ float red[256];
     red[threadIdx.x] = mn; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    for (int o = nt >> 1; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
     mn = red[0];
-    for (int64_t t = threadIdx.x; t < T; t += 256) {
+    __syncthreads();
+    for (int64_t t = threadIdx.x; t < T; t += nt) {
         const float v = Craw[(int64_t)k * ldc + t] - mn;                                           // :66
         Craw[(int64_t)k * ldc + t] = v; ck[t] = v;                                                 // :67-68
     }
 }
-
+// (1024 threads per neuron: a level is a handful of workgroups whose duration is their serial depth over T, not their work)
+__global__ void __launch_bounds__(1024) k_hals_temporal(const int *__restrict__ lvl, const int *__restrict__ nptr, const int *__restrict__ nidx,
+                                                        const float *__restrict__ nval, const float *__restrict__ aa, const float *__restrict__ U,
+                                                        float *C, float *Craw, int64_t ldc, int64_t T) {
+    __shared__ float red[1024];
+    hals_temporal_one(lvl[blockIdx.x], nptr, nidx, nval, aa, U, C, Craw, ldc, T, red);
+}
 // ---- S6: connectivity_constraint.m:1-18 on a per-neuron box -------------------------------------------
 constexpr int PP_MAX = 64;    // max box side (bbox + 2 px margin each side)
 __global__ void __launch_bounds__(256) k_connectivity(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
@@ -600,7 +605,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     if (!dopts) {
         for (int it = 0; it < maxIter; ++it)
             for (size_t l = 0; l < g.levels.size(); ++l)
-                LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
+                LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(T >= 2048 ? 1024 : 256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
                        dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dU.as<float>(), dC.as<float>(), dCraw.as<float>(), ldc, T);
     } else {
         DevBuf &dS = S_[19], &dPars = S_[21], &dSn = S_[22];

@@ -69,21 +69,35 @@ __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, in
     const int t = threadIdx.x;
     const int rbm = (int)(m % nr) + roff, cbm = (int)(m / nr) + coff;
     int n = 0;
-    for (int i = 0; i < p; ++i) {
-        const float w = W[(int64_t)i * d + m];
-        const int rb = rbm + dr[i], cb = cbm + dc[i];
-        if (w == 0.f || rb < 0 || rb >= nr_b || cb < 0 || cb >= nc_b) continue;
-        const int64_t q = (int64_t)cb * nr_b + rb;
-        for (int e = arow[q]; e < arow[q + 1]; ++e) {
-            const int k = acol[e];
-            int s = 0;
-            while (s < n && tk[s][t] != k) ++s;
-            if (s == n) {
-                if (n == WA_CAP_) { *overflow = 1; continue; }
-                tk[s][t] = k; tv[s][t] = 0.f; ++n;
-            }
-            tv[s][t] = fmaf(w, aval[e], tv[s][t]);
+    // eight ring offsets at a time: their weights and row extents are independent loads (the thread's serial depth was 96 x three dependent
+    // loads, and most neighbours lie under no footprint at all); the accumulation itself stays in ring order
+    for (int i0 = 0; i0 < p; i0 += 8) {
+        float w8[8]; int e0[8], e1[8];
+        // (every load unconditional, out-of-range neighbours clamped to pixel 0 and masked afterwards: a load behind a branch is a wait per offset)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u < p ? i0 + u : p - 1;
+            const int rb = rbm + dr[i], cb = cbm + dc[i];
+            const bool in = i0 + u < p && rb >= 0 && rb < nr_b && cb >= 0 && cb < nc_b;
+            const int64_t q = in ? (int64_t)cb * nr_b + rb : 0;
+            w8[u] = W[(int64_t)i * d + m];
+            e0[u] = arow[q]; e1[u] = arow[q + 1];
+            if (!in) w8[u] = 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (w8[u] == 0.f) e1[u] = e0[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            for (int e = e0[u]; e < e1[u]; ++e) {
+                const int k = acol[e];
+                int s = 0;
+                while (s < n && tk[s][t] != k) ++s;
+                if (s == n) {
+                    if (n == WA_CAP_) { *overflow = 1; continue; }
+                    tk[s][t] = k; tv[s][t] = 0.f; ++n;
+                }
+                tv[s][t] = fmaf(w8[u], aval[e], tv[s][t]);
+            }
     }
     wa_cnt[m] = n;
     for (int s = 0; s < n; ++s) { wa_k[(int64_t)s * d + m] = tk[s][t]; wa_v[(int64_t)s * d + m] = tv[s][t]; }
@@ -847,16 +861,32 @@ __global__ void __launch_bounds__(256) k_term_project(const int64_t *__restrict_
     }
     __syncthreads();
     const int nl = nl_s;
-    for (int i = tid; i < nl; i += 256) {
-        const int l = lst[i];
+    // M(k, l): sixteen threads per list entry, each over a contiguous sixteenth of k's pixels in storage order, the sixteen partial sums added in
+    // order by the first of them: a fixed association (bit-reproducible), 16 x shorter than one thread per entry
+    __shared__ float part16[16][17];
+    const int sub = tid & 15, slot = tid >> 4;
+    const int64_t ne = e1 - e0, per = (ne + 15) / 16;
+    const int64_t ea = e0 + sub * per, eb = ea + per < e1 ? ea + per : e1;
+    for (int i0 = 0; i0 < nl; i0 += 16) {
+        const int i = i0 + slot;
         float s = 0.f;
-        for (int64_t e = e0; e < e1; ++e) {
-            const int m = erow[e], n = cnt[m];
-            for (int j = 0; j < n; ++j) if (wk[(int64_t)j * d + m] == l) { s = fmaf(aval[e], wv[(int64_t)j * d + m], s); break; }
+        if (i < nl) {
+            const int l = lst[i];
+            for (int64_t e = ea; e < eb; ++e) {
+                const int m = erow[e], n = cnt[m];
+                for (int j = 0; j < n; ++j) if (wk[(int64_t)j * d + m] == l) { s = fmaf(aval[e], wv[(int64_t)j * d + m], s); break; }
+            }
         }
-        Mv[i] = sign * s;
+        part16[slot][sub] = s;
+        __syncthreads();
+        if (sub == 0 && i < nl) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += part16[slot][q];
+            Mv[i] = sign * tot;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float4 *urow = reinterpret_cast<float4 *>(U + (int64_t)k * ldu);
     for (int64_t c = tid; c < (ldu >> 2); c += 256) {
         float4 a4 = urow[c];
