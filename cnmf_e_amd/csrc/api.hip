@@ -219,13 +219,15 @@ int ctx_errflag(cnmfe_ctx *ctx, int **dflag) {
     *dflag = ctx->errflag.as<int>();
     return 0;
 }
+// waits for the stream and reports what its kernels raised since the last call
 int ctx_check_errflag(cnmfe_ctx *ctx) {
-    if (!ctx->errflag.p) return 0;
+    if (!ctx->errflag.p) { CK(hipStreamSynchronize(ctx->stream)); return 0; }
     int h = 0;
     CK(hipMemcpyAsync(&h, ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     if (!h) return 0;
     CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->stream));
+    if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 32 footprints of A_prev (flag %d)", h);
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
 }
 

@@ -447,15 +447,13 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     ctx->spatial_nnz = nnz;                                  // the result stays in scr[6] until the next spatial update (cnmfe_update_spatial_fetch)
     if (!A_out) return 0;                                    // deferred: the caller does other host work under the sweeps and fetches afterwards
     CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_check_errflag(ctx);                           // the wait, and what the kernels queued since the last one had to report
 }
 
 int spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
     if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
     if (nnz) CK(hipMemcpyAsync(A_out, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_check_errflag(ctx);
 }
 
 // implemented in deconv.hip
@@ -592,7 +590,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     int ovf = 0;
     CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (term_applied) CK(hipMemcpyAsync(&ovf, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    RET(ctx_check_errflag(ctx));                                // the wait for A'A; also what the residual's kernels had to report
     ht.mark("wait for A'A (sync)");
     if (ovf) RET(reproject());                                  // a footprint near more than 512 traces: the list kernel gave up
     std::vector<float> aa(K);
@@ -649,8 +647,7 @@ int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, c
            dBox.as<int4>(), d1, d2, dKeep.as<unsigned char>());
     CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_check_errflag(ctx);
 }
 
 static int postproc_boxes(int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, std::vector<int4> &box) {

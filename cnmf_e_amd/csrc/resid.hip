@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, in
                 int s = 0;
                 while (s < n && tk[s][t] != k) ++s;
                 if (s == n) {
-                    if (n == WA_CAP_) { *overflow = 1; continue; }
+                    if (n == WA_CAP_) { atomicOr(overflow, 2); continue; }     // (bit 1 of the context's error flag: reported at the next wait)
                     tk[s][t] = k; tv[s][t] = 0.f; ++n;
                 }
                 tv[s][t] = fmaf(w8[u], aval[e], tv[s][t]);
@@ -1068,7 +1068,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     const bool delta = !outbuf && P->ysig_valid && P->res_kind == 1 && P->ysig.p && ctx->opt("r1_delta", 1) != 0;
     RET(ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
     DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
-           &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10], &dFlag = ctx->tmp[11];
+           &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10];
     int64_t ldc = 4;
     bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
     if (has_ac) {
@@ -1081,15 +1081,14 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         RET(dWaCnt.ensure(P->d * sizeof(int)));
         RET(dWaK.ensure((size_t)WA_CAP * P->d * sizeof(int)));
         RET(dWaV.ensure((size_t)WA_CAP * P->d * sizeof(float)));
-        RET(dFlag.ensure(64));
-        CK(hipMemsetAsync(dFlag.p, 0, 64, ctx->stream));
+        // a ring that touches more than WA_CAP footprints raises the context's error flag (ctx_check_errflag at the next wait of this call chain: the
+        // spatial / temporal update's own download) instead of costing a drain of the stream here -- with several patches per context that drain
+        // was what kept the host from setting up patch m + 1 under patch m's kernels
+        int *dErrWa = nullptr;
+        RET(ctx_errflag(ctx, &dErrWa));
         LAUNCH(ctx, "r1_ring_wa", k_ring_wa, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
                P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(),
-               dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dFlag.as<int>());
-        int flag = 0;
-        CK(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        if (flag) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than %d footprints of A_prev", WA_CAP);
+               dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
     }
     if (tables_only) { ctx->last_ldc = ldc; return 0; }       // bg_ssub: the caller only wants (W*A) and the centred traces (tmp[8..10], tmp[1])
     // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)
