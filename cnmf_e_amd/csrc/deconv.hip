@@ -741,8 +741,7 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     RET(dSn.ensure((size_t)P->d * sizeof(float)));
     LAUNCH(ctx, "spatial_sn_pixels", k_sn_pixels, dim3((unsigned)P->d), dim3(256), shmem, c, P->ysig.as<float4>(), P->d, dSn.as<float>());
     CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_check_errflag(ctx);
 }
 
 // ---- P.sn = estimate_noise(obj) (Sources2D.m:328-379, method 'psd'): GetSn of the first frames of the RAW video, per block pixel ------

@@ -803,7 +803,7 @@ int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out
            ysig.as<float4>(), P->d, T, dstp);
     if (out_memspace != CNMFE_DEVICE)
         CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    RET(ctx_check_errflag(ctx));
     return 0;
 }
 
@@ -1020,7 +1020,7 @@ int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const 
            has_a ? dCnt.as<int>() : nullptr, dK.as<int>(), dV.as<float>(), dC.as<float>(), ldc, dPart.as<double>());
     std::vector<double> part((size_t)nblk * nseg);
     CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    RET(ctx_check_errflag(ctx));
     double s = 0.0;
     for (double v : part) s += v;                              // fixed order: reproducible
     *rss_out = s;
@@ -1056,8 +1056,7 @@ int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const fl
     LAUNCH(ctx, "bg_reconstruct", k_bg_out, dim3((unsigned)((d + 255) / 256), (unsigned)nframes), dim3(256), 0, P->Yc4.as<float4>(), P->d_b, P->nr, P->nr_b, P->roff, P->coff,
            P->ysig.as<float4>(), d, P->ymean_f.as<float>(), dKap.as<float>(), frame0, nframes, dst);
     if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return ctx_check_errflag(ctx);
 }
 
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,

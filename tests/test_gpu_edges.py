@@ -677,3 +677,28 @@ def test_lazy_traces_keep_their_iteration(eng):
         assert np.array_equal(c - eager[2], np.zeros_like(eager[2])) and float(c.max()) == float(eager[2].max())
     finally:
         eng2.close()
+
+
+def test_more_footprints_on_a_ring_than_the_engine_holds(eng):
+    """A pixel whose ring touches more than 32 footprints of A_prev: CNMFE_EUNSUPPORTED.  The check rides on the context's error flag, so it is
+    reported by the first call of the chain that waits for the device -- here the export of the residual -- and the context stays usable."""
+    from cnmf_e_amd import _lib as L
+    d1, d2, T, r = 48, 48, 64, 5
+    f, Y, video = _video(eng, d1, d2, T, 3, r, 7)
+    eng.ring_init(0, r)
+    eng.fit_ring_model(0, None, None)
+    K = 44                                                       # 44 one-pixel footprints on the ring of pixel (24, 24)
+    rs, cs = np.array(orc_nhood(r))
+    rows = [(24 + int(cs[i % rs.size]) + (i // rs.size)) * d1 + 24 + int(rs[i % rs.size]) for i in range(K)]
+    A = sp.csc_matrix((np.ones(K, np.float32), (rows, np.arange(K))), shape=(d1 * d2, K))
+    Cm = np.random.default_rng(0).random((K, T)).astype(np.float32)
+    with pytest.raises(L.CnmfeError, match="more than 32 footprints"):
+        eng.residual(0, A, Cm, want=True)
+    out = eng.residual(0, A[:, :20], Cm[:20], want=True)         # fine again with fewer
+    assert np.isfinite(out).all()
+
+
+def orc_nhood(r):
+    import cnmfe_oracle as orc
+    rs, cs = orc.get_nhood(r)
+    return np.ravel(rs), np.ravel(cs)
