@@ -312,7 +312,10 @@ def main():
                                ("%s (weak): %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
                                 "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub)),
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
-                   "parallelism": "patches round-robin over %d rank(s)" % world},
+                   "parallelism": "patches round-robin over %d rank(s)" % world,
+                   **({"note": "strong scaling of the 4 x 4-patch decomposition (BASELINE configs[3]); its own N = 1 point is `python bench.py --config c4` "
+                               "(16 patches on one GPU: profiles/r02/bench_c4_n1_v4.json, 11.5 iter/s) -- the default N = 1 line is configs[2], the same "
+                               "video as ONE patch, which has no halo re-reads and 16x larger launches"} if (world > 1 and a.config == "c4" and not a.weak) else {})},
         "roofline": roof,
         "roofline_r1": r1r,
         "roofline_solve": solve_roof(),
