@@ -226,3 +226,27 @@ def test_bench_line_contract_of_the_committed_profile():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_noise_image_bookkeeping_and_nearest_rows_match_the_oracle():
+    """host pieces of round 2: the storage-block bookkeeping of Sources2D.m:361-376 applied to per-pixel estimates == the oracle's literal block
+    loop, on several geometries; and the rows imresize(., 1/s, 'nearest') keeps == the oracle's box-kernel weights"""
+    from cnmf_e_amd.sources2d import storage_block_index, estimate_noise_image, nearest_rows
+    rng = np.random.default_rng(3)
+    for (d1, d2, pd, r) in ((44, 40, [22, 20], 5), (60, 51, [20, 17], 4), (37, 64, [37, 16], 6), (48, 48, [48, 48], 7)):
+        T = 80
+        Y = rng.standard_normal((d1, d2, T)).astype(np.float32)
+        K = 2
+        A = sp.csc_matrix((d1 * d2, K), dtype=np.float32); Cm = np.zeros((K, T), np.float32)
+        o = orc.OracleSources2D(Y, d1, d2, T, pd, r, A, Cm, np.ones(d1 * d2))
+        ref = o.estimate_noise()
+        from oasis_oracle import GetSn
+        pix = np.array([[GetSn(Y[i, j].astype(np.float64)) for j in range(d2)] for i in range(d1)])
+        nr, nc = o.patch_pos.shape
+        pr = np.array([int(o.patch_pos[m, 0][0]) for m in range(nr)] + [d1]); pc = np.array([int(o.patch_pos[0, j][2]) for j in range(nc)] + [d2])
+        got = estimate_noise_image(pix, storage_block_index(d1, pr, r), storage_block_index(d2, pc, r))
+        assert np.array_equal(got, ref), (d1, d2, pd)
+    for n in (7, 16, 33, 46, 50, 158):
+        for s_ in (2, 3, 4):
+            M = orc.imresize_weights(n, -(-n // s_), 1.0 / s_, "nearest")
+            assert (M.max(axis=1) == 1).all() and np.array_equal(M.argmax(axis=1), nearest_rows(n, s_)), (n, s_)
