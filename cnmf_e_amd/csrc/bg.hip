@@ -1038,13 +1038,19 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     if (has_a) {
         RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
         RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
+    }
+    // the CSR rows of A (b0, ind_active, the table corrections): built AFTER the window projection is queued when that can go first (below)
+    auto upload_csr = [&]() -> int {
+        if (!has_a) return 0;
         csc_to_csr(P->d_b, K, A_colptr, A_rowidx, A_val, csr);
         RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
-    }
-    ht.mark("traces + A csr");
-    if (b0_only & 1) {                                    // bg_ssub > 1: b0 = mean(Y - A*C, 2) on the patch (update_background_parallel.m:222-223)
+        return 0;
+    };
+    ht.mark("traces");
+    if (b0_only & 1) {
+        RET(upload_csr());                                    // bg_ssub > 1: b0 = mean(Y - A*C, 2) on the patch (update_background_parallel.m:222-223)
         BgGeom g0{};
         g0.nr = P->nr; g0.nc = P->nc; g0.nr_b = P->nr_b; g0.nc_b = P->nc_b; g0.roff = P->roff; g0.coff = P->coff; g0.d = P->d; g0.d_b = P->d_b;
         LAUNCH(ctx, "bg_b0", k_b0, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->ymean_d.as<double>(), g0,
@@ -1123,6 +1129,35 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
     const int nblk = g.nbr * g.nbc;
+
+    // ---- the window projection first: it needs the footprint lists and the traces, nothing else, and takes 5 ms at the headline size -- the host
+    // builds the CSR rows of A, ind_active and the pair tables underneath it (a later fit of a patch: the video's table exists)
+    DevBuf &dLp = ctx->inc[0], &dLk = ctx->inc[1], &dSlot = ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5], &dGb = ctx->inc[6];
+    std::vector<int> blall;
+    int nsg = 1; int64_t ut_stride = 0, gb_stride = 0;
+    bool proj_queued = false;
+    auto queue_projection = [&]() -> int {
+        for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());      // longest lists first
+        RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
+        RET(to_dev(ctx, dLk, lst_k.data(), lst_k.size()));
+        RET(to_dev(ctx, dBl, blall.data(), blall.size()));
+        RET(dCsum.ensure((size_t)K * sizeof(double)));
+        LAUNCH(ctx, "bg_trace_subsum", k_trace_subsum, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, g.Tp, g.kstride, dCsum.as<double>());
+        const int nb_ = (int)blall.size();
+        // frame segments per block: enough workgroups to fill the chip; small patches (few blocks) get more, shorter segments
+        nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
+        ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX; gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
+        RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
+        RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
+        LAUNCH(ctx, "bg_win_proj", k_win_proj, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
+               dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+        proj_queued = true;
+        return 0;
+    };
+    if (incr && has_a && !build_base) RET(queue_projection());
+    ht.mark("projection queued");
+    RET(upload_csr());
+    ht.mark("A csr");
 
     // ---- ind_active (:25-29) ----
     RET(dActive.ensure(P->d));
@@ -1333,29 +1368,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         }
         if (incr) {
             // ---- B2a': U~ on the blocks near footprints, then one sweep base -> cov ----
-            DevBuf &dLp = ctx->inc[0], &dLk = ctx->inc[1], &dSlot = ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5], &dGb = ctx->inc[6];
             RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
             if (has_a) {
-                std::vector<int> blall;
-                for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());      // longest lists first
-                RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
-                RET(to_dev(ctx, dLk, lst_k.data(), lst_k.size()));
+                if (!proj_queued) RET(queue_projection());             // (first fit of the patch: behind the video's table)
                 RET(to_dev(ctx, dSlot, slot_of.data(), slot_of.size()));
-                RET(to_dev(ctx, dBl, blall.data(), blall.size()));
-                RET(dCsum.ensure((size_t)K * sizeof(double)));
-                LAUNCH(ctx, "bg_trace_subsum", k_trace_subsum, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, g.Tp, g.kstride, dCsum.as<double>());
-                {
-                    const int nb_ = (int)blall.size();
-                    // frame segments per block: enough workgroups to fill the chip; small patches (few blocks) get more, shorter segments
-                    const int nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
-                    const int64_t ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX, gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
-                    RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
-                    RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
-                    LAUNCH(ctx, "bg_win_proj", k_win_proj, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
-                           dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
-                    LAUNCH(ctx, "bg_win_fix", k_win_fix, dim3((unsigned)nb_), dim3(256), 0, g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(),
-                           dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
-                }
+                LAUNCH(ctx, "bg_win_fix", k_win_fix, dim3((unsigned)blall.size()), dim3(256), 0, g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(),
+                       dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
                 const int csplit = npairs >= 8192 ? 1 : npairs >= 4096 ? 2 : 4;      // (small patches: a pair's sweep is a long serial loop, one workgroup per pair leaves the chip idle)
                 LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs, (unsigned)csplit), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
                        dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
