@@ -171,7 +171,7 @@ def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
     return IND
 
 
-def rows_of(A, lut, nloc, cols=None, span=None):
+def rows_of(A, lut, nloc, cols=None, span=None, cand=None):
     """A(rows, :) for the rows a lookup table selects (global pixel -> local row or -1; local order ascending with the global one), as
     (ind, A(rows, ind)) in CSC with ind = the columns whose selected entries sum to > 0 (`sum(A(mask,:),1) > 0`, the reference's neuron
     selection) -- or, with `cols` (ascending) given, A(rows, cols).  No CSR conversion and no per-row index array: columns that cannot reach
@@ -180,7 +180,9 @@ def rows_of(A, lut, nloc, cols=None, span=None):
     if not A.has_sorted_indices:
         A = A.copy(); A.sort_indices()
     K = A.shape[1]
-    if cols is None:
+    if cols is None and cand is not None:
+        cand = np.asarray(cand, dtype=np.int64)                      # the caller's prefilter (a superset of the columns that can reach the rows)
+    elif cols is None:
         cnt_all = np.diff(A.indptr)
         cand = np.nonzero(cnt_all > 0)[0]
         if span is not None and cand.size:
@@ -190,22 +192,32 @@ def rows_of(A, lut, nloc, cols=None, span=None):
         cand = np.asarray(cols, dtype=np.int64)
         if cand.size and np.any(np.diff(cand) < 0):
             raise ValueError("cols must be ascending")
-    S = A[:, cand] if cand.size != K else A                       # CSC column slice: O(nnz of the kept columns)
-    loc = lut[S.indices]
+    # the entries of the kept columns, gathered with index arithmetic (a scipy column slice costs more than the data it moves here)
+    nS = int(cand.size)
+    if nS != K:
+        starts = A.indptr[cand].astype(np.int64); lens = (A.indptr[cand + 1] - A.indptr[cand]).astype(np.int64)
+        tot = int(lens.sum())
+        ends = np.cumsum(lens)
+        src = np.arange(tot, dtype=np.int64) + np.repeat(starts - (ends - lens), lens)
+        S_indices = A.indices[src]; S_data = A.data[src]
+    else:
+        lens = np.diff(A.indptr).astype(np.int64)
+        S_indices = A.indices; S_data = A.data
+    loc = lut[S_indices]
     keep = loc >= 0
-    cid = np.repeat(np.arange(S.shape[1], dtype=np.int64), np.diff(S.indptr))
+    cid = np.repeat(np.arange(nS, dtype=np.int64), lens)
     if cols is None:
-        csum = np.bincount(cid[keep], weights=S.data[keep], minlength=S.shape[1])
+        csum = np.bincount(cid[keep], weights=S_data[keep], minlength=nS)
         sub = np.nonzero(csum > 0)[0]
-        if sub.size != S.shape[1]:
-            colsel = np.zeros(S.shape[1], dtype=bool); colsel[sub] = True
+        if sub.size != nS:
+            colsel = np.zeros(nS, dtype=bool); colsel[sub] = True
             keep &= colsel[cid]
         ind = cand[sub]
     else:
-        sub = np.arange(S.shape[1]); ind = cand
-    cnt = np.bincount(cid[keep], minlength=S.shape[1])[sub]
+        sub = np.arange(nS); ind = cand
+    cnt = np.bincount(cid[keep], minlength=nS)[sub]
     indptr = np.zeros(sub.size + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
-    M = sp.csc_matrix((S.data[keep], loc[keep].astype(np.int32), indptr), shape=(nloc, sub.size))
+    M = sp.csc_matrix((S_data[keep], loc[keep].astype(np.int32), indptr), shape=(nloc, sub.size))
     return ind, M
 
 # --------------------------------------------------------------------------------------
@@ -372,7 +384,38 @@ class Sources2D:
     def _slice(self, A, idx, kind, cols=None):
         """(ind, A(pixels of idx's block / patch / halo, ind)): the reference's `mask` selections (update_*_parallel.m) without a CSR of A"""
         t, n, span = self.video.lut(idx, kind)
-        return rows_of(A, t, n, cols=cols, span=span)
+        cand = None
+        if cols is None and sp.isspmatrix_csc(A) and A.has_sorted_indices:
+            # columns whose bounding box meets the rectangle (block for 'block' / 'halo', patch for 'patch'): with 4 x 4 patches the first / last
+            # stored row test of rows_of alone passes every neuron of the patch's COLUMN band; the boxes are found once per matrix
+            bb = self._bbox_of(A)
+            if bb is not None:
+                v = self.video
+                r0, r1, c0, c1 = [int(x) - 1 for x in (v.patch_pos[idx] if kind == "patch" else v.block_pos[idx])]
+                nz, rmin, rmax, cmin, cmax = bb
+                cand = nz[(rmax >= r0) & (rmin <= r1) & (cmax >= c0) & (cmin <= c1)]
+        return rows_of(A, t, n, cols=cols, span=span, cand=cand)
+
+    def _bbox_of(self, A):
+        """(non-empty columns, their first / last image row and column), cached for the last few matrices by identity"""
+        cache = self.__dict__.setdefault("_bbox_cache", [])
+        for M, bb in cache:
+            if M is A:
+                return bb
+        nz = np.nonzero(np.diff(A.indptr) > 0)[0]
+        if nz.size == 0:
+            bb = (nz, nz, nz, nz, nz)
+        else:
+            d1 = self.video.d1
+            rr = A.indices % d1
+            starts = A.indptr[nz]
+            # rows of a column are stored ascending in pixel index = image column major: first / last entry give the column range
+            cmin = A.indices[starts] // d1; cmax = A.indices[A.indptr[nz + 1] - 1] // d1
+            rmin = np.minimum.reduceat(rr, starts); rmax = np.maximum.reduceat(rr, starts)
+            bb = (nz, rmin, rmax, cmin, cmax)
+        cache.append((A, bb))
+        del cache[:-4]
+        return bb
 
     @staticmethod
     def _rows(Cm, ind):
