@@ -57,13 +57,18 @@ function update_spatial_parallel(obj, use_parallel, update_sn)
     if update_sn, obj.P.sn = reshape(sn_all, size(obj.P.sn)); end
 
     % post-processing: connected component of the peak (spatial_constraints.connected), on the device
-    if isfield(opt, 'spatial_constraints') && isfield(opt.spatial_constraints, 'circular') && opt.spatial_constraints.circular
-        error('cnmfe:circular', 'spatial_constraints.circular is not built on the engine');
-    end
     if ~isfield(opt, 'spatial_constraints') || ~isfield(opt.spatial_constraints, 'connected') || opt.spatial_constraints.connected
         keep = cnmfe_mex('postprocess', eng.h(1), A_new, d1, d2);
         [r, c, v] = find(A_new);
         A_new = sparse(r(keep), c(keep), v(keep), d1 * d2, K);
+    end
+    % spatial_constraints.circular (off in every demo): one small image per neuron, the reference's own circular_constraints on the host,
+    % after the connectivity step as in post_process_spatial.m:22-31
+    if isfield(opt, 'spatial_constraints') && isfield(opt.spatial_constraints, 'circular') && opt.spatial_constraints.circular
+        for k = 1:K
+            ai = circular_constraints(reshape(full(A_new(:, k)), d1, d2));
+            A_new(:, k) = sparse(ai(:));
+        end
     end
     obj.A = A_new;
     Ymean = cell2mat(obj.P.Ymean);

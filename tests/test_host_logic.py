@@ -203,6 +203,26 @@ def test_matlab_host_speaks_the_gateways_commands():
     assert used and used <= gateway, used - gateway
     for name in ("update_background_parallel.m", "update_spatial_parallel.m", "update_temporal_parallel.m"):
         assert os.path.exists(os.path.join(mdir, "@Sources2D", name))
+    # the classdef methods of Sources2D.m that touch the video have a body on the engine too, and the host files use the commands made for them
+    for name, cmds in (("cnmfe_estimate_noise.m", {"estimate_noise"}), ("cnmfe_compute_RSS.m", {"compute_rss", "compute_rss_ssub", "background_ssub"}),
+                       ("cnmfe_reconstruct_background.m", {"reconstruct_background", "reconstruct_background_ssub", "background_ssub"})):
+        txt = open(os.path.join(mdir, name)).read()
+        assert cmds <= set(re.findall(r"cnmfe_mex\('(\w+)'", txt)), name
+    # number of arguments of every call = what the gateway checks (nin counts the command string too)
+    src = open(os.path.join(mdir, "cnmfe_mex.cpp")).read()
+    need = {m.group(1): int(m.group(2)) for m in re.finditer(r'strcmp\(cmd, "(\w+)"\)\) \{[^\n]*\n\s*if \(nin != (\d+)\)', src)}
+    for fn in mfiles:
+        txt = open(fn).read()
+        for m in re.finditer(r"cnmfe_mex\('(\w+)'", txt):
+            cmd, i, depth, nargs = m.group(1), m.end(), 1, 1
+            while depth:
+                ch = txt[i]
+                depth += ch in "([{"
+                depth -= ch in ")]}"
+                nargs += ch == "," and depth == 1
+                i += 1
+            if cmd in need and nargs > 1:                                # (a bare cnmfe_mex('name') is a mention in a comment)
+                assert nargs == need[cmd], (os.path.basename(fn), cmd, nargs, need[cmd])
 
 
 def test_bench_line_contract_of_the_committed_profile():
