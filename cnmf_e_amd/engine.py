@@ -222,6 +222,12 @@ class Engine:
     def upload_block(self, pid, Y, t0=0):
         """Y: (nt, d_b) host array (float32/float64/uint16/uint8/float16), frames t0..t0+nt."""
         Y = np.ascontiguousarray(Y)
+        if Y.dtype not in _DT:
+            # element types the ABI has no code for (int16 TIFF / HDF5 recordings, int32, bool): widened on the host to the narrowest float that holds
+            # them exactly -- the device stores fp32 either way
+            if Y.dtype.kind not in "iub":
+                raise TypeError("cannot upload a block of %s" % Y.dtype)
+            Y = Y.astype(np.float32 if Y.dtype.itemsize <= 2 else np.float64)
         info = self._patch[pid]
         if Y.ndim != 2 or Y.shape[1] != info["d_b"]:
             raise ValueError("block must be (frames, %d), got %s" % (info["d_b"], Y.shape))

@@ -328,6 +328,105 @@ class PatchedVideo:
         else:
             self.upload_from_images(mm.reshape(self.T, self.d1, self.d2), chunk)
 
+    def upload_from_hdf5(self, path, dataset=None, chunk=256, frame0=0):
+        """a `.h5` / `.hdf5` recording with its movie in the root group (smod_bigread2.m:338-355) or a v7.3 `.mat` recording holding `Y` or a single
+        array (smod_bigread2.m:378-400).  A d1 x d2 x T MATLAB array / h5read view is the HDF5 dataset of dims (T, d2, d1) -- singleton dims anywhere, as
+        in the 5-D files get_data_dimension.m:32-35 indexes with [2 3 5] -- so a hyperslab over the first axis is a run of frames already in the reference's
+        pixel order.  Read once, in frame chunks; frame0 = frames to skip (obj.frame_range(1) - 1)."""
+        from . import h5io
+        with h5io.H5File(path) as f:
+            name = dataset if dataset is not None else _pick_movie(f)
+            dims = f.shape(name)
+            axes = [i for i, n in enumerate(dims) if n != 1]
+            if len(axes) != 3 or (dims[axes[1]], dims[axes[2]]) != (self.d2, self.d1):
+                raise ValueError("dataset %r of %s has MATLAB size %s, the field of view is %d x %d" % (name, path, tuple(reversed(dims)), self.d1, self.d2))
+            if frame0 < 0 or frame0 + self.T > dims[axes[0]]:
+                raise ValueError("dataset %r has %d frames, frames %d..%d were asked for" % (name, dims[axes[0]], frame0 + 1, frame0 + self.T))
+            f.dtype(name)                                                  # (raises for a non-numeric dataset before anything is uploaded)
+            for t0 in range(0, self.T, chunk):
+                n = min(chunk, self.T - t0)
+                start = [0] * len(dims); count = list(dims)
+                start[axes[0]], count[axes[0]] = frame0 + t0, n
+                cm = f.read(name, start, count).reshape(n, self.d1 * self.d2)
+                for idx in self.owned:
+                    self.engine.upload_block(self.pid[idx], cm[:, self.block_pix[idx]], t0)
+
+    def upload_from_mat_data(self, path, chunk=256, frame0=0):
+        """the blocked file distribute_data.m:127-173 wrote (`mat_data`): every owned block (patch + halo) is put together from the storage blocks
+        `Y_r0_r1_c0_c1` that meet it, as get_patch_data.m:50-93 does -- neighbouring storage blocks share their cut line, the shared line is the same data
+        in both -- and goes up in the file's element type.  Only the parts of the file this rank's blocks cover are read."""
+        from . import h5io
+        with h5io.H5File(path) as f:
+            info = mat_data_info(f)
+            if tuple(info["dims"][:2]) != (self.d1, self.d2):
+                raise ValueError("%s holds a %d x %d field of view, the patches were created for %d x %d" % ((path,) + tuple(info["dims"][:2]) + (self.d1, self.d2)))
+            if frame0 < 0 or frame0 + self.T > info["dims"][2]:
+                raise ValueError("%s holds %d frames, frames %d..%d were asked for" % (path, info["dims"][2], frame0 + 1, frame0 + self.T))
+            stored = info["blocks"]
+            for idx in self.owned:
+                r0, r1, c0, c1 = [int(v) for v in self.block_pos[idx]]
+                nr, nc = r1 - r0 + 1, c1 - c0 + 1
+                parts = []
+                for (s0, s1, q0, q1), name in stored.items():
+                    a0, a1, b0, b1 = max(r0, s0), min(r1, s1), max(c0, q0), min(c1, q1)
+                    if a0 <= a1 and b0 <= b1:
+                        parts.append((name, (b0 - q0, a0 - s0), (b1 - b0 + 1, a1 - a0 + 1), (b0 - c0, a0 - r0)))
+                cover = np.zeros((nc, nr), dtype=bool)
+                for _, _, (wc, wr), (oc, orr) in parts:
+                    cover[oc:oc + wc, orr:orr + wr] = True
+                if not cover.all():
+                    raise ValueError("%s: the stored blocks do not cover block [%d %d %d %d]" % (path, r0, r1, c0, c1))
+                for t0 in range(0, self.T, chunk):
+                    n = min(chunk, self.T - t0)
+                    buf = np.empty((n, nc, nr), dtype=info["dtype"])
+                    for name, (sc, sr), (wc, wr), (oc, orr) in parts:
+                        buf[:, oc:oc + wc, orr:orr + wr] = f.read(name, (frame0 + t0, sc, sr), (n, wc, wr))
+                    self.engine.upload_block(self.pid[idx], buf.reshape(n, nc * nr), t0)
+
+
+def _pick_movie(f):
+    """the movie of a recording: `Y` when there is one (a .mat with Y and Ysiz), else the only numeric dataset with three non-singleton dims"""
+    if f.has("Y"):
+        return "Y"
+    cand = []
+    for n in f.names():
+        if f.has(n):
+            try:
+                f.dtype(n)
+            except TypeError:
+                continue
+            if sum(1 for v in f.shape(n) if v != 1) == 3:
+                cand.append(n)
+    if len(cand) != 1:
+        raise ValueError("%s: cannot tell which dataset is the movie (%s); name it" % (f.path, ", ".join(cand) or "none has three dimensions"))
+    return cand[0]
+
+
+def mat_data_info(f):
+    """what a blocked `mat_data` file says about itself (distribute_data.m:129-158): dims, patch_dims, w_overlap, the cut lines, the element type and
+    the name of every stored block keyed by its rectangle.  `f`: a path or an open h5io.H5File."""
+    from . import h5io
+    import re
+    if not isinstance(f, h5io.H5File):
+        with h5io.H5File(f) as g:
+            return mat_data_info(g)
+    ints = lambda name: [int(v) for v in np.asarray(f.matlab_value(name)).reshape(-1, order="F")]
+    blocks = {}
+    for n in f.names():
+        m = re.fullmatch(r"Y_(\d+)_(\d+)_(\d+)_(\d+)", n)
+        if m:
+            rect = tuple(int(v) for v in m.groups())
+            if f.matlab_size(n)[:2] != (rect[1] - rect[0] + 1, rect[3] - rect[2] + 1):
+                raise ValueError("%s: block %s has size %s" % (f.path, n, f.matlab_size(n)))
+            blocks[rect] = n
+    if not blocks:
+        raise ValueError("%s holds no Y_r0_r1_c0_c1 block: not a file distribute_data wrote" % f.path)
+    dts = {f.dtype(n) for n in blocks.values()}
+    if len(dts) != 1:
+        raise ValueError("%s: the stored blocks have different element types" % f.path)
+    return {"dims": tuple(ints("dims")), "patch_dims": tuple(ints("patch_dims")), "w_overlap": ints("w_overlap")[0],
+            "block_idx_r": np.array(ints("block_idx_r")), "block_idx_c": np.array(ints("block_idx_c")), "dtype": dts.pop(), "blocks": blocks}
+
 
 # --------------------------------------------------------------------------------------
 # Sources2D

@@ -507,6 +507,28 @@ def test_data_plane_uint16_tiff_to_device(eng, tmp_path):
         assert out.shape == (T, v.patch_pix[idx].size) and np.isfinite(out).all()
 
 
+def test_data_plane_hdf5_files_to_device(eng):
+    """the reference's blocked mat_data file (uint16 blocks, deflate) and an int16 5-D .hdf5 recording go up block by block; the resident blocks have
+    the means of the video's rectangles (fixtures written by h5py: tests/golden/make_h5_fixtures.py)"""
+    from cnmf_e_amd import h5io
+    from cnmf_e_amd.sources2d import PatchedVideo, mat_data_info
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    try:
+        h5io.lib()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    Y = np.load(os.path.join(gold, "h5_video.npy")).astype(np.float64)     # d1 x d2 x T
+    info = mat_data_info(os.path.join(gold, "h5_mat_data.mat"))
+    d1, d2, T = info["dims"]
+    Y_td = Y.reshape(d1 * d2, T, order="F").T
+    for loader in (lambda v: v.upload_from_mat_data(os.path.join(gold, "h5_mat_data.mat"), chunk=16),
+                   lambda v: v.upload_from_hdf5(os.path.join(gold, "h5_recording5d.hdf5"), chunk=13)):
+        v = PatchedVideo(d1, d2, T, info["patch_dims"], info["w_overlap"], eng)
+        loader(v)
+        for idx in v.owned:
+            assert np.allclose(eng.ymean(v.pid[idx]), Y_td[:, v.block_pix[idx]].mean(axis=0), rtol=1e-6), idx
+
+
 def test_deconv_degenerate_traces_terminate_with_finite_output(eng):
     """all-zero, constant, single-spike and monotone traces: no stable AR(1) estimate / zero noise level / NaN intermediates must neither hang
     the per-trace kernel nor leak NaN or Inf into C and S (deconvolveCa.m:84-89,206)"""
