@@ -771,24 +771,41 @@ class Sources2D:
         rows, cols, vals = [], [], []
         whole_result = whole_pp = None
         IND = None
-        for idx in v.owned:
-            pp, bp, ip = v.patch_pix[idx], v.block_pix[idx], v.ind_patch[idx]
+
+        def prev_of(idx):
             # A_prev restricted to neurons that touch the HALO only (mask==1 after the patch is set to 2, :84-85,96)
-            halo = v.halo_pix(idx)
-            if halo.size:
+            if v.halo_pix(idx).size:
                 indp, _ = self._slice(self.A_prev, idx, "halo")
             else:
                 indp = np.zeros(0, dtype=np.int64)
             A_prev_b = self._slice(self.A_prev, idx, "block", cols=indp)[1] if indp.size else None   # :97
             C_prev_b = self._rows(self.C_prev, indp) if indp.size else None                         # :98
+            return A_prev_b, C_prev_b
+
+        def masks_of(idx):
+            ind, IND_patch = self._slice(IND, idx, "patch")                                          # :87, :89
+            if ind.size == 0:
+                return ind, IND_patch, None, None
+            return ind, IND_patch, self._slice(self.A, idx, "patch", cols=ind)[1], self._rows(self.C, ind)   # :88,199 / :91
+
+        ahead = None                                                       # the next patch's slices, cut while this patch's sweeps run
+        for i, idx in enumerate(v.owned):
+            pp = v.patch_pix[idx]
             launched = IND is None
             if launched:
                 # the residual sweep (:162-166) does not depend on the search mask: start it (the call returns with
                 # the kernel in flight) and build IND (:66) on the host underneath it
+                A_prev_b, C_prev_b = prev_of(idx)
                 self._residual(idx, A_prev_b, C_prev_b)
                 IND = self._search_location_csc()
-            ind, IND_patch = self._slice(IND, idx, "patch")                                          # :87, :89
+                ind, IND_patch, A_patch, C_patch = masks_of(idx)
+            else:
+                (A_prev_b, C_prev_b), (ind, IND_patch, A_patch, C_patch) = ahead
+            ahead = None
+            nxt = v.owned[i + 1] if i + 1 < len(v.owned) else None
             if ind.size == 0 and not update_sn:
+                if nxt is not None:
+                    ahead = (prev_of(nxt), masks_of(nxt))
                 continue                                                                             # :121-124
             if not launched:
                 self._residual(idx, A_prev_b, C_prev_b)                                # :162-166
@@ -797,14 +814,16 @@ class Sources2D:
                 sn_patch = self.engine.get_sn(v.pid[idx])                                           # :191-194  sn_patch = GetSn(Ypatch)
                 sn_new[pp] = sn_patch
             if ind.size == 0:
+                if nxt is not None:
+                    ahead = (prev_of(nxt), masks_of(nxt))
                 continue                                                                             # :196-199
-            A_patch = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # :88,199
-            C_patch = self._rows(self.C, ind)                                                       # :91
             param = 20 if o.spatial_algorithm == "nnls" else 3                                      # :203,205,211
             if getattr(self.engine, "supports_lazy_traces", False):
                 fetch = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                                    sn_patch if o.spatial_algorithm == "hals_thresh" else None, param, defer=True)
                 self._temporal_residual_early(idx)                       # host work under the sweeps
+                if nxt is not None:
+                    ahead = (prev_of(nxt), masks_of(nxt))                # ... and the slices of the next patch: its launches follow this fetch at once
                 whole = pp.size == v.d1 * v.d2 and ind.size == K
                 if whole and o.spatial_constraints.get("connected", True) and (self.dist is None or (v.world_size == 1 and not self.force_collectives)):
                     # one patch = the field of view: post_process_spatial's connectivity constraint (:341) runs on the result where it lies
@@ -814,6 +833,8 @@ class Sources2D:
             else:
                 Anew = self.engine.update_spatial(v.pid[idx], o.spatial_algorithm, A_patch, C_patch, IND_patch,
                                                   sn_patch if o.spatial_algorithm == "hals_thresh" else None, param)
+                if nxt is not None:
+                    ahead = (prev_of(nxt), masks_of(nxt))
             if pp.size == v.d1 * v.d2 and ind.size == K:
                 whole_result = Anew                                                                  # one patch over the whole FOV, every neuron: already A_
                 continue
