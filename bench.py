@@ -167,6 +167,9 @@ def main():
     fence()
     warm_ms = 1e3 * (time.perf_counter() - tw0) / max(1, a.warmup)
     warm_tab = eng.profile_table()
+    # timed region: HIP events only around the kernels a roofline is quoted for (an event pair around EVERY launch costs host and device time per
+    # launch -- 8 ms per iteration with the ~2000 small launches of c4, ~1 % at c3); the per-kernel breakdown comes from EXTRA steps after it
+    eng.profile(2)
     eng.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -174,6 +177,13 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    tab_timed = eng.profile_table()
+    XSTEPS = 2
+    eng.profile(1)
+    eng.profile_reset()
+    for _ in range(XSTEPS):                                     # (every rank: the steps hold the collectives)
+        step()
+    fence()
     if world > 1:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -183,9 +193,11 @@ def main():
         return
     n_patches = video.nr_patch * video.nc_patch
     value = (n_patches if a.weak else 1) * a.steps / dt          # whole-FOV iterations/s (weak mode: patch-iterations/s, every patch a full 512 x 512 FOV)
-    tab = eng.profile_table()
-    kern = {k: {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / a.steps,
-                "ms_per_step": v["total_ms"] / a.steps} for k, v in tab.items() if v["calls"]}
+    kern = {k: {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / float(XSTEPS),
+                "ms_per_step": v["total_ms"] / XSTEPS, "from": "extra steps"} for k, v in eng.profile_table().items() if v["calls"]}
+    for k, v in tab_timed.items():                              # the roofline kernels: measured inside the timed region
+        if v["calls"]:
+            kern[k] = {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / float(a.steps), "ms_per_step": v["total_ms"] / a.steps, "from": "timed region"}
     dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
     # ---- roofline of the dominant kernel; algorithmic work per launch from SURVEY.md section 8(d) ----
     P = {idx: video.patch_pix[idx].size for idx in video.owned}
@@ -314,7 +326,7 @@ def main():
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
                    "parallelism": "patches round-robin over %d rank(s)" % world,
                    **({"note": "strong scaling of the 4 x 4-patch decomposition (BASELINE configs[3]); its own N = 1 point is `python bench.py --config c4` "
-                               "(16 patches on one GPU: profiles/r02/bench_c4_n1_v4.json, 11.5 iter/s) -- the default N = 1 line is configs[2], the same "
+                               "(16 patches on one GPU: profiles/r02/bench_c4_n1_v6.json, 13.4 iter/s) -- the default N = 1 line is configs[2], the same "
                                "video as ONE patch, which has no halo re-reads and 16x larger launches"} if (world > 1 and a.config == "c4" and not a.weak) else {})},
         "roofline": roof,
         "roofline_r1": r1r,
@@ -325,6 +337,10 @@ def main():
                             "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},
                             "note": "the first background fit of a patch also builds the block-pair covariance table of the video on the fp64 matrix pipe (kept until the "
                                     "video or the frame stride changes); it falls into the warm-up step(s), `--warmup 0` puts it inside the timed region"},
+        "kernel_timing": {"timed_region": sorted(k for k, v in kern.items() if v["from"] == "timed region"),
+                          "note": "HIP events on the engine's stream.  Inside the timed region only the kernels a roofline is quoted for are bracketed "
+                                  "(cnmfe_profile_enable(ctx, 2)); every other row of kernels_ms_per_step is the average of %d extra steps run after it with "
+                                  "events around every launch" % XSTEPS},
         "kernel_sum_ms_per_step": round(sum(v["ms_per_step"] for v in kern.values()), 3),
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "kernel_calls_per_step": {k: round(v["calls_per_step"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] > 0.5},

@@ -927,7 +927,7 @@ int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K
     return postproc_run(ctx, d1, d2, K, A_colptr, A_rowidx, A_val, keep);
 }
 
-int cnmfe_profile_enable(cnmfe_ctx *ctx, int on) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.drain(); ctx->prof.on = on != 0; return 0; }
+int cnmfe_profile_enable(cnmfe_ctx *ctx, int on) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.drain(); ctx->prof.on = on == 2 ? 2 : (on != 0); return 0; }
 int cnmfe_profile_reset(cnmfe_ctx *ctx) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.reset(); return 0; }
 int cnmfe_profile_count(cnmfe_ctx *ctx) { if (!ctx) return fail(CNMFE_EINVAL, "null context"); ctx->prof.drain(); return (int)ctx->prof.names.size(); }
 int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int cap, double *total_ms, int64_t *calls) {

@@ -46,7 +46,14 @@ struct DevBuf {
 
 // ---- per-kernel event timing ---------------------------------------------------
 struct Profiler {
-    bool on = false;
+    int on = 0;                        // 0 off, 1 every kernel, 2 only the kernels a roofline is quoted for (a pair of events costs a few microseconds of
+                                       // host AND device time per launch: thousands of small launches per iteration feel it, cnmfe_profile_enable)
+    static bool selected(const char *n) {
+        static const char *const sel[] = {"residual_r1", "bg_ring_solve", "bg_win_proj", "bg_cov_correct", "spatial_proj_U", "temporal_proj_U"};
+        for (const char *s : sel) if (!strcmp(n, s)) return true;
+        return false;
+    }
+    bool want(const char *n) const { return on == 1 || (on == 2 && selected(n)); }
     struct Rec { hipEvent_t a, b; int id; };
     std::vector<std::string> names;
     std::vector<double> total_ms; std::vector<int64_t> calls;
@@ -73,7 +80,7 @@ struct Profiler {
 
 // launch wrapper: LAUNCH(ctx, "name", kernel, grid, block, shmem, args...)
 #define LAUNCH(ctx, name, kern, grid, block, shmem, ...) do { \
-    cnmfe::Profiler::Rec pr_; bool pon_ = (ctx)->prof.on; \
+    cnmfe::Profiler::Rec pr_; bool pon_ = (ctx)->prof.on && (ctx)->prof.want(name); \
     if (pon_) (ctx)->prof.begin(name, (ctx)->stream, pr_); \
     hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
     if (pon_) (ctx)->prof.end((ctx)->stream, pr_); \

@@ -551,6 +551,7 @@ class Engine:
 
     # ---- measurement ---------------------------------------------------------------
     def profile(self, on=True):
+        """True / 1: events around every kernel; 2: only around the roofline kernels (cnmfe.h); False: off"""
         L.check(L.lib.cnmfe_profile_enable(self._ctx, int(on)))
 
     def profile_reset(self):

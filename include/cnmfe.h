@@ -300,7 +300,10 @@ int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K
                                const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                                uint8_t *keep);
 
-/* ---- measurement: per-kernel HIP-event timing on the engine's stream --------- */
+/* ---- measurement: per-kernel HIP-event timing on the engine's stream ---------
+ * on = 1: every launch is bracketed by a pair of events; on = 2: only the kernels a roofline is quoted for (residual sweep, ring solve, window
+ * projection / table correction, the two residual projections) -- the pairs cost host and device time per launch, which a run that wants its
+ * wall time undisturbed avoids; on = 0: off. */
 int cnmfe_profile_enable(cnmfe_ctx *ctx, int on);
 int cnmfe_profile_reset(cnmfe_ctx *ctx);
 /* number of distinct kernel names seen; name/total_ms/calls of the i-th */
