@@ -144,3 +144,36 @@ class FakeEngine:
     def post_process_spatial(self, A_full, d1, d2):
         A = sp.csc_matrix(A_full).toarray().astype(np.float64)
         return sp.csc_matrix(orc.post_process_spatial(A.reshape(d1, d2, A.shape[1], order="F")))
+
+
+class LazyFakeEngine(FakeEngine):
+    """the same double with the asynchronous surface of the real engine (Engine.supports_lazy_traces): update_spatial(defer=True) returns a fetch
+    closure and stitch_finish(want="lazy") hands out the traces -- so the orderings sources2d only takes with such an engine (the temporal update's
+    residual requested under the spatial sweeps, the next patch's slices cut before this patch's fetch, the connectivity constraint applied with the
+    fetch of a whole-FOV patch) run on CPU.  The spatial result is computed when the call is made, from the residual resident at that moment: the
+    real engine has the sweeps queued by then and only records a later residual request as pending."""
+    supports_lazy_traces = True
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def residual(self, pid, A_prev_block=None, C_prev=None, want=False):
+        self.calls.append(("residual", pid))
+        return super().residual(pid, A_prev_block, C_prev, want)
+
+    def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3, defer=False):
+        self.calls.append(("update_spatial", pid))
+        out = super().update_spatial(pid, algorithm, A_patch, C_patch, IND_patch, sn, param)
+        if not defer:
+            return out
+
+        def fetch(connected_fov=None):
+            self.calls.append(("fetch", pid))
+            if connected_fov is None:
+                return out
+            return out, self.post_process_spatial(out, *connected_fov)
+        return fetch
+
+    def stitch_finish(self, subtract_min, want=True):
+        return super().stitch_finish(subtract_min)

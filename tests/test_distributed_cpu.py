@@ -15,18 +15,18 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out, update_sn):
+def _worker(rank, world, port, out, update_sn, lazy=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     from cnmf_e_amd import synth
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-    from fake_engine import FakeEngine
+    from fake_engine import FakeEngine, LazyFakeEngine
     c = CASE
     f = synth.make_factors(c["d1"], c["d2"], c["T"], c["K"], c["seed"], gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
-    video = PatchedVideo(c["d1"], c["d2"], c["T"], [20, 22], c["r"], FakeEngine(), rank=rank, world_size=world)
+    video = PatchedVideo(c["d1"], c["d2"], c["T"], [20, 22], c["r"], LazyFakeEngine() if lazy else FakeEngine(), rank=rank, world_size=world)
     assert len(video.owned) == 4 // world
     video.upload_from_full(Y.astype(np.float64))
     s = Sources2D(video, Options(ring_radius=c["r"], spatial_algorithm="hals", maxIter=3), f.A_init, f.C_init, f.sn,
@@ -41,14 +41,15 @@ def _worker(rank, world, port, out, update_sn):
 import pytest
 
 
-@pytest.mark.parametrize("update_sn", [False, True])
-def test_two_rank_sharded_iteration_matches_single_process(tmp_path, update_sn):
+@pytest.mark.parametrize("update_sn,lazy", [(False, False), (True, False), (False, True)])
+def test_two_rank_sharded_iteration_matches_single_process(tmp_path, update_sn, lazy):
+    """lazy: the engine double defers its results like the real engine, so the sharded run takes the orderings it takes under RCCL"""
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnmfe_oracle as orc
     from cnmf_e_amd import synth
     out = str(tmp_path / "r0.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out, update_sn), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, update_sn, lazy), nprocs=2, join=True)
     got = np.load(out)
     c = CASE
     f = synth.make_factors(c["d1"], c["d2"], c["T"], c["K"], c["seed"], gSig=1.5, gSiz=7, min_sep=5)

@@ -270,3 +270,35 @@ def test_noise_image_bookkeeping_and_nearest_rows_match_the_oracle():
         for s_ in (2, 3, 4):
             M = orc.imresize_weights(n, -(-n // s_), 1.0 / s_, "nearest")
             assert (M.max(axis=1) == 1).all() and np.array_equal(M.argmax(axis=1), nearest_rows(n, s_)), (n, s_)
+
+
+@pytest.mark.parametrize("pdims,update_sn", [([20, 22], False), ([20, 22], True), (None, False)])
+def test_asynchronous_engine_orderings_give_the_same_iteration(pdims, update_sn):
+    """with an engine that defers its results (the real one) sources2d reorders host work: the temporal update's residual is requested under the
+    spatial sweeps, the next patch's slices are cut before this patch's fetch, a whole-FOV patch gets its connectivity constraint with the fetch.
+    Two iterations with the deferring test double = two iterations with the blocking one, exactly; and the call order is the intended one."""
+    from fake_engine import FakeEngine, LazyFakeEngine
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 40, 44, 120, 6, 4
+    f = synth.make_factors(d1, d2, T, K, 31, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32).astype(np.float64)
+
+    def run(engine):
+        v = PatchedVideo(d1, d2, T, pdims or [d1, d2], r, engine)
+        v.upload_from_full(Y)
+        s = Sources2D(v, Options(ring_radius=r, spatial_algorithm="hals", maxIter=3), f.A_init, f.C_init, f.sn)
+        for _ in range(2):
+            s.update_background_parallel(); s.update_spatial_parallel(update_sn=update_sn); s.update_temporal_parallel()
+        return s, v
+
+    a, _ = run(FakeEngine())
+    eng = LazyFakeEngine()
+    b, v = run(eng)
+    assert (a.A != b.A).nnz == 0 and np.array_equal(np.asarray(a.C), np.asarray(b.C)) and np.array_equal(np.asarray(a.C_raw), np.asarray(b.C_raw))
+    assert np.array_equal(a.b0_new, b.b0_new) and np.array_equal(a.P["sn"], b.P["sn"])
+    # per patch of a spatial update: residual, update_spatial, the temporal update's residual, fetch -- and the temporal update asks for no further sweep
+    n = len(v.owned)
+    calls = eng.calls[-4 * n:]
+    assert [c[0] for c in calls] == ["residual", "update_spatial", "residual", "fetch"] * n, calls
+    assert [c[1] for c in calls] == [v.pid[idx] for idx in v.owned for _ in range(4)]
