@@ -302,3 +302,58 @@ def test_asynchronous_engine_orderings_give_the_same_iteration(pdims, update_sn)
     calls = eng.calls[-4 * n:]
     assert [c[0] for c in calls] == ["residual", "update_spatial", "residual", "fetch"] * n, calls
     assert [c[1] for c in calls] == [v.pid[idx] for idx in v.owned for _ in range(4)]
+
+
+def test_sparse_row_selection_matches_scipy_on_random_matrices():
+    """rows_of / Sources2D._slice (the O(nnz) selection of a block's, patch's or halo's rows out of the d x K footprints, with the bounding-box
+    prefilter) against plain scipy indexing: `ind = find(sum(A(mask, :), 1) > 0)`, `A(mask, ind)` -- on random matrices with empty columns,
+    stored zeros, negative entries and footprints that straddle patch borders"""
+    from fake_engine import FakeEngine
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options, rows_of
+    rng = np.random.default_rng(5)
+    d1, d2, T, r = 37, 41, 8, 3
+    v = PatchedVideo(d1, d2, T, [12, 13], r, FakeEngine())
+    d = d1 * d2
+    for trial in range(6):
+        K = int(rng.integers(1, 40))
+        cols, rows, vals = [], [], []
+        for k in range(K):
+            if rng.random() < 0.15:
+                continue                                                   # empty column
+            r0, c0 = int(rng.integers(0, d1 - 1)), int(rng.integers(0, d2 - 1))
+            h, w = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+            rr, cc = np.meshgrid(np.arange(r0, min(d1, r0 + h)), np.arange(c0, min(d2, c0 + w)), indexing="ij")
+            keep = rng.random(rr.size) < 0.7
+            pix = (cc.ravel() * d1 + rr.ravel())[keep]
+            val = rng.normal(0.3, 1.0, pix.size)
+            val[rng.random(pix.size) < 0.1] = 0.0                          # stored zeros
+            rows.append(pix); cols.append(np.full(pix.size, k)); vals.append(val)
+        if rows:
+            A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(d, K))
+        else:
+            A = sp.csc_matrix((d, K))
+        A.sort_indices()
+        s = Sources2D.__new__(Sources2D)
+        s.video = v
+        Ar = A.tocsr()
+        for idx in v.order:
+            for kind in ("block", "patch", "halo"):
+                pix = v.block_pix[idx] if kind == "block" else v.patch_pix[idx] if kind == "patch" else v.halo_pix(idx)
+                sub = Ar[pix]
+                want_ind = np.nonzero(np.asarray(sub.sum(axis=0)).ravel() > 0)[0]
+                ind, M = s._slice(A, idx, kind)
+                assert np.array_equal(ind, want_ind), (trial, idx, kind)
+                assert M.shape == (pix.size, want_ind.size) and abs(M - sub[:, want_ind]).max() == 0 if want_ind.size else M.shape[1] == 0
+                # an explicit ascending column list instead of the selection
+                pick = np.sort(rng.choice(K, size=min(K, 5), replace=False))
+                ind2, M2 = s._slice(A, idx, kind, cols=pick)
+                assert np.array_equal(ind2, pick) and (M2.shape[1] == 0 or abs(M2 - sub[:, pick]).max() == 0)
+        # rows_of on its own, without the prefilter and with an unsorted input
+        t, n, span = v.lut(v.order[0], "block")
+        B = sp.csc_matrix(A.toarray()[:, ::-1])
+        ind, M = rows_of(B, t, n, span=span)
+        sub = B.tocsr()[v.block_pix[v.order[0]]]
+        want = np.nonzero(np.asarray(sub.sum(axis=0)).ravel() > 0)[0]
+        assert np.array_equal(ind, want) and (want.size == 0 or abs(M - sub[:, want]).max() == 0)
+    with pytest.raises(ValueError):
+        rows_of(A, t, n, cols=np.array([2, 1]))
