@@ -28,7 +28,9 @@ template <int R> struct ArcTab {
     int ra0[4][24];           // arc-local index of the run's first offset
 };
 
-template <int R> constexpr ArcTab<R> make_arcs() {
+// B > 0 (experiment, k_residual_arc_dma1b): the arcs of roles 1 (right) and 3 (bottom) give their corner offsets within B of the diagonal to roles 2 (top)
+// and 0 (left) -- the waves of roles 1 and 3 share SIMDs 2 and 3 and role 3 also carries the final pass of the one-barrier kernel
+template <int R, int B = 0> constexpr ArcTab<R> make_arcs() {
     ArcTab<R> t{};
     constexpr RingTab<R> ring = make_ring<R>();
     int fx[4][40] = {}, mv[4][40] = {}, id[4][40] = {};
@@ -40,6 +42,10 @@ template <int R> constexpr ArcTab<R> make_arcs() {
         if (adc > adr) a = dc < 0 ? 0 : 1;
         else if (adr > adc) a = dr < 0 ? 2 : 3;
         else a = (dc < 0 && dr < 0) ? 0 : (dc > 0 && dr > 0) ? 1 : (dr < 0 ? 2 : 3);
+        if (B > 0) {
+            if (a == 1 && dc > 0 && dr < 0 && !(adc > adr + B)) a = 2;       // top-right corner: right -> top
+            if (a == 3 && dc < 0 && dr > 0 && !(adr > adc + B)) a = 0;       // bottom-left corner: bottom -> left
+        }
         const int k = t.n[a]++;
         fx[a][k] = a < 2 ? dc : dr; mv[a][k] = a < 2 ? dr : dc; id[a][k] = i;
     }
@@ -61,7 +67,7 @@ template <int R> constexpr ArcTab<R> make_arcs() {
     }
     return t;
 }
-template <int R> struct ArcConst { static constexpr ArcTab<R> tab = make_arcs<R>(); };
+template <int R, int B = 0> struct ArcConst { static constexpr ArcTab<R> tab = make_arcs<R, B>(); };
 
 // flat per-role program for P centres per thread: the LDS reads in order, and for every read the (centre j,
 // arc-local weight index a) pairs it feeds
@@ -71,9 +77,9 @@ template <int R, int P> struct ArcProg {
     int nf[4][96];
     int fj[4][96][4], fa[4][96][4];
 };
-template <int R, int P> constexpr ArcProg<R, P> make_prog() {
+template <int R, int P, int B = 0> constexpr ArcProg<R, P> make_prog() {
     ArcProg<R, P> g{};
-    constexpr ArcTab<R> t = make_arcs<R>();
+    constexpr ArcTab<R> t = make_arcs<R, B>();
     for (int arc = 0; arc < 4; ++arc) {
         int li = 0;
         for (int run = 0; run < t.nrun[arc]; ++run)
@@ -91,18 +97,19 @@ template <int R, int P> constexpr ArcProg<R, P> make_prog() {
     }
     return g;
 }
-template <int R, int P> struct ProgConst { static constexpr ArcProg<R, P> tab = make_prog<R, P>(); };
+template <int R, int P, int B = 0> struct ProgConst { static constexpr ArcProg<R, P> tab = make_prog<R, P, B>(); };
 
 // the ring product of one role: ARC in 0..3, P centres per thread.  hb = thread base in the halo:
 //   vertical roles  (ARC 0/1): &halo[c * HRp + g*P]      -> value of (row g*P + i, col c + j) at hb[(j+R)*HRp + (i+R)]
 //   horizontal roles(ARC 2/3): &halo[h*P * HRp + r]      -> value of (row r + i, col h*P + j) at the same expression
 // wp[j][a/2] holds the arc weights of centre j as pairs; acc[j][0] = frames 0,1, acc[j][1] = frames 2,3.
-template <int R, int ARC, int P, int HRp, int NW, int D = 4>
+template <int R, int ARC, int P, int HRp, int NW, int D = 4, int B = 0>
 __device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][NW], f2 (&acc)[P][2]) {
-    constexpr int NL = ProgConst<R, P>::tab.nl[ARC];       // D = LDS reads in flight ahead of their FMAs
+    using PC = ProgConst<R, P, B>;
+    constexpr int NL = PC::tab.nl[ARC];                    // D = LDS reads in flight ahead of their FMAs
     float4 r[D + 1];
-#define ARC_ADDR(li) (ARC < 2 ? hb + (ProgConst<R, P>::tab.fix[ARC][li] + R) * HRp + (ProgConst<R, P>::tab.mov[ARC][li] + R) \
-                              : hb + (ProgConst<R, P>::tab.mov[ARC][li] + R) * HRp + (ProgConst<R, P>::tab.fix[ARC][li] + R))
+#define ARC_ADDR(li) (ARC < 2 ? hb + (PC::tab.fix[ARC][li] + R) * HRp + (PC::tab.mov[ARC][li] + R) \
+                              : hb + (PC::tab.mov[ARC][li] + R) * HRp + (PC::tab.fix[ARC][li] + R))
 #pragma unroll
     for (int li = 0; li < D; ++li) if (li < NL) r[li] = *ARC_ADDR(li);
 #pragma unroll
@@ -112,8 +119,8 @@ __device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][
         const f2 r01 = {rv.x, rv.y}, r23 = {rv.z, rv.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (q < ProgConst<R, P>::tab.nf[ARC][li]) {
-                const int j = ProgConst<R, P>::tab.fj[ARC][li][q], a = ProgConst<R, P>::tab.fa[ARC][li][q];
+            if (q < PC::tab.nf[ARC][li]) {
+                const int j = PC::tab.fj[ARC][li][q], a = PC::tab.fa[ARC][li][q];
                 const f2 wv = wp[j][a >> 1];
                 if ((a & 1) == 0) {
                     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j][0]) : "v"(wv), "v"(r01));
@@ -635,6 +642,144 @@ __global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma1(R1Args 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// EXPERIMENT (option r1_arc_bias = B in 2..4, not the default, not yet measured): k_residual_arc_dma1 with UNEQUAL arcs (make_arcs<R, B>): roles 1 and 3, whose
+// waves share SIMDs 2 and 3 -- and of which role 3 also finishes the previous chunk -- hand corner offsets to roles 2 and 0.  Same LDS layout, same
+// barrier scheme; only the per-role offset counts (weights held as pairs, an odd count leaves the last .y at 0) and programs differ.
+template <int R, int ARC_D, int B>
+__global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma1b(R1Args a) {
+    constexpr int P = 4;
+    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC, NT = NC, NWV = NT / 64;
+    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
+    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;
+    constexpr int NHp = HRp * HC;
+    constexpr int NIT = (NHp + NT - 1) / NT, NHs = NIT * NT;
+    using AC = ArcConst<R, B>;
+    constexpr int NA01 = AC::tab.n[0] > AC::tab.n[1] ? AC::tab.n[0] : AC::tab.n[1], NA23 = AC::tab.n[2] > AC::tab.n[3] ? AC::tab.n[2] : AC::tab.n[3];
+    constexpr int NA = NA01 > NA23 ? NA01 : NA23;                      // the longest arc sizes the weight registers
+    static_assert(AC::tab.n[0] + AC::tab.n[1] + AC::tab.n[2] + AC::tab.n[3] == RingConst<R>::tab.n, "the arcs must partition the ring");
+    constexpr int NW = (NA + 1) / 2;
+    constexpr int TRp = TR + 1, NCp = TRp * TC;
+    constexpr int NBUF = 2, PARTN = 2 * NCp + NC;                      // roles 0, 1 (column stride TR + 1), role 2
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHs] | part[2][PARTN]
+    float4 *halo = lds, *part = lds + NBUF * NHs;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tmap = a.tile_map[blockIdx.x];
+    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
+    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
+    constexpr int TPR = NC / P;
+    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;
+    int cr[P], cc[P];
+    int hbase;
+    if (role < 2) {
+        const int c = rt & 31, g = rt >> 5;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
+        hbase = c * HRp + g * P;
+    } else {
+        const int q = rt >> 4, i = rt & 15;
+        const int sq = (q * P * HRp) & 15;
+        const int r = (i - sq) & 15;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
+        hbase = q * P * HRp + r;
+    }
+    f2 wp[P][NW];
+    uint32_t fmb[P]; float dl[P]; bool fv[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
+        fv[j] = pr < a.nr && pc < a.nc;
+        const int64_t m = fv[j] ? (int64_t)pc * a.nr + pr : 0;
+        const uint32_t mb = (uint32_t)m * 4u;
+        fmb[j] = mb; dl[j] = ld_off(a.dlt, mb);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int i0 = -1, i1 = -1;                                      // -1: past the end of this role's arc
+            if (role == 0) { if (2 * k < AC::tab.n[0]) i0 = AC::tab.ring[0][2 * k]; if (2 * k + 1 < AC::tab.n[0]) i1 = AC::tab.ring[0][2 * k + 1]; }
+            else if (role == 1) { if (2 * k < AC::tab.n[1]) i0 = AC::tab.ring[1][2 * k]; if (2 * k + 1 < AC::tab.n[1]) i1 = AC::tab.ring[1][2 * k + 1]; }
+            else if (role == 2) { if (2 * k < AC::tab.n[2]) i0 = AC::tab.ring[2][2 * k]; if (2 * k + 1 < AC::tab.n[2]) i1 = AC::tab.ring[2][2 * k + 1]; }
+            else { if (2 * k < AC::tab.n[3]) i0 = AC::tab.ring[3][2 * k]; if (2 * k + 1 < AC::tab.n[3]) i1 = AC::tab.ring[3][2 * k + 1]; }
+            wp[j][k].x = i0 >= 0 ? ld_off(a.W + (int64_t)i0 * a.d, mb) : 0.f;
+            wp[j][k].y = i1 >= 0 ? ld_off(a.W + (int64_t)i1 * a.d, mb) : 0.f;
+        }
+    }
+    uint32_t qoff[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int idx = (j * NWV + wave) * 64 + lane;
+        const int hr = idx % HRp, hc = idx / HRp;
+        int rb = hr0 + hr, cb = hc0 + (hc < HC ? hc : HC - 1);
+        rb = rb < 0 ? 0 : (rb >= a.nr_b ? a.nr_b - 1 : rb);
+        cb = cb < 0 ? 0 : (cb >= a.nc_b ? a.nc_b - 1 : cb);
+        qoff[j] = (uint32_t)(cb * a.nr_b + rb) * 16u;
+    }
+    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds;
+    const unsigned lds0 = ldsA + (unsigned)wave * 1024u;
+    const int64_t cbeg = ((int64_t)blockIdx.y * a.tseg) >> 2;
+    const int64_t tend = (int64_t)blockIdx.y * a.tseg + a.tseg < a.T ? (int64_t)blockIdx.y * a.tseg + a.tseg : a.T;
+    const int64_t cend = (tend + 3) >> 2;
+    const int probe = __builtin_amdgcn_readfirstlane(a.probe);
+    auto issue = [&](int64_t c) {
+        if ((probe & 1) && c > cbeg + 1) return;
+        const int64_t cx = c < cend ? c : cend - 1;
+        const float4 *y4 = a.Y4 + cx * a.d_b;
+        const int b = (int)((c - cbeg) & 1);
+        const unsigned dst = lds0 + (unsigned)b * (unsigned)(NHs * 16);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) glds16(y4, qoff[j], dst + (unsigned)(j * NWV) * 1024u);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(cbeg);
+    f2 keep[P][2];                                                    // keeper: its own partial of the previous chunk
+    float4 cvs[P];                                                    //         and the centre values of that chunk
+#pragma unroll
+    for (int j = 0; j < P; ++j) { keep[j][0] = (f2){0.f, 0.f}; keep[j][1] = (f2){0.f, 0.f}; cvs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int64_t c = cbeg; c <= cend; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's part of halo(c) (and the keeper's stores of chunk c-2)
+        __builtin_amdgcn_s_barrier();                                 // halo(c) complete; the partial sums of chunk c-1 complete
+        asm volatile("" ::: "memory");
+        if (c < cend) issue(c + 1);                                   // into the buffer of chunk c-1: everybody is done with it
+        const int cb_ = (int)((c - cbeg) & 1);
+        if (role == 3 && c > cbeg) {                                  // finish chunk c-1
+            const float4 *pb = part + (cb_ ^ 1) * PARTN;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int cv_ = cc[j] * TRp + cr[j], ci = cc[j] * TR + cr[j];
+                const float4 p0 = pb[cv_], p1 = pb[NCp + cv_], p2 = pb[2 * NCp + ci];
+                const float4 cv = cvs[j];
+                const float4 yo = make_float4(cv.x + dl[j] - ((p0.x + p1.x) + (p2.x + keep[j][0].x)), cv.y + dl[j] - ((p0.y + p1.y) + (p2.y + keep[j][0].y)),
+                                              cv.z + dl[j] - ((p0.z + p1.z) + (p2.z + keep[j][1].x)), cv.w + dl[j] - ((p0.w + p1.w) + (p2.w + keep[j][1].y)));
+                if (fv[j] && !(probe & 8)) st4_off(a.Ysig4 + (c - 1) * a.d, fmb[j] * 4u, yo);
+            }
+        }
+        if (c == cend) break;
+        const float4 *hb = halo + cb_ * NHs + hbase;
+        f2 acc[P][2];
+#pragma unroll
+        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
+        if (probe & 2) { }
+        else if (role == 0) arc_product<R, 0, P, HRp, NW, ARC_D, B>(hb, wp, acc);
+        else if (role == 1) arc_product<R, 1, P, HRp, NW, ARC_D, B>(hb, wp, acc);
+        else if (role == 2) arc_product<R, 2, P, HRp, NW, ARC_D, B>(hb, wp, acc);
+        else arc_product<R, 3, P, HRp, NW, ARC_D, B>(hb, wp, acc);
+        if (role == 3) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                keep[j][0] = acc[j][0]; keep[j][1] = acc[j][1];
+                cvs[j] = halo[cb_ * NHs + (cc[j] + R) * HRp + (cr[j] + R)];
+            }
+        } else {
+            float4 *pw = part + cb_ * PARTN;
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                pw[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + cc[j] * TR + cr[j]] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // partial sums written / centre values read before the next barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int R>
 static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int64_t nseg) {
     constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1, NT = ARC_TR * ARC_TC;
@@ -644,7 +789,17 @@ static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int6
     static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
     const int arcd = (int)ctx->opt("r1_arc_d", 4);                     // LDS reads in flight ahead of their FMAs (experiments: 6, 8)
-    if (arcd == 6) {
+    const int bias = (int)ctx->opt("r1_arc_bias", 0);                  // experiment: unequal arcs (k_residual_arc_dma1b), 2..4
+    if (bias == 2) {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 2>), grid, dim3(NT), shmem, a);
+    } else if (bias == 3) {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 3>), grid, dim3(NT), shmem, a);
+    } else if (bias == 4) {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 4>), grid, dim3(NT), shmem, a);
+    } else if (arcd == 6) {
         CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R, 6>), grid, dim3(NT), shmem, a);
     } else if (arcd == 8) {
