@@ -789,7 +789,7 @@ static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int6
     static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
     const int arcd = (int)ctx->opt("r1_arc_d", 4);                     // LDS reads in flight ahead of their FMAs (experiments: 6, 8)
-    const int bias = (int)ctx->opt("r1_arc_bias", 0);                  // experiment: unequal arcs (k_residual_arc_dma1b), 2..4
+    const int bias = (int)ctx->opt("r1_arc_bias", 0);                  // experiment: unequal arcs (k_residual_arc_dma1b): 2, 3, 4, 5 (7 spills: 240 VGPRs + scratch)
     if (bias == 2) {
         CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 2>), grid, dim3(NT), shmem, a);
@@ -799,6 +799,9 @@ static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int6
     } else if (bias == 4) {
         CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 4>), grid, dim3(NT), shmem, a);
+    } else if (bias == 5) {
+        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 5>), grid, dim3(NT), shmem, a);
     } else if (arcd == 6) {
         CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R, 6>), grid, dim3(NT), shmem, a);

@@ -1,5 +1,5 @@
-"""Round-3 experiment: the one-barrier R1 kernel with UNEQUAL arcs (k_residual_arc_dma1b, option r1_arc_bias = 2, 3, 4) against the default (equal arcs):
-   python scripts/r1_arc_bias.py [--bias 0,2,3,4] [--reps 5]
+"""Round-3 experiment: the one-barrier R1 kernel with UNEQUAL arcs (k_residual_arc_dma1b, option r1_arc_bias = 2, 3, 4, 5) against the default (equal arcs):
+   python scripts/r1_arc_bias.py [--bias 0,2,3,4,5] [--reps 5]
 For every bias: max |Ysig - Ysig(bias 0)| over the exported patch (a different summation order only: ~1e-6 relative) and the kernel's mean time at H.
 The hypothesis: roles 1 and 3 share SIMDs 2 and 3 and role 3 also finishes the previous chunk, so handing their corner offsets
 to roles 2 and 0 shortens the wait at the chunk barrier.  Not measured yet (written at the end of round 2 with no GPU time left)."""
@@ -7,7 +7,7 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--bias", default="0,2,3,4"); ap.add_argument("--reps", type=int, default=5)
+ap = argparse.ArgumentParser(); ap.add_argument("--bias", default="0,2,3,4,5"); ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--small", action="store_true", help="128 x 96 x 400 instead of the headline size (numerics only)")
 a = ap.parse_args()
 import torch
