@@ -188,164 +188,9 @@ __device__ __forceinline__ void st4_off_wt(float4 *base, uint32_t byteoff, float
     asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(byteoff), "v"(x), "s"(base) : "memory");
 }
 
-// waves/SIMD the register allocator must leave room for: weights (P VGPRs) + working registers
-template <int P, int NT> struct R1Occ { static constexpr int value = 2; };
-
-// ---- specialised kernel: ring radius known at compile time --------------------------------------
-// every neighbour address is `thread base + immediate`, so a neighbour costs one ds_read_b128 and
-// four FMAs and no address arithmetic; the P weights stay in VGPRs for the workgroup's lifetime.
-template <int R, int TR, int TC, bool HAS_AC>
-__global__ void __launch_bounds__(TR *TC, (R1Occ<RingConst<R>::tab.n, TR * TC>::value)) k_residual_r(R1Args a) {
-    constexpr int NT = TR * TC;
-    constexpr int P = RingConst<R>::tab.n;
-    constexpr int HR = TR + 2 * R, HC = TC + 2 * R, NH = HR * HC;
-    constexpr int NIT = (NH + NT - 1) / NT;                 // halo pixels staged per thread
-    extern __shared__ __attribute__((aligned(16))) float4 halo[];     // two buffers of NH float4
-    const int tid = threadIdx.x;
-    // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous range of tiles
-    // (column-major over the tile grid) so that the halos neighbouring tiles share stay in one L2.
-    const int tmap = a.tile_map[blockIdx.x];
-    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
-    const int tr = tid % TR, tc = tid / TR;
-    const int pr = tile_r * TR + tr, pc = tile_c * TC + tc;
-    const bool valid = pr < a.nr && pc < a.nc;
-    const int64_t m = valid ? (int64_t)pc * a.nr + pr : 0;
-    const int64_t qc = valid ? (int64_t)(pc + a.coff) * a.nr_b + (pr + a.roff) : 0;
-    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
-    const int hbase = tc * HR + tr;                     // biased base: neighbour (dr,dc) at halo[hbase + (dc+R)*HR + (dr+R)]
-
-    // frame-invariant staging plan of this thread: BYTE offset inside a frame (or ~0u outside the block)
-    // of the NIT halo pixels it stages
-    uint32_t qoff[NIT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int idx = tid + j * NT;
-        const int hr = idx % HR, hc = idx / HR;
-        const int rb = hr0 + hr, cb = hc0 + hc;
-        const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
-        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 16u : ~0u;
-    }
-    const uint32_t mb = (uint32_t)m * 4u;
-    (void)qc;
-    // (W*A_prev) row of this pixel: the first WA_PRE entries are kept in registers (frame-invariant) and their
-    // trace samples are fetched at the top of every iteration so they land under the ring product
-    constexpr int WA_PRE = 4;
-    uint32_t wko[WA_PRE]; float wvv[WA_PRE]; int nwa = 0;
-    if (HAS_AC) {
-        nwa = valid ? a.wa_cnt[m] : 0;
-#pragma unroll
-        for (int e = 0; e < WA_PRE; ++e) {
-            const bool on = e < nwa;
-            wko[e] = on ? (uint32_t)a.wa_k[(int64_t)e * a.d + m] * (uint32_t)(a.ldc * 4) : 0u;
-            wvv[e] = on ? a.wa_v[(int64_t)e * a.d + m] : 0.f;
-        }
-    }
-
-    static_assert(P % 2 == 0, "ring size must be even (weights are held as pairs)");
-    f2 wp[P / 2];
-#pragma unroll
-    for (int i = 0; i < P / 2; ++i) {                   // threads off the patch read pixel 0 and never store
-        wp[i].x = ld_off(a.W + (int64_t)(2 * i) * a.d, mb);
-        wp[i].y = ld_off(a.W + (int64_t)(2 * i + 1) * a.d, mb);
-    }
-    const float dl = ld_off(a.dlt, mb);
-
-    const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
-    const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
-
-    float4 pre[NIT];                                    // the NEXT chunk's halo values, in flight during the ring product
-    auto issue = [&](int64_t t0) {                      // one 16-byte load per staged pixel (4 frames)
-        const float4 *y4 = a.Y4 + (t0 >> 2) * a.d_b;
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) pre[j] = ld4_off(y4, qoff[j] == ~0u ? 0u : qoff[j]);
-    };
-    // Y' = Y - Ymean, float4 (4 frames) per halo pixel
-    auto commit = [&](float4 *buf) {
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const int idx = tid + j * NT;
-            float4 v = pre[j];
-            if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NIT * NT == NH || idx < NH) buf[idx] = v;
-        }
-    };
-
-    issue(tbeg);
-    commit(halo);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t t0 = tbeg; t0 < tend; t0 += 4) {
-        const bool more = t0 + 4 < tend;
-        if (more) issue(t0 + 4);                        // global loads of the next chunk fly under the ring product
-        float4 wc[WA_PRE];
-        if (HAS_AC) {
-#pragma unroll
-            for (int e = 0; e < WA_PRE; ++e)
-                wc[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.Cc + t0) + wko[e]);
-        }
-        const float4 *hb = halo + cur * NH + hbase;
-        // ---- ring product: groups of G neighbours = G ds_read_b128 then 4G FMAs.  The asm ties each
-        // group's FMAs into the memory order: without it all P reads are hoisted (4 VGPRs each) and spill. ----
-        f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-        constexpr int G = 4, NG = P / G, D = 3;         // D groups of reads in flight ahead of the FMAs (<= 15 outstanding: lgkmcnt is 4 bits)
-        static_assert(P % G == 0, "ring size must be a multiple of the read group");
-        float4 r[D + 1][G];
-#pragma unroll
-        for (int g = 0; g < D; ++g)
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-                r[g][j] = hb[(RingConst<R>::tab.dc[g * G + j] + R) * HR + (RingConst<R>::tab.dr[g * G + j] + R)];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + D < NG) {
-#pragma unroll
-                for (int j = 0; j < G; ++j)
-                    r[(g + D) % (D + 1)][j] = hb[(RingConst<R>::tab.dc[(g + D) * G + j] + R) * HR + (RingConst<R>::tab.dr[(g + D) * G + j] + R)];
-            }
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                // two v_pk_fma_f32 (2 FMAs per lane each) instead of four v_fma_f32.  Weights live as PAIRS
-                // (w[2k], w[2k+1]) in one 64-bit VGPR pair; op_sel/op_sel_hi broadcast the low or the high
-                // half to both packed lanes, so a weight still costs one VGPR (hipcc would splat it into two).
-                const float4 rv = r[g % (D + 1)][j];
-                const f2 r01 = {rv.x, rv.y}, r23 = {rv.z, rv.w};
-                const f2 wv = wp[(g * G + j) >> 1];
-                if (((g * G + j) & 1) == 0) {
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc01) : "v"(wv), "v"(r01));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc23) : "v"(wv), "v"(r23));
-                } else {
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc01) : "v"(wv), "v"(r01));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc23) : "v"(wv), "v"(r23));
-                }
-            }
-            asm volatile("" : "+v"(acc01), "+v"(acc23) : : "memory");
-        }
-        const float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
-        if (valid) {
-            // Ysig = (Y - Ymean)(centre) + (Ymean - b0) - W*Y' + (W*A_prev)*Cc ; the centre's Y' is in the halo
-            float4 c = hb[R * HR + R];
-            if (HAS_AC) {
-#pragma unroll
-                for (int e = 0; e < WA_PRE; ++e) {
-                    c.x = fmaf(wvv[e], wc[e].x, c.x); c.y = fmaf(wvv[e], wc[e].y, c.y);
-                    c.z = fmaf(wvv[e], wc[e].z, c.z); c.w = fmaf(wvv[e], wc[e].w, c.w);
-                }
-                for (int e = WA_PRE; e < nwa; ++e) {    // rare: more than WA_PRE footprints under this pixel's ring
-                    const float v = a.wa_v[(int64_t)e * a.d + m];
-                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + m] * a.ldc + t0);
-                    c.x = fmaf(v, c4.x, c.x); c.y = fmaf(v, c4.y, c.y); c.z = fmaf(v, c4.z, c.z); c.w = fmaf(v, c4.w, c.w);
-                }
-            }
-            st4_off(a.Ysig4 + (t0 >> 2) * a.d, mb * 4u, make_float4(c.x + dl - acc.x, c.y + dl - acc.y, c.z + dl - acc.z, c.w + dl - acc.w));
-        }
-        if (more) commit(halo + (cur ^ 1) * NH);
-        cur ^= 1;
-        __syncthreads();
-    }
-}
-
 // ---- specialised kernel, LDS-DMA staging (r1_variant 10) -------------------------------------------------
-// Same ring product as k_residual_r, but the halo goes global -> LDS directly (global_load_lds_dwordx4): no staging
+// One centre pixel per thread, every neighbour address `thread base + immediate` (one ds_read_b128 and four FMAs per neighbour, no address
+// arithmetic), the P weights in VGPRs for the workgroup's lifetime; the halo goes global -> LDS directly (global_load_lds_dwordx4): no staging
 // VGPRs, no ds_write commit phase (49 KB per chunk through the 79 B/clk store path), and the halo of chunk c+2 is in
 // flight while chunk c is consumed (three LDS buffers, ONE barrier per chunk).  The DMA writes lane-linearly, so a
 // buffer is 48 wave-instructions x 64 slots of 16 B; slots past the halo and halo pixels outside the block fetch a
@@ -744,54 +589,30 @@ __global__ void __launch_bounds__(256) k_residual_delta(float4 *__restrict__ ysi
     }
 }
 
-template <int R, int TR, int TC>
-static int launch_r1(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, dim3 grid) {
-    constexpr size_t shmem = 2 * (size_t)(TR + 2 * R) * (TC + 2 * R) * sizeof(float4);   // double-buffered halo
-    static_assert(shmem <= 160 * 1024, "halo tile exceeds LDS");
-    if (shmem > 64 * 1024) {
-        CK(hipFuncSetAttribute((const void *)k_residual_r<R, TR, TC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        CK(hipFuncSetAttribute((const void *)k_residual_r<R, TR, TC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    }
-    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_r<R, TR, TC, true>), grid, dim3(TR * TC), shmem, a);
-    else        LAUNCH(ctx, "residual_r1", (k_residual_r<R, TR, TC, false>), grid, dim3(TR * TC), shmem, a);
-    return 0;
-}
-
 }  // namespace cnmfe
 #include "resid_arc.hpp"
-#include "resid_quad.hpp"
+#include "resid_duo.hpp"
 namespace cnmfe {
 
+// r1_variant: 14 = duo roles (resid_duo.hpp; radius 15, no footprint term inside the sweep: the default), 11 = four arc roles on a 16 x 32 tile with the
+// A_prev flavour (resid_arc.hpp; radius 15), 10 = one pixel per thread (radius 18 and the low-resolution radii of bg_ssub), -1 = generic kernel.
+// Measured and removed in round 3 (numbers in profiles/r02/, profiles/r03/README.md): register-staged tiles (0-4), register-staged arc roles (5-9),
+// quad roles (12), four roles with one barrier per chunk (13, and its unequal-arc variants).
 template <int R>
 static int launch_r1_v(cnmfe_ctx *ctx, int variant, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
-    if constexpr (R == 15) {                              // arc kernel: radius 15 only (16-bit ds_read immediates, LDS size)
-        if (variant == 5) return launch_r1_arc<R, 4>(ctx, a, has_ac, ntile_c, nseg);
-        if (variant == 6) return launch_r1_arc<R, 2>(ctx, a, has_ac, ntile_c, nseg);
-        if (variant == 7) return launch_r1_arc<R, 2, 1, 3>(ctx, a, has_ac, ntile_c, nseg);   // ablation: staging + stores only, 3 chunks in flight
-        if (variant == 8) return launch_r1_arc<R, 4, 0, 2>(ctx, a, has_ac, ntile_c, nseg);   // 2 chunks in flight
-        if (variant == 9) return launch_r1_arc<R, 4, 0, 3>(ctx, a, has_ac, ntile_c, nseg);   // 3 chunks in flight
-        if (variant == 11) return launch_r1_arc_dma<R>(ctx, a, has_ac, ntile_c, nseg);         // arc roles on LDS-DMA staging
-        if (variant == 13) return launch_r1_arc_dma1<R>(ctx, a, ntile_c, nseg);                // arc roles, one barrier per chunk (keeper role finishes chunk c-1 under chunk c)
-        if (variant == 12) return launch_r1_quad<R>(ctx, a, ntile_c, nseg);                    // the four roles inside one wave, two workgroups per CU
+    if constexpr (R == 15) {                              // arc kernels: radius 15 only (16-bit ds_read immediates, LDS size)
+        if (variant == 11) return launch_r1_arc_dma<R>(ctx, a, has_ac, ntile_c, nseg);
+        if (variant == 14) return launch_r1_duo<R>(ctx, a, ntile_c, nseg);
     }
     // note: a.ntile_r / grid depend on the tile shape, set by the caller through tile_shape()
     dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
-    switch (variant) {
-        case 10: return launch_r1_dma<R, 32, 16>(ctx, a, has_ac, grid);
-        case 1: return launch_r1<R, 32, 8>(ctx, a, has_ac, grid);
-        case 2: return launch_r1<R, 32, 16>(ctx, a, has_ac, grid);
-        case 3: return launch_r1<R, 64, 4>(ctx, a, has_ac, grid);
-        case 4: return launch_r1<R, 64, 8>(ctx, a, has_ac, grid);
-        default: return launch_r1<R, 16, 16>(ctx, a, has_ac, grid);
-    }
+    return launch_r1_dma<R, 32, 16>(ctx, a, has_ac, grid);
 }
 
 static void tile_shape(int variant, int &TR, int &TC) {
-    TR = 16; TC = 16;
-    if (variant == 1) { TR = 32; TC = 8; } else if (variant == 2 || variant == 10) { TR = 32; TC = 16; }
-    else if (variant == 3) { TR = 64; TC = 4; } else if (variant == 4) { TR = 64; TC = 8; }
-    else if ((variant >= 5 && variant <= 9) || variant == 11 || variant == 13) { TR = ARC_TR; TC = ARC_TC; }
-    else if (variant == 12) { TR = QD_T; TC = QD_T; }
+    TR = 32; TC = 16;                                     // variant 10
+    if (variant == 11) { TR = ARC_TR; TC = ARC_TC; }
+    else if (variant == 14) { TR = DUO_T; TC = DUO_T; }
 }
 
 // the ABI hands Ysig out frame-major (d x T column-major); resident it is 4-frame interleaved
@@ -1114,16 +935,16 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
            P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
 
     // is the resident ring the full get_nhood(radius) ring?  (then a compile-time kernel exists for 15 / 18)
-    int variant = (int)ctx->opt("r1_variant", 13);
+    int variant = (int)ctx->opt("r1_variant", 14);
     const int h = P->radius;
-    if (variant == 13 && (has_ac || h != 15)) variant = 11;   // one-barrier arc kernel: no footprint term inside the sweep
-    if (variant == 12 && (has_ac || h != 15)) variant = 11;   // quad roles (resid_quad.hpp; measured slower, kept for A/B): radius 15, no footprint term inside the sweep
+    if (variant >= 0 && variant != 10 && variant != 11 && variant != 14) variant = 14;
+    if (variant == 14 && (has_ac || h != 15)) variant = 11;   // duo roles (resid_duo.hpp): radius 15, no footprint term inside the sweep
     bool full_ring = true;
     { int n = 0;
       for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
-    if (h == 18 && ((variant >= 5 && variant <= 9) || variant >= 11)) variant = 10;   // arc kernels: radius 15 only (ds_read immediates)
+    if (h == 18 && variant >= 11) variant = 10;               // arc kernels: radius 15 only (ds_read immediates)
     // the low-resolution rings of bg_ssub = 2, 3 (ceil(15/2) = 8, ceil(18/2) = 9, ceil(15/3) = 5, ceil(18/3) = 6): LDS-DMA kernel only
     const bool small_special = full_ring && (h == 5 || h == 6 || h == 8 || h == 9) && variant >= 0;
     if (small_special) variant = 10;
@@ -1147,13 +968,14 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     const int64_t ntiles = (int64_t)a.ntile_r * ntile_c;
     // enough workgroups to fill 256 CUs several times over; segments are a multiple of 4 frames
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((T + 255) / 256, (4096 + ntiles - 1) / ntiles));
+    if (variant == 14) nseg = std::max<int64_t>(1, std::min<int64_t>((T + 255) / 256, (512 + ntiles - 1) / ntiles));   // 1024-pixel tiles: two rounds of the chip; every segment re-reads W
     if (ctx->opt("r1_nseg", 0) > 0) nseg = std::min<int64_t>(ctx->opt("r1_nseg", 0), (T + 3) / 4);      // (experiments: force the number of frame segments)
     int64_t tseg = ((T + nseg - 1) / nseg + 3) & ~int64_t(3);
     nseg = (T + tseg - 1) / tseg;
     a.tseg = tseg;
     int rc;
     if (special) {
-        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1), variant == 12 ? 64 : 32));
+        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
         a.tile_map = dOffs.as<int>();
         const dim3 gridd((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
         if (h == 15) rc = launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg);

@@ -28,9 +28,7 @@ template <int R> struct ArcTab {
     int ra0[4][24];           // arc-local index of the run's first offset
 };
 
-// B > 0 (experiment, k_residual_arc_dma1b): the arcs of roles 1 (right) and 3 (bottom) give their corner offsets within B of the diagonal to roles 2 (top)
-// and 0 (left) -- the waves of roles 1 and 3 share SIMDs 2 and 3 and role 3 also carries the final pass of the one-barrier kernel
-template <int R, int B = 0> constexpr ArcTab<R> make_arcs() {
+template <int R> constexpr ArcTab<R> make_arcs() {
     ArcTab<R> t{};
     constexpr RingTab<R> ring = make_ring<R>();
     int fx[4][40] = {}, mv[4][40] = {}, id[4][40] = {};
@@ -42,10 +40,6 @@ template <int R, int B = 0> constexpr ArcTab<R> make_arcs() {
         if (adc > adr) a = dc < 0 ? 0 : 1;
         else if (adr > adc) a = dr < 0 ? 2 : 3;
         else a = (dc < 0 && dr < 0) ? 0 : (dc > 0 && dr > 0) ? 1 : (dr < 0 ? 2 : 3);
-        if (B > 0) {
-            if (a == 1 && dc > 0 && dr < 0 && !(adc > adr + B)) a = 2;       // top-right corner: right -> top
-            if (a == 3 && dc < 0 && dr > 0 && !(adr > adc + B)) a = 0;       // bottom-left corner: bottom -> left
-        }
         const int k = t.n[a]++;
         fx[a][k] = a < 2 ? dc : dr; mv[a][k] = a < 2 ? dr : dc; id[a][k] = i;
     }
@@ -67,7 +61,7 @@ template <int R, int B = 0> constexpr ArcTab<R> make_arcs() {
     }
     return t;
 }
-template <int R, int B = 0> struct ArcConst { static constexpr ArcTab<R> tab = make_arcs<R, B>(); };
+template <int R> struct ArcConst { static constexpr ArcTab<R> tab = make_arcs<R>(); };
 
 // flat per-role program for P centres per thread: the LDS reads in order, and for every read the (centre j,
 // arc-local weight index a) pairs it feeds
@@ -77,9 +71,9 @@ template <int R, int P> struct ArcProg {
     int nf[4][96];
     int fj[4][96][4], fa[4][96][4];
 };
-template <int R, int P, int B = 0> constexpr ArcProg<R, P> make_prog() {
+template <int R, int P> constexpr ArcProg<R, P> make_prog() {
     ArcProg<R, P> g{};
-    constexpr ArcTab<R> t = make_arcs<R, B>();
+    constexpr ArcTab<R> t = make_arcs<R>();
     for (int arc = 0; arc < 4; ++arc) {
         int li = 0;
         for (int run = 0; run < t.nrun[arc]; ++run)
@@ -97,15 +91,15 @@ template <int R, int P, int B = 0> constexpr ArcProg<R, P> make_prog() {
     }
     return g;
 }
-template <int R, int P, int B = 0> struct ProgConst { static constexpr ArcProg<R, P> tab = make_prog<R, P, B>(); };
+template <int R, int P> struct ProgConst { static constexpr ArcProg<R, P> tab = make_prog<R, P>(); };
 
 // the ring product of one role: ARC in 0..3, P centres per thread.  hb = thread base in the halo:
 //   vertical roles  (ARC 0/1): &halo[c * HRp + g*P]      -> value of (row g*P + i, col c + j) at hb[(j+R)*HRp + (i+R)]
 //   horizontal roles(ARC 2/3): &halo[h*P * HRp + r]      -> value of (row r + i, col h*P + j) at the same expression
 // wp[j][a/2] holds the arc weights of centre j as pairs; acc[j][0] = frames 0,1, acc[j][1] = frames 2,3.
-template <int R, int ARC, int P, int HRp, int NW, int D = 4, int B = 0>
+template <int R, int ARC, int P, int HRp, int NW, int D = 4>
 __device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][NW], f2 (&acc)[P][2]) {
-    using PC = ProgConst<R, P, B>;
+    using PC = ProgConst<R, P>;
     constexpr int NL = PC::tab.nl[ARC];                    // D = LDS reads in flight ahead of their FMAs
     float4 r[D + 1];
 #define ARC_ADDR(li) (ARC < 2 ? hb + (PC::tab.fix[ARC][li] + R) * HRp + (PC::tab.mov[ARC][li] + R) \
@@ -135,157 +129,6 @@ __device__ __forceinline__ void arc_product(const float4 *hb, const f2 (&wp)[P][
         asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]) : : "memory");
     }
 #undef ARC_ADDR
-}
-
-template <int R, int P, bool HAS_AC, int ABL = 0, int PD = 1>
-__global__ void __launch_bounds__(4 * (ARC_TR * ARC_TC) / P) k_residual_arc(R1Args a) {
-    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC;             // 512 centres
-    constexpr int NT = 4 * NC / P;                                    // threads
-    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
-    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;                    // odd, == 1 (mod 16)
-    constexpr int NH = HR * HC, NHp = HRp * HC;
-    constexpr int NIT = (NH + NT - 1) / NT;
-    constexpr int NA = ArcConst<R>::tab.n[0];                         // offsets per arc (equal for all four)
-    static_assert(ArcConst<R>::tab.n[1] == NA && ArcConst<R>::tab.n[2] == NA && ArcConst<R>::tab.n[3] == NA && NA % 2 == 0, "arcs must be balanced");
-    constexpr int NW = NA / 2;
-    // partial sums: the vertical roles write lane -> column at a fixed row, so their tiles use a column stride of
-    // TRp = 17 slots (odd: the 8 lanes of a ds_write_b128 group land on 8 distinct bank octets; with stride 16 they
-    // collided 8-way -- SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles); the horizontal roles write lane -> row.
-    constexpr int TRp = TR + 1, NCp = TRp * TC;
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHp] | part: 2 x NCp (vertical) + 2 x NC (horizontal)
-    float4 *halo = lds, *part = lds + 2 * NHp;
-    const int tid = threadIdx.x;
-    const int tmap = a.tile_map[blockIdx.x];                          // XCD-compact tile order (build_tile_map)
-    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
-    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
-
-    // ---- role geometry ----
-    constexpr int TPR = NC / P;                                       // threads per role
-    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;   // wave-uniform role (TPR is a multiple of 64)
-    int cr[P], cc[P];                                                 // tile-local (row, col) of the thread's centres
-    int hbase;
-    if (role < 2) {                                                   // vertical groups: lane -> column, 32-lane half -> row group
-        const int c = rt & 31, g = rt >> 5;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
-        hbase = c * HRp + g * P;
-    } else {                                                          // horizontal groups: 16-lane quarter -> column group, rotated rows
-        const int q = rt >> 4, i = rt & 15;
-        const int sq = (q * P * HRp) & 15;
-        const int r = (i - sq) & 15;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
-        hbase = q * P * HRp + r;
-    }
-    // ---- arc weights of the P centres, as pairs ----
-    f2 wp[P][NW];
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
-        const int64_t m = (pr < a.nr && pc < a.nc) ? (int64_t)pc * a.nr + pr : 0;     // off-patch centres read pixel 0; never stored
-        const uint32_t mb = (uint32_t)m * 4u;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            int i0, i1;
-            if (role == 0) { i0 = ArcConst<R>::tab.ring[0][2 * k]; i1 = ArcConst<R>::tab.ring[0][2 * k + 1]; }
-            else if (role == 1) { i0 = ArcConst<R>::tab.ring[1][2 * k]; i1 = ArcConst<R>::tab.ring[1][2 * k + 1]; }
-            else if (role == 2) { i0 = ArcConst<R>::tab.ring[2][2 * k]; i1 = ArcConst<R>::tab.ring[2][2 * k + 1]; }
-            else { i0 = ArcConst<R>::tab.ring[3][2 * k]; i1 = ArcConst<R>::tab.ring[3][2 * k + 1]; }
-            wp[j][k].x = ld_off(a.W + (int64_t)i0 * a.d, mb);
-            wp[j][k].y = ld_off(a.W + (int64_t)i1 * a.d, mb);
-        }
-    }
-    // ---- staging plan (frame-invariant) ----
-    uint32_t qoff[NIT]; int hidx[NIT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int idx = tid + j * NT;
-        const int hr = idx % HR, hc = idx / HR;
-        const int rb = hr0 + hr, cb = hc0 + hc;
-        const bool in = idx < NH && rb >= 0 && rb < a.nr_b && cb >= 0 && cb < a.nc_b;
-        qoff[j] = in ? (uint32_t)(cb * a.nr_b + rb) * 16u : ~0u;
-        hidx[j] = idx < NH ? hc * HRp + hr : -1;
-    }
-    // ---- final-pass centre of this thread (threads < NC) ----
-    const int fr = tid % TR, fc = (tid / TR) % TC;
-    const int fpr = tile_r * TR + fr, fpc = tile_c * TC + fc;
-    const bool fvalid = tid < NC && fpr < a.nr && fpc < a.nc;
-    const int64_t fm = fvalid ? (int64_t)fpc * a.nr + fpr : 0;
-    const uint32_t fmb = (uint32_t)fm * 4u;
-    const float dl = ld_off(a.dlt, fmb);
-    const int nwa = (HAS_AC && fvalid) ? a.wa_cnt[fm] : 0;
-
-    const int64_t tbeg = (int64_t)blockIdx.y * a.tseg;
-    const int64_t tend = tbeg + a.tseg < a.T ? tbeg + a.tseg : a.T;
-    // PD chunks of 16-byte loads are kept in flight: chunk c+PD is issued while chunk c is computed.  The chunk loop is
-    // unrolled PD times so that the PD register sets pre[s] are indexed statically.
-    float4 pre[PD][NIT];
-    auto issue = [&](auto slot, int64_t t0) {           // one 16-byte load per staged pixel (4 frames)
-        constexpr int S = decltype(slot)::value;
-        const float4 *y4 = a.Y4 + (t0 >> 2) * a.d_b;
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) pre[S][j] = ld4_off(y4, qoff[j] == ~0u ? 0u : qoff[j]);
-    };
-    auto commit = [&](auto slot, float4 *buf) {
-        constexpr int S = decltype(slot)::value;
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            float4 v = pre[S][j];
-            if (qoff[j] == ~0u) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hidx[j] >= 0) buf[hidx[j]] = v;
-        }
-    };
-    int cur = 0;
-    // one chunk: halo[cur] holds chunk t0; pre[S] holds chunk t0+4 (if any); chunk t0+4*PD is issued into the slot that
-    // chunk t0's data just left, i.e. slot (S + PD - 1) % PD
-    auto step = [&](auto slot, int64_t t0) {
-        constexpr int S = decltype(slot)::value;
-        if (t0 + 4 * PD < tend) issue(std::integral_constant<int, (S + PD - 1) % PD>{}, t0 + 4 * PD);
-        const bool more = t0 + 4 < tend;
-        const float4 *hb = halo + cur * NHp + hbase;
-        f2 acc[P][2];
-#pragma unroll
-        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
-        if (ABL == 1) { acc[0][0].x = hb[R * HRp + R].x * wp[0][0].x; }      // ablation: no ring product
-        else if (role == 0) arc_product<R, 0, P, HRp, NW>(hb, wp, acc);
-        else if (role == 1) arc_product<R, 1, P, HRp, NW>(hb, wp, acc);
-        else if (role == 2) arc_product<R, 2, P, HRp, NW>(hb, wp, acc);
-        else arc_product<R, 3, P, HRp, NW>(hb, wp, acc);
-#pragma unroll
-        for (int j = 0; j < P; ++j)
-            part[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + (role - 2) * NC + cc[j] * TR + cr[j]] =
-                make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
-        __syncthreads();
-        if (fvalid) {
-            const int ci = fc * TR + fr, cv = fc * TRp + fr;
-            const float4 p0 = part[cv], p1 = part[NCp + cv], p2 = part[2 * NCp + ci], p3 = part[2 * NCp + NC + ci];
-            float4 c = halo[cur * NHp + (fc + R) * HRp + (fr + R)];   // (Y - Ymean) at the centre
-            if (HAS_AC) {
-                for (int e = 0; e < nwa; ++e) {
-                    const float v = a.wa_v[(int64_t)e * a.d + fm];
-                    const float4 c4 = *reinterpret_cast<const float4 *>(a.Cc + (int64_t)a.wa_k[(int64_t)e * a.d + fm] * a.ldc + t0);
-                    c.x = fmaf(v, c4.x, c.x); c.y = fmaf(v, c4.y, c.y); c.z = fmaf(v, c4.z, c.z); c.w = fmaf(v, c4.w, c.w);
-                }
-            }
-            st4_off(a.Ysig4 + (t0 >> 2) * a.d, fmb * 4u,
-                    make_float4(c.x + dl - ((p0.x + p1.x) + (p2.x + p3.x)), c.y + dl - ((p0.y + p1.y) + (p2.y + p3.y)),
-                                c.z + dl - ((p0.z + p1.z) + (p2.z + p3.z)), c.w + dl - ((p0.w + p1.w) + (p2.w + p3.w))));
-        }
-        if (more) commit(slot, halo + (cur ^ 1) * NHp);      // chunk t0+4 lives in pre[S]
-        cur ^= 1;
-        __syncthreads();
-    };
-    // prologue: chunk 0 straight into halo[0]; chunks 1..PD-1 into slots 0..PD-2 (step<S> expects chunk t0+4 in pre[S])
-    issue(std::integral_constant<int, 0>{}, tbeg);
-    commit(std::integral_constant<int, 0>{}, halo);
-    if (PD > 1 && tbeg + 4 < tend) issue(std::integral_constant<int, 0>{}, tbeg + 4);        // PD-1 chunks in flight at loop entry
-    if (PD > 2 && tbeg + 8 < tend) issue(std::integral_constant<int, 1 % PD>{}, tbeg + 8);
-    __syncthreads();
-    for (int64_t t0 = tbeg; t0 < tend; t0 += 4 * PD) {
-        step(std::integral_constant<int, 0>{}, t0);
-        if (PD > 1 && t0 + 4 < tend) step(std::integral_constant<int, 1 % PD>{}, t0 + 4);
-        if (PD > 2 && t0 + 8 < tend) step(std::integral_constant<int, 2 % PD>{}, t0 + 8);
-    }
 }
 
 // ---- arc roles on LDS-DMA staging (r1_variant 11) -------------------------------------------------------------
@@ -503,318 +346,6 @@ __global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma(R1Args a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---- r1_variant 13: the same roles with ONE barrier per chunk -----------------------------------------------------------------------------
-// In k_residual_arc_dma every chunk ends with a serial tail behind the second barrier (read the four partial sums, add the centre term, store,
-// wait) during which nothing else runs.  Here the partial sums are double-buffered and the bottom arc's threads (role 3) are the KEEPERS of their
-// four pixels: their own partial and the centre values of chunk c stay in registers, the other three roles' partials go to part[c & 1], and the keeper
-// finishes chunk c inside the interval in which everybody computes chunk c + 1.  One barrier per chunk (halo landed = previous partials complete);
-// the store's latency overlaps the other waves' ring products.  No footprint-term flavour (the caller falls back to variant 11 for it).
-template <int R, int ARC_D = 4>
-__global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma1(R1Args a) {
-    constexpr int P = 4;
-    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC, NT = NC, NWV = NT / 64;
-    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
-    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;
-    constexpr int NHp = HRp * HC;
-    constexpr int NIT = (NHp + NT - 1) / NT, NHs = NIT * NT;
-    constexpr int NA = ArcConst<R>::tab.n[0];
-    static_assert(ArcConst<R>::tab.n[1] == NA && ArcConst<R>::tab.n[2] == NA && ArcConst<R>::tab.n[3] == NA && NA % 2 == 0, "arcs must be balanced");
-    constexpr int NW = NA / 2;
-    constexpr int TRp = TR + 1, NCp = TRp * TC;
-    constexpr int NBUF = 2, PARTN = 2 * NCp + NC;                      // roles 0, 1 (column stride TR + 1), role 2
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHs] | part[2][PARTN]
-    float4 *halo = lds, *part = lds + NBUF * NHs;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tmap = a.tile_map[blockIdx.x];
-    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
-    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
-    constexpr int TPR = NC / P;
-    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;
-    int cr[P], cc[P];
-    int hbase;
-    if (role < 2) {
-        const int c = rt & 31, g = rt >> 5;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
-        hbase = c * HRp + g * P;
-    } else {
-        const int q = rt >> 4, i = rt & 15;
-        const int sq = (q * P * HRp) & 15;
-        const int r = (i - sq) & 15;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
-        hbase = q * P * HRp + r;
-    }
-    f2 wp[P][NW];
-    uint32_t fmb[P]; float dl[P]; bool fv[P];
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
-        fv[j] = pr < a.nr && pc < a.nc;
-        const int64_t m = fv[j] ? (int64_t)pc * a.nr + pr : 0;
-        const uint32_t mb = (uint32_t)m * 4u;
-        fmb[j] = mb; dl[j] = ld_off(a.dlt, mb);
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            int i0, i1;
-            if (role == 0) { i0 = ArcConst<R>::tab.ring[0][2 * k]; i1 = ArcConst<R>::tab.ring[0][2 * k + 1]; }
-            else if (role == 1) { i0 = ArcConst<R>::tab.ring[1][2 * k]; i1 = ArcConst<R>::tab.ring[1][2 * k + 1]; }
-            else if (role == 2) { i0 = ArcConst<R>::tab.ring[2][2 * k]; i1 = ArcConst<R>::tab.ring[2][2 * k + 1]; }
-            else { i0 = ArcConst<R>::tab.ring[3][2 * k]; i1 = ArcConst<R>::tab.ring[3][2 * k + 1]; }
-            wp[j][k].x = ld_off(a.W + (int64_t)i0 * a.d, mb);
-            wp[j][k].y = ld_off(a.W + (int64_t)i1 * a.d, mb);
-        }
-    }
-    uint32_t qoff[NIT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int idx = (j * NWV + wave) * 64 + lane;
-        const int hr = idx % HRp, hc = idx / HRp;
-        int rb = hr0 + hr, cb = hc0 + (hc < HC ? hc : HC - 1);
-        rb = rb < 0 ? 0 : (rb >= a.nr_b ? a.nr_b - 1 : rb);
-        cb = cb < 0 ? 0 : (cb >= a.nc_b ? a.nc_b - 1 : cb);
-        qoff[j] = (uint32_t)(cb * a.nr_b + rb) * 16u;
-    }
-    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds;
-    const unsigned lds0 = ldsA + (unsigned)wave * 1024u;
-    const int64_t cbeg = ((int64_t)blockIdx.y * a.tseg) >> 2;
-    const int64_t tend = (int64_t)blockIdx.y * a.tseg + a.tseg < a.T ? (int64_t)blockIdx.y * a.tseg + a.tseg : a.T;
-    const int64_t cend = (tend + 3) >> 2;
-    const int probe = __builtin_amdgcn_readfirstlane(a.probe);
-    auto issue = [&](int64_t c) {
-        if ((probe & 1) && c > cbeg + 1) return;
-        const int64_t cx = c < cend ? c : cend - 1;
-        const float4 *y4 = a.Y4 + cx * a.d_b;
-        const int b = (int)((c - cbeg) & 1);
-        const unsigned dst = lds0 + (unsigned)b * (unsigned)(NHs * 16);
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) glds16(y4, qoff[j], dst + (unsigned)(j * NWV) * 1024u);
-    };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue(cbeg);
-    f2 keep[P][2];                                                    // keeper: its own partial of the previous chunk
-    float4 cvs[P];                                                    //         and the centre values of that chunk
-#pragma unroll
-    for (int j = 0; j < P; ++j) { keep[j][0] = (f2){0.f, 0.f}; keep[j][1] = (f2){0.f, 0.f}; cvs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    for (int64_t c = cbeg; c <= cend; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's part of halo(c) (and the keeper's stores of chunk c-2)
-        __builtin_amdgcn_s_barrier();                                 // halo(c) complete; the partial sums of chunk c-1 complete
-        asm volatile("" ::: "memory");
-        if (c < cend) issue(c + 1);                                   // into the buffer of chunk c-1: everybody is done with it
-        const int cb_ = (int)((c - cbeg) & 1);
-        if (role == 3 && c > cbeg) {                                  // finish chunk c-1
-            const float4 *pb = part + (cb_ ^ 1) * PARTN;
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const int cv_ = cc[j] * TRp + cr[j], ci = cc[j] * TR + cr[j];
-                const float4 p0 = pb[cv_], p1 = pb[NCp + cv_], p2 = pb[2 * NCp + ci];
-                const float4 cv = cvs[j];
-                const float4 yo = make_float4(cv.x + dl[j] - ((p0.x + p1.x) + (p2.x + keep[j][0].x)), cv.y + dl[j] - ((p0.y + p1.y) + (p2.y + keep[j][0].y)),
-                                              cv.z + dl[j] - ((p0.z + p1.z) + (p2.z + keep[j][1].x)), cv.w + dl[j] - ((p0.w + p1.w) + (p2.w + keep[j][1].y)));
-                if (fv[j] && !(probe & 8)) st4_off(a.Ysig4 + (c - 1) * a.d, fmb[j] * 4u, yo);
-            }
-        }
-        if (c == cend) break;
-        const float4 *hb = halo + cb_ * NHs + hbase;
-        f2 acc[P][2];
-#pragma unroll
-        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
-        if (probe & 2) { }
-        else if (role == 0) arc_product<R, 0, P, HRp, NW, ARC_D>(hb, wp, acc);
-        else if (role == 1) arc_product<R, 1, P, HRp, NW, ARC_D>(hb, wp, acc);
-        else if (role == 2) arc_product<R, 2, P, HRp, NW, ARC_D>(hb, wp, acc);
-        else arc_product<R, 3, P, HRp, NW, ARC_D>(hb, wp, acc);
-        if (role == 3) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                keep[j][0] = acc[j][0]; keep[j][1] = acc[j][1];
-                cvs[j] = halo[cb_ * NHs + (cc[j] + R) * HRp + (cr[j] + R)];
-            }
-        } else {
-            float4 *pw = part + cb_ * PARTN;
-#pragma unroll
-            for (int j = 0; j < P; ++j)
-                pw[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + cc[j] * TR + cr[j]] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // partial sums written / centre values read before the next barrier
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// EXPERIMENT (option r1_arc_bias = B in 2..4, not the default, not yet measured): k_residual_arc_dma1 with UNEQUAL arcs (make_arcs<R, B>): roles 1 and 3, whose
-// waves share SIMDs 2 and 3 -- and of which role 3 also finishes the previous chunk -- hand corner offsets to roles 2 and 0.  Same LDS layout, same
-// barrier scheme; only the per-role offset counts (weights held as pairs, an odd count leaves the last .y at 0) and programs differ.
-template <int R, int ARC_D, int B>
-__global__ void __launch_bounds__(ARC_TR *ARC_TC, 2) k_residual_arc_dma1b(R1Args a) {
-    constexpr int P = 4;
-    constexpr int TR = ARC_TR, TC = ARC_TC, NC = TR * TC, NT = NC, NWV = NT / 64;
-    constexpr int HR = TR + 2 * R, HC = TC + 2 * R;
-    constexpr int HRp = ((HR + 14) / 16) * 16 + 1;
-    constexpr int NHp = HRp * HC;
-    constexpr int NIT = (NHp + NT - 1) / NT, NHs = NIT * NT;
-    using AC = ArcConst<R, B>;
-    constexpr int NA01 = AC::tab.n[0] > AC::tab.n[1] ? AC::tab.n[0] : AC::tab.n[1], NA23 = AC::tab.n[2] > AC::tab.n[3] ? AC::tab.n[2] : AC::tab.n[3];
-    constexpr int NA = NA01 > NA23 ? NA01 : NA23;                      // the longest arc sizes the weight registers
-    static_assert(AC::tab.n[0] + AC::tab.n[1] + AC::tab.n[2] + AC::tab.n[3] == RingConst<R>::tab.n, "the arcs must partition the ring");
-    constexpr int NW = (NA + 1) / 2;
-    constexpr int TRp = TR + 1, NCp = TRp * TC;
-    constexpr int NBUF = 2, PARTN = 2 * NCp + NC;                      // roles 0, 1 (column stride TR + 1), role 2
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];      // halo[2][NHs] | part[2][PARTN]
-    float4 *halo = lds, *part = lds + NBUF * NHs;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tmap = a.tile_map[blockIdx.x];
-    const int tile_r = tmap & 0xffff, tile_c = tmap >> 16;
-    const int hr0 = tile_r * TR + a.roff - R, hc0 = tile_c * TC + a.coff - R;
-    constexpr int TPR = NC / P;
-    const int role = __builtin_amdgcn_readfirstlane(tid / TPR), rt = tid % TPR;
-    int cr[P], cc[P];
-    int hbase;
-    if (role < 2) {
-        const int c = rt & 31, g = rt >> 5;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { cr[j] = g * P + j; cc[j] = c; }
-        hbase = c * HRp + g * P;
-    } else {
-        const int q = rt >> 4, i = rt & 15;
-        const int sq = (q * P * HRp) & 15;
-        const int r = (i - sq) & 15;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { cr[j] = r; cc[j] = q * P + j; }
-        hbase = q * P * HRp + r;
-    }
-    f2 wp[P][NW];
-    uint32_t fmb[P]; float dl[P]; bool fv[P];
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        const int pr = tile_r * TR + cr[j], pc = tile_c * TC + cc[j];
-        fv[j] = pr < a.nr && pc < a.nc;
-        const int64_t m = fv[j] ? (int64_t)pc * a.nr + pr : 0;
-        const uint32_t mb = (uint32_t)m * 4u;
-        fmb[j] = mb; dl[j] = ld_off(a.dlt, mb);
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            int i0 = -1, i1 = -1;                                      // -1: past the end of this role's arc
-            if (role == 0) { if (2 * k < AC::tab.n[0]) i0 = AC::tab.ring[0][2 * k]; if (2 * k + 1 < AC::tab.n[0]) i1 = AC::tab.ring[0][2 * k + 1]; }
-            else if (role == 1) { if (2 * k < AC::tab.n[1]) i0 = AC::tab.ring[1][2 * k]; if (2 * k + 1 < AC::tab.n[1]) i1 = AC::tab.ring[1][2 * k + 1]; }
-            else if (role == 2) { if (2 * k < AC::tab.n[2]) i0 = AC::tab.ring[2][2 * k]; if (2 * k + 1 < AC::tab.n[2]) i1 = AC::tab.ring[2][2 * k + 1]; }
-            else { if (2 * k < AC::tab.n[3]) i0 = AC::tab.ring[3][2 * k]; if (2 * k + 1 < AC::tab.n[3]) i1 = AC::tab.ring[3][2 * k + 1]; }
-            wp[j][k].x = i0 >= 0 ? ld_off(a.W + (int64_t)i0 * a.d, mb) : 0.f;
-            wp[j][k].y = i1 >= 0 ? ld_off(a.W + (int64_t)i1 * a.d, mb) : 0.f;
-        }
-    }
-    uint32_t qoff[NIT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int idx = (j * NWV + wave) * 64 + lane;
-        const int hr = idx % HRp, hc = idx / HRp;
-        int rb = hr0 + hr, cb = hc0 + (hc < HC ? hc : HC - 1);
-        rb = rb < 0 ? 0 : (rb >= a.nr_b ? a.nr_b - 1 : rb);
-        cb = cb < 0 ? 0 : (cb >= a.nc_b ? a.nc_b - 1 : cb);
-        qoff[j] = (uint32_t)(cb * a.nr_b + rb) * 16u;
-    }
-    const unsigned ldsA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds;
-    const unsigned lds0 = ldsA + (unsigned)wave * 1024u;
-    const int64_t cbeg = ((int64_t)blockIdx.y * a.tseg) >> 2;
-    const int64_t tend = (int64_t)blockIdx.y * a.tseg + a.tseg < a.T ? (int64_t)blockIdx.y * a.tseg + a.tseg : a.T;
-    const int64_t cend = (tend + 3) >> 2;
-    const int probe = __builtin_amdgcn_readfirstlane(a.probe);
-    auto issue = [&](int64_t c) {
-        if ((probe & 1) && c > cbeg + 1) return;
-        const int64_t cx = c < cend ? c : cend - 1;
-        const float4 *y4 = a.Y4 + cx * a.d_b;
-        const int b = (int)((c - cbeg) & 1);
-        const unsigned dst = lds0 + (unsigned)b * (unsigned)(NHs * 16);
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) glds16(y4, qoff[j], dst + (unsigned)(j * NWV) * 1024u);
-    };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue(cbeg);
-    f2 keep[P][2];                                                    // keeper: its own partial of the previous chunk
-    float4 cvs[P];                                                    //         and the centre values of that chunk
-#pragma unroll
-    for (int j = 0; j < P; ++j) { keep[j][0] = (f2){0.f, 0.f}; keep[j][1] = (f2){0.f, 0.f}; cvs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    for (int64_t c = cbeg; c <= cend; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's part of halo(c) (and the keeper's stores of chunk c-2)
-        __builtin_amdgcn_s_barrier();                                 // halo(c) complete; the partial sums of chunk c-1 complete
-        asm volatile("" ::: "memory");
-        if (c < cend) issue(c + 1);                                   // into the buffer of chunk c-1: everybody is done with it
-        const int cb_ = (int)((c - cbeg) & 1);
-        if (role == 3 && c > cbeg) {                                  // finish chunk c-1
-            const float4 *pb = part + (cb_ ^ 1) * PARTN;
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const int cv_ = cc[j] * TRp + cr[j], ci = cc[j] * TR + cr[j];
-                const float4 p0 = pb[cv_], p1 = pb[NCp + cv_], p2 = pb[2 * NCp + ci];
-                const float4 cv = cvs[j];
-                const float4 yo = make_float4(cv.x + dl[j] - ((p0.x + p1.x) + (p2.x + keep[j][0].x)), cv.y + dl[j] - ((p0.y + p1.y) + (p2.y + keep[j][0].y)),
-                                              cv.z + dl[j] - ((p0.z + p1.z) + (p2.z + keep[j][1].x)), cv.w + dl[j] - ((p0.w + p1.w) + (p2.w + keep[j][1].y)));
-                if (fv[j] && !(probe & 8)) st4_off(a.Ysig4 + (c - 1) * a.d, fmb[j] * 4u, yo);
-            }
-        }
-        if (c == cend) break;
-        const float4 *hb = halo + cb_ * NHs + hbase;
-        f2 acc[P][2];
-#pragma unroll
-        for (int j = 0; j < P; ++j) { acc[j][0] = (f2){0.f, 0.f}; acc[j][1] = (f2){0.f, 0.f}; }
-        if (probe & 2) { }
-        else if (role == 0) arc_product<R, 0, P, HRp, NW, ARC_D, B>(hb, wp, acc);
-        else if (role == 1) arc_product<R, 1, P, HRp, NW, ARC_D, B>(hb, wp, acc);
-        else if (role == 2) arc_product<R, 2, P, HRp, NW, ARC_D, B>(hb, wp, acc);
-        else arc_product<R, 3, P, HRp, NW, ARC_D, B>(hb, wp, acc);
-        if (role == 3) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                keep[j][0] = acc[j][0]; keep[j][1] = acc[j][1];
-                cvs[j] = halo[cb_ * NHs + (cc[j] + R) * HRp + (cr[j] + R)];
-            }
-        } else {
-            float4 *pw = part + cb_ * PARTN;
-#pragma unroll
-            for (int j = 0; j < P; ++j)
-                pw[role < 2 ? role * NCp + cc[j] * TRp + cr[j] : 2 * NCp + cc[j] * TR + cr[j]] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // partial sums written / centre values read before the next barrier
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int R>
-static int launch_r1_arc_dma1(cnmfe_ctx *ctx, const R1Args &a, int ntile_c, int64_t nseg) {
-    constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1, NT = ARC_TR * ARC_TC;
-    constexpr int NIT = (HRp * HC + NT - 1) / NT;
-    constexpr size_t shmem = (2 * (size_t)NIT * NT + 2 * (2 * (size_t)(ARC_TR + 1) * ARC_TC + (size_t)ARC_TR * ARC_TC)) * sizeof(float4);
-    static_assert(shmem <= 160 * 1024, "arc DMA kernel (one barrier) exceeds LDS");
-    static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
-    dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
-    const int arcd = (int)ctx->opt("r1_arc_d", 4);                     // LDS reads in flight ahead of their FMAs (experiments: 6, 8)
-    const int bias = (int)ctx->opt("r1_arc_bias", 0);                  // experiment: unequal arcs (k_residual_arc_dma1b): 2, 3, 4, 5 (7 spills: 240 VGPRs + scratch)
-    if (bias == 2) {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 2>), grid, dim3(NT), shmem, a);
-    } else if (bias == 3) {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 3>), grid, dim3(NT), shmem, a);
-    } else if (bias == 4) {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 4>), grid, dim3(NT), shmem, a);
-    } else if (bias == 5) {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1b<R, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1b<R, 4, 5>), grid, dim3(NT), shmem, a);
-    } else if (arcd == 6) {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R, 6>), grid, dim3(NT), shmem, a);
-    } else if (arcd == 8) {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R, 8>), grid, dim3(NT), shmem, a);
-    } else {
-        CK(hipFuncSetAttribute((const void *)k_residual_arc_dma1<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma1<R>), grid, dim3(NT), shmem, a);
-    }
-    return 0;
-}
-
 template <int R>
 static int launch_r1_arc_dma(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
     constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1, NT = ARC_TR * ARC_TC;
@@ -828,21 +359,6 @@ static int launch_r1_arc_dma(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int n
     CK(hipFuncSetAttribute((const void *)k_residual_arc_dma<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_arc_dma<R, true>), grid, dim3(NT), shmem, a);
     else        LAUNCH(ctx, "residual_r1", (k_residual_arc_dma<R, false>), grid, dim3(NT), shmem, a);
-    return 0;
-}
-
-template <int R, int P, int ABL = 0, int PD = 1>
-static int launch_r1_arc(cnmfe_ctx *ctx, const R1Args &a, bool has_ac, int ntile_c, int64_t nseg) {
-    constexpr int HR = ARC_TR + 2 * R, HC = ARC_TC + 2 * R, HRp = ((HR + 14) / 16) * 16 + 1;
-    constexpr size_t shmem = (2 * (size_t)HRp * HC + 2 * (size_t)(ARC_TR + 1) * ARC_TC + 2 * (size_t)ARC_TR * ARC_TC) * sizeof(float4);
-    static_assert(shmem <= 160 * 1024, "arc kernel exceeds LDS");
-    static_assert(((HC + R) * HRp + HR) * 16 < 65536, "ds_read immediate offset overflow");
-    constexpr int NT = 4 * ARC_TR * ARC_TC / P;
-    dim3 grid((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
-    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, true, ABL, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CK(hipFuncSetAttribute((const void *)k_residual_arc<R, P, false, ABL, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    if (has_ac) LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, true, ABL, PD>), grid, dim3(NT), shmem, a);
-    else        LAUNCH(ctx, "residual_r1", (k_residual_arc<R, P, false, ABL, PD>), grid, dim3(NT), shmem, a);
     return 0;
 }
 
