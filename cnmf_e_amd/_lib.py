@@ -98,6 +98,7 @@ PROTOTYPES = {
     "cnmfe_deconv_temporal": (C.c_int, [c_ctx, C.c_int32, C.c_int64, f32p, C.c_int, C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p]),
     "cnmfe_post_process_spatial": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, f32p, u8p]),
     "cnmfe_stitch_begin": (C.c_int, [c_ctx, C.c_int32, C.c_int64]),
+    "cnmfe_stitch_dims": (C.c_int, [c_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "cnmfe_stitch_add": (C.c_int, [c_ctx, C.c_int32, i32p]),
     "cnmfe_stitch_buffer": (C.c_int, [c_ctx, C.POINTER(f32p), i64p]),
     "cnmfe_stitch_finish": (C.c_int, [c_ctx, C.c_int, f32p, C.c_int]),

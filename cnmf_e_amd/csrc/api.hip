@@ -843,6 +843,13 @@ int cnmfe_stitch_finish_async(cnmfe_ctx *ctx, int subtract_min, float *C_raw_pin
     return stitch_finish_one(ctx, subtract_min, C_raw_pinned, CNMFE_ROWMAJOR, true);
 }
 
+int cnmfe_stitch_dims(cnmfe_ctx *ctx, int32_t *K, int64_t *T) {
+    if (!ctx || !K || !T) return fail(CNMFE_EINVAL, "null context / K / T");
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
+    *K = ctx->stitch_K; *T = ctx->stitch_T;
+    return 0;
+}
+
 int cnmfe_stitch_wait(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     if (ctx->ev_copy_done && ctx->copy_stream) CK(hipStreamSynchronize(ctx->copy_stream));
@@ -900,6 +907,7 @@ int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int 
     if (c_order != CNMFE_ROWMAJOR && c_order != CNMFE_COLMAJOR) return fail(CNMFE_EINVAL, "bad c_order");
     CK(hipSetDevice(ctx->device));
     int64_t ldc;
+    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // a lazy download may still read `bound` (as stitch_finish_one)
     RET(upload_traces(ctx, ctx->bound, C, K, T, c_order, &ldc));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = c_order; ctx->bound_valid = true;

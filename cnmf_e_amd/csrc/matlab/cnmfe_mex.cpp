@@ -138,6 +138,11 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         const double *hv = mxGetPr(pin[1]);
         for (int i = 0; i < n; ++i) { const int k = (int)hv[i]; if (k < 1 || k > g_nctx || !g_ctx[k - 1]) FAIL("invalid context handle"); cs[i] = g_ctx[k - 1]; }
         const size_t K = (size_t)mxGetScalar(pin[3]), T = (size_t)mxGetScalar(pin[4]);
+        for (int i = 0; i < n; ++i) {                            // the engine writes stitch_K x stitch_T floats: the output is sized from ITS record, the caller's K, T are only checked
+            int32_t Ks = 0; int64_t Ts = 0;
+            CHECK(cnmfe_stitch_dims(cs[i], &Ks, &Ts));
+            if ((size_t)Ks != K || (size_t)Ts != T) FAIL("stitch_temporal: K x T = %d x %d, but context %d accumulates %d x %d (stitch_begin)", (int)K, (int)T, i + 1, (int)Ks, (int)Ts);
+        }
         pout[0] = mxCreateNumericMatrix(K, T, mxSINGLE_CLASS, mxREAL);
         CHECK(cnmfe_stitch_temporal(cs, n, mxGetScalar(pin[2]) != 0, nout > 0 ? (float *)mxGetData(pout[0]) : NULL, CNMFE_COLMAJOR));
         return;

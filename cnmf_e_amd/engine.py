@@ -94,27 +94,63 @@ class DeviceTraces:
         return self.tensor.data_ptr()
 
 
+class _PinnedBlock:
+    """Owner of one pinned host buffer of a LazyHostTraces.  The ctypes array every ndarray view of the buffer is built on holds the only strong
+    reference to this object, so the block goes back to the engine's pool -- or is freed, once the engine is closed or gone -- when the LAST view
+    dies: an array taken from `s.C` (np.asarray, a slice, .T) stays valid for as long as somebody holds it, whatever happens to `s` or the engine."""
+    def __init__(self, eng, nbytes):
+        import weakref
+        self.eng = weakref.ref(eng); self.nbytes = nbytes; self.ready = False
+        self.ptr = eng._pinned_take(nbytes)
+    def wait(self):
+        if not self.ready:
+            eng = self.eng()
+            if eng is not None and getattr(eng, "_ctx", None):
+                L.check(L.lib.cnmfe_stitch_wait(eng._ctx))       # cnmfe_destroy drains the copy stream itself
+            self.ready = True
+    def __del__(self):
+        try:
+            eng = self.eng()
+            if eng is not None and getattr(eng, "_ctx", None):
+                if not self.ready:
+                    L.lib.cnmfe_stitch_wait(eng._ctx)            # the copy may still be writing into the buffer
+                eng._pinned_give(self.ptr, self.nbytes)
+            else:
+                L.lib.cnmfe_host_free(self.ptr)
+        except Exception:
+            pass
+
+
 class LazyHostTraces:
     """The K x T result of the temporal update as the host sees it: the engine keeps the matrix bound on the device (that is what the next
     background / spatial / temporal calls read) and streams a copy into pinned host memory on a second stream; the first time somebody
     READS the values (np.asarray, indexing, mean) this object waits for that copy -- never for the compute stream.  Identity of the bound
-    matrix like any array returned by stitch_finish."""
+    matrix like any array returned by stitch_finish.  Arrays handed out are views of the pinned buffer and keep it alive (_PinnedBlock);
+    np.array(x) / x.copy() / x.astype(...) are copies as for an ndarray."""
     def __init__(self, eng, K, T):
         self._eng = eng
         self.shape = (int(K), int(T)); self.dtype = np.dtype(np.float32); self.ndim = 2
         self.flags = {"C_CONTIGUOUS": True}
-        self._nbytes = max(1, K * T) * 4
-        self._ptr = eng._pinned_take(self._nbytes)
-        self._arr = np.ctypeslib.as_array(C.cast(self._ptr, L.f32p), shape=(max(1, K * T),))[:K * T].reshape(K, T)
-        self._ready = False
+        n = max(1, K * T)
+        blk = _PinnedBlock(eng, n * 4)
+        buf = (C.c_float * n).from_address(blk.ptr)
+        buf._owner = blk                                  # buf <- memoryview <- ndarray (and every view of it): the block lives as long as they do
+        self._ptr = blk.ptr
+        self._blk = __import__("weakref").ref(blk)
+        self._arr = np.frombuffer(buf, dtype=np.float32, count=K * T).reshape(K, T)
+    @property
+    def _ready(self):
+        return self._blk().ready
     def host(self):
-        if not self._ready:
-            L.check(L.lib.cnmfe_stitch_wait(self._eng._ctx))
-            self._ready = True
+        self._blk().wait()
         return self._arr
     def __array__(self, dtype=None, copy=None):
         a = self.host()
-        return a if dtype is None else a.astype(dtype, copy=False)
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            if copy is False:
+                raise ValueError("a float32 trace matrix cannot be viewed as %s without a copy" % np.dtype(dtype))
+            return a.astype(dtype)
+        return a.copy() if copy else a
     def __getitem__(self, key):
         return self.host()[key]
     def __len__(self):
@@ -129,13 +165,6 @@ class LazyHostTraces:
         if name.startswith("_"):
             raise AttributeError(name)
         return getattr(self.host(), name)
-    def __del__(self):
-        try:
-            if not self._ready:
-                L.lib.cnmfe_stitch_wait(self._eng._ctx)          # the copy may still be writing into the buffer
-            self._eng._pinned_give(self._ptr, self._nbytes)
-        except Exception:
-            pass
 
 
 for _op in ("add", "sub", "mul", "truediv", "radd", "rsub", "rmul", "rtruediv", "lt", "le", "gt", "ge", "eq", "ne", "neg", "abs", "matmul", "rmatmul"):

@@ -79,8 +79,20 @@ def lib():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     L.iter_cb = ctypes.CFUNCTYPE(ctypes.c_int, _hid, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p)
-    L.H5Literate.restype = I
-    L.H5Literate.argtypes = [_hid, I, I, P, L.iter_cb, P]
+    # from libhdf5 1.12 on H5Literate is a macro: the library exports H5Literate1 (this callback signature) and H5Literate2 (H5L_info2_t, which
+    # the callback never looks at) instead
+    it = None
+    for name in ("H5Literate", "H5Literate1", "H5Literate2"):
+        try:
+            it = getattr(L, name)
+            break
+        except AttributeError:
+            continue
+    if it is None:
+        raise RuntimeError("libhdf5 %d.%d.%d exports none of H5Literate, H5Literate1, H5Literate2" % L.version)
+    it.restype = I
+    it.argtypes = [_hid, I, I, P, L.iter_cb, P]
+    L.iterate = it
     L.H5Eset_auto2(0, None, None)                                         # errors come back as return codes and are raised below, not printed
     _L = L
     return L
@@ -135,7 +147,7 @@ class H5File:
             out.append(name.decode())
             return 0
         keep = self.L.iter_cb(cb)
-        if self.L.H5Literate(self.fid, 0, 0, None, keep, None) < 0:        # H5_INDEX_NAME, H5_ITER_INC
+        if self.L.iterate(self.fid, 0, 0, None, keep, None) < 0:        # H5_INDEX_NAME, H5_ITER_INC
             raise OSError("cannot list %s" % self.path)
         return out
 

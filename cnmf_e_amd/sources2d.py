@@ -431,6 +431,9 @@ def mat_data_info(f):
 # --------------------------------------------------------------------------------------
 # Sources2D
 # --------------------------------------------------------------------------------------
+_UNSET = object()
+
+
 class Sources2D:
     """State and the three update methods of the reference's handle class (Sources2D.m:10-57):
     A (d x K sparse), A_prev, C, C_prev, C_raw (K x T), W{.}/b0{.} (resident on the GPU per patch,
@@ -771,6 +774,9 @@ class Sources2D:
         rows, cols, vals = [], [], []
         whole_result = whole_pp = None
         IND = None
+        se_now = o.se                                                      # :56 copies the options, :63-65 clears obj.options.se: once per update, here
+        if o.search_method == "dilate":
+            o.se = None
 
         def prev_of(idx):
             # A_prev restricted to neurons that touch the HALO only (mask==1 after the patch is set to 2, :84-85,96)
@@ -797,7 +803,7 @@ class Sources2D:
                 # the kernel in flight) and build IND (:66) on the host underneath it
                 A_prev_b, C_prev_b = prev_of(idx)
                 self._residual(idx, A_prev_b, C_prev_b)
-                IND = self._search_location_csc()
+                IND = self._search_location_csc(se_now)
                 ind, IND_patch, A_patch, C_patch = masks_of(idx)
             else:
                 (A_prev_b, C_prev_b), (ind, IND_patch, A_patch, C_patch) = ahead
@@ -894,14 +900,14 @@ class Sources2D:
         M.sort_indices()
         return M
 
-    def _search_location_csc(self):
+    def _search_location_csc(self, se=_UNSET):
         fut = getattr(self, "_ind_future", None)
         self._ind_future = None
         if fut is not None and fut[0] is self.A:
             return fut[1].result()
-        return self._as_mask_csc(self._search_location_owned())
+        return self._as_mask_csc(self._search_location_owned(se=se))
 
-    def _search_location_owned(self, A=None):
+    def _search_location_owned(self, A=None, se=_UNSET):
         """IND = determine_search_location(obj.A, ...) (:66), evaluated only for the neurons that can reach a patch
         this rank owns (bounding box of the footprint grown by the largest possible ellipse); all other columns are
         empty here and belong to other ranks.  Single rank: every neuron."""
@@ -909,10 +915,11 @@ class Sources2D:
         A = self.A if A is None else A
         K = A.shape[1]
         if o.search_method == "dilate":
-            # update_spatial_parallel.m:56 copies the options BEFORE :63-65 clears obj.options.se: this call still uses the old element and
-            # the next one strel('disk', bSiz, 0) (determine_search_location.m:42-44).  Host work on every rank (off in every demo).
+            # update_spatial_parallel.m:56 copies the options BEFORE :63-65 clears obj.options.se: an update uses the element it finds and the
+            # next one strel('disk', bSiz, 0) (determine_search_location.m:42-44).  The element is only READ here (prefetches and measurement
+            # helpers call this too); update_spatial_parallel clears it once per update.  Host work on every rank (off in every demo).
             from . import hostops
-            se, o.se = o.se, None
+            se = o.se if se is _UNSET else se
             se = hostops.strel_disk(4) if isinstance(se, str) else hostops.strel_disk(o.bSiz) if se is None else se
             return hostops.search_location_dilate(A, v.d1, v.d2, se, o.nb, o.nrgthr)
         if v.world_size == 1:

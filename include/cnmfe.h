@@ -256,6 +256,7 @@ int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, in
 int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T);
 int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m);
 int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld);
+int cnmfe_stitch_dims(cnmfe_ctx *ctx, int32_t *K, int64_t *T);   /* the K x T recorded by cnmfe_stitch_begin (CNMFE_ESTATE if no stitch is open): a gateway sizes C_raw_out from these, not from its caller */
 int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order);
 int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order);
 /* cnmfe_stitch_finish without the wait: the host copy (row-major K x T) is written by a second stream into PINNED memory (cnmfe_host_alloc) and is

@@ -357,3 +357,55 @@ def test_sparse_row_selection_matches_scipy_on_random_matrices():
         assert np.array_equal(ind, want) and (want.size == 0 or abs(M - sub[:, want]).max() == 0)
     with pytest.raises(ValueError):
         rows_of(A, t, n, cols=np.array([2, 1]))
+
+
+def test_lazy_host_traces_views_keep_the_pinned_block(monkeypatch):
+    """arrays taken from a LazyHostTraces are views of a pooled pinned buffer.  The buffer must not go back to the pool (or be
+    freed) while any view lives, np.array(x) must be a copy, and a closed engine must not free a block that still has views."""
+    import ctypes as C, gc
+    from cnmf_e_amd import engine as E
+    libc = C.CDLL(None); libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
+
+    class StubLib:
+        freed = []
+        def cnmfe_stitch_wait(self, ctx): return 0
+        def cnmfe_host_free(self, p): StubLib.freed.append(p)
+
+    class StubL:
+        lib = StubLib(); f32p = E.L.f32p; CnmfeError = RuntimeError
+        @staticmethod
+        def check(rc): assert rc == 0
+
+    monkeypatch.setattr(E, "L", StubL)
+
+    class Eng:
+        _ctx = 1
+        def __init__(self): self.pool = []; self.given = []
+        def _pinned_take(self, n): return self.pool.pop() if self.pool else libc.malloc(n)
+        def _pinned_give(self, p, n): self.given.append(p); self.pool.append(p)
+
+    eng = Eng()
+    lz = E.LazyHostTraces(eng, 3, 4)
+    p0 = lz._ptr
+    lz._arr[:] = 7.0                                    # what the copy stream would have written
+    view = np.asarray(lz); tr = lz.T; row = lz[1]
+    cp = np.array(lz); cp2 = np.asarray(lz, dtype=np.float64)
+    assert not np.shares_memory(cp, view) and cp2.dtype == np.float64 and np.shares_memory(view, tr) and np.shares_memory(view, row)
+    del lz; gc.collect()
+    assert eng.given == []                              # three views alive: the block stays out of the pool
+    lz2 = E.LazyHostTraces(eng, 3, 4)                   # the next temporal update gets a DIFFERENT buffer
+    assert lz2._ptr != p0
+    lz2._arr[:] = 9.0
+    assert (view == 7).all() and (tr == 7).all() and (row == 7).all() and (cp == 7).all()
+    del view, tr; gc.collect()
+    assert eng.given == []
+    del row; gc.collect()
+    assert eng.given == [p0]                            # last view gone: back to the pool
+    keep = np.asarray(lz2)
+    eng._ctx = None                                     # Engine.close()
+    del lz2; gc.collect()
+    assert StubLib.freed == [] and (keep == 9).all()    # closed engine, live view: not freed
+    del keep; gc.collect()
+    assert len(StubLib.freed) == 1
+    for p in eng.pool:
+        libc.free(p)
