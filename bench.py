@@ -11,12 +11,20 @@ fixed); spatial rows are all-gathered, the temporal update does one RCCL all-red
 --weak: the round-1 grown-FOV mode (512 x 512N, one 512x512 patch and 500 neurons per rank; value = patch-iterations/s).
 --demo-sequence: the calls demo_large_data_1p.m:142-211 makes on this path, from a fresh upload, as seconds per recording.
 
+`python bench.py --gpus N` without a launcher's WORLD_SIZE spawns the N ranks itself (one per GPU, nccl = RCCL; it refuses to run when fewer than
+N GPUs are visible); under `python -m torch.distributed.run` it takes RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+At N = 1 the default run also times configs[3] (`c4`: the same video as 16 patches on this one GPU) in a child process and reports it as `c4_n1`,
+the N = 1 point of the strong-scaling curve the N > 1 runs continue.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -39,9 +47,22 @@ F32_MFMA_PEAK_TF = 157.3
 BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); the split-bf16 Gram issues 4 bf16 products per fp32-equivalent product
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The float64 NumPy restatement of the reference (oracle/, 'port') timed on a bounded sample of the
-    same workload and scaled by the d*T work ratio to the headline size."""
+def _blas_info():
+    try:
+        import threadpoolctl
+        info = threadpoolctl.threadpool_info()
+        thr = max([p.get("num_threads", 1) for p in info] or [1])
+        blas = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in info if p.get("user_api") == "blas"})) or "unknown BLAS"
+    except Exception:
+        thr, blas = os.cpu_count() or 1, "unknown BLAS"
+    return int(thr), blas
+
+
+def cpu_baseline():
+    """The float64 NumPy restatement of the reference (oracle/, 'port': NOT MATLAB) timed on a bounded sample of the same workload: one full
+    iteration at 128 x 128 x 3000 with the headline's neuron density, scaled by the d*T work ratio.  K-dependent terms (the dense Y*C', A*C of
+    the reference) do not scale by d*T alone -- `python bench.py --cpu-baseline full` times C2 in full and C3 as BASELINE.md section 3 lays out;
+    its committed result (profiles/r03/cpu_baseline_full.json) is quoted beside this number when present."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnmfe_oracle as orc
     from cnmf_e_amd import synth
@@ -55,14 +76,87 @@ def cpu_baseline(seconds_budget=30.0):
     o.update_background_parallel(); o.update_spatial_parallel(); o.update_temporal_parallel()
     dt = time.time() - t0
     scale = (512.0 * 512.0 * 10000.0) / (d1 * d2 * T)
-    try:
-        import threadpoolctl
-        thr = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        thr = os.cpu_count() or 1
-    return {"value": 1.0 / (dt * scale), "unit": "iter/s (512x512x10000-equivalent)", "cores": int(thr), "kind": "port",
-            "sample": "one full iteration of the float64 NumPy restatement (oracle/cnmfe_oracle.py, not MATLAB) on %dx%dx%d, K=%d, r=%d "
-                      "took %.2f s; scaled by the d*T work ratio %.1f to 512x512x10000" % (d1, d2, T, K, r, dt, scale)}
+    thr, blas = _blas_info()
+    out = {"value": 1.0 / (dt * scale), "unit": "iter/s (512x512x10000-equivalent)", "cores": thr, "kind": "port", "blas": blas, "host_cpus": os.cpu_count(),
+           "sample": "one full iteration of the float64 NumPy restatement (oracle/cnmfe_oracle.py, not MATLAB) on %dx%dx%d, K=%d, r=%d "
+                     "took %.2f s; scaled by the d*T work ratio %.1f to 512x512x10000" % (d1, d2, T, K, r, dt, scale)}
+    full = os.path.join(ROOT, "profiles", "r03", "cpu_baseline_full.json")
+    if os.path.exists(full):
+        try:
+            out["full_run"] = dict(json.load(open(full)), source="profiles/r03/cpu_baseline_full.json (an earlier run of `bench.py --cpu-baseline full`, not this run)")
+        except Exception:
+            pass
+    return out
+
+
+def cpu_baseline_full(which=("c2", "c3")):
+    """the float64 NumPy restatement ('CPU restatement, not MATLAB') at full size on this host's cores.
+    C2 (256x256x3000, K=200): one iteration timed in full.  C3 (512x512x10000, K=500): spatial + temporal updates in full, the background
+    regression (fit_ring_model.m:92-108, an interpreted loop over 262144 pixels) on a fixed 1/64 pixel sample and scaled x64 -- an extrapolation,
+    stated as such.  Minutes of host work and ~70 GB of host memory for C3: run once, commit the JSON."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cnmfe_oracle as orc
+    from cnmf_e_amd import synth
+    thr, blas = _blas_info()
+    res = {"kind": "port", "what": "CPU restatement (not MATLAB): oracle/cnmfe_oracle.py, float64 NumPy/SciPy", "cores": thr, "blas": blas, "host_cpus": os.cpu_count()}
+    for name in which:
+        d1, d2, T, K, r, seed = CONFIGS[name]
+        f = synth.make_factors(d1, d2, T, K, seed)
+        Y = synth.make_video(f, np.float32)
+        o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [d1, d2], r, f.A_init.astype(np.float32), f.C_init, f.sn,
+                                spatial_algorithm="hals", maxIter=5)
+        del Y
+        t = {}
+        t0 = time.time()
+        if name == "c3":
+            rows = np.arange(0, d1 * d2, 64)                   # fixed 1/64 pixel sample of the per-pixel regressions
+            o.bg_only_rows = rows
+            o.update_background_parallel()
+            t["background_sampled_s"] = time.time() - t0
+            # the part of the call that does not scale with the sample (Bf, b0) is in the timed number too; the loop dominates: state both
+            t["background_extrapolated_s"] = t["background_sampled_s"] * 64.0
+            t["background_note"] = "regression loop on %d of %d pixels (every 64th), whole call time x 64 (upper bound: the Bf set-up is counted 64 times)" % (rows.size, d1 * d2)
+        else:
+            o.update_background_parallel()
+            t["background_s"] = time.time() - t0
+        t1 = time.time(); o.update_spatial_parallel(); t["spatial_s"] = time.time() - t1
+        t2 = time.time(); o.update_temporal_parallel(); t["temporal_s"] = time.time() - t2
+        total = t.get("background_s", t.get("background_extrapolated_s")) + t["spatial_s"] + t["temporal_s"]
+        t["iteration_s"] = total; t["iter_per_s"] = 1.0 / total
+        t["workload"] = "%s: %dx%dx%d, K=%d, r=%d, 1 patch, seed %d, deconv_flag=false" % (name, d1, d2, T, K, r, seed)
+        res[name] = t
+        del o
+    return res
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher: start the N ranks here (one per GPU, RANK = LOCAL_RANK, rendezvous on 127.0.0.1) and relay
+    rank 0's line.  Refuses when fewer than N GPUs are visible -- N ranks on fewer devices is not the run that was asked for."""
+    import socket
+    one_dev = os.environ.get("CNMFE_BENCH_ONE_DEVICE", "0") == "1" or os.environ.get("CNMFE_BENCH_DRY", "0") == "1"
+    if not one_dev:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node (no WORLD_SIZE in the environment, so the ranks would be spawned here)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (n, rcs))
+    lines = [l for l in out.decode().splitlines() if l.lstrip().startswith("{")]     # (gloo / RCCL banners may share rank 0's stdout)
+    if not lines:
+        raise SystemExit("bench.py --gpus %d: rank 0 printed no JSON line" % n)
+    print(lines[-1], flush=True)
 
 
 def main():
@@ -76,30 +170,52 @@ def main():
     ap.add_argument("--alg", default="hals", help="spatial algorithm: hals | hals_thresh | nnls")
     ap.add_argument("--deconv", action="store_true", help="deconv_flag=true (OASIS AR(1) FOOPSI inside the temporal sweep); reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="short", help="short (default: bounded sample, scaled) | full (BASELINE.md section 3: C2 in full, C3 with a 1/64 "
+                                                            "pixel sample of the background regression; minutes of host work, no GPU step) | none")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c4_n1 child run and the in-run PMC traffic passes (what the child runs pass)")
     ap.add_argument("--bg-ssub", type=int, default=1, help="options.bg_ssub (the shipped demo uses 2; the headline metric is quoted at 1)")
     a = ap.parse_args()
+    if a.cpu_baseline == "full":
+        print(json.dumps(cpu_baseline_full()))
+        return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus, sys.argv[1:])
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     # test hook for a 1-GPU box: CNMFE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two ranks
     # on one device); the driver's multi-GPU runs leave it unset and get one rank per GPU over nccl (= RCCL)
     one_dev = os.environ.get("CNMFE_BENCH_ONE_DEVICE", "0") == "1"
     if one_dev:
         local = 0
-    torch.cuda.set_device(local)
+    dry = os.environ.get("CNMFE_BENCH_DRY", "0") == "1"
+    if not dry:
+        torch.cuda.set_device(local)
     group = None
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if one_dev:
+        if one_dev or (dry and not torch.cuda.is_available()):
+            one_dev = True
             td.init_process_group(backend="gloo")
         else:
             td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         group = td.group.WORLD
+        if os.environ.get("CNMFE_BENCH_DRY", "0") == "1":        # launcher test (no GPU work): rendezvous + one collective, then the line
+            t_ = torch.ones(1) if one_dev else torch.ones(1, device="cuda")
+            td.all_reduce(t_)
+            if rank == 0:
+                print(json.dumps({"dry": True, "rccl_ranks": td.get_world_size(group), "backend": td.get_backend(group), "sum": float(t_.item())}))
+            td.destroy_process_group()
+            return
+    comm = {"rccl_ranks": 1, "backend": None}
+    if group is not None:
+        import torch.distributed as td
+        comm = {"rccl_ranks": int(td.get_world_size(group)), "backend": str(td.get_backend(group))}
 
     from cnmf_e_amd import synth
     from cnmf_e_amd.engine import Engine
@@ -161,11 +277,12 @@ def main():
         eng.close()
         return
     fence()
-    tw0 = time.perf_counter()
-    for _ in range(a.warmup):
+    warm_steps_ms = []
+    for _ in range(a.warmup):                                   # every warm-up step fenced and timed on its own: the FIRST one is the cold iteration
+        tw0 = time.perf_counter()
         step()
-    fence()
-    warm_ms = 1e3 * (time.perf_counter() - tw0) / max(1, a.warmup)
+        fence()
+        warm_steps_ms.append(1e3 * (time.perf_counter() - tw0))
     warm_tab = eng.profile_table()
     # timed region: HIP events only around the kernels a roofline is quoted for (an event pair around EVERY launch costs host and device time per
     # launch -- 8 ms per iteration with the ~2000 small launches of c4, ~1 % at c3); the per-kernel breakdown comes from EXTRA steps after it
@@ -244,6 +361,34 @@ def main():
                 "algorithmic_flops_per_launch": flops_alg,
                 "note": "algorithmic = the block-pair covariance table (each needed covariance once: 2*d*(p+1)^2*T/2 / 2.58 fp32-equivalent flops; the reference's "
                         "per-pixel Gram would be %.3g).  With the incremental table this kernel runs once per patch, not per iteration -- DESIGN.md" % flops_ref}
+    def pmc_traffic_live():
+        """Fabric-side bytes of ONE launch of the R1 kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
+        pass; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over scripts/r1_only.py, which uploads the same synthetic video and launches
+        the same kernel on this GPU.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes).  None if rocprofv3 is missing or fails."""
+        if a.no_extras or a.config != "c3" or world != 1 or a.bg_ssub != 1 or os.environ.get("CNMFE_BENCH_PMC", "1") == "0" or not shutil.which("rocprofv3"):
+            return None
+        import csv, glob
+        tot = {}
+        for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            tmp = tempfile.mkdtemp(prefix="cnmfe_pmc_", dir="/tmp")
+            try:
+                subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "x", "--",
+                                sys.executable, os.path.join(ROOT, "scripts", "r1_only.py"), "--variant", "14", "--reps", "2"],
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                vals = []
+                for fn in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                    for r_ in csv.DictReader(open(fn)):
+                        if "k_residual" in r_["Kernel_Name"] and "delta" not in r_["Kernel_Name"] and r_["Counter_Name"] == counter:
+                            vals.append(float(r_["Counter_Value"]))
+                if not vals:
+                    return None
+                tot[counter] = mult * 1024.0 * vals[-1]          # the counters are in KiB; the last launch (the first one also faults the pages in)
+            except Exception:
+                return None
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        return tot
+
     def pmc_traffic(kernel_substr, exclude=None):
         """HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of THIS command (profiles/<round>/
         *_pmc_FETCH_SIZE_*.csv, *_pmc_WRITE_SIZE_*.csv; separate passes, scripts/profile_round.sh).  FETCH_SIZE is
@@ -305,9 +450,16 @@ def main():
         roof["traffic"] = pmc_traffic("k_ring_solve")
     r1r = r1_roof()
     if r1r is not None:
-        r1r["traffic"] = pmc_traffic("k_residual", exclude="k_residual_delta")
+        live = pmc_traffic_live()
+        if live is not None:
+            r1r["traffic"] = live["FETCH_SIZE"] + live["WRITE_SIZE"]
+            r1r["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) on scripts/r1_only.py, same video and kernel; "
+                                     "2 x FETCH_SIZE (%.3g B) + WRITE_SIZE (%.3g B)" % (live["FETCH_SIZE"], live["WRITE_SIZE"]))
+        else:
+            r1r["traffic"] = pmc_traffic("k_residual", exclude="k_residual_delta")
+            r1r["traffic_source"] = None if r1r["traffic"] is None else "NOT this run: the newest profiles/r*/bench_c3_pmc_{FETCH,WRITE}_SIZE_v*.csv in the tree"
         if roof.get("kernel") == "residual_r1":
-            roof["traffic"] = r1r["traffic"]
+            roof["traffic"] = r1r["traffic"]; roof["traffic_source"] = r1r["traffic_source"]
     dlr = None
     if "residual_delta" in kern and a.bg_ssub == 1:             # the iteration's second residual: resident Ysig + footprint-term difference, one streaming pass
         ms = kern["residual_delta"]["ms_per_call"]
@@ -325,18 +477,21 @@ def main():
                                 "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub)),
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
                    "parallelism": "patches round-robin over %d rank(s)" % world,
-                   **({"note": "strong scaling of the 4 x 4-patch decomposition (BASELINE configs[3]); its own N = 1 point is `python bench.py --config c4` "
-                               "(16 patches on one GPU: profiles/r02/bench_c4_n1_v6.json, 13.4 iter/s) -- the default N = 1 line is configs[2], the same "
-                               "video as ONE patch, which has no halo re-reads and 16x larger launches"} if (world > 1 and a.config == "c4" and not a.weak) else {})},
+                   **({"note": "strong scaling of the 4 x 4-patch decomposition (BASELINE configs[3]); its own N = 1 point is the `c4_n1` object of the N = 1 line "
+                               "(16 patches on one GPU) -- the N = 1 `value` is configs[2], the same video as ONE patch, which has no halo re-reads and 16x larger launches"}
+                      if (world > 1 and a.config == "c4" and not a.weak) else {})},
         "roofline": roof,
         "roofline_r1": r1r,
         "roofline_solve": solve_roof(),
         "roofline_r1_delta": dlr,
         "roofline_projections": proj_roofs(),
-        "first_iteration": {"ms": warm_ms if a.warmup else None,
+        **comm,
+        "first_iteration": {"ms": warm_steps_ms[0] if warm_steps_ms else None, "warmup_steps_ms": [round(x, 3) for x in warm_steps_ms],
                             "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},
-                            "note": "the first background fit of a patch also builds the block-pair covariance table of the video on the fp64 matrix pipe (kept until the "
-                                    "video or the frame stride changes); it falls into the warm-up step(s), `--warmup 0` puts it inside the timed region"},
+                            "note": "the FIRST step after the upload (timed on its own): its background fit also builds the block-pair covariance table of the video on "
+                                    "the fp64 matrix pipe (kept until the video or the frame stride changes); `--warmup 0` puts it inside the timed region"},
+        # a recording gets TWO background updates (demos/demo_large_data_1p.m:142,199): the mean of the first two steps from a fresh upload
+        "ms_per_step_incl_cold": (sum(warm_steps_ms[:2]) / 2.0) if len(warm_steps_ms) >= 2 else None,
         "kernel_timing": {"timed_region": sorted(k for k, v in kern.items() if v["from"] == "timed region"),
                           "note": "HIP events on the engine's stream.  Inside the timed region only the kernels a roofline is quoted for are bracketed "
                                   "(cnmfe_profile_enable(ctx, 2)); every other row of kernels_ms_per_step is the average of %d extra steps run after it with "
@@ -345,12 +500,25 @@ def main():
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "kernel_calls_per_step": {k: round(v["calls_per_step"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] > 0.5},
     }
-    if not a.no_cpu_baseline and world == 1:
+    eng.close()
+    del s, video
+    torch.cuda.empty_cache()
+    out["c4_n1"] = None
+    if world == 1 and a.config == "c3" and not a.no_extras and not a.weak and a.bg_ssub == 1 and not a.deconv and a.alg == "hals":
+        # the N = 1 point of the strong-scaling curve (`--gpus N` runs configs[3] = this video in 4 x 4 patches): all 16 patches on this one GPU
+        try:
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            c4 = json.loads(r_.stdout.decode().strip().splitlines()[-1])
+            out["c4_n1"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "kernel_sum_ms_per_step")}
+            out["c4_n1"]["workload"] = c4["config"]["workload"]
+        except Exception as e:                                  # the headline line must not die with the extra
+            out["c4_n1"] = {"error": repr(e)[:200]}
+    if not a.no_cpu_baseline and a.cpu_baseline != "none" and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    eng.close()
 
 
 if __name__ == "__main__":

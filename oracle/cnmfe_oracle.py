@@ -887,7 +887,8 @@ class OracleSources2D:
             sn_patch = self.sn.reshape(-1, order="F")[mask][ip]
             if self.bg_ssub == 1:
                 self.W[idx], self.b0[idx] = fit_ring_model(Yb, A_block, C_block, self.W[idx], self.thresh_outlier,
-                                                           sn_patch, ip, self.bg_acceleration)   # :218
+                                                           sn_patch, ip, self.bg_acceleration,
+                                                           only_rows=getattr(self, "bg_only_rows", None))   # :218 (bg_only_rows: timing harness only, bench.py --cpu-baseline full)
             else:                                            # :219-230
                 nr_b, nc_b = int(b[1] - b[0] + 1), int(b[3] - b[2] + 1)
                 temp = np.asarray(Yb, dtype=np.float64) - (A_block @ C_block if A_block.shape[1] else 0.0)      # :221

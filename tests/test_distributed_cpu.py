@@ -101,3 +101,21 @@ def test_two_rank_sharded_deconvolution_matches_single_process(tmp_path):
     for k in ("C", "C_raw", "S", "kp", "sn"):
         assert np.allclose(got[k], ref[k], rtol=1e-6, atol=1e-6), k
     assert (ref["S"] > 0).any()
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_without_gpus():
+    """`python bench.py --gpus N` with no launcher in the environment starts N ranks itself (it used to run ONE rank silently).
+    CNMFE_BENCH_DRY=1 stops after the rendezvous and one all-reduce (gloo here: no GPU), so this checks the env plumbing and the relayed line;
+    without it, on a box with fewer GPUs than ranks, the launcher refuses loudly."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, CNMFE_BENCH_DRY="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["rccl_ranks"] == 2 and line["sum"] == 2.0
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        assert r.returncode != 0 and b"GPU(s) visible" in r.stderr

@@ -724,3 +724,18 @@ def orc_nhood(r):
     import cnmfe_oracle as orc
     rs, cs = orc.get_nhood(r)
     return np.ravel(rs), np.ravel(cs)
+
+
+def test_bench_two_ranks_self_spawned_on_one_device():
+    """`python bench.py --gpus 2 --config c4tiny` with NO launcher in the environment: bench.py starts its two ranks itself.  On this one-GPU box both
+    ranks share cuda:0 and talk over gloo (CNMFE_BENCH_ONE_DEVICE=1: RCCL refuses two ranks on one device); what is checked is the launcher, the
+    sharded c4 code path (2 x 2 patches over 2 ranks, all-gather of A, all-reduce of the stitch) and the line's n_gpus / rccl_ranks."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CNMFE_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
+    assert line["value"] > 0 and "c4tiny" in line["config"]["workload"]
