@@ -446,13 +446,14 @@ def test_deconv_many_pools_takes_the_global_fallbacks(eng, T):
     opts = dict(type="ar1", method="foopsi", smin=0.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
     Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
     Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Y.astype(np.float64), smin=0.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
-    assert np.allclose(sng, snr, rtol=2e-4)
-    assert np.allclose(parsg, parsr, atol=2e-3), (parsg, parsr)
+    # observed (round 3, fminbnd without FMA contraction): gamma 1.9e-8, traces 2.9e-8, spike counts equal
+    assert np.allclose(sng, snr, rtol=5e-6)
+    assert np.allclose(parsg, parsr, atol=2e-6), (parsg, parsr)
     for k in range(Y.shape[0]):
         assert (Sr[k] > 0).sum() > 480                                        # the regime the test is about (LDS holds <= ~250 / 512 pools here)
-        assert rel(Cg[k], Cr[k]) <= 5e-3, (k, rel(Cg[k], Cr[k]))
-        assert rel(Crawg[k], Crawr[k]) <= 5e-3
-        assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 0.03 * (Sr[k] > 0).sum()
+        assert rel(Cg[k], Cr[k]) <= 5e-6, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 5e-6
+        assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 1
 
 
 def test_deconv_without_the_optimisation_loops(eng):
@@ -462,10 +463,10 @@ def test_deconv_without_the_optimisation_loops(eng):
     opts = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=False, optimize_b=False, max_tau=100.0)
     Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
     Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Y.astype(np.float64), smin=-5.0, optimize_pars=False, optimize_b=False, max_tau=100.0)
-    assert np.allclose(sng, snr, rtol=2e-4) and np.allclose(parsg, parsr, atol=1e-5)
+    assert np.allclose(sng, snr, rtol=5e-6) and np.allclose(parsg, parsr, atol=2e-6)
     for k in range(Y.shape[0]):
         assert rel(Cg[k], Cr[k]) <= 1e-6, (k, rel(Cg[k], Cr[k]))
-        assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 2
+        assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 1
 
 
 @pytest.mark.parametrize("T", [18000, 24000])
@@ -478,9 +479,11 @@ def test_deconv_long_traces(eng, T):
     opts = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
     Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Y, opts)
     Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Y[:1].astype(np.float64), smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
-    assert np.allclose(sng[0], snr[0], rtol=2e-4) and abs(parsg[0] - parsr[0]) < 2e-3
-    assert rel(Cg[0], Cr[0]) <= 2e-2 and rel(Crawg[0], Crawr[0]) <= 1e-2
-    assert abs((Sg[0] > 0).sum() - (Sr[0] > 0).sum()) <= max(2, 0.05 * (Sr[0] > 0).sum())
+    print("long trace T=%d: sn %.2e gamma %.2e C %.2e Craw %.2e spikes %d/%d" % (T, abs(sng[0] / snr[0] - 1), abs(parsg[0] - parsr[0]), rel(Cg[0], Cr[0]), rel(Crawg[0], Crawr[0]),
+                                                                               (Sg[0] > 0).sum(), (Sr[0] > 0).sum()))
+    assert np.allclose(sng[0], snr[0], rtol=2e-5) and abs(parsg[0] - parsr[0]) < 2e-6
+    assert rel(Cg[0], Cr[0]) <= 2e-5 and rel(Crawg[0], Crawr[0]) <= 2e-5
+    assert abs((Sg[0] > 0).sum() - (Sr[0] > 0).sum()) <= 1
     with pytest.raises(CnmfeError):
         eng.deconv_temporal(np.zeros((1, 40000), np.float32), opts)
 

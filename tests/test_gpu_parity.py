@@ -328,13 +328,14 @@ def test_deconv_temporal_parity(eng):
     Craw0 = Craw0 + 0.7                                   # give the traces a baseline to find
     Cg, Crawg, Sg, parsg, sng = eng.deconv_temporal(Craw0, None)
     Cr, Crawr, Sr, parsr, snr = oo.deconvTemporal(Craw0.astype(np.float64))
-    assert np.allclose(sng, snr, rtol=2e-4)
-    assert np.allclose(parsg, parsr, atol=2e-3), (parsg, parsr)
+    # observed on MI355X since fminbnd runs without FMA contraction (round 3): gamma 2.4e-8, sn 5e-8, traces 3e-8, spike counts equal
+    assert np.allclose(sng, snr, rtol=5e-6)
+    assert np.allclose(parsg, parsr, atol=2e-6), (parsg, parsr)
     for k in range(Cg.shape[0]):
-        assert rel(Cg[k], Cr[k]) <= 1.2e-2, (k, rel(Cg[k], Cr[k]))
-        assert rel(Crawg[k], Crawr[k]) <= 7e-3
+        assert rel(Cg[k], Cr[k]) <= 5e-6, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 5e-6
         eg, er = np.nonzero(Sg[k] > 0)[0], np.nonzero(Sr[k] > 0)[0]
-        assert abs(len(eg) - len(er)) <= 2, (k, len(eg), len(er))
+        assert abs(len(eg) - len(er)) <= 1, (k, len(eg), len(er))
 
 
 def test_hals_temporal_deconv_parity(eng):
@@ -343,11 +344,12 @@ def test_hals_temporal_deconv_parity(eng):
     c, pid, ysig, A_p = _deconv_case(eng, T=1200, K=4)
     Cg, Crawg, Sg, sng, parsg, aa = eng.hals_temporal_deconv(pid, A_p, c.f.C_init, 2, None)
     Cr, Crawr, Sr, snr, parsr = oo.HALS_temporal_deconv(ysig, A_p.astype(np.float64), c.f.C_init, 2)
-    assert np.allclose(sng, snr, rtol=1e-3)
-    assert np.allclose(parsg, np.array(parsr, dtype=np.float64), atol=3e-3), (parsg, parsr)
+    # observed (round 3): gamma 2.5e-8, traces 9.5e-8
+    assert np.allclose(sng, snr, rtol=5e-6)
+    assert np.allclose(parsg, np.array(parsr, dtype=np.float64), atol=2e-6), (parsg, parsr)
     for k in range(Cg.shape[0]):
-        assert rel(Cg[k], Cr[k]) <= 1.3e-2, (k, rel(Cg[k], Cr[k]))
-        assert rel(Crawg[k], Crawr[k]) <= 7e-3, (k, rel(Crawg[k], Crawr[k]))
+        assert rel(Cg[k], Cr[k]) <= 5e-6, (k, rel(Cg[k], Cr[k]))
+        assert rel(Crawg[k], Crawr[k]) <= 5e-6, (k, rel(Crawg[k], Crawr[k]))
         assert np.corrcoef(Cg[k], c.f.C_true[k])[0, 1] > 0.95
 
 

@@ -71,8 +71,9 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
     obs = observed.setdefault(name, {})
     deconv = bool(cfg.get("deconv"))
     # Tolerances = <= 10x the errors observed on MI355X (gpurun_out/parity_observed.json), far inside SURVEY 8(c)'s
-    # 1e-3 (W) / 1e-4 (Ysig, U, C).  With deconv_flag the first iteration's traces already differ by the discrete OASIS decisions (worst trace
-    # 1.6e-3, median 5e-5), and everything the second iteration computes inherits that: `loose` scales its tolerances.
+    # 1e-3 (W) / 1e-4 (Ysig, U, C).  deconv_flag needs NO allowance of its own since round 3: with fminbnd evaluated without FMA contraction
+    # (csrc/deconv.hip) engine and oracle make the same pool decisions -- kernel_pars agree to 3e-8, traces to 1.7e-7, spike counts exactly,
+    # and the second iteration (which inherits the first one's deconvolved traces) is as tight as the first.
     # With thresh_outlier the fit starts with a DISCRETE decision per entry of Bf (fit_ring_model.m:53, `>` against W_old*Bf + thresh*sn).  The
     # engine's centred video is fp32 (|error| ~ 3e-5 on values ~1e3), so a handful of the d*T comparisons fall the other way; each moves one
     # entry of Bf by ~thresh*sn, i.e. the covariances of that pixel by ~thresh/T relative, and with them the rows of W whose ring holds it.
@@ -81,7 +82,7 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
     # fp32 representation is exact.
     outl = "thresh_outlier" in cfg
     for it in range(cfg["iters"]):
-        loose = 1e4 if (deconv and it) else 1e3 if outl else 1.0
+        loose = 1e3 if outl else 1.0
         # ---- background ----
         for idx in video.order:
             k = "W_%d_%d_%d" % (it, idx[0], idx[1])
@@ -127,12 +128,11 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
             obs["C_raw_%d" % it] = dict(max=max(er), median=float(np.median(er))); obs["C_%d" % it] = dict(max=max(ec), median=float(np.median(ec)))
             obs["spikes_%d" % it] = dict(max_count_diff=max(abs(a - b) for a, b in ns), total=(sum(a for a, _ in ns), sum(b for _, b in ns)))
             obs["kp_%d" % it] = float(np.abs(got["kp_%d" % it] - ref["kp_%d" % it]).max())
-            tl = 10.0 if it else 1.0
-            assert max(er) <= 1e-2 * tl and max(ec) <= 1.5e-2 * tl and np.median(ec) <= 5e-4 * tl, (name, it, max(er), max(ec), float(np.median(ec)))
-            assert all(abs(a - b) <= (2 if not it else max(2, 0.05 * b)) for a, b in ns), (name, it, ns)
-            assert obs["kp_%d" % it] <= 2e-3                       # g comes out of fminbnd with TolX = 1e-4 (foopsi_oasisAR1.m:152): a few TolX is its resolution
+            assert max(er) <= 5e-6 and max(ec) <= 5e-6, (name, it, max(er), max(ec), float(np.median(ec)))
+            assert all(abs(a - b) <= 1 for a, b in ns) and abs(sum(a for a, _ in ns) - sum(b for _, b in ns)) <= 2, (name, it, ns)
+            assert obs["kp_%d" % it] <= 2e-6, (name, it, obs["kp_%d" % it])       # (fminbnd's TolX is 1e-4: both sides stop at the SAME evaluation)
         e = float(np.abs(got["b0new_t_%d" % it] - ref["b0new_t_%d" % it]).max()); obs["b0new_t_%d" % it] = e
-        assert e <= (0.1 if deconv or outl else 1e-4), (name, it, e)
+        assert e <= (0.1 if outl else 1e-4), (name, it, e)
 
 
 # ======================================================================================================================================
@@ -245,10 +245,10 @@ class BigCase:
             live = np.nonzero(aa > 0)[0]
             ec = [rel(Cg[k], Cr[k]) for k in live]; er = [rel(Crawg[k], Crawr[k]) for k in live]
             obs[tag + "_deconv_C_patch"] = dict(max=max(ec), median=float(np.median(ec)), raw_max=max(er), n=len(live))
-            assert np.allclose(sng[live], snr[live], rtol=5e-4)
-            assert max(ec) <= 3e-2 and np.median(ec) <= 2e-3 and max(er) <= 2e-2, (tag, max(ec), float(np.median(ec)), max(er))
+            assert np.allclose(sng[live], snr[live], rtol=5e-6)
+            assert max(ec) <= 5e-6 and max(er) <= 5e-6, (tag, max(ec), float(np.median(ec)), max(er))
             for k in live:
-                assert abs(int((Sg[k] > 0).sum()) - int((Sr[k] > 0).sum())) <= max(2, 0.05 * (Sr[k] > 0).sum())
+                assert abs(int((Sg[k] > 0).sum()) - int((Sr[k] > 0).sum())) <= 1
 
 
 def _recovery(s, f):

@@ -84,3 +84,18 @@ def test_estimate_time_constant_edge_cases():
     y = rng.standard_normal(2000)                  # white noise: g ~ 0 or slightly negative -> 0.15 rule or small g
     g = oo.estimate_time_constant_ar1(y, 0.0)
     assert g is not None and 0 <= g <= 0.2
+
+
+def test_fminbnd_second_step_is_golden_not_parabolic():
+    """MATLAB's fminbnd (Forsythe-Malcolm-Moler) enters the parabolic branch on its second step with v == w and fv == fw: the fit is degenerate,
+    p = q = 0 EXACTLY, `abs(p) < abs(0.5*q*r)` is false and the step falls through to golden section.  The engine's copy of the loop must be
+    compiled without FMA contraction for the same to hold (csrc/deconv.hip; with contraction it took an arbitrary 'parabolic' step there and
+    gamma came out up to 2e-3 away from the reference's) -- this pins the evaluation sequence the GPU tests compare against."""
+    import oasis_oracle as oo
+    xs = []
+    def f(x):
+        xs.append(x); return (x - 0.93) ** 2 + 0.1 * np.sin(40 * x)
+    oo.fminbnd(f, 0.0, 1.0)
+    g = 0.5 * (3.0 - np.sqrt(5.0))
+    assert abs(xs[0] - g) < 1e-15 and abs(xs[1] - (g + g * (1 - g))) < 1e-15
+    assert abs(xs[2] - (xs[1] + g * (1 - xs[1]))) < 1e-15            # golden section of [x1, 1], not a parabola through two coincident points
