@@ -603,20 +603,130 @@ __device__ __forceinline__ void win_body(const float4 *__restrict__ Y4, const Bg
     }
 }
 
+// The same GEMMs with 16-BYTE loads (round 3; frame strides 1, 2, 4 -- every first fit, and every fit at the headline size).  Probes showed the
+// scalar-load version above bound by its loads, not by the matrix pipe: 5.0 ms with the MFMAs removed against 5.4 ms with them
+// (profiles/r03/win_probe.txt) -- 256 bytes per wave instruction.  Here lane (fi, kq) loads the float4 of ITS pixel for chunk s + kq (and the float4
+// of its trace for the same four frames): a wave instruction moves 1 KB, and the four components are the k = kq slices of FOUR MFMAs -- MFMA m
+// contracts over the frames 4 (s + kq) + m, kq = 0..3, on both operands alike, so no value ever changes lanes.  16 frames per step.
+template <int NT>
+__device__ __forceinline__ void win_body4(const float4 *__restrict__ Y4, const BgGeom &g, const float *__restrict__ Cc, int64_t ldc, int blk, int l0, int nl,
+                                          const int *__restrict__ lst_k, int64_t c0, int64_t c1, double *__restrict__ Ut, double *__restrict__ Gb) {
+    constexpr int AHEAD = NT <= 2 ? 2 : 1;
+    const int bi = blk % g.nbr, bj = blk / g.nbr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kq = lane >> 4;
+    const float4 *ya[4]; const float4 *tb[NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int lp = (wave * 4 + a) * 16 + fi;
+        const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
+        const int rb = bi * BLK + lr, cb = bj * BLK + lc;
+        ya[a] = (rb < g.nr_b && cb < g.nc_b) ? Y4 + ((int64_t)cb * g.nr_b + rb) : nullptr;
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) { const int sl = b * 16 + fi; tb[b] = sl < nl ? reinterpret_cast<const float4 *>(Cc + (int64_t)lst_k[l0 + sl] * ldc) : nullptr; }
+    double4_t acc[4][NT], accg[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        accg[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    struct Frag { float4 y[4]; float4 t[NT]; };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](int64_t s) {
+        Frag f;
+        const int64_t c = s + kq;
+        const bool on = c < c1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) f.y[a] = (on && ya[a]) ? ya[a][c * g.d_b] : z4;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) f.t[b] = (on && tb[b]) ? tb[b][c] : z4;
+        return f;
+    };
+    const bool gw = wave < NT;                              // wave w also owns row-group w of G
+    const int ks = g.kstride;
+    auto comp = [](const float4 &v, int m) -> float { return m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w; };
+    auto mm = [&](const Frag &f) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m & (ks - 1)) continue;                     // frame stride 2: components 0, 2; stride 4: component 0 (fit_ring_model.m:84-87)
+            double bv[NT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bv[b] = (double)comp(f.t[b], m);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double av = (double)comp(f.y[a], m);
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[b], acc[a][b], 0, 0, 0);
+            }
+            if (gw) {
+                double gv = bv[0];
+#pragma unroll
+                for (int b = 1; b < NT; ++b) gv = wave == b ? bv[b] : gv;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) accg[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv, bv[b], accg[b], 0, 0, 0);
+            }
+        }
+    };
+    Frag f[AHEAD];
+#pragma unroll
+    for (int d = 0; d < AHEAD; ++d) f[d] = load(c0 + 4 * d);
+    for (int64_t s = c0; s < c1; s += 4 * AHEAD) {
+#pragma unroll
+        for (int d = 0; d < AHEAD; ++d) {
+            const Frag nx = load(s + 4 * (AHEAD + d));
+            mm(f[d]);
+            f[d] = nx;
+        }
+    }
+    // D layout (fp64 16x16): row = (lane>>4) + 4r, col = lane&15
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int slot = b * 16 + fi;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (slot < nl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ut[(int64_t)(l0 + slot) * BLKPX + (wave * 4 + a) * 16 + kq + 4 * r] = acc[a][b][r];
+        if (gw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gb[(int64_t)blk * WIN_NLB * WIN_NLB + (wave * 16 + kq + 4 * r) * WIN_NLB + slot] = accg[b][r];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
                                                   const int *__restrict__ lst_k, const int *__restrict__ blk_list, int nseg, double *__restrict__ Ut, int64_t ut_stride,
                                                   double *__restrict__ Gb, int64_t gb_stride) {
     const int blk = blk_list[blockIdx.x / nseg], seg = blockIdx.x % nseg;
     const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+    double *ut = Ut + seg * ut_stride, *gb = Gb + seg * gb_stride;
     const int64_t nchunk = (g.Tp + 3) >> 2;
     int64_t cseg = ((nchunk + nseg - 1) / nseg + 1) & ~int64_t(1);
     const int64_t c0 = seg * cseg, c1 = c0 + cseg < nchunk ? c0 + cseg : nchunk;
-    double *ut = Ut + seg * ut_stride, *gb = Gb + seg * gb_stride;
     switch ((nl + 15) >> 4) {
         case 1: win_body<1>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         case 2: win_body<2>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         case 3: win_body<3>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         case 4: win_body<4>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        default: break;
+    }
+}
+
+// frame strides 1, 2, 4: 16-byte loads over the video's chunks (the used frames are components of them)
+__global__ void __launch_bounds__(256, 2) k_win_proj4(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
+                                                      const int *__restrict__ lst_k, const int *__restrict__ blk_list, int nseg, double *__restrict__ Ut, int64_t ut_stride,
+                                                      double *__restrict__ Gb, int64_t gb_stride) {
+    const int blk = blk_list[blockIdx.x / nseg], seg = blockIdx.x % nseg;
+    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+    double *ut = Ut + seg * ut_stride, *gb = Gb + seg * gb_stride;
+    const int64_t nchunk = (g.T + 3) >> 2;
+    const int64_t cseg = ((nchunk + nseg - 1) / nseg + 7) & ~int64_t(7);
+    const int64_t c0 = seg * cseg, c1 = c0 + cseg < nchunk ? c0 + cseg : nchunk;
+    switch ((nl + 15) >> 4) {
+        case 1: win_body4<1>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        case 2: win_body4<2>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        case 3: win_body4<3>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
+        case 4: win_body4<4>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         default: break;
     }
 }
@@ -1149,6 +1259,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX; gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
         RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
         RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
+        if (g.kstride == 1 || g.kstride == 2 || g.kstride == 4)
+            LAUNCH(ctx, "bg_win_proj", k_win_proj4, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
+                   dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+        else
         LAUNCH(ctx, "bg_win_proj", k_win_proj, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
                dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
         proj_queued = true;
