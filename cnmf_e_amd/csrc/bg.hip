@@ -762,6 +762,8 @@ __global__ void __launch_bounds__(256) k_win_fix(BgGeom g, int K, const int *__r
 }
 
 // cov(pair)(i,j) = base(pair)(i,j) - sum_{k at j} A_jk U~_a(k, i) - sum_{k at i} A_ik U~_b(k, j)  over the needed 16x16 sub-tiles
+// Thread = (half h, row ty of a sub-tile, column PAIR tx2): 16-byte loads and stores (one wave instruction moves 1 KB of the 7.7 GB sweep); the two
+// 128-thread halves of the workgroup take the row patches pi, pi + 1 side by side (a half is two whole waves: their need masks may differ).
 __global__ void __launch_bounds__(256) k_cov_correct(const double *__restrict__ base, double *__restrict__ cov, const int4 *__restrict__ pairs,
                                                      const unsigned short *__restrict__ needmask, BgGeom g, int K, const int *__restrict__ arow,
                                                      const int *__restrict__ acol, const float *__restrict__ aval, const int *__restrict__ lst_ptr,
@@ -769,7 +771,7 @@ __global__ void __launch_bounds__(256) k_cov_correct(const double *__restrict__ 
     const int pair = blockIdx.x;
     const int4 pr = pairs[pair];
     const int ba = pr.x, bb = pr.y, rel = pr.z;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int half = threadIdx.x >> 7, ty = (threadIdx.x >> 3) & 15, tx = (threadIdx.x & 7) * 2;
     const int la = lst_ptr[ba], lb = lst_ptr[bb];
     auto pix = [&](int blk, int lp, int &e0, int &e1) {
         const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
@@ -781,7 +783,7 @@ __global__ void __launch_bounds__(256) k_cov_correct(const double *__restrict__ 
     double *cp = cov + (int64_t)pair * BLKPX * BLKPX;
     // gridDim.y workgroups share a pair (its 16 row patches split evenly): a small patch has too few pairs to fill the chip with one each
     const int pi0 = (int)blockIdx.y * (16 / (int)gridDim.y), pi1 = pi0 + 16 / (int)gridDim.y;
-    for (int pi = pi0; pi < pi1; ++pi) {
+    for (int pi = pi0 + half; pi < pi1; pi += 2) {
         const unsigned mask = needmask[rel * 16 + pi];
         if (!mask) continue;
         const int ilp = pi * 16 + ty;
@@ -789,12 +791,16 @@ __global__ void __launch_bounds__(256) k_cov_correct(const double *__restrict__ 
         for (int pj = 0; pj < 16; ++pj) {
             if (!((mask >> pj) & 1u)) continue;
             const int jlp = pj * 16 + tx;
-            int ej0, ej1; pix(bb, jlp, ej0, ej1);
+            int ej0, ej1, ek0, ek1; pix(bb, jlp, ej0, ej1); pix(bb, jlp + 1, ek0, ek1);
             const int idx = ilp * BLKPX + jlp;
-            double v = bp[idx];
-            for (int e = ej0; e < ej1; ++e) v -= (double)aval[e] * Ut[(int64_t)(la + slot_of[(int64_t)ba * K + acol[e]]) * BLKPX + ilp];
-            for (int e = ei0; e < ei1; ++e) v -= (double)aval[e] * Ut[(int64_t)(lb + slot_of[(int64_t)bb * K + acol[e]]) * BLKPX + jlp];
-            cp[idx] = v;
+            double2 v = *reinterpret_cast<const double2 *>(bp + idx);
+            for (int e = ej0; e < ej1; ++e) v.x -= (double)aval[e] * Ut[(int64_t)(la + slot_of[(int64_t)ba * K + acol[e]]) * BLKPX + ilp];
+            for (int e = ek0; e < ek1; ++e) v.y -= (double)aval[e] * Ut[(int64_t)(la + slot_of[(int64_t)ba * K + acol[e]]) * BLKPX + ilp];
+            for (int e = ei0; e < ei1; ++e) {
+                const double2 u = *reinterpret_cast<const double2 *>(Ut + (int64_t)(lb + slot_of[(int64_t)bb * K + acol[e]]) * BLKPX + jlp);
+                v.x -= (double)aval[e] * u.x; v.y -= (double)aval[e] * u.y;
+            }
+            *reinterpret_cast<double2 *>(cp + idx) = v;
         }
     }
 }
