@@ -16,3 +16,10 @@ for i in range(1, len(it) + 1):
 for g, p, n in sorted(gaps, reverse=True)[:14]:
     print("%7.3f ms  after %-50s before %s" % (g, p, n))
 print("sum of gaps %.2f ms; gaps < 20 us: %d totalling %.2f ms" % (sum(g for g, _, _ in gaps), sum(1 for g, _, _ in gaps if g < 0.02), sum(g for g, _, _ in gaps if g < 0.02)))
+if len(sys.argv) > 2 and sys.argv[2] == "seq":
+    t0 = it[0][0]
+    prev = None
+    for s_, e_, n_ in it:
+        gap = (s_ - prev) / 1e3 if prev else 0.0
+        print("%8.3f ms  +%7.1f us gap  %8.1f us  %s" % ((s_ - t0) / 1e6, gap, (e_ - s_) / 1e3, n_[:70]))
+        prev = e_
