@@ -377,7 +377,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_kernel", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "solve_mode", "r1_delta", "r1_lazy", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", nullptr};
+    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }

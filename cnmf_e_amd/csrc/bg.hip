@@ -284,24 +284,14 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
 // the instruction's k index is irrelevant.  4 ds_read_b128 + 4 MFMAs per tile and 32 frames.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct G4Frag { float4 ah, al, bh, bl; };                             // hi / lo planes of the A and B fragments of one tile (4 x ds_read_b128)
-// LDS stage geometry (floats) and the DMA of one 16-frame stage, for the two work-item shapes of the split-bf16 mode:
+// LDS stage geometry (floats) and the DMA of one 16-frame stage of the split-bf16 mode:
 // G4Quad: 4 waves, item = (block pair, 128x128 quadrant): stage = [A half: e(2) x plane(2) x 128 px][B half: same] x 16 B = 16 KB
-// G4Half: 8 waves, item = (block pair, 128-row half): stage = [A half: e(2) x plane(2) x 128 px][B block: e(2) x plane(2) x 256 px] = 24 KB.
-//         The B stream is shared by both column halves: 768 instead of 1024 pixel-streams per pair cross the fabric (the kernel is bound
-//         by that traffic: 385 GB at 7.7 TB/s per launch with quadrant items at the headline size)
 struct G4Quad {
     static constexpr int STAGE_F = G4_STAGE_F, APL = 512, BPL = 512, WAVES = 4, LIST = 64, NBUF = 4, DEPTH = 1, NDMA = 4;   // DEPTH steps in flight
     static __device__ __forceinline__ void issue(const G4Wave &w, int sc, unsigned d) {
         const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
         glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
         glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
-    }
-};
-struct G4Half {
-    static constexpr int STAGE_F = 6144, APL = 512, BPL = 1024, WAVES = 8, LIST = 128, NBUF = 6, DEPTH = 2, NDMA = 3;
-    static __device__ __forceinline__ void issue(const G4Wave &w, int sc, unsigned d) {
-        const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
-        glds16(sa, w.vo0, d); glds16(sb, w.vo1, d + 8192u); glds16(sb, w.vo2, d + 16384u);
     }
 };
 template <class CFG, int NS>
@@ -444,48 +434,6 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
         G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
         G4_CASE(9) G4_CASE(10) G4_CASE(11) G4_CASE(12) G4_CASE(13) G4_CASE(14) G4_CASE(15) G4_CASE(16)
 #undef G4_CASE
-        default: break;
-    }
-}
-
-// split-bf16 Gram over (block pair, 128-row half) items: 8 waves, one workgroup per CU (96 KB of stage buffers)
-__global__ void __launch_bounds__(512) k_gram5(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
-                                               const int *__restrict__ work, int nwork, const int *__restrict__ tl_cnt,
-                                               const int *__restrict__ tl, int flush_every, double *__restrict__ cov) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    if (nwg % 8 == 0) bid = (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
-    if (bid >= nwork) return;
-    const int wk = work[bid];
-    const int pair = wk >> 1, ih = wk & 1;
-    const int4 pr = pairs[pair];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lidx = pr.z * 2 + ih;
-    const int cnt = __builtin_amdgcn_readfirstlane(tl_cnt[lidx]);
-    G4Wave w;
-    w.gA = bf + ((int64_t)pr.x * Tpad) * BLKPX + ih * 512;
-    w.gB = bf + ((int64_t)pr.y * Tpad) * BLKPX;
-    // DMA of a 16-frame stage = 24 wave-instructions of 1 KB: A piece `wave` = (8-frame row wave>>2, plane (wave>>1)&1, 64-px group wave&1);
-    // B pieces `wave` and `wave + 8` = (row 0 / 1, plane wave>>2, group wave&3).  LDS destinations are piece-linear.
-    w.vo0 = (unsigned)((((wave >> 2) * 2 + ((wave >> 1) & 1)) * BLKPX + (wave & 1) * 64 + lane) * 16);
-    w.vo1 = (unsigned)(((wave >> 2) * BLKPX + (wave & 3) * 64 + lane) * 16);
-    w.vo2 = w.vo1 + 2u * BLKPX * 16u;
-    w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
-    w.lbase = (lane >> 5) * G4Half::STAGE_F + ((lane >> 4) & 1) * 1024 + (lane & 15) * 4;
-    w.lbaseB = (lane >> 5) * G4Half::STAGE_F + 2048 + ((lane >> 4) & 1) * 2048 + (lane & 15) * 4;
-    w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
-    const int nsmax = (cnt + 7) >> 3;
-    const int lo_ = wave * nsmax;
-    w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0;      // tiles [wave*nsmax, ...): a contiguous run of the row-major list
-    w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX;
-    const int *tlw = tl + lidx * G4Half::LIST + (w.ns ? lo_ : 0);
-    switch (nsmax) {
-#define G5_CASE(N) case N: gram4_run_k32<G4Half, N>(w, smem, tlw); break;
-        G5_CASE(1) G5_CASE(2) G5_CASE(3) G5_CASE(4) G5_CASE(5) G5_CASE(6) G5_CASE(7) G5_CASE(8)
-        G5_CASE(9) G5_CASE(10) G5_CASE(11) G5_CASE(12) G5_CASE(13) G5_CASE(14) G5_CASE(15) G5_CASE(16)
-#undef G5_CASE
         default: break;
     }
 }
@@ -827,225 +775,6 @@ struct CovTab {
 // canonical displacement index: dC in 0..maxd; dC == 0 -> dR in 0..maxd (0..maxd); dC >= 1 -> dR in -maxd..maxd.  maxd = 2: 13 classes (0..2, 3..7, 8..12)
 __host__ __device__ __forceinline__ int rel_index(int dR, int dC, int maxd) { return dC == 0 ? dR : (maxd + 1) + (dC - 1) * (2 * maxd + 1) + dR + maxd; }
 __host__ __device__ __forceinline__ int nrel_of(int maxd) { return (maxd + 1) + maxd * (2 * maxd + 1); }
-// ---- B2b v2: panel-blocked Cholesky, 256 threads per pixel ------------------------------------------
-// The system is augmented with the right-hand side as row n of the packed lower triangle, so the
-// factorisation leaves z = L^-1 g in that row (forward substitution for free).  Per panel of PW
-// columns: wave 0 factors the (n-j0+1) x PW panel entirely in registers (lane = row, column broadcasts
-// by v_readlane), then all 4 waves apply the rank-PW update to the trailing triangle, 8 fp64 FMAs per
-// element visit.  Back substitution is a 97-step readlane chain in wave 0.
-constexpr int PW = 8;
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
-__device__ __forceinline__ double rsqrt_f64(double x) { return rs_rsqrt(x); }
-
-__global__ void __launch_bounds__(256) k_ring_solve2(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc,
-                                                     const double *__restrict__ rowsum, const unsigned char *__restrict__ active,
-                                                     float *__restrict__ W, int *__restrict__ errflag, int probe) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int p = g.p, n = p + 1, na = n + 1;
-    double *L = sm;                                   // rows 0..n packed; row n = [g ; unused]
-    double *red = sm + tri(na);                       // 4 partial traces
-    int *nb = reinterpret_cast<int *>(red + 4);       // p neighbour codes
-    int *node = nb + p;                               // p+1 node codes (block-local), see the assembly
-    int *pt = node + p + 1;                           // nbw^4 block-pair codes
-    const int64_t m = blockIdx.x;
-    if (active && !active[m]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
-    for (int i = tid; i < p; i += 256) {
-        const int rb = rbm + dr[i], cb = cbm + dc[i];
-        const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-        nb[i] = (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) ? (rb | (cb << 16)) : -1;
-    }
-    __syncthreads();
-    // ---- assemble the packed triangle ----
-    // The p ring neighbours and the centre (node p) lie within a 31x31 window = at most 3x3 16x16 blocks.  The
-    // pair-table indirection of cov_lookup is resolved once per block pair (81 lookups, PT in LDS); every entry of the
-    // triangle is then ONE independent 8-byte load, issued eight at a time per thread (the two-level dependent
-    // lookup per entry, 19 entries per thread in sequence, left this kernel waiting on memory latency).
-    const int br0 = (rbm - g.p_radius) >> 4, bc0 = (cbm - g.p_radius) >> 4;     // arithmetic shift: floor
-    const int nbw = g.nbw, nb2 = nbw * nbw;                                     // window: nbw x nbw blocks (3 for radius 15, 4 for 18)
-    for (int q = tid; q < nb2 * nb2; q += 256) {
-        const int a = q / nb2, b = q % nb2;
-        int ia = br0 + a % nbw, ja = bc0 + a / nbw, ib = br0 + b % nbw, jb = bc0 + b / nbw;
-        int code = -1;
-        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
-            int dR = ib - ia, dC = jb - ja, sw = 0;
-            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
-            if (dC <= tab.maxd && dR <= tab.maxd && dR >= -tab.maxd) {
-                const int pidx = tab.pair_of[(ja * tab.nbr + ia) * tab.nrel + rel_index(dR, dC, tab.maxd)];
-                code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
-            }
-        }
-        pt[q] = code;
-    }
-    // node codes: local block (0..8) << 8 | local pixel (4x4-patch order); node p = the centre pixel
-    for (int i = tid; i <= p; i += 256) {
-        const int c = i < p ? nb[i] : (rbm | (cbm << 16));
-        int nc = -1;
-        if (c >= 0) { const int rb = c & 0xffff, cb = c >> 16; nc = ((((rb >> 4) - br0) + nbw * ((cb >> 4) - bc0)) << 8) | lp_of(rb & 15, cb & 15); }
-        node[i] = nc;
-    }
-    __syncthreads();
-    const int ne = tri(na);
-    if (probe & 1) { for (int e = tid; e < ne; e += 256) L[e] = 0.0; if (tid < na) L[tri(tid) + tid] = 1.0; }   // A/B probe: no assembly
-    else
-    for (int e0 = tid; e0 < ne; e0 += 256 * 8) {
-        const double *src[8]; double val[8]; int idx[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            src[u] = nullptr; val[u] = 0.0; idx[u] = e;
-            if (e < ne) {
-                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                while (tri(i + 1) <= e) ++i;
-                while (tri(i) > e) --i;
-                const int j = e - tri(i);
-                int na_ = -1, nb_ = -1;                 // the two nodes whose covariance this entry is (or -1)
-                if (i < p) { na_ = node[i]; nb_ = node[j]; if (na_ < 0 || nb_ < 0) { val[u] = (i == j) ? 1.0 : 0.0; na_ = -1; } }
-                else if (i == p) {                      // the row of ones (fit_ring_model.m:101)
-                    if (j < p) { const int nj = nb[j]; if (nj >= 0) src[u] = &rowsum[(((nj >> 16) >> 4) * g.nbr + ((nj & 0xffff) >> 4)) * BLKPX + lp_of(nj & 15, (nj >> 16) & 15)]; }
-                    else val[u] = (double)g.Tp;
-                } else {                                // right-hand side X*y' (:104)
-                    if (j < p) { na_ = node[j]; nb_ = node[p]; if (na_ < 0) na_ = -1; }
-                    else if (j == p) src[u] = &rowsum[((cbm >> 4) * g.nbr + (rbm >> 4)) * BLKPX + lp_of(rbm & 15, cbm & 15)];
-                }
-                if (na_ >= 0) {
-                    int code = pt[(na_ >> 8) * nb2 + (nb_ >> 8)];
-                    if (code < 0) { atomicOr(errflag, 1); code = 0; }      // a needed block pair is not in the table: reported by the host, never indexed
-                    int la = na_ & 255, lb = nb_ & 255;
-                    if (code & 2) { const int t0 = la; la = lb; lb = t0; }
-                    if ((code & 1) && (la >> 4) > (lb >> 4)) { const int t0 = la; la = lb; lb = t0; }   // self pair: upper patch triangle only
-                    src[u] = tab.cov + ((int64_t)(code >> 2) * BLKPX + la) * BLKPX + lb;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (src[u]) val[u] = *src[u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (idx[u] < ne) L[idx[u]] = val[u];
-    }
-    __syncthreads();
-    // ---- ridge: lambda = 1e-5 * trace over the real rows (:106) ----
-    double tr = 0;
-    if (tid < n && (tid == p || nb[tid] >= 0)) tr = L[tri(tid) + tid];
-    for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);
-    if (lane == 0) red[wave] = tr;
-    __syncthreads();
-    const double lam = ((red[0] + red[1]) + (red[2] + red[3])) * 1e-5;
-    if (tid < n && (tid == p || nb[tid] >= 0)) L[tri(tid) + tid] += lam;
-    __syncthreads();
-    // ---- blocked right-looking Cholesky over columns 0..n-1; rows 0..n ----
-    for (int j0 = 0; j0 < ((probe & 2) ? 0 : n); j0 += PW) {
-        const int w = n - j0 < PW ? n - j0 : PW;
-        if (wave == 0 && !(probe & 8)) {
-            const int ra = j0 + lane, rb = j0 + lane + 64;
-            double a[PW], b[PW];
-#pragma unroll
-            for (int jj = 0; jj < PW; ++jj) {
-                a[jj] = (jj < w && ra < na && j0 + jj <= ra) ? L[tri(ra) + j0 + jj] : 0.0;
-                b[jj] = (jj < w && rb < na) ? L[tri(rb) + j0 + jj] : 0.0;
-            }
-#pragma unroll
-            for (int jj = 0; jj < PW; ++jj) {
-                if (jj < w) {
-                    const double piv = readlane_f64(a[jj], jj);
-                    const double inv = rsqrt_f64(piv);
-                    const double dj = piv * inv;
-                    (void)dj;                                  // the diagonal slot keeps 1/L(j,j): that is all back substitution needs, and
-                    if (lane == jj) a[jj] = inv;               // dropping the separate array brings the workgroup under 40 KB of LDS (4 per CU)
-                    else if (lane > jj) a[jj] *= inv;
-                    b[jj] *= inv;
-#pragma unroll
-                    for (int c = jj + 1; c < PW; ++c) {
-                        if (c < w) {
-                            const double lcj = readlane_f64(a[jj], c);
-                            if (lane >= c) a[c] -= a[jj] * lcj;
-                            b[c] -= b[jj] * lcj;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < PW; ++jj) {
-                if (jj < w && ra < na && j0 + jj <= ra) L[tri(ra) + j0 + jj] = a[jj];
-                if (jj < w && rb < na) L[tri(rb) + j0 + jj] = b[jj];
-            }
-        }
-        __syncthreads();
-        const int j1 = j0 + w;
-        const int ti = tid >> 4, tk = tid & 15;       // lanes run along k: L(i, k..k+15) is contiguous in the packed triangle (conflict-free RMW)
-        // four rows (i, i+16, i+32, i+48) per thread: one fetch of panel row k serves four elements -- the LDS pipe,
-        // not the fp64 FMAs, bounds this kernel (10 LDS operations per element visit before, 4 now)
-        for (int ib = j1 + ti; ib <= ((probe & 16) ? -1 : n); ib += 64) {
-            double li[4][PW];
-            double *lrow[4]; int irow[4];                 // row base in the packed triangle and row index (-1: no such row) -- fixed over the k loop
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ib + 16 * r;
-                irow[r] = i <= n ? i : -1;
-                lrow[r] = L + tri(i <= n ? i : n);
-                const double *ri = lrow[r] + j0;
-#pragma unroll
-                for (int jj = 0; jj < PW; ++jj) li[r][jj] = (jj < w && i <= n) ? ri[jj] : 0.0;
-            }
-            const int itop = ib + 48 <= n ? ib + 48 : (ib + 32 <= n ? ib + 32 : (ib + 16 <= n ? ib + 16 : ib));
-            const int kmax = itop < n - 1 ? itop : n - 1;
-            for (int k = j1 + tk; k <= kmax; k += 16) {
-                const double *rk = L + tri(k) + j0;
-                double rkv[PW];
-#pragma unroll
-                for (int jj = 0; jj < PW; ++jj) rkv[jj] = jj < w ? rk[jj] : 0.0;
-                // the products run unconditionally (rows that do not exist hold zeros); only the read-modify-write is predicated:
-                // the nested per-row branches of the first version cost 36 scalar + 38 vector instructions per 16 fp64 FMAs
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int jj = 0; jj < PW; jj += 2) { s0 = fma(li[r][jj], rkv[jj], s0); s1 = fma(li[r][jj + 1], rkv[jj + 1], s1); }
-                    if (k <= irow[r]) lrow[r][k] -= s0 + s1;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- back substitution L^T w = z (z = row n), wave 0, lane owns entries lane and lane+64 ----
-    if (wave == 0 && !(probe & 4)) {
-        const double *zrow = L + tri(n);
-        double za = lane < n ? zrow[lane] : 0.0;
-        double zb = lane + 64 < n ? zrow[lane + 64] : 0.0;
-        // the rows of L a step needs do not depend on the running solution: four steps' worth of LDS reads are issued ahead of the
-        // four dependent readlane / multiply / fma steps (one LDS round trip per step sat on the chain before)
-        for (int jt = n - 1; jt >= 0; jt -= 4) {
-            double dj[4], ra_[4], rb_[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jt - u;
-                const double *rj = L + tri(j >= 0 ? j : 0);
-                dj[u] = j >= 0 ? rj[j] : 0.0;
-                ra_[u] = (j >= 0 && lane < j) ? rj[lane] : 0.0;
-                rb_[u] = (j >= 0 && lane + 64 < j) ? rj[lane + 64] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jt - u;
-                if (j < 0) break;
-                const double zj = j < 64 ? readlane_f64(za, j) : readlane_f64(zb, j - 64);
-                const double wj = zj * dj[u];
-                if (lane == (j & 63)) { if (j < 64) za = wj; else zb = wj; }
-                za -= ra_[u] * wj;
-                zb -= rb_[u] * wj;
-            }
-        }
-        if (lane < p) W[(int64_t)lane * g.d + m] = nb[lane] >= 0 ? (float)za : 0.f;
-        if (lane + 64 < p) W[(int64_t)(lane + 64) * g.d + m] = nb[lane + 64] >= 0 ? (float)zb : 0.f;   // intercept (index p) discarded (:107)
-    }
-}
-
 }  // namespace cnmfe
 #include "ring_solve.hpp"
 namespace cnmfe {
@@ -1242,7 +971,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
     ht.mark("footprint block lists");
-    g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16; gram_kernel 5: k_gram5 (half items) in mode 3
+    g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
     const int nblk = g.nbr * g.nbc;
 
@@ -1355,15 +1084,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // work order: pair-major (the 13 displacement classes of one I block are consecutive), so heavy and light
         // quadrants are mixed in time.  (Measured: class-major order, which makes concurrent workgroups equal-cost,
         // was slower -- 150 vs 131 ms at 512x512x10000 -- and did not raise the L2 hit rate.)
-        const bool half_items = g.bf4 == 2 && ctx->opt("gram_kernel", 4) == 5 && ctx->opt("gram_mode", 3) == 3;      // (pair, row half) items on k_gram5
         std::vector<int> work;
-        for (int pp = 0; pp < npairs && half_items; ++pp)
-            for (int ih = 0; ih < 2; ++ih) {
-                bool any = false;
-                for (int pi = ih * 8; pi < ih * 8 + 8; ++pi) if (needmask[pairs[pp].z * 16 + pi]) any = true;
-                if (any) work.push_back(pp * 2 + ih);
-            }
-        for (int pp = 0; pp < npairs && !half_items; ++pp)
+        for (int pp = 0; pp < npairs; ++pp)
             for (int q = 0; q < 4; ++q) {
                 const int ih = q & 1, jh = q >> 1;
                 bool any = false;
@@ -1381,20 +1103,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         if (ctx->opt("debug", 0)) CK(hipMemsetAsync(ctx->cov.p, 0xff, (size_t)npairs * BLKPX * BLKPX * sizeof(double), ctx->stream));   // NaN-poison skipped sub-tiles
         int nwg = (nwork + 7) / 8 * 8;                      // multiple of 8 for the XCD remap (extra workgroups exit)
         DevBuf &dTcnt = ctx->tmp[12], &dTl = ctx->tmp[13];
-        if (half_items) {
-            // tile lists per (displacement class, row half): i | j << 4 with i < 8 (rows of the half), j < 16
-            std::vector<int> tcnt((size_t)nrel * 2, 0);
-            std::vector<int> tlist((size_t)nrel * 2 * G4Half::LIST, 0);
-            for (int rel = 0; rel < nrel; ++rel)
-                for (int ih = 0; ih < 2; ++ih) {
-                    int n = 0;
-                    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j)
-                        if ((needmask[rel * 16 + ih * 8 + i] >> j) & 1) tlist[(size_t)(rel * 2 + ih) * G4Half::LIST + n++] = i | (j << 4);
-                    tcnt[rel * 2 + ih] = n;
-                }
-            RET(to_dev(ctx, dTcnt, tcnt.data(), tcnt.size()));
-            RET(to_dev(ctx, dTl, tlist.data(), tlist.size()));
-        } else {
+        {
             // tile lists per (displacement class, quadrant): needed 16x16 sub-tiles as i | j << 4 (quadrant coordinates)
             std::vector<int> tcnt((size_t)nrel * 4, 0);
             std::vector<int> tlist((size_t)nrel * 4 * 64, 0);
@@ -1468,13 +1177,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 attr4 = true;
             }
             const int flushw = (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16);
-            if (half_items) {
-                const size_t shmem5 = (size_t)G4Half::NBUF * G4Half::STAGE_F * sizeof(float);
-                static bool attr5 = false;
-                if (!attr5) { CK(hipFuncSetAttribute((const void *)k_gram5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem5)); attr5 = true; }
-                LAUNCH(ctx, "bg_gram_bf16x4", k_gram5, dim3(nwg), dim3(512), shmem5, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
-            } else if (g.bf4 == 2)
+            if (g.bf4 == 2)
                 LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
             else if (f32s)
@@ -1507,30 +1210,18 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ht.mark("base / correction launches");
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
-        const int n = p + 1;
         int *dErr = nullptr;
         RET(ctx_errflag(ctx, &dErr));
         const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();
         const int probe = (int)ctx->opt("solve_probe", 0);
         const int nt = (p + 15) / 16;
-        if (ctx->opt("solve_mode", 5) >= 5 && nt >= 1 && nt <= 8) {
-            // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp)
-#define RS5_CASE(NT_) case NT_: if (unrolled) LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_, false>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
-                                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); \
-                      else LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_, true>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
-                                  P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); break;
-            const bool unrolled = ctx->opt("solve_mode", 5) != 6;      // 5 (default): everything unrolled; 6: the block columns in a real loop (smaller code, more spills: slower)
-            switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
+        if (nt < 1 || nt > 8) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
+        // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp).  Measured and removed (profiles/r02/solve_ab_c3.txt): the
+        // panel-blocked LDS solver (22.5 ms against 8.0) and the looped-block-column variant (10.6 ms: it spills ~200 tile registers)
+#define RS5_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); break;
+        switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
 #undef RS5_CASE
-        } else if (n + 1 <= 130) {
-            // panel-blocked Cholesky out of LDS, one 256-thread workgroup per pixel (solve_mode = 2: kept for A/B runs)
-            const int na = n + 1;
-            size_t shmem = ((size_t)(na * (na + 1)) / 2 + 4) * sizeof(double) + (size_t)(2 * p + 1 + g.nbw * g.nbw * g.nbw * g.nbw) * sizeof(int);
-            shmem = (shmem + 15) & ~size_t(15);
-            if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_ring_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            LAUNCH(ctx, "bg_ring_solve", k_ring_solve2, dim3((unsigned)P->d), dim3(256), shmem, tab, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-                   ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe);
-        } else return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
     }
     RET(ring_stats_enqueue(ctx, P));                         // what the NEXT fit of this patch asks of the W being written now
     ht.mark("solve launch");

@@ -6,7 +6,7 @@ namespace cnmfe {
 
 __device__ const double rs_fill[2] = {0.0, 1.0};   // what a load reads for an entry with a missing neighbour: identity rows, no select (and no live mask) behind the load
 
-template <int NT, bool LOOP>
+template <int NT>
 __global__ void __launch_bounds__(64, (NT <= 2 ? 4 : (NT <= 3 ? 3 : (NT <= 6 ? 2 : 1))))
 k_ring_solve5(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc, const double *__restrict__ rowsum,
               const unsigned char *__restrict__ active, float *__restrict__ W, int *__restrict__ errflag, int probe) {
@@ -107,7 +107,7 @@ k_ring_solve5(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__res
     __syncthreads();
     // ---- factorisation + substitutions (ring_solve_core.hpp) ----
     double wc[NT];
-    rs_solve_core<NT, LOOP>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
+    rs_solve_core<NT>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
     // the intercept w0 is discarded (fit_ring_model.m:107); neighbours outside the FOV keep weight 0
     if (rq == 0) {
 #pragma unroll

@@ -129,19 +129,8 @@ __device__ __forceinline__ void rs_put_diag(const double4_t &D, double *s_blk, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = D[r];
 }
-// LOOP = false (default): the block columns are unrolled, every tile index a compile-time constant; the NT = 6 kernel is 87 KB of code.
-// LOOP = true (cnmfe_set_option("solve_mode", 6)): the block columns run in a real loop with ONE copy of the 16x16 diagonal step and the
-// tile indices compile-time inside the arms of an if-chain on k: 53 KB (the instruction cache two CUs share holds 64 KB), but hipcc then
-// spills ~200 tile registers around the loop -- measured at 512 x 512, p = 96: 10.6 ms against 8.5 ms unrolled.
-template <int NT, int K>
-__device__ __forceinline__ void rs_step_k(double4_t (&T)[(NT * (NT + 1)) / 2], int k, const double4_t &X1, double *s_blk, int c, int rq) {
-    if constexpr (K < NT) {
-        if (k == K) {
-            rs_step<NT, K>(T, X1);
-            if constexpr (K + 1 < NT) rs_put_diag(T[rs_tix(K + 1, K + 1)], s_blk, c, rq);
-        } else rs_step_k<NT, K + 1>(T, k, X1, s_blk, c, rq);
-    }
-}
+// the block columns are unrolled, every tile index a compile-time constant (the NT = 6 kernel is 87 KB of code; a looped variant with the tile
+// indices in an if-chain spilled ~200 tile registers: 10.6 ms against 8.5 ms, removed in round 3)
 template <int NT, int K>
 __device__ __forceinline__ void rs_factor_unrolled(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq) {
     if constexpr (K < NT) {
@@ -156,21 +145,10 @@ __device__ __forceinline__ void rs_factor_unrolled(double4_t (&T)[(NT * (NT + 1)
         rs_factor_unrolled<NT, K + 1>(T, s_blk, lane, c, rq);
     }
 }
-template <int NT, bool LOOP>
+template <int NT>
 __device__ __forceinline__ void rs_factor(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq) {
     rs_put_diag(T[0], s_blk, c, rq);
-    if constexpr (LOOP) {
-#pragma unroll 1
-        for (int k = 0; k < NT; ++k) {
-            __syncthreads();
-            rs_diag_block(s_blk, lane);
-            double4_t X1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) X1[r] = s_blk[c * RS_DS + rq + 4 * r];
-            __syncthreads();
-            rs_step_k<NT, 0>(T, k, X1, s_blk, c, rq);
-        }
-    } else rs_factor_unrolled<NT, 0>(T, s_blk, lane, c, rq);
+    rs_factor_unrolled<NT, 0>(T, s_blk, lane, c, rq);
 }
 
 
@@ -180,13 +158,13 @@ __device__ __forceinline__ void rs_factor(double4_t (&T)[(NT * (NT + 1)) / 2], d
 //   s_blk   : [16 * RS_DS] LDS, s_part : [4][64] LDS
 //   sc, lam, Tp : s, the ridge, the number of frames (the ones row's own Gram entry)
 //   wc[k]   : on return, w(16 k + c) in every lane with l & 15 == c
-template <int NT, bool LOOP>
+template <int NT>
 __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2], double (*s_vec)[16 * NT], double *s_blk, double (*s_part)[64],
                                               double sc, double lam, double Tp, int lane, int probe, double (&wc)[NT]) {
     constexpr int N = 16 * NT;
     const int c = lane & 15, rq = lane >> 4;
     // ---- block Cholesky ----
-    if (!(probe & 2)) rs_factor<NT, LOOP>(T, s_blk, lane, c, rq);
+    if (!(probe & 2)) rs_factor<NT>(T, s_blk, lane, c, rq);
     if (probe & 4) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) wc[k] = T[rs_tix(k, k)][0];

@@ -1,11 +1,12 @@
-"""A/B of the ring-regression solve kernels on one patch: python scripts/solve_ab.py --cfg c3 [--modes 2,5,6] [--probes 0,1,2,4]
-Every mode fits the same first-run problem (ring re-initialised before each fit), so the W of the modes are comparable entry by entry."""
+"""Phase probes of the ring-regression solve kernel on one patch: python scripts/solve_ab.py --cfg c3 [--probes 0,1,3,7]
+(solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions).  Every run fits the same first-run problem (ring
+re-initialised before each fit).  The --modes argument only repeats the runs: the alternative solve kernels were removed in round 3."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="2,5,6"); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0)
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="5"); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0)
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -24,7 +25,7 @@ Ws = {}
 for mode in [int(x) for x in a.modes.split(",")]:
     for probe in [int(x) for x in a.probes.split(",")]:
         eng.ring_init(0, r)
-        eng.set_option("solve_mode", mode); eng.set_option("solve_probe", probe); eng.profile_reset()
+        eng.set_option("solve_probe", probe); eng.profile_reset()
         _, info = eng.fit_ring_model(0, f.A_init.astype(np.float32), f.C_init)
         eng.synchronize()
         tab = eng.profile_table()

@@ -463,21 +463,6 @@ def test_residual_dma_many_footprints(eng, variant):
     assert rel(got, base) <= 2e-6, rel(got, base)
 
 
-def test_fit_ring_solve_modes_agree(eng):
-    """B2b: the experimental MFMA register-tile solver (solve_mode=3) against the default panel solver (solve_mode=2)."""
-    c = Case(eng, 48, 40, 120, 4, 15, seed=11)
-    A = c.f.A_init.tocsc().astype(np.float32)
-    out = {}
-    for mode in (2, 3, 4):
-        eng.ring_init(0, 15)
-        eng.set_option("solve_mode", mode)
-        eng.fit_ring_model(0, A, c.f.C_init)
-        out[mode] = eng.ring_csr(0).data.copy()
-    eng.set_option("solve_mode", 2)
-    assert rel(out[3], out[2]) <= 1e-5, rel(out[3], out[2])
-    assert rel(out[4], out[2]) <= 1e-5, rel(out[4], out[2])
-
-
 @pytest.mark.parametrize("dims,pdims,ssub,r", [((40, 36), None, 2, 6), ((45, 38), [23, 19], 2, 6), ((42, 39), None, 3, 9)])
 def test_residual_ssub_parity(eng, dims, pdims, ssub, r):
     """bg_ssub > 1 (update_spatial_parallel.m:167-178): imresize down -> W -> imresize up, against the restatement
