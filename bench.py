@@ -89,7 +89,7 @@ def cpu_baseline():
     return out
 
 
-def cpu_baseline_full(which=("c2", "c3")):
+def cpu_baseline_full(which=("c2", "c3"), out_path=None):
     """the float64 NumPy restatement ('CPU restatement, not MATLAB') at full size on this host's cores.
     C2 (256x256x3000, K=200): one iteration timed in full.  C3 (512x512x10000, K=500): spatial + temporal updates in full, the background
     regression (fit_ring_model.m:92-108, an interpreted loop over 262144 pixels) on a fixed 1/64 pixel sample and scaled x64 -- an extrapolation,
@@ -126,6 +126,9 @@ def cpu_baseline_full(which=("c2", "c3")):
         t["workload"] = "%s: %dx%dx%d, K=%d, r=%d, 1 patch, seed %d, deconv_flag=false" % (name, d1, d2, T, K, r, seed)
         res[name] = t
         del o
+        if out_path:                                            # every finished configuration is on disk at once (C3 takes many minutes)
+            with open(out_path, "w") as fh:
+                json.dump(res, fh, indent=1)
     return res
 
 
@@ -176,7 +179,8 @@ def main():
     ap.add_argument("--bg-ssub", type=int, default=1, help="options.bg_ssub (the shipped demo uses 2; the headline metric is quoted at 1)")
     a = ap.parse_args()
     if a.cpu_baseline == "full":
-        print(json.dumps(cpu_baseline_full()))
+        which = tuple(a.config.split(",")) if a.config else ("c2", "c3")
+        print(json.dumps(cpu_baseline_full(which, os.environ.get("CNMFE_CPU_BASELINE_OUT"))))
         return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
