@@ -14,7 +14,67 @@ import cnmfe_oracle as orc
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 IN = os.path.join(GOLD, "matlab_inputs.mat")
 OUT = os.path.join(GOLD, "matlab_outputs.mat")
-needs_matlab = pytest.mark.skipif(not os.path.exists(OUT), reason="tests/golden/matlab_outputs.mat not generated (oracle/matlab/make_fixtures.m needs MATLAB)")
+needs_matlab = pytest.mark.skipif(not os.path.exists(OUT), reason="tests/golden/matlab_outputs.mat not generated (oracle/matlab/make_fixtures.m needs MATLAB or Octave)")
+
+# what every field of matlab_outputs.mat pins: field (or prefix) -> (oracle function, reference file:line, produced by a MathWorks-only toolbox function?)
+PINS = {
+    "nhood_r": ("cnmfe_oracle.get_nhood", "ca_source_extraction/endoscope/get_nhood.m:1-25", False),
+    "fit_W": ("cnmfe_oracle.fit_ring_model (W: first run, second run, no projection, outlier branch)", "endoscope/fit_ring_model.m:1-127", False),
+    "fit_b0": ("cnmfe_oracle.fit_ring_model (b0)", "endoscope/fit_ring_model.m:44", False),
+    "Ysig": ("cnmfe_oracle.residual_ysig", "@Sources2D/update_spatial_parallel.m:162-166", False),
+    "IND_ellipse": ("cnmfe_oracle.determine_search_location", "utilities/determine_search_location.m:57-89", False),
+    "A_hals": ("cnmfe_oracle.HALS_spatial", "utilities/HALS_spatial.m:27-44", False),
+    "A_thresh": ("cnmfe_oracle.HALS_spatial_thresh", "utilities/HALS_spatial_thresh.m:30-53", False),
+    "A_nnls": ("cnmfe_oracle.nnls_spatial / nnls", "endoscope/nnls_spatial.m:26-109", False),
+    "cm": ("cnmfe_oracle.com", "utilities/com.m:20-28", False),
+    "C_hals": ("cnmfe_oracle.HALS_temporal (C)", "utilities/HALS_temporal.m:47-68", False),
+    "Craw_hals": ("cnmfe_oracle.HALS_temporal (C_raw)", "utilities/HALS_temporal.m:62-68", False),
+    "conn": ("cnmfe_oracle.connectivity_constraint (imopen, bwlabel restated)", "endoscope/connectivity_constraint.m:12-18", True),
+    "circ": ("cnmfe_oracle.circular_constraints (medfilt2, imdilate restated)", "endoscope/circular_constraints.m:1-55", True),
+    "thr_comp": ("cnmfe_oracle.threshold_components", "utilities/threshold_components.m", True),
+    "IND_dilate": ("cnmfe_oracle.determine_search_location_dilate", "utilities/determine_search_location.m:89-98", True),
+    "resize_": ("cnmfe_oracle.imresize_scale / imresize_size (MathWorks imresize restated)", "bg_ssub > 1: update_background_parallel.m:137,224", True),
+    "quant": ("cnmfe_oracle.matlab_quantile", "endoscope/fit_ring_model.m:64; OASIS foopsi_oasisAR1.m:93", True),
+    "medfilt": ("cnmfe_oracle._medfilt3", "endoscope/circular_constraints.m:33", True),
+    "sn_tr": ("oasis_oracle.GetSn (pwelch restated)", "OASIS_matlab/functions/GetSn.m:33-47", True),
+    "g0_tr": ("oasis_oracle.estimate_time_constant_ar1", "OASIS_matlab/functions/estimate_time_constant.m:35-66", False),
+    "g_tr": ("oasis_oracle.deconvolveCa_ar1_foopsi (gamma; fminbnd restated)", "OASIS_matlab/packages/oasis/foopsi_oasisAR1.m:122-179", True),
+    "b_tr": ("oasis_oracle.deconvolveCa_ar1_foopsi (baseline)", "foopsi_oasisAR1.m:93-98", True),
+    "c_tr": ("oasis_oracle.oasisAR1 via deconvolveCa (denoised trace)", "OASIS_matlab/packages/oasis/oasisAR1.m:30-109", True),
+    "s_tr": ("oasis_oracle.oasisAR1 via deconvolveCa (spikes)", "oasisAR1.m:109", True),
+    "engine": ("(which interpreter wrote the file)", "-", False),
+    "skipped": ("(groups the interpreter could not run)", "-", False),
+}
+
+
+def _pin_of(field):
+    return next((v for k, v in PINS.items() if field == k or field.startswith(k)), None)
+
+
+def test_pin_map_covers_every_field_the_script_writes(capsys):
+    """every `out.<field>` of oracle/matlab/make_fixtures.m is named in PINS -- the table below is what a committed matlab_outputs.mat pins
+    (run with -s to read it)"""
+    import re
+    src = open(os.path.join(os.path.dirname(GOLD), "..", "oracle", "matlab", "make_fixtures.m")).read()
+    fields = sorted(set(re.findall(r"out\.([A-Za-z_0-9]+)\b", src)) | {"nhood_r15"})
+    missing = [f for f in fields if _pin_of(f) is None]
+    assert not missing, missing
+    have = sio.loadmat(OUT) if os.path.exists(OUT) else {}
+    with capsys.disabled():
+        print("\nmatlab_outputs.mat: %s" % ("present, written by %s" % "".join(np.ravel(have.get("engine", ["?"]))) if have else "ABSENT -- nothing below is pinned yet"))
+        for f in fields:
+            fn, ref, toolbox = _pin_of(f)
+            print("  %-22s %-7s pins %-70s <- %s%s" % (f, "[have]" if any(k.startswith(f) for k in have) else "[none]", fn, ref, "   (MathWorks-toolbox semantics: MATLAB only)" if toolbox else ""))
+
+
+def _engine_is_matlab(o):
+    return "".join(np.ravel(o.get("engine", ["matlab"]))).lower().startswith("matlab")
+
+
+def _need(o, *keys):
+    miss = [k for k in keys if k not in o]
+    if miss:
+        pytest.skip("matlab_outputs.mat has no %s (group skipped by the interpreter that wrote it: %s)" % (miss, "".join(np.ravel(o.get("skipped", [""])))))
 
 
 def rel(a, b):
@@ -52,6 +112,7 @@ def test_inputs_are_the_seeded_ones(case):
 @needs_matlab
 def test_ring_geometry(case):
     o = case["out"]
+    _need(o, "nhood_r15", "nhood_r15_k40")
     for r in (3, 5, 15, 18):
         rs, cs = orc.get_nhood(r)
         assert np.array_equal(np.c_[np.ravel(rs), np.ravel(cs)], o["nhood_r%d" % r])
@@ -62,6 +123,7 @@ def test_ring_geometry(case):
 @needs_matlab
 def test_fit_ring_model_and_residual(case):
     o = case["out"]; c = case
+    _need(o, "fit_W1", "fit_W4", "Ysig")
     snp = c["sn"][c["mask"]][c["ip"]]
     W1, b01 = orc.fit_ring_model(c["Yb"], c["Ab"], c["C"], c["W0"], np.nan, snp, c["ip"], True)
     W2, b02 = orc.fit_ring_model(c["Yb"], c["Ab"], c["C"], W1, np.nan, snp, c["ip"], True)
@@ -77,6 +139,7 @@ def test_fit_ring_model_and_residual(case):
 @needs_matlab
 def test_spatial_temporal(case):
     o = case["out"]; c = case
+    _need(o, "IND_ellipse", "A_hals", "A_nnls", "C_hals", "Ysig")
     IND = orc.determine_search_location(c["z"]["A"], c["d1"], c["d2"])
     assert np.array_equal(IND, o["IND_ellipse"].astype(bool))
     INDp = sp.csc_matrix(IND[c["mask"]][c["ip"]])
@@ -93,6 +156,9 @@ def test_spatial_temporal(case):
 @needs_matlab
 def test_post_processing_and_optional_branches(case):
     o = case["out"]; c = case
+    _need(o, "conn", "circ", "thr_comp", "IND_dilate")
+    if not _engine_is_matlab(o):
+        pytest.skip("written by Octave: imopen / bwlabel / medfilt2 / imdilate there are not the MathWorks implementations the restatement follows")
     imgs = c["z"]["imgs"]
     for k in range(imgs.shape[2]):
         assert rel(orc.connectivity_constraint(imgs[:, :, k]), o["conn"][:, :, k]) <= 1e-12, k
@@ -105,6 +171,9 @@ def test_post_processing_and_optional_branches(case):
 @needs_matlab
 def test_toolbox_restatements(case):
     o = case["out"]; z = case["z"]
+    _need(o, "resize_half", "quant", "medfilt")
+    if not _engine_is_matlab(o):
+        pytest.skip("written by Octave: imresize / quantile / medfilt2 there are not the MathWorks implementations the restatement follows")
     img = z["resize_img"]
     assert rel(orc.imresize_scale(img, 1 / 2), o["resize_half"]) <= 1e-10
     assert rel(orc.imresize_scale(img, 1 / 3), o["resize_third"]) <= 1e-10
@@ -119,6 +188,9 @@ def test_toolbox_restatements(case):
 def test_oasis(case):
     import oasis_oracle as oo
     o = case["out"]; tr = case["z"]["traces"]
+    _need(o, "sn_tr", "g_tr", "c_tr")
+    if not _engine_is_matlab(o):
+        pytest.skip("written by Octave: pwelch and fminbnd there are not the MathWorks implementations the restatement follows")
     for i in range(tr.shape[0]):
         sn = oo.GetSn(tr[i])
         assert abs(sn - float(o["sn_tr"][i])) <= 1e-9 * sn
