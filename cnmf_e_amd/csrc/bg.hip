@@ -941,9 +941,11 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     std::vector<int> lst_ptr, lst_k, blk_nt[4];
     std::vector<short> slot_of;
     if (incr) {
+        // (flat arrays, two passes: a vector of vectors cost 0.4 ms of allocator churn per fit at the headline size, in front of the window projection)
         const int nblk_ = g.nbr * g.nbc;
-        std::vector<std::vector<int>> bl(nblk_);
-        std::vector<int> own(nblk_, -1), seen(nblk_, -1), mark;
+        static thread_local std::vector<int> own, seen, cnt, pairs_b, pairs_k, mark;
+        own.assign(nblk_, -1); seen.assign(nblk_, -1); cnt.assign(nblk_ + 1, 0);
+        pairs_b.clear(); pairs_k.clear();
         for (int k = 0; k < K && has_a; ++k) {
             mark.clear();
             for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
@@ -956,17 +958,24 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                         const int i2 = b_ % g.nbr + di, j2 = b_ / g.nbr + dj;
                         if (i2 < 0 || i2 >= g.nbr || j2 < 0 || j2 >= g.nbc) continue;
                         const int nb_ = j2 * g.nbr + i2;
-                        if (seen[nb_] != k) { seen[nb_] = k; bl[nb_].push_back(k); }
+                        if (seen[nb_] != k) { seen[nb_] = k; pairs_b.push_back(nb_); pairs_k.push_back(k); ++cnt[nb_ + 1]; }
                     }
         }
         lst_ptr.assign(nblk_ + 1, 0);
-        slot_of.assign((size_t)nblk_ * std::max(1, K), (short)-1);
-        for (int b_ = 0; b_ < nblk_ && incr; ++b_) {
-            const int n = (int)bl[b_].size();
-            if (n > WIN_NLB) { incr = false; break; }                       // denser than the window kernel is built for: direct Gram
-            lst_ptr[b_ + 1] = lst_ptr[b_] + n;
-            for (int s_ = 0; s_ < n; ++s_) { lst_k.push_back(bl[b_][s_]); slot_of[(size_t)b_ * K + bl[b_][s_]] = (short)s_; }
-            if (n) blk_nt[(n - 1) >> 4].push_back(b_);
+        for (int b_ = 0; b_ < nblk_; ++b_) {
+            if (cnt[b_ + 1] > WIN_NLB) { incr = false; break; }                     // denser than the window kernel is built for: direct Gram
+            lst_ptr[b_ + 1] = lst_ptr[b_] + cnt[b_ + 1];
+        }
+        if (incr) {
+            lst_k.resize(pairs_k.size());
+            slot_of.assign((size_t)nblk_ * std::max(1, K), (short)-1);
+            std::vector<int> &fill = cnt;                                           // next free slot per block
+            for (int b_ = 0; b_ < nblk_; ++b_) fill[b_] = 0;
+            for (size_t i = 0; i < pairs_k.size(); ++i) {                           // pairs are k-major: every list comes out in ascending k, as before
+                const int b_ = pairs_b[i], k = pairs_k[i], s_ = fill[b_]++;
+                lst_k[lst_ptr[b_] + s_] = k; slot_of[(size_t)b_ * K + k] = (short)s_;
+            }
+            for (int b_ = 0; b_ < nblk_; ++b_) { const int n = lst_ptr[b_ + 1] - lst_ptr[b_]; if (n) blk_nt[(n - 1) >> 4].push_back(b_); }
         }
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);

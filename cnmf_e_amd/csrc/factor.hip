@@ -581,7 +581,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     std::vector<char> upd(K, 0);
     for (int k = 0; k < K; ++k)
         for (int64_t e = A_colptr[k]; e < A_colptr[k + 1] && !upd[k]; ++e) upd[k] = A_val[e] * A_val[e] > 0.f;
-    build_graph(K, csr, d, upd, g);
+    if (upd != nonempty) build_graph(K, csr, d, upd, g);     // (almost always the same set: a stored column without a non-zero value is rare -- reuse the graph above)
     std::vector<int> flat, off;
     for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
     RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
