@@ -1,0 +1,37 @@
+"""What ONE rank of an N-rank c4 run computes per iteration, without the collectives (single process, dist_group = None, only this rank's patches):
+   python scripts/rank_load.py --world 8 [--rank 0]
+An estimate of the per-rank floor of `bench.py --gpus N` (the collectives and the other ranks' stragglers come on top)."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--steps", type=int, default=6)
+a = ap.parse_args()
+import torch
+from cnmf_e_amd import synth
+from cnmf_e_amd.engine import Engine
+from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+d1, d2, T, K, r = 512, 512, 10000, 500, 15
+f = synth.make_factors(d1, d2, T, K, 2)
+eng = Engine(0)
+video = PatchedVideo(d1, d2, T, [128, 128], r, eng, rank=a.rank, world_size=a.world)
+for idx in video.owned:
+    Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()
+    video.upload_block_device(idx, Yb.data_ptr()); del Yb
+s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=5), f.A_init, f.C_init, f.sn)
+def step():
+    t0 = time.perf_counter(); s.update_background_parallel(); t1 = time.perf_counter(); s.update_spatial_parallel(); t2 = time.perf_counter(); s.update_temporal_parallel()
+    return t1 - t0, t2 - t1, time.perf_counter() - t2
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+eng.profile(True); eng.profile_reset()
+t0 = time.perf_counter(); parts = np.zeros(3)
+for _ in range(a.steps):
+    parts += step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+tab = eng.profile_table()
+print("rank %d of %d (%d patches): %.2f ms / iteration; host time in calls: bg %.2f spatial %.2f temporal %.2f ms; kernel sum %.2f ms" % (
+    a.rank, a.world, len(video.owned), 1e3 * dt, *(1e3 * parts / a.steps), sum(v["total_ms"] for v in tab.values()) / a.steps))
+print({k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["total_ms"])[:14]})
