@@ -96,6 +96,7 @@ PROTOTYPES = {
     "cnmfe_hals_temporal_deconv": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32,
                                              C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p, f32p, f32p]),
     "cnmfe_deconv_temporal": (C.c_int, [c_ctx, C.c_int32, C.c_int64, f32p, C.c_int, C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p]),
+    "cnmfe_deconv_temporal_bound": (C.c_int, [c_ctx, C.POINTER(DeconvOpts), f32p, f32p, f32p, f32p, f32p]),
     "cnmfe_post_process_spatial": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, f32p, u8p]),
     "cnmfe_stitch_begin": (C.c_int, [c_ctx, C.c_int32, C.c_int64]),
     "cnmfe_stitch_dims": (C.c_int, [c_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

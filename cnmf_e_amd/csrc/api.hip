@@ -924,6 +924,13 @@ int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, in
     return deconv_all_run(ctx, K, T, C_raw, c_order, opts, C_out, S_out, kernel_pars_out, sn_out);
 }
 
+int cnmfe_deconv_temporal_bound(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out, float *C_raw_out, float *S_out, float *kernel_pars_out, float *sn_out) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (!opts) return fail(CNMFE_EINVAL, "null deconvolution options");
+    CK(hipSetDevice(ctx->device));
+    return deconv_bound_run(ctx, opts, C_out, C_raw_out, S_out, kernel_pars_out, sn_out);
+}
+
 int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr,
                                const int32_t *A_rowidx, const float *A_val, uint8_t *keep) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");

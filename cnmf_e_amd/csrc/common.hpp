@@ -220,6 +220,7 @@ struct cnmfe_ctx {
     // the traces the last cnmfe_hals_temporal[_deconv] / cnmfe_fast_temporal left on the device (C_raw rows, row stride last_t_ldc, and aa): what
     // cnmfe_stitch_add folds into the stitch accumulator without a host round trip
     cnmfe::DevBuf last_craw, last_aa;
+    cnmfe::DevBuf dcv_c, dcv_s, dcv_pars, dcv_sn;          // cnmfe_deconv_temporal_bound: C_raw - b (after the swap with `bound`), S, kernel_pars, sn -- read by the copy stream, so not shared scratch
     int32_t last_t_K = 0; int64_t last_t_ldc = 0, last_t_T = 0; bool last_t_valid = false;
     // overlap-region stitch of update_temporal_parallel.m:264-280: acc[k][0..T) = sum_m aa_m(k) C_raw_m(k,:), acc[k][ld-1..] ... see cnmfe_stitch_begin
     cnmfe::DevBuf stitch;     // K rows of stitch_ld floats: [0, T) the weighted sum, column stitch_ld - 4 the sum of the weights
@@ -293,6 +294,7 @@ __device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned
 int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out);
 int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                       int c_order, float *C_raw_out, float *aa_out);
+int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out, float *C_raw_out, float *S_out, float *pars_out, float *sn_out);
 int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,
                    float *C_out, float *S_out, float *pars_out, float *sn_out);
 int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,

@@ -897,4 +897,52 @@ int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_ord
     return 0;
 }
 
+// deconvTemporal on the bound matrix (cnmfe_deconv_temporal_bound): C_raw read and rewritten (C_raw - b) where it lies, C into a buffer of the context that is
+// then SWAPPED with `bound`; the host copies go out on the copy stream behind an event (as cnmfe_stitch_finish_async)
+int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out, float *C_raw_out, float *S_out, float *pars_out, float *sn_out) {
+    if (!ctx->bound_valid || ctx->bound_K <= 0) return fail(CNMFE_ESTATE, "no bound trace matrix (cnmfe_traces_bind / cnmfe_stitch_finish)");
+    const int32_t K = ctx->bound_K; const int64_t T = ctx->bound_T, ldc = (T + 3) & ~int64_t(3);
+    DeconvCfg c; size_t shmem;
+    RET(deconv_setup(opts, T, 0, c, shmem));
+    c.trace = (int)ctx->opt("deconv_trace", 0);
+    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last downloads still read bound / dcv_*
+    DevBuf &dC = ctx->dcv_c, &dS = ctx->dcv_s, &dPars = ctx->dcv_pars, &dSn = ctx->dcv_sn, &dB = ctx->scr[20], &dList = ctx->scr[5];
+    RET(dC.ensure((size_t)K * ldc * sizeof(float))); RET(dS.ensure((size_t)K * ldc * sizeof(float)));
+    CK(hipMemsetAsync(dC.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    RET(dPars.ensure((size_t)K * sizeof(float))); RET(dSn.ensure((size_t)K * sizeof(float))); RET(dB.ensure((size_t)K * sizeof(float)));
+    CK(hipMemsetAsync(dPars.p, 0, (size_t)K * sizeof(float), ctx->stream));         // fresh time-constant estimate for every trace
+    CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
+    std::vector<int> list(K);
+    for (int k = 0; k < K; ++k) list[k] = k;
+    RET(to_dev(ctx, dList, list.data(), list.size()));
+    DeconvIO io;
+    io.C = dC.as<float>(); io.Craw = ctx->bound.as<float>(); io.S = dS.as<float>(); io.ldc = ldc;
+    io.U = nullptr; io.nptr = nullptr; io.nidx = nullptr; io.nval = nullptr; io.aa = nullptr;
+    io.pars = dPars.as<float>(); io.sn_out = dSn.as<float>(); io.b_out = dB.as<float>();
+    const int batch = 512;
+    for (int k0 = 0; k0 < K; k0 += batch)
+        RET(deconv_launch(ctx, c, shmem, io, dList.as<int>() + k0, std::min(batch, K - k0), ctx->dscr));
+    ctx->bound.swap(dC);                                    // bound = C (row-major), dcv_c = C_raw - b
+    ctx->bound_order = CNMFE_ROWMAJOR;
+    if (C_out || C_raw_out || S_out || pars_out || sn_out) {
+        if (!ctx->copy_stream) {
+            CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            CK(hipEventCreateWithFlags(&ctx->ev_bound_ready, hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&ctx->ev_copy_done, hipEventDisableTiming));
+        }
+        CK(hipEventRecord(ctx->ev_bound_ready, ctx->stream));
+        CK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_bound_ready, 0));
+        const size_t rb = (size_t)T * sizeof(float), pb = (size_t)ldc * sizeof(float);
+        if (C_out) CK(hipMemcpy2DAsync(C_out, rb, ctx->bound.p, pb, rb, K, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (C_raw_out) CK(hipMemcpy2DAsync(C_raw_out, rb, dC.p, pb, rb, K, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (S_out) CK(hipMemcpy2DAsync(S_out, rb, dS.p, pb, rb, K, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (pars_out) CK(hipMemcpyAsync(pars_out, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+        CK(hipEventRecord(ctx->ev_copy_done, ctx->copy_stream));
+        ctx->copy_pending = true;
+    }
+    return 0;
+}
+
 }  // namespace cnmfe

@@ -94,6 +94,16 @@ class DeviceTraces:
         return self.tensor.data_ptr()
 
 
+class BoundOnly:
+    """identity of a trace matrix that exists only as the engine's bound device matrix (stitch_finish(want="bound")): it can be passed where the bound
+    matrix is meant; it has no host values"""
+    def __init__(self, K, T):
+        self.shape = (int(K), int(T)); self.dtype = np.dtype(np.float32); self.ndim = 2
+        self.flags = {"C_CONTIGUOUS": True}
+    def __array__(self, dtype=None, copy=None):
+        raise RuntimeError("this trace matrix was left on the device only (stitch_finish(want='bound')): deconvolve or download it through the engine")
+
+
 class _PinnedBlock:
     """Owner of one pinned host buffer of a LazyHostTraces.  The ctypes array every ndarray view of the buffer is built on holds the only strong
     reference to this object, so the block goes back to the engine's pool -- or is freed, once the engine is closed or gone -- when the LAST view
@@ -530,6 +540,10 @@ class Engine:
             L.check(L.lib.cnmfe_stitch_finish_async(self._ctx, int(bool(subtract_min)), C.cast(out._ptr, L.f32p)))
             self._bound = out
             return out
+        if want == "bound" and K > 0:                    # no host copy at all: the caller goes on with the bound matrix (deconv_temporal_bound)
+            L.check(L.lib.cnmfe_stitch_finish(self._ctx, int(bool(subtract_min)), None, L.ROWMAJOR))
+            self._bound = BoundOnly(K, T)
+            return self._bound
         out = np.empty((K, T), dtype=np.float32) if want else None
         L.check(L.lib.cnmfe_stitch_finish(self._ctx, int(bool(subtract_min)), _p(out, L.f32p), L.ROWMAJOR))
         self._bound = out if (want and K > 0) else None
@@ -568,6 +582,19 @@ class Engine:
         opts = self._dopts(deconv_options)
         L.check(L.lib.cnmfe_deconv_temporal(self._ctx, K, T, _p(Craw, L.f32p), L.ROWMAJOR, C.byref(opts), _p(Cout, L.f32p), _p(S, L.f32p),
                                             _p(pars, L.f32p), _p(sn, L.f32p)))
+        return Cout, Craw, S, pars, sn
+
+    def deconv_temporal_bound(self, deconv_options):
+        """obj.deconvTemporal() on the engine's BOUND trace matrix (the C_raw that stitch_finish left on the device): returns (C, C_raw, S, kernel_pars, sn) as
+        lazy host views (LazyHostTraces: the values arrive in pinned memory behind the kernels, the first read waits for that copy only); C is the
+        engine's bound matrix from here on.  No K x T array crosses PCIe before the call returns."""
+        K, T = self._bound.shape
+        Cout, Craw, S = LazyHostTraces(self, K, T), LazyHostTraces(self, K, T), LazyHostTraces(self, K, T)
+        pars, sn = LazyHostTraces(self, 1, K), LazyHostTraces(self, 1, K)
+        opts = self._dopts(deconv_options)
+        L.check(L.lib.cnmfe_deconv_temporal_bound(self._ctx, C.byref(opts), C.cast(Cout._ptr, L.f32p), C.cast(Craw._ptr, L.f32p), C.cast(S._ptr, L.f32p),
+                                                  C.cast(pars._ptr, L.f32p), C.cast(sn._ptr, L.f32p)))
+        self._bound = Cout
         return Cout, Craw, S, pars, sn
 
     def post_process_spatial(self, A_full, d1, d2):

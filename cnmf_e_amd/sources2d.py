@@ -431,6 +431,26 @@ def mat_data_info(f):
 # --------------------------------------------------------------------------------------
 # Sources2D
 # --------------------------------------------------------------------------------------
+class _LazyRow:
+    """a length-K vector that arrives with a LazyHostTraces of shape (1, K) (kernel_pars, neuron_sn of deconvTemporal on the bound matrix)"""
+    def __init__(self, lazy):
+        self._lazy = lazy
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self._lazy)[0]
+        return a.copy() if (copy or dtype is None) else a.astype(dtype)
+    def __getitem__(self, k):
+        return np.asarray(self._lazy)[0][k]
+    def __len__(self):
+        return self._lazy.shape[1]
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(np.asarray(self._lazy)[0], name)
+
+for _op in ("add", "sub", "mul", "truediv", "radd", "rsub", "rmul", "rtruediv", "lt", "le", "gt", "ge", "eq", "ne", "and", "rand"):
+    setattr(_LazyRow, "__%s__" % _op, (lambda op: lambda self, *a: getattr(np.asarray(self._lazy)[0], "__%s__" % op)(*a))(_op))
+_LazyRow.__hash__ = object.__hash__
+
 _UNSET = object()
 
 
@@ -654,6 +674,12 @@ class Sources2D:
             return self.C_raw.copy()
         v = self.video
         rows = np.arange(K)[v.rank::v.world_size] if (self.dist is not None and v.world_size > 1) else np.arange(K)
+        if rows.size == K and hasattr(self.engine, "deconv_temporal_bound") and self.C_raw is getattr(self.engine, "_bound", None):
+            # the stitched C_raw is the engine's bound matrix: deconvolved where it lies; C, C_raw - b, S come back lazily (pinned copies behind the kernels)
+            C, Craw, S, kp, sn = self.engine.deconv_temporal_bound(self.options.deconv_options)
+            self.C, self.C_raw, self.S = C, Craw, S
+            self.P["kernel_pars"], self.P["neuron_sn"] = _LazyRow(kp), _LazyRow(sn)
+            return C
         if rows.size == K:                                               # not sharded: no row gather / scatter of K x T arrays on the host
             # the ABI writes ck_raw - b into C_raw in place: only a PRIVATE plain array may be handed over -- with deconv_flag = false C_raw
             # is the same object as C / C_prev (and the engine's bound matrix), and a DeviceTraces' host cache must not diverge from its tensor
@@ -1074,7 +1100,8 @@ class Sources2D:
         # without deconvolution nobody needs the values on the host right away: the engine keeps the matrix bound and streams a copy into pinned
         # memory behind the kernels (LazyHostTraces); the next background fit is set up while the temporal sweep is still running
         lazy = (not o.deconv_flag) and getattr(eng, "supports_lazy_traces", False)
-        C_raw = eng.stitch_finish(subtract_min=not o.deconv_flag, want="lazy" if lazy else True)       # :279-280, :285
+        bound_deconv = o.deconv_flag and not sharded and hasattr(eng, "deconv_temporal_bound") and getattr(eng, "supports_lazy_traces", False)
+        C_raw = eng.stitch_finish(subtract_min=not o.deconv_flag, want="lazy" if lazy else ("bound" if bound_deconv else True))       # :279-280, :285
         if o.deconv_flag:                                                                             # :282-283  obj.C = obj.deconvTemporal()
             self.C_raw = C_raw
             self.C = self.deconvTemporal()

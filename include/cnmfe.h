@@ -237,6 +237,12 @@ int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const in
 int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order,
                           const cnmfe_deconv_opts *opts, float *C_out, float *S_out,
                           float *kernel_pars_out, float *sn_out);
+/* The same on the BOUND trace matrix (cnmfe_traces_bind, cnmfe_stitch_finish*): the stitched C_raw is deconvolved where it lies, the denoised C becomes
+ * the bound matrix (what the next background / spatial / temporal update reads with (NULL, CNMFE_BOUND)), C_raw - b and S stay in the context -- no
+ * K x T array crosses PCIe on the critical path.  The host outputs (row-major K x T / K floats, PINNED memory from cnmfe_host_alloc, any may be NULL) are
+ * written by a second stream behind the kernels: cnmfe_stitch_wait waits for them.  CNMFE_ESTATE without a bound matrix. */
+int cnmfe_deconv_temporal_bound(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out, float *C_raw_out, float *S_out,
+                                float *kernel_pars_out, float *sn_out);
 
 /* ---- T5: the overlap-region stitch of the temporal update, on the device
  * @Sources2D/update_temporal_parallel.m:264-280:

@@ -742,3 +742,24 @@ def test_bench_two_ranks_self_spawned_on_one_device():
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
     assert line["value"] > 0 and "c4tiny" in line["config"]["workload"]
+
+
+def test_deconv_temporal_on_the_bound_matrix_equals_the_host_path(eng):
+    """cnmfe_deconv_temporal_bound: the stitched C_raw deconvolved where it lies (C becomes the bound matrix, the five outputs arrive lazily in pinned
+    memory) against cnmfe_deconv_temporal on the same values through host arrays -- bit for bit; afterwards a call that is handed the returned C passes
+    (NULL, CNMFE_BOUND) and reads the deconvolved traces."""
+    from cnmf_e_amd.engine import LazyHostTraces
+    from cnmf_e_amd import _lib as L
+    Y = _ar1_traces(6, 2100, seed=13)
+    opts = dict(type="ar1", method="foopsi", smin=-5.0, optimize_pars=True, optimize_b=True, max_tau=100.0)
+    Cr, Crawr, Sr, parsr, snr = eng.deconv_temporal(Y.copy(), opts)
+    eng.bind_traces(Y)
+    C, Craw, S, pars, sn = eng.deconv_temporal_bound(opts)
+    assert isinstance(C, LazyHostTraces) and eng._bound is C
+    assert np.array_equal(np.asarray(C), Cr) and np.array_equal(np.asarray(Craw), Crawr) and np.array_equal(np.asarray(S), Sr)
+    assert np.array_equal(np.asarray(pars)[0], parsr) and np.array_equal(np.asarray(sn)[0], snr)
+    ptr, order, _ = eng._targs(C, 6, 2100)
+    assert ptr is None and order == L.BOUND
+    # the bound matrix now holds C: a second deconvolution of the bound matrix deconvolves C, not Y
+    C2 = np.asarray(eng.deconv_temporal_bound(opts)[0])
+    assert np.array_equal(C2, eng.deconv_temporal(Cr.copy(), opts)[0])
