@@ -858,8 +858,7 @@ int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64
         for (size_t l = 0; l < levels.size(); ++l)
             RET(deconv_launch(ctx, c, shmem, io, dLvl + off[l], (int)levels[l].size(), scr));
     }
-    CK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return 0;                                                // (the caller waits when it takes results back to the host)
 }
 
 int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,

@@ -614,10 +614,15 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
         RET(temporal_deconv_sweeps(ctx, dopts, T, K, maxIter, g.levels, dLvl.as<int>(), off, dC.as<float>(), dCraw.as<float>(), dS.as<float>(), ldc,
                                    dU.as<float>(), dNptr.as<int>(), dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dPars.as<float>(), dSn.as<float>()));
+        // nothing asked back (the sharded-free update_temporal_parallel keeps C_raw and aa on the device for the stitch and re-estimates the time constants
+        // in deconvTemporal): kernel_pars is then input only and the call returns with the sweeps in flight
+        const bool want_back = C_out || C_raw_out || S_out || sn_out;
         RET(download_traces(ctx, dS.as<float>(), ldc, S_out, K, T, c_order));
-        CK(hipMemcpyAsync(kernel_pars, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
+        if (want_back) {
+            CK(hipMemcpyAsync(kernel_pars, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+        }
     }
     ctx->last_t_K = K; ctx->last_t_ldc = ldc; ctx->last_t_T = T; ctx->last_t_valid = true;      // C_raw rows + aa stay on the device for cnmfe_stitch_add
     RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));

@@ -559,7 +559,7 @@ class Engine:
         Craw = np.empty_like(Cm) if want_all is not None else None      # want_all=None: nothing but aa comes back (C_raw stays on the device for stitch_add)
         Cout = np.empty_like(Cm) if want_all else None
         S = np.empty_like(Cm) if want_all else None
-        aa = np.empty(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32)
+        aa = np.empty(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32) if want_all is not None else None   # want_all=None: the call returns with the sweeps in flight
         pars = np.zeros(K, dtype=np.float32) if kernel_pars is None else np.ascontiguousarray(kernel_pars, dtype=np.float32).copy()
         opts = self._dopts(deconv_options)
         L.check(L.lib.cnmfe_hals_temporal_deconv(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,

@@ -227,7 +227,9 @@ typedef struct cnmfe_deconv_opts {
 
 /* [C, C_raw, results_deconv] = HALS_temporal(Y, A, C, maxIter, deconv_options)   utilities/HALS_temporal.m:70-104
  * (the deconvolution branch: per row GetSn + deconvolveCa inside the Gauss-Seidel sweep).
- * kernel_pars[K] in/out (0 = not yet estimated), S_out / sn_out receive results_deconv.S / .sn. */
+ * kernel_pars[K] in/out (0 = not yet estimated), S_out / sn_out receive results_deconv.S / .sn.
+ * With C_out, C_raw_out, S_out and sn_out all NULL nothing is copied back -- kernel_pars is then input only -- and the call returns with the sweeps in
+ * flight (C_raw and aa stay on the device for cnmfe_stitch_add). */
 int cnmfe_hals_temporal_deconv(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr,
                                const int32_t *A_rowidx, const float *A_val, const float *C_in, int c_order,
                                int32_t maxIter, const cnmfe_deconv_opts *opts, float *kernel_pars,
