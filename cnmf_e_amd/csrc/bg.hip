@@ -900,7 +900,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         g0.nr = P->nr; g0.nc = P->nc; g0.nr_b = P->nr_b; g0.nc_b = P->nc_b; g0.roff = P->roff; g0.coff = P->coff; g0.d = P->d; g0.d_b = P->d_b;
         LAUNCH(ctx, "bg_b0", k_b0, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->ymean_d.as<double>(), g0,
                has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCm.as<double>(), P->b0.as<double>());
-        CK(hipStreamSynchronize(ctx->stream));
+        // (no drain: every upload above went through the pinned arena -- or, too large for it, waited itself -- and what reads b0 is stream-ordered behind this)
         P->ysig_valid = false;
         return 0;
     }
