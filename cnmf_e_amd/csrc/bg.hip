@@ -580,20 +580,21 @@ __device__ __forceinline__ void win_body4(const float4 *__restrict__ Y4, const B
         for (int a = 0; a < 4; ++a) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
     struct Frag { float4 y[4]; float4 t[NT]; };
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load = [&](int64_t s) {
         Frag f;
         const int64_t c = s + kq;
         const bool on = c < c1;
+        // (`cond ? *p : z4` on two lvalues becomes a select of ADDRESSES: z4 then lives in scratch memory and the kernel's first launch makes the runtime
+        //  set its scratch arena up -- an intermittent 0.5-0.8 s stall of the first fit, profiles/r03/README.md)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) f.y[a] = (on && ya[a]) ? ya[a][c * g.d_b] : z4;
+        for (int a = 0; a < 4; ++a) { f.y[a] = make_float4(0.f, 0.f, 0.f, 0.f); if (on && ya[a]) f.y[a] = ya[a][c * g.d_b]; }
 #pragma unroll
-        for (int b = 0; b < NT; ++b) f.t[b] = (on && tb[b]) ? tb[b][c] : z4;
+        for (int b = 0; b < NT; ++b) { f.t[b] = make_float4(0.f, 0.f, 0.f, 0.f); if (on && tb[b]) f.t[b] = tb[b][c]; }
         return f;
     };
     const bool gw = wave < NT;                              // wave w also owns row-group w of G
     const int ks = g.kstride;
-    auto comp = [](const float4 &v, int m) -> float { return m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w; };
+    auto comp = [](float4 v, int m) -> float { return m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w; };
     auto mm = [&](const Frag &f) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -616,15 +617,21 @@ __device__ __forceinline__ void win_body4(const float4 *__restrict__ Y4, const B
             }
         }
     };
-    Frag f[AHEAD];
+    if constexpr (NT >= 3) {
+        // 33..64 traces: 160 accumulator registers leave no room for a second fragment set -- no software prefetch (the other wave of the SIMD covers the
+        // latency; with it the body spilled to scratch memory)
+        for (int64_t s = c0; s < c1; s += 4) { const Frag f = load(s); mm(f); }
+    } else {
+        Frag f[AHEAD];
 #pragma unroll
-    for (int d = 0; d < AHEAD; ++d) f[d] = load(c0 + 4 * d);
-    for (int64_t s = c0; s < c1; s += 4 * AHEAD) {
+        for (int d = 0; d < AHEAD; ++d) f[d] = load(c0 + 4 * d);
+        for (int64_t s = c0; s < c1; s += 4 * AHEAD) {
 #pragma unroll
-        for (int d = 0; d < AHEAD; ++d) {
-            const Frag nx = load(s + 4 * (AHEAD + d));
-            mm(f[d]);
-            f[d] = nx;
+            for (int d = 0; d < AHEAD; ++d) {
+                const Frag nx = load(s + 4 * (AHEAD + d));
+                mm(f[d]);
+                f[d] = nx;
+            }
         }
     }
     // D layout (fp64 16x16): row = (lane>>4) + 4r, col = lane&15
@@ -660,8 +667,11 @@ __global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4,
     }
 }
 
-// frame strides 1, 2, 4: 16-byte loads over the video's chunks (the used frames are components of them)
-__global__ void __launch_bounds__(256, 2) k_win_proj4(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
+// frame strides 1, 2, 4: 16-byte loads over the video's chunks (the used frames are components of them).  BIG = the blocks with 49..64 traces, a kernel of
+// their own: together with the other bodies the 4-group body did not fit 256 registers, and a kernel that spills needs scratch memory, whose arena the
+// runtime sets up at the kernel's FIRST launch -- measured as an intermittent 0.5-0.8 s inside the first fit of a process (profiles/r03/README.md)
+template <bool BIG>
+__global__ void __launch_bounds__(256, (BIG ? 1 : 2)) k_win_proj4(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
                                                       const int *__restrict__ lst_k, const int *__restrict__ blk_list, int nseg, double *__restrict__ Ut, int64_t ut_stride,
                                                       double *__restrict__ Gb, int64_t gb_stride) {
     const int blk = blk_list[blockIdx.x / nseg], seg = blockIdx.x % nseg;
@@ -670,11 +680,11 @@ __global__ void __launch_bounds__(256, 2) k_win_proj4(const float4 *__restrict__
     const int64_t nchunk = (g.T + 3) >> 2;
     const int64_t cseg = ((nchunk + nseg - 1) / nseg + 7) & ~int64_t(7);
     const int64_t c0 = seg * cseg, c1 = c0 + cseg < nchunk ? c0 + cseg : nchunk;
-    switch ((nl + 15) >> 4) {
+    if constexpr (BIG) win_body4<4>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb);
+    else switch ((nl + 15) >> 4) {
         case 1: win_body4<1>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         case 2: win_body4<2>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         case 3: win_body4<3>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
-        case 4: win_body4<4>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
         default: break;
     }
 }
@@ -1003,10 +1013,15 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX; gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
         RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
         RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
-        if (g.kstride == 1 || g.kstride == 2 || g.kstride == 4)
-            LAUNCH(ctx, "bg_win_proj", k_win_proj4, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
-                   dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
-        else
+        if (g.kstride == 1 || g.kstride == 2 || g.kstride == 4) {
+            const int nbig = (int)blk_nt[3].size();              // blall starts with the longest lists
+            if (nbig)
+                LAUNCH(ctx, "bg_win_proj", k_win_proj4<true>, dim3((unsigned)(nbig * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
+                       dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+            if (nb_ > nbig)
+                LAUNCH(ctx, "bg_win_proj", k_win_proj4<false>, dim3((unsigned)((nb_ - nbig) * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(),
+                       dLk.as<int>(), dBl.as<int>() + nbig, nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+        } else
         LAUNCH(ctx, "bg_win_proj", k_win_proj, dim3((unsigned)(nb_ * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
                dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
         proj_queued = true;
