@@ -147,6 +147,19 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
     return 0;
 }
 
+// copy of a pinned-arena slot to device memory by a kernel (to_dev, common.hpp): both ends are 256-byte granular (PinArena::take, DevBuf::ensure)
+__global__ void __launch_bounds__(256) k_pin_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t bytes) {
+    if (bytes > (size_t(8) << 20)) { CK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream)); return 0; }
+    const size_t n16 = (bytes + 15) / 16;
+    const unsigned nb = (unsigned)std::min<size_t>((n16 + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_pin_copy, dim3(nb), dim3(256), 0, ctx->stream, (const uint4 *)src_pinned, (uint4 *)dst, n16);
+    CK(hipGetLastError());
+    return 0;
+}
+
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
     if (P->ymean_valid) return 0;
     if (P->frames_uploaded < P->T) return fail(CNMFE_ESTATE, "block has %lld of %lld frames uploaded", (long long)P->frames_uploaded, (long long)P->T);

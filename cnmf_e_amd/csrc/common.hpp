@@ -246,14 +246,17 @@ struct HostTrace {
     }
 };
 inline Patch *get_patch(cnmfe_ctx *ctx, int id) { auto it = ctx->patches.find(id); return it == ctx->patches.end() ? nullptr : it->second; }
+int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t bytes);   // api.hip
 // upload a host vector to a DevBuf on the context stream
 template <class T> inline int to_dev(cnmfe_ctx *ctx, DevBuf &b, const T *h, size_t n) {
     RET(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
     if (!n) return 0;
     if (void *st = ctx->pin.take(n * sizeof(T), ctx->stream)) {             // staged: `h` is free again when this returns
         memcpy(st, h, n * sizeof(T));
-        CK(hipMemcpyAsync(b.p, st, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-        return 0;
+        // small uploads go by a copy KERNEL that reads the pinned arena over PCIe, not by hipMemcpyAsync: the copy engine also serves the big asynchronous
+        // downloads of the traces (20-60 MB behind every temporal update), and an upload of a few KB queued behind one of those held the next call's first
+        // kernel back by 0.5-1.5 ms (profiles/r03/gap_analysis_*.txt)
+        return pinned_to_dev(ctx, b.p, st, n * sizeof(T));
     }
     CK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));                                   // too large for the arena: straight from the caller's buffer
