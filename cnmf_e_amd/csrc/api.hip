@@ -105,7 +105,7 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
     if (order == CNMFE_BOUND) {                            // the matrix bound with cnmfe_traces_bind: a device copy, no PCIe transfer
         if (!ctx->bound_valid || ctx->bound_K != K || ctx->bound_T != T)
             return fail(CNMFE_ESTATE, "no bound trace matrix of %d x %lld (cnmfe_traces_bind)", K, (long long)T);
-        CK(hipMemcpyAsync(dst.p, ctx->bound.p, (size_t)K * ldc * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        CK(hipMemcpyAsync(dst.p, ctx->bound.p, (size_t)K * ldc * sizeof(float), hipMemcpyDeviceToDevice, ctx->st()));
         return 0;
     }
     if (!C) return fail(CNMFE_EINVAL, "null trace matrix");
@@ -119,16 +119,16 @@ int upload_traces(cnmfe_ctx *ctx, DevBuf &dst, const float *C, int32_t K, int64_
         LAUNCH(ctx, "gather_rows", k_gather_rows, dim3((unsigned)K), dim3(256), 0, ctx->bound.as<float4>(), ldc >> 2, dIdx.as<int>(), dst.as<float4>());
         return 0;                                          // (the index array went through the pinned arena: the caller may drop it)
     }
-    CK(hipMemsetAsync(dst.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dst.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
     if (order == CNMFE_ROWMAJOR) {
-        CK(hipMemcpy2DAsync(dst.p, ldc * sizeof(float), C, T * sizeof(float), T * sizeof(float), K, hipMemcpyDefault, ctx->stream));
+        CK(hipMemcpy2DAsync(dst.p, ldc * sizeof(float), C, T * sizeof(float), T * sizeof(float), K, hipMemcpyDefault, ctx->st()));
     } else {
         RET(ctx->stage.ensure((size_t)K * T * sizeof(float)));
-        CK(hipMemcpyAsync(ctx->stage.p, C, (size_t)K * T * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemcpyAsync(ctx->stage.p, C, (size_t)K * T * sizeof(float), hipMemcpyHostToDevice, ctx->st()));
         dim3 g((unsigned)((T + 31) / 32), (unsigned)((K + 31) / 32)), b(32, 8);
         LAUNCH(ctx, "transpose_in", k_transpose_in, g, b, 0, ctx->stage.as<float>(), dst.as<float>(), K, T, ldc);
     }
-    CK(hipStreamSynchronize(ctx->stream));                 // the caller's matrix was read in place: it is free again when this returns
+    CK(hipStreamSynchronize(ctx->st()));                 // the caller's matrix was read in place: it is free again when this returns
     return 0;
 }
 
@@ -136,29 +136,46 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
     if (K == 0 || !C) return 0;
     if (order == CNMFE_BOUND || order == CNMFE_BOUND_ROWS) order = ctx->bound_order;   // outputs of a call on the bound matrix come back in ITS layout
     if (order == CNMFE_ROWMAJOR) {
-        CK(hipMemcpy2DAsync(C, T * sizeof(float), dC, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpy2DAsync(C, T * sizeof(float), dC, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->st()));
     } else {
         RET(ctx->stage.ensure((size_t)K * T * sizeof(float)));
         dim3 g((unsigned)((T + 31) / 32), (unsigned)((K + 31) / 32)), b(32, 8);
         LAUNCH(ctx, "transpose_out", k_transpose_out, g, b, 0, dC, ldc, ctx->stage.as<float>(), K, T);
-        CK(hipMemcpyAsync(C, ctx->stage.p, (size_t)K * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(C, ctx->stage.p, (size_t)K * T * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     }
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 
 // copy of a pinned-arena slot to device memory by a kernel (to_dev, common.hpp): both ends are 256-byte granular (PinArena::take, DevBuf::ensure)
-__global__ void __launch_bounds__(256) k_pin_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+// (blockIdx.y = segment: the held-back uploads of cnmfe_ctx::st go out as one dispatch)
+__global__ void __launch_bounds__(256) k_pin_copy(PinSegs s) {
+    const int g = blockIdx.y;
+    const uint4 *__restrict__ src = s.src[g]; uint4 *__restrict__ dst = s.dst[g];
+    const unsigned n16 = s.n16[g];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
 }
+static thread_local cnmfe_ctx *g_pin_ctx = nullptr;        // the context of this thread that may hold uploads back
+void pin_flush_thread() { if (g_pin_ctx && g_pin_ctx->npseg) g_pin_ctx->flush_copies(); }
 int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t bytes) {
-    if (bytes > (size_t(8) << 20)) { CK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream)); return 0; }
-    const size_t n16 = (bytes + 15) / 16;
-    const unsigned nb = (unsigned)std::min<size_t>((n16 + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_pin_copy, dim3(nb), dim3(256), 0, ctx->stream, (const uint4 *)src_pinned, (uint4 *)dst, n16);
-    CK(hipGetLastError());
+    if (bytes > (size_t(8) << 20)) { CK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->st())); return 0; }
+    if (ctx->npseg == PIN_NSEG) ctx->flush_copies();
+    const int i = ctx->npseg++;
+    ctx->pseg.src[i] = (const uint4 *)src_pinned; ctx->pseg.dst[i] = (uint4 *)dst; ctx->pseg.n16[i] = (unsigned)((bytes + 15) / 16);
+    g_pin_ctx = ctx;
     return 0;
 }
+}  // namespace cnmfe
+void cnmfe_ctx::flush_copies() {
+    if (!npseg) return;
+    unsigned mx = 0;
+    for (int i = 0; i < npseg; ++i) mx = std::max(mx, pseg.n16[i]);
+    for (int i = npseg; i < cnmfe::PIN_NSEG; ++i) { pseg.src[i] = nullptr; pseg.dst[i] = nullptr; pseg.n16[i] = 0; }
+    const unsigned nb = std::min<unsigned>((mx + 255) / 256, 256);
+    const int n = npseg; npseg = 0;
+    hipLaunchKernelGGL(cnmfe::k_pin_copy, dim3(nb, (unsigned)n), dim3(256), 0, stream_, pseg);      // (a failed launch is reported by the next LAUNCH's hipGetLastError)
+}
+namespace cnmfe {
 
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
     if (P->ymean_valid) return 0;
@@ -172,7 +189,7 @@ int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
     RET(P->Yc4.ensure((size_t)P->Tc * P->d_b * sizeof(float4)));
     LAUNCH(ctx, "center4", k_center4, dim3((unsigned)((P->d_b + 255) / 256), (unsigned)P->Tc), dim3(256), 0,
            P->Y.as<float>(), P->ymean_f.as<float>(), P->d_b, P->T, P->Yc4.as<float4>());
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     (void)hipFree(P->Y.p); P->Y.p = nullptr; P->Y.cap = 0;
     P->ymean_valid = true;
     return 0;
@@ -206,11 +223,11 @@ int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P) {
     if (!P->stat_host) CK(hipHostMalloc(&P->stat_host, bytes, hipHostMallocDefault));
     if (!P->stat_ev) CK(hipEventCreateWithFlags(&P->stat_ev, hipEventDisableTiming));
     RET(P->stat_dev.ensure(64));
-    CK(hipMemsetAsync(P->stat_dev.p, 0, 64, ctx->stream));
+    CK(hipMemsetAsync(P->stat_dev.p, 0, 64, ctx->st()));
     LAUNCH(ctx, "ring_pmax", k_ring_pmax, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, P->W.as<float>(), P->d, P->p, P->stat_dev.as<int>());
-    CK(hipMemcpyAsync(P->stat_host, P->stat_dev.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipMemcpy2DAsync((char *)P->stat_host + 64, sizeof(float), P->W.p, P->d * sizeof(float), sizeof(float), P->p, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipEventRecord(P->stat_ev, ctx->stream));
+    CK(hipMemcpyAsync(P->stat_host, P->stat_dev.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipMemcpy2DAsync((char *)P->stat_host + 64, sizeof(float), P->W.p, P->d * sizeof(float), sizeof(float), P->p, hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipEventRecord(P->stat_ev, ctx->st()));
     P->stat_valid = true;
     return 0;
 }
@@ -227,19 +244,19 @@ int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first) { return ring_stats_ge
 int ctx_errflag(cnmfe_ctx *ctx, int **dflag) {
     if (!ctx->errflag.p) {
         RET(ctx->errflag.ensure(sizeof(int)));
-        CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->stream));
+        CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
     }
     *dflag = ctx->errflag.as<int>();
     return 0;
 }
 // waits for the stream and reports what its kernels raised since the last call
 int ctx_check_errflag(cnmfe_ctx *ctx) {
-    if (!ctx->errflag.p) { CK(hipStreamSynchronize(ctx->stream)); return 0; }
+    if (!ctx->errflag.p) { CK(hipStreamSynchronize(ctx->st())); return 0; }
     int h = 0;
-    CK(hipMemcpyAsync(&h, ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(&h, ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     if (!h) return 0;
-    CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->stream));
+    CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
     if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 32 footprints of A_prev (flag %d)", h);
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
 }
@@ -294,7 +311,7 @@ static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out,
     const int32_t K = ctx->stitch_K; const int64_t T = ctx->stitch_T, ldc = (T + 3) & ~int64_t(3);
     CK(hipSetDevice(ctx->device));
     RET(ctx->bound.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
-    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last download still reads `bound`
+    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->st(), ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last download still reads `bound`
     if (K > 0) LAUNCH(ctx, "stitch_finish", k_stitch_finish, dim3((unsigned)K), dim3(256), 0, ctx->stitch.as<float>(), ctx->stitch_ld, T, subtract_min, ctx->bound.as<float>(), ldc);
     ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = (c_order == CNMFE_COLMAJOR) ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR; ctx->bound_valid = K > 0;
     ctx->stitch_open = false;
@@ -305,7 +322,7 @@ static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out,
             CK(hipEventCreateWithFlags(&ctx->ev_bound_ready, hipEventDisableTiming));
             CK(hipEventCreateWithFlags(&ctx->ev_copy_done, hipEventDisableTiming));
         }
-        CK(hipEventRecord(ctx->ev_bound_ready, ctx->stream));
+        CK(hipEventRecord(ctx->ev_bound_ready, ctx->st()));
         CK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_bound_ready, 0));
         CK(hipMemcpy2DAsync(C_raw_out, T * sizeof(float), ctx->bound.p, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->copy_stream));
         CK(hipEventRecord(ctx->ev_copy_done, ctx->copy_stream));
@@ -353,7 +370,9 @@ cnmfe_ctx::~cnmfe_ctx() {
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (ev_bound_ready) (void)hipEventDestroy(ev_bound_ready);
     if (ev_copy_done) (void)hipEventDestroy(ev_copy_done);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (cnmfe::g_pin_ctx == this) cnmfe::g_pin_ctx = nullptr;
+    for (auto e : tickets) (void)hipEventDestroy(e);
+    if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 extern "C" {
@@ -369,7 +388,7 @@ cnmfe_ctx *cnmfe_create(int device) {
     if (hipSetDevice(device) != hipSuccess) { fail(CNMFE_EHIP, "hipSetDevice(%d) failed", device); return nullptr; }
     cnmfe_ctx *ctx = new cnmfe_ctx();
     ctx->device = device;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    if (hipStreamCreate(&ctx->stream_) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
     if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
     return ctx;
 }
@@ -377,13 +396,13 @@ cnmfe_ctx *cnmfe_create(int device) {
 void cnmfe_destroy(cnmfe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->st());
     delete ctx;
 }
 
 int cnmfe_synchronize(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     if (ctx->copy_stream) CK(hipStreamSynchronize(ctx->copy_stream));
     return ctx_check_errflag(ctx);
 }
@@ -413,7 +432,7 @@ int cnmfe_patch_create(cnmfe_ctx *ctx, int patch_id, const int32_t pr[4], const 
     P->d = (int64_t)P->nr * P->nc; P->d_b = (int64_t)P->nr_b * P->nc_b;
     int rc = P->Y.ensure((size_t)P->d_b * T * sizeof(float));
     if (rc) { delete P; return rc; }
-    if (hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * T * sizeof(float), ctx->stream) != hipSuccess) { delete P; return fail(CNMFE_EHIP, "hipMemsetAsync of the upload staging failed"); }
+    if (hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * T * sizeof(float), ctx->st()) != hipSuccess) { delete P; return fail(CNMFE_EHIP, "hipMemsetAsync of the upload staging failed"); }
     P->frame_seen.assign((size_t)T, 0);
     P->Tc = (T + 3) / 4;
     ctx->patches[patch_id] = P;
@@ -431,7 +450,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     if (memspace != CNMFE_HOST && memspace != CNMFE_DEVICE) return fail(CNMFE_EINVAL, "unknown memspace %d", memspace);
     if (!P->Y.p) {                                   // a re-upload after the block was finalised: start over with a zeroed staging copy
         RET(P->Y.ensure((size_t)P->d_b * P->T * sizeof(float)));
-        CK(hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * P->T * sizeof(float), ctx->stream));
+        CK(hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * P->T * sizeof(float), ctx->st()));
         P->frames_uploaded = 0;
         P->frame_seen.assign((size_t)P->T, 0);
     }
@@ -440,7 +459,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     float *dst = P->Y.as<float>() + t0 * P->d_b;
     int64_t n = nt * P->d_b;
     if (dtype == CNMFE_F32) {
-        CK(hipMemcpyAsync(dst, Y, (size_t)n * 4, memspace == CNMFE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+        CK(hipMemcpyAsync(dst, Y, (size_t)n * 4, memspace == CNMFE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->st()));
     } else {
         // stage in slabs of <= 64 Mi elements, convert on device
         const int64_t slab = int64_t(1) << 26;
@@ -449,7 +468,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
             const void *src = (const char *)Y + (size_t)o * esz;
             if (memspace == CNMFE_HOST) {
                 RET(ctx->stage.ensure((size_t)m * esz));
-                CK(hipMemcpyAsync(ctx->stage.p, src, (size_t)m * esz, hipMemcpyHostToDevice, ctx->stream));
+                CK(hipMemcpyAsync(ctx->stage.p, src, (size_t)m * esz, hipMemcpyHostToDevice, ctx->st()));
                 src = ctx->stage.p;
             }
             dim3 g((unsigned)std::min<int64_t>((m + 255) / 256, 65535)), b(256);
@@ -459,10 +478,10 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
                 case CNMFE_U8:  LAUNCH(ctx, "convert", k_convert<uint8_t>, g, b, 0, (const uint8_t *)src, dst + o, m); break;
                 default:        LAUNCH(ctx, "convert", k_convert<__half>, g, b, 0, (const __half *)src, dst + o, m); break;
             }
-            if (memspace == CNMFE_HOST) CK(hipStreamSynchronize(ctx->stream));   // staging buffer reuse
+            if (memspace == CNMFE_HOST) CK(hipStreamSynchronize(ctx->st()));   // staging buffer reuse
         }
     }
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     std::fill(P->frame_seen.begin() + t0, P->frame_seen.begin() + t0 + nt, (uint8_t)1);
     P->frames_uploaded += nt;
     P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false;
@@ -475,8 +494,8 @@ int cnmfe_get_ymean(cnmfe_ctx *ctx, int patch_id, double *out) {
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
     CK(hipSetDevice(ctx->device));
     RET(ensure_ymean(ctx, P));
-    CK(hipMemcpyAsync(out, P->ymean_d.p, P->d_b * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(out, P->ymean_d.p, P->d_b * sizeof(double), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 
@@ -504,10 +523,10 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     RET(to_dev(ctx, P->ring_dc, P->dc.data(), P->dc.size()));
     RET(P->W.ensure((size_t)P->p * P->d * sizeof(float)));
     RET(P->b0.ensure(P->d * sizeof(double)));
-    CK(hipMemsetAsync(P->b0.p, 0, P->d * sizeof(double), ctx->stream));          // initComponents_parallel.m:221
+    CK(hipMemsetAsync(P->b0.p, 0, P->d * sizeof(double), ctx->st()));          // initComponents_parallel.m:221
     LAUNCH(ctx, "ring_init", k_ring_init, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
            P->W.as<float>(), P->d, P->nr, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->prect[0], P->prect[2], P->d1, P->d2);
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     P->stat_valid = false;
     if (P->stat_host) { (void)hipHostFree(P->stat_host); P->stat_host = nullptr; }      // sized by the number of ring offsets
     P->ring_ready = true; P->ysig_valid = false; P->base_valid = false;   // (the kept covariance table covers the sub-tiles THIS ring needs)
@@ -540,8 +559,8 @@ int cnmfe_ring_get_csr(cnmfe_ctx *ctx, int patch_id, int64_t *rowptr, int32_t *c
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
     CK(hipSetDevice(ctx->device));
     std::vector<float> W((size_t)P->p * P->d);
-    CK(hipMemcpyAsync(W.data(), P->W.p, W.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(W.data(), P->W.p, W.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     int64_t e = 0;
     for (int64_t m = 0; m < P->d; ++m) {
         rowptr[m] = e;
@@ -573,8 +592,8 @@ int cnmfe_ring_set_values(cnmfe_ctx *ctx, int patch_id, const float *val) {
             W[(size_t)i * P->d + m] = val[e++];
         }
     }
-    CK(hipMemcpyAsync(P->W.p, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(P->W.p, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     P->stat_valid = false;
     P->ysig_valid = false;
     return 0;
@@ -597,8 +616,8 @@ int cnmfe_b0_get(cnmfe_ctx *ctx, int patch_id, float *b0) {
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
     CK(hipSetDevice(ctx->device));
     std::vector<double> tmp(P->d);
-    CK(hipMemcpyAsync(tmp.data(), P->b0.p, P->d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(tmp.data(), P->b0.p, P->d * sizeof(double), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     for (int64_t i = 0; i < P->d; ++i) b0[i] = (float)tmp[i];
     return 0;
 }
@@ -610,8 +629,8 @@ int cnmfe_b0_set(cnmfe_ctx *ctx, int patch_id, const float *b0) {
     CK(hipSetDevice(ctx->device));
     std::vector<double> tmp(P->d);
     for (int64_t i = 0; i < P->d; ++i) tmp[i] = (double)b0[i];
-    CK(hipMemcpyAsync(P->b0.p, tmp.data(), P->d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(P->b0.p, tmp.data(), P->d * sizeof(double), hipMemcpyHostToDevice, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     P->ysig_valid = false;
     return 0;
 }
@@ -656,7 +675,7 @@ int cnmfe_set_noise(cnmfe_ctx *ctx, int patch_id, const float *sn_block) {
     if (!sn_block) return fail(CNMFE_EINVAL, "null sn_block");
     CK(hipSetDevice(ctx->device));
     RET(to_dev(ctx, P->sn_b, sn_block, (size_t)P->d_b));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     P->sn_ready = true;
     return 0;
 }
@@ -718,6 +737,33 @@ int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
     if (!A_out && nnz) return fail(CNMFE_EINVAL, "null A_out");
     CK(hipSetDevice(ctx->device));
     return spatial_fetch(ctx, A_out, nnz);
+}
+
+int cnmfe_update_spatial_fetch_async(cnmfe_ctx *ctx, float *A_out_pinned, int64_t nnz, int64_t *ticket) {
+    if (!ctx || !ticket) return fail(CNMFE_EINVAL, "null context / ticket");
+    if (!A_out_pinned && nnz) return fail(CNMFE_EINVAL, "null A_out");
+    CK(hipSetDevice(ctx->device));
+    if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
+    if (nnz) CK(hipMemcpyAsync(A_out_pinned, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    size_t t = 0;
+    while (t < ctx->tickets.size() && ctx->ticket_busy[t]) ++t;
+    if (t == ctx->tickets.size()) {
+        hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->tickets.push_back(e); ctx->ticket_busy.push_back(0);
+    }
+    CK(hipEventRecord(ctx->tickets[t], ctx->st()));
+    ctx->ticket_busy[t] = 1;
+    *ticket = (int64_t)t;
+    return 0;
+}
+
+int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (ticket < 0 || (size_t)ticket >= ctx->tickets.size() || !ctx->ticket_busy[ticket]) return fail(CNMFE_ESTATE, "ticket %lld is not outstanding", (long long)ticket);
+    CK(hipSetDevice(ctx->device));
+    CK(hipEventSynchronize(ctx->tickets[ticket]));
+    ctx->ticket_busy[ticket] = 0;
+    return 0;
 }
 
 int cnmfe_update_spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx,
@@ -809,7 +855,7 @@ int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T) {
     CK(hipSetDevice(ctx->device));
     const int64_t ld = ((T + 3) & ~int64_t(3)) + 4;
     RET(ctx->stitch.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float)));
-    CK(hipMemsetAsync(ctx->stitch.p, 0, (size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(ctx->stitch.p, 0, (size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float), ctx->st()));
     ctx->stitch_K = K; ctx->stitch_T = T; ctx->stitch_ld = ld; ctx->stitch_open = true;
     return 0;
 }
@@ -840,7 +886,7 @@ int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld) {
     if (!ctx || !dev_acc || !ld) return fail(CNMFE_EINVAL, "null argument");
     if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
     CK(hipSetDevice(ctx->device));
-    CK(hipStreamSynchronize(ctx->stream));                 // the caller's collective runs on ITS stream: everything added so far must have landed
+    CK(hipStreamSynchronize(ctx->st()));                 // the caller's collective runs on ITS stream: everything added so far must have landed
     *dev_acc = ctx->stitch.as<float>(); *ld = ctx->stitch_ld;
     return 0;
 }
@@ -876,6 +922,31 @@ void *cnmfe_host_alloc(size_t bytes) {
 }
 void cnmfe_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// A(mask, cols) of a CSC matrix (what the reference writes as sparse indexing, e.g. update_spatial_parallel.m:87-91,96-97): host code, no device involved.
+int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const float *val, const int32_t *lut, int64_t ncand, const int64_t *cand,
+                          int keep_all, int64_t cap, int64_t *out_ind, int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nkept) {
+    if (!colptr || !rowidx || !val || !lut || (ncand > 0 && !cand) || !out_ind || !out_colptr || !nkept || (cap > 0 && (!out_rowidx || !out_val)))
+        return fail(CNMFE_EINVAL, "cnmfe_csc_select_rows: null argument");
+    int64_t n = 0, nc = 0;
+    out_colptr[0] = 0;
+    for (int64_t j = 0; j < ncand; ++j) {
+        const int64_t k = cand[j];
+        if (j > 0 && k <= cand[j - 1]) return fail(CNMFE_EINVAL, "cnmfe_csc_select_rows: columns must be ascending");
+        const int64_t n0 = n;
+        double s = 0.0;
+        for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
+            const int32_t loc = lut[rowidx[e]];
+            if (loc < 0) continue;
+            if (n >= cap) return fail(CNMFE_EINVAL, "cnmfe_csc_select_rows: output capacity %lld exceeded", (long long)cap);
+            out_rowidx[n] = loc; out_val[n] = val[e]; s += (double)val[e]; ++n;
+        }
+        if (keep_all || s > 0.0) { out_ind[nc] = k; out_colptr[++nc] = n; }
+        else n = n0;                                       // sum(A(mask, k)) > 0 fails: the column is not selected
+    }
+    *nkept = nc;
+    return 0;
+}
+
 int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order) {
     if (!ctxs || n <= 0) return fail(CNMFE_EINVAL, "no contexts");
     for (int i = 0; i < n; ++i) {
@@ -901,14 +972,14 @@ int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float
             int rc = g_rccl.GroupStart();
             for (int i = 0; i < n && rc == 0; ++i) {
                 CK(hipSetDevice(ctxs[i]->device));
-                rc = g_rccl.AllReduce(ctxs[i]->stitch.p, ctxs[i]->stitch.p, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, ctxs[i]->rccl_comm, ctxs[i]->stream);
+                rc = g_rccl.AllReduce(ctxs[i]->stitch.p, ctxs[i]->stitch.p, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, ctxs[i]->rccl_comm, ctxs[i]->st());
             }
             const int rc2 = g_rccl.GroupEnd();
             if (rc != 0 || rc2 != 0) return fail(CNMFE_EHIP, "ncclAllReduce of the stitch accumulator failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "?");
         }
     }
     for (int i = 0; i < n; ++i) RET(stitch_finish_one(ctxs[i], subtract_min, i == 0 ? C_raw_out : nullptr, c_order));
-    for (int i = 0; i < n; ++i) { CK(hipSetDevice(ctxs[i]->device)); CK(hipStreamSynchronize(ctxs[i]->stream)); }
+    for (int i = 0; i < n; ++i) { CK(hipSetDevice(ctxs[i]->device)); CK(hipStreamSynchronize(ctxs[i]->st())); }
     return 0;
 }
 
@@ -920,9 +991,9 @@ int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int 
     if (c_order != CNMFE_ROWMAJOR && c_order != CNMFE_COLMAJOR) return fail(CNMFE_EINVAL, "bad c_order");
     CK(hipSetDevice(ctx->device));
     int64_t ldc;
-    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // a lazy download may still read `bound` (as stitch_finish_one)
+    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->st(), ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // a lazy download may still read `bound` (as stitch_finish_one)
     RET(upload_traces(ctx, ctx->bound, C, K, T, c_order, &ldc));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = c_order; ctx->bound_valid = true;
     return 0;
 }

@@ -26,20 +26,25 @@ inline int fail(int code, const char *fmt, ...) {
     return cnmfe::fail(CNMFE_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)
 #define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
 
+void pin_flush_thread();      // api.hip: enqueue the small uploads this thread's context still holds back (see cnmfe_ctx::st)
+
 // ---- owned device buffer -----------------------------------------------------
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) { pin_flush_thread(); (void)hipFree(p); } }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p) { pin_flush_thread(); (void)hipFree(p); p = nullptr; cap = 0; }     // (an upload into the old allocation may still be held back)
         size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return fail(CNMFE_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
         cap = want; return 0;
     }
+    // for buffers that change hands (swap) between the context's scratch and the patches: every one of them grows to the largest request seen (`hw`),
+    // otherwise a buffer sized for one patch's traces is re-allocated -- hipFree drains the device -- whenever it lands under a patch with more
+    int ensure_hw(size_t bytes, size_t &hw) { if (bytes > hw) hw = bytes; return ensure(hw); }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); }
 };
@@ -81,9 +86,10 @@ struct Profiler {
 // launch wrapper: LAUNCH(ctx, "name", kernel, grid, block, shmem, args...)
 #define LAUNCH(ctx, name, kern, grid, block, shmem, ...) do { \
     cnmfe::Profiler::Rec pr_; bool pon_ = (ctx)->prof.on && (ctx)->prof.want(name); \
-    if (pon_) (ctx)->prof.begin(name, (ctx)->stream, pr_); \
-    hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
-    if (pon_) (ctx)->prof.end((ctx)->stream, pr_); \
+    hipStream_t lst_ = (ctx)->st(); \
+    if (pon_) (ctx)->prof.begin(name, lst_, pr_); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, lst_, __VA_ARGS__); \
+    if (pon_) (ctx)->prof.end(lst_, pr_); \
     hipError_t le_ = hipGetLastError(); \
     if (le_ != hipSuccess) return cnmfe::fail(CNMFE_EHIP, "launch %s failed: %s", name, hipGetErrorString(le_)); \
 } while (0)
@@ -174,12 +180,12 @@ struct PinArena {
         return 0;
     }
     // nullptr: the request does not fit half the arena (the caller copies straight from its buffer and waits)
-    void *take(size_t n, hipStream_t st) {
+    template <class F> void *take(size_t n, F &&stream_of) {      // stream_of(): asked for only when the halves switch (it sends the held-back uploads first)
         n = (n + 255) & ~size_t(255);
         if (!p || n > cap / 2) return nullptr;
         const size_t end = (size_t)(half + 1) * (cap / 2);
         if (off + n > end) {
-            (void)hipEventRecord(ev[half], st); ev_set[half] = true;
+            (void)hipEventRecord(ev[half], stream_of()); ev_set[half] = true;
             half ^= 1; off = (size_t)half * (cap / 2);
             if (ev_set[half]) (void)hipEventSynchronize(ev[half]);
         }
@@ -189,13 +195,26 @@ struct PinArena {
 };
 }  // namespace cnmfe
 
+namespace cnmfe {
+// Small uploads out of the pinned arena are not enqueued one by one: to_dev() notes (destination, arena slot, length) here, and whatever next asks for
+// the stream -- a launch, a memset, a copy, a wait: cnmfe_ctx::st() -- first sends all of them as ONE copy kernel.  A call's ten or twenty index
+// lists and tables then cost one dispatch instead of one each (44 per patch and iteration in the 4 x 4-patch configuration: 700 dependent
+// 4-microsecond dispatches, 6 ms of GPU time line per iteration, profiles/r03/gap_analysis_c4.txt).
+constexpr int PIN_NSEG = 24;
+struct PinSegs { const uint4 *src[PIN_NSEG]; uint4 *dst[PIN_NSEG]; unsigned n16[PIN_NSEG]; };
+}  // namespace cnmfe
+
 struct cnmfe_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream_ = nullptr;
+    cnmfe::PinSegs pseg; int npseg = 0;
+    void flush_copies();                                   // api.hip
+    hipStream_t st() { if (npseg) flush_copies(); return stream_; }   // the compute stream, every held-back upload enqueued first
     cnmfe::PinArena pin;
     int64_t spatial_nnz = -1;                              // values of the last cnmfe_update_spatial still in scr[6] (deferred fetch)
     hipStream_t copy_stream = nullptr;                     // device -> pinned host downloads that should not hold up the compute stream
     hipEvent_t ev_bound_ready = nullptr, ev_copy_done = nullptr; bool copy_pending = false;
+    std::vector<hipEvent_t> tickets; std::vector<char> ticket_busy;   // cnmfe_update_spatial_fetch_async / cnmfe_ticket_wait
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)
@@ -211,6 +230,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
     cnmfe::DevBuf rowsum;     // [blk][256] double
     cnmfe::DevBuf tmp[16];    // small scratch
+    size_t hw_cc = 0, hw_cm = 0, hw_wa[3] = {0, 0, 0};     // high-water sizes of the buffers that rotate through tmp[1], tmp[2], tmp[8..10] (DevBuf::ensure_hw)
     cnmfe::DevBuf inc[7];     // incremental ring regression: block footprint lists, U~, trace sums
     cnmfe::DevBuf stage;      // upload staging
     // per-call device scratch of the factor updates (factor.hip, deconv.hip): grown on demand, NEVER freed between calls -- a hipMalloc /
@@ -251,15 +271,15 @@ int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t byte
 template <class T> inline int to_dev(cnmfe_ctx *ctx, DevBuf &b, const T *h, size_t n) {
     RET(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
     if (!n) return 0;
-    if (void *st = ctx->pin.take(n * sizeof(T), ctx->stream)) {             // staged: `h` is free again when this returns
+    if (void *st = ctx->pin.take(n * sizeof(T), [ctx] { return ctx->st(); })) {             // staged: `h` is free again when this returns
         memcpy(st, h, n * sizeof(T));
         // small uploads go by a copy KERNEL that reads the pinned arena over PCIe, not by hipMemcpyAsync: the copy engine also serves the big asynchronous
         // downloads of the traces (20-60 MB behind every temporal update), and an upload of a few KB queued behind one of those held the next call's first
         // kernel back by 0.5-1.5 ms (profiles/r03/gap_analysis_*.txt)
         return pinned_to_dev(ctx, b.p, st, n * sizeof(T));
     }
-    CK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));                                   // too large for the arena: straight from the caller's buffer
+    CK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));                                   // too large for the arena: straight from the caller's buffer
     return 0;
 }
 // [k][t] row-major fp32 copy of a K x T matrix given in `order`; device result has row stride ldc (multiple of 4)
@@ -310,6 +330,7 @@ int ring_first_run(cnmfe_ctx *ctx, Patch *P, bool *first);
 int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P);                    // after W changed on the stream: count + row 1 to pinned memory, event
 int ring_stats_get(cnmfe_ctx *ctx, Patch *P, int *pmax, bool *first); // waits for that event only (falls back to a fresh evaluation)
 int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean);
+int upload_centered(cnmfe_ctx *ctx, DevBuf &stage, const float *C, int32_t K, int64_t T, int order, DevBuf &Cc, DevBuf &Cmean, int64_t *ldc_out);
 int ctx_errflag(cnmfe_ctx *ctx, int **dflag);            // the device error word (allocated and cleared on first use)
 int ctx_check_errflag(cnmfe_ctx *ctx);                   // after a stream sync: CNMFE_ESTATE if a kernel raised it (and clears it)
 }  // namespace cnmfe

@@ -753,7 +753,7 @@ int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     DevBuf &dSn = ctx->tmp[14];
     RET(dSn.ensure((size_t)P->d * sizeof(float)));
     LAUNCH(ctx, "spatial_sn_pixels", k_sn_pixels, dim3((unsigned)P->d), dim3(256), shmem, c, P->ysig.as<float4>(), P->d, dSn.as<float>());
-    CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     return ctx_check_errflag(ctx);
 }
 
@@ -788,8 +788,8 @@ int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out) {
     DevBuf &dSn = ctx->tmp[14];
     RET(dSn.ensure((size_t)P->d_b * sizeof(float)));
     LAUNCH(ctx, "estimate_noise", k_sn_video, dim3((unsigned)P->d_b), dim3(256), shmem, c, P->Yc4.as<float4>(), P->d_b, P->ymean_f.as<float>(), dSn.as<float>());
-    CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d_b * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)P->d_b * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 
@@ -871,11 +871,11 @@ int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_ord
     int64_t ldc;
     RET(upload_traces(ctx, dCraw, C_raw, K, T, c_order, &ldc));
     RET(dC.ensure((size_t)K * ldc * sizeof(float))); RET(dS.ensure((size_t)K * ldc * sizeof(float)));
-    CK(hipMemsetAsync(dC.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
-    CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dC.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
+    CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
     RET(dPars.ensure((size_t)K * sizeof(float))); RET(dSn.ensure((size_t)K * sizeof(float))); RET(dB.ensure((size_t)K * sizeof(float)));
-    CK(hipMemsetAsync(dPars.p, 0, (size_t)K * sizeof(float), ctx->stream));         // fresh time-constant estimate for every trace
-    CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dPars.p, 0, (size_t)K * sizeof(float), ctx->st()));         // fresh time-constant estimate for every trace
+    CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->st()));
     std::vector<int> list(K);
     for (int k = 0; k < K; ++k) list[k] = k;
     RET(to_dev(ctx, dList, list.data(), list.size()));
@@ -890,9 +890,9 @@ int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_ord
     RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));
     RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw, K, T, c_order));
     RET(download_traces(ctx, dS.as<float>(), ldc, S_out, K, T, c_order));
-    if (pars_out) CK(hipMemcpyAsync(pars_out, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    if (pars_out) CK(hipMemcpyAsync(pars_out, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 
@@ -904,14 +904,14 @@ int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out
     DeconvCfg c; size_t shmem;
     RET(deconv_setup(opts, T, 0, c, shmem));
     c.trace = (int)ctx->opt("deconv_trace", 0);
-    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last downloads still read bound / dcv_*
+    if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->st(), ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last downloads still read bound / dcv_*
     DevBuf &dC = ctx->dcv_c, &dS = ctx->dcv_s, &dPars = ctx->dcv_pars, &dSn = ctx->dcv_sn, &dB = ctx->scr[20], &dList = ctx->scr[5];
     RET(dC.ensure((size_t)K * ldc * sizeof(float))); RET(dS.ensure((size_t)K * ldc * sizeof(float)));
-    CK(hipMemsetAsync(dC.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
-    CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dC.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
+    CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
     RET(dPars.ensure((size_t)K * sizeof(float))); RET(dSn.ensure((size_t)K * sizeof(float))); RET(dB.ensure((size_t)K * sizeof(float)));
-    CK(hipMemsetAsync(dPars.p, 0, (size_t)K * sizeof(float), ctx->stream));         // fresh time-constant estimate for every trace
-    CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dPars.p, 0, (size_t)K * sizeof(float), ctx->st()));         // fresh time-constant estimate for every trace
+    CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->st()));
     std::vector<int> list(K);
     for (int k = 0; k < K; ++k) list[k] = k;
     RET(to_dev(ctx, dList, list.data(), list.size()));
@@ -930,7 +930,7 @@ int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out
             CK(hipEventCreateWithFlags(&ctx->ev_bound_ready, hipEventDisableTiming));
             CK(hipEventCreateWithFlags(&ctx->ev_copy_done, hipEventDisableTiming));
         }
-        CK(hipEventRecord(ctx->ev_bound_ready, ctx->stream));
+        CK(hipEventRecord(ctx->ev_bound_ready, ctx->st()));
         CK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_bound_ready, 0));
         const size_t rb = (size_t)T * sizeof(float), pb = (size_t)ldc * sizeof(float);
         if (C_out) CK(hipMemcpy2DAsync(C_out, rb, ctx->bound.p, pb, rb, K, hipMemcpyDeviceToHost, ctx->copy_stream));

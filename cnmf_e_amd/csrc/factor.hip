@@ -183,20 +183,24 @@ __global__ void __launch_bounds__(256) k_proj_temporal(const float4 *__restrict_
     }
 }
 
-// ---- T2: V(k,k') = <A(:,k), A(:,k')> on the overlap pairs: merge of two sorted columns per thread ----
-__global__ void k_ata_pairs(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
-                            const int *__restrict__ nk, const int *__restrict__ nidx, int nn, float *__restrict__ nval) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- T2: V(k,k') = <A(:,k), A(:,k')> on the overlap pairs: one WAVE per pair -- lanes stride the shorter column and look their row up in the
+// other by bisection (both sorted); a two-pointer merge per thread was a chain of ~300 dependent loads, 75 us whatever the size of the problem ----
+__global__ void __launch_bounds__(256) k_ata_pairs(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
+                                                   const int *__restrict__ nk, const int *__restrict__ nidx, int nn, float *__restrict__ nval) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nn) return;
-    const int k = nk[i], k2 = nidx[i];
-    int64_t a = colptr[k], ae = colptr[k + 1], b = colptr[k2], be = colptr[k2 + 1];
+    int k = nk[i], k2 = nidx[i];
+    if (colptr[k + 1] - colptr[k] > colptr[k2 + 1] - colptr[k2]) { const int t = k; k = k2; k2 = t; }
+    const int64_t a0 = colptr[k], a1 = colptr[k + 1], b0 = colptr[k2], b1 = colptr[k2 + 1];
     double s = 0;
-    while (a < ae && b < be) {
-        const int ra = erow[a], rb = erow[b];
-        if (ra == rb) { s += (double)aval[a] * (double)aval[b]; ++a; ++b; }
-        else if (ra < rb) ++a; else ++b;
+    for (int64_t a = a0 + lane; a < a1; a += 64) {
+        const int r = erow[a];
+        int64_t lo = b0, hi = b1;                            // first entry of column k2 with row >= r
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (erow[mid] < r) lo = mid + 1; else hi = mid; }
+        if (lo < b1 && erow[lo] == r) s += (double)aval[a] * (double)aval[lo];
     }
-    nval[i] = (float)s;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) nval[i] = (float)s;
 }
 
 // ---- T3: one Gauss-Seidel level of HALS_temporal (no-deconvolution branch :62-68) --------------------
@@ -372,8 +376,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     DevBuf &dColptr = S_[0], &dErow = S_[1], &dEcol = S_[2], &dRptr = S_[3], &dRcol = S_[4], &dRsrc = S_[5], &dAval = S_[6], &dU = S_[7], &dPart = S_[8], &dV = S_[9], &dPairs = S_[10], &dSn = S_[11], &dLvl = S_[12];
     HostTrace ht(ctx, "spatial");
     int64_t ldc;
-    RET(upload_traces(ctx, dC, C, K, T, c_order, &ldc));
-    RET(center_traces(ctx, dC.as<float>(), ldc, K, T, dCc, dCm));
+    RET(upload_centered(ctx, dC, C, K, T, c_order, dCc, dCm, &ldc));
     // A restricted to the IND pattern (A(~active_pixel) = 0, HALS_spatial.m:26); NNLS starts from 0 (:32)
     std::vector<float> aval(nnz, 0.f);
     std::vector<int32_t> ecol(nnz);
@@ -414,7 +417,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     ht.mark("graph");
     RET(to_dev(ctx, dPairs, g.pairs.data(), g.pairs.size()));
     RET(dV.ensure((size_t)K * K * sizeof(float)));
-    CK(hipMemsetAsync(dV.p, 0, (size_t)K * K * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dV.p, 0, (size_t)K * K * sizeof(float), ctx->st()));
     LAUNCH(ctx, "spatial_pair_gram", k_pair_gram, dim3((unsigned)g.pairs.size()), dim3(256), 0, dCc.as<float>(), ldc, T, dPairs.as<int2>(), K, dV.as<float>());
     if (algorithm == CNMFE_SPATIAL_NNLS) {
         const int maxN = (int)param;
@@ -446,13 +449,13 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     ht.mark("sweep launches");
     ctx->spatial_nnz = nnz;                                  // the result stays in scr[6] until the next spatial update (cnmfe_update_spatial_fetch)
     if (!A_out) return 0;                                    // deferred: the caller does other host work under the sweeps and fetches afterwards
-    CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     return ctx_check_errflag(ctx);                           // the wait, and what the kernels queued since the last one had to report
 }
 
 int spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
     if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
-    if (nnz) CK(hipMemcpyAsync(A_out, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (nnz) CK(hipMemcpyAsync(A_out, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     return ctx_check_errflag(ctx);
 }
 
@@ -497,7 +500,7 @@ int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colp
     RET(to_dev(ctx, dAval, av.data(), (size_t)nnz));
     RET(to_dev(ctx, dInv, inv.data(), (size_t)K));
     RET(dU.ensure((size_t)K * ldc * sizeof(float)));
-    CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+    CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
     const int64_t Tc = (T + 3) / 4;
     const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
     const int64_t tchunk = (Tc + nchunk - 1) / nchunk;
@@ -529,8 +532,8 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     RET(to_dev(ctx, dAval, A_val, (size_t)nnz));
     RET(dU.ensure((size_t)K * ldc * sizeof(float)));
     RET(dCraw.ensure((size_t)K * ldc * sizeof(float)));
-    CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
-    CK(hipMemsetAsync(dCraw.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));             // C_raw = zeros(K,T)  (:45)
+    CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
+    CK(hipMemsetAsync(dCraw.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));             // C_raw = zeros(K,T)  (:45)
     // T1
     const int64_t Tc = (T + 3) / 4;
     const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
@@ -538,7 +541,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     bool term_applied = false;
     auto reproject = [&]() -> int {                             // fold the pending term into Ysig and project again
         RET(residual_materialize(ctx, P));
-        CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));
+        CK(hipMemsetAsync(dU.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));
         LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
         return 0;
@@ -549,7 +552,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
         RET(dOvf.ensure(64));
-        CK(hipMemsetAsync(dOvf.p, 0, 64, ctx->stream));
+        CK(hipMemsetAsync(dOvf.p, 0, 64, ctx->st()));
         const int rc_ = residual_term_project(ctx, P, K, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(), dU.as<float>(), ldc, dOvf.as<int>());
         if (rc_ < 0) return rc_;
         if (rc_ > 0) RET(reproject());
@@ -573,7 +576,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     const int nn = (int)nidx.size();
     RET(to_dev(ctx, dNk, nk.data(), nk.size())); RET(to_dev(ctx, dNidx, nidx.data(), nidx.size())); RET(to_dev(ctx, dNptr, nptr.data(), nptr.size()));
     RET(dNval.ensure((size_t)std::max(1, nn) * sizeof(float)));
-    LAUNCH(ctx, "temporal_ata_pairs", k_ata_pairs, dim3((nn + 255) / 256), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
+    LAUNCH(ctx, "temporal_ata_pairs", k_ata_pairs, dim3((nn + 3) / 4), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
            dNk.as<int>(), dNidx.as<int>(), nn, dNval.as<float>());
     // T3's level schedule only needs WHICH neurons are updated (ind_update = find(aa > 0), :51): aa(k) = sum of squares of column k is positive
     // exactly when some stored value squares to a non-zero float, so the schedule is built here, under the projection kernel, instead of
@@ -588,8 +591,8 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     ht.mark("csr + graph + lists + levels");
     std::vector<float> nval(nn);
     int ovf = 0;
-    CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (term_applied) CK(hipMemcpyAsync(&ovf, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    if (term_applied) CK(hipMemcpyAsync(&ovf, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
     RET(ctx_check_errflag(ctx));                                // the wait for A'A; also what the residual's kernels had to report
     ht.mark("wait for A'A (sync)");
     if (ovf) RET(reproject());                                  // a footprint near more than 512 traces: the list kernel gave up
@@ -608,10 +611,10 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     } else {
         DevBuf &dS = S_[19], &dPars = S_[21], &dSn = S_[22];
         RET(dS.ensure((size_t)K * ldc * sizeof(float)));
-        CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->stream));                 // S = zeros(K,T)  (:55)
+        CK(hipMemsetAsync(dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));                 // S = zeros(K,T)  (:55)
         RET(to_dev(ctx, dPars, kernel_pars, (size_t)K));
         RET(dSn.ensure((size_t)K * sizeof(float)));
-        CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->stream));
+        CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->st()));
         RET(temporal_deconv_sweeps(ctx, dopts, T, K, maxIter, g.levels, dLvl.as<int>(), off, dC.as<float>(), dCraw.as<float>(), dS.as<float>(), ldc,
                                    dU.as<float>(), dNptr.as<int>(), dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dPars.as<float>(), dSn.as<float>()));
         // nothing asked back (the sharded-free update_temporal_parallel keeps C_raw and aa on the device for the stitch and re-estimates the time constants
@@ -619,16 +622,16 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         const bool want_back = C_out || C_raw_out || S_out || sn_out;
         RET(download_traces(ctx, dS.as<float>(), ldc, S_out, K, T, c_order));
         if (want_back) {
-            CK(hipMemcpyAsync(kernel_pars, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-            if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipStreamSynchronize(ctx->stream));
+            CK(hipMemcpyAsync(kernel_pars, dPars.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+            if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+            CK(hipStreamSynchronize(ctx->st()));
         }
     }
     ctx->last_t_K = K; ctx->last_t_ldc = ldc; ctx->last_t_T = T; ctx->last_t_valid = true;      // C_raw rows + aa stay on the device for cnmfe_stitch_add
     RET(download_traces(ctx, dC.as<float>(), ldc, C_out, K, T, c_order));
     RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw_out, K, T, c_order));
     if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));
-    if (C_out || C_raw_out) CK(hipStreamSynchronize(ctx->stream));
+    if (C_out || C_raw_out) CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 
@@ -647,11 +650,11 @@ int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, c
     DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dBox = S_[13], &dKeep = S_[14];
     RET(to_dev(ctx, dBox, box.data(), box.size()));
     RET(dKeep.ensure((size_t)nnz));
-    CK(hipMemsetAsync(dKeep.p, 0, (size_t)nnz, ctx->stream));
+    CK(hipMemsetAsync(dKeep.p, 0, (size_t)nnz, ctx->st()));
     LAUNCH(ctx, "spatial_connectivity", k_connectivity, dim3(K), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
            dBox.as<int4>(), d1, d2, dKeep.as<unsigned char>());
-    CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->st()));
     return ctx_check_errflag(ctx);
 }
 
@@ -696,11 +699,11 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
     RET(to_dev(ctx, dAval, A_val, (size_t)nnz));
     RET(to_dev(ctx, dBox, box.data(), box.size()));
     RET(dKeep.ensure((size_t)nnz));
-    CK(hipMemsetAsync(dKeep.p, 0, (size_t)nnz, ctx->stream));
+    CK(hipMemsetAsync(dKeep.p, 0, (size_t)nnz, ctx->st()));
     LAUNCH(ctx, "spatial_connectivity", k_connectivity, dim3(K), dim3(256), 0, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(),
            dBox.as<int4>(), d1, d2, dKeep.as<unsigned char>());
-    CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 

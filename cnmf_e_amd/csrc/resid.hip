@@ -12,10 +12,11 @@
 
 namespace cnmfe {
 
-// row means (double) and centred copy of a [k][ldc] trace matrix
-__global__ void k_center_traces(const float *__restrict__ C, int64_t ldc, int64_t T, float *__restrict__ Cc, double *__restrict__ Cmean) {
+// row means (double) and centred copy of a [k][ldc] trace matrix; with `idx`, row k of the result is row idx[k] of C (the selected rows of the bound
+// matrix are centred where they lie: no gathered copy in between)
+__global__ void k_center_traces(const float *__restrict__ C, int64_t ldc, int64_t T, float *__restrict__ Cc, double *__restrict__ Cmean, const int *__restrict__ idx) {
     int k = blockIdx.x;
-    const float *row = C + (int64_t)k * ldc;
+    const float *row = C + (int64_t)(idx ? idx[k] : k) * ldc;
     __shared__ double red[256];
     double s = 0;
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) s += row[t];
@@ -28,10 +29,37 @@ __global__ void k_center_traces(const float *__restrict__ C, int64_t ldc, int64_
 }
 
 int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean) {
-    RET(Cc.ensure(std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
-    RET(Cmean.ensure(std::max<int32_t>(1, K) * sizeof(double)));
-    if (K > 0) LAUNCH(ctx, "center_traces", k_center_traces, dim3(K), dim3(256), 0, C, ldc, T, Cc.as<float>(), Cmean.as<double>());
+    RET(Cc.ensure_hw(std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float), ctx->hw_cc));
+    RET(Cmean.ensure_hw(std::max<int32_t>(1, K) * sizeof(double), ctx->hw_cm));
+    if (K > 0) LAUNCH(ctx, "center_traces", k_center_traces, dim3(K), dim3(256), 0, C, ldc, T, Cc.as<float>(), Cmean.as<double>(), (const int *)nullptr);
     return 0;
+}
+
+// upload_traces + center_traces for a caller that only wants the centred copy: rows of the bound matrix (CNMFE_BOUND / CNMFE_BOUND_ROWS) are centred
+// straight out of it -- one launch, no K x T staging copy; a host matrix goes through `stage` as before
+int upload_centered(cnmfe_ctx *ctx, DevBuf &stage, const float *C, int32_t K, int64_t T, int order, DevBuf &Cc, DevBuf &Cmean, int64_t *ldc_out) {
+    const int64_t ldc = (T + 3) & ~int64_t(3);
+    if (K > 0 && (order == CNMFE_BOUND || order == CNMFE_BOUND_ROWS)) {
+        *ldc_out = ldc;
+        if (!ctx->bound_valid || ctx->bound_T != T || (order == CNMFE_BOUND && ctx->bound_K != K))
+            return fail(CNMFE_ESTATE, "no bound trace matrix of %d x %lld (cnmfe_traces_bind)", K, (long long)T);
+        const int *didx = nullptr;
+        if (order == CNMFE_BOUND_ROWS) {
+            if (!C) return fail(CNMFE_EINVAL, "null trace matrix");
+            const int32_t *rows = reinterpret_cast<const int32_t *>(C);
+            for (int32_t k = 0; k < K; ++k)
+                if (rows[k] < 0 || rows[k] >= ctx->bound_K) return fail(CNMFE_EINVAL, "row %d of the bound trace matrix (%d rows) does not exist", rows[k], ctx->bound_K);
+            DevBuf &dIdx = ctx->tmp[15];
+            RET(to_dev(ctx, dIdx, rows, (size_t)K));
+            didx = dIdx.as<int>();
+        }
+        RET(Cc.ensure_hw(std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float), ctx->hw_cc));
+        RET(Cmean.ensure_hw(std::max<int32_t>(1, K) * sizeof(double), ctx->hw_cm));
+        LAUNCH(ctx, "center_traces", k_center_traces, dim3(K), dim3(256), 0, ctx->bound.as<float>(), ldc, T, Cc.as<float>(), Cmean.as<double>(), didx);
+        return 0;
+    }
+    RET(upload_traces(ctx, stage, C, K, T, order, ldc_out));
+    return center_traces(ctx, stage.as<float>(), *ldc_out, K, T, Cc, Cmean);
 }
 
 // Ysig4 [T/4][d] float4  ->  frame-major [T][d]
@@ -58,12 +86,24 @@ __global__ void k_dlt(const float *__restrict__ ymean_f, const double *__restric
 // W*A_prev per patch pixel (ELL rows): wa(m,k) = sum_i W(m,i) * A_prev(m + o_i, k), accumulated in ring order.
 // One thread per pixel; its <= WA_CAP (k, value) slots live in LDS ([slot][thread], conflict-free).
 constexpr int WA_CAP_ = 32;
+// STAGE: the (column, value) arrays of the block's CSR are copied to LDS first (dynamic, 8 B per entry) and the per-entry loop reads them there.  A pixel
+// whose ring crosses footprints walks tens of entries one dependent load after the other; out of L2 that walk made the kernel's duration (70-130 us for
+// a 128 x 128 patch, as much as for the 512 x 512 frame) -- what a small patch's footprints need fits the LDS many times over.
+template <bool STAGE>
 __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, int64_t d, int nr, int nr_b, int nc_b, int roff, int coff, int p,
                                                  const int *__restrict__ dr, const int *__restrict__ dc, const int *__restrict__ arow,
-                                                 const int *__restrict__ acol, const float *__restrict__ aval,
+                                                 const int *__restrict__ acol_g, const float *__restrict__ aval_g, int nnz,
                                                  int *__restrict__ wa_cnt, int *__restrict__ wa_k, float *__restrict__ wa_v, int *__restrict__ overflow) {
     __shared__ int tk[WA_CAP_][128];
     __shared__ float tv[WA_CAP_][128];
+    extern __shared__ __attribute__((aligned(16))) char wa_dyn[];
+    const int *acol = acol_g; const float *aval = aval_g;
+    if constexpr (STAGE) {
+        int *sc = reinterpret_cast<int *>(wa_dyn); float *sv = reinterpret_cast<float *>(wa_dyn) + nnz;
+        for (int e = threadIdx.x; e < nnz; e += 128) { sc[e] = acol_g[e]; sv[e] = aval_g[e]; }
+        __syncthreads();
+        acol = sc; aval = sv;
+    }
     const int64_t m = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (m >= d) return;
     const int t = threadIdx.x;
@@ -623,7 +663,7 @@ int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out
     LAUNCH(ctx, "ysig_unpack", k_ysig_unpack, dim3((unsigned)((P->d + 255) / 256), (unsigned)P->Tc), dim3(256), 0,
            ysig.as<float4>(), P->d, T, dstp);
     if (out_memspace != CNMFE_DEVICE)
-        CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(Ysig_out, dstp, (size_t)P->d * T * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     RET(ctx_check_errflag(ctx));
     return 0;
 }
@@ -840,7 +880,7 @@ int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const 
     LAUNCH(ctx, "rss_sweep", k_rss, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, P->ysig.as<float4>(), d, T, P->Tc, cseg, dKap.as<float>(),
            has_a ? dCnt.as<int>() : nullptr, dK.as<int>(), dV.as<float>(), dC.as<float>(), ldc, dPart.as<double>());
     std::vector<double> part((size_t)nblk * nseg);
-    CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->st()));
     RET(ctx_check_errflag(ctx));
     double s = 0.0;
     for (double v : part) s += v;                              // fixed order: reproducible
@@ -876,7 +916,7 @@ int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const fl
     if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)d * nframes * sizeof(float))); dst = ctx->stage.as<float>(); }
     LAUNCH(ctx, "bg_reconstruct", k_bg_out, dim3((unsigned)((d + 255) / 256), (unsigned)nframes), dim3(256), 0, P->Yc4.as<float4>(), P->d_b, P->nr, P->nr_b, P->roff, P->coff,
            P->ysig.as<float4>(), d, P->ymean_f.as<float>(), dKap.as<float>(), frame0, nframes, dst);
-    if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     return ctx_check_errflag(ctx);
 }
 
@@ -892,23 +932,31 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     int64_t ldc = 4;
     bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
     if (has_ac) {
-        RET(upload_traces(ctx, dC, C, Ksel, T, c_order, &ldc));
-        RET(center_traces(ctx, dC.as<float>(), ldc, Ksel, T, dCc, dCm));
+        RET(upload_centered(ctx, dC, C, Ksel, T, c_order, dCc, dCm, &ldc));
         HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
         RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
-        RET(dWaCnt.ensure(P->d * sizeof(int)));
-        RET(dWaK.ensure((size_t)WA_CAP * P->d * sizeof(int)));
-        RET(dWaV.ensure((size_t)WA_CAP * P->d * sizeof(float)));
+        RET(dWaCnt.ensure_hw(P->d * sizeof(int), ctx->hw_wa[0]));
+        RET(dWaK.ensure_hw((size_t)WA_CAP * P->d * sizeof(int), ctx->hw_wa[1]));
+        RET(dWaV.ensure_hw((size_t)WA_CAP * P->d * sizeof(float), ctx->hw_wa[2]));
         // a ring that touches more than WA_CAP footprints raises the context's error flag (ctx_check_errflag at the next wait of this call chain: the
         // spatial / temporal update's own download) instead of costing a drain of the stream here -- with several patches per context that drain
         // was what kept the host from setting up patch m + 1 under patch m's kernels
         int *dErrWa = nullptr;
         RET(ctx_errflag(ctx, &dErrWa));
-        LAUNCH(ctx, "r1_ring_wa", k_ring_wa, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
-               P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(),
-               dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
+        const int nnzA = (int)csr.col.size();
+        const size_t wa_stage = (size_t)nnzA * 8;
+        if (wa_stage <= 96 * 1024) {                               // (32 KB static + this: one workgroup per CU above ~48 KB, still every CU of a small patch's grid)
+            static bool attr = false;
+            if (!attr) { CK(hipFuncSetAttribute((const void *)k_ring_wa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+            LAUNCH(ctx, "r1_ring_wa", k_ring_wa<true>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), wa_stage, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
+                   P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
+                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
+        } else
+            LAUNCH(ctx, "r1_ring_wa", k_ring_wa<false>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
+                   P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
+                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
     }
     if (tables_only) { ctx->last_ldc = ldc; return 0; }       // bg_ssub: the caller only wants (W*A) and the centred traces (tmp[8..10], tmp[1])
     // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)
@@ -989,7 +1037,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         for (int i = 0; i < P->p; ++i) offs[i] = P->dc[i] * HR + P->dr[i];
         RET(to_dev(ctx, dOffs, offs.data(), offs.size()));
         a.offs = dOffs.as<int>();
-        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipStreamSynchronize(ctx->st()));
         size_t shmem = (size_t)HR * HC * sizeof(float4);
         if (shmem > 160 * 1024) return fail(CNMFE_EUNSUPPORTED, "ring radius %d needs %zu B of LDS per tile", h, shmem);
         if (shmem > 64 * 1024) {

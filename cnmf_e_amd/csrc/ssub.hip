@@ -273,16 +273,16 @@ int ssub_derive(cnmfe_ctx *ctx, Patch *S, int dst_id, int ssub, int mode) {
         LAUNCH(ctx, "ssub_derive_gather", k_derive_gather, grid, dim3(256), 0, S->Yc4.as<float4>(), S->d_b, dSel.as<int>(), P->Yc4.as<float4>(), P->d_b);
         LAUNCH(ctx, "ssub_gather_mean", k_gather_mean, dim3((unsigned)((P->d_b + 255) / 256)), dim3(256), 0, S->ymean_d.as<double>(), dSel.as<int>(),
                P->ymean_d.as<double>(), P->ymean_f.as<float>(), P->d_b);
-        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipStreamSynchronize(ctx->st()));
     } else {
         DevBuf dIr, dWr, dIc, dWc;
         RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
         RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
         LAUNCH(ctx, "ssub_derive_bicubic", k_resample2d, grid, dim3(256), 0, S->Yc4.as<float4>(), S->nr_b, S->d_b, P->Yc4.as<float4>(), d1s, P->d_b,
                dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P);
-        CK(hipMemsetAsync(P->ymean_d.p, 0, P->d_b * sizeof(double), ctx->stream));
-        CK(hipMemsetAsync(P->ymean_f.p, 0, P->d_b * sizeof(float), ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipMemsetAsync(P->ymean_d.p, 0, P->d_b * sizeof(double), ctx->st()));
+        CK(hipMemsetAsync(P->ymean_f.p, 0, P->d_b * sizeof(float), ctx->st()));
+        CK(hipStreamSynchronize(ctx->st()));
     }
     P->ymean_valid = true; P->frames_uploaded = P->T;
     return 0;
@@ -331,7 +331,7 @@ int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, 
                     thresh_outlier));          // sn of the low-resolution block: cnmfe_set_noise on the fit patch (update_background_parallel.m:137)
     if (R && R != F) {
         if (R->p != F->p || R->d != F->d) return fail(CNMFE_ESTATE, "fit / residual low-resolution patches have different rings");
-        CK(hipMemcpyAsync(R->W.p, F->W.p, (size_t)F->p * F->d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        CK(hipMemcpyAsync(R->W.p, F->W.p, (size_t)F->p * F->d * sizeof(float), hipMemcpyDeviceToDevice, ctx->st()));
         R->stat_valid = false;
         R->ysig_valid = false;
     }
@@ -408,16 +408,16 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
             DevBuf &dFlag = ctx->tmp[11];
             RET(tCnt.ensure((size_t)M->d * sizeof(int))); RET(tK.ensure((size_t)UP_CAP * M->d * sizeof(int))); RET(tV.ensure((size_t)UP_CAP * M->d * sizeof(float)));
             RET(dFlag.ensure(64));
-            CK(hipMemsetAsync(dFlag.p, 0, 64, ctx->stream));
+            CK(hipMemsetAsync(dFlag.p, 0, 64, ctx->st()));
             LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + 127) / 128)), dim3(128), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
                    dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P, ctx->tmp[8].as<int>(), ctx->tmp[9].as<int>(), ctx->tmp[10].as<float>(),
                    tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dFlag.as<int>());
             int flag = 0;
-            CK(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipStreamSynchronize(ctx->stream));
+            CK(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+            CK(hipStreamSynchronize(ctx->st()));
             term_ok = flag == 0;                              // a pixel near more than UP_CAP footprints: no term kept, the next call sweeps again
             (reuse ? M->pendCc : M->resCc).swap(tCc);
-        } else CK(hipStreamSynchronize(ctx->stream));         // the tap vectors die with this call
+        } else CK(hipStreamSynchronize(ctx->st()));         // the tap vectors die with this call
         if (reuse && term_ok) {
             M->pend = true; M->pend_ac = has_a; M->pend_ldc = ldc_t; M->pend_K = K;
             if (ctx->opt("r1_lazy", 1) == 0 || Ysig_out) RET(residual_materialize(ctx, M));
@@ -428,7 +428,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
             RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, 0));
             RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
             RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
-            CK(hipStreamSynchronize(ctx->stream));
+            CK(hipStreamSynchronize(ctx->st()));
         }
         M->res_ac = has_a && term_ok; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
         M->res_kind = term_ok ? 2 : 0;
@@ -581,7 +581,7 @@ int ssub_background(cnmfe_ctx *ctx, Patch *M, int pid, Patch *F, int ssub, int32
         RET(upload_traces(ctx, dC, C, K, M->T, c_order, &ldc));
         HostCSR csr; csc_to_csr(dF, K, ocp.data(), ori.data(), ova.data(), csr);
         RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
-        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipStreamSynchronize(ctx->st()));
     }
     const std::vector<int> sr = nearest_sel(make_taps(M->nr_b, d1s, 1.0 / ssub, true)), sc = nearest_sel(make_taps(M->nc_b, d2s, 1.0 / ssub, true));
     std::vector<float> b0low((size_t)dF);
@@ -596,7 +596,7 @@ int ssub_background(cnmfe_ctx *ctx, Patch *M, int pid, Patch *F, int ssub, int32
            dAcol.as<int>(), dAval.as<float>(), dC.as<float>(), ldc, ctx->bgs_r.as<float4>());
     LAUNCH(ctx, "bgs_wr", k_bgs_wr, grid, dim3(256), 0, ctx->bgs_r.as<float4>(), dF, d1s, d2s, F->p, F->ring_dr.as<int>(), F->ring_dc.as<int>(), F->W.as<float>(),
            ctx->bgs_b.as<float4>());
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipStreamSynchronize(ctx->st()));
     ctx->bgs_patch = pid; ctx->bgs_d1s = d1s; ctx->bgs_dF = dF;
     return 0;
 }
@@ -608,8 +608,8 @@ int ssub_bg_out(cnmfe_ctx *ctx, Patch *M, const float *b0_new, int64_t frame0, i
     if (out_memspace != CNMFE_DEVICE) { RET(ctx->stage.ensure((size_t)M->d * nframes * sizeof(float))); dst = ctx->stage.as<float>(); }
     LAUNCH(ctx, "bgs_out", k_bgs_out, dim3((unsigned)((M->d + 255) / 256), (unsigned)nframes), dim3(256), 0, ctx->bgs_b.as<float4>(), ctx->bgs_dF, ctx->bgs_d1s,
            ctx->bgs_upr.as<int>(), ctx->bgs_upc.as<int>(), M->d, M->nr, M->roff, M->coff, dB0n.as<float>(), frame0, dst);
-    if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)M->d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    if (out_memspace != CNMFE_DEVICE) CK(hipMemcpyAsync(out, dst, (size_t)M->d * nframes * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     return 0;
 }
 
@@ -622,7 +622,7 @@ int ssub_rss(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *cp, const int32
         RET(upload_traces(ctx, dC, C, K, M->T, c_order, &ldc));
         HostCSR csr; csc_to_csr(M->d, K, cp, ri, va, csr);
         RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size())); RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size())); RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
-        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipStreamSynchronize(ctx->st()));
     }
     RET(to_dev(ctx, dB0n, b0_new, (size_t)M->d));
     const int64_t nblk = (M->d + 255) / 256;
@@ -634,8 +634,8 @@ int ssub_rss(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *cp, const int32
            ctx->bgs_upc.as<int>(), M->Yc4.as<float4>(), M->d_b, M->nr_b, M->ymean_f.as<float>(), M->d, M->nr, M->roff, M->coff, dB0n.as<float>(),
            has_a ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dC.as<float>(), ldc, M->T, M->Tc, cseg, dPart.as<double>());
     std::vector<double> part((size_t)nblk * nseg);
-    CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpyAsync(part.data(), dPart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
     double s_ = 0.0;
     for (double v : part) s_ += v;
     *rss_out = s_;

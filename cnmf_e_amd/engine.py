@@ -402,11 +402,34 @@ class Engine:
         L.check(L.lib.cnmfe_update_spatial(self._ctx, pid, alg, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                            _p(icp, L.i64p), _p(iri, L.i32p), _p(snf, L.f32p), int(param), None if defer else _p(out, L.f32p)))
         if defer:
+            pend = {}
+            def start():
+                """queue the download into pinned memory right behind the sweeps (cnmfe_update_spatial_fetch_async): fetch() then waits for that point of
+                the stream only, so the caller may queue the next patch's kernels first"""
+                if out.size == 0 or "t" in pend:
+                    return
+                nb = 1 << max(12, int(out.size * 4 - 1).bit_length())          # pooled by size class
+                ptr = self._pinned_take(nb)
+                tk = C.c_int64(0)
+                try:
+                    L.check(L.lib.cnmfe_update_spatial_fetch_async(self._ctx, ptr, int(out.size), C.byref(tk)))
+                except Exception:
+                    self._pinned_give(ptr, nb)
+                    raise
+                pend["t"] = (tk.value, ptr, nb)
             def fetch(connected_fov=None):
                 """connected_fov = (d1, d2): the patch is the whole field of view -- also apply the connectivity constraint on the device and
                 return (A_raw, A) instead of A_raw"""
                 if connected_fov is None:
-                    L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
+                    if "t" in pend:
+                        tk, ptr, nb = pend.pop("t")
+                        try:
+                            L.check(L.lib.cnmfe_ticket_wait(self._ctx, tk))
+                            C.memmove(out.ctypes.data, ptr, out.size * 4)
+                        finally:
+                            self._pinned_give(ptr, nb)
+                    else:
+                        L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
                     return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 keep = np.zeros(out.size, dtype=np.uint8)
                 L.check(L.lib.cnmfe_update_spatial_fetch_connected(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
@@ -414,6 +437,7 @@ class Engine:
                 A_raw = sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 A_pp = sp.csc_matrix((out * keep, iri.copy(), icp.copy()), shape=(info["d"], K))
                 return A_raw, A_pp
+            fetch.start = start
             return fetch
         return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
 

@@ -190,6 +190,12 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx,
                          const float *sn, int32_t param, float *A_out);
 int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz);
+/* the same fetch without the wait: the copy into PINNED host memory (cnmfe_host_alloc) is queued behind the sweeps and *ticket names the point of the
+ * stream where it is complete; cnmfe_ticket_wait(ctx, ticket) waits for exactly that point (not for what was queued after it) and releases the ticket.
+ * With several patches per context the host mirror queues patch m + 1 before it collects patch m, so the device never waits for the host's assembly
+ * of A (update_spatial_parallel.m:324-334).  A kernel-raised error is reported by the next waiting call of the context, not by the ticket. */
+int cnmfe_update_spatial_fetch_async(cnmfe_ctx *ctx, float *A_out_pinned, int64_t nnz, int64_t *ticket);
+int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket);
 /* the same fetch with post_process_spatial's connectivity constraint (cnmfe_post_process_spatial below) applied to the result where it lies on the
  * device: for a patch that IS the d1 x d2 field of view (patch rows = FOV pixels), IND = the mask the deferred update ran on.  A_out = the raw update
  * (obj.A before post-processing), keep_out[e] = 1 where entry e survives. */
@@ -274,6 +280,15 @@ int cnmfe_stitch_finish_async(cnmfe_ctx *ctx, int subtract_min, float *C_raw_pin
 int cnmfe_stitch_wait(cnmfe_ctx *ctx);         /* waits for the downloads of cnmfe_stitch_finish_async only (not for the compute stream) */
 void *cnmfe_host_alloc(size_t bytes);          /* page-locked host memory (NULL + cnmfe_last_error on failure) */
 void cnmfe_host_free(void *p);
+
+/* ---- host helper: the reference's sparse row selections `A(mask, ind)` with `ind = find(sum(A(mask, :), 1) > 0)` (@Sources2D/update_spatial_parallel.m:87-91,96-97,
+ * update_temporal_parallel.m:136-141, update_background_parallel.m:129-131), which MATLAB's sparse indexing does natively and a host in another language does not.
+ * CSC in (colptr / rowidx / val of the whole-FOV matrix), `lut[pixel]` = row inside the selection or -1, `cand` = ascending candidate columns.
+ * keep_all = 0: a candidate is kept when its selected values sum to > 0 (double accumulation in storage order); 1: every candidate is kept.
+ * Out: out_ind[0..*nkept) the kept columns, out_colptr[0..*nkept], their entries (row = lut value, in storage order) in out_rowidx / out_val (capacity `cap`
+ * entries: the candidates' total nnz always suffices).  No device involved; CNMFE_EINVAL on a null argument, unsorted candidates or too small a capacity. */
+int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const float *val, const int32_t *lut, int64_t ncand, const int64_t *cand,
+                          int keep_all, int64_t cap, int64_t *out_ind, int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nkept);
 
 /* ---- objective: [RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, one patch, all frames:
  *   RSS = sum((Y(patch,:) - A(patch,:)*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)

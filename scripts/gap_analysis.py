@@ -1,9 +1,11 @@
-"""Idle gaps of the GPU between consecutive kernels of one iteration, from a rocprofv3 --kernel-trace CSV: python scripts/gap_analysis.py <kernel_trace.csv> [n_last_kernels]"""
+"""Idle gaps of the GPU between consecutive kernels of one iteration, from a rocprofv3 --kernel-trace CSV:
+   python scripts/gap_analysis.py <kernel_trace.csv> [seq|agg] [background fits per iteration (patches), default 1]"""
 import csv, sys
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))), key=lambda x: x[0])
 # one iteration = from one k_ring_pmax (the kernel a background fit ends with) to the next
 idx = [i for i, r in enumerate(rows) if "k_ring_pmax" in r[2]]
-a, b = idx[-2], idx[-1]
+npi = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+a, b = idx[-1 - npi], idx[-1]
 it = rows[a:b]
 span = (it[-1][1] - it[0][0]) / 1e6
 busy = sum(e - s for s, e, _ in it) / 1e6
@@ -23,3 +25,18 @@ if len(sys.argv) > 2 and sys.argv[2] == "seq":
         gap = (s_ - prev) / 1e3 if prev else 0.0
         print("%8.3f ms  +%7.1f us gap  %8.1f us  %s" % ((s_ - t0) / 1e6, gap, (e_ - s_) / 1e3, n_[:70]))
         prev = e_
+if len(sys.argv) > 2 and sys.argv[2] == "agg":
+    import collections
+    short = lambda n: n.split("(")[0].replace("void ", "").replace("cnmfe::", "")[:40]
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for g, p, n in gaps:
+        agg[(short(p), short(n))][0] += g; agg[(short(p), short(n))][1] += 1
+    print("gaps by (kernel before, kernel after), summed over the iteration:")
+    for (p, n), (g, c) in sorted(agg.items(), key=lambda x: -x[1][0])[:40]:
+        print("%8.3f ms in %4d gaps (%.1f us each)  after %-40s before %s" % (g, c, 1e3 * g / c, p, n))
+    kk = collections.defaultdict(lambda: [0.0, 0])
+    for s_, e_, n_ in it:
+        kk[short(n_)][0] += (e_ - s_) / 1e6; kk[short(n_)][1] += 1
+    print("kernels:")
+    for n, (t, c) in sorted(kk.items(), key=lambda x: -x[1][0])[:40]:
+        print("%8.3f ms in %4d launches (%.1f us each)  %s" % (t, c, 1e3 * t / c, n))

@@ -85,3 +85,50 @@ def test_methods_with_dilate_and_circular_match_oracle():
         assert np.array_equal(Ag != 0, Ar != 0), it
         assert np.abs(Ag - Ar).max() <= 1e-5 * np.abs(Ar).max() and np.abs(np.asarray(s.C) - o.C).max() <= 1e-5 * np.abs(o.C).max(), it
     assert s.options.se is None and o.se is None
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_native_row_selection_equals_the_numpy_formulation(seed):
+    """cnmfe_csc_select_rows (the library's host helper behind Sources2D._slice) against the index-arithmetic NumPy version of the same
+    selection: `A(mask, ind)` with `ind = find(sum(A(mask,:),1) > 0)` (update_spatial_parallel.m:87-91) and `A(mask, cols)` (:96-97) --
+    identical columns, pointers, row indices and values; empty candidates, empty selections, columns that only touch the mask with zeros or
+    with values summing to <= 0, explicit zeros kept inside selected columns."""
+    from cnmf_e_amd import sources2d as S
+    rng = np.random.default_rng(seed)
+    d1, d2, K = 40, 36, 30
+    d = d1 * d2
+    rows, cols, vals = [], [], []
+    for k in range(K):
+        if k % 7 == 3:
+            continue                                                        # an empty column
+        r0, c0 = rng.integers(0, d1 - 6), rng.integers(0, d2 - 6)
+        rr, cc = np.meshgrid(np.arange(r0, r0 + 6), np.arange(c0, c0 + 6), indexing="ij")
+        v = rng.standard_normal(36).astype(np.float32)
+        v[rng.random(36) < 0.3] = 0.0                                       # explicit zeros
+        if k % 5 == 0:
+            v = -np.abs(v)                                                  # a column whose selected sum cannot be positive
+        rows.append((cc * d1 + rr).ravel()); cols.append(np.full(36, k)); vals.append(v)
+    A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(d, K), dtype=np.float32)
+    A.sort_indices()
+    assert A.indices.dtype == np.int32
+    lut = np.full(d, -1, dtype=np.int32)
+    rr, cc = np.meshgrid(np.arange(8, 30), np.arange(5, 25), indexing="ij")
+    pix = np.sort((cc * d1 + rr).ravel())
+    lut[pix] = np.arange(pix.size, dtype=np.int32)
+    every = np.nonzero(np.diff(A.indptr) > 0)[0]
+    for cand, keep_all in ((every, False), (every, True), (every[::3], False), (np.arange(K)[::2], True), (np.zeros(0, dtype=np.int64), False)):
+        got = S._select_rows_native(A, lut, pix.size, cand, keep_all)
+        assert got is not None, "the library's host helper did not run (int32 / float32 CSC)"
+        ref = S._select_rows_numpy(A, lut, pix.size, np.asarray(cand, dtype=np.int64), keep_all)
+        assert np.array_equal(got[0], ref[0])
+        assert got[1].shape == ref[1].shape
+        assert np.array_equal(got[1].indptr, ref[1].indptr) and np.array_equal(got[1].indices, ref[1].indices)
+        assert np.array_equal(got[1].data, ref[1].data)
+    # the public entry: rows_of goes through the helper and agrees with a dense selection
+    ind, M = S.rows_of(A, lut, pix.size, span=(int(pix.min()), int(pix.max())))
+    dense = A.toarray()[pix]
+    assert np.array_equal(ind, np.nonzero(dense.sum(axis=0, dtype=np.float64) > 0)[0])
+    assert np.array_equal(M.toarray(), dense[:, ind])
+    # unsorted candidates are refused, not silently mis-sliced
+    with pytest.raises(ValueError):
+        S._select_rows_native(A, lut, pix.size, np.array([4, 2], dtype=np.int64), True)
