@@ -199,7 +199,17 @@ int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
 __global__ void k_ring_pmax(const float *__restrict__ W, int64_t d, int p, int *__restrict__ pmax) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int c = 0;
-    if (m < d) for (int i = 0; i < p; ++i) c += W[(int64_t)i * d + m] > 0.f;
+    if (m < d) {                                              // (16 independent loads in flight per thread: one load per trip made the kernel 96 memory latencies long)
+        int i = 0;
+        for (; i + 16 <= p; i += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = W[(int64_t)(i + u) * d + m];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c += w[u] > 0.f;
+        }
+        for (; i < p; ++i) c += W[(int64_t)i * d + m] > 0.f;
+    }
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(c, o); c = v > c ? v : c; }
     if ((threadIdx.x & 63) == 0) atomicMax(pmax, c);
 }

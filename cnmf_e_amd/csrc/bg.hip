@@ -809,10 +809,21 @@ __global__ void k_active(const float *__restrict__ W, BgGeom g, const int *__res
     if (m < g.d) {
         const int rbm = (int)(m % g.nr) + g.roff, cbm = (int)(m / g.nr) + g.coff;
         float s = 0.f;
-        for (int i = 0; i < g.p; ++i) {
-            const int rb = rbm + dr[i], cb = cbm + dc[i];
-            if (rb < 0 || rb >= g.nr_b || cb < 0 || cb >= g.nc_b) continue;
-            s += fabsf(W[(int64_t)i * g.d + m]) * asum[(int64_t)cb * g.nr_b + rb];
+        // eight offsets at a time, every load unconditional (neighbours outside the block read pixel 0 and are masked): the loads of a group are
+        // independent, one load behind a branch per trip made the kernel 2 x 96 memory latencies long.  The sum keeps the ring order.
+        for (int i0 = 0; i0 < g.p; i0 += 8) {
+            float w8[8], a8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u < g.p ? i0 + u : g.p - 1;
+                const int rb = rbm + dr[i], cb = cbm + dc[i];
+                const bool in = i0 + u < g.p && rb >= 0 && rb < g.nr_b && cb >= 0 && cb < g.nc_b;
+                w8[u] = W[(int64_t)i * g.d + m];
+                a8[u] = asum[in ? (int64_t)cb * g.nr_b + rb : 0];
+                if (!in) w8[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (w8[u] != 0.f) s += fabsf(w8[u]) * a8[u];
         }
         on = s > 0.f;
         active[m] = (unsigned char)on;

@@ -204,28 +204,82 @@ __global__ void __launch_bounds__(256) k_ata_pairs(const int64_t *__restrict__ c
 }
 
 // ---- T3: one Gauss-Seidel level of HALS_temporal (no-deconvolution branch :62-68) --------------------
+constexpr int HT_NB = 64;        // neighbours of a neuron staged in LDS (more: read from the lists in global memory)
+constexpr int HT_NR = 12;        // frames per thread kept in registers
 __device__ __forceinline__ void hals_temporal_one(int k, const int *__restrict__ nptr, const int *__restrict__ nidx, const float *__restrict__ nval,
                                                   const float *__restrict__ aa, const float *__restrict__ U, float *C, float *Craw, int64_t ldc, int64_t T, float *red) {
+    __shared__ int s_idx[HT_NB]; __shared__ float s_val[HT_NB];
     const float a = aa[k];
     float *ck = C + (int64_t)k * ldc;
     const float *uk = U + (int64_t)k * ldc;
-    const int n0 = nptr[k], n1 = nptr[k + 1];
-    float mn = INFINITY;
+    const int n0 = nptr[k], nn = nptr[k + 1] - n0;
     const int nt = (int)blockDim.x;
-    for (int64_t t = threadIdx.x; t < T; t += nt) {
-        float vc = 0.f;
-        for (int j = n0; j < n1; ++j) vc = fmaf(nval[j], C[(int64_t)nidx[j] * ldc + t], vc);    // V(k,:)*C
-        const float v = ck[t] + (uk[t] - vc) / a;                                                  // :62
-        Craw[(int64_t)k * ldc + t] = v;
-        mn = fminf(mn, v);
-    }
-    red[threadIdx.x] = mn; __syncthreads();
-    for (int o = nt >> 1; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
-    mn = red[0];
+    // the neighbour list goes to LDS once: the trace loads below then depend on nothing but their own address, and a thread's frames are taken two
+    // at a time -- this kernel is a handful of workgroups whose duration is the length of one thread's chain of loads
+    const bool staged = nn <= HT_NB;
+    if (staged && (int)threadIdx.x < nn) { s_idx[threadIdx.x] = nidx[n0 + threadIdx.x]; s_val[threadIdx.x] = nval[n0 + threadIdx.x]; }
     __syncthreads();
+    float mn = INFINITY;
+    float *rk = Craw + (int64_t)k * ldc;
+    if (staged && T <= (int64_t)HT_NR * nt) {
+        // every frame of the thread at once (T <= 12 blockDim): all trace loads of a neighbour are independent and the new values wait in registers
+        // for the row minimum -- no second read of C_raw
+        float vc[HT_NR], val[HT_NR];
+#pragma unroll
+        for (int i = 0; i < HT_NR; ++i) vc[i] = 0.f;
+        const int64_t tl = T - 1;
+        for (int j = 0; j < nn; ++j) {
+            const float *cj = C + (int64_t)s_idx[j] * ldc; const float v = s_val[j];
+#pragma unroll
+            for (int i = 0; i < HT_NR; ++i) { const int64_t t = threadIdx.x + (int64_t)i * nt; vc[i] = fmaf(v, cj[t < T ? t : tl], vc[i]); }      // V(k,:)*C
+        }
+#pragma unroll
+        for (int i = 0; i < HT_NR; ++i) {
+            const int64_t t = threadIdx.x + (int64_t)i * nt, tc = t < T ? t : tl;
+            val[i] = ck[tc] + (uk[tc] - vc[i]) / a;                                                    // :62
+            if (t < T) mn = fminf(mn, val[i]);
+        }
+        for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+        __syncthreads();
+        mn = red[0];
+        for (int w = 1; w < (nt >> 6); ++w) mn = fminf(mn, red[w]);
+#pragma unroll
+        for (int i = 0; i < HT_NR; ++i) {
+            const int64_t t = threadIdx.x + (int64_t)i * nt;
+            if (t < T) { const float v = val[i] - mn; rk[t] = v; ck[t] = v; }                         // :66-68
+        }
+        return;
+    }
+    for (int64_t t0 = threadIdx.x; t0 < T; t0 += 2 * nt) {
+        const int64_t t1 = t0 + nt;
+        const bool two = t1 < T;
+        const int64_t t1c = two ? t1 : t0;
+        float vc0 = 0.f, vc1 = 0.f;
+        if (staged) {
+#pragma unroll 4
+            for (int j = 0; j < nn; ++j) {
+                const float *cj = C + (int64_t)s_idx[j] * ldc; const float v = s_val[j];
+                vc0 = fmaf(v, cj[t0], vc0); vc1 = fmaf(v, cj[t1c], vc1);                        // V(k,:)*C
+            }
+        } else {
+            for (int j = 0; j < nn; ++j) {
+                const float *cj = C + (int64_t)nidx[n0 + j] * ldc; const float v = nval[n0 + j];
+                vc0 = fmaf(v, cj[t0], vc0); vc1 = fmaf(v, cj[t1c], vc1);
+            }
+        }
+        const float v0 = ck[t0] + (uk[t0] - vc0) / a;                                              // :62
+        rk[t0] = v0; mn = fminf(mn, v0);
+        if (two) { const float v1 = ck[t1] + (uk[t1] - vc1) / a; rk[t1] = v1; mn = fminf(mn, v1); }
+    }
+    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    mn = red[0];
+    for (int w = 1; w < (nt >> 6); ++w) mn = fminf(mn, red[w]);
     for (int64_t t = threadIdx.x; t < T; t += nt) {
-        const float v = Craw[(int64_t)k * ldc + t] - mn;                                           // :66
-        Craw[(int64_t)k * ldc + t] = v; ck[t] = v;                                                 // :67-68
+        const float v = rk[t] - mn;                                                                // :66
+        rk[t] = v; ck[t] = v;                                                                      // :67-68
     }
 }
 // (1024 threads per neuron: a level is a handful of workgroups whose duration is their serial depth over T, not their work)

@@ -14,18 +14,35 @@ namespace cnmfe {
 
 // row means (double) and centred copy of a [k][ldc] trace matrix; with `idx`, row k of the result is row idx[k] of C (the selected rows of the bound
 // matrix are centred where they lie: no gathered copy in between)
-__global__ void k_center_traces(const float *__restrict__ C, int64_t ldc, int64_t T, float *__restrict__ Cc, double *__restrict__ Cmean, const int *__restrict__ idx) {
+__global__ void __launch_bounds__(256) k_center_traces(const float *__restrict__ C, int64_t ldc, int64_t T, float *__restrict__ Cc, double *__restrict__ Cmean, const int *__restrict__ idx) {
     int k = blockIdx.x;
-    const float *row = C + (int64_t)(idx ? idx[k] : k) * ldc;
-    __shared__ double red[256];
-    double s = 0;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) s += row[t];
-    red[threadIdx.x] = s; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    double mean = red[0] / (double)T;
+    const float4 *row = reinterpret_cast<const float4 *>(C + (int64_t)(idx ? idx[k] : k) * ldc);      // ldc is a multiple of 4, the base 256-byte aligned
+    __shared__ double red[4];
+    const int64_t n4 = ldc >> 2;
+    // 16-byte loads, four partial sums per thread: a row is 40 KB and one workgroup's, so the kernel lasts as long as one thread's chain of loads
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t c = threadIdx.x; c < n4; c += 256) {
+        const float4 v = row[c];
+        const int64_t t = 4 * c;
+        s0 += v.x; s1 += t + 1 < T ? v.y : 0.f; s2 += t + 2 < T ? v.z : 0.f; s3 += t + 3 < T ? v.w : 0.f;     // (t < T for every c: ldc - T < 4)
+    }
+    double s = (s0 + s1) + (s2 + s3);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double mean = ((red[0] + red[1]) + (red[2] + red[3])) / (double)T;
     if (threadIdx.x == 0) Cmean[k] = mean;
-    float *out = Cc + (int64_t)k * ldc;
-    for (int64_t t = threadIdx.x; t < ldc; t += blockDim.x) out[t] = t < T ? (float)((double)row[t] - mean) : 0.f;
+    float4 *out = reinterpret_cast<float4 *>(Cc + (int64_t)k * ldc);
+    for (int64_t c = threadIdx.x; c < n4; c += 256) {
+        const float4 v = row[c];
+        const int64_t t = 4 * c;
+        float4 o;
+        o.x = (float)((double)v.x - mean);
+        o.y = t + 1 < T ? (float)((double)v.y - mean) : 0.f;
+        o.z = t + 2 < T ? (float)((double)v.z - mean) : 0.f;
+        o.w = t + 3 < T ? (float)((double)v.w - mean) : 0.f;
+        out[c] = o;
+    }
 }
 
 int center_traces(cnmfe_ctx *ctx, const float *C, int64_t ldc, int32_t K, int64_t T, DevBuf &Cc, DevBuf &Cmean) {
@@ -109,6 +126,9 @@ __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, in
     const int t = threadIdx.x;
     const int rbm = (int)(m % nr) + roff, cbm = (int)(m / nr) + coff;
     int n = 0;
+    // slots 0..3 live in registers (a ring rarely meets more footprints), slots 4.. in LDS: the per-entry step was a serial walk of LDS reads -- find
+    // the slot, read-modify-write its value -- and the wave runs it for every (offset, entry) ANY of its 64 pixels has, ~150 times in a row
+    int rk0 = -1, rk1 = -1, rk2 = -1, rk3 = -1; float rv0 = 0.f, rv1 = 0.f, rv2 = 0.f, rv3 = 0.f;
     // eight ring offsets at a time: their weights and row extents are independent loads (the thread's serial depth was 96 x three dependent
     // loads, and most neighbours lie under no footprint at all); the accumulation itself stays in ring order
     for (int i0 = 0; i0 < p; i0 += 8) {
@@ -130,17 +150,31 @@ __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, in
         for (int u = 0; u < 8; ++u)
             for (int e = e0[u]; e < e1[u]; ++e) {
                 const int k = acol[e];
-                int s = 0;
-                while (s < n && tk[s][t] != k) ++s;
-                if (s == n) {
-                    if (n == WA_CAP_) { atomicOr(overflow, 2); continue; }     // (bit 1 of the context's error flag: reported at the next wait)
-                    tk[s][t] = k; tv[s][t] = 0.f; ++n;
+                const float a = aval[e], w = w8[u];
+                const bool m0 = rk0 == k, m1 = rk1 == k, m2 = rk2 == k, m3 = rk3 == k;
+                if (m0 | m1 | m2 | m3) {
+                    rv0 = m0 ? fmaf(w, a, rv0) : rv0; rv1 = m1 ? fmaf(w, a, rv1) : rv1; rv2 = m2 ? fmaf(w, a, rv2) : rv2; rv3 = m3 ? fmaf(w, a, rv3) : rv3;
+                } else if (n < 4) {
+                    const float v = fmaf(w, a, 0.f);
+                    if (n == 0) { rk0 = k; rv0 = v; } else if (n == 1) { rk1 = k; rv1 = v; } else if (n == 2) { rk2 = k; rv2 = v; } else { rk3 = k; rv3 = v; }
+                    ++n;
+                } else {
+                    int s = 4;
+                    while (s < n && tk[s][t] != k) ++s;
+                    if (s == n) {
+                        if (n == WA_CAP_) { atomicOr(overflow, 2); continue; }     // (bit 1 of the context's error flag: reported at the next wait)
+                        tk[s][t] = k; tv[s][t] = 0.f; ++n;
+                    }
+                    tv[s][t] = fmaf(w, a, tv[s][t]);
                 }
-                tv[s][t] = fmaf(w8[u], aval[e], tv[s][t]);
             }
     }
     wa_cnt[m] = n;
-    for (int s = 0; s < n; ++s) { wa_k[(int64_t)s * d + m] = tk[s][t]; wa_v[(int64_t)s * d + m] = tv[s][t]; }
+    if (n > 0) { wa_k[m] = rk0; wa_v[m] = rv0; }
+    if (n > 1) { wa_k[d + m] = rk1; wa_v[d + m] = rv1; }
+    if (n > 2) { wa_k[2 * d + m] = rk2; wa_v[2 * d + m] = rv2; }
+    if (n > 3) { wa_k[3 * d + m] = rk3; wa_v[3 * d + m] = rv3; }
+    for (int s = 4; s < n; ++s) { wa_k[(int64_t)s * d + m] = tk[s][t]; wa_v[(int64_t)s * d + m] = tv[s][t]; }
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
