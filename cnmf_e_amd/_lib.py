@@ -78,6 +78,7 @@ PROTOTYPES = {
     "cnmfe_stitch_wait": (C.c_int, [c_ctx]),
     "cnmfe_host_alloc": (C.c_void_p, [C.c_size_t]),
     "cnmfe_host_free": (None, [C.c_void_p]),
+    "cnmfe_csc_drop_zeros": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "cnmfe_update_spatial_fetch_async": (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "cnmfe_ticket_wait": (C.c_int, [c_ctx, C.c_int64]),
     "cnmfe_csc_select_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64,

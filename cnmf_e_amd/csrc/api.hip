@@ -932,6 +932,23 @@ void *cnmfe_host_alloc(size_t bytes) {
 }
 void cnmfe_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// a CSC matrix without its stored zeros (and, with `keep`, without the entries whose flag is 0): what MATLAB's sparse assignment does implicitly
+int cnmfe_csc_drop_zeros(int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, const uint8_t *keep,
+                         int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nnz_out) {
+    if (ncol < 0 || !colptr || !out_colptr || !nnz_out) return fail(CNMFE_EINVAL, "cnmfe_csc_drop_zeros: null argument");
+    const int64_t nnz = colptr[ncol];
+    if (nnz > 0 && (!rowidx || !val || !out_rowidx || !out_val)) return fail(CNMFE_EINVAL, "cnmfe_csc_drop_zeros: null argument");
+    int64_t n = 0;
+    out_colptr[0] = 0;
+    for (int32_t k = 0; k < ncol; ++k) {
+        if (keep) { for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) if (val[e] != 0.f && keep[e]) { out_rowidx[n] = rowidx[e]; out_val[n] = val[e]; ++n; } }
+        else      { for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) if (val[e] != 0.f) { out_rowidx[n] = rowidx[e]; out_val[n] = val[e]; ++n; } }
+        out_colptr[k + 1] = n;
+    }
+    *nnz_out = n;
+    return 0;
+}
+
 // A(mask, cols) of a CSC matrix (what the reference writes as sparse indexing, e.g. update_spatial_parallel.m:87-91,96-97): host code, no device involved.
 int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const float *val, const int32_t *lut, int64_t ncand, const int64_t *cand,
                           int keep_all, int64_t cap, int64_t *out_ind, int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nkept) {

@@ -417,9 +417,19 @@ class Engine:
                     self._pinned_give(ptr, nb)
                     raise
                 pend["t"] = (tk.value, ptr, nb)
-            def fetch(connected_fov=None):
+            def compacted(vals, keep=None):
+                """CSC of the non-zero values (keep: and flagged entries) on IND's pattern, rows sorted: one pass in the library's host helper --
+                scipy's eliminate_zeros() on the 250 k-entry mask pattern was the longest host step between the spatial and the temporal update"""
+                optr = np.empty(K + 1, dtype=np.int64); orow = np.empty(max(1, vals.size), dtype=np.int32); oval = np.empty(max(1, vals.size), dtype=np.float32)
+                n = C.c_int64(0)
+                L.check(L.lib.cnmfe_csc_drop_zeros(K, icp.ctypes.data, iri.ctypes.data, vals.ctypes.data, None if keep is None else keep.ctypes.data,
+                                                   optr.ctypes.data, orow.ctypes.data, oval.ctypes.data, C.byref(n)))
+                M = sp.csc_matrix((oval[:n.value], orow[:n.value], optr), shape=(info["d"], K))
+                M.has_canonical_format = True                            # (sorted rows, no duplicates: the mask's pattern was canonical)
+                return M
+            def fetch(connected_fov=None, compact=False):
                 """connected_fov = (d1, d2): the patch is the whole field of view -- also apply the connectivity constraint on the device and
-                return (A_raw, A) instead of A_raw"""
+                return (A_raw, A) instead of A_raw.  compact: without the stored zeros of the mask pattern (rows sorted)"""
                 if connected_fov is None:
                     if "t" in pend:
                         tk, ptr, nb = pend.pop("t")
@@ -430,10 +440,12 @@ class Engine:
                             self._pinned_give(ptr, nb)
                     else:
                         L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
-                    return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
+                    return compacted(out) if compact else sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 keep = np.zeros(out.size, dtype=np.uint8)
                 L.check(L.lib.cnmfe_update_spatial_fetch_connected(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
                                                                    _p(out, L.f32p), _p(keep, L.u8p)))
+                if compact:
+                    return compacted(out), compacted(out, keep)
                 A_raw = sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 A_pp = sp.csc_matrix((out * keep, iri.copy(), icp.copy()), shape=(info["d"], K))
                 return A_raw, A_pp

@@ -858,9 +858,10 @@ class Sources2D:
             return ind, IND_patch, self._slice(self.A, idx, "patch", cols=ind)[1], self._rows(self.C, ind)   # :88,199 / :91
 
         in_flight = []                                                     # (fetch, patch pixels, neurons) of deferred updates not collected yet
+        clean = False
 
         def collect(fetch, pp, ind):
-            coo = fetch().tocoo()
+            coo = (fetch(compact=True) if hasattr(fetch, "start") else fetch()).tocoo()
             rows.append(pp[coo.row]); cols.append(ind[coo.col]); vals.append(coo.data)             # :324-334 (patches are disjoint)
 
         ahead = None                                                       # the next patch's slices, cut while this patch's sweeps run
@@ -907,7 +908,8 @@ class Sources2D:
                     ahead = (prev_of(nxt), masks_of(nxt))                # ... and the slices of the next patch
                 if whole and o.spatial_constraints.get("connected", True) and (self.dist is None or (v.world_size == 1 and not self.force_collectives)):
                     # one patch = the field of view: post_process_spatial's connectivity constraint (:341) runs on the result where it lies
-                    Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2))
+                    clean = hasattr(fetch, "start")                          # the engine's fetch: no stored zeros, rows sorted -- nothing left to clean below
+                    Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2), **({"compact": True} if clean else {}))
                 elif late:
                     in_flight.append((fetch, pp, ind))
                     while len(in_flight) > 1:
@@ -936,11 +938,13 @@ class Sources2D:
         A_ = self._gather_sparse(A_)
         if update_sn:
             self.P["sn"] = self._allreduce(sn_new).astype(np.float32)                               # :336-337 (patches are disjoint)
-        A_.eliminate_zeros()
-        A_.sort_indices()
+        if not clean:
+            A_.eliminate_zeros()
+            A_.sort_indices()
         self.A_raw = A_
         if whole_pp is not None:
-            whole_pp.eliminate_zeros(); whole_pp.sort_indices()
+            if not clean:
+                whole_pp.eliminate_zeros(); whole_pp.sort_indices()
             self.A = whole_pp                                                                        # :341, done with the fetch
         else:
             self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                          # :341, :24-26

@@ -289,6 +289,11 @@ void cnmfe_host_free(void *p);
  * entries: the candidates' total nnz always suffices).  No device involved; CNMFE_EINVAL on a null argument, unsorted candidates or too small a capacity. */
 int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const float *val, const int32_t *lut, int64_t ncand, const int64_t *cand,
                           int keep_all, int64_t cap, int64_t *out_ind, int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nkept);
+/* host helper: the CSC matrix (ncol columns) without its stored zeros -- and, with keep != NULL, without the entries whose flag is 0 (the connectivity
+ * flags of cnmfe_update_spatial_fetch_connected).  A spatial update returns values on the search mask's pattern, most of them zero; MATLAB's sparse
+ * matrices drop them on assignment (update_spatial_parallel.m:324-334).  Outputs sized for nnz(in) always suffice; *nnz_out = entries written. */
+int cnmfe_csc_drop_zeros(int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, const uint8_t *keep,
+                         int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nnz_out);
 
 /* ---- objective: [RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, one patch, all frames:
  *   RSS = sum((Y(patch,:) - A(patch,:)*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)

@@ -132,3 +132,26 @@ def test_native_row_selection_equals_the_numpy_formulation(seed):
     # unsorted candidates are refused, not silently mis-sliced
     with pytest.raises(ValueError):
         S._select_rows_native(A, lut, pix.size, np.array([4, 2], dtype=np.int64), True)
+
+
+def test_native_drop_zeros_equals_eliminate_zeros():
+    """cnmfe_csc_drop_zeros (behind Engine.update_spatial's compact fetch) against scipy: the matrix without its stored zeros, and with the
+    connectivity flags applied -- pointers, rows and values identical to csc(...).eliminate_zeros(); empty columns and an all-zero matrix."""
+    import ctypes as C
+    from cnmf_e_amd import _lib as L
+    rng = np.random.default_rng(5)
+    d, K = 300, 17
+    M = sp.random(d, K, density=0.2, format="csc", random_state=3, dtype=np.float32)
+    M.sort_indices()
+    vals = M.data.copy(); vals[rng.random(vals.size) < 0.5] = 0.0
+    keep = (rng.random(vals.size) < 0.8).astype(np.uint8)
+    icp = M.indptr.astype(np.int64); iri = M.indices.astype(np.int32)
+    for v, kp in ((vals, None), (vals, keep), (np.zeros_like(vals), None)):
+        optr = np.empty(K + 1, dtype=np.int64); orow = np.empty(vals.size, dtype=np.int32); oval = np.empty(vals.size, dtype=np.float32)
+        n = C.c_int64(-1)
+        rc = L.lib.cnmfe_csc_drop_zeros(K, icp.ctypes.data, iri.ctypes.data, v.ctypes.data, None if kp is None else kp.ctypes.data,
+                                        optr.ctypes.data, orow.ctypes.data, oval.ctypes.data, C.byref(n))
+        assert rc == 0
+        ref = sp.csc_matrix((v * (1 if kp is None else kp), iri.copy(), icp.copy()), shape=(d, K)); ref.eliminate_zeros()
+        assert n.value == ref.nnz
+        assert np.array_equal(optr, ref.indptr) and np.array_equal(orow[:n.value], ref.indices) and np.array_equal(oval[:n.value], ref.data)
