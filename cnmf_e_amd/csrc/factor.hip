@@ -392,20 +392,50 @@ struct PairGraph {
 
 // co-occurrence graph of columns from a CSR (row -> columns), plus the order-preserving level schedule
 static void build_graph(int K, const HostCSR &csr, int64_t nrow, const std::vector<char> &include, PairGraph &g) {
-    std::vector<std::pair<int, int>> pr;
-    for (int64_t r = 0; r < nrow; ++r) {
-        const int64_t a = csr.rowptr[r], b = csr.rowptr[r + 1];
-        for (int64_t i = a; i < b; ++i) for (int64_t j = i + 1; j < b; ++j) {
-            int k1 = csr.col[i], k2 = csr.col[j];
-            if (k1 > k2) std::swap(k1, k2);
-            pr.push_back({k1, k2});
-        }
-    }
-    std::sort(pr.begin(), pr.end());
-    pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
     g.pairs.clear(); g.lower.assign(K, {});
     for (int k = 0; k < K; ++k) g.pairs.push_back(make_int2(k, k));
-    for (auto &p : pr) { g.pairs.push_back(make_int2(p.first, p.second)); g.lower[p.second].push_back(p.first); }
+    if ((int64_t)K * K <= (int64_t(1) << 28)) {
+        // co-occurrence bitmap (bit k1*K + k2, k1 < k2), read back row by row: the pairs come out sorted and unique without the sort of a
+        // (pixels x columns^2) pair list -- that sort was a millisecond of host time under a projection kernel that lasts 0.9 ms
+        static thread_local std::vector<uint64_t> bm;
+        const size_t nw = ((size_t)K * K + 63) / 64;
+        bm.assign(nw, 0);
+        for (int64_t r = 0; r < nrow; ++r) {
+            const int64_t a = csr.rowptr[r], b = csr.rowptr[r + 1];
+            for (int64_t i = a; i < b; ++i) for (int64_t j = i + 1; j < b; ++j) {
+                int k1 = csr.col[i], k2 = csr.col[j];
+                if (k1 > k2) std::swap(k1, k2);
+                const size_t bit = (size_t)k1 * K + k2;
+                bm[bit >> 6] |= uint64_t(1) << (bit & 63);
+            }
+        }
+        for (int k1 = 0; k1 < K; ++k1) {
+            const size_t b0 = (size_t)k1 * K + k1 + 1, b1 = (size_t)(k1 + 1) * K;     // bits of row k1, columns k1+1 .. K-1
+            for (size_t w = b0 >> 6; w <= (b1 - 1) >> 6 && b0 < b1; ++w) {
+                uint64_t x = bm[w];
+                while (x) {
+                    const size_t bit = (w << 6) + (size_t)__builtin_ctzll(x);
+                    x &= x - 1;
+                    if (bit < b0 || bit >= b1) continue;
+                    const int k2 = (int)(bit - (size_t)k1 * K);
+                    g.pairs.push_back(make_int2(k1, k2)); g.lower[k2].push_back(k1);
+                }
+            }
+        }
+    } else {
+        std::vector<std::pair<int, int>> pr;
+        for (int64_t r = 0; r < nrow; ++r) {
+            const int64_t a = csr.rowptr[r], b = csr.rowptr[r + 1];
+            for (int64_t i = a; i < b; ++i) for (int64_t j = i + 1; j < b; ++j) {
+                int k1 = csr.col[i], k2 = csr.col[j];
+                if (k1 > k2) std::swap(k1, k2);
+                pr.push_back({k1, k2});
+            }
+        }
+        std::sort(pr.begin(), pr.end());
+        pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+        for (auto &p : pr) { g.pairs.push_back(make_int2(p.first, p.second)); g.lower[p.second].push_back(p.first); }
+    }
     std::vector<int> lvl(K, 0);
     int nl = 0;
     for (int k = 0; k < K; ++k) {

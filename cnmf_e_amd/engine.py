@@ -429,7 +429,8 @@ class Engine:
                 return M
             def fetch(connected_fov=None, compact=False):
                 """connected_fov = (d1, d2): the patch is the whole field of view -- also apply the connectivity constraint on the device and
-                return (A_raw, A) instead of A_raw.  compact: without the stored zeros of the mask pattern (rows sorted)"""
+                return (A_raw, A) instead of A_raw.  compact: without the stored zeros of the mask pattern (rows sorted); with connected_fov, A_raw then comes as a
+                callable that builds it on first use"""
                 if connected_fov is None:
                     if "t" in pend:
                         tk, ptr, nb = pend.pop("t")
@@ -444,8 +445,8 @@ class Engine:
                 keep = np.zeros(out.size, dtype=np.uint8)
                 L.check(L.lib.cnmfe_update_spatial_fetch_connected(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
                                                                    _p(out, L.f32p), _p(keep, L.u8p)))
-                if compact:
-                    return compacted(out), compacted(out, keep)
+                if compact:                                  # the raw update (obj.A before post-processing) is compacted when somebody reads it: nothing in the iteration does
+                    return (lambda: compacted(out)), compacted(out, keep)
                 A_raw = sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 A_pp = sp.csc_matrix((out * keep, iri.copy(), icp.copy()), shape=(info["d"], K))
                 return A_raw, A_pp

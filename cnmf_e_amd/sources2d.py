@@ -623,6 +623,19 @@ class Sources2D:
     def get_b0(self, idx):
         return self.engine.b0(self.video.pid[idx])
 
+    # obj.A_raw: the spatial update before post-processing.  Nothing in the iteration reads it, so the one-patch path stores the recipe (a callable) and
+    # the matrix is assembled on first read
+    @property
+    def A_raw(self):
+        v = self.__dict__.get("_A_raw")
+        if callable(v):
+            v = self.__dict__["_A_raw"] = v()
+        return v
+
+    @A_raw.setter
+    def A_raw(self, val):
+        self.__dict__["_A_raw"] = val
+
     def _need_data(self):
         if self.video is None:
             raise RuntimeError("No data file selected")                   # update_spatial_parallel.m:13-38
@@ -858,7 +871,6 @@ class Sources2D:
             return ind, IND_patch, self._slice(self.A, idx, "patch", cols=ind)[1], self._rows(self.C, ind)   # :88,199 / :91
 
         in_flight = []                                                     # (fetch, patch pixels, neurons) of deferred updates not collected yet
-        clean = False
 
         def collect(fetch, pp, ind):
             coo = (fetch(compact=True) if hasattr(fetch, "start") else fetch()).tocoo()
@@ -908,8 +920,8 @@ class Sources2D:
                     ahead = (prev_of(nxt), masks_of(nxt))                # ... and the slices of the next patch
                 if whole and o.spatial_constraints.get("connected", True) and (self.dist is None or (v.world_size == 1 and not self.force_collectives)):
                     # one patch = the field of view: post_process_spatial's connectivity constraint (:341) runs on the result where it lies
-                    clean = hasattr(fetch, "start")                          # the engine's fetch: no stored zeros, rows sorted -- nothing left to clean below
-                    Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2), **({"compact": True} if clean else {}))
+                    # (the engine's fetch: A without stored zeros, rows sorted, and the raw update as a recipe -- see the early return below)
+                    Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2), **({"compact": True} if hasattr(fetch, "start") else {}))
                 elif late:
                     in_flight.append((fetch, pp, ind))
                     while len(in_flight) > 1:
@@ -929,6 +941,16 @@ class Sources2D:
         while in_flight:
             collect(*in_flight.pop(0))
         d = v.d1 * v.d2
+        if whole_result is not None and callable(whole_result):
+            self.A_raw = whole_result                                                                # (not sharded: nothing to gather; assembled on first read)
+            if update_sn:
+                self.P["sn"] = self._allreduce(sn_new).astype(np.float32)
+            self.A = whole_pp
+            if o.spatial_constraints.get("circular", False):
+                from . import hostops
+                self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)
+            self._update_b0_new()
+            return
         if whole_result is not None:
             A_ = whole_result
         elif rows:
@@ -938,13 +960,11 @@ class Sources2D:
         A_ = self._gather_sparse(A_)
         if update_sn:
             self.P["sn"] = self._allreduce(sn_new).astype(np.float32)                               # :336-337 (patches are disjoint)
-        if not clean:
-            A_.eliminate_zeros()
-            A_.sort_indices()
+        A_.eliminate_zeros()
+        A_.sort_indices()
         self.A_raw = A_
         if whole_pp is not None:
-            if not clean:
-                whole_pp.eliminate_zeros(); whole_pp.sort_indices()
+            whole_pp.eliminate_zeros(); whole_pp.sort_indices()
             self.A = whole_pp                                                                        # :341, done with the fetch
         else:
             self.A = self._post_process(A_) if o.spatial_constraints.get("connected", True) else A_                          # :341, :24-26
