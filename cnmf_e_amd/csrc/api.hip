@@ -419,7 +419,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", nullptr};
+    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -730,7 +730,7 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
     Patch *P = get_patch(ctx, patch_id);
     if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
     if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
-    RET(residual_materialize(ctx, P));                       // a pending footprint term must be in Ysig for this consumer
+    // (a pending footprint term enters through the projection, spatial_run; only a term that cannot is folded into Ysig first)
     if (algorithm < CNMFE_SPATIAL_HALS || algorithm > CNMFE_SPATIAL_NNLS) return fail(CNMFE_EINVAL, "unknown spatial algorithm %d", algorithm);
     if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
     RET(check_csc("A", K, P->d, A_colptr, A_rowidx));

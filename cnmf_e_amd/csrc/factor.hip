@@ -461,6 +461,7 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     HostTrace ht(ctx, "spatial");
     int64_t ldc;
     RET(upload_centered(ctx, dC, C, K, T, c_order, dCc, dCm, &ldc));
+    if (P->pend && !residual_term_foldable_spatial(P, K, ldc)) RET(residual_materialize(ctx, P));    // (a term that cannot enter through the projection below)
     // A restricted to the IND pattern (A(~active_pixel) = 0, HALS_spatial.m:26); NNLS starts from 0 (:32)
     std::vector<float> aval(nnz, 0.f);
     std::vector<int32_t> ecol(nnz);
@@ -494,6 +495,8 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, P->ysig.as<float4>(), d, T,
            dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
     LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
+    // a footprint term pending beside Ysig (patches with halo neurons: the sweep ran without it) enters here: U += (W A_prev)(Cc_prev Cc')
+    RET(residual_term_fold_spatial(ctx, P, K, nnz, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>(), S_[20]));
     ht.mark("uploads + projection launch");
     // S2 on the co-occurrence pairs
     std::vector<char> include(K, 1);

@@ -808,6 +808,59 @@ int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dC
     return 0;
 }
 
+// The same term seen through the SPATIAL projection U(m,k) = sum_t Ysig(m,t) Cc(k,t) on the entries of the search mask:
+//   U(m,k) += sign * sum_j (W A_term)(m, l_j) <Cc_term(l_j,:), Cc(k,:)>
+// -- a K_term x K matrix of inner products (k_cross_gram) and one pass over the mask's entries.
+__global__ void __launch_bounds__(256) k_cross_gram(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int64_t T, int KB, float *__restrict__ G) {
+    const int k = blockIdx.x, l = blockIdx.y;
+    const float4 *a = reinterpret_cast<const float4 *>(A + (int64_t)l * lda), *b = reinterpret_cast<const float4 *>(B + (int64_t)k * ldb);
+    double s = 0;
+    for (int64_t c = threadIdx.x; 4 * c < T; c += 256) {     // (both matrices are zero beyond T up to their row stride)
+        const float4 x = a[c], y = b[c];
+        s += ((double)x.x * y.x + (double)x.y * y.y) + ((double)x.z * y.z + (double)x.w * y.w);
+    }
+    __shared__ double red[4];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) G[(int64_t)l * KB + k] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void __launch_bounds__(256) k_term_fold_spatial(const int *__restrict__ erow, const int *__restrict__ ecol, int64_t nnz, int64_t d, const int *__restrict__ cnt,
+                                                           const int *__restrict__ wk, const float *__restrict__ wv, const float *__restrict__ G, int KB, float sign,
+                                                           float *__restrict__ U) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const int m = erow[e], n = cnt[m];
+    if (n == 0) return;
+    const int k = ecol[e];
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s = fmaf(wv[(int64_t)j * d + m], G[(int64_t)wk[(int64_t)j * d + m] * KB + k], s);
+    U[e] += sign * s;
+}
+constexpr int64_t FOLD_MAX_PAIRS = int64_t(1) << 16;
+// can the pending / applied terms of P be taken in through a spatial projection onto K traces with row stride ldc?
+bool residual_term_foldable_spatial(const Patch *P, int32_t K, int64_t ldc) {
+    if (!P->pend) return true;
+    if (P->pend_ac && (P->pend_ldc != ldc || (int64_t)P->pend_K * K > FOLD_MAX_PAIRS)) return false;
+    if (P->res_ac && (P->res_ldc != ldc || (int64_t)P->res_K * K > FOLD_MAX_PAIRS)) return false;
+    return true;
+}
+int residual_term_fold_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, int64_t nnz, const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU, DevBuf &dG) {
+    if (!P->pend || nnz == 0) return 0;
+    const int64_t T = P->T;
+    auto one = [&](int Kt, const DevBuf &cnt, const DevBuf &wk, const DevBuf &wv, const DevBuf &cc, float sign) -> int {
+        if (Kt <= 0) return 0;
+        RET(dG.ensure((size_t)Kt * K * sizeof(float)));
+        LAUNCH(ctx, "spatial_term_gram", k_cross_gram, dim3((unsigned)K, (unsigned)Kt), dim3(256), 0, cc.as<float>(), ldc, dCc, ldc, T, (int)K, dG.as<float>());
+        LAUNCH(ctx, "spatial_term_fold", k_term_fold_spatial, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dErow, dEcol, nnz, P->d, cnt.as<int>(), wk.as<int>(),
+               wv.as<float>(), dG.as<float>(), (int)K, sign, dU);
+        return 0;
+    };
+    if (P->pend_ac) RET(one(P->pend_K, P->pendCnt, P->pendK, P->pendV, P->pendCc, 1.f));
+    if (P->res_ac)  RET(one(P->res_K, P->resCnt, P->resK, P->resV, P->resCc, -1.f));
+    return 0;
+}
+
 // ---- compute_RSS (Sources2D.m:1358-1510), ring model, bg_ssub = 1 ------------------------------------------------------------
 // E = Y(patch) - A C - (W (Y_block - b0_block - A_prev C_prev) + b0_new).  With the resident residual of (A_prev, C_prev),
 // Ysig = Yc + (Ymean - b0) - W Yc + (W A_prev)(C_prev - mean):  E = Ysig + kappa - A C,
@@ -1020,12 +1073,17 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     int variant = (int)ctx->opt("r1_variant", 14);
     const int h = P->radius;
     if (variant >= 0 && variant != 10 && variant != 11 && variant != 14) variant = 14;
-    if (variant == 14 && (has_ac || h != 15)) variant = 11;   // duo roles (resid_duo.hpp): radius 15, no footprint term inside the sweep
     bool full_ring = true;
     { int n = 0;
       for (int c = -h; c <= h && full_ring; ++c) for (int r = -h; r <= h; ++r) { int d2 = c * c + r * r;
           if (d2 >= h * h && d2 < (h + 1) * (h + 1)) { if (n >= P->p || P->dr[n] != r || P->dc[n] != c) { full_ring = false; break; } ++n; } }
       if (n != P->p) full_ring = false; }
+    // The footprint term (W A_prev)(C_prev - mean) of a patch with halo neurons need not go through the sweep at all: the sweep runs without it (so the
+    // faster duo-role kernel serves patched runs too) and the term stays PENDING beside Ysig -- the spatial and the temporal update both take it in
+    // algebraically, through their projections (residual_term_fold_spatial, residual_term_project); any other consumer materialises it first.
+    const bool defer_term = has_ac && variant == 14 && h == 15 && full_ring && !outbuf && !Ysig_out && ctx->opt("r1_lazy", 1) != 0 && ctx->opt("r1_defer", 1) != 0;
+    const bool sweep_ac = has_ac && !defer_term;
+    if (variant == 14 && (sweep_ac || h != 15)) variant = 11;   // duo roles (resid_duo.hpp): radius 15, no footprint term inside the sweep
     if (h == 18 && variant >= 11) variant = 10;               // arc kernels: radius 15 only (ds_read immediates)
     // the low-resolution rings of bg_ssub = 2, 3 (ceil(15/2) = 8, ceil(18/2) = 9, ceil(15/3) = 5, ceil(18/3) = 6): LDS-DMA kernel only
     const bool small_special = full_ring && (h == 5 || h == 6 || h == 8 || h == 9) && variant >= 0;
@@ -1041,8 +1099,8 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     a.T = T;
     a.W = P->W.as<float>(); a.p = P->p; a.h = h; a.offs = nullptr;
     a.ymean_f = P->ymean_f.as<float>(); a.dlt = dDlt.as<float>();
-    a.wa_cnt = has_ac ? dWaCnt.as<int>() : nullptr; a.wa_k = has_ac ? dWaK.as<int>() : nullptr;
-    a.wa_v = has_ac ? dWaV.as<float>() : nullptr; a.Cc = has_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
+    a.wa_cnt = sweep_ac ? dWaCnt.as<int>() : nullptr; a.wa_k = sweep_ac ? dWaK.as<int>() : nullptr;
+    a.wa_v = sweep_ac ? dWaV.as<float>() : nullptr; a.Cc = sweep_ac ? dCc.as<float>() : nullptr; a.ldc = ldc;
     a.Ysig4 = ysig.as<float4>();
     a.ntile_r = (P->nr + TR - 1) / TR;
     a.probe = (int)ctx->opt("r1_probe", 0);
@@ -1060,12 +1118,12 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
         a.tile_map = dOffs.as<int>();
         const dim3 gridd((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
-        if (h == 15) rc = launch_r1_v<15>(ctx, variant, a, has_ac, ntile_c, nseg);
-        else if (h == 18) rc = launch_r1_v<18>(ctx, variant, a, has_ac, ntile_c, nseg);
-        else if (h == 8) rc = launch_r1_dma<8, 32, 16>(ctx, a, has_ac, gridd);
-        else if (h == 9) rc = launch_r1_dma<9, 32, 16>(ctx, a, has_ac, gridd);
-        else if (h == 5) rc = launch_r1_dma<5, 32, 16>(ctx, a, has_ac, gridd);
-        else rc = launch_r1_dma<6, 32, 16>(ctx, a, has_ac, gridd);
+        if (h == 15) rc = launch_r1_v<15>(ctx, variant, a, sweep_ac, ntile_c, nseg);
+        else if (h == 18) rc = launch_r1_v<18>(ctx, variant, a, sweep_ac, ntile_c, nseg);
+        else if (h == 8) rc = launch_r1_dma<8, 32, 16>(ctx, a, sweep_ac, gridd);
+        else if (h == 9) rc = launch_r1_dma<9, 32, 16>(ctx, a, sweep_ac, gridd);
+        else if (h == 5) rc = launch_r1_dma<5, 32, 16>(ctx, a, sweep_ac, gridd);
+        else rc = launch_r1_dma<6, 32, 16>(ctx, a, sweep_ac, gridd);
     } else {
         std::vector<int32_t> offs(std::max(1, P->p), 0);
         for (int i = 0; i < P->p; ++i) offs[i] = P->dc[i] * HR + P->dr[i];
@@ -1079,12 +1137,17 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
             CK(hipFuncSetAttribute((const void *)k_residual_gen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         }
         dim3 grid((unsigned)ntiles, (unsigned)nseg);
-        if (has_ac) LAUNCH(ctx, "residual_r1_generic", k_residual_gen<true>, grid, dim3(256), shmem, a);
-        else        LAUNCH(ctx, "residual_r1_generic", k_residual_gen<false>, grid, dim3(256), shmem, a);
+        if (sweep_ac) LAUNCH(ctx, "residual_r1_generic", k_residual_gen<true>, grid, dim3(256), shmem, a);
+        else          LAUNCH(ctx, "residual_r1_generic", k_residual_gen<false>, grid, dim3(256), shmem, a);
         rc = 0;
     }
     RET(rc);
-    keep();
+    if (defer_term) {                                        // Ysig carries no term; the one asked for waits beside it
+        P->res_ac = false; P->res_ldc = ldc; P->res_kind = 1; P->res_K = 0;
+        P->pend = true; P->pend_ac = true; P->pend_ldc = ldc; P->pend_K = Ksel;
+        P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm);
+    } else
+        keep();
     ctx->last_ldc = ldc;
     P->ysig_valid = true;
     if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
