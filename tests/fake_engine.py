@@ -177,3 +177,30 @@ class LazyFakeEngine(FakeEngine):
 
     def stitch_finish(self, subtract_min, want=True):
         return super().stitch_finish(subtract_min)
+
+
+class LateFakeEngine(LazyFakeEngine):
+    """... and with the real engine's queued download: fetch.start() (cnmfe_update_spatial_fetch_async) and fetch(compact=True) (no stored zeros; with
+    connected_fov the raw update comes as a recipe) -- the surface behind which sources2d collects a patch's result one patch late"""
+    def update_spatial(self, pid, algorithm, A_patch, C_patch, IND_patch, sn=None, param=3, defer=False):
+        inner = super().update_spatial(pid, algorithm, A_patch, C_patch, IND_patch, sn, param, defer)
+        if not defer:
+            return inner
+
+        def comp(M):
+            M = sp.csc_matrix(M).copy(); M.eliminate_zeros(); M.sort_indices()
+            return M
+
+        def fetch(connected_fov=None, compact=False):
+            r = inner(connected_fov)
+            if not compact:
+                return r
+            if connected_fov is None:
+                return comp(r)
+            raw, pp = r
+            return (lambda: comp(raw)), comp(pp)
+
+        def start():
+            self.calls.append(("start", pid))
+        fetch.start = start
+        return fetch

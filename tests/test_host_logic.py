@@ -304,6 +304,53 @@ def test_asynchronous_engine_orderings_give_the_same_iteration(pdims, update_sn)
     assert [c[1] for c in calls] == [v.pid[idx] for idx in v.owned for _ in range(4)]
 
 
+@pytest.mark.parametrize("pdims", [[20, 22], [14, 15], None])
+def test_late_collection_of_spatial_results_gives_the_same_iteration(pdims):
+    """with the real engine's queued download (fetch.start / fetch(compact=True)) sources2d queues patch m + 1 before it collects patch m and leaves the
+    one-patch A_raw as a recipe: two iterations equal the blocking double's exactly, A_raw included, and every fetch but the last follows the NEXT
+    patch's launches."""
+    from fake_engine import FakeEngine, LateFakeEngine
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 40, 44, 120, 6, 4
+    f = synth.make_factors(d1, d2, T, K, 31, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32).astype(np.float64)
+
+    def run(engine):
+        v = PatchedVideo(d1, d2, T, pdims or [d1, d2], r, engine)
+        v.upload_from_full(Y)
+        s = Sources2D(v, Options(ring_radius=r, spatial_algorithm="hals", maxIter=3), f.A_init, f.C_init, f.sn)
+        for _ in range(2):
+            s.update_background_parallel()
+            mark[0] = len(getattr(engine, "calls", []))
+            s.update_spatial_parallel(); s.update_temporal_parallel()
+        return s, v
+
+    mark = [0]
+    a, _ = run(FakeEngine())
+    eng = LateFakeEngine()
+    b, v = run(eng)
+    assert (a.A != b.A).nnz == 0 and np.array_equal(np.asarray(a.C), np.asarray(b.C)) and np.array_equal(np.asarray(a.C_raw), np.asarray(b.C_raw))
+    assert callable(b.__dict__["_A_raw"]) == (pdims is None)               # one patch: still the recipe ...
+    assert (sp.csc_matrix(a.A_raw) != sp.csc_matrix(b.A_raw)).nnz == 0     # ... that builds the same matrix on first read
+    assert not callable(b.__dict__["_A_raw"])
+    assert np.array_equal(a.b0_new, b.b0_new)
+    last = eng.calls[mark[0]:]
+    if pdims is None:
+        assert [c[0] for c in last[:4]] == ["residual", "update_spatial", "residual", "fetch"]      # the whole-FOV fetch is not deferred
+        return
+    calls = [c for c in last if c[0] in ("update_spatial", "start", "fetch")]
+    pids = [p_ for c, p_ in calls if c == "update_spatial"]               # (patches without a neuron are skipped)
+    assert len(pids) > 2
+    expect = []
+    for i, p_ in enumerate(pids):
+        expect += [("update_spatial", p_), ("start", p_)]
+        if i > 0:
+            expect.append(("fetch", pids[i - 1]))
+    expect.append(("fetch", pids[-1]))
+    assert calls == expect, calls
+
+
 def test_sparse_row_selection_matches_scipy_on_random_matrices():
     """rows_of / Sources2D._slice (the O(nnz) selection of a block's, patch's or halo's rows out of the d x K footprints, with the bounding-box
     prefilter) against plain scipy indexing: `ind = find(sum(A(mask, :), 1) > 0)`, `A(mask, ind)` -- on random matrices with empty columns,
