@@ -1,5 +1,6 @@
 // C-ABI surface + context / data-plane / ring-pattern plumbing.   (gfx950 only)
 #include "common.hpp"
+#include <mutex>
 #include <hip/hip_fp16.h>
 #include <math.h>
 #include <dlfcn.h>
@@ -155,25 +156,49 @@ __global__ void __launch_bounds__(256) k_pin_copy(PinSegs s) {
     const unsigned n16 = s.n16[g];
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
 }
-static thread_local cnmfe_ctx *g_pin_ctx = nullptr;        // the context of this thread that may hold uploads back
-void pin_flush_thread() { if (g_pin_ctx && g_pin_ctx->npseg) g_pin_ctx->flush_copies(); }
+// every live context, so that a buffer about to be freed can have ALL held-back uploads sent first whoever holds them (DevBuf::ensure / ~DevBuf); the
+// mutex also serialises the segment lists against a second host thread driving the same context
+static std::mutex g_pin_mu;
+static std::vector<cnmfe_ctx *> g_pin_live;
+void pin_register(cnmfe_ctx *ctx, bool live) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = std::find(g_pin_live.begin(), g_pin_live.end(), ctx);
+    if (live && it == g_pin_live.end()) g_pin_live.push_back(ctx);
+    if (!live && it != g_pin_live.end()) g_pin_live.erase(it);
+}
+static void flush_locked(cnmfe_ctx *ctx) {
+    if (!ctx->npseg) return;
+    PinSegs &pseg = ctx->pseg;
+    unsigned mx = 0;
+    for (int i = 0; i < ctx->npseg; ++i) mx = std::max(mx, pseg.n16[i]);
+    for (int i = ctx->npseg; i < PIN_NSEG; ++i) { pseg.src[i] = nullptr; pseg.dst[i] = nullptr; pseg.n16[i] = 0; }
+    const unsigned nb = std::min<unsigned>((mx + 255) / 256, 256);
+    const int n = ctx->npseg; ctx->npseg = 0;
+    hipLaunchKernelGGL(k_pin_copy, dim3(nb, (unsigned)n), dim3(256), 0, ctx->stream_, pseg);      // (a failed launch is reported by the next LAUNCH's hipGetLastError)
+}
+void pin_flush_all() {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    int cur = -1;
+    for (cnmfe_ctx *c : g_pin_live) {
+        if (!c->npseg) continue;
+        if (cur < 0) (void)hipGetDevice(&cur);
+        if (c->device != cur) (void)hipSetDevice(c->device);         // a launch goes to the current device's streams only
+        flush_locked(c);
+        if (c->device != cur) (void)hipSetDevice(cur);
+    }
+}
 int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t bytes) {
     if (bytes > (size_t(8) << 20)) { CK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->st())); return 0; }
-    if (ctx->npseg == PIN_NSEG) ctx->flush_copies();
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (ctx->npseg == PIN_NSEG) flush_locked(ctx);
     const int i = ctx->npseg++;
     ctx->pseg.src[i] = (const uint4 *)src_pinned; ctx->pseg.dst[i] = (uint4 *)dst; ctx->pseg.n16[i] = (unsigned)((bytes + 15) / 16);
-    g_pin_ctx = ctx;
     return 0;
 }
 }  // namespace cnmfe
 void cnmfe_ctx::flush_copies() {
-    if (!npseg) return;
-    unsigned mx = 0;
-    for (int i = 0; i < npseg; ++i) mx = std::max(mx, pseg.n16[i]);
-    for (int i = npseg; i < cnmfe::PIN_NSEG; ++i) { pseg.src[i] = nullptr; pseg.dst[i] = nullptr; pseg.n16[i] = 0; }
-    const unsigned nb = std::min<unsigned>((mx + 255) / 256, 256);
-    const int n = npseg; npseg = 0;
-    hipLaunchKernelGGL(cnmfe::k_pin_copy, dim3(nb, (unsigned)n), dim3(256), 0, stream_, pseg);      // (a failed launch is reported by the next LAUNCH's hipGetLastError)
+    std::lock_guard<std::mutex> lk(cnmfe::g_pin_mu);
+    cnmfe::flush_locked(this);
 }
 namespace cnmfe {
 
@@ -380,7 +405,7 @@ cnmfe_ctx::~cnmfe_ctx() {
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (ev_bound_ready) (void)hipEventDestroy(ev_bound_ready);
     if (ev_copy_done) (void)hipEventDestroy(ev_copy_done);
-    if (cnmfe::g_pin_ctx == this) cnmfe::g_pin_ctx = nullptr;
+    cnmfe::pin_register(this, false);
     for (auto e : tickets) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -399,6 +424,7 @@ cnmfe_ctx *cnmfe_create(int device) {
     cnmfe_ctx *ctx = new cnmfe_ctx();
     ctx->device = device;
     if (hipStreamCreate(&ctx->stream_) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    pin_register(ctx, true);
     if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
     return ctx;
 }

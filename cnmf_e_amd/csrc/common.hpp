@@ -26,17 +26,17 @@ inline int fail(int code, const char *fmt, ...) {
     return cnmfe::fail(CNMFE_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)
 #define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
 
-void pin_flush_thread();      // api.hip: enqueue the small uploads this thread's context still holds back (see cnmfe_ctx::st)
+void pin_flush_all();         // api.hip: enqueue the small uploads any context still holds back (see cnmfe_ctx::st) -- before device memory is freed
 
 // ---- owned device buffer -----------------------------------------------------
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
-    ~DevBuf() { if (p) { pin_flush_thread(); (void)hipFree(p); } }
+    ~DevBuf() { if (p) { pin_flush_all(); (void)hipFree(p); } }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) { pin_flush_thread(); (void)hipFree(p); p = nullptr; cap = 0; }     // (an upload into the old allocation may still be held back)
+        if (p) { pin_flush_all(); (void)hipFree(p); p = nullptr; cap = 0; }     // (an upload into the old allocation may still be held back)
         size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return fail(CNMFE_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
@@ -267,6 +267,7 @@ struct HostTrace {
 };
 inline Patch *get_patch(cnmfe_ctx *ctx, int id) { auto it = ctx->patches.find(id); return it == ctx->patches.end() ? nullptr : it->second; }
 int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t bytes);   // api.hip
+void pin_register(cnmfe_ctx *ctx, bool live);
 // upload a host vector to a DevBuf on the context stream
 template <class T> inline int to_dev(cnmfe_ctx *ctx, DevBuf &b, const T *h, size_t n) {
     RET(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
