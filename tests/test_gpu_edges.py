@@ -763,3 +763,48 @@ def test_deconv_temporal_on_the_bound_matrix_equals_the_host_path(eng):
     # the bound matrix now holds C: a second deconvolution of the bound matrix deconvolves C, not Y
     C2 = np.asarray(eng.deconv_temporal_bound(opts)[0])
     assert np.array_equal(C2, eng.deconv_temporal(Cr.copy(), opts)[0])
+
+
+@pytest.mark.parametrize("dims", [(64, 64), (70, 50)])
+def test_deferred_footprint_term_through_update_spatial(eng, dims):
+    """r1_defer (default, ring radius 15): a residual with a footprint term runs its sweep WITHOUT the term (the duo-role kernel) and leaves the term
+    pending; cnmfe_update_spatial takes it in through its projection, U += (W A_prev)(Cc_prev Cc'), cnmfe_hals_temporal through A' as before, and a
+    consumer of Ysig itself (GetSn, an exported residual) folds it in first.  Against the in-sweep term (r1_defer = 0) on a tile-aligned patch and on
+    one with partial tiles; HALS and NNLS read the same U."""
+    d1, d2 = dims
+    T, r, K = 160, 15, 6
+    f, Y, video = _video(eng, d1, d2, T, K, r, 21)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32)
+    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    eng.fit_ring_model(0, A, Cm)
+    prev = np.array([0, 3, 4])                                  # the "halo neurons" of the term
+    IND = sp.csc_matrix((A.toarray() > 0) | (np.roll(A.toarray(), 1, axis=0) > 0)).astype(np.float32)
+    def run(defer, alg):
+        eng.set_option("r1_defer", defer)
+        eng.set_b0(0, eng.b0(0))                                # invalidates the resident Ysig: the next residual is a sweep
+        eng.profile(True); eng.profile_reset()
+        eng.residual(0, A[:, prev], Cm[prev])
+        Anew = eng.update_spatial(0, alg, A, Cm, IND, param=20 if alg == "nnls" else 3)
+        tab = eng.profile_table()
+        eng.residual(0, A, Cm)                                  # the temporal update's request: pending in both modes
+        c = eng.hals_temporal(0, A, Cm, 3)
+        sn = eng.get_sn(0)
+        y = eng.residual(0, A, Cm, want=True)
+        eng.profile(False)
+        return Anew, tab, c, sn, y
+    try:
+        for alg in ("hals", "nnls"):
+            (a0, t0, c0, sn0, y0), (a1, t1, c1, sn1, y1) = run(0, alg), run(1, alg)
+            calls = lambda t, k: t.get(k, {"calls": 0})["calls"]
+            assert calls(t0, "spatial_term_fold") == 0 and calls(t1, "spatial_term_fold") == 1 and calls(t1, "spatial_term_gram") == 1, (t0, t1)
+            assert calls(t1, "residual_delta") == 0                                 # the deferred term never went through Ysig before the spatial update
+            d0, d1_ = a0.toarray(), a1.toarray()
+            assert np.array_equal(d0 > 0, d1_ > 0) or np.abs(d0 - d1_).max() <= 1e-5 * np.abs(d0).max()
+            assert np.abs(d0 - d1_).max() <= 1e-5 * np.abs(d0).max()
+            for x, z in zip(c0, c1):
+                assert np.abs(x - z).max() <= 1e-5 * max(1.0, np.abs(x).max())
+            assert np.allclose(sn0, sn1, rtol=1e-5)
+            assert np.abs(y0 - y1).max() <= 2e-6 * np.abs(y0).max()
+    finally:
+        eng.set_option("r1_defer", 1)
