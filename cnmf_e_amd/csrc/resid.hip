@@ -1035,8 +1035,8 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         const int nnzA = (int)csr.col.size();
         const size_t wa_stage = (size_t)nnzA * 8;
         if (wa_stage <= 96 * 1024) {                               // (32 KB static + this: one workgroup per CU above ~48 KB, still every CU of a small patch's grid)
-            static bool attr = false;
-            if (!attr) { CK(hipFuncSetAttribute((const void *)k_ring_wa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+            if (wa_stage > 32 * 1024)                                // (per device: set where it is needed, not once per process)
+                CK(hipFuncSetAttribute((const void *)k_ring_wa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             LAUNCH(ctx, "r1_ring_wa", k_ring_wa<true>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), wa_stage, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
                    P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
                    dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);

@@ -164,7 +164,10 @@ int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssu
  * term (W*A_prev)*(C_prev - mean): the difference is folded into the resident Ysig in one streaming pass (option "r1_delta",
  * default 1), or merely recorded (option "r1_lazy", default 1) -- cnmfe_hals_temporal[_deconv] then adds A'*(W*A_prev)*(C_prev - mean)
  * to A'*Ysig without another pass over the video, every other consumer folds it in first.  The values any caller sees are those of
- * the full expression above (up to fp32 rounding of the re-association). */
+ * the full expression above (up to fp32 rounding of the re-association).
+ * Option "r1_defer" (default 1; ring radius 15, no Ysig_out): the FIRST residual after a fit also runs its sweep without the footprint term and leaves
+ * the term pending -- cnmfe_update_spatial adds (W*A_prev)*((C_prev - mean)*(C - mean)') to its projection Ysig*C' on the search mask, so patches with
+ * halo neurons are swept by the same (fastest) kernel as a patch without. */
 int cnmfe_residual(cnmfe_ctx *ctx, int patch_id, int32_t Ksel, const int64_t *A_colptr,
                    const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                    float *Ysig_out, int out_memspace);
@@ -339,7 +342,7 @@ int cnmfe_profile_reset(cnmfe_ctx *ctx);
 int cnmfe_profile_count(cnmfe_ctx *ctx);
 int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *calls);
 int cnmfe_synchronize(cnmfe_ctx *ctx);
-/* tunables for A/B runs; unknown names -> CNMFE_EINVAL.  r1_variant (R1 kernel), r1_delta / r1_lazy (incremental residual, see
+/* tunables for A/B runs; unknown names -> CNMFE_EINVAL.  r1_variant (R1 kernel), r1_delta / r1_lazy / r1_defer (incremental residual, see
  * cnmfe_residual), gram_incremental (see cnmfe_fit_ring_model), gram_mode 1 | 2 | 3 = fp64 | fp32 | split-bf16 matrix pipe for the direct
  * Gram, gram_kernel, gram_flush, solve_mode, tile_order, debug (1: NaN-poison never-computed table entries), *_probe (timing experiments) */
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);
