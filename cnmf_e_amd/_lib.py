@@ -81,6 +81,8 @@ PROTOTYPES = {
     "cnmfe_csc_drop_zeros": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "cnmfe_update_spatial_fetch_async": (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "cnmfe_ticket_wait": (C.c_int, [c_ctx, C.c_int64]),
+    "cnmfe_copy_generation": (C.c_int, [c_ctx, C.POINTER(C.c_int64)]),
+    "cnmfe_copy_wait": (C.c_int, [c_ctx, C.c_int64]),
     "cnmfe_csc_select_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "cnmfe_set_noise": (C.c_int, [c_ctx, C.c_int, f32p]),

@@ -196,6 +196,14 @@ int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t byte
     return 0;
 }
 }  // namespace cnmfe
+int cnmfe_ctx::copy_batch_mark() {
+    hipEvent_t e;
+    if (!copy_ev_pool.empty()) { e = copy_ev_pool.back(); copy_ev_pool.pop_back(); }
+    else CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CK(hipEventRecord(e, copy_stream));
+    copy_gens.push_back({++copy_gen, e});
+    return 0;
+}
 void cnmfe_ctx::flush_copies() {
     std::lock_guard<std::mutex> lk(cnmfe::g_pin_mu);
     cnmfe::flush_locked(this);
@@ -293,6 +301,7 @@ int ctx_check_errflag(cnmfe_ctx *ctx) {
     if (!h) return 0;
     CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
     if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 32 footprints of A_prev (flag %d)", h);
+    if (h & 4) return fail(CNMFE_EUNSUPPORTED, "bg_ssub > 1: a pixel's interpolation window meets more than 32 footprints of A_prev (flag %d)", h);
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
 }
 
@@ -362,6 +371,7 @@ static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out,
         CK(hipMemcpy2DAsync(C_raw_out, T * sizeof(float), ctx->bound.p, ldc * sizeof(float), T * sizeof(float), K, hipMemcpyDeviceToHost, ctx->copy_stream));
         CK(hipEventRecord(ctx->ev_copy_done, ctx->copy_stream));
         ctx->copy_pending = true;
+        RET(ctx->copy_batch_mark());
         return 0;
     }
     if (C_raw_out) RET(download_traces(ctx, ctx->bound.as<float>(), ldc, C_raw_out, K, T, c_order == CNMFE_COLMAJOR ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR));
@@ -405,6 +415,8 @@ cnmfe_ctx::~cnmfe_ctx() {
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (ev_bound_ready) (void)hipEventDestroy(ev_bound_ready);
     if (ev_copy_done) (void)hipEventDestroy(ev_copy_done);
+    for (auto &g : copy_gens) (void)hipEventDestroy(g.second);
+    for (auto e : copy_ev_pool) (void)hipEventDestroy(e);
     cnmfe::pin_register(this, false);
     for (auto e : tickets) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -948,6 +960,26 @@ int cnmfe_stitch_dims(cnmfe_ctx *ctx, int32_t *K, int64_t *T) {
 int cnmfe_stitch_wait(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     if (ctx->ev_copy_done && ctx->copy_stream) CK(hipStreamSynchronize(ctx->copy_stream));
+    for (auto &g : ctx->copy_gens) ctx->copy_ev_pool.push_back(g.second);
+    ctx->copy_gens.clear();
+    return 0;
+}
+
+int cnmfe_copy_generation(cnmfe_ctx *ctx, int64_t *gen) {
+    if (!ctx || !gen) return fail(CNMFE_EINVAL, "null context / gen");
+    *gen = ctx->copy_gen;
+    return 0;
+}
+
+int cnmfe_copy_wait(cnmfe_ctx *ctx, int64_t gen) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (gen > ctx->copy_gen) return fail(CNMFE_ESTATE, "download batch %lld has not been queued (last: %lld)", (long long)gen, (long long)ctx->copy_gen);
+    size_t n = 0;
+    while (n < ctx->copy_gens.size() && ctx->copy_gens[n].first <= gen) ++n;       // (ascending; batches complete in order)
+    if (n == 0) return 0;                                  // already known to be complete
+    CK(hipEventSynchronize(ctx->copy_gens[n - 1].second));
+    for (size_t i = 0; i < n; ++i) ctx->copy_ev_pool.push_back(ctx->copy_gens[i].second);
+    ctx->copy_gens.erase(ctx->copy_gens.begin(), ctx->copy_gens.begin() + n);
     return 0;
 }
 

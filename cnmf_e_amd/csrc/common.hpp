@@ -214,6 +214,10 @@ struct cnmfe_ctx {
     int64_t spatial_nnz = -1;                              // values of the last cnmfe_update_spatial still in scr[6] (deferred fetch)
     hipStream_t copy_stream = nullptr;                     // device -> pinned host downloads that should not hold up the compute stream
     hipEvent_t ev_bound_ready = nullptr, ev_copy_done = nullptr; bool copy_pending = false;
+    // every batch of downloads on the copy stream gets a generation number and an event of its own: a host buffer waits for ITS batch (cnmfe_copy_wait),
+    // not for whatever was queued on the copy stream since (cnmfe_stitch_wait) -- releasing last iteration's traces must not wait for this iteration's
+    int64_t copy_gen = 0; std::vector<std::pair<int64_t, hipEvent_t>> copy_gens; std::vector<hipEvent_t> copy_ev_pool;
+    int copy_batch_mark();                                 // api.hip: after the last enqueue of a batch on copy_stream
     std::vector<hipEvent_t> tickets; std::vector<char> ticket_busy;   // cnmfe_update_spatial_fetch_async / cnmfe_ticket_wait
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;

@@ -940,6 +940,7 @@ int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out
         if (sn_out) CK(hipMemcpyAsync(sn_out, dSn.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
         CK(hipEventRecord(ctx->ev_copy_done, ctx->copy_stream));
         ctx->copy_pending = true;
+        RET(ctx->copy_batch_mark());
     }
     return 0;
 }

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(128) k_wa_upsample(int64_t d, int nr, int nr_b
                 int s_ = 0;
                 while (s_ < n && tk[s_][t] != k) ++s_;
                 if (s_ == n) {
-                    if (n == UP_CAP) { *overflow = 1; continue; }
+                    if (n == UP_CAP) { atomicOr(overflow, 4); continue; }     // (bit 2 of the context's error flag: reported at the next wait)
                     tk[s_][t] = k; tv[s_][t] = 0.f; ++n;
                 }
                 tv[s_][t] = fmaf(w, v_l[(int64_t)e * d_low + j], tv[s_][t]);
@@ -400,38 +400,28 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     DevBuf &dIr = ctx->tmp[0], &dWr = ctx->scr[21], &dIc = ctx->tmp[2], &dWc = ctx->tmp[3], &dDlt = ctx->tmp[7];
     RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
     RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
-    // the footprint term of this call at full resolution: into the pending (reuse) or the applied slot of the main patch
-    bool term_ok = true;
+    // the footprint term of this call at full resolution: into the pending (reuse) or the applied slot of the main patch.  A pixel whose interpolation
+    // window meets more than UP_CAP footprints raises the context's error flag (reported by the next call that waits, like the low-resolution ring's own
+    // limit in k_ring_wa): reading a flag back here cost a drain of the stream in each of the iteration's two residual calls
     {
         DevBuf &tCnt = reuse ? M->pendCnt : M->resCnt, &tK = reuse ? M->pendK : M->resK, &tV = reuse ? M->pendV : M->resV;
         if (has_a) {
-            DevBuf &dFlag = ctx->tmp[11];
+            int *dErr = nullptr;
+            RET(ctx_errflag(ctx, &dErr));
             RET(tCnt.ensure((size_t)M->d * sizeof(int))); RET(tK.ensure((size_t)UP_CAP * M->d * sizeof(int))); RET(tV.ensure((size_t)UP_CAP * M->d * sizeof(float)));
-            RET(dFlag.ensure(64));
-            CK(hipMemsetAsync(dFlag.p, 0, 64, ctx->st()));
             LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + 127) / 128)), dim3(128), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
                    dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P, ctx->tmp[8].as<int>(), ctx->tmp[9].as<int>(), ctx->tmp[10].as<float>(),
-                   tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dFlag.as<int>());
-            int flag = 0;
-            CK(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
-            CK(hipStreamSynchronize(ctx->st()));
-            term_ok = flag == 0;                              // a pixel near more than UP_CAP footprints: no term kept, the next call sweeps again
+                   tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dErr);
             (reuse ? M->pendCc : M->resCc).swap(tCc);
-        } else CK(hipStreamSynchronize(ctx->st()));         // the tap vectors die with this call
-        if (reuse && term_ok) {
+        }
+        if (reuse) {
             M->pend = true; M->pend_ac = has_a; M->pend_ldc = ldc_t; M->pend_K = K;
             if (ctx->opt("r1_lazy", 1) == 0 || Ysig_out) RET(residual_materialize(ctx, M));
             if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
             return 0;
         }
-        if (reuse) {                                           // (overflow) fall back to the sweep: the tables are there, run it now
-            RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, 0));
-            RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
-            RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
-            CK(hipStreamSynchronize(ctx->st()));
-        }
-        M->res_ac = has_a && term_ok; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
-        M->res_kind = term_ok ? 2 : 0;
+        M->res_ac = has_a; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
+        M->res_kind = 2;
     }
     const int64_t ntmp = (int64_t)d1s * M->nc_b;
     RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));

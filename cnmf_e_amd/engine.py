@@ -111,19 +111,25 @@ class _PinnedBlock:
     def __init__(self, eng, nbytes):
         import weakref
         self.eng = weakref.ref(eng); self.nbytes = nbytes; self.ready = False
+        self.gen = None                                   # the download batch that fills the buffer (Engine._mark_batch): what wait() waits for
         self.ptr = eng._pinned_take(nbytes)
+    def _wait_ctx(self, ctx, check):
+        # this block's batch only: the copy stream may already hold the NEXT iteration's downloads, which a release of this buffer must not wait for
+        rc = L.lib.cnmfe_stitch_wait(ctx) if self.gen is None else L.lib.cnmfe_copy_wait(ctx, self.gen)
+        if check:
+            L.check(rc)
     def wait(self):
         if not self.ready:
             eng = self.eng()
             if eng is not None and getattr(eng, "_ctx", None):
-                L.check(L.lib.cnmfe_stitch_wait(eng._ctx))       # cnmfe_destroy drains the copy stream itself
+                self._wait_ctx(eng._ctx, True)                   # cnmfe_destroy drains the copy stream itself
             self.ready = True
     def __del__(self):
         try:
             eng = self.eng()
             if eng is not None and getattr(eng, "_ctx", None):
                 if not self.ready:
-                    L.lib.cnmfe_stitch_wait(eng._ctx)            # the copy may still be writing into the buffer
+                    self._wait_ctx(eng._ctx, False)              # the copy may still be writing into the buffer
                 eng._pinned_give(self.ptr, self.nbytes)
             else:
                 L.lib.cnmfe_host_free(self.ptr)
@@ -575,6 +581,7 @@ class Engine:
         if want == "lazy" and K > 0:
             out = LazyHostTraces(self, K, T)
             L.check(L.lib.cnmfe_stitch_finish_async(self._ctx, int(bool(subtract_min)), C.cast(out._ptr, L.f32p)))
+            self._mark_batch(out)
             self._bound = out
             return out
         if want == "bound" and K > 0:                    # no host copy at all: the caller goes on with the bound matrix (deconv_temporal_bound)
@@ -631,8 +638,18 @@ class Engine:
         opts = self._dopts(deconv_options)
         L.check(L.lib.cnmfe_deconv_temporal_bound(self._ctx, C.byref(opts), C.cast(Cout._ptr, L.f32p), C.cast(Craw._ptr, L.f32p), C.cast(S._ptr, L.f32p),
                                                   C.cast(pars._ptr, L.f32p), C.cast(sn._ptr, L.f32p)))
+        self._mark_batch(Cout, Craw, S, pars, sn)
         self._bound = Cout
         return Cout, Craw, S, pars, sn
+
+    def _mark_batch(self, *lazies):
+        """the asynchronous call just made queued one batch of downloads: its generation number goes to the buffers it fills"""
+        g = C.c_int64(0)
+        L.check(L.lib.cnmfe_copy_generation(self._ctx, C.byref(g)))
+        for x in lazies:
+            blk = x._blk()
+            if blk is not None:
+                blk.gen = g.value
 
     def post_process_spatial(self, A_full, d1, d2):
         K, cp, ri, va = _csc(A_full, d1 * d2)

@@ -281,6 +281,10 @@ int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float
  * traces from the device binding this call leaves -- while the temporal kernels and the download are still running. */
 int cnmfe_stitch_finish_async(cnmfe_ctx *ctx, int subtract_min, float *C_raw_pinned);
 int cnmfe_stitch_wait(cnmfe_ctx *ctx);         /* waits for the downloads of cnmfe_stitch_finish_async only (not for the compute stream) */
+/* every asynchronous download batch (cnmfe_stitch_finish_async, cnmfe_deconv_temporal_bound) has a generation number: cnmfe_copy_generation after the call
+ * that queued it, cnmfe_copy_wait(ctx, gen) waits for THAT batch only -- a host that releases last iteration's buffers must not wait for this iteration's. */
+int cnmfe_copy_generation(cnmfe_ctx *ctx, int64_t *gen);
+int cnmfe_copy_wait(cnmfe_ctx *ctx, int64_t gen);
 void *cnmfe_host_alloc(size_t bytes);          /* page-locked host memory (NULL + cnmfe_last_error on failure) */
 void cnmfe_host_free(void *p);
 

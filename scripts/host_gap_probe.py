@@ -1,8 +1,10 @@
 """Where the HOST spends the time between the spatial update's download and the temporal update's first launch at configuration c3 (one patch):
    python scripts/host_gap_probe.py
 wall-clock per call of the Python-side steps (engine fetch, its compaction, stitch_begin, hals_temporal up to its return), averaged over iterations."""
-import os, sys, time, collections
+import argparse, os, sys, time, collections
 import numpy as np
+ap = argparse.ArgumentParser(); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--deconv", action="store_true")
+a_ = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -17,7 +19,7 @@ video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
 for idx in video.owned:
     Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()
     video.upload_block_device(idx, Yb.data_ptr()); del Yb
-s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=5), f.A_init, f.C_init, f.sn)
+s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=5, bg_ssub=a_.bg_ssub, deconv_flag=a_.deconv), f.A_init, f.C_init, f.sn)
 acc = collections.defaultdict(float); cnt = collections.Counter(); marks = []
 def timed(obj, name, label=None):
     fn = getattr(obj, name)
@@ -28,12 +30,13 @@ def timed(obj, name, label=None):
         finally:
             t2 = time.perf_counter(); acc[label or name] += t2 - t; cnt[label or name] += 1; marks.append((label or name, "out", t2))
     setattr(obj, name, w)
-for n in ("stitch_begin", "hals_temporal", "stitch_add", "stitch_finish", "update_spatial", "residual", "fit_ring_model"):
+for n in ("stitch_begin", "hals_temporal", "hals_temporal_deconv", "deconv_temporal_bound", "stitch_add", "stitch_finish", "update_spatial", "residual", "residual_ssub",
+          "fit_ring_model", "fit_ring_model_ssub", "ring_first_run", "bind_traces"):
     timed(eng, n)
-for n in ("_update_b0_new", "_temporal_residual_early", "_search_location_csc", "_prev_block_of"):
+for n in ("_update_b0_new", "_temporal_residual_early", "_search_location_csc", "_prev_block_of", "deconvTemporal", "update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
     timed(s, n)
 L.lib.cnmfe_version()                                                     # (loads the library)
-for n in ("cnmfe_update_spatial_fetch_connected", "cnmfe_csc_drop_zeros", "cnmfe_hals_temporal"):
+for n in ("cnmfe_update_spatial_fetch_connected", "cnmfe_csc_drop_zeros", "cnmfe_hals_temporal", "cnmfe_stitch_wait", "cnmfe_synchronize"):
     timed(L._Lib._dll, n)
 def step():
     t0 = time.perf_counter(); s.update_background_parallel(); t1 = time.perf_counter(); s.update_spatial_parallel(); t2 = time.perf_counter(); s.update_temporal_parallel(); t3 = time.perf_counter()
