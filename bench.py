@@ -39,8 +39,10 @@ CONFIGS = {
     "tiny": (96, 96, 600, 18, 15, 5),
     "c4": (512, 512, 10000, 500, 15, 2),     # BASELINE.json configs[3]: c3's video, 4 x 4 patches sharded over the ranks
     "c4tiny": (96, 96, 600, 18, 15, 5),      # (test size of the c4 code path: 2 x 2 patches of 48 x 48)
+    "c5shard": (1024, 1024, 20000, 2000, 15, 3),   # BASELINE.json configs[4]: ONE rank's share (rank 0 of 8: 8 of the 8 x 8 patches) on one GPU, video uploaded as fp16
 }
-PATCHES = {"c4": [128, 128], "c4tiny": [48, 48]}
+PATCHES = {"c4": [128, 128], "c4tiny": [48, 48], "c5shard": [128, 128]}
+SHARD_OF = {"c5shard": 8}    # configurations that run one rank's patches of an N-rank decomposition without the collectives (a per-rank load figure, not a scaling point)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (157.3 TF), spec
 F32_MFMA_PEAK_TF = 157.3
@@ -176,7 +178,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default=None, help="c3 (default at 1 GPU) | c4 (default at N > 1) | c2 | tiny | c4tiny")
+    ap.add_argument("--config", default=None, help="c3 (default at 1 GPU) | c4 (default at N > 1) | c2 | tiny | c4tiny | c5shard (rank 0 of 8 of configs[4] on one GPU)")
     ap.add_argument("--weak", action="store_true", help="grown-FOV weak scaling (512 x 512N, one patch per rank) instead of the sharded 4 x 4 patches")
     ap.add_argument("--demo-sequence", action="store_true", help="time the call sequence of demo_large_data_1p.m:142-211 from a fresh upload")
     ap.add_argument("--alg", default="hals", help="spatial algorithm: hals | hals_thresh | nnls")
@@ -245,11 +247,21 @@ def main():
     d2, K = (d2p, Kp) if sharded_fov else (d2p * world, Kp * world)
     f = synth.make_factors(d1, d2, T, K, seed)
     eng = Engine(local)
-    video = PatchedVideo(d1, d2, T, PATCHES[a.config] if sharded_fov else [d1, d2p], r, eng, rank=rank, world_size=world)
+    shard_of = SHARD_OF.get(a.config, 0)
+    if shard_of and world > 1:
+        raise SystemExit("%s is one rank's share of a %d-rank run on ONE GPU" % (a.config, shard_of))
+    video = PatchedVideo(d1, d2, T, PATCHES[a.config] if sharded_fov else [d1, d2p], r, eng, rank=0 if shard_of else rank, world_size=shard_of or world)
     for idx in video.owned:                                   # synthesise each owned block directly in HBM
         Yb = synth.make_video_device(f, "cuda:%d" % local, pixels=video.block_pix[idx])
         torch.cuda.synchronize()
-        video.upload_block_device(idx, Yb.data_ptr())
+        if shard_of:                                          # the file's samples are fp16 (configs[4]): uploaded as such, widened on the device
+            from cnmf_e_amd import _lib as L_
+            Yh = Yb.half(); del Yb
+            torch.cuda.synchronize()
+            eng.upload_block_device(video.pid[idx], Yh.data_ptr(), T, dtype=L_.F16)
+            Yb = Yh
+        else:
+            video.upload_block_device(idx, Yb.data_ptr())
         del Yb
     torch.cuda.empty_cache()
     s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=5, deconv_flag=a.deconv, bg_ssub=a.bg_ssub),
@@ -480,7 +492,7 @@ def main():
         dlr = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
                "traffic": pmc_traffic("k_residual_delta"), "kernel": "residual_delta", "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     out = {
-        "metric": "cnmfe_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "metric": "cnmfe_iters_per_sec" if not shard_of else "cnmfe_rank_share_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak" if a.weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("%s: %dx%dx%d fp32 video, K=%d, ring_radius=%d, %dx%d patches of distribute_data.m (%d resident blocks per GPU), "
@@ -489,7 +501,9 @@ def main():
                                ("%s (weak): %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
                                 "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub)),
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
-                   "parallelism": "patches round-robin over %d rank(s)" % world,
+                   "parallelism": ("patches round-robin over %d rank(s)" % world) if not shard_of else
+                                  ("rank 0 of %d: this rank's %d of the %d patches on ONE GPU, no collectives (a per-rank load figure, not a scaling point); "
+                                   "the video is uploaded as fp16 and widened on the device" % (shard_of, len(video.owned), len(video.order))),
                    **({"note": "strong scaling of the 4 x 4-patch decomposition (BASELINE configs[3]); its own N = 1 point is the `c4_n1` object of the N = 1 line "
                                "(16 patches on one GPU) -- the N = 1 `value` is configs[2], the same video as ONE patch, which has no halo re-reads and 16x larger launches"}
                       if (world > 1 and a.config == "c4" and not a.weak) else {})},

@@ -532,7 +532,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     CK(hipStreamSynchronize(ctx->st()));
     std::fill(P->frame_seen.begin() + t0, P->frame_seen.begin() + t0 + nt, (uint8_t)1);
     P->frames_uploaded += nt;
-    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false;
+    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false;
     return 0;
 }
 
@@ -577,7 +577,7 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     CK(hipStreamSynchronize(ctx->st()));
     P->stat_valid = false;
     if (P->stat_host) { (void)hipHostFree(P->stat_host); P->stat_host = nullptr; }      // sized by the number of ring offsets
-    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false;   // (the kept covariance table covers the sub-tiles THIS ring needs)
+    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false;   // (the kept covariance tables cover the sub-tiles THIS ring needs)
     return 0;
 }
 

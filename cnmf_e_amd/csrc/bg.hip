@@ -1010,6 +1010,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             for (int b_ = 0; b_ < nblk_; ++b_) { const int n = lst_ptr[b_ + 1] - lst_ptr[b_]; if (n) blk_nt[(n - 1) >> 4].push_back(b_); }
         }
     }
+    if (incr && P->base_valid && P->base_kstride != kstride) {
+        // the table in place is of another stride: it moves to the second slot, and what that slot held -- the table of THIS stride, if the recording
+        // alternates -- comes forward (otherwise its memory is where the new table is built)
+        P->cov_base.swap(P->cov_base_alt); P->rowsum_base.swap(P->rowsum_base_alt);
+        std::swap(P->base_valid, P->base_alt_valid); std::swap(P->base_kstride, P->base_alt_kstride);
+    }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
     ht.mark("footprint block lists");
     g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16

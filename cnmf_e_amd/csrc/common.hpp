@@ -153,6 +153,10 @@ struct Patch {
     DevBuf cov_base, rowsum_base;
     bool base_valid = false, derived = false;             // derived: a low-resolution patch of bg_ssub > 1 (its video is rebuilt every call)
     int base_kstride = 0;
+    // a second table of the same video at ANOTHER frame stride: the stride follows pmax (fit_ring_model.m:84-87: k = floor(T / min(T, 100 pmax))), and a
+    // recording whose T / (100 pmax) sits at an integer -- T = 20000 with pmax around 66 -- alternates between two strides from fit to fit; one kept table
+    // meant a full fp64 rebuild (10-15 ms per patch) on every flip.  Allocated only when a second stride turns up.
+    DevBuf cov_base_alt, rowsum_base_alt; bool base_alt_valid = false; int base_alt_kstride = 0;
     // what the next fit asks of W before it can queue anything (pmax of fit_ring_model.m:60, row 1 for the first-run test of :25), copied to
     // pinned memory behind the fit that produced W: the next fit reads it without draining the stream (ring_stats_*, api.hip)
     DevBuf stat_dev; void *stat_host = nullptr; hipEvent_t stat_ev = nullptr; bool stat_valid = false;

@@ -808,3 +808,41 @@ def test_deferred_footprint_term_through_update_spatial(eng, dims):
             assert np.abs(y0 - y1).max() <= 2e-6 * np.abs(y0).max()
     finally:
         eng.set_option("r1_defer", 1)
+
+
+def test_two_frame_strides_keep_their_tables(eng):
+    """The frame stride of a fit follows pmax, the largest number of positive weights of W_old (fit_ring_model.m:60,84-87): a recording whose
+    T / (100 pmax) sits near an integer alternates between two strides from fit to fit.  The engine keeps the video's covariance table for BOTH
+    (a second slot, filled when a second stride turns up): three fits at strides 2, 1, 2 build two tables, not three, and every W equals the
+    direct fp64 Gram's."""
+    d1, d2, T, r = 44, 40, 1200, 5
+    f, Y, video = _video(eng, d1, d2, T, 4, r, 41)
+    eng.ring_init(0, r)
+    A = f.A_init.tocsc().astype(np.float32); Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    Wcsr = eng.ring_csr(0)
+    def w_with(npos):
+        """ring weights with exactly min(npos, row length) positive entries per row (the rest negative): pmax = npos"""
+        v = -np.ones(Wcsr.nnz, np.float32) * 0.01
+        for i in range(Wcsr.shape[0]):
+            a, b = Wcsr.indptr[i], Wcsr.indptr[i + 1]
+            v[a:a + min(npos, b - a)] = 0.02
+        return v
+    out = {}
+    try:
+        for incr in (0, 1):
+            eng.set_option("gram_incremental", incr); eng.set_option("gram_mode", 3 if incr else 1)
+            eng.profile(True); eng.profile_reset()
+            res = []
+            for npos, stride in ((6, 2), (12, 1), (6, 2)):
+                eng.ring_set_values(0, w_with(npos))
+                _, info = eng.fit_ring_model(0, A, Cm)
+                assert info["frame_stride"] == stride and info["pmax"] == npos, info
+                res.append(eng.ring_csr(0).data.astype(np.float64))
+            tab = eng.profile_table(); eng.profile(False)
+            out[incr] = res
+            if incr:
+                assert tab["bg_gram_f64"]["calls"] == 2, tab["bg_gram_f64"]              # one table per stride; the third fit found its own again
+        for a, b in zip(out[0], out[1]):
+            assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
+    finally:
+        eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
