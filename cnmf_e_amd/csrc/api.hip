@@ -418,6 +418,7 @@ cnmfe_ctx::~cnmfe_ctx() {
     for (auto &g : copy_gens) (void)hipEventDestroy(g.second);
     for (auto e : copy_ev_pool) (void)hipEventDestroy(e);
     cnmfe::pin_register(this, false);
+    for (auto *j : tjobs) delete j;
     for (auto e : tickets) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -905,6 +906,52 @@ int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T) {
     RET(ctx->stitch.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float)));
     CK(hipMemsetAsync(ctx->stitch.p, 0, (size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float), ctx->st()));
     ctx->stitch_K = K; ctx->stitch_T = T; ctx->stitch_ld = ld; ctx->stitch_open = true;
+    ctx->tjobs_used = 0;                                   // the temporal jobs of the last update are over (their buffers stay for this one's)
+    return 0;
+}
+
+// ---- several patches per context: set every patch's temporal update up first (cnmfe_hals_temporal_job), sweep them together, then add each to the stitch ----
+int cnmfe_hals_temporal_job(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                            const float *C_in, int c_order, int32_t maxIter, const cnmfe_deconv_opts *opts, const float *kernel_pars, int32_t *job_out) {
+    if (!ctx || !job_out) return fail(CNMFE_EINVAL, "null context / job_out");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_ESTATE, "patch %d not created", patch_id);
+    if (!P->ysig_valid) return fail(CNMFE_ESTATE, "cnmfe_residual has not been run for patch %d", patch_id);
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called (it opens a round of temporal jobs)");
+    if (K <= 0) return fail(CNMFE_EINVAL, "K=%d", K);
+    RET(check_csc("A", K, P->d, A_colptr, A_rowidx));
+    if ((!A_val && A_colptr[K] > 0) || (!C_in && c_order != CNMFE_BOUND) || (opts && !kernel_pars)) return fail(CNMFE_EINVAL, "null A_val / C_in / kernel_pars");
+    if (maxIter <= 0) return fail(CNMFE_EINVAL, "maxIter must be positive");
+    CK(hipSetDevice(ctx->device));
+    if (ctx->tjobs_used == (int)ctx->tjobs.size()) ctx->tjobs.push_back(new TemporalJob());
+    TemporalJob *job = ctx->tjobs[ctx->tjobs_used];
+    job->K = 0; job->swept = false;
+    RET(temporal_run(ctx, P, K, A_colptr, A_rowidx, A_val, C_in, c_order, maxIter, nullptr, nullptr, nullptr, opts, const_cast<float *>(kernel_pars), nullptr, nullptr, job));
+    *job_out = ctx->tjobs_used++;
+    return 0;
+}
+int cnmfe_temporal_jobs_sweep(cnmfe_ctx *ctx) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    CK(hipSetDevice(ctx->device));
+    return temporal_sweep_jobs(ctx);
+}
+int cnmfe_stitch_add_job(cnmfe_ctx *ctx, int32_t job_id, int32_t K_m, const int32_t *ind_m) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
+    if (job_id < 0 || job_id >= ctx->tjobs_used) return fail(CNMFE_EINVAL, "temporal job %d does not exist (%d set up since cnmfe_stitch_begin)", job_id, ctx->tjobs_used);
+    TemporalJob *job = ctx->tjobs[job_id];
+    if (!job->swept) return fail(CNMFE_ESTATE, "temporal job %d has not been swept (cnmfe_temporal_jobs_sweep)", job_id);
+    if (K_m != job->K || !ind_m || job->T != ctx->stitch_T) return fail(CNMFE_EINVAL, "temporal job %d holds %d rows x %lld frames", job_id, job->K, (long long)job->T);
+    std::vector<char> seen((size_t)ctx->stitch_K, 0);
+    for (int32_t j = 0; j < K_m; ++j) {
+        if (ind_m[j] < 0 || ind_m[j] >= ctx->stitch_K) return fail(CNMFE_EINVAL, "row %d outside the %d-row accumulator", ind_m[j], ctx->stitch_K);
+        if (seen[ind_m[j]]) return fail(CNMFE_EINVAL, "row %d listed twice", ind_m[j]);
+        seen[ind_m[j]] = 1;
+    }
+    CK(hipSetDevice(ctx->device));
+    RET(to_dev(ctx, ctx->scr[23], ind_m, (size_t)K_m));
+    LAUNCH(ctx, "stitch_add", k_stitch_add, dim3((unsigned)((ctx->stitch_T + 255) / 256), (unsigned)K_m), dim3(256), 0, job->dCraw.as<float>(), job->ldc,
+           job->dAa.as<float>(), ctx->scr[23].as<int>(), ctx->stitch.as<float>(), ctx->stitch_ld, ctx->stitch_T);
     return 0;
 }
 

@@ -166,6 +166,22 @@ struct Patch {
 // device scratch of the OASIS kernels (deconv.hip): pool / task tables, grown on demand and kept with the context
 struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf; };
 
+// One patch's temporal update set up but not swept (cnmfe_hals_temporal_job): its projections, A'A lists and traces in buffers of its own, its
+// Gauss-Seidel level schedule on the host.  cnmfe_temporal_jobs_sweep then runs level l of EVERY job of the context in one launch -- the patches of a
+// rank are independent (update_temporal_parallel.m:112-186 is a parfor over them), and a level is a handful of workgroups whose duration is one
+// trace's chain of work: sixteen patches' levels one after the other leave the chip empty sixteen times as long.
+struct TemporalJob {
+    Patch *P = nullptr; int32_t K = 0; int64_t ldc = 0, T = 0; int maxIter = 0; bool deconv = false; cnmfe_deconv_opts dopts{};
+    DevBuf dC, dColptr, dErow, dAval, dU, dCraw, dNk, dNidx, dNval, dNptr, dAa, dOvf, dS, dPars, dSn, dB;
+    std::vector<std::vector<int>> levels;
+    bool swept = false;
+    // A'A of the job comes back into pinned memory WITHOUT a wait in cnmfe_hals_temporal_job (the host goes on to the next patch); the sweep call waits once
+    // for all jobs and finishes each: aa = diag(A'A) against the host-side column test, the projection again if a footprint term overflowed its list
+    std::vector<int> diag; std::vector<char> upd; bool term_applied = false, finished = false; int nn = 0;
+    float *pin = nullptr; size_t pin_cap = 0;             // nn floats of A'A values + one int (the term-projection overflow word)
+    ~TemporalJob() { if (pin) (void)hipHostFree(pin); }
+};
+
 }  // namespace cnmfe
 
 namespace cnmfe {
@@ -248,6 +264,7 @@ struct cnmfe_ctx {
     // the traces the last cnmfe_hals_temporal[_deconv] / cnmfe_fast_temporal left on the device (C_raw rows, row stride last_t_ldc, and aa): what
     // cnmfe_stitch_add folds into the stitch accumulator without a host round trip
     cnmfe::DevBuf last_craw, last_aa;
+    std::vector<cnmfe::TemporalJob *> tjobs; int tjobs_used = 0;          // cnmfe_hals_temporal_job: kept (with their buffers) from update to update, counted from cnmfe_stitch_begin
     cnmfe::DevBuf dcv_c, dcv_s, dcv_pars, dcv_sn;          // cnmfe_deconv_temporal_bound: C_raw - b (after the swap with `bound`), S, kernel_pars, sn -- read by the copy stream, so not shared scratch
     int32_t last_t_K = 0; int64_t last_t_ldc = 0, last_t_T = 0; bool last_t_valid = false;
     // overlap-region stitch of update_temporal_parallel.m:264-280: acc[k][0..T) = sum_m aa_m(k) C_raw_m(k,:), acc[k][ld-1..] ... see cnmfe_stitch_begin
@@ -314,7 +331,8 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
                 const float *sn, int32_t param, float *A_out);
 int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                  const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out,
-                 const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out);
+                 const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out, TemporalJob *job = nullptr);
+int temporal_sweep_jobs(cnmfe_ctx *ctx);                  // factor.hip: the level sweeps of every job set up since cnmfe_stitch_begin, level by level across the jobs
 #ifdef __HIPCC__
 // LDS-DMA: 64 lanes x 16 B, global (uniform base + per-lane 32-bit byte offset) -> LDS [lds_dst + lane*16].  Invisible to
 // hipcc's s_waitcnt bookkeeping: count completion by hand (vmcnt), then barrier, then read (cdna_hip_programming 5.7).

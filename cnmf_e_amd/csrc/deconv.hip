@@ -25,7 +25,10 @@ struct DeconvCfg {
     int trace;                         // option deconv_trace = k + 1: thread 0 of trace k prints the foopsi / fminbnd sequence (scripts/deconv_trace.py compares it with the oracle's)
 };
 
+// the per-job part of DeconvIO when one launch serves several temporal jobs (factor.hip, temporal_sweep_jobs): workgroup -> jlist[slot] = (job, neuron)
+struct DeconvJobDev { float *C, *Craw, *S; int64_t ldc; const float *U; const int *nptr, *nidx; const float *nval, *aa; float *pars, *sn_out, *b_out; };
 struct DeconvIO {
+    const DeconvJobDev *jobs = nullptr; const int2 *jlist = nullptr;
     const int *list;                   // neuron ids handled by this launch
     float *C; float *Craw; float *S; int64_t ldc;
     const float *U; const int *nptr; const int *nidx; const float *nval; const float *aa;   // HALS inputs
@@ -495,7 +498,15 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     __shared__ double red[8];
     __shared__ int sh_i[4];
     const int tid = threadIdx.x, T = c.T;
-    const int slot = blockIdx.x, k = io.list[slot];
+    const int slot = blockIdx.x;
+    int k;
+    if (io.jobs) {                                         // several jobs in one launch: this workgroup's trace belongs to job e.x
+        const int2 e = io.jlist[slot];
+        const DeconvJobDev j = io.jobs[e.x];
+        k = e.y;
+        io.C = j.C; io.Craw = j.Craw; io.S = j.S; io.ldc = j.ldc; io.U = j.U; io.nptr = j.nptr; io.nidx = j.nidx; io.nval = j.nval; io.aa = j.aa;
+        io.pars = j.pars; io.sn_out = j.sn_out; io.b_out = j.b_out;
+    } else k = io.list[slot];
     const int Tal = (T + 3) & ~3;
     float *y = LONG ? io.ybuf + (int64_t)blockIdx.x * Tal : sm;          // T raw samples (fp32), persistent
     float *scr = LONG ? sm : sm + Tal;               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
@@ -859,6 +870,32 @@ int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64
             RET(deconv_launch(ctx, c, shmem, io, dLvl + off[l], (int)levels[l].size(), scr));
     }
     return 0;                                                // (the caller waits when it takes results back to the host)
+}
+
+// the in-sweep deconvolution of several temporal jobs: one launch per level over all of them
+int temporal_deconv_sweeps_jobs(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64_t T, int maxIter, const std::vector<TemporalJob *> &jobs,
+                                const int2 *dList, const std::vector<int> &off, DevBuf &dTab) {
+    DeconvCfg c; size_t shmem;
+    RET(deconv_setup(dopts, T, 1, c, shmem));
+    std::vector<DeconvJobDev> tab(jobs.size());
+    for (size_t ji = 0; ji < jobs.size(); ++ji) {
+        TemporalJob *j = jobs[ji];
+        tab[ji] = DeconvJobDev{j->dC.as<float>(), j->dCraw.as<float>(), j->dS.as<float>(), j->ldc, j->dU.as<float>(), j->dNptr.as<int>(), j->dNidx.as<int>(),
+                               j->dNval.as<float>(), j->dAa.as<float>(), j->dPars.as<float>(), j->dSn.as<float>(), j->dB.as<float>()};
+    }
+    RET(to_dev(ctx, dTab, tab.data(), tab.size()));
+    DeconvIO io;
+    io.C = io.Craw = io.S = nullptr; io.ldc = 0; io.U = nullptr; io.nptr = io.nidx = nullptr; io.nval = io.aa = nullptr; io.pars = io.sn_out = io.b_out = nullptr;
+    io.jobs = dTab.as<DeconvJobDev>();
+    const size_t nlev = off.size() - 1;
+    for (int it = 0; it < maxIter; ++it) {
+        c.last = it == maxIter - 1;
+        for (size_t l = 0; l < nlev; ++l) {
+            io.jlist = dList + off[l];
+            RET(deconv_launch(ctx, c, shmem, io, nullptr, off[l + 1] - off[l], ctx->dscr));
+        }
+    }
+    return 0;
 }
 
 int deconv_all_run(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, int c_order, const cnmfe_deconv_opts *opts,

@@ -289,6 +289,14 @@ __global__ void __launch_bounds__(1024) k_hals_temporal(const int *__restrict__ 
     __shared__ float red[1024];
     hals_temporal_one(lvl[blockIdx.x], nptr, nidx, nval, aa, U, C, Craw, ldc, T, red);
 }
+// the same level over the jobs of a context (TemporalJob, common.hpp): workgroup -> (job, neuron)
+struct HJobDev { const int *nptr, *nidx; const float *nval, *aa, *U; float *C, *Craw; int64_t ldc; };
+__global__ void __launch_bounds__(1024) k_hals_temporal_jobs(const HJobDev *__restrict__ jobs, const int2 *__restrict__ lvl, int64_t T) {
+    __shared__ float red[1024];
+    const int2 e = lvl[blockIdx.x];
+    const HJobDev j = jobs[e.x];
+    hals_temporal_one(e.y, j.nptr, j.nidx, j.nval, j.aa, j.U, j.C, j.Craw, j.ldc, T, red);
+}
 // ---- S6: connectivity_constraint.m:1-18 on a per-neuron box -------------------------------------------
 constexpr int PP_MAX = 64;    // max box side (bbox + 2 px margin each side)
 __global__ void __launch_bounds__(256) k_connectivity(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
@@ -604,13 +612,16 @@ int fast_temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colp
 
 int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                  const float *C_in, int c_order, int32_t maxIter, float *C_out, float *C_raw_out, float *aa_out,
-                 const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out) {
+                 const cnmfe_deconv_opts *dopts, float *kernel_pars, float *S_out, float *sn_out, TemporalJob *job) {
     const int64_t T = P->T, d = P->d, nnz = A_colptr[K];
     if (nnz >= (int64_t(1) << 31)) return fail(CNMFE_EUNSUPPORTED, "nnz(A) too large");
-    DevBuf &dC = ctx->tmp[0];
+    // a job (cnmfe_hals_temporal_job) works in buffers of its own and stops in front of the sweeps: temporal_sweep_jobs runs them for all jobs together
     DevBuf *S_ = ctx->scr;
-    DevBuf &dColptr = S_[0], &dErow = S_[1], &dAval = S_[6], &dU = S_[7], &dCraw = ctx->last_craw, &dNk = S_[14], &dNidx = S_[15], &dNval = S_[16], &dNptr = S_[17], &dAa = ctx->last_aa, &dLvl = S_[12], &dOvf = S_[18];
-    ctx->last_t_valid = false;
+    DevBuf &dC = job ? job->dC : ctx->tmp[0];
+    DevBuf &dColptr = job ? job->dColptr : S_[0], &dErow = job ? job->dErow : S_[1], &dAval = job ? job->dAval : S_[6], &dU = job ? job->dU : S_[7],
+           &dCraw = job ? job->dCraw : ctx->last_craw, &dNk = job ? job->dNk : S_[14], &dNidx = job ? job->dNidx : S_[15], &dNval = job ? job->dNval : S_[16],
+           &dNptr = job ? job->dNptr : S_[17], &dAa = job ? job->dAa : ctx->last_aa, &dLvl = S_[12], &dOvf = job ? job->dOvf : S_[18];
+    if (!job) ctx->last_t_valid = false;
     HostTrace ht(ctx, "temporal");
     int64_t ldc;
     RET(upload_traces(ctx, dC, C_in, K, T, c_order, &ldc));
@@ -674,8 +685,35 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     if (upd != nonempty) build_graph(K, csr, d, upd, g);     // (almost always the same set: a stored column without a non-zero value is rare -- reuse the graph above)
     std::vector<int> flat, off;
     for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
-    RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
+    if (!job) RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
     ht.mark("csr + graph + lists + levels");
+    if (job) {
+        // no wait here: A'A (and the overflow word of the term projection) go to the job's pinned buffer behind the kernels; temporal_sweep_jobs finishes the job
+        const size_t need = ((size_t)nn + 1) * sizeof(float);
+        if (need > job->pin_cap) {
+            if (job->pin) (void)hipHostFree(job->pin);
+            job->pin = nullptr; job->pin_cap = 0;
+            CK(hipHostMalloc((void **)&job->pin, need * 2, hipHostMallocDefault));
+            job->pin_cap = need * 2;
+        }
+        job->nn = nn; job->pin[nn] = 0.f;
+        CK(hipMemcpyAsync(job->pin, dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+        if (term_applied) CK(hipMemcpyAsync(job->pin + nn, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+        job->P = P; job->K = K; job->ldc = ldc; job->T = T; job->maxIter = maxIter; job->deconv = dopts != nullptr; job->swept = false; job->finished = false;
+        job->diag = std::move(diag); job->upd = std::move(upd); job->term_applied = term_applied;
+        job->levels = std::move(g.levels);
+        if (dopts) {
+            job->dopts = *dopts;
+            RET(job->dS.ensure((size_t)K * ldc * sizeof(float)));
+            CK(hipMemsetAsync(job->dS.p, 0, (size_t)K * ldc * sizeof(float), ctx->st()));         // S = zeros(K,T)  (:55)
+            RET(to_dev(ctx, job->dPars, kernel_pars, (size_t)K));
+            RET(job->dSn.ensure((size_t)K * sizeof(float)));
+            CK(hipMemsetAsync(job->dSn.p, 0, (size_t)K * sizeof(float), ctx->st()));
+            RET(job->dB.ensure((size_t)K * sizeof(float)));
+        }
+        ht.mark("job queued");
+        return 0;
+    }
     std::vector<float> nval(nn);
     int ovf = 0;
     CK(hipMemcpyAsync(nval.data(), dNval.p, (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
@@ -719,6 +757,79 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     RET(download_traces(ctx, dCraw.as<float>(), ldc, C_raw_out, K, T, c_order));
     if (aa_out) memcpy(aa_out, aa.data(), (size_t)K * sizeof(float));
     if (C_out || C_raw_out) CK(hipStreamSynchronize(ctx->st()));
+    return 0;
+}
+
+struct DeconvJobDev;     // deconv.hip
+int temporal_deconv_sweeps_jobs(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64_t T, int maxIter, const std::vector<TemporalJob *> &jobs,
+                                const int2 *dList, const std::vector<int> &off, DevBuf &dTab);
+
+// Level l of every job in one launch (jobs are independent; inside a job the levels keep the k = 1..K order of HALS_temporal.m:60)
+int temporal_sweep_jobs(cnmfe_ctx *ctx) {
+    std::vector<TemporalJob *> jobs;
+    for (int i = 0; i < ctx->tjobs_used; ++i) if (!ctx->tjobs[i]->swept && ctx->tjobs[i]->K > 0) jobs.push_back(ctx->tjobs[i]);
+    if (jobs.empty()) return 0;
+    // ONE wait for the A'A of all jobs (and for what the residuals' kernels had to report), then every job is finished as temporal_run finishes a single one
+    bool waiting = false;
+    for (auto *j : jobs) waiting = waiting || !j->finished;
+    if (waiting) RET(ctx_check_errflag(ctx));
+    for (auto *j : jobs) {
+        if (j->finished) continue;
+        int ovf = 0;
+        memcpy(&ovf, j->pin + j->nn, sizeof(int));
+        if (j->term_applied && ovf) {                            // a footprint near more than 512 traces: fold the term into Ysig and project again
+            Patch *P = j->P;
+            const int64_t Tc = (j->T + 3) / 4;
+            const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
+            const int64_t tchunk = (Tc + nchunk - 1) / nchunk;
+            RET(residual_materialize(ctx, P));
+            CK(hipMemsetAsync(j->dU.p, 0, (size_t)j->K * j->ldc * sizeof(float), ctx->st()));
+            LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(j->K, nchunk), dim3(256), 0, P->ysig.as<float4>(), P->d, j->T, j->dColptr.as<int64_t>(),
+                   j->dErow.as<int>(), j->dAval.as<float>(), tchunk, j->dU.as<float>(), j->ldc);
+        }
+        std::vector<float> aa(j->K);
+        for (int k = 0; k < j->K; ++k) {
+            aa[k] = j->pin[j->diag[k]];
+            if ((aa[k] > 0.f) != (j->upd[k] != 0)) return fail(CNMFE_EHIP, "temporal update: aa(%d) = %g disagrees with the host-side test of its column", k, (double)aa[k]);
+        }
+        RET(to_dev(ctx, j->dAa, aa.data(), aa.size()));
+        j->finished = true;
+    }
+    const TemporalJob *j0 = jobs[0];
+    size_t lmax = 0;
+    for (auto *j : jobs) {
+        if (j->T != j0->T || j->maxIter != j0->maxIter || j->deconv != j0->deconv || (j->deconv && memcmp(&j->dopts, &j0->dopts, sizeof(j->dopts)) != 0))
+            return fail(CNMFE_ESTATE, "the temporal jobs of one sweep must share T, maxIter and the deconvolution options");
+        lmax = std::max(lmax, j->levels.size());
+    }
+    std::vector<int2> flat; std::vector<int> off;
+    for (size_t l = 0; l < lmax; ++l) {
+        off.push_back((int)flat.size());
+        for (size_t ji = 0; ji < jobs.size(); ++ji)
+            if (l < jobs[ji]->levels.size()) for (int k : jobs[ji]->levels[l]) flat.push_back(make_int2((int)ji, k));
+    }
+    off.push_back((int)flat.size());
+    DevBuf &dList = ctx->scr[12], &dTab = ctx->scr[13];
+    RET(to_dev(ctx, dList, flat.data(), flat.size()));
+    HostTrace ht(ctx, "temporal sweep (jobs)");
+    if (!j0->deconv) {
+        std::vector<HJobDev> tab(jobs.size());
+        for (size_t ji = 0; ji < jobs.size(); ++ji) {
+            TemporalJob *j = jobs[ji];
+            tab[ji] = HJobDev{j->dNptr.as<int>(), j->dNidx.as<int>(), j->dNval.as<float>(), j->dAa.as<float>(), j->dU.as<float>(), j->dC.as<float>(), j->dCraw.as<float>(), j->ldc};
+        }
+        RET(to_dev(ctx, dTab, tab.data(), tab.size()));
+        for (int it = 0; it < j0->maxIter; ++it)
+            for (size_t l = 0; l < lmax; ++l) {
+                const int n = off[l + 1] - off[l];
+                if (n > 0)
+                    LAUNCH(ctx, "temporal_hals_level", k_hals_temporal_jobs, dim3((unsigned)n), dim3(j0->T >= 2048 ? 1024 : 256), 0, dTab.as<HJobDev>(), dList.as<int2>() + off[l], j0->T);
+            }
+    } else {
+        RET(temporal_deconv_sweeps_jobs(ctx, &j0->dopts, j0->T, j0->maxIter, jobs, dList.as<int2>(), off, dTab));
+    }
+    for (auto *j : jobs) j->swept = true;
+    ht.mark("launches");
     return 0;
 }
 

@@ -548,6 +548,31 @@ class Engine:
         L.check(L.lib.cnmfe_stitch_begin(self._ctx, int(K), int(T)))
         self._stitch_shape = (int(K), int(T))
 
+    # ---- several patches per context: set the patches' temporal updates up, sweep them together, add each to the stitch (cnmfe_hals_temporal_job) ----
+    supports_temporal_jobs = True
+
+    def hals_temporal_job(self, pid, A_patch, C_patch, maxIter, deconv_options=None, kernel_pars=None):
+        """everything of hals_temporal / hals_temporal_deconv up to the Gauss-Seidel sweeps; returns the job number (for stitch_add_job)"""
+        info = self._patch[pid]
+        K, cp, ri, va = _csc(A_patch, info["d"])
+        cptr, cord, _keep = self._targs(C_patch, K, info["T"])
+        opts = pars = None
+        if deconv_options is not None:
+            opts = self._dopts(deconv_options)
+            pars = np.zeros(K, dtype=np.float32) if kernel_pars is None else np.ascontiguousarray(kernel_pars, dtype=np.float32)
+        job = C.c_int32(-1)
+        L.check(L.lib.cnmfe_hals_temporal_job(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord, int(maxIter),
+                                              None if opts is None else C.byref(opts), _p(pars, L.f32p), C.byref(job)))
+        return job.value
+
+    def temporal_jobs_sweep(self):
+        """level l of EVERY job set up since stitch_begin in one launch (the patches are independent)"""
+        L.check(L.lib.cnmfe_temporal_jobs_sweep(self._ctx))
+
+    def stitch_add_job(self, job, ind):
+        ind = np.ascontiguousarray(ind, dtype=np.int32)
+        L.check(L.lib.cnmfe_stitch_add_job(self._ctx, int(job), ind.size, _p(ind, L.i32p)))
+
     def stitch_add(self, ind):
         """rows `ind` of the accumulator += aa .* C_raw of the temporal call just made (its result is still on the device)"""
         ind = np.ascontiguousarray(ind, dtype=np.int32)
@@ -599,14 +624,15 @@ class Engine:
         only keeps C_raw and aa; two K x T copies over PCIe otherwise)."""
         info = self._patch[pid]
         K, cp, ri, va = _csc(A_patch, info["d"])
-        Cm = _traces(C_patch, K, info["T"])
-        Craw = np.empty_like(Cm) if want_all is not None else None      # want_all=None: nothing but aa comes back (C_raw stays on the device for stitch_add)
-        Cout = np.empty_like(Cm) if want_all else None
-        S = np.empty_like(Cm) if want_all else None
+        T = info["T"]
+        cptr, cord, _keep = self._targs(C_patch, K, T)                   # (the bound matrix or rows of it: no K x T upload, as in hals_temporal)
+        Craw = np.empty((K, T), dtype=np.float32) if want_all is not None else None      # want_all=None: nothing but aa comes back (C_raw stays on the device for stitch_add)
+        Cout = np.empty((K, T), dtype=np.float32) if want_all else None
+        S = np.empty((K, T), dtype=np.float32) if want_all else None
         aa = np.empty(K, dtype=np.float32); sn = np.zeros(K, dtype=np.float32) if want_all is not None else None   # want_all=None: the call returns with the sweeps in flight
         pars = np.zeros(K, dtype=np.float32) if kernel_pars is None else np.ascontiguousarray(kernel_pars, dtype=np.float32).copy()
         opts = self._dopts(deconv_options)
-        L.check(L.lib.cnmfe_hals_temporal_deconv(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), _p(Cm, L.f32p), L.ROWMAJOR,
+        L.check(L.lib.cnmfe_hals_temporal_deconv(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                                  int(maxIter), C.byref(opts), _p(pars, L.f32p), _p(Cout, L.f32p), _p(Craw, L.f32p),
                                                  _p(S, L.f32p), _p(sn, L.f32p), _p(aa, L.f32p)))
         return Cout, Craw, S, sn, pars, aa

@@ -1139,6 +1139,10 @@ class Sources2D:
         launched_any = False
         sharded = self.dist is not None and (v.world_size > 1 or self.force_collectives)
         eng.stitch_begin(K, T)
+        # several patches on this rank: every patch's update is set up first and the Gauss-Seidel sweeps run level by level ACROSS the patches (they are
+        # independent: the reference's parfor, :112-186) -- one patch's level is a few workgroups as long as one trace's work
+        batch = use_c_hat and len(v.owned) > 1 and getattr(eng, "supports_temporal_jobs", False)
+        jobs = []
         for idx in v.owned:
             pp, bp = v.patch_pix[idx], v.block_pix[idx]
             indp, A_prev_b = self._prev_block_of(idx)                                                # :90-91
@@ -1168,11 +1172,18 @@ class Sources2D:
                 A_pp = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175
                 eng.fast_temporal(v.pid[idx], A_pp, want_raw=False)
+            elif batch:
+                jobs.append((eng.hals_temporal_job(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options if o.deconv_flag else None), ind))
+                continue
             elif o.deconv_flag:                                                                       # :106-110
                 eng.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options, want_all=None)
             else:
                 eng.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False, want_raw=False)  # :180-181
             eng.stitch_add(ind)                                                                       # :274-275
+        if jobs:
+            eng.temporal_jobs_sweep()
+            for job, ind in jobs:
+                eng.stitch_add_job(job, ind)                                                          # :274-275
         if sharded:                                                        # the overlap-region stitch: ONE all-reduce, in place on the device
             eng.stitch_allreduce(self.dist)
         # without deconvolution nobody needs the values on the host right away: the engine keeps the matrix bound and streams a copy into pinned

@@ -272,6 +272,15 @@ int cnmfe_deconv_temporal_bound(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, f
  *   all-reduce (count = K * ld floats), cnmfe_stitch_finish does :279-286 + bind on this context. */
 int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T);
 int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m);
+/* Several patches per context: cnmfe_hals_temporal_job does everything cnmfe_hals_temporal[_deconv] does up to the Gauss-Seidel sweeps (opts == NULL: the
+ * no-deconvolution branch; kernel_pars: K time constants in, with opts) and keeps the patch's buffers as job *job_out (numbered from cnmfe_stitch_begin);
+ * cnmfe_temporal_jobs_sweep runs level l of EVERY job in one launch -- the patches are independent (update_temporal_parallel.m:112-186 is a parfor), and one
+ * patch's level is a handful of workgroups as long as one trace's work; cnmfe_stitch_add_job(job, ...) then adds that job's aa .* C_raw to the accumulator.
+ * Same values as the per-patch calls (the same kernels on the same operands). */
+int cnmfe_hals_temporal_job(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                            const float *C_in, int c_order, int32_t maxIter, const cnmfe_deconv_opts *opts, const float *kernel_pars, int32_t *job_out);
+int cnmfe_temporal_jobs_sweep(cnmfe_ctx *ctx);
+int cnmfe_stitch_add_job(cnmfe_ctx *ctx, int32_t job, int32_t K_m, const int32_t *ind_m);
 int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld);
 int cnmfe_stitch_dims(cnmfe_ctx *ctx, int32_t *K, int64_t *T);   /* the K x T recorded by cnmfe_stitch_begin (CNMFE_ESTATE if no stitch is open): a gateway sizes C_raw_out from these, not from its caller */
 int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order);

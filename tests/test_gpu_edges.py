@@ -846,3 +846,39 @@ def test_two_frame_strides_keep_their_tables(eng):
             assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
     finally:
         eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
+
+
+@pytest.mark.parametrize("deconv", [False, True])
+def test_temporal_jobs_across_patches_equal_the_per_patch_updates(deconv):
+    """Several patches per context: cnmfe_hals_temporal_job sets every patch's temporal update up, cnmfe_temporal_jobs_sweep runs level l of ALL
+    jobs in one launch, cnmfe_stitch_add_job adds each to the stitch.  The same kernels on the same operands as one cnmfe_hals_temporal[_deconv]
+    per patch: two full iterations agree bit for bit (with and without the in-sweep deconvolution)."""
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.engine import Engine
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    d1, d2, T, K, r = 96, 96, 500, 14, 5
+    f = synth.make_factors(d1, d2, T, K, 17, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32)
+    res = []
+    for jobs in (False, True):
+        e = Engine(0)
+        try:
+            if not jobs:
+                e.supports_temporal_jobs = False              # (instance attribute: this run takes the per-patch calls)
+            v = PatchedVideo(d1, d2, T, [48, 48], r, e)
+            v.upload_from_full(Y)
+            s = Sources2D(v, Options(ring_radius=r, maxIter=3, deconv_flag=deconv), f.A_init, f.C_init, f.sn)
+            if jobs:
+                e.profile(True)
+            for _ in range(2):
+                s.update_background_parallel(); s.update_spatial_parallel(); s.update_temporal_parallel()
+            if jobs:
+                tab = e.profile_table()
+                lv = tab["temporal_hals_deconv_level" if deconv else "temporal_hals_level"]["calls"]
+            res.append((np.asarray(s.C).copy(), np.asarray(s.C_raw).copy(), s.A.copy()))
+        finally:
+            e.close()
+    (c0, r0, a0), (c1, r1, a1) = res
+    assert np.array_equal(r0, r1) and np.array_equal(c0, c1) and (a0 != a1).nnz == 0
+    assert np.isfinite(c1).all() and np.abs(c1).max() > 0
+    assert lv <= 2 * 3 * 8, lv                                 # levels x maxIter launches per update for ALL four patches together, not per patch
