@@ -636,6 +636,10 @@ class Sources2D:
     def A_raw(self, val):
         self.__dict__["_A_raw"] = val
 
+    # how many patches' spatial results may be outstanding before the oldest is collected: the host queues that many patches ahead of the device (each
+    # result waits in a pinned buffer of its size; a lag of 1 tied the host to the device's pace and left the device idle whenever a patch's host work ran long)
+    spatial_lag = 16
+
     def _need_data(self):
         if self.video is None:
             raise RuntimeError("No data file selected")                   # update_spatial_parallel.m:13-38
@@ -912,7 +916,7 @@ class Sources2D:
                 whole = pp.size == v.d1 * v.d2 and ind.size == K
                 late = not whole and hasattr(fetch, "start")
                 if late:
-                    # several patches: the download is queued right behind the sweeps and collected one patch LATE -- this patch's values are assembled
+                    # several patches: the download is queued right behind the sweeps and collected `spatial_lag` patches LATE -- a patch's values are assembled
                     # on the host while the next patch's kernels, queued first, keep the device busy (a fetch per patch drained the stream 16 times per update)
                     fetch.start()
                 self._temporal_residual_early(idx)                       # host work under the sweeps
@@ -924,7 +928,7 @@ class Sources2D:
                     Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2), **({"compact": True} if hasattr(fetch, "start") else {}))
                 elif late:
                     in_flight.append((fetch, pp, ind))
-                    while len(in_flight) > 1:
+                    while len(in_flight) > self.spatial_lag:
                         collect(*in_flight.pop(0))
                     continue
                 else:

@@ -3,7 +3,7 @@
 wall-clock per call of the Python-side steps (engine fetch, its compaction, stitch_begin, hals_temporal up to its return), averaged over iterations."""
 import argparse, os, sys, time, collections
 import numpy as np
-ap = argparse.ArgumentParser(); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--deconv", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--patch", type=int, default=512, help="128: the 4 x 4 patches of configs[3]")
 a_ = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +15,7 @@ from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
 d1 = d2 = 512; T = 10000; K = 500; r = 15
 f = synth.make_factors(d1, d2, T, K, 2)
 eng = Engine(0)
-video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+video = PatchedVideo(d1, d2, T, [a_.patch, a_.patch], r, eng)
 for idx in video.owned:
     Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()
     video.upload_block_device(idx, Yb.data_ptr()); del Yb
@@ -31,9 +31,10 @@ def timed(obj, name, label=None):
             t2 = time.perf_counter(); acc[label or name] += t2 - t; cnt[label or name] += 1; marks.append((label or name, "out", t2))
     setattr(obj, name, w)
 for n in ("stitch_begin", "hals_temporal", "hals_temporal_deconv", "deconv_temporal_bound", "stitch_add", "stitch_finish", "update_spatial", "residual", "residual_ssub",
-          "fit_ring_model", "fit_ring_model_ssub", "ring_first_run", "bind_traces"):
+          "fit_ring_model", "fit_ring_model_ssub", "ring_first_run", "bind_traces", "hals_temporal_job", "temporal_jobs_sweep", "stitch_add_job", "post_process_spatial"):
     timed(eng, n)
-for n in ("_update_b0_new", "_temporal_residual_early", "_search_location_csc", "_prev_block_of", "deconvTemporal", "update_background_parallel", "update_spatial_parallel", "update_temporal_parallel"):
+for n in ("_update_b0_new", "_temporal_residual_early", "_search_location_csc", "_prev_block_of", "deconvTemporal", "update_background_parallel", "update_spatial_parallel", "update_temporal_parallel",
+          "_slice", "_gather_sparse", "_post_process"):
     timed(s, n)
 L.lib.cnmfe_version()                                                     # (loads the library)
 for n in ("cnmfe_update_spatial_fetch_connected", "cnmfe_csc_drop_zeros", "cnmfe_hals_temporal", "cnmfe_stitch_wait", "cnmfe_synchronize"):
@@ -52,7 +53,8 @@ eng.synchronize()
 print("per iteration: background %.3f ms, spatial %.3f ms, temporal %.3f ms (host wall of the three calls)" % tuple(1e3 * tot / N))
 for k, v in sorted(acc.items(), key=lambda x: -x[1]):
     print("%-28s %8.3f ms per iteration in %d calls" % (k, 1e3 * v / N, cnt[k] // N))
-print("last iteration, order of events (ms from the first):")
-t0 = marks[0][2]
-for name, io, t in marks:
-    print("  %8.3f  %-4s %s" % (1e3 * (t - t0), io, name))
+if a_.patch == 512:
+    print("last iteration, order of events (ms from the first):")
+    t0 = marks[0][2]
+    for name, io, t in marks:
+        print("  %8.3f  %-4s %s" % (1e3 * (t - t0), io, name))

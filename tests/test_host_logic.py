@@ -304,8 +304,8 @@ def test_asynchronous_engine_orderings_give_the_same_iteration(pdims, update_sn)
     assert [c[1] for c in calls] == [v.pid[idx] for idx in v.owned for _ in range(4)]
 
 
-@pytest.mark.parametrize("pdims", [[20, 22], [14, 15], None])
-def test_late_collection_of_spatial_results_gives_the_same_iteration(pdims):
+@pytest.mark.parametrize("pdims,lag", [([20, 22], 1), ([14, 15], 1), (None, 1), ([14, 15], 16)])
+def test_late_collection_of_spatial_results_gives_the_same_iteration(pdims, lag):
     """with the real engine's queued download (fetch.start / fetch(compact=True)) sources2d queues patch m + 1 before it collects patch m and leaves the
     one-patch A_raw as a recipe: two iterations equal the blocking double's exactly, A_raw included, and every fetch but the last follows the NEXT
     patch's launches."""
@@ -329,7 +329,11 @@ def test_late_collection_of_spatial_results_gives_the_same_iteration(pdims):
     mark = [0]
     a, _ = run(FakeEngine())
     eng = LateFakeEngine()
-    b, v = run(eng)
+    Sources2D.spatial_lag, lag0 = lag, Sources2D.spatial_lag      # (a lag of one patch makes the order below simple to state; 16 = the default: everything collected at the end)
+    try:
+        b, v = run(eng)
+    finally:
+        Sources2D.spatial_lag = lag0
     assert (a.A != b.A).nnz == 0 and np.array_equal(np.asarray(a.C), np.asarray(b.C)) and np.array_equal(np.asarray(a.C_raw), np.asarray(b.C_raw))
     assert callable(b.__dict__["_A_raw"]) == (pdims is None)               # one patch: still the recipe ...
     assert (sp.csc_matrix(a.A_raw) != sp.csc_matrix(b.A_raw)).nnz == 0     # ... that builds the same matrix on first read
@@ -342,6 +346,9 @@ def test_late_collection_of_spatial_results_gives_the_same_iteration(pdims):
     calls = [c for c in last if c[0] in ("update_spatial", "start", "fetch")]
     pids = [p_ for c, p_ in calls if c == "update_spatial"]               # (patches without a neuron are skipped)
     assert len(pids) > 2
+    if lag > 1:
+        assert [c for c in calls if c[0] == "fetch"] == [("fetch", p_) for p_ in pids] and calls[-len(pids):] == [("fetch", p_) for p_ in pids]
+        return
     expect = []
     for i, p_ in enumerate(pids):
         expect += [("update_spatial", p_), ("start", p_)]
