@@ -791,32 +791,12 @@ __global__ void __launch_bounds__(256) k_rowsum_correct(const double *__restrict
 // ---- helpers on the covariance table ----------------------------------------------------------------
 struct CovTab {
     const double *cov; const int *pair_of;   // pair_of[blk*nrel + rel] or -1
-    const int *wcodes;                       // [(bc0 + 1) * (nbr + 1) + (br0 + 1)][256]: the block-pair codes of the 4 x 4-block window with origin (br0, bc0), k_win_codes
     int nbr, nbc;
     int maxd, nrel;                          // largest block displacement between two ring pixels of one centre (2: radius <= 16, 3: <= 24); nrel_of(maxd)
 };
 // canonical displacement index: dC in 0..maxd; dC == 0 -> dR in 0..maxd (0..maxd); dC >= 1 -> dR in -maxd..maxd.  maxd = 2: 13 classes (0..2, 3..7, 8..12)
 __host__ __device__ __forceinline__ int rel_index(int dR, int dC, int maxd) { return dC == 0 ? dR : (maxd + 1) + (dC - 1) * (2 * maxd + 1) + dR + maxd; }
 __host__ __device__ __forceinline__ int nrel_of(int maxd) { return (maxd + 1) + maxd * (2 * maxd + 1); }
-
-// The block-pair codes of a pixel's 4 x 4-block window depend on the window's origin only -- (nbr + 1) x (nbc + 1) origins for 262144 pixels -- so they
-// are tabulated once per fit instead of being re-derived (25 integer operations and a dependent load per entry, 256 entries) by every pixel's wave:
-// code(a, b) for window blocks a, b = pair index << 2 | swapped << 1 | self pair, or -1.
-__global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_of, int nbr, int nbc, int maxd, int nrel, int *__restrict__ wcodes) {
-    const int br0 = (int)(blockIdx.x % (nbr + 1)) - 1, bc0 = (int)(blockIdx.x / (nbr + 1)) - 1;
-    const int q = threadIdx.x, a = q >> 4, b = q & 15;
-    int ia = br0 + (a & 3), ja = bc0 + (a >> 2), ib = br0 + (b & 3), jb = bc0 + (b >> 2);
-    int code = -1;
-    if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < nbr && ib < nbr && ja < nbc && jb < nbc) {
-        int dR = ib - ia, dC = jb - ja, sw = 0;
-        if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
-        if (dC <= maxd && dR <= maxd && dR >= -maxd) {
-            const int pidx = pair_of[(ja * nbr + ia) * nrel + rel_index(dR, dC, maxd)];
-            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
-        }
-    }
-    wcodes[(int64_t)blockIdx.x * 256 + q] = code;
-}
 }  // namespace cnmfe
 #include "ring_solve.hpp"
 namespace cnmfe {
@@ -1282,11 +1262,6 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ht.mark("base / correction launches");
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
-        DevBuf &dWcodes = ctx->tmp[14];
-        const int nwin = (g.nbr + 1) * (g.nbc + 1);
-        RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
-        LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, maxd, nrel, dWcodes.as<int>());
-        tab.wcodes = dWcodes.as<int>();
         int *dErr = nullptr;
         RET(ctx_errflag(ctx, &dErr));
         const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();

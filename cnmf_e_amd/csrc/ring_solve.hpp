@@ -32,10 +32,19 @@ k_ring_solve5(CovTab tab, BgGeom g, const int *__restrict__ dr, const int *__res
         }
         s_node[a] = code;
     }
-    {   // the window's block-pair codes: tabulated per window origin (k_win_codes), four coalesced loads
-        const int *wc = tab.wcodes + ((int64_t)(bc0 + 1) * (tab.nbr + 1) + (br0 + 1)) * 256;
-#pragma unroll
-        for (int q = lane; q < 256; q += 64) s_pt[q] = wc[q];
+    for (int q = lane; q < 256; q += 64) {
+        const int a = q >> 4, b = q & 15;
+        int ia = br0 + (a & 3), ja = bc0 + (a >> 2), ib = br0 + (b & 3), jb = bc0 + (b >> 2);
+        int code = -1;
+        if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < g.nbr && ib < g.nbr && ja < g.nbc && jb < g.nbc) {
+            int dR = ib - ia, dC = jb - ja, sw = 0;
+            if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
+            if (dC <= tab.maxd && dR <= tab.maxd && dR >= -tab.maxd) {
+                const int pidx = tab.pair_of[(ja * tab.nbr + ia) * tab.nrel + rel_index(dR, dC, tab.maxd)];
+                code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
+            }
+        }
+        s_pt[q] = code;
     }
     __syncthreads();
     int bad = 0;
