@@ -204,3 +204,33 @@ class LateFakeEngine(LazyFakeEngine):
             self.calls.append(("start", pid))
         fetch.start = start
         return fetch
+
+    # ... and the temporal jobs of the real engine (cnmfe_hals_temporal_job / cnmfe_temporal_jobs_sweep / cnmfe_stitch_add_job): every patch is set up first,
+    # the sweeps of all patches run together, each job is then added to the stitch.  Here a job is the per-patch update evaluated at the sweep.
+    supports_temporal_jobs = True
+
+    def stitch_begin(self, K, T):
+        super().stitch_begin(K, T)
+        self._jobs = []
+
+    def hals_temporal_job(self, pid, A_patch, C_patch, maxIter, deconv_options=None, kernel_pars=None):
+        self.calls.append(("job", pid))
+        self._jobs.append(dict(args=(pid, A_patch, np.array(C_patch, dtype=np.float64, copy=True), maxIter, deconv_options), done=None))
+        return len(self._jobs) - 1
+
+    def temporal_jobs_sweep(self):
+        self.calls.append(("sweep", len(self._jobs)))
+        for j in self._jobs:
+            if j["done"] is None:
+                pid, A, Cm, maxIter, dopt = j["args"]
+                if dopt is None:
+                    self.hals_temporal(pid, A, Cm, maxIter, want_C=False, want_raw=False)
+                else:
+                    self.hals_temporal_deconv(pid, A, Cm, maxIter, dopt, want_all=None)
+                j["done"] = self._last
+
+    def stitch_add_job(self, job, ind):
+        self.calls.append(("add_job", job))
+        assert self._jobs[job]["done"] is not None, "job %d added before the sweep" % job
+        self._last = self._jobs[job]["done"]
+        self.stitch_add(ind)

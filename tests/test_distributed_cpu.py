@@ -22,11 +22,11 @@ def _worker(rank, world, port, out, update_sn, lazy=False):
     td.init_process_group("gloo", rank=rank, world_size=world)
     from cnmf_e_amd import synth
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-    from fake_engine import FakeEngine, LazyFakeEngine
+    from fake_engine import FakeEngine, LazyFakeEngine, LateFakeEngine
     c = CASE
     f = synth.make_factors(c["d1"], c["d2"], c["T"], c["K"], c["seed"], gSig=1.5, gSiz=7, min_sep=5)
     Y = synth.make_video(f, np.float32)
-    video = PatchedVideo(c["d1"], c["d2"], c["T"], [20, 22], c["r"], LazyFakeEngine() if lazy else FakeEngine(), rank=rank, world_size=world)
+    video = PatchedVideo(c["d1"], c["d2"], c["T"], [20, 22], c["r"], (LateFakeEngine() if lazy == "late" else LazyFakeEngine()) if lazy else FakeEngine(), rank=rank, world_size=world)
     assert len(video.owned) == 4 // world
     video.upload_from_full(Y.astype(np.float64))
     s = Sources2D(video, Options(ring_radius=c["r"], spatial_algorithm="hals", maxIter=3), f.A_init, f.C_init, f.sn,
@@ -41,9 +41,10 @@ def _worker(rank, world, port, out, update_sn, lazy=False):
 import pytest
 
 
-@pytest.mark.parametrize("update_sn,lazy", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("update_sn,lazy", [(False, False), (True, False), (False, True), (False, "late")])
 def test_two_rank_sharded_iteration_matches_single_process(tmp_path, update_sn, lazy):
-    """lazy: the engine double defers its results like the real engine, so the sharded run takes the orderings it takes under RCCL"""
+    """lazy: the engine double defers its results like the real engine, so the sharded run takes the orderings it takes under RCCL; "late": also the queued
+    downloads collected late and the temporal jobs swept together (two patches per rank here), in front of the collectives"""
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnmfe_oracle as orc

@@ -343,6 +343,10 @@ def test_late_collection_of_spatial_results_gives_the_same_iteration(pdims, lag)
     if pdims is None:
         assert [c[0] for c in last[:4]] == ["residual", "update_spatial", "residual", "fetch"]      # the whole-FOV fetch is not deferred
         return
+    # the temporal update of several patches: every patch's job first, ONE sweep, then the jobs into the stitch in order
+    tcalls = [c for c in last if c[0] in ("job", "sweep", "add_job")]
+    nj = sum(1 for c in tcalls if c[0] == "job")
+    assert nj > 2 and [c[0] for c in tcalls] == ["job"] * nj + ["sweep"] + ["add_job"] * nj and [c[1] for c in tcalls[nj + 1:]] == list(range(nj)), tcalls
     calls = [c for c in last if c[0] in ("update_spatial", "start", "fetch")]
     pids = [p_ for c, p_ in calls if c == "update_spatial"]               # (patches without a neuron are skipped)
     assert len(pids) > 2
