@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnmfe_hip.so")
+# CNMFE_LIB: another build of the same ABI (A/B runs of kernel variants, scripts/build_variant.py); the default is the in-tree library
+LIB_PATH = os.environ.get("CNMFE_LIB") or os.path.join(_HERE, "libcnmfe_hip.so")
 
 
 class _Lib:

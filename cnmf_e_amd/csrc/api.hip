@@ -439,6 +439,19 @@ cnmfe_ctx *cnmfe_create(int device) {
     if (hipStreamCreate(&ctx->stream_) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
     pin_register(ctx, true);
     if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
+    // CNMFE_OPTS="name=value,name=value": tunables of cnmfe_set_option preset for every context of the process (A/B runs of the test suite and the bench
+    // without touching their code); names this build does not know are ignored -- the same environment serves builds with different option sets
+    if (const char *env = getenv("CNMFE_OPTS")) {
+        std::string s(env);
+        size_t pos = 0;
+        while (pos < s.size()) {
+            size_t end = s.find(',', pos); if (end == std::string::npos) end = s.size();
+            const std::string kv = s.substr(pos, end - pos); pos = end + 1;
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || eq == 0) continue;
+            (void)cnmfe_set_option(ctx, kv.substr(0, eq).c_str(), strtoll(kv.c_str() + eq + 1, nullptr, 10));
+        }
+    }
     return ctx;
 }
 
