@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcnmfe_hip.so")
-SOURCES = ["api.hip", "resid.hip", "bg.hip", "factor.hip", "deconv.hip", "ssub.hip"]
+SOURCES = ["api.hip", "resid.hip", "bg.hip", "factor.hip", "deconv.hip", "ssub.hip", "vproj.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -32,7 +32,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "cnmfe.h")]   # every header: resid_arc.hpp, ring_solve.hpp hold whole kernels
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + [os.path.join(HERE, "..", "include", "cnmfe.h")]   # every header: resid_arc.hpp, ring_solve.hpp hold whole kernels
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

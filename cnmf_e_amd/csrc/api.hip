@@ -210,6 +210,24 @@ void cnmfe_ctx::flush_copies() {
 }
 namespace cnmfe {
 
+bool bound_rows_of(const cnmfe_ctx *ctx, const float *C, int c_order, int32_t K, std::vector<int32_t> &rows) {
+    rows.clear();
+    if (!ctx->bound_valid || K <= 0) return false;
+    if (c_order == CNMFE_BOUND) {
+        if (K != ctx->bound_K) return false;
+        rows.resize((size_t)K);
+        for (int32_t k = 0; k < K; ++k) rows[k] = k;
+        return true;
+    }
+    if (c_order == CNMFE_BOUND_ROWS && C) {
+        const int32_t *r = reinterpret_cast<const int32_t *>(C);
+        for (int32_t k = 0; k < K; ++k) if (r[k] < 0 || r[k] >= ctx->bound_K) return false;
+        rows.assign(r, r + K);
+        return true;
+    }
+    return false;
+}
+
 int ensure_ymean(cnmfe_ctx *ctx, Patch *P) {
     if (P->ymean_valid) return 0;
     if (P->frames_uploaded < P->T) return fail(CNMFE_ESTATE, "block has %lld of %lld frames uploaded", (long long)P->frames_uploaded, (long long)P->T);
@@ -358,6 +376,7 @@ static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out,
     if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->st(), ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last download still reads `bound`
     if (K > 0) LAUNCH(ctx, "stitch_finish", k_stitch_finish, dim3((unsigned)K), dim3(256), 0, ctx->stitch.as<float>(), ctx->stitch_ld, T, subtract_min, ctx->bound.as<float>(), ldc);
     ctx->bound_K = K; ctx->bound_T = T; ctx->bound_order = (c_order == CNMFE_COLMAJOR) ? CNMFE_COLMAJOR : CNMFE_ROWMAJOR; ctx->bound_valid = K > 0;
+    ++ctx->bound_gen;
     ctx->stitch_open = false;
     if (C_raw_out && async_copy && K > 0) {
         // the copy goes out on its own stream behind an event: the compute stream is free for the next call's kernels at once
@@ -471,7 +490,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", nullptr};
+    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual",
+                                  /* retired experiment switches (rounds 2-3): still accepted, ignored -- scripts/r1_probe.py, r1_duo.py, solve_ab.py name them */
+                                  "r1_arc_d", "r1_arc_bias", "r1_duo_ord", "solve_mode", "gram_kernel", "solve_gfill", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -546,7 +567,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     CK(hipStreamSynchronize(ctx->st()));
     std::fill(P->frame_seen.begin() + t0, P->frame_seen.begin() + t0 + nt, (uint8_t)1);
     P->frames_uploaded += nt;
-    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false;
+    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->pt_valid = false;
     return 0;
 }
 
@@ -591,7 +612,7 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     CK(hipStreamSynchronize(ctx->st()));
     P->stat_valid = false;
     if (P->stat_host) { (void)hipHostFree(P->stat_host); P->stat_host = nullptr; }      // sized by the number of ring offsets
-    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false;   // (the kept covariance tables cover the sub-tiles THIS ring needs)
+    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->pt_valid = false;   // (the kept covariance tables cover the sub-tiles THIS ring needs)
     return 0;
 }
 
@@ -1130,7 +1151,7 @@ int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float
 
 int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int c_order) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
-    ctx->bound_valid = false;
+    ctx->bound_valid = false; ++ctx->bound_gen;
     if (K == 0 || !C) return 0;                            // unbind
     if (K < 0 || T <= 0) return fail(CNMFE_EINVAL, "bad K / T");
     if (c_order != CNMFE_ROWMAJOR && c_order != CNMFE_COLMAJOR) return fail(CNMFE_EINVAL, "bad c_order");

@@ -14,28 +14,12 @@
 // covariance exactly once (symmetric pairs once) instead of once per centre pixel.
 #include "common.hpp"
 #include "ring_solve_core.hpp"
+#include "win_proj.hpp"
 #include <type_traits>
 
 namespace cnmfe {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
-
-// local pixel index inside a 16x16 block: 4x4-pixel patches (patch = (r>>2) + 4*(c>>2)), 16 pixels per patch.
-// One MFMA 16-row/col fragment is then one 4x4 patch, so the set of pixel displacements a 16x16 sub-tile of a
-// block-pair covariance covers is a 7x7 window and sub-tiles no ring can ever touch are skipped.
-__host__ __device__ __forceinline__ int lp_of(int r, int c) { return (((r >> 2) + ((c >> 2) << 2)) << 4) + (r & 3) + ((c & 3) << 2); }
-
-struct BgGeom {
-    int nr, nc, nr_b, nc_b, roff, coff;    // patch / block sizes, patch origin in block
-    int r0_abs, c0_abs;                    // absolute 1-based row/col of block pixel (0,0)
-    int d1, d2;
-    int nbr, nbc;                          // 16x16 blocks tiling the block region
-    int64_t d, d_b, T, Tp, Tpad;           // Tp frames used (stride kstride), padded to a multiple of 16
-    int kstride;
-    int p;
-    int p_radius, nbw;                     // largest |offset| of the ring; blocks per side of the (2*radius+1)-pixel window
-    int bf4;                               // Bf layout: 0 = [blk][frame][256], 1 = [blk][frame/4][256][4] (k_gram4)
-};
 
 // ---- B1 ------------------------------------------------------------------------------------------
 // fp32 -> (hi, lo) bf16 pair, round-to-nearest-even: x = hi + lo + O(2^-17 |x|)
@@ -445,12 +429,6 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
 // SYRK above on Yc alone) and kept; every later fit only needs U~ for pixels within two 16x16 blocks of a footprint -- per block a
 // (256 px) x (footprints near it, <= 64) x T' GEMM on the fp64 pipe, 0.1-0.2 TFLOP instead of 9.6 -- and one sweep over the table.
 // Everything is fp64 (exact fp32 products, fp64 sums): the difference of the two large terms keeps ~1e-13 relative accuracy.
-constexpr int WIN_NLB = 64;
-#ifndef WIN_AHEAD_N
-#define WIN_AHEAD_N 2
-#endif
-constexpr int WIN_AHEAD = WIN_AHEAD_N;
-
 // csum[k] = sum over the used frames of Cc_k  (the ones-row of X: rowsum(Bf) = rowsum(Yc) - A csum)
 __global__ void __launch_bounds__(256) k_trace_subsum(const float *__restrict__ Cc, int64_t ldc, int64_t Tp, int kstride, double *__restrict__ csum) {
     const float *row = Cc + (int64_t)blockIdx.x * ldc;
@@ -551,104 +529,6 @@ __device__ __forceinline__ void win_body(const float4 *__restrict__ Y4, const Bg
     }
 }
 
-// The same GEMMs with 16-BYTE loads (round 3; frame strides 1, 2, 4 -- every first fit, and every fit at the headline size).  Probes showed the
-// scalar-load version above bound by its loads, not by the matrix pipe: 5.0 ms with the MFMAs removed against 5.4 ms with them
-// (profiles/r03/win_probe.txt) -- 256 bytes per wave instruction.  Here lane (fi, kq) loads the float4 of ITS pixel for chunk s + kq (and the float4
-// of its trace for the same four frames): a wave instruction moves 1 KB, and the four components are the k = kq slices of FOUR MFMAs -- MFMA m
-// contracts over the frames 4 (s + kq) + m, kq = 0..3, on both operands alike, so no value ever changes lanes.  16 frames per step.
-template <int NT>
-__device__ __forceinline__ void win_body4(const float4 *__restrict__ Y4, const BgGeom &g, const float *__restrict__ Cc, int64_t ldc, int blk, int l0, int nl,
-                                          const int *__restrict__ lst_k, int64_t c0, int64_t c1, double *__restrict__ Ut, double *__restrict__ Gb) {
-    constexpr int AHEAD = NT <= 2 ? 2 : 1;
-    const int bi = blk % g.nbr, bj = blk / g.nbr;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kq = lane >> 4;
-    const float4 *ya[4]; const float4 *tb[NT];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int lp = (wave * 4 + a) * 16 + fi;
-        const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
-        const int rb = bi * BLK + lr, cb = bj * BLK + lc;
-        ya[a] = (rb < g.nr_b && cb < g.nc_b) ? Y4 + ((int64_t)cb * g.nr_b + rb) : nullptr;
-    }
-#pragma unroll
-    for (int b = 0; b < NT; ++b) { const int sl = b * 16 + fi; tb[b] = sl < nl ? reinterpret_cast<const float4 *>(Cc + (int64_t)lst_k[l0 + sl] * ldc) : nullptr; }
-    double4_t acc[4][NT], accg[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        accg[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    }
-    struct Frag { float4 y[4]; float4 t[NT]; };
-    auto load = [&](int64_t s) {
-        Frag f;
-        const int64_t c = s + kq;
-        const bool on = c < c1;
-        // (`cond ? *p : z4` on two lvalues becomes a select of ADDRESSES: z4 then lives in scratch memory and the kernel's first launch makes the runtime
-        //  set its scratch arena up -- an intermittent 0.5-0.8 s stall of the first fit, profiles/r03/README.md)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { f.y[a] = make_float4(0.f, 0.f, 0.f, 0.f); if (on && ya[a]) f.y[a] = ya[a][c * g.d_b]; }
-#pragma unroll
-        for (int b = 0; b < NT; ++b) { f.t[b] = make_float4(0.f, 0.f, 0.f, 0.f); if (on && tb[b]) f.t[b] = tb[b][c]; }
-        return f;
-    };
-    const bool gw = wave < NT;                              // wave w also owns row-group w of G
-    const int ks = g.kstride;
-    auto comp = [](float4 v, int m) -> float { return m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w; };
-    auto mm = [&](const Frag &f) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (m & (ks - 1)) continue;                     // frame stride 2: components 0, 2; stride 4: component 0 (fit_ring_model.m:84-87)
-            double bv[NT];
-#pragma unroll
-            for (int b = 0; b < NT; ++b) bv[b] = (double)comp(f.t[b], m);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const double av = (double)comp(f.y[a], m);
-#pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[b], acc[a][b], 0, 0, 0);
-            }
-            if (gw) {
-                double gv = bv[0];
-#pragma unroll
-                for (int b = 1; b < NT; ++b) gv = wave == b ? bv[b] : gv;
-#pragma unroll
-                for (int b = 0; b < NT; ++b) accg[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv, bv[b], accg[b], 0, 0, 0);
-            }
-        }
-    };
-    if constexpr (NT >= 3) {
-        // 33..64 traces: 160 accumulator registers leave no room for a second fragment set -- no software prefetch (the other wave of the SIMD covers the
-        // latency; with it the body spilled to scratch memory)
-        for (int64_t s = c0; s < c1; s += 4) { const Frag f = load(s); mm(f); }
-    } else {
-        Frag f[AHEAD];
-#pragma unroll
-        for (int d = 0; d < AHEAD; ++d) f[d] = load(c0 + 4 * d);
-        for (int64_t s = c0; s < c1; s += 4 * AHEAD) {
-#pragma unroll
-            for (int d = 0; d < AHEAD; ++d) {
-                const Frag nx = load(s + 4 * (AHEAD + d));
-                mm(f[d]);
-                f[d] = nx;
-            }
-        }
-    }
-    // D layout (fp64 16x16): row = (lane>>4) + 4r, col = lane&15
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int slot = b * 16 + fi;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if (slot < nl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Ut[(int64_t)(l0 + slot) * BLKPX + (wave * 4 + a) * 16 + kq + 4 * r] = acc[a][b][r];
-        if (gw)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Gb[(int64_t)blk * WIN_NLB * WIN_NLB + (wave * 16 + kq + 4 * r) * WIN_NLB + slot] = accg[b][r];
-    }
-}
-
 __global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
                                                   const int *__restrict__ lst_k, const int *__restrict__ blk_list, int nseg, double *__restrict__ Ut, int64_t ut_stride,
                                                   double *__restrict__ Gb, int64_t gb_stride) {
@@ -667,35 +547,13 @@ __global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4,
     }
 }
 
-// frame strides 1, 2, 4: 16-byte loads over the video's chunks (the used frames are components of them).  BIG = the blocks with 49..64 traces, a kernel of
-// their own: together with the other bodies the 4-group body did not fit 256 registers, and a kernel that spills needs scratch memory, whose arena the
-// runtime sets up at the kernel's FIRST launch -- measured as an intermittent 0.5-0.8 s inside the first fit of a process (profiles/r03/README.md)
-template <bool BIG>
-__global__ void __launch_bounds__(256, (BIG ? 1 : 2)) k_win_proj4(const float4 *__restrict__ Y4, BgGeom g, const float *__restrict__ Cc, int64_t ldc, const int *__restrict__ lst_ptr,
-                                                      const int *__restrict__ lst_k, const int *__restrict__ blk_list, int nseg, double *__restrict__ Ut, int64_t ut_stride,
-                                                      double *__restrict__ Gb, int64_t gb_stride) {
-    const int blk = blk_list[blockIdx.x / nseg], seg = blockIdx.x % nseg;
-    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
-    double *ut = Ut + seg * ut_stride, *gb = Gb + seg * gb_stride;
-    const int64_t nchunk = (g.T + 3) >> 2;
-    const int64_t cseg = ((nchunk + nseg - 1) / nseg + 7) & ~int64_t(7);
-    const int64_t c0 = seg * cseg, c1 = c0 + cseg < nchunk ? c0 + cseg : nchunk;
-    if constexpr (BIG) win_body4<4>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb);
-    else switch ((nl + 15) >> 4) {
-        case 1: win_body4<1>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
-        case 2: win_body4<2>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
-        case 3: win_body4<3>(Y4, g, Cc, ldc, blk, l0, nl, lst_k, c0, c1, ut, gb); break;
-        default: break;
-    }
-}
-
 // U~(i,k) = sum_seg U_seg(i,k) - 1/2 sum_{l at i} A_il sum_seg G_seg(l,k), written to segment 0.
 // Workgroup = (block, WF_S traces of its list): a small patch has ~100 blocks but 16 frame segments, and one workgroup per block summed its
 // 16 x (list length + 16) strided partials in one serial loop per thread -- 0.21 ms per launch against 0.06 ms for the whole 512 x 512 frame.
 constexpr int WF_S = 4;
 __global__ void __launch_bounds__(256) k_win_fix(BgGeom g, int K, const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
                                                  const int *__restrict__ lst_ptr, const short *__restrict__ slot_of, const int *__restrict__ blk_list, int nseg,
-                                                 double *__restrict__ Ut, int64_t ut_stride, const double *__restrict__ Gb, int64_t gb_stride) {
+                                                 double *__restrict__ Ut, int64_t ut_stride, const double *__restrict__ Gb, int64_t gb_stride, double *__restrict__ Praw) {
     __shared__ double G[WIN_NLB * WF_S];                     // G[r][j]: column s0 + j of the block's list Gram matrix
     const int blk = blk_list[blockIdx.x];
     const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
@@ -727,6 +585,7 @@ __global__ void __launch_bounds__(256) k_win_fix(BgGeom g, int K, const int *__r
         double w = 0.0;
         for (int e = e0; e < e1; ++e) w += (double)aval[e] * G[(int)slot_of[(int64_t)blk * K + acol[e]] * WF_S + (s - s0)];
         u[0] = v - 0.5 * w;
+        if (Praw) Praw[(int64_t)(l0 + s) * BLKPX + lp] = v;      // U itself = Yc Cc' on the block: the P table of the sweep-free spatial update (vproj.hip)
     }
 }
 static_assert(WIN_NLB * WF_S == 256, "k_win_fix: one Gram entry per thread");
@@ -791,12 +650,31 @@ __global__ void __launch_bounds__(256) k_rowsum_correct(const double *__restrict
 // ---- helpers on the covariance table ----------------------------------------------------------------
 struct CovTab {
     const double *cov; const int *pair_of;   // pair_of[blk*nrel + rel] or -1
+    const int *wcodes; int woff;             // [(bc0 + woff) * (nbr + 2 woff) + (br0 + woff)][256]: the block-pair codes of the 4 x 4-block window with origin (br0, bc0) >= -woff, k_win_codes
     int nbr, nbc;
     int maxd, nrel;                          // largest block displacement between two ring pixels of one centre (2: radius <= 16, 3: <= 24); nrel_of(maxd)
 };
 // canonical displacement index: dC in 0..maxd; dC == 0 -> dR in 0..maxd (0..maxd); dC >= 1 -> dR in -maxd..maxd.  maxd = 2: 13 classes (0..2, 3..7, 8..12)
 __host__ __device__ __forceinline__ int rel_index(int dR, int dC, int maxd) { return dC == 0 ? dR : (maxd + 1) + (dC - 1) * (2 * maxd + 1) + dR + maxd; }
 __host__ __device__ __forceinline__ int nrel_of(int maxd) { return (maxd + 1) + maxd * (2 * maxd + 1); }
+
+// The block-pair codes of a pixel's 4 x 4-block window depend on the window's origin only, so they are tabulated once per fit instead of being
+// re-derived (25 integer operations and a dependent load per entry, 256 entries) by every pixel's wave.
+__global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_of, int nbr, int nbc, int woff, int maxd, int nrel, int *__restrict__ wcodes) {
+    const int br0 = (int)(blockIdx.x % (nbr + 2 * woff)) - woff, bc0 = (int)(blockIdx.x / (nbr + 2 * woff)) - woff;
+    const int q = threadIdx.x, a = q >> 4, b = q & 15;
+    int ia = br0 + (a & 3), ja = bc0 + (a >> 2), ib = br0 + (b & 3), jb = bc0 + (b >> 2);
+    int code = -1;
+    if (ia >= 0 && ja >= 0 && ib >= 0 && jb >= 0 && ia < nbr && ib < nbr && ja < nbc && jb < nbc) {
+        int dR = ib - ia, dC = jb - ja, sw = 0;
+        if (dC < 0 || (dC == 0 && dR < 0)) { sw = 1; ia = ib; ja = jb; dR = -dR; dC = -dC; }
+        if (dC <= maxd && dR <= maxd && dR >= -maxd) {
+            const int pidx = pair_of[(ja * nbr + ia) * nrel + rel_index(dR, dC, maxd)];
+            code = pidx < 0 ? -1 : ((pidx << 2) | (sw << 1) | ((dR == 0 && dC == 0) ? 1 : 0));
+        }
+    }
+    wcodes[(int64_t)blockIdx.x * 256 + q] = code;
+}
 }  // namespace cnmfe
 #include "ring_solve.hpp"
 namespace cnmfe {
@@ -1024,7 +902,11 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
 
     // ---- the window projection first: it needs the footprint lists and the traces, nothing else, and takes 5 ms at the headline size -- the host
     // builds the CSR rows of A, ind_active and the pair tables underneath it (a later fit of a patch: the video's table exists)
-    DevBuf &dLp = ctx->inc[0], &dLk = ctx->inc[1], &dSlot = ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5], &dGb = ctx->inc[6];
+    // keep_pt: this fit's window projection is the P = Yc Cc' table the next spatial update wants (all frames, the block's neurons, the same centred traces):
+    // the raw sums are kept with the patch, and so are the lists that index them (then the fit works out of the patch's copies)
+    const bool keep_pt = incr && has_a && kstride == 1 && !P->derived && !(b0_only & 2) && ctx->opt("r1_virtual", 1) != 0;
+    DevBuf &dLp = keep_pt ? P->pt_lp : ctx->inc[0], &dLk = ctx->inc[1], &dSlot = keep_pt ? P->pt_slot : ctx->inc[2], &dBl = ctx->inc[3], &dUt = ctx->inc[4], &dCsum = ctx->inc[5], &dGb = ctx->inc[6];
+    if (keep_pt) P->pt_valid = false;                        // (until the new table is queued)
     std::vector<int> blall;
     int nsg = 1; int64_t ut_stride = 0, gb_stride = 0;
     bool proj_queued = false;
@@ -1247,8 +1129,14 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             if (has_a) {
                 if (!proj_queued) RET(queue_projection());             // (first fit of the patch: behind the video's table)
                 RET(to_dev(ctx, dSlot, slot_of.data(), slot_of.size()));
+                if (keep_pt) RET(P->pt_tab.ensure(std::max<size_t>(1, lst_k.size()) * BLKPX * sizeof(double)));
                 LAUNCH(ctx, "bg_win_fix", k_win_fix, dim3((unsigned)blall.size(), WIN_NLB / WF_S), dim3(256), 0, g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(),
-                       dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride);
+                       dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride, keep_pt ? P->pt_tab.as<double>() : nullptr);
+                if (keep_pt) {
+                    P->pt_K = K; P->pt_lp_h = lst_ptr; P->pt_slot_h = slot_of;
+                    P->pt_gen = bound_rows_of(ctx, C, c_order, K, P->pt_rows) ? ctx->bound_gen : -1;
+                    P->pt_valid = true;
+                }
                 const int csplit = npairs >= 8192 ? 1 : npairs >= 4096 ? 2 : 4;      // (small patches: a pair's sweep is a long serial loop, one workgroup per pair leaves the chip idle)
                 LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs, (unsigned)csplit), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
                        dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
@@ -1262,6 +1150,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ht.mark("base / correction launches");
         // ---- B2b ----
         CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
+        DevBuf &dWcodes = ctx->wcodes;
+        const int woff = (g.p_radius + 15) >> 4;            // window origins reach -ceil(p_radius / 16) blocks (1 for rings up to 16 pixels, 2 up to 32)
+        const int nwin = (g.nbr + 2 * woff) * (g.nbc + 2 * woff);
+        RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
+        LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());
+        tab.wcodes = dWcodes.as<int>(); tab.woff = woff;
         int *dErr = nullptr;
         RET(ctx_errflag(ctx, &dErr));
         const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();
@@ -1270,10 +1164,15 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         if (nt < 1 || nt > 8) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
         // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp).  Measured and removed (profiles/r02/solve_ab_c3.txt): the
         // panel-blocked LDS solver (22.5 ms against 8.0) and the looped-block-column variant (10.6 ms: it spills ~200 tile registers)
+        {
+            DevBuf &dFill = ctx->solve_fill;                 // the fill values {0, 1} of missing neighbours, in global memory (ring_solve.hpp)
+            const double fillv[2] = {0.0, 1.0};
+            RET(to_dev(ctx, dFill, fillv, 2));
 #define RS5_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe); break;
-        switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe, dFill.as<double>()); break;
+            switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
 #undef RS5_CASE
+        }
     }
     RET(ring_stats_enqueue(ctx, P));                         // what the NEXT fit of this patch asks of the W being written now
     ht.mark("solve launch");

@@ -142,6 +142,17 @@ struct Patch {
     // footprint term (W*A)(C - mean C), whose applied instance is kept beside it (ELL rows + centred traces) -- see residual_run
     DevBuf ysig;
     bool ysig_valid = false;
+    // sweep-free ("virtual") residual, round 4: nothing between two background fits needs Ysig itself, only its projections.  After a fit cnmfe_residual only
+    // RECORDS the request (ysig_valid and ysig_virtual set, the footprint term pending as before): the spatial update takes Ysig C' out of the table
+    // P = Yc Cc' below (U = P - W P, vproj.hip), the temporal update projects the centred video through B = A - W'A.  Whoever needs Ysig itself (GetSn,
+    // compute_RSS, an export, fast_temporal ...) calls residual_realize first, which runs the sweep.
+    bool ysig_virtual = false;
+    // P(j,k) = sum_t Yc_j(t) Cc_k(t) in fp64 per 16x16 block of the block region and list slot: pt_tab[(pt_lp[b] + slot) * 256 + lp_of(pixel)], pt_slot[b * pt_K + k]
+    // = slot or -1.  The ring fit's window projection computes exactly this (all frames, the same centred traces) and leaves it here; otherwise the
+    // spatial update builds it.  Columns are rows pt_rows[] of the bound trace matrix of generation pt_gen (-1: some other matrix -- not reusable).
+    DevBuf pt_tab, pt_lp, pt_slot;
+    bool pt_valid = false; int32_t pt_K = 0; int64_t pt_gen = -1;
+    std::vector<int32_t> pt_rows; std::vector<int> pt_lp_h; std::vector<short> pt_slot_h;
     bool res_ac = false; int res_kind = 0; int64_t res_ldc = 0;    // res_kind: who wrote Ysig and the term beside it: 1 = cnmfe_residual, 2 = cnmfe_residual_ssub (0: no term kept)
     DevBuf resCnt, resK, resV, resCc, resCm;              // resCm: the means the centred traces were taken about (fp64, per trace)
     // a footprint term asked for by the last cnmfe_residual but not yet folded into Ysig: cnmfe_hals_temporal only needs A' Ysig and adds
@@ -244,6 +255,9 @@ struct cnmfe_ctx {
     // scratch shared by all patches of this context (sized for the largest)
     cnmfe::DevBuf bound;      // trace matrix bound with cnmfe_traces_bind (K x ldc fp32), passed as c_order = CNMFE_BOUND
     int32_t bound_K = 0; int64_t bound_T = 0; int bound_order = 1; bool bound_valid = false;
+    int64_t bound_gen = 0;    // counts the changes of the bound matrix' CONTENT (cnmfe_traces_bind, the stitch, deconvTemporal on it): what a table derived from its rows is valid for
+    cnmfe::DevBuf vp[16];     // scratch of the sweep-free projections (vproj.hip)
+    size_t hw_vp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int64_t last_ldc = 0;     // row stride of the centred traces the last residual_run left in tmp[1]
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
@@ -256,6 +270,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf tmp[16];    // small scratch
     size_t hw_cc = 0, hw_cm = 0, hw_wa[3] = {0, 0, 0};     // high-water sizes of the buffers that rotate through tmp[1], tmp[2], tmp[8..10] (DevBuf::ensure_hw)
     cnmfe::DevBuf inc[7];     // incremental ring regression: block footprint lists, U~, trace sums
+    cnmfe::DevBuf wcodes, solve_fill;   // ring solve: the block-pair codes per window origin (k_win_codes); the fill values {0, 1} in global memory (ring_solve.hpp)
     cnmfe::DevBuf stage;      // upload staging
     // per-call device scratch of the factor updates (factor.hip, deconv.hip): grown on demand, NEVER freed between calls -- a hipMalloc /
     // hipFree pair per buffer and call cost more than the small kernels they serve, and hipFree drains the device
@@ -321,7 +336,15 @@ int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out
 int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
             const float *b0_block, const float *b0_new, double *rss_out);
 int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const float *b0_new, int64_t frame0, int64_t nframes, float *out, int out_memspace);
-int residual_materialize(cnmfe_ctx *ctx, Patch *P);       // fold a pending footprint term into the resident Ysig (no-op without one)
+int residual_materialize(cnmfe_ctx *ctx, Patch *P);       // fold a pending footprint term into the resident Ysig (no-op without one); realizes a virtual residual first
+int residual_realize(cnmfe_ctx *ctx, Patch *P);           // a virtual residual (Patch::ysig_virtual) becomes a resident one: the ring sweep runs now (no-op otherwise)
+// rows of the bound trace matrix a (C, c_order) argument names: false when it is some other matrix
+bool bound_rows_of(const cnmfe_ctx *ctx, const float *C, int c_order, int32_t K, std::vector<int32_t> &rows);
+// vproj.hip -- the projections of a virtual residual.  Return 1 when they cannot serve the request (the caller realizes the residual and projects Ysig).
+int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                  const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU);
+int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                   const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu);
 int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu, int *dOverflow);   // 1: cannot be applied, materialise instead; *dOverflow set on the device if a footprint meets > 512 traces
 bool residual_term_foldable_spatial(const Patch *P, int32_t K, int64_t ldc);   // the pending term can enter the spatial update through its projection (no pass over Ysig)
 int residual_term_fold_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, int64_t nnz, const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU, DevBuf &dG);

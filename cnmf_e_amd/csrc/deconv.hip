@@ -163,7 +163,7 @@ __device__ double get_sn(const float *y, const DeconvCfg &c, float *scr, double 
 }
 
 // estimate_time_constant(y, 1, sn): returns g, or a negative flag (-2) when |g| > 1
-__device__ double est_g(const float *y, double shift, int T, double sn, double *red) {
+__device__ __forceinline__ double est_g(const float *y, double shift, int T, double sn, double *red) {
     const int tid = threadIdx.x;
     double m = 0;
     for (int t = tid; t < T; t += 256) m += (double)y[t] - shift;
@@ -291,7 +291,7 @@ __device__ void oasis_cold(const float *y, double bsub, int T, double g, double 
 // The warm-started pass (foopsi_oasisAR1.m:155-161 hands update_g's pools back to oasisAR1) with its input pools staged in LDS by the
 // whole workgroup -- v, w, t, l and g^l per pool, 32 B each -- so that lane 0 neither waits for a global load nor evaluates a pow() per pool
 // (90 us per pass for ~10^2 pools).  Same tests as oasis_seq_t<true>; the stack is written to P as there.
-__device__ void oasis_warm(int nin, double g, double smin, Pools &P, const double *sv, const double *sw, const double *sg, const int *st, const int *sl) {
+__device__ __forceinline__ void oasis_warm(int nin, double g, double smin, Pools &P, const double *sv, const double *sw, const double *sg, const int *st, const int *sl) {
     double cv = sv[0], cw = sw[0], cgl = sg[0];
     int ct = st[0], cl = sl[0], top = 0;
     double pv = 0, pw = 1, pgl = 1, plim = -INFINITY; int pt = 0, pl = 0;
@@ -434,7 +434,7 @@ __device__ __forceinline__ void oasis_first(const float *y, double bsub, int T, 
 
 // split the pools into tasks of <= 64 samples: wave 0, 64 pools per round, task slots from a wave prefix sum of the per-pool counts
 // (one lane walking the pool list paid a dependent global load per pool: 65 us for 115 pools)
-__device__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
+__device__ __forceinline__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
     const int lane = threadIdx.x;                                           // called by tid < 64 with P.n uniform
     __threadfence_block();                                                  // lane 0 wrote the pools
     int nt = 0;
@@ -457,7 +457,7 @@ __device__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
 // given -- the denominators hh_p = sum_{j<l_p} g^2j = cumsum(h.*h)(l_p) of foopsi_oasisAR1.m:166-174 from the same sweep.  tkv (2 doubles per
 // task), num and hh are flat pointers: k_deconv places them in LDS when the pool list is short enough (a Brent step is then not three
 // global-memory round trips long), else in the global scratch.
-__device__ void pool_numerators(const float *y, double bsub, double lam, double g, const Pools &P, const DeconvIO &io, int64_t base2,
+__device__ __forceinline__ void pool_numerators(const float *y, double bsub, double lam, double g, const Pools &P, const DeconvIO &io, int64_t base2,
                                 int ntask, double *tkv, double *num, double *hh) {
     const int tid = threadIdx.x;
     double g64 = g; for (int i = 0; i < 6; ++i) g64 *= g64;       // g^64: a task starts at a multiple of 64 samples into its pool
@@ -959,7 +959,7 @@ int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out
     const int batch = 512;
     for (int k0 = 0; k0 < K; k0 += batch)
         RET(deconv_launch(ctx, c, shmem, io, dList.as<int>() + k0, std::min(batch, K - k0), ctx->dscr));
-    ctx->bound.swap(dC);                                    // bound = C (row-major), dcv_c = C_raw - b
+    ctx->bound.swap(dC); ++ctx->bound_gen;                  // bound = C (row-major), dcv_c = C_raw - b
     ctx->bound_order = CNMFE_ROWMAJOR;
     if (C_out || C_raw_out || S_out || pars_out || sn_out) {
         if (!ctx->copy_stream) {

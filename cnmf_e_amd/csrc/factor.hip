@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(64) k_nnls_spatial(const int *__restrict__ row
 // ---- T1: U(k,t) = sum_e A(e) * Ysig(m_e, t)  (HALS_temporal.m:48) --------------------------------------
 // one workgroup per (neuron, frame chunk); a wave owns frames t = t0 + wave, +4, ...; lanes stride the
 // neuron's pixels and a 6-step DPP butterfly finishes the dot product.
+constexpr int PT_NE = 6;      // entries of A per lane kept in registers over the chunk loop (64 * 6 = 384 pixels per footprint; more: the tail loop)
 __global__ void __launch_bounds__(256) k_proj_temporal(const float4 *__restrict__ ysig4, int64_t d, int64_t T, const int64_t *__restrict__ colptr,
                                                        const int *__restrict__ erow, const float *__restrict__ aval, int64_t cchunk,
                                                        float *__restrict__ U, int64_t ldc) {
@@ -168,12 +169,29 @@ __global__ void __launch_bounds__(256) k_proj_temporal(const float4 *__restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t Tc = (T + 3) >> 2;
     const int64_t c0 = (int64_t)blockIdx.y * cchunk, c1 = c0 + cchunk < Tc ? c0 + cchunk : Tc;     // 4-frame groups
+    // a lane's (row, value) entries do not change over the chunk loop: read once, so that the loop issues nothing but independent video loads
+    // (it used to reload value and row per product, the video load waiting for the row load)
+    const int nit = (int)(e1 - e0 + 63 < (int64_t)64 * PT_NE ? (e1 - e0 + 63) >> 6 : PT_NE);       // workgroup-uniform
+    int rw[PT_NE]; float av[PT_NE];
+#pragma unroll
+    for (int i = 0; i < PT_NE; ++i) {
+        const int64_t e = e0 + lane + 64 * i;
+        const bool in = i < nit && e < e1;
+        rw[i] = in ? erow[e] : 0; av[i] = in ? aval[e] : 0.f;
+    }
+    const int64_t et = e0 + (int64_t)64 * PT_NE;               // entries beyond the registers (footprints of more than 384 pixels)
     for (int64_t c = c0 + wave; c < c1; c += 4) {
         const float4 *y = ysig4 + c * d;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int64_t e = e0 + lane; e < e1; e += 64) {
-            const float av = aval[e]; const float4 yv = y[erow[e]];
-            s0 = fmaf(av, yv.x, s0); s1 = fmaf(av, yv.y, s1); s2 = fmaf(av, yv.z, s2); s3 = fmaf(av, yv.w, s3);
+#pragma unroll
+        for (int i = 0; i < PT_NE; ++i)
+            if (i < nit) {
+                const float4 yv = y[rw[i]];
+                s0 = fmaf(av[i], yv.x, s0); s1 = fmaf(av[i], yv.y, s1); s2 = fmaf(av[i], yv.z, s2); s3 = fmaf(av[i], yv.w, s3);
+            }
+        for (int64_t e = et + lane; e < e1; e += 64) {
+            const float a = aval[e]; const float4 yv = y[erow[e]];
+            s0 = fmaf(a, yv.x, s0); s1 = fmaf(a, yv.y, s1); s2 = fmaf(a, yv.z, s2); s3 = fmaf(a, yv.w, s3);
         }
         for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o); }
         if (lane == 0) {
@@ -290,12 +308,16 @@ __global__ void __launch_bounds__(1024) k_hals_temporal(const int *__restrict__ 
     hals_temporal_one(lvl[blockIdx.x], nptr, nidx, nval, aa, U, C, Craw, ldc, T, red);
 }
 // the same level over the jobs of a context (TemporalJob, common.hpp): workgroup -> (job, neuron)
-struct HJobDev { const int *nptr, *nidx; const float *nval, *aa, *U; float *C, *Craw; int64_t ldc; };
+// (the operand pointers come out of a device table: declared in the GLOBAL address space, or every access through them is a flat load / store that the
+//  LDS waits of the staged neighbour list serialise -- scripts/isa_scan.py)
+#define CNMFE_GPTR(T) T __attribute__((address_space(1))) *
+struct HJobDev { CNMFE_GPTR(const int) nptr; CNMFE_GPTR(const int) nidx; CNMFE_GPTR(const float) nval; CNMFE_GPTR(const float) aa; CNMFE_GPTR(const float) U;
+                 CNMFE_GPTR(float) C; CNMFE_GPTR(float) Craw; int64_t ldc; };
 __global__ void __launch_bounds__(1024) k_hals_temporal_jobs(const HJobDev *__restrict__ jobs, const int2 *__restrict__ lvl, int64_t T) {
     __shared__ float red[1024];
     const int2 e = lvl[blockIdx.x];
     const HJobDev j = jobs[e.x];
-    hals_temporal_one(e.y, j.nptr, j.nidx, j.nval, j.aa, j.U, j.C, j.Craw, j.ldc, T, red);
+    hals_temporal_one(e.y, (const int *)j.nptr, (const int *)j.nidx, (const float *)j.nval, (const float *)j.aa, (const float *)j.U, (float *)j.C, (float *)j.Craw, j.ldc, T, red);
 }
 // ---- S6: connectivity_constraint.m:1-18 on a per-neuron box -------------------------------------------
 constexpr int PP_MAX = 64;    // max box side (bbox + 2 px margin each side)
@@ -500,9 +522,19 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     const int64_t tchunk = ((T + nparts - 1) / nparts + 3) & ~int64_t(3);
     RET(dPart.ensure((size_t)nparts * nnz * sizeof(float)));
     RET(dU.ensure((size_t)nnz * sizeof(float)));
+    // a virtual residual (no sweep has run, resid.hip): U = P - W P out of the table P = Yc Cc' (vproj.hip); if that path cannot serve this update the sweep
+    // runs now and Ysig is projected as before
+    bool virt = P->ysig_virtual;
+    if (virt) {
+        const int rcv = vproj_spatial(ctx, P, K, C, c_order, IND_colptr, IND_rowidx, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>());
+        if (rcv < 0) return rcv;
+        if (rcv > 0) { RET(residual_realize(ctx, P)); virt = false; }
+    }
+    if (!virt) {
     LAUNCH(ctx, "spatial_proj_U", k_proj_spatial, dim3((unsigned)((nnz + 255) / 256), nparts), dim3(256), 0, P->ysig.as<float4>(), d, T,
            dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
     LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
+    }
     // a footprint term pending beside Ysig (patches with halo neurons: the sweep ran without it) enters here: U += (W A_prev)(Cc_prev Cc')
     RET(residual_term_fold_spatial(ctx, P, K, nnz, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>(), S_[20]));
     ht.mark("uploads + projection launch");
@@ -647,6 +679,14 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     if (nnz > 0) {
         // a footprint term still pending on the residual enters through A' (W A)(C - mean C); if it cannot, it is folded into Ysig first
         if (P->pend && (P->pend_ldc != ldc || (P->res_ac && P->res_ldc != ldc))) RET(residual_materialize(ctx, P));
+        // a virtual residual: A' Ysig = B' Yc + A' (Ymean - b0), B = A - W'A, one block-tiled pass over the centred video (vproj.hip)
+        bool virt = P->ysig_virtual;
+        if (virt) {
+            const int rcv = vproj_temporal(ctx, P, K, A_colptr, A_rowidx, A_val, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(), dU.as<float>(), ldc);
+            if (rcv < 0) return rcv;
+            if (rcv > 0) { RET(residual_realize(ctx, P)); virt = false; }
+        }
+        if (!virt)
         LAUNCH(ctx, "temporal_proj_U", k_proj_temporal, dim3(K, nchunk), dim3(256), 0, P->ysig.as<float4>(), d, T, dColptr.as<int64_t>(),
                dErow.as<int>(), dAval.as<float>(), tchunk, dU.as<float>(), ldc);
         RET(dOvf.ensure(64));
@@ -816,7 +856,9 @@ int temporal_sweep_jobs(cnmfe_ctx *ctx) {
         std::vector<HJobDev> tab(jobs.size());
         for (size_t ji = 0; ji < jobs.size(); ++ji) {
             TemporalJob *j = jobs[ji];
-            tab[ji] = HJobDev{j->dNptr.as<int>(), j->dNidx.as<int>(), j->dNval.as<float>(), j->dAa.as<float>(), j->dU.as<float>(), j->dC.as<float>(), j->dCraw.as<float>(), j->ldc};
+            tab[ji] = HJobDev{(CNMFE_GPTR(const int))j->dNptr.as<int>(), (CNMFE_GPTR(const int))j->dNidx.as<int>(), (CNMFE_GPTR(const float))j->dNval.as<float>(),
+                              (CNMFE_GPTR(const float))j->dAa.as<float>(), (CNMFE_GPTR(const float))j->dU.as<float>(), (CNMFE_GPTR(float))j->dC.as<float>(),
+                              (CNMFE_GPTR(float))j->dCraw.as<float>(), j->ldc};
         }
         RET(to_dev(ctx, dTab, tab.data(), tab.size()));
         for (int it = 0; it < j0->maxIter; ++it)

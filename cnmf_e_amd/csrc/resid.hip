@@ -704,6 +704,7 @@ int ysig_export(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, float *Ysig_out, int out
 
 // Ysig += (pending term) - (applied term); the pending term becomes the applied one
 int residual_materialize(cnmfe_ctx *ctx, Patch *P) {
+    RET(residual_realize(ctx, P));                           // a virtual residual: the sweep runs now (every caller is about to read Ysig itself)
     if (!P->pend) return 0;
     if (!P->ysig_valid || !P->ysig.p) return fail(CNMFE_ESTATE, "pending footprint term without a resident residual");
     if (P->pend_ac || P->res_ac) {
@@ -1007,64 +1008,12 @@ int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const fl
     return ctx_check_errflag(ctx);
 }
 
-int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
-                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf, int tables_only) {
+// The ring sweep itself: Ysig = Yc(patch) + (Ymean - b0) - W Yc_block [+ (W A_prev)(C_prev - mean) when `has_ac`: the ELL rows of W A_prev in tmp[8..10], the
+// centred traces in tmp[1]] into `ysig`.  can_defer: the caller can leave the footprint term PENDING beside Ysig instead (then *deferred is set and the sweep
+// runs without it -- the fastest kernel, see below).
+static int r1_sweep(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, bool has_ac, int64_t ldc, bool can_defer, bool *deferred) {
     const int64_t T = P->T;
-    DevBuf &ysig = outbuf ? *outbuf : P->ysig;               // bg_ssub > 1 sweeps the low-resolution patch into its own buffer
-    // the resident Ysig of this patch is still the residual under the current video, W and b0: only the footprint term changes
-    const bool delta = !outbuf && P->ysig_valid && P->res_kind == 1 && P->ysig.p && ctx->opt("r1_delta", 1) != 0;
-    RET(ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
-    DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
-           &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10];
-    int64_t ldc = 4;
-    bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
-    if (has_ac) {
-        RET(upload_centered(ctx, dC, C, Ksel, T, c_order, dCc, dCm, &ldc));
-        HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
-        RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));
-        RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
-        RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
-        RET(dWaCnt.ensure_hw(P->d * sizeof(int), ctx->hw_wa[0]));
-        RET(dWaK.ensure_hw((size_t)WA_CAP * P->d * sizeof(int), ctx->hw_wa[1]));
-        RET(dWaV.ensure_hw((size_t)WA_CAP * P->d * sizeof(float), ctx->hw_wa[2]));
-        // a ring that touches more than WA_CAP footprints raises the context's error flag (ctx_check_errflag at the next wait of this call chain: the
-        // spatial / temporal update's own download) instead of costing a drain of the stream here -- with several patches per context that drain
-        // was what kept the host from setting up patch m + 1 under patch m's kernels
-        int *dErrWa = nullptr;
-        RET(ctx_errflag(ctx, &dErrWa));
-        const int nnzA = (int)csr.col.size();
-        const size_t wa_stage = (size_t)nnzA * 8;
-        if (wa_stage <= 96 * 1024) {                               // (32 KB static + this: one workgroup per CU above ~48 KB, still every CU of a small patch's grid)
-            if (wa_stage > 32 * 1024)                                // (per device: set where it is needed, not once per process)
-                CK(hipFuncSetAttribute((const void *)k_ring_wa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            LAUNCH(ctx, "r1_ring_wa", k_ring_wa<true>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), wa_stage, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
-                   P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
-                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
-        } else
-            LAUNCH(ctx, "r1_ring_wa", k_ring_wa<false>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
-                   P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
-                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
-    }
-    if (tables_only) { ctx->last_ldc = ldc; return 0; }       // bg_ssub: the caller only wants (W*A) and the centred traces (tmp[8..10], tmp[1])
-    // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)
-    auto keep = [&]() {
-        if (outbuf) return;
-        P->res_ac = has_ac; P->res_ldc = ldc; P->res_kind = 1; P->res_K = Ksel; P->pend = false;
-        if (has_ac) { P->resCnt.swap(dWaCnt); P->resK.swap(dWaK); P->resV.swap(dWaV); P->resCc.swap(dCc); P->resCm.swap(dCm); }
-    };
-    if (delta) {
-        // lazy: keep the term pending; cnmfe_hals_temporal folds it in algebraically, anybody else materialises it
-        if (ctx->opt("r1_lazy", 1) != 0 && !Ysig_out) {
-            P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
-            if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
-            return 0;
-        }
-        P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
-        if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
-        RET(residual_materialize(ctx, P));
-        if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
-        return 0;
-    }
+    DevBuf &dCc = ctx->tmp[1], &dOffs = ctx->tmp[6], &dDlt = ctx->tmp[7], &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10];
     RET(dDlt.ensure(P->d * sizeof(float)));
     LAUNCH(ctx, "r1_dlt", k_dlt, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0,
            P->ymean_f.as<float>(), P->b0.as<double>(), dDlt.as<float>(), P->d, P->nr, P->nr_b, P->roff, P->coff);
@@ -1081,7 +1030,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     // The footprint term (W A_prev)(C_prev - mean) of a patch with halo neurons need not go through the sweep at all: the sweep runs without it (so the
     // faster duo-role kernel serves patched runs too) and the term stays PENDING beside Ysig -- the spatial and the temporal update both take it in
     // algebraically, through their projections (residual_term_fold_spatial, residual_term_project); any other consumer materialises it first.
-    const bool defer_term = has_ac && variant == 14 && h == 15 && full_ring && !outbuf && !Ysig_out && ctx->opt("r1_lazy", 1) != 0 && ctx->opt("r1_defer", 1) != 0;
+    const bool defer_term = has_ac && variant == 14 && h == 15 && full_ring && can_defer && ctx->opt("r1_lazy", 1) != 0 && ctx->opt("r1_defer", 1) != 0;
     const bool sweep_ac = has_ac && !defer_term;
     if (variant == 14 && (sweep_ac || h != 15)) variant = 11;   // duo roles (resid_duo.hpp): radius 15, no footprint term inside the sweep
     if (h == 18 && variant >= 11) variant = 10;               // arc kernels: radius 15 only (ds_read immediates)
@@ -1142,6 +1091,92 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         rc = 0;
     }
     RET(rc);
+    if (deferred) *deferred = defer_term;
+    return 0;
+}
+
+// a virtual residual becomes a resident one: the sweep without any footprint term (the term, if any, is pending beside it either way)
+int residual_realize(cnmfe_ctx *ctx, Patch *P) {
+    if (!P->ysig_virtual) return 0;
+    if (!P->ysig_valid) { P->ysig_virtual = false; return 0; }
+    RET(P->ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
+    RET(r1_sweep(ctx, P, P->ysig, false, 4, false, nullptr));
+    P->ysig_virtual = false;
+    return 0;
+}
+
+int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
+                 const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf, int tables_only) {
+    const int64_t T = P->T;
+    DevBuf &ysig = outbuf ? *outbuf : P->ysig;               // bg_ssub > 1 sweeps the low-resolution patch into its own buffer
+    // the resident Ysig of this patch is still the residual under the current video, W and b0: only the footprint term changes
+    const bool delta = !outbuf && P->ysig_valid && P->res_kind == 1 && (P->ysig.p || P->ysig_virtual) && ctx->opt("r1_delta", 1) != 0;
+    DevBuf &dC = ctx->tmp[0], &dCc = ctx->tmp[1], &dCm = ctx->tmp[2], &dArow = ctx->tmp[3], &dAcol = ctx->tmp[4], &dAval = ctx->tmp[5],
+           &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10];
+    int64_t ldc = 4;
+    bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
+    if (has_ac) {
+        RET(upload_centered(ctx, dC, C, Ksel, T, c_order, dCc, dCm, &ldc));
+        HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
+        RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));
+        RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
+        RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
+        RET(dWaCnt.ensure_hw(P->d * sizeof(int), ctx->hw_wa[0]));
+        RET(dWaK.ensure_hw((size_t)WA_CAP * P->d * sizeof(int), ctx->hw_wa[1]));
+        RET(dWaV.ensure_hw((size_t)WA_CAP * P->d * sizeof(float), ctx->hw_wa[2]));
+        // a ring that touches more than WA_CAP footprints raises the context's error flag (ctx_check_errflag at the next wait of this call chain: the
+        // spatial / temporal update's own download) instead of costing a drain of the stream here -- with several patches per context that drain
+        // was what kept the host from setting up patch m + 1 under patch m's kernels
+        int *dErrWa = nullptr;
+        RET(ctx_errflag(ctx, &dErrWa));
+        const int nnzA = (int)csr.col.size();
+        const size_t wa_stage = (size_t)nnzA * 8;
+        if (wa_stage <= 96 * 1024) {                               // (32 KB static + this: one workgroup per CU above ~48 KB, still every CU of a small patch's grid)
+            if (wa_stage > 32 * 1024)                                // (per device: set where it is needed, not once per process)
+                CK(hipFuncSetAttribute((const void *)k_ring_wa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            LAUNCH(ctx, "r1_ring_wa", k_ring_wa<true>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), wa_stage, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
+                   P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
+                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
+        } else
+            LAUNCH(ctx, "r1_ring_wa", k_ring_wa<false>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
+                   P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
+                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
+    }
+    if (tables_only) { ctx->last_ldc = ldc; return 0; }       // bg_ssub: the caller only wants (W*A) and the centred traces (tmp[8..10], tmp[1])
+    // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)
+    auto keep = [&]() {
+        if (outbuf) return;
+        P->res_ac = has_ac; P->res_ldc = ldc; P->res_kind = 1; P->res_K = Ksel; P->pend = false;
+        if (has_ac) { P->resCnt.swap(dWaCnt); P->resK.swap(dWaK); P->resV.swap(dWaV); P->resCc.swap(dCc); P->resCm.swap(dCm); }
+    };
+    if (delta) {
+        // lazy: keep the term pending; cnmfe_hals_temporal folds it in algebraically, anybody else materialises it
+        if (ctx->opt("r1_lazy", 1) != 0 && !Ysig_out) {
+            P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
+            if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
+            return 0;
+        }
+        P->pend = true; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = Ksel;
+        if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
+        RET(residual_materialize(ctx, P));
+        if (Ysig_out) RET(ysig_export(ctx, P, ysig, Ysig_out, out_memspace));
+        return 0;
+    }
+    // Sweep-free residual (round 4, option "r1_virtual", default 1): nobody has asked for Ysig itself -- the request is only recorded.  The spatial update
+    // takes Ysig C' out of the table P = Yc Cc' (U = P - W P), the temporal update projects the centred video through B = A - W'A (vproj.hip), a footprint
+    // term pends beside the virtual Ysig exactly as beside a resident one; every other consumer goes through residual_realize, which runs the sweep then.
+    if (!outbuf && !Ysig_out && ctx->opt("r1_virtual", 1) != 0 && ctx->opt("r1_lazy", 1) != 0 && ctx->opt("r1_delta", 1) != 0) {
+        P->res_ac = false; P->res_ldc = ldc; P->res_kind = 1; P->res_K = 0;
+        P->pend = has_ac; P->pend_ac = has_ac; P->pend_ldc = ldc; P->pend_K = has_ac ? Ksel : 0;
+        if (has_ac) { P->pendCnt.swap(dWaCnt); P->pendK.swap(dWaK); P->pendV.swap(dWaV); P->pendCc.swap(dCc); P->pendCm.swap(dCm); }
+        ctx->last_ldc = ldc;
+        P->ysig_valid = true; P->ysig_virtual = true;
+        return 0;
+    }
+    RET(ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
+    bool defer_term = false;
+    RET(r1_sweep(ctx, P, ysig, has_ac, ldc, !outbuf && !Ysig_out, &defer_term));
+    if (!outbuf) P->ysig_virtual = false;
     if (defer_term) {                                        // Ysig carries no term; the one asked for waits beside it
         P->res_ac = false; P->res_ldc = ldc; P->res_kind = 1; P->res_K = 0;
         P->pend = true; P->pend_ac = true; P->pend_ldc = ldc; P->pend_K = Ksel;

@@ -421,7 +421,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
             return 0;
         }
         M->res_ac = has_a; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
-        M->res_kind = 2;
+        M->res_kind = 2; M->ysig_virtual = false;
     }
     const int64_t ntmp = (int64_t)d1s * M->nc_b;
     RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));

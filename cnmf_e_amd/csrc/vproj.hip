@@ -1,0 +1,415 @@
+// The projections of a VIRTUAL residual (round 4): what the spatial and the temporal update need of
+//     Ysig = Y(patch) - b0 - W (R - mean R),  R = Y_block - A_prev C_prev          (update_spatial_parallel.m:162-166 == update_temporal_parallel.m:149-152)
+// without ever forming Ysig.  With the centred video Yc = Y - Ymean (resident) and dlt = Ymean(patch) - b0:
+//     Ysig = Yc(patch) + dlt - W Yc_block + (W A_prev)(C_prev - mean)             (the last term: the "footprint term", kept pending beside Ysig, resid.hip)
+// * spatial update (HALS_spatial.m:31, U = Ysig C' - T mean(Ysig) mean(C)' = Ysig Cc', Cc the centred traces: constants drop out):
+//       U(m,k) = P(m,k) - sum_i W(m,i) P(m + o_i, k),        P = Yc Cc'  (block pixels x neurons, fp64)
+//   P is what the ring fit's window projection computes anyway (bg.hip, k_win_proj4 / k_win_fix) in the same iteration with the same traces: the fit leaves
+//   it with the patch and the update costs nnz(IND) (p + 1) table reads.  When no valid table is there (traces changed since the fit, a frame stride != 1 in the
+//   fit, masks that reach beyond the fit's lists) the table is built here by the same kernel -- one read of the video.
+// * temporal update (HALS_temporal.m:48, U = A' Ysig):
+//       U(k,t) = sum_j B(j,k) Yc(j,t) + sum_m A(m,k) dlt(m),   B = E A - W' A   (E: patch rows -> block rows; support: footprint (+) ring)
+//   a block-tiled projection of the centred video on the fp64 matrix pipe: per 16x16 block of pixels the neurons whose B meets it (<= 64), contraction over
+//   the block's 256 pixels, partial sums per (block, neuron) added in a fixed order (bit-reproducible).  One read of the video.
+// Everything is accumulated in fp64 from exact fp32 products, so the cancellation between the A and W'A parts of B (the background they remove) costs nothing.
+// The pending footprint term enters both updates through their projections as before (residual_term_fold_spatial / residual_term_project, resid.hip).
+#include "common.hpp"
+#include "win_proj.hpp"
+#include <climits>
+
+namespace cnmfe {
+
+static BgGeom vp_geom(const Patch *P) {
+    BgGeom g{};
+    g.nr = P->nr; g.nc = P->nc; g.nr_b = P->nr_b; g.nc_b = P->nc_b; g.roff = P->roff; g.coff = P->coff;
+    g.r0_abs = P->brect[0]; g.c0_abs = P->brect[2]; g.d1 = P->d1; g.d2 = P->d2;
+    g.nbr = (P->nr_b + BLK - 1) / BLK; g.nbc = (P->nc_b + BLK - 1) / BLK;
+    g.d = P->d; g.d_b = P->d_b; g.T = P->T; g.kstride = 1; g.Tp = P->T; g.Tpad = (P->T + 15) / 16 * 16;
+    g.p = P->p; g.p_radius = 0;
+    for (int i = 0; i < P->p; ++i) g.p_radius = std::max(g.p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
+    g.nbw = ((2 * g.p_radius) >> 4) + 2; g.bf4 = 1;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// spatial:  U(e) = P(m_e, k_e) - sum_i W(m_e, i) P(m_e + o_i, k_e)
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// sum over the frame segments of the window projection's partial tables (k_win_proj4 writes one per segment)
+__global__ void __launch_bounds__(256) k_vp_segsum(const double *__restrict__ Ut, int64_t ut_stride, int nseg, int64_t n, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = Ut[i];
+    for (int sg = 1; sg < nseg; ++sg) v += Ut[sg * ut_stride + i];
+    out[i] = v;
+}
+
+// One thread per entry of the search mask (entries of a column are consecutive pixels: for a fixed ring offset the lanes of a wave read consecutive weights and,
+// mostly, consecutive table entries).  Eight offsets at a time: their loads are independent; the sum keeps the ring order (bit-reproducible).
+__global__ void __launch_bounds__(256) k_vp_spatial(const int *__restrict__ erow, const int *__restrict__ ecol, int64_t nnz, BgGeom g, const int *__restrict__ dr,
+                                                    const int *__restrict__ dc, const float *__restrict__ W, const double *__restrict__ tab,
+                                                    const int *__restrict__ lp, const short *__restrict__ slot_of, int Kt, const int *__restrict__ kmap,
+                                                    float *__restrict__ U, int *__restrict__ err) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const int m = erow[e], kt = kmap[ecol[e]];
+    const int rbm = m % g.nr + g.roff, cbm = m / g.nr + g.coff;
+    bool bad = false;
+    auto at = [&](int rb, int cb) -> int64_t {              // index of P(pixel, kt) in the table, -1 if the table does not hold it
+        const int b = (cb >> 4) * g.nbr + (rb >> 4);
+        const int sl = slot_of[(int64_t)b * Kt + kt];
+        return sl < 0 ? -1 : ((int64_t)lp[b] + sl) * BLKPX + lp_of(rb & 15, cb & 15);
+    };
+    double acc = 0.0;
+    for (int i0 = 0; i0 < g.p; i0 += 8) {
+        float w8[8]; int64_t ix[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u < g.p ? i0 + u : g.p - 1;
+            const int rb = rbm + dr[i], cb = cbm + dc[i];
+            const bool in = i0 + u < g.p && rb >= 0 && rb < g.nr_b && cb >= 0 && cb < g.nc_b;
+            w8[u] = in ? W[(int64_t)i * g.d + m] : 0.f;     // (a weight is 0 where the neighbour is outside the field of view)
+            ix[u] = (in && w8[u] != 0.f) ? at(rb, cb) : 0;
+            if (ix[u] < 0) { bad = true; ix[u] = 0; w8[u] = 0.f; }
+        }
+        double p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p8[u] = tab[ix[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (w8[u] != 0.f) acc += (double)w8[u] * p8[u];
+    }
+    const int64_t i0 = at(rbm, cbm);
+    if (i0 < 0) bad = true;
+    U[e] = (float)((i0 < 0 ? 0.0 : tab[i0]) - acc);
+    if (bad) atomicOr(err, 1);                             // (the host checked the coverage: an inconsistent table, reported by the next wait)
+}
+
+// which blocks of the block region the entries of a CSC column (patch rows) reach when every pixel is grown by R: per block column bj the block rows lo..hi
+// (exact for masks whose image columns are runs; a superset otherwise).  Appends (block) to `out`.
+static void reach_blocks(const Patch *P, const BgGeom &g, int R, const int32_t *rowidx, int64_t e0, int64_t e1, std::vector<int> &lo, std::vector<int> &hi, std::vector<int> &out) {
+    int bjmin = INT_MAX, bjmax = -1;
+    for (int64_t e = e0; e < e1; ++e) {
+        const int m = rowidx[e];
+        const int rb = m % P->nr + P->roff, cb = m / P->nr + P->coff;
+        const int bi0 = std::max(0, rb - R) >> 4, bi1 = std::min(P->nr_b - 1, rb + R) >> 4;
+        const int bj0 = std::max(0, cb - R) >> 4, bj1 = std::min(P->nc_b - 1, cb + R) >> 4;
+        for (int bj = bj0; bj <= bj1; ++bj) {
+            if (hi[bj] < 0) { lo[bj] = bi0; hi[bj] = bi1; } else { lo[bj] = std::min(lo[bj], bi0); hi[bj] = std::max(hi[bj], bi1); }
+        }
+        bjmin = std::min(bjmin, bj0); bjmax = std::max(bjmax, bj1);
+    }
+    for (int bj = bjmin; bj <= bjmax; ++bj) {
+        if (hi[bj] < 0) continue;
+        for (int bi = lo[bj]; bi <= hi[bj]; ++bi) out.push_back(bj * g.nbr + bi);
+        hi[bj] = -1;
+    }
+}
+
+int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                  const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU) {
+    HostTrace ht(ctx, "vproj_spatial");
+    const BgGeom g = vp_geom(P);
+    const int nblk = g.nbr * g.nbc, R = g.p_radius;
+    const int64_t nnz = IND_colptr[K];
+    if ((int64_t)nblk * K >= (int64_t(1) << 31)) return 1;
+    // the (block, neuron) pairs the update reads: the mask of k grown by the ring
+    std::vector<int> lo(g.nbc, 0), hi(g.nbc, -1), need_ptr((size_t)K + 1, 0), need;
+    need.reserve((size_t)K * 16);
+    for (int32_t k = 0; k < K; ++k) {
+        reach_blocks(P, g, R, IND_rowidx, IND_colptr[k], IND_colptr[k + 1], lo, hi, need);
+        need_ptr[k + 1] = (int)need.size();
+    }
+    // does the patch's table hold them?  (the fit's window projection left it: same video, traces = rows of the bound matrix of this generation)
+    std::vector<int32_t> rows;
+    const bool have_rows = bound_rows_of(ctx, C, c_order, K, rows);
+    std::vector<int> kmap((size_t)K, -1);
+    bool reuse = P->pt_valid && have_rows && P->pt_gen == ctx->bound_gen && P->pt_K > 0 && (int)P->pt_lp_h.size() == nblk + 1;
+    if (reuse) {
+        std::vector<int> colof((size_t)ctx->bound_K, -1);
+        for (int32_t c = 0; c < P->pt_K; ++c) colof[P->pt_rows[c]] = c;
+        for (int32_t k = 0; k < K && reuse; ++k) {
+            if (need_ptr[k + 1] == need_ptr[k]) { kmap[k] = 0; continue; }        // (an empty mask reads nothing)
+            const int c = colof[rows[k]];
+            if (c < 0) { reuse = false; break; }
+            kmap[k] = c;
+            for (int i = need_ptr[k]; i < need_ptr[k + 1]; ++i)
+                if (P->pt_slot_h[(size_t)need[i] * P->pt_K + c] < 0) { reuse = false; break; }
+        }
+    }
+    ht.mark(reuse ? "need lists (table of the fit)" : "need lists (table to build)");
+    if (!reuse) {
+        // the table of exactly these pairs, by the fit's own kernel: lists per block, longest first
+        std::vector<int> cnt((size_t)nblk + 1, 0);
+        for (int b : need) ++cnt[b + 1];
+        std::vector<int> lst_ptr((size_t)nblk + 1, 0);
+        for (int b = 0; b < nblk; ++b) {
+            if (cnt[b + 1] > WIN_NLB) return 1;            // denser than the window kernel is built for: the sweep serves this update
+            lst_ptr[b + 1] = lst_ptr[b] + cnt[b + 1];
+        }
+        std::vector<int> lst_k(need.size()), fill((size_t)nblk, 0), blk_nt[4], blall;
+        std::vector<short> slot_of((size_t)nblk * K, (short)-1);
+        for (int32_t k = 0; k < K; ++k)
+            for (int i = need_ptr[k]; i < need_ptr[k + 1]; ++i) {
+                const int b = need[i], s_ = fill[b]++;
+                lst_k[lst_ptr[b] + s_] = k; slot_of[(size_t)b * K + k] = (short)s_;
+            }
+        for (int b = 0; b < nblk; ++b) { const int n = lst_ptr[b + 1] - lst_ptr[b]; if (n) blk_nt[(n - 1) >> 4].push_back(b); }
+        for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());
+        DevBuf &dLk = ctx->inc[1], &dBl = ctx->inc[3], &dUt = ctx->inc[4];
+        P->pt_valid = false;
+        RET(to_dev(ctx, P->pt_lp, lst_ptr.data(), lst_ptr.size()));
+        RET(to_dev(ctx, P->pt_slot, slot_of.data(), slot_of.size()));
+        RET(to_dev(ctx, dLk, lst_k.data(), lst_k.size()));
+        RET(to_dev(ctx, dBl, blall.data(), blall.size()));
+        const int nb_ = (int)blall.size();
+        const int64_t nent = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX;
+        RET(P->pt_tab.ensure((size_t)nent * sizeof(double)));
+        if (nb_ > 0) {
+            const int nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
+            RET(dUt.ensure((size_t)nsg * nent * sizeof(double)));
+            const int nbig = (int)blk_nt[3].size();
+            if (nbig)
+                LAUNCH(ctx, "spatial_ptab_proj", k_win_proj4<true>, dim3((unsigned)(nbig * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc, ldc, P->pt_lp.as<int>(), dLk.as<int>(),
+                       dBl.as<int>(), nsg, dUt.as<double>(), nent, (double *)nullptr, (int64_t)0);
+            if (nb_ > nbig)
+                LAUNCH(ctx, "spatial_ptab_proj", k_win_proj4<false>, dim3((unsigned)((nb_ - nbig) * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc, ldc, P->pt_lp.as<int>(),
+                       dLk.as<int>(), dBl.as<int>() + nbig, nsg, dUt.as<double>(), nent, (double *)nullptr, (int64_t)0);
+            LAUNCH(ctx, "spatial_ptab_sum", k_vp_segsum, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, dUt.as<double>(), nent, nsg, nent, P->pt_tab.as<double>());
+        }
+        P->pt_K = K; P->pt_lp_h.swap(lst_ptr); P->pt_slot_h.swap(slot_of);
+        P->pt_rows = rows; P->pt_gen = have_rows ? ctx->bound_gen : -1;
+        P->pt_valid = true;
+        for (int32_t k = 0; k < K; ++k) kmap[k] = k;
+        ht.mark("table built");
+    }
+    if (nnz == 0) return 0;
+    DevBuf &dKmap = ctx->vp[0];
+    RET(to_dev(ctx, dKmap, kmap.data(), kmap.size()));
+    int *dErr = nullptr;
+    RET(ctx_errflag(ctx, &dErr));
+    LAUNCH(ctx, "spatial_from_ptab", k_vp_spatial, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dErow, dEcol, nnz, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
+           P->W.as<float>(), P->pt_tab.as<double>(), P->pt_lp.as<int>(), P->pt_slot.as<short>(), (int)P->pt_K, dKmap.as<int>(), dU, dErr);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// temporal:  U(k,t) = sum_j B(j,k) Yc(j,t) + sum_m A(m,k) dlt(m),   B = E A - W' A
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// B of one (block, neuron) entry: 256 threads = the block's pixels in memory order (px = r + 16 c).  The neuron's footprint inside the block grown by the ring
+// radius sits in LDS as a dense (16 + 2R)^2 window; B(j) = A(j) - sum_i W(j - o_i, i) A(j - o_i) then costs p LDS reads and a weight load per non-zero hit.
+// Table layout: Bt[((g16[b] + slot / 16) * 256 + px) * 16 + slot % 16] -- per block and group of 16 list slots a [pixel][16] panel, what the projection's
+// A operand reads with one conflict-free LDS access per lane.
+constexpr int VP_WS = 64;                                   // window side: 16 + 2 * 24
+__global__ void __launch_bounds__(256) k_vp_build_b(const int *__restrict__ ent_blk, const int *__restrict__ ent_k, const int *__restrict__ ent_slot, const int *__restrict__ g16,
+                                                    BgGeom g, int R, const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
+                                                    const int *__restrict__ dr, const int *__restrict__ dc, const float *__restrict__ W, double *__restrict__ Bt) {
+    __shared__ float win[VP_WS * VP_WS];
+    const int b = ent_blk[blockIdx.x], k = ent_k[blockIdx.x], slot = ent_slot[blockIdx.x];
+    const int bi = b % g.nbr, bj = b / g.nbr;
+    const int wr0 = bi * 16 - R, wc0 = bj * 16 - R, ws = 16 + 2 * R;
+    for (int i = threadIdx.x; i < ws * ws; i += 256) win[i] = 0.f;
+    __syncthreads();
+    for (int64_t e = colptr[k] + threadIdx.x; e < colptr[k + 1]; e += 256) {
+        const int m = erow[e];
+        const int rw = m % g.nr + g.roff - wr0, cw = m / g.nr + g.coff - wc0;
+        if (rw >= 0 && rw < ws && cw >= 0 && cw < ws) win[cw * ws + rw] = aval[e];
+    }
+    __syncthreads();
+    const int px = threadIdx.x, rb = bi * 16 + (px & 15), cb = bj * 16 + (px >> 4);
+    double v = 0.0;
+    if (rb < g.nr_b && cb < g.nc_b) {
+        double acc = 0.0;
+        for (int i = 0; i < g.p; ++i) {
+            const int rm = rb - dr[i], cm = cb - dc[i];                     // the centre pixel whose i-th ring neighbour is this pixel
+            const float a = win[(cm - wc0) * ws + (rm - wr0)];
+            if (a != 0.f) acc += (double)W[(int64_t)i * g.d + (int64_t)(cm - g.coff) * g.nr + (rm - g.roff)] * (double)a;      // (a != 0: a patch pixel)
+        }
+        v = (double)win[(cb - wc0) * ws + (rb - wr0)] - acc;
+    }
+    Bt[(((int64_t)g16[b] + (slot >> 4)) * BLKPX + px) * 16 + (slot & 15)] = v;
+}
+
+// cst[k] = sum_m A(m,k) (Ymean(m) - b0(m)) in fp64, one workgroup per neuron, fixed association
+__global__ void __launch_bounds__(256) k_vp_const(const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval, BgGeom g,
+                                                  const double *__restrict__ ymean, const double *__restrict__ b0, double *__restrict__ cst) {
+    __shared__ double red[256];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int64_t e = colptr[k] + threadIdx.x; e < colptr[k + 1]; e += 256) {
+        const int m = erow[e];
+        const int64_t q = (int64_t)(m / g.nr + g.coff) * g.nr_b + (m % g.nr + g.roff);
+        s += (double)aval[e] * (ymean[q] - b0[m]);
+    }
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) cst[k] = red[0];
+}
+
+// The projection.  Workgroup = (block, frame segment), 4 waves; a wave takes chunk GROUPS of 16 chunks (64 frames) and contracts over the block's 256 pixels:
+//   v_mfma_f64_16x16x4:  A operand [M = list slot (lane & 15)][K = pixel (lane >> 4)]  <- the B panel in LDS
+//                        B operand [K = pixel (lane >> 4)][N = chunk s + (lane & 15)]   <- lane loads the float4 of ITS pixel and chunk: component j feeds MFMA j,
+//                                                                                         whose column n is frame 4 (s + n) + j
+//   64 steps of 4 pixels; a wave load moves 16 chunks x 4 consecutive pixels x 16 B (64-byte runs, every byte used).
+// D: lane holds rows (lane >> 4) + 4 r = list slots, column lane & 15 = its chunk: the four components are four consecutive frames -> one 32-byte store per
+// (slot, chunk) into the partial buffer part[(l0 + slot) * ldp + 4 chunk ..].
+template <int NT>
+__global__ void __launch_bounds__(256) k_vp_proj_b(const float4 *__restrict__ Y4, BgGeom g, int64_t Tc, const int *__restrict__ blk_list, const int *__restrict__ lst_ptr,
+                                                   const int *__restrict__ g16, const double *__restrict__ Bt, int nseg, double *__restrict__ part, int64_t ldp) {
+    extern __shared__ __attribute__((aligned(16))) double Bl[];        // [NT][256][16]
+    const int blk = blk_list[blockIdx.x / nseg], seg = blockIdx.x % nseg;
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(Bt + (int64_t)g16[blk] * BLKPX * 16);
+        double2 *dst = reinterpret_cast<double2 *>(Bl);
+        for (int i = threadIdx.x; i < NT * BLKPX * 8; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+    const int bi = blk % g.nbr, bj = blk / g.nbr;
+    // pixel of step st for this lane: px = 4 st + kq -> row (px & 15), column (px >> 4) of the block; clamped at the region's edge (B is 0 there)
+    const int rb0 = bi * 16, cb0 = bj * 16;
+    const int64_t ncg = (Tc + 15) >> 4;
+    const int64_t cgs = (ncg + nseg - 1) / nseg, cg0 = seg * cgs, cg1 = cg0 + cgs < ncg ? cg0 + cgs : ncg;
+    for (int64_t cg = cg0 + wave; cg < cg1; cg += 4) {
+        const int64_t cl = cg * 16 + n, clc = cl < Tc ? cl : Tc - 1;
+        const float4 *yb = Y4 + clc * g.d_b;
+        double4_t acc[4][NT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[j][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        auto qof = [&](int st) -> int64_t {
+            const int px = 4 * st + kq;
+            int rb = rb0 + (px & 15), cb = cb0 + (px >> 4);
+            rb = rb < g.nr_b ? rb : g.nr_b - 1; cb = cb < g.nc_b ? cb : g.nc_b - 1;
+            return (int64_t)cb * g.nr_b + rb;
+        };
+        constexpr int AH = 8;                              // loads in flight per lane
+        float4 y[AH];
+#pragma unroll
+        for (int u = 0; u < AH; ++u) y[u] = yb[qof(u)];
+#pragma unroll 1
+        for (int st0 = 0; st0 < 64; st0 += AH) {
+            // the NEXT eight steps' loads go out before this iteration's MFMAs (the compiler sinks them behind the MFMAs otherwise: no prefetch distance at all);
+            // the last iteration repeats step 63 -- no branch in the loop
+            float4 yn[AH];
+#pragma unroll
+            for (int u = 0; u < AH; ++u) yn[u] = yb[qof(st0 + AH + u < 64 ? st0 + AH + u : 63)];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < AH; ++u) {
+                const int px = 4 * (st0 + u) + kq;
+                const double b0 = (double)y[u].x, b1 = (double)y[u].y, b2 = (double)y[u].z, b3 = (double)y[u].w;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double a = Bl[(t * BLKPX + px) * 16 + n];
+                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[1][t], 0, 0, 0);
+                    acc[2][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[2][t], 0, 0, 0);
+                    acc[3][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[3][t], 0, 0, 0);
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < AH; ++u) y[u] = yn[u];
+        }
+        if (cl < Tc) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = t * 16 + kq + 4 * r;
+                    if (slot < nl) {
+                        double *o = part + (int64_t)(l0 + slot) * ldp + 4 * cl;
+                        *reinterpret_cast<double2 *>(o) = make_double2(acc[0][t][r], acc[1][t][r]);
+                        *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2][t][r], acc[3][t][r]);
+                    }
+                }
+        }
+    }
+}
+
+// U(k, t) = float(cst[k] + sum over the (block, k) entries of k, in ascending block order, of their partial sums); 0 past T
+__global__ void __launch_bounds__(256) k_vp_reduce(const double *__restrict__ part, int64_t ldp, const int *__restrict__ nptr, const int *__restrict__ nent,
+                                                   const double *__restrict__ cst, int64_t T, float *__restrict__ U, int64_t ldu) {
+    const int k = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ldu) return;
+    double s = cst[k];
+    for (int i = nptr[k]; i < nptr[k + 1]; ++i) s += part[(int64_t)nent[i] * ldp + t];
+    U[(int64_t)k * ldu + t] = t < T ? (float)s : 0.f;
+}
+
+int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                   const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu) {
+    HostTrace ht(ctx, "vproj_temporal");
+    const BgGeom g = vp_geom(P);
+    const int nblk = g.nbr * g.nbc, R = g.p_radius;
+    if (16 + 2 * R > VP_WS) return 1;
+    (void)A_val;
+    // the blocks B(:, k) meets: the footprint grown by the ring
+    std::vector<int> lo(g.nbc, 0), hi(g.nbc, -1), need_ptr((size_t)K + 1, 0), need;
+    need.reserve((size_t)K * 16);
+    for (int32_t k = 0; k < K; ++k) {
+        reach_blocks(P, g, R, A_rowidx, A_colptr[k], A_colptr[k + 1], lo, hi, need);
+        need_ptr[k + 1] = (int)need.size();
+    }
+    const int64_t nent = (int64_t)need.size();
+    std::vector<int> cnt((size_t)nblk + 1, 0);
+    for (int b : need) ++cnt[b + 1];
+    std::vector<int> lst_ptr((size_t)nblk + 1, 0), g16((size_t)nblk + 1, 0);
+    for (int b = 0; b < nblk; ++b) {
+        if (cnt[b + 1] > WIN_NLB) return 1;                // more than 64 neurons over one block: the sweep serves this update
+        lst_ptr[b + 1] = lst_ptr[b] + cnt[b + 1];
+        g16[b + 1] = g16[b] + ((cnt[b + 1] + 15) >> 4);
+    }
+    const int64_t ldp = ldu;                               // partial sums: one row of ldu doubles per entry
+    if (nent * ldp * 8 > (int64_t(24) << 30)) return 1;    // (a partial buffer beyond 24 GB: not what this path is for)
+    // entries in (block, slot) order; per neuron its entries in ascending block order (the order of the final sum)
+    std::vector<int> ent_blk((size_t)nent), ent_k((size_t)nent), ent_slot((size_t)nent), fill((size_t)nblk, 0), kent((size_t)nent), blk_nt[4], blall;
+    for (int32_t k = 0; k < K; ++k)
+        for (int i = need_ptr[k]; i < need_ptr[k + 1]; ++i) {
+            const int b = need[i], s_ = fill[b]++, e = lst_ptr[b] + s_;
+            ent_blk[e] = b; ent_k[e] = k; ent_slot[e] = s_; kent[i] = e;
+        }
+    for (int32_t k = 0; k < K; ++k) std::sort(kent.begin() + need_ptr[k], kent.begin() + need_ptr[k + 1]);     // (entry index ascends with the block)
+    for (int b = 0; b < nblk; ++b) { const int n = lst_ptr[b + 1] - lst_ptr[b]; if (n) blk_nt[(n - 1) >> 4].push_back(b); }
+    ht.mark("lists");
+    DevBuf *V = ctx->vp;
+    DevBuf &dEb = V[1], &dEk = V[2], &dEs = V[3], &dG16 = V[4], &dLp = V[5], &dBt = V[6], &dCst = V[7], &dPart = V[8], &dNptr = V[9], &dNent = V[10], &dBl = V[11];
+    RET(to_dev(ctx, dEb, ent_blk.data(), ent_blk.size())); RET(to_dev(ctx, dEk, ent_k.data(), ent_k.size())); RET(to_dev(ctx, dEs, ent_slot.data(), ent_slot.size()));
+    RET(to_dev(ctx, dG16, g16.data(), g16.size())); RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
+    RET(to_dev(ctx, dNptr, need_ptr.data(), need_ptr.size())); RET(to_dev(ctx, dNent, kent.data(), kent.size()));
+    for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());
+    RET(to_dev(ctx, dBl, blall.data(), blall.size()));
+    const size_t bt_bytes = (size_t)std::max(1, g16[nblk]) * BLKPX * 16 * sizeof(double);
+    RET(dBt.ensure_hw(bt_bytes, ctx->hw_vp[6]));
+    RET(dCst.ensure_hw((size_t)K * sizeof(double), ctx->hw_vp[7]));
+    RET(dPart.ensure_hw((size_t)std::max<int64_t>(1, nent) * ldp * sizeof(double), ctx->hw_vp[8]));
+    CK(hipMemsetAsync(dBt.p, 0, bt_bytes, ctx->st()));      // (the padding slots of a group must be 0)
+    if (nent > 0)
+        LAUNCH(ctx, "temporal_build_B", k_vp_build_b, dim3((unsigned)nent), dim3(256), 0, dEb.as<int>(), dEk.as<int>(), dEs.as<int>(), dG16.as<int>(), g, R, dColptr, dErow, dAval,
+               P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->W.as<float>(), dBt.as<double>());
+    LAUNCH(ctx, "temporal_const", k_vp_const, dim3((unsigned)K), dim3(256), 0, dColptr, dErow, dAval, g, P->ymean_d.as<double>(), P->b0.as<double>(), dCst.as<double>());
+    int off = 0;
+    for (int t = 3; t >= 0; --t) {
+        const int nb_ = (int)blk_nt[t].size();
+        if (!nb_) continue;
+        const int total = (int)blall.size();
+        // frame segments: enough workgroups to fill the chip a few times over, each at least a few chunk groups per wave
+        const int64_t ncg = ((P->Tc + 15) >> 4);
+        int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((ncg + 7) / 8, (2048 + total - 1) / std::max(1, total)));
+        const size_t shmem = (size_t)(t + 1) * BLKPX * 16 * sizeof(double);
+#define VP_GO(NT_) do { if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+            LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->Yc4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \
+                   dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); } while (0)
+        if (t == 0) VP_GO(1); else if (t == 1) VP_GO(2); else if (t == 2) VP_GO(3); else VP_GO(4);
+#undef VP_GO
+        off += nb_;
+    }
+    LAUNCH(ctx, "temporal_reduce_B", k_vp_reduce, dim3((unsigned)((ldu + 255) / 256), (unsigned)K), dim3(256), 0, dPart.as<double>(), ldp, dNptr.as<int>(), dNent.as<int>(),
+           dCst.as<double>(), P->T, dU, ldu);
+    ht.mark("launches");
+    return 0;
+}
+
+}  // namespace cnmfe

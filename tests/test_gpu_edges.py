@@ -780,6 +780,7 @@ def test_deferred_footprint_term_through_update_spatial(eng, dims):
     eng.fit_ring_model(0, A, Cm)
     prev = np.array([0, 3, 4])                                  # the "halo neurons" of the term
     IND = sp.csc_matrix((A.toarray() > 0) | (np.roll(A.toarray(), 1, axis=0) > 0)).astype(np.float32)
+    eng.set_option("r1_virtual", 0)                             # (this test is about the SWEPT residual's deferred term; the sweep-free path: test_gpu_virtual.py)
     def run(defer, alg):
         eng.set_option("r1_defer", defer)
         eng.set_b0(0, eng.b0(0))                                # invalidates the resident Ysig: the next residual is a sweep
@@ -807,7 +808,7 @@ def test_deferred_footprint_term_through_update_spatial(eng, dims):
             assert np.allclose(sn0, sn1, rtol=1e-5)
             assert np.abs(y0 - y1).max() <= 2e-6 * np.abs(y0).max()
     finally:
-        eng.set_option("r1_defer", 1)
+        eng.set_option("r1_defer", 1); eng.set_option("r1_virtual", 1)
 
 
 def test_two_frame_strides_keep_their_tables(eng):
