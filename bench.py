@@ -326,6 +326,25 @@ def main():
     for _ in range(XSTEPS):                                     # (every rank: the steps hold the collectives)
         step()
     fence()
+    # The iteration no longer runs the ring sweep (sweep-free residual): the kernel the north star names is timed on its own, in this
+    # run, on this video -- a few separate launches per owned patch with the engine switched to the swept residual, HIP events on the engine's stream.
+    r1_sep = None
+    if a.bg_ssub == 1 and os.environ.get("CNMFE_BENCH_R1", "1") != "0":
+        before = {k: dict(v) for k, v in eng.profile_table().items()}
+        eng.set_option("r1_virtual", 0); eng.set_option("r1_delta", 0)
+        NR1 = 5 if len(video.owned) == 1 else 1
+        for idx in video.owned:
+            for _ in range(NR1 + 1):                            # (+1: the first launch also allocates the Ysig buffer)
+                eng.residual(video.pid[idx], None, None)
+        eng.synchronize()
+        eng.set_option("r1_virtual", 1); eng.set_option("r1_delta", 1)
+        after = eng.profile_table()
+        r1_sep = {}
+        for k, v in after.items():
+            if k.startswith("residual_r1"):
+                c0 = before.get(k, {"calls": 0, "total_ms": 0.0})
+                if v["calls"] > c0["calls"]:
+                    r1_sep[k] = {"calls": v["calls"] - c0["calls"], "total_ms": v["total_ms"] - c0["total_ms"]}
     if world > 1:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -335,8 +354,16 @@ def main():
         return
     n_patches = video.nr_patch * video.nc_patch
     value = (n_patches if a.weak else 1) * a.steps / dt          # whole-FOV iterations/s (weak mode: patch-iterations/s, every patch a full 512 x 512 FOV)
+    tab_x = eng.profile_table()
+    if r1_sep:                                                  # the separate sweep launches are not part of the extra steps
+        for k, v in r1_sep.items():
+            tab_x[k] = {"calls": tab_x[k]["calls"] - v["calls"], "total_ms": tab_x[k]["total_ms"] - v["total_ms"]}
     kern = {k: {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / float(XSTEPS),
-                "ms_per_step": v["total_ms"] / XSTEPS, "from": "extra steps"} for k, v in eng.profile_table().items() if v["calls"]}
+                "ms_per_step": v["total_ms"] / XSTEPS, "from": "extra steps"} for k, v in tab_x.items() if v["calls"] > 0}
+    r1_kern = None
+    if r1_sep:
+        n_ = sum(v["calls"] for v in r1_sep.values()); ms_ = sum(v["total_ms"] for v in r1_sep.values())
+        r1_kern = {"ms_per_call": ms_ / n_, "calls": n_, "from": "separate launches of the ring sweep after the timed region (the iteration itself runs none)"}
     for k, v in tab_timed.items():                              # the roofline kernels: measured inside the timed region
         if v["calls"]:
             kern[k] = {"ms_per_call": v["total_ms"] / v["calls"], "calls_per_step": v["calls"] / float(a.steps), "ms_per_step": v["total_ms"] / a.steps, "from": "timed region"}
@@ -348,13 +375,15 @@ def main():
     d, d_b, p = sum(P.values()) / float(len(P)), sum(B.values()) / float(len(B)), 96 if r == 15 else None
     roof = None
     def r1_roof():
-        if "residual_r1" not in kern or a.bg_ssub != 1:         # bg_ssub > 1: the sweep runs on the low-resolution patch, a different kernel mix
+        src = kern.get("residual_r1") or r1_kern                # inside the iteration (r1_virtual = 0) or, by default, the separate launches
+        if src is None or a.bg_ssub != 1 or p is None:          # bg_ssub > 1: the sweep runs on the low-resolution patch, a different kernel mix
             return None
         bytes_r1 = 4.0 * d_b * T + 4.0 * d * T + 8.0 * d * p + 4.0 * (Kp if not sharded_fov else Kp * d_b / float(d1 * d2)) * T       # read Y + write Ysig + W + C
-        ms = kern["residual_r1"]["ms_per_call"]
+        ms = src["ms_per_call"]
         return {"bound": "hbm", "achieved": bytes_r1 / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_r1 / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "residual_r1", "ms_per_launch": ms,
-                "algorithmic_bytes_per_launch": bytes_r1}
+                "algorithmic_bytes_per_launch": bytes_r1, "timed": src["from"],
+                "in_iteration": "residual_r1" in kern}
     def proj_roofs():
         """the two projection kernels (north_star's "residual projections"): S1 U = Ysig*C' on the search mask (HALS_spatial.m:27-32) and T1
         U = A'*Ysig (HALS_temporal.m:48).  Algorithmic bytes = the rows of Ysig a launch needs, once (pixels under the mask / under a footprint,
@@ -369,6 +398,14 @@ def main():
             nnz = {"spatial_proj_U": int(IND.nnz), "temporal_proj_U": int(Acsc.nnz)}
         except Exception:
             return None
+        # the sweep-free formulation's video passes: the temporal projection through B = A - W'A (one read of the centred block video + the K x T result;
+        # its fp64 partial sums per (16x16 block, neuron) are traffic, not algorithmic bytes) and the fit's window projection P = Yc Cc' (one read + the traces)
+        for name in ("temporal_proj_B", "bg_win_proj"):
+            if name in kern:
+                by = 4.0 * d_b * T + 4.0 * K * T
+                ms = kern[name]["ms_per_step"]                  # (one projection per iteration, possibly split into launches by list length)
+                out[name] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": name, "ms_per_update": ms, "algorithmic_bytes_per_update": by}
         for name in ("spatial_proj_U", "temporal_proj_U"):
             if name not in kern:
                 continue
@@ -501,6 +538,10 @@ def main():
                                ("%s (weak): %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
                                 "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub)),
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
+                   "formulation": ("sweep-free residual (option r1_virtual = 1, the default): the spatial update reads Ysig*C' = P - W*P out of the fit's table "
+                                   "P = Yc*Cc', the temporal update projects the centred video through B = A - W'*A; same values as the swept residual "
+                                   "(tests/test_gpu_virtual.py); the ring sweep itself is timed separately for `roofline_r1`")
+                                  if os.environ.get("CNMFE_OPTS", "").find("r1_virtual=0") < 0 else "swept residual (r1_virtual = 0): one ring sweep per iteration",
                    "parallelism": ("patches round-robin over %d rank(s)" % world) if not shard_of else
                                   ("rank 0 of %d: this rank's %d of the %d patches on ONE GPU, no collectives (a per-rank load figure, not a scaling point); "
                                    "the video is uploaded as fp16 and widened on the device" % (shard_of, len(video.owned), len(video.order))),

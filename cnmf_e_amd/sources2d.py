@@ -720,6 +720,33 @@ class Sources2D:
     def b0_new(self, val):
         self._b0_new_val, self._b0_new_src = val, None
 
+    def set_components(self, A, C, C_raw=None):
+        """Replace obj.A, obj.C (and obj.C_raw) between two update calls -- what the reference's merge / delete methods do to the handle object between
+        the calls of demo_large_data_1p.m:203-209 (merge_neurons_dist_corr, merge_high_corr, remove_false_positives: not on this engine's path).  K may
+        change; obj.A_prev / obj.C_prev stay what the last background update left (the reference's methods do not touch them either), so the next
+        residual still subtracts the neurons the background was fitted against.  The new trace matrix is bound on the engine."""
+        A = sp.csc_matrix(A, dtype=np.float32)
+        C = np.ascontiguousarray(C, dtype=np.float32)
+        if A.shape[0] != self.video.d1 * self.video.d2 or A.shape[1] != C.shape[0] or C.shape[1] != self.video.T:
+            raise ValueError("A is %s, C is %s; expected (%d, K) and (K, %d)" % (A.shape, C.shape, self.video.d1 * self.video.d2, self.video.T))
+        self.A, self.C = A, C
+        self.C_raw = C if C_raw is None else np.ascontiguousarray(C_raw, dtype=np.float32)
+        self._bind_C()
+        self._update_b0_new()
+
+    def delete(self, ind):
+        """obj.delete(ind)  (@Sources2D/Sources2D.m:762-811): columns of A, rows of C / C_raw / S and of P.kernel_pars go; A_prev, C_prev stay"""
+        ind = np.atleast_1d(np.asarray(ind, dtype=np.int64))
+        if ind.size == 0:
+            return                                                                # :764-766
+        keep = np.setdiff1d(np.arange(self.A.shape[1]), ind)
+        C_raw = np.asarray(self.C_raw)[keep] if self.C_raw is not None and np.asarray(self.C_raw).shape[0] == self.A.shape[1] else None
+        if getattr(self, "S", None) is not None and np.asarray(self.S).shape[0] == self.A.shape[1]:
+            self.S = np.asarray(self.S)[keep]                                     # :801-803
+        if self.P.get("kernel_pars") is not None and len(self.P["kernel_pars"]) == self.A.shape[1]:
+            self.P["kernel_pars"] = np.asarray(self.P["kernel_pars"])[keep]       # :807-809
+        self.set_components(sp.csc_matrix(self.A)[:, keep], np.asarray(self.C)[keep], C_raw)   # :799-806
+
     def deconvTemporal(self):
         """@Sources2D/deconvTemporal.m:29-105: deconvolve every row of C_raw again (fresh time constants); sets
         C, C_raw, S, P.kernel_pars, P.neuron_sn.  Rows are sharded over ranks and all-reduced when distributed."""

@@ -233,6 +233,8 @@ def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projectio
     """
     Y = np.asarray(Y)
     d_b, T = Y.shape
+    if only_rows is not None and np.isnan(thresh_outlier) and d_b * T > (1 << 28):
+        return _fit_ring_model_rows(Y, A, C, W_old, ind_patch, with_projection, only_rows)
     if A is None or A.shape[1] == 0:
         A = np.ones((d_b, 1)); C = np.zeros((1, T))          # :15-17 (isempty(A))
     if sp.issparse(A):
@@ -308,6 +310,64 @@ def fit_ring_model(Y, A, C, W_old, thresh_outlier, sn, ind_patch, with_projectio
     return W, b0
 
 
+def _fit_ring_model_rows(Y, A, C, W_old, ind_patch, with_projection, only_rows):
+    """TEST HARNESS ONLY (not in the reference): fit_ring_model's regressions (:92-108) for a SAMPLE of patch pixels of a block too large to form the dense
+    d_b x T float64 matrices of :42-47 for (512 x 512 x 10000: two of 21 GB and a 1.3 TFLOP dense A*C).  The same statements as above, evaluated on the pixels
+    the sampled regressions read -- the sampled pixels and their ring neighbours -- with A kept sparse; Ymean and b0 (:42-44) for every pixel.  thresh_outlier
+    = NaN only (what every demo runs)."""
+    d_b, T = Y.shape
+    a_empty = A is None or A.shape[1] == 0
+    if a_empty:
+        A = sp.csr_matrix(np.ones((d_b, 1))); C = np.zeros((1, T))          # :15-17
+    A = sp.csr_matrix(A, dtype=np.float64)
+    C = np.asarray(C, dtype=np.float64)
+    W_old = sp.csr_matrix(W_old); W_old.sort_indices()
+    row0 = W_old.getrow(0)
+    vals = set(np.unique(row0.data).tolist())
+    if row0.nnz < W_old.shape[1]:
+        vals.add(0.0)
+    if len(vals) == 2:
+        ind_active = np.ones(W_old.shape[0], dtype=bool)     # :26
+    else:
+        ind_active = np.asarray(abs(W_old) @ np.asarray(A.sum(axis=1)).ravel()).ravel() > 0     # :28
+    if ind_patch is None:
+        ind_patch = np.ones(d_b, dtype=bool)
+    ind_patch = np.asarray(ind_patch, dtype=bool).ravel()
+    Ymean = np.mean(Y, axis=1, dtype=np.float64)             # :42
+    Cmean = C.mean(axis=1)                                   # :43
+    b0 = Ymean[ind_patch] - np.asarray(A[ind_patch] @ Cmean).ravel()        # :44
+    Cc = C - Cmean[:, None]                                  # :46
+    pmax = int(np.max(np.asarray((W_old > 0).sum(axis=1)).ravel()))          # :60
+    nmax = pmax * 100                                        # :61
+    ind_pixels = np.nonzero(ind_patch)[0]                    # :71
+    indptr, indices, data = W_old.indptr, W_old.indices, W_old.data
+    rows = [m for m in only_rows if ind_active[m]]
+    rings = {}
+    for m in rows:
+        sl = slice(indptr[m], indptr[m + 1])
+        rings[m] = indices[sl][data[sl] != 0]                # :99
+    need = np.unique(np.concatenate([ind_pixels[np.asarray(rows, dtype=np.int64)]] + [rings[m] for m in rows])) if rows else np.zeros(0, dtype=np.int64)
+    pos_of = {int(q): i for i, q in enumerate(need)}
+    Bf = (np.asarray(Y[need], dtype=np.float64) - Ymean[need, None]) - np.asarray(A[need] @ Cc)     # :45-47 on the needed pixels
+    if with_projection:
+        nk = min(int(_matlab_round(T / 1)), nmax)            # :84
+        k = T // nk                                          # :85
+        if k != 1:
+            Bf = Bf[:, ::k]                                  # :87
+    vec_ones = np.ones((1, Bf.shape[1]))
+    new_data = data.copy()
+    for m in rows:                                           # :92
+        sl = slice(indptr[m], indptr[m + 1])
+        nzmask = data[sl] != 0
+        y = Bf[pos_of[int(ind_pixels[m])], :]
+        X = np.vstack([Bf[[pos_of[int(q)] for q in rings[m]], :], vec_ones])             # :101
+        XX = X @ X.T                                         # :103
+        Xy = X @ y                                           # :104
+        w = np.linalg.solve(XX + np.eye(XX.shape[0]) * np.trace(XX) * 1e-5, Xy)          # :106
+        new_data[np.nonzero(nzmask)[0] + indptr[m]] = w[:-1] + 1e-100                   # :107
+    return sp.csr_matrix((new_data, indices.copy(), indptr.copy()), shape=W_old.shape), b0
+
+
 def matlab_quantile(x, p):
     """quantile(x, p) of the Statistics Toolbox for a vector (a MathWorks function, not in the repository; restated from its documented
     definition: the sorted values are the 0.5/n, 1.5/n, ..., (n-0.5)/n quantiles, linear interpolation between them, the minimum /
@@ -341,6 +401,21 @@ def residual_ysig(Y_block, A_prev, C_prev, W, b0, ind_patch, only_rows=None):
     @Sources2D/update_spatial_parallel.m:162-166 (= update_temporal_parallel.m:149-152).
     only_rows (test harness only): just these patch pixels' rows of the result (rows of the expression are independent).
     """
+    if only_rows is not None and np.asarray(Y_block).size > (1 << 28):
+        # TEST HARNESS ONLY: the same expression for sampled rows of a block too large for the dense d_b x T float64 copies -- evaluated on the block pixels
+        # the sampled rows of W read (the rows of the expression are independent, a row needs its own pixel and its ring neighbours)
+        rows = np.asarray(only_rows)
+        ipx = np.nonzero(np.asarray(ind_patch, dtype=bool).ravel())[0]
+        Wr = sp.csr_matrix(W)[rows]
+        need = np.unique(np.concatenate([Wr.indices, ipx[rows]]))
+        pos = np.full(np.asarray(Y_block).shape[0], -1, dtype=np.int64); pos[need] = np.arange(need.size)
+        tmp = np.asarray(Y_block[need], dtype=np.float64)
+        Yrows = tmp[pos[ipx[rows]]].copy()
+        if A_prev is not None and A_prev.shape[1] > 0:
+            tmp = tmp - np.asarray(sp.csr_matrix(A_prev)[need] @ np.asarray(C_prev, dtype=np.float64))       # :163
+        Wn = sp.csr_matrix((Wr.data, pos[Wr.indices], Wr.indptr), shape=(rows.size, need.size))
+        b0r = np.asarray(b0, dtype=np.float64).ravel()[rows]
+        return (Yrows - Wn @ tmp) - (b0r - Wn @ tmp.mean(axis=1))[:, None]                                   # :166
     Yb = np.asarray(Y_block, dtype=np.float64)
     if A_prev is not None and A_prev.shape[1] > 0:
         tmp_Y = Yb - (A_prev @ np.asarray(C_prev, dtype=np.float64))         # :163

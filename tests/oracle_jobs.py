@@ -31,6 +31,10 @@ JOBS = {
     "m64_outlier": dict(d1=64, d2=64, T=3000, K=8, r=4, seed=13, alg="hals", thresh_outlier=3.0, iters=1),
     "m64_outlier_all": dict(d1=64, d2=64, T=1200, K=8, r=7, seed=14, alg="hals", thresh_outlier=2.5, iters=1),
     "m64_outlier_ssub2": dict(d1=64, d2=64, T=3000, K=8, r=8, seed=15, alg="hals", bg_ssub=2, thresh_outlier=3.0, iters=2),
+    # the shipped demo's parameter set as ONE trajectory (demos/demo_large_data_1p.m:16-55,142-201): ring_radius = 18 with bg_ssub = 2 (a low-resolution ring of
+    # radius 9), spatial_algorithm = 'hals_thresh' on the P.sn that update_sn = true just re-estimated, deconv_flag = true, two temporal updates, then the
+    # switch to 'nnls' and a second background / spatial / temporal round
+    "m96_demo": dict(d1=96, d2=96, T=1500, K=16, r=18, seed=11, alg="hals_thresh", bg_ssub=2, deconv=True, demo=True, iters=2),
     # BASELINE configs[1] (C2: 256 x 256 x 3000, K = 200, seed 1): a 64 x 64 window of the same video
     "c2_crop64": dict(d1=256, d2=256, T=3000, K=200, r=15, seed=1, alg="hals", crop=(96, 96, 64), iters=2),
 }
@@ -73,6 +77,8 @@ def trajectory(name):
                             bg_ssub=cfg.get("bg_ssub", 1), deconv_options={} if cfg.get("deconv") else None,
                             thresh_outlier=cfg.get("thresh_outlier", np.nan))
     out = {}
+    if cfg.get("demo"):
+        return demo_sequence(o, out, oracle=True)
     first = o._patches()[0]
     p0 = o.patch_pos[first]
     rows = sample_rows(cfg, int((p0[1] - p0[0] + 1) * (p0[3] - p0[2] + 1)))
@@ -93,6 +99,38 @@ def trajectory(name):
         out["b0new_t_%d" % it] = np.asarray(o.b0_new).copy()
         if cfg.get("deconv"):
             out["S_%d" % it] = o.S.copy(); out["kp_%d" % it] = np.asarray(o.kernel_pars, dtype=np.float64)
+    return out
+
+
+def demo_sequence(o, out, oracle):
+    """demos/demo_large_data_1p.m:142,161-182,189,199-201 on either side (the oracle's OracleSources2D or the engine's Sources2D -- the same method names):
+    background; spatial with update_sn; temporal x 2; spatial_algorithm = 'nnls'; background; spatial; temporal.  Records what the test compares."""
+    def snap(tag, what):
+        for w in what:
+            if w == "W":
+                if oracle:
+                    Wc = sp.csr_matrix(o.W[(0, 0)]); Wc.sort_indices(); out["W_" + tag] = Wc.data.copy(); out["b0_" + tag] = np.asarray(o.b0[(0, 0)]).copy()
+                else:
+                    out["W_" + tag] = o.get_W((0, 0)).data.copy(); out["b0_" + tag] = o.get_b0((0, 0)).copy()
+            elif w == "A":
+                out["A_raw_" + tag] = sp.csc_matrix(o.A_raw).copy(); out["A_" + tag] = sp.csc_matrix(o.A).copy()
+            elif w == "sn":
+                out["sn_" + tag] = np.asarray(o.sn if oracle else o.P["sn"], dtype=np.float64).reshape(-1, order="F").copy()
+            elif w == "C":
+                out["C_" + tag] = np.asarray(o.C).copy(); out["C_raw_" + tag] = np.asarray(o.C_raw).copy(); out["S_" + tag] = np.asarray(o.S).copy()
+                out["kp_" + tag] = np.asarray(o.kernel_pars if oracle else o.P["kernel_pars"], dtype=np.float64).copy()
+    o.update_background_parallel(); snap("bg0", ["W"])                            # :142
+    out["C_before_spatial_0"] = np.asarray(o.C).copy()
+    o.update_spatial_parallel(update_sn=True); snap("sp0", ["A", "sn"])           # :161-163
+    o.update_temporal_parallel(); snap("t0a", ["C"])                              # :172 (m = 1)
+    o.update_temporal_parallel(); snap("t0b", ["C"])                              # :172 (m = 2)
+    if oracle:
+        o.spatial_algorithm = "nnls"                                              # :182
+    else:
+        o.options.spatial_algorithm = "nnls"
+    o.update_background_parallel(); snap("bg1", ["W"])                            # :199
+    o.update_spatial_parallel(); snap("sp1", ["A"])                               # :200
+    o.update_temporal_parallel(); snap("t1", ["C"])                               # :201
     return out
 
 

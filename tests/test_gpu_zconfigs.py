@@ -135,6 +135,51 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
         assert e <= (0.1 if outl else 1e-4), (name, it, e)
 
 
+def test_demo_defaults_sequence_against_oracle(eng, oracle_jobs, observed):
+    """The shipped demo's own parameter set as ONE trajectory (demos/demo_large_data_1p.m:16-55,142-201): ring_radius = 18, bg_ssub = 2 (low-resolution
+    ring of radius 9), spatial_algorithm = 'hals_thresh' thresholding against the P.sn that update_sn = true re-estimated in the same call, deconv_flag = true,
+    two temporal updates in a row, the switch to 'nnls' and a second background / spatial / temporal round -- every stage against the float64 oracle."""
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    name = "m96_demo"
+    cfg = oj.JOBS[name]
+    Y, A, C, sn, d1, d2 = oj.make_inputs(cfg)
+    T, r = cfg["T"], cfg["r"]
+    video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals_thresh", maxIter=5, bg_ssub=2, deconv_flag=True), A, C, sn)
+    got = oj.demo_sequence(s, {}, oracle=False)
+    ref = oracle_jobs[name].result(timeout=900)
+    obs = observed.setdefault(name, {})
+    for tag in ("bg0", "bg1"):
+        e = rel(got["W_" + tag], ref["W_" + tag]); obs["W_" + tag] = e
+        eb = float(np.abs(got["b0_" + tag] - ref["b0_" + tag]).max()); obs["b0_" + tag] = eb
+        assert e <= 2e-6 and eb <= 5e-4, (tag, e, eb)
+    e = rel(got["sn_sp0"], ref["sn_sp0"]); obs["sn_sp0"] = e
+    assert e <= 2e-6, e                                                   # GetSn of every pixel of Ysig (update_spatial_parallel.m:191-194)
+    Cb = ref["C_before_spatial_0"]
+    cc = (Cb * Cb).sum(axis=1) - Cb.shape[1] * Cb.mean(axis=1) ** 2
+    thr = ref["sn_sp0"][:, None] * (3.0 / np.sqrt(cc))[None, :]           # HALS_spatial_thresh.m:50-51 with the NEW sn
+    n_m, n_off, e, nnz = _support_report(got["A_raw_sp0"], ref["A_raw_sp0"], thr)
+    obs["A_raw_sp0"] = dict(mismatch=n_m, off_threshold=n_off, rel=e, nnz=nnz)
+    assert n_off == 0 and n_m <= 2 and e <= 1e-6, (n_m, n_off, e)
+    for tag in ("sp0", "sp1"):
+        n_m, n_off, e, nnz = _support_report(got["A_" + tag], ref["A_" + tag])
+        obs["A_" + tag] = dict(mismatch=n_m, rel=e, nnz=nnz)
+        assert n_m == 0 and e <= 1e-6, (tag, n_m, e)
+    n_m, n_off, e, nnz = _support_report(got["A_raw_sp1"], ref["A_raw_sp1"])
+    obs["A_raw_sp1"] = dict(mismatch=n_m, off_threshold=n_off, rel=e, nnz=nnz)
+    assert n_off == 0 and e <= 1e-6, (n_m, n_off, e)
+    for tag in ("t0a", "t0b", "t1"):
+        K = ref["C_" + tag].shape[0]
+        er = [rel(got["C_raw_" + tag][j], ref["C_raw_" + tag][j]) for j in range(K) if np.abs(ref["C_raw_" + tag][j]).max() > 0]
+        ec = [rel(got["C_" + tag][j], ref["C_" + tag][j]) for j in range(K) if np.abs(ref["C_" + tag][j]).max() > 0]
+        ns = [(int((got["S_" + tag][j] > 0).sum()), int((ref["S_" + tag][j] > 0).sum())) for j in range(K)]
+        kp = float(np.abs(got["kp_" + tag] - ref["kp_" + tag]).max())
+        obs["C_" + tag] = dict(raw_max=max(er), max=max(ec), kp=kp, spikes=(sum(a for a, _ in ns), sum(b for _, b in ns)))
+        assert max(er) <= 5e-6 and max(ec) <= 5e-6 and kp <= 2e-6, (tag, max(er), max(ec), kp)
+        assert all(abs(a - b) <= 1 for a, b in ns), (tag, ns)
+
+
 # ======================================================================================================================================
 # BASELINE configurations at FULL size.  The float64 oracle cannot run them whole (hours), but every stage is a set of independent
 # per-pixel or per-patch problems, so it is run on SAMPLES: rows of W (the per-pixel regressions), rows of the background-subtracted
@@ -161,7 +206,10 @@ class BigCase:
             torch.cuda.synchronize()
             eng.upload_block_device(v.pid[idx], Yd.data_ptr(), T, dtype=_lib.F16 if upload_dtype == "f16" else _lib.F32)
             if idx in sample_patches:
-                self.Yb[idx] = Yd.float().cpu().numpy().T.copy()                      # d_b x T float32, exactly what the engine holds
+                Yh = Yd.float().cpu().numpy()                                         # T x d_b float32, exactly what the engine holds
+                # d_b x T: a copy at the block sizes the oracle's functions densify anyway; at 512 x 512 x 10000 (10.5 GB) a transposed VIEW -- the oracle's
+                # sampled-row harness paths only gather the pixels they need from it
+                self.Yb[idx] = Yh.T.copy() if Yh.size <= (1 << 28) else Yh.T
             del Yd
         torch.cuda.empty_cache()
         self.s = Sources2D(v, Options(ring_radius=r, maxIter=5, **opts), f.A_init, f.C_init, f.sn)
@@ -222,6 +270,36 @@ class BigCase:
         assert np.array_equal(got != 0, ref != 0), (tag, int(((got != 0) != (ref != 0)).sum()))
         e = rel(got, ref); obs[tag + "_A_rows"] = e
         assert e <= 2e-6, (tag, e)
+
+    def check_temporal_rows(self, idx, C_before, nneur, obs, tag, maxIter=5):
+        """the METHOD-level temporal update (HALS_temporal.m:47-68 inside update_temporal_parallel.m:149-186, one patch = the field of view) for a connected
+        group of neurons: a neuron's new trace depends on its own projection A_k' Ysig and on the already updated traces of the neurons it overlaps, so the
+        oracle runs the same Gauss-Seidel sweeps on the overlap-closure of a few sampled neurons, with Ysig formed by the oracle on the rows under their
+        footprints only (residual_ysig: update_temporal_parallel.m:149-152 with the block's A_prev, C_prev)."""
+        v, s = self.video, self.s
+        A = sp.csc_matrix(s.A).astype(np.float64)
+        K = A.shape[1]
+        G = (A.T @ A).tocsr()                                             # overlap graph
+        seeds = self.rng.choice(np.nonzero(np.diff(A.indptr) > 0)[0], size=nneur, replace=False)
+        grp = set()
+        for k0 in seeds:                                                  # closure under "shares a pixel with"
+            todo = [int(k0)]
+            while todo:
+                k = todo.pop()
+                if k in grp:
+                    continue
+                grp.add(k)
+                todo.extend(int(j) for j in G.indices[G.indptr[k]:G.indptr[k + 1]] if j not in grp)
+        grp = np.array(sorted(grp))
+        rows = np.unique(np.concatenate([A.indices[A.indptr[k]:A.indptr[k + 1]] for k in grp]))
+        indp, A_prev_b = self.block_neurons(s.A_prev, idx)
+        Ysig = orc.residual_ysig(self.Yb[idx], A_prev_b, np.asarray(s.C_prev, dtype=np.float64)[indp], s.get_W(idx), s.get_b0(idx).astype(np.float64),
+                                 self.ip(idx), only_rows=rows)
+        A_g = sp.csc_matrix(A.tocsr()[rows][:, grp])
+        Cr, Crawr, _ = orc.HALS_temporal(Ysig, A_g, np.asarray(C_before, dtype=np.float64)[grp], maxIter, None)
+        Crawr = Crawr - Crawr.min(axis=1, keepdims=True)                  # update_temporal_parallel.m:285 (one patch: the stitch is the identity)
+        e = rel(np.asarray(s.C_raw)[grp], Crawr); obs[tag + "_C_method_rows"] = e; obs[tag + "_C_method_group"] = int(grp.size)
+        assert e <= 5e-6, (tag, e, grp.size)
 
     def check_temporal_patch(self, idx, obs, tag, deconv=False, maxIter=5):
         """the temporal update of ONE patch through the engine-level call against HALS_temporal.m on the engine's exported Ysig (R1 itself is
@@ -290,6 +368,33 @@ def test_c2_full_size(own_engine, observed):
         c.check_spatial(idx, A0, C0, s.A_prev, s.C_prev, 512, obs, "it%d" % it)
         s.update_temporal_parallel()
         c.check_temporal_patch(idx, obs, "it%d" % it)
+        rss.append(s.compute_RSS()[0])
+    med, mn = _recovery(s, c.f)
+    obs["recovery_median_min"] = [med, mn]; obs["rss"] = rss
+    assert med > 0.98 and rss[1] <= rss[0] * (1 + 1e-6), (med, mn, rss)
+
+
+def test_c3_full_size(own_engine, observed):
+    """BASELINE configs[2], the headline the bench quotes: 512 x 512 x 10000, K = 500, r = 15, one patch -- two iterations through the method-level
+    calls (the sweep-free residual of round 4: no ring sweep runs inside them) with sampled-oracle checks of every stage, like C2 / C4"""
+    _need_big_gpu()
+    obs = observed.setdefault("c3_full", {})
+    c = BigCase(own_engine, 512, 512, 10000, 500, 15, 2, [512, 512], {(0, 0)}, spatial_algorithm="hals")
+    s, idx = c.s, (0, 0)
+    W_old = orc.build_ring_W(c.video.patch_pos[idx], c.video.block_pos[idx], 512, 512, c.rs, c.cs)
+    rss = []
+    for it in range(2):
+        A0, C0 = s.A.copy(), np.asarray(s.C).copy()
+        info = s.update_background_parallel()
+        assert info[idx]["first_run"] == (it == 0)
+        W_old = c.check_background(idx, A0, C0, W_old, 48, obs, "it%d" % it)
+        s.update_spatial_parallel()
+        c.check_spatial(idx, A0, C0, s.A_prev, s.C_prev, 256, obs, "it%d" % it)
+        C_before = np.asarray(s.C).copy()
+        s.update_temporal_parallel()
+        c.check_temporal_rows(idx, C_before, 12, obs, "it%d" % it)
+        if it == 1:
+            c.check_residual(idx, s.A_prev, np.asarray(s.C_prev), 128, obs, "it%d" % it)      # (an export: the sweep runs for it, after the iteration)
         rss.append(s.compute_RSS()[0])
     med, mn = _recovery(s, c.f)
     obs["recovery_median_min"] = [med, mn]; obs["rss"] = rss

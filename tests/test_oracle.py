@@ -171,3 +171,33 @@ def test_method_level_iteration_recovers_planted_model():
         a_t = f.A_true[:, k].toarray().ravel()
         assert np.corrcoef(A[:, k], a_t)[0, 1] > 0.8
         assert np.corrcoef(o.C[k], f.C_true[k])[0, 1] > 0.9
+
+
+def test_sampled_row_harness_paths_equal_the_full_restatement():
+    """fit_ring_model / residual_ysig switch to a sampled-row evaluation for blocks too large to densify (tests at 512 x 512 x 10000): the same statements on
+    the needed pixels only -- equal to the full restatement on a small case, first and later fits, with and without footprints"""
+    import scipy.sparse as sp
+    from cnmf_e_amd import synth
+    d1, d2, T, K, r = 40, 36, 300, 5, 5
+    f = synth.make_factors(d1, d2, T, K, 3, gSig=1.5, gSiz=7, min_sep=5)
+    Y = synth.make_video(f, np.float32).T.copy()
+    rs, cs = orc.get_nhood(r)
+    pos = np.array([1, d1, 1, d2])
+    W0 = orc.build_ring_W(pos, pos, d1, d2, rs, cs)
+    ip = np.ones(d1 * d2, bool)
+    A = sp.csc_matrix(f.A_init.astype(np.float64)); C = f.C_init.astype(np.float64)
+    rows = np.sort(np.random.default_rng(0).choice(d1 * d2, 40, replace=False))
+    Wf, b0 = orc.fit_ring_model(Y, A, C, W0, np.nan, None, ip, True)
+    for W_old in (W0, Wf):
+        for A_, C_ in ((A, C), (None, None)):
+            W1, b1 = orc.fit_ring_model(Y, A_, C_, W_old, np.nan, None, ip, True, only_rows=rows)
+            W2, b2 = orc._fit_ring_model_rows(Y, A_, C_, W_old, ip, True, rows)
+            assert abs(W1 - W2).max() <= 1e-13 and np.abs(b1 - b2).max() <= 1e-9
+    import types
+    src = open(orc.__file__).read().replace("np.asarray(Y_block).size > (1 << 28)", "True")
+    mod = types.ModuleType("orc_harness"); exec(compile(src, orc.__file__, "exec"), mod.__dict__)
+    for A_, C_ in ((A, C), (None, None)):
+        y1 = orc.residual_ysig(Y, A_, C_, Wf, b0, ip, only_rows=rows)
+        y2 = mod.residual_ysig(Y, A_, C_, Wf, b0, ip, only_rows=rows)
+        y3 = mod.residual_ysig(Y.T.copy().T, A_, C_, Wf, b0, ip, only_rows=rows)          # (a transposed view of a frame-major array, as the full-size test passes)
+        assert np.abs(y1 - y2).max() <= 1e-9 * np.abs(y1).max() and np.abs(y1 - y3).max() <= 1e-9 * np.abs(y1).max()
