@@ -176,6 +176,23 @@ static void flush_locked(cnmfe_ctx *ctx) {
     const int n = ctx->npseg; ctx->npseg = 0;
     hipLaunchKernelGGL(k_pin_copy, dim3(nb, (unsigned)n), dim3(256), 0, ctx->stream_, pseg);      // (a failed launch is reported by the next LAUNCH's hipGetLastError)
 }
+// Before device memory [p, p + bytes) is freed: the held-back uploads INTO it must go out first.  Only the context that owns the allocation ever uploads into it,
+// and a context is driven by one thread -- so this flushes the caller's own context and nobody else's (flushing every context from here let one thread reset
+// another thread's npseg, which cnmfe_ctx::st() reads without the lock: ADVICE round 3).
+void pin_flush_range(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    const char *lo = (const char *)p, *hi = lo + bytes;
+    int cur = -1;
+    for (cnmfe_ctx *c : g_pin_live) {
+        bool hit = false;
+        for (int i = 0; i < c->npseg && !hit; ++i) { const char *d_ = (const char *)c->pseg.dst[i]; hit = d_ >= lo && d_ < hi; }
+        if (!hit) continue;
+        if (cur < 0) (void)hipGetDevice(&cur);
+        if (c->device != cur) (void)hipSetDevice(c->device);
+        flush_locked(c);
+        if (c->device != cur) (void)hipSetDevice(cur);
+    }
+}
 void pin_flush_all() {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     int cur = -1;
@@ -318,8 +335,12 @@ int ctx_check_errflag(cnmfe_ctx *ctx) {
     CK(hipStreamSynchronize(ctx->st()));
     if (!h) return 0;
     CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
+    // whatever raised the flag left truncated or inconsistent tables behind (the footprint terms beside a residual, a P table): nothing kept with the patches may
+    // be trusted by a later call -- the next residual sweeps again, the next spatial update builds its own table
+    for (auto &kv : ctx->patches) { Patch *q = kv.second; q->ysig_valid = false; q->ysig_virtual = false; q->pend = false; q->res_ac = false; q->res_kind = 0; q->pt_valid = false; }
+    ctx->bgs_patch = -1;
     if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 32 footprints of A_prev (flag %d)", h);
-    if (h & 4) return fail(CNMFE_EUNSUPPORTED, "bg_ssub > 1: a pixel's interpolation window meets more than 32 footprints of A_prev (flag %d)", h);
+    if (h & 4) return fail(CNMFE_EUNSUPPORTED, "bg_ssub > 1: a pixel's interpolation window meets more than 64 footprints of A_prev (flag %d)", h);
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
 }
 

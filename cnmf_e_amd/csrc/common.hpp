@@ -26,17 +26,18 @@ inline int fail(int code, const char *fmt, ...) {
     return cnmfe::fail(CNMFE_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)
 #define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
 
-void pin_flush_all();         // api.hip: enqueue the small uploads any context still holds back (see cnmfe_ctx::st) -- before device memory is freed
+void pin_flush_all();         // api.hip: enqueue the small uploads every context still holds back (see cnmfe_ctx::st)
+void pin_flush_range(const void *p, size_t bytes);   // ... those into [p, p + bytes) -- before that device memory is freed (only its owner's context holds any)
 
 // ---- owned device buffer -----------------------------------------------------
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
-    ~DevBuf() { if (p) { pin_flush_all(); (void)hipFree(p); } }
+    ~DevBuf() { if (p) { pin_flush_range(p, cap); (void)hipFree(p); } }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) { pin_flush_all(); (void)hipFree(p); p = nullptr; cap = 0; }     // (an upload into the old allocation may still be held back)
+        if (p) { pin_flush_range(p, cap); (void)hipFree(p); p = nullptr; cap = 0; }     // (an upload into the old allocation may still be held back)
         size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return fail(CNMFE_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
@@ -240,7 +241,7 @@ struct cnmfe_ctx {
     hipStream_t stream_ = nullptr;
     cnmfe::PinSegs pseg; int npseg = 0;
     void flush_copies();                                   // api.hip
-    hipStream_t st() { if (npseg) flush_copies(); return stream_; }   // the compute stream, every held-back upload enqueued first
+    hipStream_t st() { if (npseg) flush_copies(); return stream_; }   // the compute stream, every held-back upload enqueued first (npseg: written by this context's own thread only, pin_flush_range)
     cnmfe::PinArena pin;
     int64_t spatial_nnz = -1;                              // values of the last cnmfe_update_spatial still in scr[6] (deferred fetch)
     hipStream_t copy_stream = nullptr;                     // device -> pinned host downloads that should not hold up the compute stream

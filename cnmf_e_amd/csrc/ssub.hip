@@ -341,14 +341,14 @@ int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, 
 
 // (W A)(C - mean C) of the low-resolution sweep, seen from the full-resolution patch: up[(W A_low)] as ELL rows per patch pixel.
 // wa_up(i, l) = sum over the row / column taps of pixel i of w_r w_c wa_low(j(r,c), l).  One thread per patch pixel, its <= UP_CAP slots in LDS.
-constexpr int UP_CAP = 32;
-__global__ void __launch_bounds__(128) k_wa_upsample(int64_t d, int nr, int nr_b, int roff, int coff, int d1s, int64_t d_low, const int *__restrict__ ir,
+constexpr int UP_CAP = 64, UP_NT = 64;    // slots per pixel (twice what ONE low-resolution ring may touch, WA_CAP: the 6 x 6 taps of a pixel share most of theirs) / threads per workgroup
+__global__ void __launch_bounds__(UP_NT) k_wa_upsample(int64_t d, int nr, int nr_b, int roff, int coff, int d1s, int64_t d_low, const int *__restrict__ ir,
                                                      const float *__restrict__ wr, int Pr, const int *__restrict__ ic, const float *__restrict__ wc, int Pc,
                                                      const int *__restrict__ cnt_l, const int *__restrict__ k_l, const float *__restrict__ v_l,
                                                      int *__restrict__ cnt, int *__restrict__ kk, float *__restrict__ vv, int *__restrict__ overflow) {
-    __shared__ int tk[UP_CAP][128];
-    __shared__ float tv[UP_CAP][128];
-    const int64_t m = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    __shared__ int tk[UP_CAP][UP_NT];
+    __shared__ float tv[UP_CAP][UP_NT];
+    const int64_t m = (int64_t)blockIdx.x * UP_NT + threadIdx.x;
     if (m >= d) return;
     const int t = threadIdx.x;
     const int rb = (int)(m % nr) + roff, cb = (int)(m / nr) + coff;
@@ -409,7 +409,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
             int *dErr = nullptr;
             RET(ctx_errflag(ctx, &dErr));
             RET(tCnt.ensure((size_t)M->d * sizeof(int))); RET(tK.ensure((size_t)UP_CAP * M->d * sizeof(int))); RET(tV.ensure((size_t)UP_CAP * M->d * sizeof(float)));
-            LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + 127) / 128)), dim3(128), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
+            LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + UP_NT - 1) / UP_NT)), dim3(UP_NT), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
                    dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P, ctx->tmp[8].as<int>(), ctx->tmp[9].as<int>(), ctx->tmp[10].as<float>(),
                    tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dErr);
             (reuse ? M->pendCc : M->resCc).swap(tCc);

@@ -635,6 +635,8 @@ class Engine:
         L.check(L.lib.cnmfe_hals_temporal_deconv(self._ctx, pid, K, _p(cp, L.i64p), _p(ri, L.i32p), _p(va, L.f32p), cptr, cord,
                                                  int(maxIter), C.byref(opts), _p(pars, L.f32p), _p(Cout, L.f32p), _p(Craw, L.f32p),
                                                  _p(S, L.f32p), _p(sn, L.f32p), _p(aa, L.f32p)))
+        if want_all is None:                                 # nothing was copied back (the ABI treats kernel_pars as input only then): no stale copies of the inputs
+            return None, None, None, None, None, aa
         return Cout, Craw, S, sn, pars, aa
 
     def deconv_temporal(self, C_raw, deconv_options, overwrite=False):

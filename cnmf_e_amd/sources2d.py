@@ -969,8 +969,13 @@ class Sources2D:
                 whole_result = Anew                                                                  # one patch over the whole FOV, every neuron: already A_
                 continue
             collect(lambda Anew=Anew: Anew, pp, ind)
+        late_any = bool(in_flight)
         while in_flight:
             collect(*in_flight.pop(0))
+        if late_any and hasattr(self.engine, "synchronize"):
+            # the late-collected results waited for their own point of the stream only (cnmfe_ticket_wait): what the kernels had to report (a ring over too many
+            # footprints, an inconsistent table) must be heard BEFORE obj.A is replaced by what they computed
+            self.engine.synchronize()
         d = v.d1 * v.d2
         if whole_result is not None and callable(whole_result):
             self.A_raw = whole_result                                                                # (not sharded: nothing to gather; assembled on first read)

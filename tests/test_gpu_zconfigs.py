@@ -135,12 +135,12 @@ def test_two_iterations_against_oracle(eng, oracle_jobs, observed, name):
         assert e <= (0.1 if outl else 1e-4), (name, it, e)
 
 
-def test_demo_defaults_sequence_against_oracle(eng, oracle_jobs, observed):
+@pytest.mark.parametrize("name", ["m96_demo"])            # (the job name in the test id: conftest starts the oracle worker of every job a collected test names)
+def test_demo_defaults_sequence_against_oracle(eng, oracle_jobs, observed, name):
     """The shipped demo's own parameter set as ONE trajectory (demos/demo_large_data_1p.m:16-55,142-201): ring_radius = 18, bg_ssub = 2 (low-resolution
     ring of radius 9), spatial_algorithm = 'hals_thresh' thresholding against the P.sn that update_sn = true re-estimated in the same call, deconv_flag = true,
     two temporal updates in a row, the switch to 'nnls' and a second background / spatial / temporal round -- every stage against the float64 oracle."""
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-    name = "m96_demo"
     cfg = oj.JOBS[name]
     Y, A, C, sn, d1, d2 = oj.make_inputs(cfg)
     T, r = cfg["T"], cfg["r"]
