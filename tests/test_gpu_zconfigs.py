@@ -394,7 +394,7 @@ def test_c3_full_size(own_engine, observed):
         s.update_temporal_parallel()
         c.check_temporal_rows(idx, C_before, 12, obs, "it%d" % it)
         if it == 1:
-            c.check_residual(idx, s.A_prev, np.asarray(s.C_prev), 128, obs, "it%d" % it)      # (an export: the sweep runs for it, after the iteration)
+            c.check_residual(idx, s.A, np.asarray(s.C), 128, obs, "it%d" % it)      # (an export of Y - A C - ring background with the CURRENT A, C: the sweep runs for it, after the iteration)
         rss.append(s.compute_RSS()[0])
     med, mn = _recovery(s, c.f)
     obs["recovery_median_min"] = [med, mn]; obs["rss"] = rss
