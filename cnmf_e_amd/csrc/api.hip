@@ -511,7 +511,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual",
+    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual", "prealloc",
                                   /* retired experiment switches (rounds 2-3): still accepted, ignored -- scripts/r1_probe.py, r1_duo.py, solve_ab.py name them */
                                   "r1_arc_d", "r1_arc_bias", "r1_duo_ord", "solve_mode", "gram_kernel", "solve_gfill", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; return 0; }
@@ -770,6 +770,15 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
     int rc = bg_fit_ring(ctx, P, K, A_colptr, A_rowidx, A_val, C, c_order, with_projection, b0_out, info ? info : dummy, 0, thresh_outlier);
     P->ysig_valid = false;
     return rc;
+}
+
+int cnmfe_fit_reserve(cnmfe_ctx *ctx, int patch_id) {
+    if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
+    CK(hipSetDevice(ctx->device));
+    if (ctx->opt("prealloc", 1) == 0) return 0;
+    return bg_reserve(ctx, P);
 }
 
 int cnmfe_set_noise(cnmfe_ctx *ctx, int patch_id, const float *sn_block) {

@@ -777,6 +777,39 @@ static double matlab_quantile(std::vector<int> x, double q) {
     return x[lo - 1] + (r - (double)lo) * (double)(x[lo] - x[lo - 1]);
 }
 
+// The large buffers of the ring fit, allocated when the ring is set (cnmfe_ring_init: once per patch, after the upload) instead of inside the first fit: the
+// video's covariance table, the context's working table, the tiled Bf and the window projection's partial sums -- 18 GB at the headline size.  A fit then
+// queues its kernels without a hipMalloc in between (tens of milliseconds of the first iteration, and on some boxes the dispatch behind a fresh multi-GB
+// allocation stalled for 0.5-0.8 s, profiles/r03/README.md).  Sizes follow the geometry only; a buffer that is already large enough is left alone.
+int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
+    if (ctx->opt("gram_incremental", 1) == 0 || P->p <= 0) return 0;
+    int p_radius = 0;
+    for (int i = 0; i < P->p; ++i) p_radius = std::max(p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
+    const int maxd = (2 * p_radius + 15) >> 4;
+    if (maxd > 3) return 0;
+    const int nbr = (P->nr_b + BLK - 1) / BLK, nbc = (P->nc_b + BLK - 1) / BLK, nblk = nbr * nbc;
+    const int pi0 = std::max(0, P->roff - p_radius) / BLK, pi1 = std::min(P->nr_b - 1, P->roff + P->nr - 1 + p_radius) / BLK;
+    const int pj0 = std::max(0, P->coff - p_radius) / BLK, pj1 = std::min(P->nc_b - 1, P->coff + P->nc - 1 + p_radius) / BLK;
+    int64_t npairs = 0;                                      // as the pair list of bg_fit_ring counts them: touched blocks, canonical displacements within maxd
+    for (int j = pj0; j <= pj1; ++j)
+        for (int i = pi0; i <= pi1; ++i)
+            for (int dC = 0; dC <= maxd; ++dC)
+                for (int dR = (dC == 0 ? 0 : -maxd); dR <= maxd; ++dR) {
+                    const int i2 = i + dR, j2 = j + dC;
+                    if (i2 >= pi0 && i2 <= pi1 && j2 >= pj0 && j2 <= pj1) ++npairs;
+                }
+    const int64_t Tpad = (P->T + GK - 1) / GK * GK;
+    const size_t tab = (size_t)npairs * BLKPX * BLKPX * sizeof(double);
+    RET(P->cov_base.ensure(tab));
+    RET(P->rowsum_base.ensure((size_t)nblk * BLKPX * sizeof(double)));
+    RET(ctx->cov.ensure(tab));
+    RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
+    RET(ctx->bf.ensure((size_t)nblk * Tpad * BLKPX * sizeof(float)));
+    const int nsg = nblk >= 512 ? std::max(1, std::min(8, (2048 + nblk - 1) / nblk)) : std::max(1, std::min(16, (4096 + nblk - 1) / std::max(1, nblk)));
+    RET(ctx->inc[6].ensure((size_t)nsg * nblk * WIN_NLB * WIN_NLB * sizeof(double)));
+    return 0;
+}
+
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only, double thresh_outlier) {
     HostTrace ht(ctx, "fit_ring");

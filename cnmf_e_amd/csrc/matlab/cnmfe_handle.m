@@ -37,6 +37,9 @@ function eng = cnmfe_handle(obj, gpus)
             cnmfe_mex('derive', h, eng.pid(m), eng.pid_res(m), opt.bg_ssub, 'bicubic');
             cnmfe_mex('ring_init', h, eng.pid_fit(m), rr, opt.num_neighbors);
             cnmfe_mex('ring_init', h, eng.pid_res(m), rr, opt.num_neighbors);
+            cnmfe_mex('fit_reserve', h, eng.pid_fit(m));                   % the fit's large device buffers now, not inside the first update_background_parallel
+        else
+            cnmfe_mex('fit_reserve', h, eng.pid(m));
         end
         % a W{m}, b0{m} fitted in an earlier session goes back on the device (same ring pattern; values in MATLAB's column order of W.')
         if ~isempty(obj.W) && numel(obj.W) >= m && ~isempty(obj.W{m}) && nnz(obj.W{m}) > 0 && opt.bg_ssub == 1

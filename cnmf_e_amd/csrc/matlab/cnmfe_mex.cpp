@@ -213,6 +213,8 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
     } else if (!strcmp(cmd, "ring_init")) {
         if (nin < 4) FAIL("ring_init: radius required");
         CHECK(cnmfe_ring_init(c, pid, (int32_t)mxGetScalar(pin[3]), nin > 4 && !mxIsEmpty(pin[4]) ? (int32_t)mxGetScalar(pin[4]) : 0));
+    } else if (!strcmp(cmd, "fit_reserve")) {
+        CHECK(cnmfe_fit_reserve(c, pid));
     } else if (!strcmp(cmd, "first_run")) {
         int f = 0;
         CHECK(cnmfe_ring_first_run(c, pid, &f));

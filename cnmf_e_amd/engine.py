@@ -291,6 +291,10 @@ class Engine:
     def ring_init(self, pid, radius, num_neighbors=None):
         L.check(L.lib.cnmfe_ring_init(self._ctx, pid, int(radius), int(num_neighbors or 0)))
 
+    def fit_reserve(self, pid):
+        """allocate the ring fit's large device buffers of this patch now (cnmfe_fit_reserve): the first fit then queues its kernels without a hipMalloc"""
+        L.check(L.lib.cnmfe_fit_reserve(self._ctx, pid))
+
     def ring_csr(self, pid):
         nnz = C.c_int64(); p = C.c_int32()
         L.check(L.lib.cnmfe_ring_nnz(self._ctx, pid, C.byref(nnz), C.byref(p)))

@@ -533,6 +533,8 @@ class Sources2D:
                 self.engine.patch_derive(video.pid[idx], self.pid_res[idx], self.ssub, "bicubic")
                 self.engine.ring_init(self.pid_fit[idx], rr, options.num_neighbors)
                 self.engine.ring_init(self.pid_res[idx], rr, options.num_neighbors)
+            if hasattr(self.engine, "fit_reserve"):                       # the fit's large buffers now, not inside the first update_background_parallel
+                self.engine.fit_reserve(video.pid[idx] if self.ssub == 1 else self.pid_fit[idx])
             self.P["Ymean"][idx] = self.engine.ymean(video.pid[idx])[video.ind_patch[idx]]      # :338-339, patch part
         self._ymean_full = None
 

@@ -120,6 +120,13 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
                          double thresh_outlier, int with_projection,
                          float *b0_out /* d or NULL */, int64_t info[4]);
 
+/* Optional, once per patch that will be FITTED (after cnmfe_ring_init; with bg_ssub > 1 that is the low-resolution fit patch): allocate the ring fit's large
+ * device buffers now -- the block-pair covariance tables, the tiled residual, the window projection's partial sums (18 GB for 512 x 512 x 10000, radius 15) --
+ * so that the first cnmfe_fit_ring_model queues its kernels without a hipMalloc in between.  Sizes follow the geometry only; nothing is computed.  The host
+ * mirror calls it while it sets the patches up (initComponents_parallel.m:213-236 is where the reference allocates W, b0); a host that does not simply gets
+ * the allocations inside its first fit. */
+int cnmfe_fit_reserve(cnmfe_ctx *ctx, int patch_id);
+
 /* P.sn: sn = estimate_noise(obj, frame_range, 'psd')  (@Sources2D/Sources2D.m:328-379 -> OASIS_matlab/functions/GetSn.m:19-46) for the block
  * pixels of a patch: the Welch estimate of the first `nframes` frames (the reference's default is min(T, 3000)) of the resident RAW video
  * (pixel mean included, as pwelch sees it).  The per-storage-block bookkeeping of :361-375 (row / column end-1 of every block but the
