@@ -61,34 +61,59 @@ def _blas_info():
 
 
 def cpu_baseline():
-    """The float64 NumPy restatement of the reference (oracle/, 'port': NOT MATLAB) timed on a bounded sample of the same workload: one full
-    iteration at 128 x 128 x 3000 with the headline's neuron density, scaled by the d*T work ratio.  K-dependent terms (the dense Y*C', A*C of
-    the reference) do not scale by d*T alone -- `python bench.py --cpu-baseline full` times C2 in full and C3 as BASELINE.md section 3 lays out;
-    its committed result (profiles/r03/cpu_baseline_full.json) is quoted beside this number when present."""
+    """The float64 NumPy restatement of the reference (oracle/, 'port': NOT MATLAB) on this host.  `value` is the headline workload (C3) as
+    `bench.py --cpu-baseline full` measured it on the GPU box's host (committed: profiles/r03/cpu_baseline_full.json) -- spatial and
+    temporal updates in full, the per-pixel background regression on every 64th pixel and extrapolated, said so in `unit`.  What THIS run times is a bounded
+    sample with the same thread count (one full iteration at 128 x 128 x 3000 with the headline's neuron density, ~12 s): `in_run_sample`, with its d*T-scaled
+    figure -- K-dependent terms (the dense Y*C', A*C of the reference) do not scale by d*T alone, which is why the two differ and why `value` is the full run."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnmfe_oracle as orc
     from cnmf_e_amd import synth
+    full = None
+    fpath = os.path.join(ROOT, "profiles", "r03", "cpu_baseline_full.json")
+    if os.path.exists(fpath):
+        try:
+            full = json.load(open(fpath))
+        except Exception:
+            full = None
+    threads = int(full["cores"]) if full else None          # the same BLAS thread count as the full run: one core count in the whole object
     d1, d2, T, r = 128, 128, 3000, 15                  # ~12 s of host work on the GPU box
     K = max(2, int(round(500 * d1 * d2 / (512.0 * 512.0))))
     f = synth.make_factors(d1, d2, T, K, 9)
     Y = synth.make_video(f, np.float32)
     o = orc.OracleSources2D(Y.T.reshape(d1, d2, T, order="F"), d1, d2, T, [d1, d2], r, f.A_init.astype(np.float32), f.C_init, f.sn,
                             spatial_algorithm="hals", maxIter=5)
-    t0 = time.time()
-    o.update_background_parallel(); o.update_spatial_parallel(); o.update_temporal_parallel()
-    dt = time.time() - t0
+    def run():
+        t0 = time.time()
+        o.update_background_parallel(); o.update_spatial_parallel(); o.update_temporal_parallel()
+        return time.time() - t0
+    try:
+        import threadpoolctl
+        if threads:
+            with threadpoolctl.threadpool_limits(limits=threads):
+                dt = run()
+        else:
+            dt = run()
+    except ImportError:
+        dt = run()
     scale = (512.0 * 512.0 * 10000.0) / (d1 * d2 * T)
     thr, blas = _blas_info()
-    out = {"value": 1.0 / (dt * scale), "unit": "iter/s (512x512x10000-equivalent)", "cores": thr, "kind": "port", "blas": blas, "host_cpus": os.cpu_count(),
-           "sample": "one full iteration of the float64 NumPy restatement (oracle/cnmfe_oracle.py, not MATLAB) on %dx%dx%d, K=%d, r=%d "
-                     "took %.2f s; scaled by the d*T work ratio %.1f to 512x512x10000" % (d1, d2, T, K, r, dt, scale)}
-    full = os.path.join(ROOT, "profiles", "r03", "cpu_baseline_full.json")
-    if os.path.exists(full):
-        try:
-            out["full_run"] = dict(json.load(open(full)), source="profiles/r03/cpu_baseline_full.json (an earlier run of `bench.py --cpu-baseline full`, not this run)")
-        except Exception:
-            pass
-    return out
+    used = min(threads, thr) if threads else thr
+    sample = {"seconds": dt, "workload": "%dx%dx%d, K=%d, r=%d, one full iteration" % (d1, d2, T, K, r), "scaled_by_dT": scale,
+              "iter_per_s_scaled_to_c3": 1.0 / (dt * scale), "cores": used}
+    if full and "c3" in full:
+        c3 = full["c3"]
+        return {"value": c3["iter_per_s"], "unit": "iter/s (C3 = 512x512x10000, K=500; spatial + temporal measured in full, background regression loop extrapolated from every 64th pixel)",
+                "cores": int(full["cores"]), "kind": "port", "blas": full.get("blas", blas), "host_cpus": os.cpu_count(),
+                "sample": "C3 by `bench.py --cpu-baseline full` on the GPU box's host (profiles/r03/cpu_baseline_full.json, not this run): %.0f s per iteration = background %.0f s "
+                          "(set-up %.0f s + 64 x %.1f s of the per-pixel loop timed on 4096 of 262144 pixels: extrapolated) + spatial %.0f s + temporal %.0f s; "
+                          "this run timed a bounded sample with the same %d BLAS threads (in_run_sample: %.1f s for one iteration at %dx%dx%d)"
+                          % (c3["iteration_s"], c3["background_extrapolated_s"], c3["background_setup_s"], c3["background_loop_sampled_s"], c3["spatial_s"], c3["temporal_s"],
+                             int(full["cores"]), dt, d1, d2, T),
+                "in_run_sample": sample, "full_run": dict(full, source="profiles/r03/cpu_baseline_full.json")}
+    return {"value": 1.0 / (dt * scale), "unit": "iter/s (512x512x10000-equivalent: a 128x128x3000 iteration scaled by d*T -- extrapolated)", "cores": used, "kind": "port", "blas": blas,
+            "host_cpus": os.cpu_count(), "sample": "one full iteration of the float64 NumPy restatement (oracle/cnmfe_oracle.py, not MATLAB) on %dx%dx%d, K=%d, r=%d "
+            "took %.2f s; scaled by the d*T work ratio %.1f to 512x512x10000" % (d1, d2, T, K, r, dt, scale), "in_run_sample": sample}
 
 
 def cpu_baseline_full(which=("c2", "c3"), out_path=None):

@@ -479,6 +479,8 @@ cnmfe_ctx *cnmfe_create(int device) {
     if (hipStreamCreate(&ctx->stream_) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
     pin_register(ctx, true);
     if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
+    // every translation unit's code object is loaded now, not at the first launch of one of its kernels inside the first iteration (tens of milliseconds in all)
+    (void)tu_warm_resid(); (void)tu_warm_bg(); (void)tu_warm_factor(); (void)tu_warm_deconv(); (void)tu_warm_ssub(); (void)tu_warm_vproj();
     // CNMFE_OPTS="name=value,name=value": tunables of cnmfe_set_option preset for every context of the process (A/B runs of the test suite and the bench
     // without touching their code); names this build does not know are ignored -- the same environment serves builds with different option sets
     if (const char *env = getenv("CNMFE_OPTS")) {
@@ -1047,6 +1049,43 @@ int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld) {
     CK(hipSetDevice(ctx->device));
     CK(hipStreamSynchronize(ctx->st()));                 // the caller's collective runs on ITS stream: everything added so far must have landed
     *dev_acc = ctx->stitch.as<float>(); *ld = ctx->stitch_ld;
+    return 0;
+}
+
+// The same hand-over without the drain: the accumulator and the stream its additions are queued on.  A caller that enqueues its collective ON that stream (or
+// orders its own stream behind it with an event) keeps the host out of the exchange: cnmfe_stitch_finish* then follows in stream order.
+int cnmfe_stitch_buffer_stream(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld, void **hip_stream) {
+    if (!ctx || !dev_acc || !ld || !hip_stream) return fail(CNMFE_EINVAL, "null argument");
+    if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
+    CK(hipSetDevice(ctx->device));
+    *dev_acc = ctx->stitch.as<float>(); *ld = ctx->stitch_ld; *hip_stream = (void *)ctx->st();      // (st(): the held-back small uploads go out first)
+    return 0;
+}
+
+// host helper: a CSC matrix (ncol columns, rows sorted per column) from n (row, column, value) triplets in any order -- the assembly of the gathered rows of A
+// (update_spatial_parallel.m:324-334: every rank's patches contribute disjoint rows) without a sort of the whole triplet list: counting pass per column, then
+// an insertion sort of each column's few entries by row.  Duplicate (row, column) pairs are an error (the patches are disjoint).
+int cnmfe_csc_from_triplets(int64_t n, const int32_t *rows, const int32_t *cols, const float *vals, int32_t ncol, int64_t nrow,
+                            int64_t *out_colptr, int32_t *out_rowidx, float *out_val) {
+    if (n < 0 || ncol < 0 || !out_colptr || (n > 0 && (!rows || !cols || !vals || !out_rowidx || !out_val))) return fail(CNMFE_EINVAL, "cnmfe_csc_from_triplets: null argument");
+    for (int32_t k = 0; k <= ncol; ++k) out_colptr[k] = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        if (cols[e] < 0 || cols[e] >= ncol || rows[e] < 0 || rows[e] >= nrow) return fail(CNMFE_EINVAL, "cnmfe_csc_from_triplets: entry %lld = (%d, %d) outside %lld x %d", (long long)e, rows[e], cols[e], (long long)nrow, ncol);
+        ++out_colptr[cols[e] + 1];
+    }
+    for (int32_t k = 0; k < ncol; ++k) out_colptr[k + 1] += out_colptr[k];
+    std::vector<int64_t> cur(out_colptr, out_colptr + ncol);
+    for (int64_t e = 0; e < n; ++e) { const int64_t at = cur[cols[e]]++; out_rowidx[at] = rows[e]; out_val[at] = vals[e]; }
+    for (int32_t k = 0; k < ncol; ++k) {                    // (a rank's part arrives sorted within the column: the insertion sort mostly merges a few runs)
+        const int64_t a = out_colptr[k], b = out_colptr[k + 1];
+        for (int64_t i = a + 1; i < b; ++i) {
+            const int32_t r = out_rowidx[i]; const float v = out_val[i];
+            int64_t j = i;
+            while (j > a && out_rowidx[j - 1] > r) { out_rowidx[j] = out_rowidx[j - 1]; out_val[j] = out_val[j - 1]; --j; }
+            out_rowidx[j] = r; out_val[j] = v;
+        }
+        for (int64_t i = a + 1; i < b; ++i) if (out_rowidx[i] == out_rowidx[i - 1]) return fail(CNMFE_EINVAL, "cnmfe_csc_from_triplets: entry (%d, %d) given twice", out_rowidx[i], k);
+    }
     return 0;
 }
 

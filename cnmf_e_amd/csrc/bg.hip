@@ -1222,4 +1222,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     return 0;
 }
 
+// loads this translation unit's code object now (HIP loads it at the first launch of one of its kernels -- milliseconds each that would otherwise fall into the first iteration): cnmfe_create
+int tu_warm_bg() { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)k_rowsum) == hipSuccess ? 0 : -1; }
+
 }  // namespace cnmfe

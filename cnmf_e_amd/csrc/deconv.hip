@@ -982,4 +982,7 @@ int deconv_bound_run(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, float *C_out
     return 0;
 }
 
+// loads this translation unit's code object now (HIP loads it at the first launch of one of its kernels -- milliseconds each that would otherwise fall into the first iteration): cnmfe_create
+int tu_warm_deconv() { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)k_sn_pixels) == hipSuccess ? 0 : -1; }
+
 }  // namespace cnmfe

@@ -947,4 +947,7 @@ int postproc_run(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_
     return 0;
 }
 
+// loads this translation unit's code object now (HIP loads it at the first launch of one of its kernels -- milliseconds each that would otherwise fall into the first iteration): cnmfe_create
+int tu_warm_factor() { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)k_reduce_parts) == hipSuccess ? 0 : -1; }
+
 }  // namespace cnmfe

@@ -1191,4 +1191,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     return 0;
 }
 
+// loads this translation unit's code object now (HIP loads it at the first launch of one of its kernels -- milliseconds each that would otherwise fall into the first iteration): cnmfe_create
+int tu_warm_resid() { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)k_center_traces) == hipSuccess ? 0 : -1; }
+
 }  // namespace cnmfe

@@ -632,6 +632,9 @@ int ssub_rss(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *cp, const int32
     return 0;
 }
 
+// loads this translation unit's code object now (HIP loads it at the first launch of one of its kernels -- milliseconds each that would otherwise fall into the first iteration): cnmfe_create
+int tu_warm_ssub() { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)k_wa_upsample) == hipSuccess ? 0 : -1; }
+
 }  // namespace cnmfe
 
 using namespace cnmfe;

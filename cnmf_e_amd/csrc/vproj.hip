@@ -412,4 +412,7 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
     return 0;
 }
 
+// loads this translation unit's code object now (HIP loads it at the first launch of one of its kernels -- milliseconds each that would otherwise fall into the first iteration): cnmfe_create
+int tu_warm_vproj() { hipFuncAttributes at; return hipFuncGetAttributes(&at, (const void *)k_vp_segsum) == hipSuccess ? 0 : -1; }
+
 }  // namespace cnmfe

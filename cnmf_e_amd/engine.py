@@ -587,20 +587,29 @@ class Engine:
         (nccl == RCCL over xGMI).  gloo (CPU test hook with every rank on one device) goes through a host copy."""
         import torch
         import torch.distributed as td
-        ptr = L.f32p(); ld = C.c_int64()
-        L.check(L.lib.cnmfe_stitch_buffer(self._ctx, C.byref(ptr), C.byref(ld)))
+        ptr = L.f32p(); ld = C.c_int64(); sp_ = C.c_void_p()
+        nccl = td.get_backend(group) == "nccl"
         K, _ = self._stitch_shape
+        if nccl:
+            # RCCL: the collective is enqueued with the ENGINE's stream as torch's current stream -- the process group orders its own stream behind and in front
+            # of it with events, so neither the additions before it nor the finish after it need the host (two drains of the stream per update until round 3)
+            L.check(L.lib.cnmfe_stitch_buffer_stream(self._ctx, C.byref(ptr), C.byref(ld), C.byref(sp_)))
+        else:
+            L.check(L.lib.cnmfe_stitch_buffer(self._ctx, C.byref(ptr), C.byref(ld)))      # (gloo goes through the host: everything added so far must have landed)
         n = K * ld.value
         if n == 0:
             return
 
         class _View:                                                    # zero-copy torch view of the engine's accumulator
             __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (C.cast(ptr, C.c_void_p).value, False), "version": 2}
+        if nccl:
+            ext = torch.cuda.ExternalStream(int(sp_.value), device=torch.device("cuda", torch.cuda.current_device()))
+            with torch.cuda.stream(ext):
+                t = torch.as_tensor(_View(), device="cuda")
+                td.all_reduce(t, group=group)
+            return
         t = torch.as_tensor(_View(), device="cuda")
-        if td.get_backend(group) == "nccl":
-            td.all_reduce(t, group=group)
-        else:
-            h = t.cpu(); td.all_reduce(h, group=group); t.copy_(h)
+        h = t.cpu(); td.all_reduce(h, group=group); t.copy_(h)
         torch.cuda.current_stream().synchronize()                       # the engine continues on its own stream
 
     def stitch_finish(self, subtract_min, want=True):

@@ -201,6 +201,24 @@ def rows_of(A, lut, nloc, cols=None, span=None, cand=None):
     return _select_rows_numpy(A, lut, nloc, cand, cols is not None)
 
 
+def _csc_from_triplets(r, c, v, shape):
+    """the CSC matrix of disjoint (row, column, value) triplets: one counting pass in the library's host helper (cnmfe_csc_from_triplets) -- scipy's COO -> CSC
+    conversion sorts the whole list, and every rank of a sharded run assembles the WHOLE gathered A; falls back to scipy without the library"""
+    r = np.ascontiguousarray(r, dtype=np.int32); c = np.ascontiguousarray(c, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.float32)
+    try:
+        fn = L.lib.cnmfe_csc_from_triplets
+    except (ImportError, OSError):
+        return sp.csc_matrix((v, (r, c)), shape=shape)
+    n = int(r.size)
+    optr = np.empty(shape[1] + 1, dtype=np.int64); orow = np.empty(max(n, 1), dtype=np.int32); oval = np.empty(max(n, 1), dtype=np.float32)
+    rc = fn(n, r.ctypes.data, c.ctypes.data, v.ctypes.data, int(shape[1]), int(shape[0]), optr.ctypes.data, orow.ctypes.data, oval.ctypes.data)
+    if rc != 0:
+        raise ValueError(L.lib.cnmfe_last_error().decode())
+    M = sp.csc_matrix((oval[:n], orow[:n], optr), shape=shape)
+    M.has_sorted_indices = True
+    return M
+
+
 def _select_rows_native(A, lut, nloc, cand, keep_all):
     """rows_of's selection by the library's host helper cnmfe_csc_select_rows (one pass over the candidates' entries in C: ~10x the NumPy
     formulation below at the 100-neuron patches of a 4 x 4 decomposition, where six such slices per patch and iteration were most of the
@@ -992,7 +1010,7 @@ class Sources2D:
         if whole_result is not None:
             A_ = whole_result
         elif rows:
-            A_ = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(d, K))
+            A_ = _csc_from_triplets(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), (d, K))
         else:
             A_ = sp.csc_matrix((d, K), dtype=np.float32)
         A_ = self._gather_sparse(A_)
@@ -1111,7 +1129,7 @@ class Sources2D:
         r = np.concatenate([o[0, :m] for o, m in zip(out, sizes)])            # int32 row / column indices: the CSC build is index-bound
         c = np.concatenate([o[1, :m] for o, m in zip(out, sizes)])
         d_ = np.concatenate([np.ascontiguousarray(o[2, :m]).view(np.float32) for o, m in zip(out, sizes)])
-        return sp.csc_matrix((d_, (r, c)), shape=A_.shape)
+        return _csc_from_triplets(r, c, d_, A_.shape)
 
     # -- objective ----------------------------------------------------------------------
     def compute_RSS(self):

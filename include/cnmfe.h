@@ -289,6 +289,10 @@ int cnmfe_hals_temporal_job(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64
 int cnmfe_temporal_jobs_sweep(cnmfe_ctx *ctx);
 int cnmfe_stitch_add_job(cnmfe_ctx *ctx, int32_t job, int32_t K_m, const int32_t *ind_m);
 int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld);
+/* cnmfe_stitch_buffer without the drain of the stream: also hands out the hipStream_t the additions are queued on.  A collective enqueued ON that stream (torch:
+ * `with torch.cuda.stream(torch.cuda.ExternalStream(ptr)): all_reduce(...)` -- RCCL orders itself behind and in front of the current stream with events) needs
+ * no host wait on either side; cnmfe_stitch_finish* follows in stream order. */
+int cnmfe_stitch_buffer_stream(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld, void **hip_stream);
 int cnmfe_stitch_dims(cnmfe_ctx *ctx, int32_t *K, int64_t *T);   /* the K x T recorded by cnmfe_stitch_begin (CNMFE_ESTATE if no stitch is open): a gateway sizes C_raw_out from these, not from its caller */
 int cnmfe_stitch_finish(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out, int c_order);
 int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order);
@@ -317,6 +321,12 @@ int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const fl
  * matrices drop them on assignment (update_spatial_parallel.m:324-334).  Outputs sized for nnz(in) always suffice; *nnz_out = entries written. */
 int cnmfe_csc_drop_zeros(int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, const uint8_t *keep,
                          int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nnz_out);
+
+/* host helper: the CSC matrix (nrow x ncol, rows ascending per column) of n (row, column, value) triplets in any order -- the gathered rows of A after the spatial
+ * update (update_spatial_parallel.m:324-334: every patch writes its own disjoint rows of A_), assembled in one counting pass + a short sort per column instead of a
+ * sort of the whole list.  Outputs: out_colptr[ncol + 1], out_rowidx[n], out_val[n].  CNMFE_EINVAL on an index out of range or a (row, column) given twice. */
+int cnmfe_csc_from_triplets(int64_t n, const int32_t *rows, const int32_t *cols, const float *vals, int32_t ncol, int64_t nrow,
+                            int64_t *out_colptr, int32_t *out_rowidx, float *out_val);
 
 /* ---- objective: [RSS_total, RSS] = compute_RSS(obj)  (@Sources2D/Sources2D.m:1358-1510), ring model, bg_ssub = 1, one patch, all frames:
  *   RSS = sum((Y(patch,:) - A(patch,:)*C - (W*(Y_block - b0_block - A_prev*C_prev) + b0_new(patch))).^2)

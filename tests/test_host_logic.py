@@ -471,3 +471,21 @@ def test_lazy_host_traces_views_keep_the_pinned_block(monkeypatch):
     assert len(StubLib.freed) == 1
     for p in eng.pool:
         libc.free(p)
+
+
+def test_csc_from_triplets_native_helper():
+    """the assembly of the gathered rows of A (update_spatial_parallel.m:324-334) by the library's host helper equals scipy's COO -> CSC on disjoint triplets in
+    any order, and a pair given twice (patches are disjoint: it cannot happen) is an error, not a silent sum"""
+    from cnmf_e_amd.sources2d import _csc_from_triplets
+    rng = np.random.default_rng(4)
+    M = sp.random(3000, 120, density=0.02, format="coo", random_state=2, dtype=np.float32)
+    perm = rng.permutation(M.nnz)
+    A = _csc_from_triplets(M.row[perm], M.col[perm], M.data[perm], M.shape)
+    B = sp.csc_matrix(M); B.sort_indices()
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices) and np.array_equal(A.data, B.data)
+    E = _csc_from_triplets(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), (10, 4))
+    assert E.nnz == 0 and E.shape == (10, 4)
+    with pytest.raises(ValueError):
+        _csc_from_triplets(np.array([1, 1]), np.array([0, 0]), np.array([1.0, 2.0]), (5, 2))
+    with pytest.raises(ValueError):
+        _csc_from_triplets(np.array([7]), np.array([0]), np.array([1.0]), (5, 2))
