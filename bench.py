@@ -370,6 +370,8 @@ def main():
                 c0 = before.get(k, {"calls": 0, "total_ms": 0.0})
                 if v["calls"] > c0["calls"]:
                     r1_sep[k] = {"calls": v["calls"] - c0["calls"], "total_ms": v["total_ms"] - c0["total_ms"]}
+    if rank == 0 and os.environ.get("CNMFE_BENCH_DUMP"):       # (tests: the traces after the last step, to compare runs with different rank counts)
+        np.save(os.environ["CNMFE_BENCH_DUMP"], np.asarray(s.C))
     if world > 1:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")

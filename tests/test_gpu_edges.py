@@ -744,6 +744,33 @@ def test_bench_two_ranks_self_spawned_on_one_device():
     assert line["value"] > 0 and "c4tiny" in line["config"]["workload"]
 
 
+def test_bench_eight_ranks_full_size_c4_on_one_device():
+    """BASELINE configs[3] at FULL size through the code path of an 8-GPU run: `python bench.py --gpus 8 --config c4` spawns its eight ranks, each owns two of the
+    sixteen 128 x 128 patches of the 512 x 512 x 10000 video; on this one-GPU box they share cuda:0 and talk over gloo (CNMFE_BENCH_ONE_DEVICE=1).  What is checked:
+    the eight-rank run completes (all-gather of the spatial rows, sharded post-processing, the all-reduce of the 500 x 10000 stitch, lazy b0 reductions), reports
+    8 ranks, and every rank's traces agree with the one-rank run of the same configuration (the seconds of eight processes sharing a GPU mean nothing)."""
+    import json, subprocess
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs a 128+ GB GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CNMFE_BENCH_ONE_DEVICE"] = "1"; env["CNMFE_BENCH_R1"] = "0"
+    outs = {}
+    for n in (8, 1):
+        e = dict(env, CNMFE_BENCH_DUMP=os.path.join("/tmp", "cnmfe_c4_n%d.npy" % n))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "c4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                           env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == n and line["rccl_ranks"] == n and line["value"] > 0 and "c4: 512x512x10000" in line["config"]["workload"]
+        if n > 1:
+            assert line["backend"] == "gloo" and line["scaling"] == "strong"
+        outs[n] = np.load(e["CNMFE_BENCH_DUMP"])
+        os.remove(e["CNMFE_BENCH_DUMP"])
+    assert outs[8].shape == outs[1].shape == (500, 10000)
+    assert rel(outs[8], outs[1]) <= 1e-6, rel(outs[8], outs[1])          # (the stitch adds the patches' contributions in another order across ranks: fp32 re-association)
+
+
 def test_deconv_temporal_on_the_bound_matrix_equals_the_host_path(eng):
     """cnmfe_deconv_temporal_bound: the stitched C_raw deconvolved where it lies (C becomes the bound matrix, the five outputs arrive lazily in pinned
     memory) against cnmfe_deconv_temporal on the same values through host arrays -- bit for bit; afterwards a call that is handed the returned C passes

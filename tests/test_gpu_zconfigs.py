@@ -301,6 +301,20 @@ class BigCase:
         e = rel(np.asarray(s.C_raw)[grp], Crawr); obs[tag + "_C_method_rows"] = e; obs[tag + "_C_method_group"] = int(grp.size)
         assert e <= 5e-6, (tag, e, grp.size)
 
+    def check_temporal_rows_patched(self, idx, obs, tag):
+        """after a method-level temporal update of a PATCHED field of view: neurons whose footprint lies inside patch idx (no other patch contributes to their
+        stitched trace, update_temporal_parallel.m:269-280) must be non-negative with minimum 0 (:285) and reproduce the planted traces"""
+        v, s = self.video, self.s
+        A = sp.csc_matrix(s.A)
+        inside = np.zeros(self.d1 * self.d2, bool); inside[v.patch_pix[idx]] = True
+        ks = [k for k in range(A.shape[1]) if A.indptr[k + 1] > A.indptr[k] and inside[A.indices[A.indptr[k]:A.indptr[k + 1]]].all()]
+        assert len(ks) >= 3, len(ks)
+        Cr = np.asarray(s.C_raw)[ks]
+        assert np.all(np.abs(Cr.min(axis=1)) <= 1e-6 * np.abs(Cr).max(axis=1))
+        cc = [np.corrcoef(Cr[i], self.f.C_true[k])[0, 1] for i, k in enumerate(ks)]
+        obs[tag + "_patch_recovery"] = float(np.median(cc))
+        assert np.median(cc) > 0.98, np.median(cc)
+
     def check_temporal_patch(self, idx, obs, tag, deconv=False, maxIter=5):
         """the temporal update of ONE patch through the engine-level call against HALS_temporal.m on the engine's exported Ysig (R1 itself is
         checked on sampled rows above; here the 16384 x T product A' Ysig, A'A and the Gauss-Seidel sweeps at full length)"""
@@ -428,6 +442,39 @@ def test_c4_sixteen_patches_on_one_gpu(own_engine, observed):
     med, mn = _recovery(s, c.f)
     obs["recovery_median_min"] = [med, mn]; obs["rss"] = rss
     assert np.all(np.asarray(s.C) >= 0) and med > 0.98 and rss[1] <= rss[0] * (1 + 1e-6), (med, mn, rss)
+
+
+def test_c5_whole_on_one_gpu(own_engine, observed):
+    """BASELINE configs[4] WHOLE on one GPU: 1024 x 1024 x 20000 (uploaded as fp16, widened on the device), K = 2000, all 8 x 8 patches of
+    distribute_data.m resident at once (64 blocks with their halos: ~130 GB of centred video, ~35 GB of covariance tables).  Two iterations through the
+    method-level calls; an interior patch is checked stage by stage against the oracle on samples, the whole field of view through properties (finite,
+    non-negative traces, planted recovery, RSS not increasing)."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 250e9:
+        pytest.skip("needs a 288 GB GPU")
+    obs = observed.setdefault("c5_whole", {})
+    sample = {(3, 4)}
+    c = BigCase(own_engine, 1024, 1024, 20000, 2000, 15, 3, [128, 128], sample, upload_dtype="f16", spatial_algorithm="hals")
+    s, v = c.s, c.video
+    assert len(v.owned) == 64 and (v.nr_patch, v.nc_patch) == (8, 8)
+    idx = (3, 4)
+    W_old = orc.build_ring_W(v.patch_pos[idx], v.block_pos[idx], 1024, 1024, c.rs, c.cs)
+    for it in range(2):
+        A0, C0 = s.A.copy(), np.asarray(s.C).copy()
+        info = s.update_background_parallel()
+        if it == 0:
+            assert info[idx]["frame_stride"] == 2                # T = 20000 > 100 * pmax (fit_ring_model.m:84-87)
+        W_old = c.check_background(idx, A0, C0, W_old, 32, obs, "it%d" % it)
+        s.update_spatial_parallel()
+        c.check_spatial(idx, A0, C0, s.A_prev, s.C_prev, 256, obs, "it%d" % it)
+        s.update_temporal_parallel()
+        if it == 1:
+            c.check_temporal_rows_patched(idx, obs, "it%d" % it)
+    # (no compute_RSS here: it needs the background-subtracted video of every patch resident at once -- another 130 GB beside the 130 GB of video)
+    C = np.asarray(s.C)
+    med, mn = _recovery(s, c.f)
+    obs["recovery_median_min"] = [med, mn]
+    assert np.all(np.isfinite(C)) and np.all(C >= 0) and med > 0.98, (med, mn)
 
 
 def test_c5_one_rank_shard(own_engine, observed):
