@@ -328,11 +328,14 @@ def main():
         return
     fence()
     warm_steps_ms = []
+    first_tab = None
     for _ in range(a.warmup):                                   # every warm-up step fenced and timed on its own: the FIRST one is the cold iteration
         tw0 = time.perf_counter()
         step()
         fence()
         warm_steps_ms.append(1e3 * (time.perf_counter() - tw0))
+        if first_tab is None:
+            first_tab = eng.profile_table()
     warm_tab = eng.profile_table()
     # timed region: HIP events only around the kernels a roofline is quoted for (an event pair around EVERY launch costs host and device time per
     # launch -- 8 ms per iteration with the ~2000 small launches of c4, ~1 % at c3); the per-kernel breakdown comes from EXTRA steps after it
@@ -583,6 +586,8 @@ def main():
         **comm,
         "first_iteration": {"ms": warm_steps_ms[0] if warm_steps_ms else None, "warmup_steps_ms": [round(x, 3) for x in warm_steps_ms],
                             "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},
+                            "kernels_ms": None if first_tab is None else {k: round(v["total_ms"], 3) for k, v in sorted(first_tab.items(), key=lambda kv: -kv[1]["total_ms"])[:14] if v["calls"]},
+                            "kernel_sum_ms": None if first_tab is None else round(sum(v["total_ms"] for v in first_tab.values()), 3),
                             "note": "the FIRST step after the upload (timed on its own): its background fit also builds the block-pair covariance table of the video on "
                                     "the fp64 matrix pipe (kept until the video or the frame stride changes); `--warmup 0` puts it inside the timed region"},
         # a recording gets TWO background updates (demos/demo_large_data_1p.m:142,199): the mean of the first two steps from a fresh upload

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcnmfe_hip.so")
 SOURCES = ["api.hip", "resid.hip", "bg.hip", "factor.hip", "deconv.hip", "ssub.hip", "vproj.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CNMFE_EXTRA_FLAGS", "").split()   # (-D... of a variant build, scripts/build_variant.py)
 
 
 def _hipcc():

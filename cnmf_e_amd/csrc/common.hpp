@@ -176,7 +176,7 @@ struct Patch {
 };
 
 // device scratch of the OASIS kernels (deconv.hip): pool / task tables, grown on demand and kept with the context
-struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf; };
+struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf, tbuf; };
 
 // One patch's temporal update set up but not swept (cnmfe_hals_temporal_job): its projections, A'A lists and traces in buffers of its own, its
 // Gauss-Seidel level schedule on the host.  cnmfe_temporal_jobs_sweep then runs level l of EVERY job of the context in one launch -- the patches of a

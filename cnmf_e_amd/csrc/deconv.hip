@@ -16,7 +16,7 @@ namespace cnmfe {
 
 struct DeconvCfg {
     int T, P2, nfft, L, nov, nseg;     // trace length, pow2 >= T, Welch geometry
-    int ylong;                         // the trace lives in global memory (k_deconv<true>)
+    int ylong;                         // 1: the trace lives in global memory (k_deconv<true>); 2: and so do the Welch tables (T > 36868: nfft = 16384)
     int maxIter;                       // foopsi iterations (20 inside HALS_temporal, 10 in deconvTemporal)
     int optimize_b, optimize_g;
     double smin_opt, lam, gmax;
@@ -38,6 +38,7 @@ struct DeconvIO {
     double *tk_val;
     double *pnum;                      // per-pool numerators, T per trace slot
     float *ybuf, *obuf;                // long traces only: the raw trace and the output staging, Tal floats per trace slot each
+    float *tbuf = nullptr;             // ylong == 2 (nfft = 16384): the Welch twiddle / window tables, 2 nfft floats per trace slot
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red) {
@@ -115,11 +116,20 @@ __device__ void fft_lds(float *re, float *im, const float2 *tw, int n, int logn)
 // with `wintab`; k_sn_pixels does without to keep two workgroups per CU).
 // Two real segments ride one complex transform (z = a + i b): the Welch sum only needs |A_k|^2 + |B_k|^2 = (|Z_k|^2 + |Z_{n-k}|^2) / 2,
 // and the same expression is |A_k|^2 for an unpaired last segment (b = 0).
-__device__ double get_sn(const float *y, const DeconvCfg &c, float *scr, double *red, bool wintab) {
+struct Ysig4Acc {                                    // frame t of one pixel of a [T/4][npix] float4 video (+ a constant): no LDS copy of the trace
+    const float4 *base; int64_t npix; float add;
+    __device__ __forceinline__ float operator[](int t) const { return reinterpret_cast<const float *>(base + (int64_t)(t >> 2) * npix)[t & 3] + add; }
+};
+// `y` is anything indexable by the frame (a pointer into LDS or global memory, or an accessor of the 4-frame-interleaved video: Ysig4Acc below).
+// `tabs`: where the twiddle (nfft / 2 floats) and window (nfft floats) tables live -- nullptr: behind re | im in scr; a global buffer for recordings whose
+// transform (nfft = 16384: T > 36868) leaves no room for them in the 160 KB of LDS.
+template <class YT>
+__device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *red, bool wintab, float *tabs = nullptr) {
     const int tid = threadIdx.x;
     const int nfft = c.nfft, L = c.L, step = c.L - c.nov;
-    float *re = scr, *im = scr + nfft, *win = scr + 2 * nfft + nfft / 2;
-    float2 *tw = reinterpret_cast<float2 *>(scr + 2 * nfft);
+    float *tb = tabs ? tabs : scr + 2 * nfft;
+    float *re = scr, *im = scr + nfft, *win = tb + nfft / 2;
+    float2 *tw = reinterpret_cast<float2 *>(tb);
     int logn = 0; while ((1 << logn) < nfft) ++logn;
     const int k0 = (nfft + 3) / 4, k1 = nfft / 2;              // bins with 0.25 <= k/nfft <= 0.5
     const int nb = k1 - k0 + 1;
@@ -130,6 +140,7 @@ __device__ double get_sn(const float *y, const DeconvCfg &c, float *scr, double 
     double w2 = 0;
     for (int i = tid; i < L; i += 256) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; if (wintab) win[i] = (float)w; }
     for (int k = tid; k < nfft / 4; k += 256) { float sn_, cs_; sincospif(-(float)k / (float)(nfft / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
+    if (tabs) __threadfence_block();                 // (tables in global memory: written and read by this workgroup alone; block_sum's barriers order them)
     w2 = block_sum(w2, red);
     for (int sg = 0; sg < c.nseg; sg += 2) {
         const bool two = sg + 1 < c.nseg;
@@ -510,7 +521,8 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     const int Tal = (T + 3) & ~3;
     float *y = LONG ? io.ybuf + (int64_t)blockIdx.x * Tal : sm;          // T raw samples (fp32), persistent
     float *scr = LONG ? sm : sm + Tal;               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
-    const size_t scr_bytes = (size_t)(LONG ? 4 * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
+    const size_t scr_bytes = (size_t)(LONG ? (c.ylong == 2 ? 2 : 4) * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
+    float *tabs = (LONG && c.ylong == 2) ? io.tbuf + (int64_t)blockIdx.x * 2 * c.nfft : nullptr;      // nfft = 16384: the Welch tables do not fit beside re | im
     float *ostage = LONG ? io.obuf + (int64_t)blockIdx.x * Tal : scr;   // the solution c(t), before it is written out
     const int nc_pools = (int)(scr_bytes / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
@@ -572,7 +584,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     }
     __syncthreads();
     // ---- noise level (GetSn on the raw trace: HALS_temporal.m:79, deconvTemporal.m:45) ----
-    const double sn = get_sn(y, c, scr, red, true);
+    const double sn = get_sn(y, c, scr, red, true, tabs);
     // ---- time constant (deconvolveCa.m:73-89) ----
     double g = (double)io.pars[k];
     if (g == 0.0) {
@@ -617,7 +629,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         if (!optimize_g) break;                      // :113-115
         const double g0 = g;
         if (g > c.gmax) {                            // :104-108
-            const double sn2 = get_sn(y, c, scr, red, true);
+            const double sn2 = get_sn(y, c, scr, red, true, tabs);
             const double g2 = est_g(y, bsub, T, sn2, red);
             if (g2 >= -1.0) g = g2;
             if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
@@ -749,10 +761,51 @@ __global__ void __launch_bounds__(256) k_sn_pixels(DeconvCfg c, const float4 *__
     const double v = get_sn(y, c, scr, red, false);
     if (tid == 0) sn[m] = (float)v;
 }
+// Long recordings (trace + transform beyond 160 KB of LDS: T > 20400): the trace stays where it is -- the windowed segments are read out of the interleaved
+// video (every sample twice: the segments overlap by half) -- and LDS holds the transform alone; with nfft = 16384 (T > 36868) the twiddle table lives in a
+// per-workgroup slot of global memory.  `add`: the pixel mean for the RAW video (estimate_noise), nullptr / 0 for Ysig.
+__global__ void __launch_bounds__(256) k_sn_pixels_long(DeconvCfg c, const float4 *__restrict__ v4, int64_t npix, const float *__restrict__ add, float *__restrict__ tabs, float *__restrict__ sn) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red[4];
+    for (int64_t m = blockIdx.x; m < npix; m += gridDim.x) {
+        Ysig4Acc y{v4 + m, npix, add ? add[m] : 0.f};
+        const double v = get_sn(y, c, lds, red, false, tabs ? tabs + (int64_t)blockIdx.x * c.nfft : nullptr);
+        if (threadIdx.x == 0) sn[m] = (float)v;
+        __syncthreads();
+    }
+}
+// the per-pixel GetSn of a video of `npix` pixels ([T/4][npix] float4), the first T frames: picks the LDS-resident or the long flavour
+static int sn_pixels_launch(cnmfe_ctx *ctx, const char *name, const float4 *v4, int64_t npix, int64_t T, const float *add_mean, float *dSn) {
+    if (T < 64 || T > 73728) return fail(CNMFE_EUNSUPPORTED, "GetSn on the device supports 64 <= T <= 73728 frames (got %lld)", (long long)T);
+    DeconvCfg c{};
+    c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
+    c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
+    c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
+    c.nseg = (int)((T - c.nov) / (c.L - c.nov));
+    const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
+    if (shmem <= 160 * 1024 - 256) return 1;                                 // the LDS-resident kernels (the caller launches its own: raw video / Ysig differ in the load)
+    const bool tab_global = (2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float) > 160 * 1024 - 256;
+    const size_t sh = (tab_global ? 2 * (size_t)c.nfft : 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
+    const unsigned nwg = (unsigned)std::min<int64_t>(npix, 1024);
+    float *tabs = nullptr;
+    if (tab_global) { RET(ctx->dscr.tbuf.ensure((size_t)nwg * c.nfft * sizeof(float))); tabs = ctx->dscr.tbuf.as<float>(); }
+    if (sh > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels_long, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    LAUNCH(ctx, name, k_sn_pixels_long, dim3(nwg), dim3(256), sh, c, v4, npix, add_mean, tabs, dSn);
+    return 0;
+}
 
 int sn_pixels_run(cnmfe_ctx *ctx, Patch *P, float *sn_out) {
     const int64_t T = P->T;
-    if (T < 64 || T > 32768) return fail(CNMFE_EUNSUPPORTED, "GetSn on the device supports 64 <= T <= 32768 frames (got %lld)", (long long)T);
+    {   // long recordings: the transform alone in LDS
+        DevBuf &dSnL = ctx->tmp[14];
+        RET(dSnL.ensure((size_t)P->d * sizeof(float)));
+        const int rcl = sn_pixels_launch(ctx, "spatial_sn_pixels", P->ysig.as<float4>(), P->d, T, nullptr, dSnL.as<float>());
+        if (rcl < 0) return rcl;
+        if (rcl == 0) {
+            CK(hipMemcpyAsync(sn_out, dSnL.p, (size_t)P->d * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+            return ctx_check_errflag(ctx);
+        }
+    }
     DeconvCfg c{};
     c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
     c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
@@ -788,6 +841,17 @@ __global__ void __launch_bounds__(256) k_sn_video(DeconvCfg c, const float4 *__r
 int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out) {
     const int64_t T = nframes;
     if (T < 64 || T > P->T) return fail(CNMFE_EUNSUPPORTED, "estimate_noise on the device supports 64 <= frames <= T (got %lld of %lld)", (long long)T, (long long)P->T);
+    {
+        DevBuf &dSnL = ctx->tmp[14];
+        RET(dSnL.ensure((size_t)P->d_b * sizeof(float)));
+        const int rcl = sn_pixels_launch(ctx, "estimate_noise", P->Yc4.as<float4>(), P->d_b, T, P->ymean_f.as<float>(), dSnL.as<float>());
+        if (rcl < 0) return rcl;
+        if (rcl == 0) {
+            CK(hipMemcpyAsync(sn_out, dSnL.p, (size_t)P->d_b * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+            CK(hipStreamSynchronize(ctx->st()));
+            return 0;
+        }
+    }
     DeconvCfg c{};
     c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
     c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
@@ -809,7 +873,7 @@ int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out) {
 int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg &c, size_t &shmem) {
     if (!o) return fail(CNMFE_EINVAL, "null deconvolution options");
     if (o->type != 1 || o->method != 1) return fail(CNMFE_EUNSUPPORTED, "only type 'ar1' / method 'foopsi' is built (demo_large_data_1p.m:38-43)");
-    if (T < 64 || T > 36868) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= 36868 frames (got %lld)", (long long)T);
+    if (T < 64 || T > 73728) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= 73728 frames (got %lld)", (long long)T);
     c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
     c.L = (int)(T / 4.5); c.nov = c.L / 2;
     c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
@@ -825,7 +889,11 @@ int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg 
     if (shmem > 160 * 1024 - 256) {                  // long recording: trace and output staging in global memory, LDS = the scratch alone
         c.ylong = 1;
         shmem = 4 * (size_t)c.nfft * sizeof(float);
-        if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames: the Welch transform (nfft = %d) does not fit the deconvolution kernel's LDS (T <= 36868)", (long long)T, c.nfft);
+        if (shmem > 160 * 1024 - 256) {              // nfft = 16384 (36868 < T <= 73728): re | im alone in LDS (128 KB), the twiddle / window tables in global memory
+            c.ylong = 2;
+            shmem = 2 * (size_t)c.nfft * sizeof(float);
+        }
+        if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames: the Welch transform (nfft = %d) does not fit the deconvolution kernel's LDS (T <= 73728)", (long long)T, c.nfft);
     }
     return 0;
 }
@@ -845,6 +913,7 @@ int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const
         const size_t Tal = ((size_t)T + 3) & ~size_t(3);
         RET(s.ybuf.ensure((size_t)n * Tal * 4)); RET(s.obuf.ensure((size_t)n * Tal * 4));
         io.ybuf = s.ybuf.as<float>(); io.obuf = s.obuf.as<float>();
+        if (c.ylong == 2) { RET(s.tbuf.ensure((size_t)n * 2 * c.nfft * 4)); io.tbuf = s.tbuf.as<float>(); }
         if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<true>, dim3(n), dim3(256), shmem, c, io);
         return 0;

@@ -198,6 +198,12 @@ int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_ord
 // radius sits in LDS as a dense (16 + 2R)^2 window; B(j) = A(j) - sum_i W(j - o_i, i) A(j - o_i) then costs p LDS reads and a weight load per non-zero hit.
 // Table layout: Bt[((g16[b] + slot / 16) * 256 + px) * 16 + slot % 16] -- per block and group of 16 list slots a [pixel][16] panel, what the projection's
 // A operand reads with one conflict-free LDS access per lane.
+#ifndef VP_AH
+#define VP_AH 8
+#endif
+#ifndef VP_WG_TARGET
+#define VP_WG_TARGET 2048
+#endif
 constexpr int VP_WS = 64;                                   // window side: 16 + 2 * 24
 __global__ void __launch_bounds__(256) k_vp_build_b(const int *__restrict__ ent_blk, const int *__restrict__ ent_k, const int *__restrict__ ent_slot, const int *__restrict__ g16,
                                                     BgGeom g, int R, const int64_t *__restrict__ colptr, const int *__restrict__ erow, const float *__restrict__ aval,
@@ -283,7 +289,7 @@ __global__ void __launch_bounds__(256) k_vp_proj_b(const float4 *__restrict__ Y4
             rb = rb < g.nr_b ? rb : g.nr_b - 1; cb = cb < g.nc_b ? cb : g.nc_b - 1;
             return (int64_t)cb * g.nr_b + rb;
         };
-        constexpr int AH = 8;                              // loads in flight per lane
+        constexpr int AH = VP_AH;                          // loads in flight per lane
         float4 y[AH];
 #pragma unroll
         for (int u = 0; u < AH; ++u) y[u] = yb[qof(u)];
@@ -397,7 +403,7 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
         const int total = (int)blall.size();
         // frame segments: enough workgroups to fill the chip a few times over, each at least a few chunk groups per wave
         const int64_t ncg = ((P->Tc + 15) >> 4);
-        int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((ncg + 7) / 8, (2048 + total - 1) / std::max(1, total)));
+        int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((ncg + 7) / 8, (VP_WG_TARGET + total - 1) / std::max(1, total)));
         const size_t shmem = (size_t)(t + 1) * BLKPX * 16 * sizeof(double);
 #define VP_GO(NT_) do { if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
             LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->Yc4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \

@@ -469,10 +469,11 @@ def test_deconv_without_the_optimisation_loops(eng):
         assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 1
 
 
-@pytest.mark.parametrize("T", [18000, 24000])
+@pytest.mark.parametrize("T", [18000, 24000, 50000])
 def test_deconv_long_traces(eng, T):
     """T = 18000: trace (72 KB) + scratch (72 KB) is the largest image k_deconv<false> keeps in LDS; T = 24000 runs k_deconv<true> (trace and
-    output staging in global memory, LDS = the Welch transform's scratch).  Beyond nfft = 8192 (T > 36868) the call is refused."""
+    output staging in global memory, LDS = the Welch transform's scratch); T = 50000 (round 4: nfft = 16384) also keeps the Welch twiddle / window tables in
+    global memory, LDS = re | im alone.  Beyond nfft = 16384 (T > 73728) the call is refused (deconvolveCa.m:61 / GetSn.m:33 take any T)."""
     import oasis_oracle as oo
     from cnmf_e_amd._lib import CnmfeError
     Y = _ar1_traces(2, T, seed=21, rate=0.004)
@@ -485,7 +486,30 @@ def test_deconv_long_traces(eng, T):
     assert rel(Cg[0], Cr[0]) <= 2e-5 and rel(Crawg[0], Crawr[0]) <= 2e-5
     assert abs((Sg[0] > 0).sum() - (Sr[0] > 0).sum()) <= 1
     with pytest.raises(CnmfeError):
-        eng.deconv_temporal(np.zeros((1, 40000), np.float32), opts)
+        eng.deconv_temporal(np.zeros((1, 80000), np.float32), opts)
+
+
+@pytest.mark.parametrize("T", [24000, 50000])
+def test_get_sn_of_long_recordings(eng, T):
+    """per-pixel GetSn (update_spatial_parallel.m:191-194, Sources2D.m:328-379 -> GetSn.m:33-47) beyond the 20400 frames a trace + its Welch transform fit the
+    LDS with: the segments are read out of the interleaved video, the transform alone sits in LDS (T = 50000: nfft = 16384, twiddles in global memory).  Both
+    flavours -- the raw video (estimate_noise) and the background-subtracted one (update_sn) -- against the oracle's GetSn on the same rows."""
+    import oasis_oracle as oo
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo
+    d1, d2, r = 12, 10, 3
+    f = synth.make_factors(d1, d2, T, 2, 71, gSig=1.5, gSiz=5, min_sep=4)
+    Y = synth.make_video(f, np.float32)
+    video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
+    video.upload_from_full(Y)
+    eng.ring_init(0, r)
+    raw = eng.estimate_noise(0, T)
+    ref_raw = np.array([oo.GetSn(Y[:, m].astype(np.float64)) for m in range(0, d1 * d2, 7)])
+    assert np.max(np.abs(raw[::7] - ref_raw) / ref_raw) <= 2e-4
+    Ysig = eng.residual(0, None, None, want=True)
+    got = eng.get_sn(0)
+    ref = np.array([oo.GetSn(Ysig[:, m].astype(np.float64)) for m in range(0, d1 * d2, 7)])
+    assert np.max(np.abs(got[::7] - ref) / ref) <= 2e-4
 
 
 def test_data_plane_uint16_tiff_to_device(eng, tmp_path):
