@@ -83,6 +83,7 @@ PROTOTYPES = {
     "cnmfe_csc_drop_zeros": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "cnmfe_update_spatial_fetch_async": (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "cnmfe_ticket_wait": (C.c_int, [c_ctx, C.c_int64]),
+    "cnmfe_update_spatial_fetch_connected_async": (C.c_int, [c_ctx, C.c_int32, C.c_int32, C.c_int32, i64p, i32p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "cnmfe_hals_temporal_job": (C.c_int, [c_ctx, C.c_int, C.c_int32, i64p, i32p, f32p, f32p, C.c_int, C.c_int32, C.POINTER(DeconvOpts), f32p, i32p]),
     "cnmfe_temporal_jobs_sweep": (C.c_int, [c_ctx]),
     "cnmfe_stitch_add_job": (C.c_int, [c_ctx, C.c_int32, C.c_int32, i32p]),

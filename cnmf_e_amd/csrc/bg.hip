@@ -777,11 +777,47 @@ static double matlab_quantile(std::vector<int> x, double q) {
     return x[lo - 1] + (r - (double)lo) * (double)(x[lo] - x[lo - 1]);
 }
 
+// active & E / active & ~E (active == nullptr: every pixel)
+__global__ void __launch_bounds__(256) k_split_active(const unsigned char *__restrict__ active, const unsigned char *__restrict__ E, int64_t d,
+                                                      unsigned char *__restrict__ outE, unsigned char *__restrict__ outL) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= d) return;
+    const unsigned char a = active ? active[m] : (unsigned char)1, e = E[m];
+    outE[m] = a & e; outL[m] = a & (unsigned char)(e ^ 1);
+}
+
+static int solve_launch(cnmfe_ctx *ctx, Patch *P, const CovTab &tab, const BgGeom &g, const double *rowsum, const unsigned char *act, int nt, int probe, const double *fill) {
+    int *dErr = nullptr;
+    RET(ctx_errflag(ctx, &dErr));
+    // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp).  Measured and removed (profiles/r02/solve_ab_c3.txt): the
+    // panel-blocked LDS solver (22.5 ms against 8.0) and the looped-block-column variant (10.6 ms: it spills ~200 tile registers)
+#define RS5_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), rowsum, act, P->W.as<float>(), dErr, probe, fill); break;
+    switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
+#undef RS5_CASE
+    return 0;
+}
+
+struct WArgs { CovTab tab; BgGeom g; const double *rowsum, *fill; int nt, probe; };
+int w_finish(cnmfe_ctx *ctx, Patch *P) {
+    if (!P->w_pending) return 0;
+    P->w_pending = false;
+    if (P->w_blob.size() != sizeof(WArgs)) return fail(CNMFE_ESTATE, "pending ring solve without its arguments");
+    WArgs a; memcpy(&a, P->w_blob.data(), sizeof(a));
+    RET(solve_launch(ctx, P, a.tab, a.g, a.rowsum, P->w_maskL.as<unsigned char>(), a.nt, a.probe, a.fill));
+    return ring_stats_enqueue(ctx, P);                       // what the NEXT fit of this patch asks of the (now complete) W
+}
+int w_finish_all(cnmfe_ctx *ctx) {
+    for (auto &kv : ctx->patches) RET(w_finish(ctx, kv.second));
+    return 0;
+}
+
 // The large buffers of the ring fit, allocated when the ring is set (cnmfe_ring_init: once per patch, after the upload) instead of inside the first fit: the
 // video's covariance table, the context's working table, the tiled Bf and the window projection's partial sums -- 18 GB at the headline size.  A fit then
 // queues its kernels without a hipMalloc in between (tens of milliseconds of the first iteration, and on some boxes the dispatch behind a fresh multi-GB
 // allocation stalled for 0.5-0.8 s, profiles/r03/README.md).  Sizes follow the geometry only; a buffer that is already large enough is left alone.
 int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
+    RET(w_finish_all(ctx));                                  // (a pending half solve reads the context's tables: they may be re-allocated below)
     if (ctx->opt("gram_incremental", 1) == 0 || P->p <= 0) return 0;
     int p_radius = 0;
     for (int i = 0; i < P->p; ++i) p_radius = std::max(p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
@@ -813,6 +849,7 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only, double thresh_outlier) {
     HostTrace ht(ctx, "fit_ring");
+    RET(w_finish_all(ctx));                                  // a half solve still pending (of this or another patch) reads the tables this fit rewrites, and W_old must be complete
     const bool outl = thresh_outlier == thresh_outlier;      // ~isnan(thresh_outlier), :50
     if (outl && !P->sn_ready && !(b0_only & 1)) return fail(CNMFE_ESTATE, "fit_ring_model with thresh_outlier needs the noise levels of the block (cnmfe_set_noise)");
     const int64_t T = P->T;
@@ -1189,24 +1226,55 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
         LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());
         tab.wcodes = dWcodes.as<int>(); tab.woff = woff;
-        int *dErr = nullptr;
-        RET(ctx_errflag(ctx, &dErr));
         const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();
         const int probe = (int)ctx->opt("solve_probe", 0);
         const int nt = (p + 15) / 16;
         if (nt < 1 || nt > 8) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
-        // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp).  Measured and removed (profiles/r02/solve_ab_c3.txt): the
-        // panel-blocked LDS solver (22.5 ms against 8.0) and the looped-block-column variant (10.6 ms: it spills ~200 tile registers)
-        {
-            DevBuf &dFill = ctx->solve_fill;                 // the fill values {0, 1} of missing neighbours, in global memory (ring_solve.hpp)
-            const double fillv[2] = {0.0, 1.0};
-            RET(to_dev(ctx, dFill, fillv, 2));
-#define RS5_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErr, probe, dFill.as<double>()); break;
-            switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
-#undef RS5_CASE
+        DevBuf &dFill = ctx->solve_fill;                     // the fill values {0, 1} of missing neighbours, in global memory (ring_solve.hpp)
+        const double fillv[2] = {0.0, 1.0};
+        RET(to_dev(ctx, dFill, fillv, 2));
+        // ---- the solve in two halves: E = the pixels within SOLVE_DE of a footprint's bounding box (what the next spatial update's masks read) now, the others
+        // when the first reader of the whole W comes along (w_finish) -- the one fitted full-resolution patch of a context only: the tables are the context's
+        bool split = false;
+        if (has_a && !P->derived && !b0_out && ctx->opt("solve_defer", 1) != 0) {
+            int nfit = 0;
+            for (auto &kv : ctx->patches) nfit += kv.second->ring_ready && !kv.second->derived;
+            if (nfit == 1) {
+                constexpr int SOLVE_DE = 12;
+                std::vector<uint8_t> &E = P->w_emask_h;
+                E.assign((size_t)P->d, 0);
+                for (int k = 0; k < K; ++k) {
+                    if (A_colptr[k + 1] == A_colptr[k]) continue;
+                    int r0 = 1 << 30, r1 = -1, c0 = 1 << 30, c1 = -1;
+                    for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
+                        const int q = A_rowidx[e], rb = q % P->nr_b, cb = q / P->nr_b;
+                        r0 = std::min(r0, rb); r1 = std::max(r1, rb); c0 = std::min(c0, cb); c1 = std::max(c1, cb);
+                    }
+                    const int pr0 = std::max(0, r0 - SOLVE_DE - P->roff), pr1 = std::min(P->nr - 1, r1 + SOLVE_DE - P->roff);
+                    const int pc0 = std::max(0, c0 - SOLVE_DE - P->coff), pc1 = std::min(P->nc - 1, c1 + SOLVE_DE - P->coff);
+                    for (int c = pc0; c <= pc1; ++c)
+                        if (pr1 >= pr0) memset(&E[(size_t)c * P->nr + pr0], 1, (size_t)(pr1 - pr0 + 1));
+                }
+                int64_t nE = 0;
+                for (uint8_t v : E) nE += v;
+                split = nE > 0 && nE <= (int64_t)(0.85 * P->d);        // (a field of view covered by footprints: nothing worth deferring)
+                if (split) {
+                    DevBuf &dE = ctx->tmp[14];
+                    RET(to_dev(ctx, dE, E.data(), E.size()));
+                    RET(P->w_maskE.ensure((size_t)P->d)); RET(P->w_maskL.ensure((size_t)P->d));
+                    LAUNCH(ctx, "bg_split_active", k_split_active, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, act, dE.as<unsigned char>(), P->d,
+                           P->w_maskE.as<unsigned char>(), P->w_maskL.as<unsigned char>());
+                }
+            }
+        }
+        RET(solve_launch(ctx, P, tab, g, ctx->rowsum.as<double>(), split ? P->w_maskE.as<unsigned char>() : act, nt, probe, dFill.as<double>()));
+        if (split) {
+            WArgs a; a.tab = tab; a.g = g; a.rowsum = ctx->rowsum.as<double>(); a.fill = dFill.as<double>(); a.nt = nt; a.probe = probe;
+            P->w_blob.resize(sizeof(WArgs)); memcpy(P->w_blob.data(), &a, sizeof(a));
+            P->w_pending = true; P->stat_valid = false;
         }
     }
+    if (!P->w_pending)
     RET(ring_stats_enqueue(ctx, P));                         // what the NEXT fit of this patch asks of the W being written now
     ht.mark("solve launch");
     if (b0_out) {

@@ -133,7 +133,7 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
     int logn = 0; while ((1 << logn) < nfft) ++logn;
     const int k0 = (nfft + 3) / 4, k1 = nfft / 2;              // bins with 0.25 <= k/nfft <= 0.5
     const int nb = k1 - k0 + 1;
-    constexpr int MAXB = 16;                                   // bins per thread (nfft <= 16384)
+    constexpr int MAXB = 17;                                   // bins per thread: nfft / 4 + 1 bins over 256 threads (nfft <= 16384: 4097 bins)
     float acc[MAXB];
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) acc[i] = 0.f;

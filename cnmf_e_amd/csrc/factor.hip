@@ -880,7 +880,7 @@ static int postproc_boxes(int32_t d1, int32_t d2, int32_t K, const int64_t *A_co
 // The connectivity constraint on the result of a deferred spatial update WHERE IT LIES (scr[0], scr[1], scr[6]: the mask's CSC pattern and the new
 // values, explicit zeros included -- they are zero pixels of the footprint image either way): valid when the patch is the whole field of view, so
 // that patch rows are FOV pixels.  One wait, one download of values + keep flags; no second upload of A.
-int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx, float *A_out, uint8_t *keep) {
+int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx, float *A_out, uint8_t *keep, bool wait) {
     const int64_t nnz = IND_colptr[K];
     if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
     if (nnz == 0) return 0;
@@ -895,7 +895,7 @@ int spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, c
            dBox.as<int4>(), d1, d2, dKeep.as<unsigned char>());
     CK(hipMemcpyAsync(A_out, dAval.p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     CK(hipMemcpyAsync(keep, dKeep.p, (size_t)nnz, hipMemcpyDeviceToHost, ctx->st()));
-    return ctx_check_errflag(ctx);
+    return wait ? ctx_check_errflag(ctx) : 0;                // (no wait: the caller records a ticket behind the copies, cnmfe_update_spatial_fetch_connected_async)
 }
 
 static int postproc_boxes(int32_t d1, int32_t d2, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, std::vector<int4> &box) {

@@ -437,6 +437,20 @@ class Engine:
                 M = sp.csc_matrix((oval[:n.value], orow[:n.value], optr), shape=(info["d"], K))
                 M.has_canonical_format = True                            # (sorted rows, no duplicates: the mask's pattern was canonical)
                 return M
+            def start_connected(connected_fov):
+                """queue the connectivity constraint + the downloads of (values, keep flags) into pinned memory now; fetch(connected_fov=...) then only waits for them"""
+                if out.size == 0 or "c" in pend or "t" in pend:
+                    return
+                nb = 1 << max(12, int(out.size * 5 - 1).bit_length())
+                ptr = self._pinned_take(nb)
+                tk = C.c_int64(0)
+                try:
+                    L.check(L.lib.cnmfe_update_spatial_fetch_connected_async(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
+                                                                             ptr, ptr + out.size * 4, C.byref(tk)))
+                except Exception:
+                    self._pinned_give(ptr, nb)
+                    raise
+                pend["c"] = (tk.value, ptr, nb)
             def fetch(connected_fov=None, compact=False):
                 """connected_fov = (d1, d2): the patch is the whole field of view -- also apply the connectivity constraint on the device and
                 return (A_raw, A) instead of A_raw.  compact: without the stored zeros of the mask pattern (rows sorted); with connected_fov, A_raw then comes as a
@@ -453,14 +467,24 @@ class Engine:
                         L.check(L.lib.cnmfe_update_spatial_fetch(self._ctx, _p(out, L.f32p), int(out.size)))
                     return compacted(out) if compact else sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 keep = np.zeros(out.size, dtype=np.uint8)
-                L.check(L.lib.cnmfe_update_spatial_fetch_connected(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
-                                                                   _p(out, L.f32p), _p(keep, L.u8p)))
+                if "c" in pend:
+                    tk, ptr, nb = pend.pop("c")
+                    try:
+                        L.check(L.lib.cnmfe_ticket_wait(self._ctx, tk))
+                        C.memmove(out.ctypes.data, ptr, out.size * 4)
+                        C.memmove(keep.ctypes.data, ptr + out.size * 4, out.size)
+                    finally:
+                        self._pinned_give(ptr, nb)
+                else:
+                    L.check(L.lib.cnmfe_update_spatial_fetch_connected(self._ctx, int(connected_fov[0]), int(connected_fov[1]), K, _p(icp, L.i64p), _p(iri, L.i32p),
+                                                                       _p(out, L.f32p), _p(keep, L.u8p)))
                 if compact:                                  # the raw update (obj.A before post-processing) is compacted when somebody reads it: nothing in the iteration does
                     return (lambda: compacted(out)), compacted(out, keep)
                 A_raw = sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
                 A_pp = sp.csc_matrix((out * keep, iri.copy(), icp.copy()), shape=(info["d"], K))
                 return A_raw, A_pp
             fetch.start = start
+            fetch.start_connected = start_connected
             return fetch
         return sp.csc_matrix((out, iri.copy(), icp.copy()), shape=(info["d"], K))
 

@@ -962,14 +962,19 @@ class Sources2D:
                                                    sn_patch if o.spatial_algorithm == "hals_thresh" else None, param, defer=True)
                 whole = pp.size == v.d1 * v.d2 and ind.size == K
                 late = not whole and hasattr(fetch, "start")
+                whole_conn = (whole and o.spatial_constraints.get("connected", True) and (self.dist is None or (v.world_size == 1 and not self.force_collectives)))
                 if late:
                     # several patches: the download is queued right behind the sweeps and collected `spatial_lag` patches LATE -- a patch's values are assembled
                     # on the host while the next patch's kernels, queued first, keep the device busy (a fetch per patch drained the stream 16 times per update)
                     fetch.start()
+                elif whole_conn and hasattr(fetch, "start_connected"):
+                    # one patch = the field of view: the connectivity kernel and the downloads are queued NOW, so that what the temporal update's residual request
+                    # starts on the device (the deferred half of the ring solve, the W*A_prev tables) runs behind them, under the host's assembly of A
+                    fetch.start_connected((v.d1, v.d2))
                 self._temporal_residual_early(idx)                       # host work under the sweeps
                 if nxt is not None:
                     ahead = (prev_of(nxt), masks_of(nxt))                # ... and the slices of the next patch
-                if whole and o.spatial_constraints.get("connected", True) and (self.dist is None or (v.world_size == 1 and not self.force_collectives)):
+                if whole_conn:
                     # one patch = the field of view: post_process_spatial's connectivity constraint (:341) runs on the result where it lies
                     # (the engine's fetch: A without stored zeros, rows sorted, and the raw update as a recipe -- see the early return below)
                     Anew, whole_pp = fetch(connected_fov=(v.d1, v.d2), **({"compact": True} if hasattr(fetch, "start") else {}))

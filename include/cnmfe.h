@@ -212,6 +212,12 @@ int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket);
 int cnmfe_update_spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx,
                                          float *A_out, uint8_t *keep_out);
 
+/* the connected fetch without the wait: the connectivity kernel and the two copies into PINNED memory (cnmfe_host_alloc) are queued, *ticket names the point of
+ * the stream where they are complete (cnmfe_ticket_wait).  The host mirror queues the temporal update's residual request behind it -- whatever that request starts
+ * on the device (the deferred half of the ring solve, the W*A_prev tables) then runs while the host turns the result into the next call's A. */
+int cnmfe_update_spatial_fetch_connected_async(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                                               float *A_out_pinned, uint8_t *keep_out_pinned, int64_t *ticket);
+
 /* ---- fast_temporal (use_c_hat = false)                @Sources2D/update_temporal_parallel.m:174-175,314-337
  *   tmp_A = A .* (A ./ max(A,[],1) >= 0.5);  aa = sum(tmp_A.^2,1);  C_raw = (tmp_A' * Ysig) ./ aa'
  * (rows with aa == 0 are 0 and report aa = 0).  A is d x K CSC over PATCH rows; Ysig = the resident
