@@ -1240,7 +1240,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             int nfit = 0;
             for (auto &kv : ctx->patches) nfit += kv.second->ring_ready && !kv.second->derived;
             if (nfit == 1) {
-                constexpr int SOLVE_DE = 12;
+                // E: per footprint the disc around its bounding box' centre that reaches SOLVE_DE pixels beyond the box -- the 'ellipse' search masks of
+                // determine_search_location.m:57-89 (semi-axes 9..24 pixels about the centre of mass) of compact footprints stay inside; a mask that does not
+                // (checked on the host against this very map, vproj.hip) simply triggers the second half early
+                constexpr int SOLVE_DE = 4;
                 std::vector<uint8_t> &E = P->w_emask_h;
                 E.assign((size_t)P->d, 0);
                 for (int k = 0; k < K; ++k) {
@@ -1250,10 +1253,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                         const int q = A_rowidx[e], rb = q % P->nr_b, cb = q / P->nr_b;
                         r0 = std::min(r0, rb); r1 = std::max(r1, rb); c0 = std::min(c0, cb); c1 = std::max(c1, cb);
                     }
-                    const int pr0 = std::max(0, r0 - SOLVE_DE - P->roff), pr1 = std::min(P->nr - 1, r1 + SOLVE_DE - P->roff);
-                    const int pc0 = std::max(0, c0 - SOLVE_DE - P->coff), pc1 = std::min(P->nc - 1, c1 + SOLVE_DE - P->coff);
-                    for (int c = pc0; c <= pc1; ++c)
+                    const double cr = 0.5 * (r0 + r1) - P->roff, cc = 0.5 * (c0 + c1) - P->coff, rad = 0.5 * std::max(r1 - r0, c1 - c0) + SOLVE_DE + 0.5;
+                    const int pc0 = std::max(0, (int)std::ceil(cc - rad)), pc1 = std::min(P->nc - 1, (int)std::floor(cc + rad));
+                    for (int c = pc0; c <= pc1; ++c) {
+                        const double hh = std::sqrt(std::max(0.0, rad * rad - (c - cc) * (c - cc)));
+                        const int pr0 = std::max(0, (int)std::ceil(cr - hh)), pr1 = std::min(P->nr - 1, (int)std::floor(cr + hh));
                         if (pr1 >= pr0) memset(&E[(size_t)c * P->nr + pr0], 1, (size_t)(pr1 - pr0 + 1));
+                    }
                 }
                 int64_t nE = 0;
                 for (uint8_t v : E) nE += v;

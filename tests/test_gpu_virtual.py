@@ -200,11 +200,13 @@ def test_virtual_spatial_update_with_changed_traces_builds_its_own_table(eng):
 
 
 @pytest.mark.parametrize("dims,r", [((96, 80), 15), ((110, 90), 5)])
-def test_deferred_half_of_the_ring_solve(eng, dims, r):
+def test_deferred_half_of_the_ring_solve(dims, r):
     """the ring solve in two halves (bg.hip, w_finish): the fit solves the pixels near footprints, the others when the first reader of the whole W comes along --
     the same W bit for bit as the one-launch solve, whoever that reader is (a CSR export, the next fit, a residual with footprints, the temporal projection), and
     a spatial update whose masks stay inside the solved pixels does not trigger it"""
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    from cnmf_e_amd.engine import Engine
+    eng = Engine(0)                                           # (a context with ONE fitted patch: the halves share the context's tables)
     d1, d2 = dims
     T, K = 200, 4
     f, Y, video = _setup(eng, d1, d2, T, K, r, 81)
@@ -249,5 +251,4 @@ def test_deferred_half_of_the_ring_solve(eng, dims, r):
         assert np.array_equal(eng.ring_csr(0).data, w_ref3)
         assert np.array_equal(w_csr, w_ref3)                      # (the third fit of the same inputs, read through the CSR export while its second half was pending)
     finally:
-        eng.set_option("solve_defer", 1)
-        eng.bind_traces(None)
+        eng.close()
