@@ -777,34 +777,28 @@ static double matlab_quantile(std::vector<int> x, double q) {
     return x[lo - 1] + (r - (double)lo) * (double)(x[lo] - x[lo - 1]);
 }
 
-// active & E / active & ~E (active == nullptr: every pixel)
-__global__ void __launch_bounds__(256) k_split_active(const unsigned char *__restrict__ active, const unsigned char *__restrict__ E, int64_t d,
-                                                      unsigned char *__restrict__ outE, unsigned char *__restrict__ outL) {
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= d) return;
-    const unsigned char a = active ? active[m] : (unsigned char)1, e = E[m];
-    outE[m] = a & e; outL[m] = a & (unsigned char)(e ^ 1);
-}
-
-static int solve_launch(cnmfe_ctx *ctx, Patch *P, const CovTab &tab, const BgGeom &g, const double *rowsum, const unsigned char *act, int nt, int probe, const double *fill) {
+static int solve_launch(cnmfe_ctx *ctx, Patch *P, const CovTab &tab, const BgGeom &g, const double *rowsum, const unsigned char *act, int nt, int probe, const double *fill,
+                        const int *pix = nullptr, int64_t npix = -1) {
+    if (npix == 0) return 0;
+    const unsigned ngrid = (unsigned)(pix ? npix : P->d);
     int *dErr = nullptr;
     RET(ctx_errflag(ctx, &dErr));
     // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp).  Measured and removed (profiles/r02/solve_ab_c3.txt): the
     // panel-blocked LDS solver (22.5 ms against 8.0) and the looped-block-column variant (10.6 ms: it spills ~200 tile registers)
-#define RS5_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_>), dim3((unsigned)P->d), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), rowsum, act, P->W.as<float>(), dErr, probe, fill); break;
+#define RS5_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve5<NT_>), dim3(ngrid), dim3(64), 0, tab, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), rowsum, act, P->W.as<float>(), dErr, probe, pix, fill); break;
     switch (nt) { RS5_CASE(1) RS5_CASE(2) RS5_CASE(3) RS5_CASE(4) RS5_CASE(5) RS5_CASE(6) RS5_CASE(7) RS5_CASE(8) default: break; }
 #undef RS5_CASE
     return 0;
 }
 
-struct WArgs { CovTab tab; BgGeom g; const double *rowsum, *fill; int nt, probe; };
+struct WArgs { CovTab tab; BgGeom g; const double *rowsum, *fill; const unsigned char *act; int nt, probe; int64_t nE, nL; };
 int w_finish(cnmfe_ctx *ctx, Patch *P) {
     if (!P->w_pending) return 0;
     P->w_pending = false;
     if (P->w_blob.size() != sizeof(WArgs)) return fail(CNMFE_ESTATE, "pending ring solve without its arguments");
     WArgs a; memcpy(&a, P->w_blob.data(), sizeof(a));
-    RET(solve_launch(ctx, P, a.tab, a.g, a.rowsum, P->w_maskL.as<unsigned char>(), a.nt, a.probe, a.fill));
+    RET(solve_launch(ctx, P, a.tab, a.g, a.rowsum, a.act, a.nt, a.probe, a.fill, P->w_maskL.as<int>(), a.nL));
     return ring_stats_enqueue(ctx, P);                       // what the NEXT fit of this patch asks of the (now complete) W
 }
 int w_finish_all(cnmfe_ctx *ctx) {
@@ -1236,6 +1230,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // ---- the solve in two halves: E = the pixels within SOLVE_DE of a footprint's bounding box (what the next spatial update's masks read) now, the others
         // when the first reader of the whole W comes along (w_finish) -- the one fitted full-resolution patch of a context only: the tables are the context's
         bool split = false;
+        int64_t nE = -1, nL = 0;
         if (has_a && !P->derived && !b0_out && ctx->opt("solve_defer", 1) != 0) {
             int nfit = 0;
             for (auto &kv : ctx->patches) nfit += kv.second->ring_ready && !kv.second->derived;
@@ -1261,21 +1256,25 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                         if (pr1 >= pr0) memset(&E[(size_t)c * P->nr + pr0], 1, (size_t)(pr1 - pr0 + 1));
                     }
                 }
-                int64_t nE = 0;
-                for (uint8_t v : E) nE += v;
-                split = nE > 0 && nE <= (int64_t)(0.85 * P->d);        // (a field of view covered by footprints: nothing worth deferring)
-                if (split) {
-                    DevBuf &dE = ctx->tmp[14];
-                    RET(to_dev(ctx, dE, E.data(), E.size()));
-                    RET(P->w_maskE.ensure((size_t)P->d)); RET(P->w_maskL.ensure((size_t)P->d));
-                    LAUNCH(ctx, "bg_split_active", k_split_active, dim3((unsigned)((P->d + 255) / 256)), dim3(256), 0, act, dE.as<unsigned char>(), P->d,
-                           P->w_maskE.as<unsigned char>(), P->w_maskL.as<unsigned char>());
+                static thread_local std::vector<int> lE, lL;
+                lE.clear(); lL.clear();
+                for (int64_t m = 0; m < P->d; ++m) (E[(size_t)m] ? lE : lL).push_back((int)m);
+                nE = (int64_t)lE.size(); nL = (int64_t)lL.size();
+                split = nE > 0 && nL >= P->d / 8;                  // (a field of view covered by footprints: nothing worth deferring)
+                if (split) {                                         // the two halves as pixel lists (w_maskE / w_maskL: int lists despite the name of the first version)
+                    RET(to_dev(ctx, P->w_maskE, lE.data(), lE.size()));
+                    RET(to_dev(ctx, P->w_maskL, lL.data(), lL.size()));
+                    if (act) {                                       // the active flags must outlive the context's scratch (tmp[8]) until the second half runs
+                        RET(ctx->vp[12].ensure((size_t)P->d));
+                        CK(hipMemcpyAsync(ctx->vp[12].p, act, (size_t)P->d, hipMemcpyDeviceToDevice, ctx->st()));
+                        act = ctx->vp[12].as<unsigned char>();
+                    }
                 }
             }
         }
-        RET(solve_launch(ctx, P, tab, g, ctx->rowsum.as<double>(), split ? P->w_maskE.as<unsigned char>() : act, nt, probe, dFill.as<double>()));
+        RET(solve_launch(ctx, P, tab, g, ctx->rowsum.as<double>(), act, nt, probe, dFill.as<double>(), split ? P->w_maskE.as<int>() : nullptr, nE));
         if (split) {
-            WArgs a; a.tab = tab; a.g = g; a.rowsum = ctx->rowsum.as<double>(); a.fill = dFill.as<double>(); a.nt = nt; a.probe = probe;
+            WArgs a; a.tab = tab; a.g = g; a.rowsum = ctx->rowsum.as<double>(); a.fill = dFill.as<double>(); a.act = act; a.nt = nt; a.probe = probe; a.nE = nE; a.nL = nL;
             P->w_blob.resize(sizeof(WArgs)); memcpy(P->w_blob.data(), &a, sizeof(a));
             P->w_pending = true; P->stat_valid = false;
         }
