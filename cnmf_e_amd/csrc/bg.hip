@@ -1231,7 +1231,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // when the first reader of the whole W comes along (w_finish) -- the one fitted full-resolution patch of a context only: the tables are the context's
         bool split = false;
         int64_t nE = -1, nL = 0;
-        if (has_a && !P->derived && !b0_out && ctx->opt("solve_defer", 1) != 0) {
+        // MEASURED, NOT THE DEFAULT (option "solve_defer", profiles/r04/solve_defer_ab.txt): at the headline size the host's work in front of the spatial kernels
+        // (search masks, slices, the mask's CSR, the need lists: 5 ms) hides behind the 7.6 ms of the one-launch solve -- with the first half alone (4.1 ms) in front
+        // of it that work is exposed instead of the turnaround behind it: 17.7-19.3 ms against 17.9-18.1, and 6.4-6.7 against 6.2-6.3 at 256 x 256.
+        if (has_a && !P->derived && !b0_out && ctx->opt("solve_defer", 0) != 0) {
             int nfit = 0;
             for (auto &kv : ctx->patches) nfit += kv.second->ring_ready && !kv.second->derived;
             if (nfit == 1) {

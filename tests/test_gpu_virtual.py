@@ -240,6 +240,7 @@ def test_deferred_half_of_the_ring_solve(dims, r):
             assert n1 == (1, 1, 2), n1                            # the second half ran in front of the residual with footprints, not before
             assert np.array_equal(w0, w1) and np.array_equal(a0, a1) and np.array_equal(c0, c1)
         # other first readers of the whole W: a CSR export, the next fit
+        eng.ring_init(0, r); eng.fit_ring_model(0, A, Cm, want_b0=False); eng.fit_ring_model(0, A, Cm, want_b0=False)
         eng.set_option("solve_defer", 1)
         eng.fit_ring_model(0, A, Cm, want_b0=False)
         w_csr = eng.ring_csr(0).data.copy()
