@@ -3,9 +3,10 @@
 # Usage (on the GPU box): bash scripts/profile_round.sh <tag>   -> gpurun_out/prof_<tag>/*
 set -u
 tag=${1:-r01}
-out=gpurun_out/prof_$tag; mkdir -p $out
-export TMPDIR=/tmp
-cmd="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
+R=${GRAFT_REPO_ROOT:-$PWD}
+out=$R/gpurun_out/prof_$tag; mkdir -p $out
+export TMPDIR=/tmp; cd /tmp                      # (rocprofv3 wants a writable scratch directory as its working directory)
+cmd="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $cmd > $out/bench_under_rocprof.json 2> $out/kt.err
 cp $(find $out/kt -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
