@@ -51,6 +51,17 @@ __global__ void k_center4(const float *__restrict__ Y, const float *__restrict__
     out[c * d_b + q] = v;
 }
 
+// 576 bytes of private (scratch) memory per lane, touched: launched once when a context is created.  The runtime sets a queue's scratch arena up at the
+// first launch of a kernel that needs one -- the ring solve spills 76 bytes per lane -- and on a fresh box that first set-up took 0.5-0.9 s (profiles/r04/
+// cold_start.txt: the stall sat on the first bg_ring_solve of the first process or two of every lease, on the first kernel with scratch in round 3).
+__global__ void k_scratch_warm(int *out, int n) {
+    volatile int a[144];
+    for (int i = 0; i < 144; ++i) a[i] = i * n;
+    int s = 0;
+    for (int i = 0; i < n; ++i) s += a[(i * 7 + n) % 144];
+    if (out) *out = s;
+}
+
 // W = 1/count on the in-FOV ring neighbours (initComponents_parallel.m:229-233)
 __global__ void k_ring_init(float *__restrict__ W, int64_t d, int nr, int p, const int *__restrict__ dr, const int *__restrict__ dc,
                             int r0, int c0, int d1, int d2) {
@@ -481,6 +492,8 @@ cnmfe_ctx *cnmfe_create(int device) {
     pin_register(ctx, true);
     if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
     // every translation unit's code object is loaded now, not at the first launch of one of its kernels inside the first iteration (tens of milliseconds in all)
+    hipLaunchKernelGGL(k_scratch_warm, dim3(1), dim3(64), 0, ctx->stream_, (int *)nullptr, 3);
+    (void)hipStreamSynchronize(ctx->stream_); (void)hipGetLastError();
     (void)tu_warm_resid(); (void)tu_warm_bg(); (void)tu_warm_factor(); (void)tu_warm_deconv(); (void)tu_warm_ssub(); (void)tu_warm_vproj();
     // CNMFE_OPTS="name=value,name=value": tunables of cnmfe_set_option preset for every context of the process (A/B runs of the test suite and the bench
     // without touching their code); names this build does not know are ignored -- the same environment serves builds with different option sets

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    name, patches = sys.argv[1], [os.path.abspath(p) for p in sys.argv[2:]]
+    name, patches = sys.argv[1], [("R:" if p.startswith("R:") else "") + os.path.abspath(p[2:] if p.startswith("R:") else p) for p in sys.argv[2:]]     # "R:<patch>": applied in reverse
     work = "/tmp/cnmfe_var_" + name
     shutil.rmtree(work, ignore_errors=True)
     os.makedirs(work)
@@ -25,8 +25,10 @@ def main():
         shutil.copy(os.path.join(ROOT, f), os.path.join(work, f))
     subprocess.run(["git", "init", "-q"], cwd=work, check=True)
     for p in patches:
-        subprocess.run(["git", "apply", "--whitespace=nowarn", p], cwd=work, check=True)
-        print("applied", os.path.relpath(p, ROOT), flush=True)
+        rev = p.startswith("R:")
+        p = p[2:] if rev else p
+        subprocess.run(["git", "apply", "--whitespace=nowarn"] + (["-R"] if rev else []) + [p], cwd=work, check=True)
+        print("applied" + (" in reverse" if rev else ""), os.path.relpath(p, ROOT), flush=True)
     subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, '.'); from cnmf_e_amd import build; build.build(force=True, verbose=False)"], cwd=work, check=True)
     dst = os.path.join(ROOT, "cnmf_e_amd", "variants")
     os.makedirs(dst, exist_ok=True)
