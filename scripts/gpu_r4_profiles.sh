@@ -14,7 +14,8 @@ python bench.py $X --deconv > $o/bench_c3_deconv_$ver.json 2>/dev/null
 python bench.py $X --bg-ssub 2 --deconv --alg hals_thresh > $o/bench_c3_demo_defaults_$ver.json 2>/dev/null
 python bench.py $X --config c2 > $o/bench_c2_$ver.json 2>/dev/null
 python bench.py $X --config c4 --steps 5 > $o/bench_c4_n1_$ver.json 2>/dev/null
-python bench.py $X --config c5shard --steps 5 --deconv > $o/bench_c5shard_$ver.json 2>/dev/null
+python bench.py $X --config c5shard --steps 5 > $o/bench_c5shard_$ver.json 2>/dev/null
+python bench.py $X --config c5shard --steps 5 --deconv > $o/bench_c5shard_deconv_$ver.json 2>/dev/null
 python bench.py $X --warmup 0 --steps 5 > $o/bench_c3_warmup0_$ver.json 2>/dev/null
 python bench.py $X --demo-sequence > $o/bench_c3_demo_sequence_$ver.json 2>/dev/null
 CNMFE_OPTS=r1_virtual=0 python bench.py $X > $o/bench_c3_swept_$ver.json 2>/dev/null
