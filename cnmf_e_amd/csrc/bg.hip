@@ -677,6 +677,7 @@ __global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_
 }
 }  // namespace cnmfe
 #include "ring_solve.hpp"
+#include "ring_solve_packed.hpp"
 namespace cnmfe {
 
 // ind_active = abs(W_old)*sum(A,2) > 0  (fit_ring_model.m:28)
@@ -957,8 +958,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // alternates -- comes forward (otherwise its memory is where the new table is built)
         P->cov_base.swap(P->cov_base_alt); P->rowsum_base.swap(P->rowsum_base_alt);
         std::swap(P->base_valid, P->base_alt_valid); std::swap(P->base_kstride, P->base_alt_kstride);
+        P->sys.swap(P->sys_alt); std::swap(P->sys_valid, P->sys_alt_valid);          // (the packed systems belong to their table)
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
+    if (build_base) P->sys_valid = false;
     ht.mark("footprint block lists");
     g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16
     g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
@@ -1187,8 +1190,48 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         }
         if (incr) { P->base_valid = true; P->base_kstride = kstride; }
         }
+        const int nt = (p + 15) / 16;
+        if (nt < 1 || nt > 8) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
+        DevBuf &dFill = ctx->solve_fill;                     // the fill values {0, 1} of missing neighbours, in global memory (ring_solve.hpp)
+        const double fillv[2] = {0.0, 1.0};
+        RET(to_dev(ctx, dFill, fillv, 2));
+        CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
+        DevBuf &dWcodes = ctx->wcodes;
+        const int woff = (g.p_radius + 15) >> 4;            // window origins reach -ceil(p_radius / 16) blocks (1 for rings up to 16 pixels, 2 up to 32)
+        const int nwin = (g.nbr + 2 * woff) * (g.nbc + 2 * woff);
+        // ---- packed systems (ring_solve_packed.hpp): the video's table re-laid once per pixel in the solve's register-tile order; the fits then apply the
+        // footprints' corrections in registers and neither sweep the table (k_cov_correct) nor gather from it.  Conditions: the incremental table, at most
+        // RSP_CAP footprints over any pixel, the memory (43 KB per pixel at p = 96), one launch (no split solve)
+        bool packed = incr && ctx->opt("solve_packed", 1) != 0 && ctx->opt("solve_defer", 0) == 0 && (int64_t)nblk * std::max(1, K) < (int64_t)1 << 31 &&
+                      (int64_t)lst_k.size() * BLKPX < (int64_t)1 << 31;
+        if (packed && has_a) {
+            int64_t mx = 0;
+            for (int64_t q = 0; q < P->d_b; ++q) mx = std::max<int64_t>(mx, csr.rowptr[q + 1] - csr.rowptr[q]);
+            if (mx > RSP_CAP) packed = false;
+        }
+        const size_t sys_bytes = (size_t)P->d * ((size_t)(nt * (nt + 1) / 2) * 256 + 16 * nt) * sizeof(double);
+        if (packed && !(P->sys_valid && P->sys.cap >= sys_bytes)) {
+            if (P->sys.cap < sys_bytes) {
+                size_t fr = 0, tot = 0;
+                CK(hipMemGetInfo(&fr, &tot));
+                if (fr < sys_bytes + ((size_t)8 << 30)) packed = false;          // (not worth the last gigabytes: the table path needs none of this)
+            }
+            if (packed) {
+                RET(P->sys.ensure(sys_bytes));
+                RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
+                LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());
+                CovTab tb = tab; tb.cov = P->cov_base.as<double>(); tb.wcodes = dWcodes.as<int>(); tb.woff = woff;
+                int *dErrP = nullptr;
+                RET(ctx_errflag(ctx, &dErrP));
+#define RSP_CASE(NT_) case NT_: LAUNCH(ctx, "bg_sys_pack", (k_sys_pack<NT_>), dim3((unsigned)P->d), dim3(64), 0, tb, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(), \
+                                        P->rowsum_base.as<double>(), (const unsigned char *)nullptr, (float *)nullptr, dErrP, 0, (const int *)nullptr, dFill.as<double>(), P->sys.as<double>()); break;
+                switch (nt) { RSP_CASE(1) RSP_CASE(2) RSP_CASE(3) RSP_CASE(4) RSP_CASE(5) RSP_CASE(6) RSP_CASE(7) RSP_CASE(8) default: break; }
+#undef RSP_CASE
+                P->sys_valid = true;
+            }
+        }
         if (incr) {
-            // ---- B2a': U~ on the blocks near footprints, then one sweep base -> cov ----
+            // ---- B2a': U~ on the blocks near footprints, then one sweep base -> cov (table path) or nothing (packed path: the solve corrects in registers) ----
             RET(ctx->rowsum.ensure((size_t)nblk * BLKPX * sizeof(double)));
             if (has_a) {
                 if (!proj_queued) RET(queue_projection());             // (first fit of the patch: behind the video's table)
@@ -1202,31 +1245,37 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                     P->pt_valid = true;
                 }
                 const int csplit = npairs >= 8192 ? 1 : npairs >= 4096 ? 2 : 4;      // (small patches: a pair's sweep is a long serial loop, one workgroup per pair leaves the chip idle)
+                if (!packed)
                 LAUNCH(ctx, "bg_cov_correct", k_cov_correct, dim3((unsigned)npairs, (unsigned)csplit), dim3(256), 0, P->cov_base.as<double>(), ctx->cov.as<double>(), dPairs.as<int4>(),
                        dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
                 LAUNCH(ctx, "bg_rowsum_correct", k_rowsum_correct, dim3(nblk), dim3(256), 0, P->rowsum_base.as<double>(), ctx->rowsum.as<double>(), g,
                        dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dCsum.as<double>());
             } else {                                                   // no footprints: Bf is the centred video itself
+                if (!packed)
                 CK(hipMemcpyAsync(ctx->cov.p, P->cov_base.p, (size_t)npairs * BLKPX * BLKPX * sizeof(double), hipMemcpyDeviceToDevice, ctx->st()));
                 CK(hipMemcpyAsync(ctx->rowsum.p, P->rowsum_base.p, (size_t)nblk * BLKPX * sizeof(double), hipMemcpyDeviceToDevice, ctx->st()));
             }
         }
         ht.mark("base / correction launches");
         // ---- B2b ----
-        CovTab tab; tab.cov = ctx->cov.as<double>(); tab.pair_of = dPairOf.as<int>(); tab.nbr = g.nbr; tab.nbc = g.nbc; tab.maxd = maxd; tab.nrel = nrel;
-        DevBuf &dWcodes = ctx->wcodes;
-        const int woff = (g.p_radius + 15) >> 4;            // window origins reach -ceil(p_radius / 16) blocks (1 for rings up to 16 pixels, 2 up to 32)
-        const int nwin = (g.nbr + 2 * woff) * (g.nbc + 2 * woff);
+        const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();
+        const int probe = (int)ctx->opt("solve_probe", 0);
+        if (packed) {
+            PackArgs pa{};
+            if (has_a) {
+                pa.arow = dArow.as<int>(); pa.acol = dAcol.as<int>(); pa.aval = dAval.as<float>(); pa.lst_ptr = dLp.as<int>(); pa.lst_k = dLk.as<int>();
+                pa.slot_of = dSlot.as<short>(); pa.K = (int)K; pa.Ut = dUt.as<double>();
+            }
+            int *dErrS = nullptr;
+            RET(ctx_errflag(ctx, &dErrS));
+#define RS6_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr); break;
+            switch (nt) { RS6_CASE(1) RS6_CASE(2) RS6_CASE(3) RS6_CASE(4) RS6_CASE(5) RS6_CASE(6) RS6_CASE(7) RS6_CASE(8) default: break; }
+#undef RS6_CASE
+        } else {
         RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
         LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());
         tab.wcodes = dWcodes.as<int>(); tab.woff = woff;
-        const unsigned char *act = first_run ? nullptr : dActive.as<unsigned char>();
-        const int probe = (int)ctx->opt("solve_probe", 0);
-        const int nt = (p + 15) / 16;
-        if (nt < 1 || nt > 8) return fail(CNMFE_EUNSUPPORTED, "fit_ring_model: %d ring neighbours (<= %d supported)", p, PMAX_RING);
-        DevBuf &dFill = ctx->solve_fill;                     // the fill values {0, 1} of missing neighbours, in global memory (ring_solve.hpp)
-        const double fillv[2] = {0.0, 1.0};
-        RET(to_dev(ctx, dFill, fillv, 2));
         // ---- the solve in two halves: E = the pixels within SOLVE_DE of a footprint's bounding box (what the next spatial update's masks read) now, the others
         // when the first reader of the whole W comes along (w_finish) -- the one fitted full-resolution patch of a context only: the tables are the context's
         bool split = false;
@@ -1280,6 +1329,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             WArgs a; a.tab = tab; a.g = g; a.rowsum = ctx->rowsum.as<double>(); a.fill = dFill.as<double>(); a.act = act; a.nt = nt; a.probe = probe; a.nE = nE; a.nL = nL;
             P->w_blob.resize(sizeof(WArgs)); memcpy(P->w_blob.data(), &a, sizeof(a));
             P->w_pending = true; P->stat_valid = false;
+        }
         }
     }
     if (!P->w_pending)

@@ -169,6 +169,9 @@ struct Patch {
     // recording whose T / (100 pmax) sits at an integer -- T = 20000 with pmax around 66 -- alternates between two strides from fit to fit; one kept table
     // meant a full fp64 rebuild (10-15 ms per patch) on every flip.  Allocated only when a second stride turns up.
     DevBuf cov_base_alt, rowsum_base_alt; bool base_alt_valid = false; int base_alt_kstride = 0;
+    // the video's normal equations per patch pixel, packed in the ring solve's register-tile order (ring_solve_packed.hpp): gathered once from cov_base
+    // (and once more for a second frame stride), 43 KB per pixel at p = 96
+    DevBuf sys, sys_alt; bool sys_valid = false, sys_alt_valid = false;
     // The ring solve in two halves (round 4): the fit solves the pixels near footprints (mask E: what the spatial update's masks can reach) and leaves the rest
     // -- pixels whose weights nobody reads before the spatial update's result has gone to the host -- PENDING; w_finish() (bg.hip) launches that second half in
     // front of the first reader of W that may touch it, in practice right behind the spatial update's download: the host's turnaround between the spatial and
