@@ -116,6 +116,9 @@ PROTOTYPES = {
     "cnmfe_stitch_add": (C.c_int, [c_ctx, C.c_int32, i32p]),
     "cnmfe_stitch_buffer": (C.c_int, [c_ctx, C.POINTER(f32p), i64p]),
     "cnmfe_stitch_buffer_stream": (C.c_int, [c_ctx, C.POINTER(f32p), i64p, C.POINTER(C.c_void_p)]),
+    "cnmfe_footprint_moments": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10),
+    "cnmfe_search_ellipse": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnmfe_csc_from_triplets": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnmfe_stitch_finish": (C.c_int, [c_ctx, C.c_int, f32p, C.c_int]),
     "cnmfe_stitch_temporal": (C.c_int, [C.POINTER(c_ctx), C.c_int, C.c_int, f32p, C.c_int]),

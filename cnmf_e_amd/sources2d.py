@@ -129,26 +129,30 @@ def _rect_pixels(rect, d1):
     return (cc[None, :] * d1 + rr[:, None]).reshape(-1, order="F")
 
 
-def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
+def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0, native=True):
     """'ellipse' search masks, utilities/determine_search_location.m:50-104 + utilities/com.m:20-28.
     Vectorised over neurons; returns a boolean CSC matrix (d x K)."""
-    A = sp.csc_matrix(A, dtype=np.float64)
     d, K = A.shape
-    A.sort_indices()
-    coo = A.tocoo()
-    pix, col, val = coo.row, coo.col, coo.data
-    x = (pix % d1 + 1).astype(np.float64)
-    y = (pix // d1 + 1).astype(np.float64)
-    s = np.bincount(col, weights=val, minlength=K)
-    empty = s == 0                                                        # :52
-    ss = np.where(empty, 1.0, s)
-    cmx = np.bincount(col, weights=val * x, minlength=K) / ss             # com.m:24
-    cmy = np.bincount(col, weights=val * y, minlength=K) / ss
-    cmx = np.clip(cmx, 0, d1); cmy = np.clip(cmy, 0, d2)                  # com.m:26-28
-    dx, dy = x - cmx[col], y - cmy[col]
-    vxx = np.bincount(col, weights=val * dx * dx, minlength=K) / ss       # :73
-    vxy = np.bincount(col, weights=val * dx * dy, minlength=K) / ss
-    vyy = np.bincount(col, weights=val * dy * dy, minlength=K) / ss
+    mom = _footprint_moments_native(A, d1, d2) if native and K > 0 and d < 2 ** 31 else None
+    if mom is not None:
+        empty, cmx, cmy, vxx, vxy, vyy = mom
+    else:
+        A = sp.csc_matrix(A, dtype=np.float64)
+        A.sort_indices()
+        coo = A.tocoo()
+        pix, col, val = coo.row, coo.col, coo.data
+        x = (pix % d1 + 1).astype(np.float64)
+        y = (pix // d1 + 1).astype(np.float64)
+        s = np.bincount(col, weights=val, minlength=K)
+        empty = s == 0                                                        # :52
+        ss = np.where(empty, 1.0, s)
+        cmx = np.bincount(col, weights=val * x, minlength=K) / ss             # com.m:24
+        cmy = np.bincount(col, weights=val * y, minlength=K) / ss
+        cmx = np.clip(cmx, 0, d1); cmy = np.clip(cmy, 0, d2)                  # com.m:26-28
+        dx, dy = x - cmx[col], y - cmy[col]
+        vxx = np.bincount(col, weights=val * dx * dx, minlength=K) / ss       # :73
+        vxy = np.bincount(col, weights=val * dx * dy, minlength=K) / ss
+        vyy = np.bincount(col, weights=val * dy * dy, minlength=K) / ss
     M = np.stack([np.stack([vxx, vxy], -1), np.stack([vxy, vyy], -1)], -2)
     D, V = np.linalg.eigh(M)                                              # :74 ascending eigenvalues
     d11 = np.minimum(max_size ** 2, np.maximum(min_size ** 2, D[:, 0]))   # :81
@@ -156,6 +160,30 @@ def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
     # candidate window: the ellipse reaches dist*sqrt(d22) from the centre along its long axis (d22 <= max_size^2); sizing the window by the
     # largest ellipse actually present instead of the largest possible one cuts the (K, W, W) arrays below ~3x for typical footprints
     R = min(int(np.ceil(dist * max_size)), int(np.ceil(dist * np.sqrt(float(d22.max()) if K else 0.0)))) + 1
+    if native and K > 0 and d < 2 ** 31:
+        # the window test (:84) in the library's host helper: per image column the run of rows, its ends settled with the same expression in the same
+        # order as below -- identical masks (tests/test_host_logic.py) in ~0.2 ms instead of 7-20 ms of (K, W, W) array passes, which had become the
+        # host's critical path between the ring fit and the spatial update once the fit took under 9 ms
+        try:
+            fn = L.lib.cnmfe_search_ellipse
+        except (ImportError, OSError, AttributeError):
+            fn = None
+        if fn is not None:
+            vk = np.ascontiguousarray(np.stack([V[:, 0, 0], V[:, 1, 0], V[:, 0, 1], V[:, 1, 1]], -1), dtype=np.float64)
+            cx = np.ascontiguousarray(cmx, dtype=np.float64); cy = np.ascontiguousarray(cmy, dtype=np.float64)
+            a11 = np.ascontiguousarray(d11, dtype=np.float64); a22 = np.ascontiguousarray(d22, dtype=np.float64)
+            em = np.ascontiguousarray(empty, dtype=np.uint8)
+            optr = np.empty(K + 1, dtype=np.int64); nn = np.zeros(1, dtype=np.int64)
+            cap = int(K) * (2 * R + 1) ** 2
+            orow = np.empty(max(cap, 1), dtype=np.int32)
+            rc = fn(int(K), int(d1), int(d2), cx.ctypes.data, cy.ctypes.data, vk.ctypes.data, a11.ctypes.data, a22.ctypes.data, em.ctypes.data, float(dist), int(R),
+                    cap, optr.ctypes.data, orow.ctypes.data, nn.ctypes.data)
+            if rc != 0:
+                raise ValueError(L.lib.cnmfe_last_error().decode())
+            n = int(nn[0])
+            IND = sp.csc_matrix((np.ones(n, dtype=bool), orow[:n].copy(), optr), shape=(d, K))
+            IND.has_sorted_indices = True
+            return IND
     off = np.arange(-R, R + 1)
     rows = np.floor(cmx)[:, None] + off[None, :]                           # (K, W) candidate rows (1-based)
     cols = np.floor(cmy)[:, None] + off[None, :]
@@ -172,6 +200,25 @@ def determine_search_location(A, d1, d2, min_size=3.0, max_size=8.0, dist=3.0):
     IND = sp.csc_matrix((np.ones(kk.size, dtype=bool), (gp, kk)), shape=(d, K))
     IND.sort_indices()
     return IND
+
+
+def _footprint_moments_native(A, d1, d2):
+    """(empty, cmx, cmy, vxx, vxy, vyy) of determine_search_location by the library's host helper cnmfe_footprint_moments (the same sums in the same order as the
+    bincount formulation, in one pass over A); None when the library is not built or A is not a sorted float32 / int32 CSC matrix"""
+    if not sp.isspmatrix_csc(A) or A.data.dtype != np.float32 or A.indices.dtype != np.int32 or not A.has_sorted_indices:
+        return None
+    try:
+        fn = L.lib.cnmfe_footprint_moments
+    except (ImportError, OSError, AttributeError):
+        return None
+    K = A.shape[1]
+    indptr = A.indptr if A.indptr.dtype == np.int64 else A.indptr.astype(np.int64)
+    out = np.empty((6, K), dtype=np.float64); em = np.empty(K, dtype=np.uint8)
+    rc = fn(int(K), int(d1), int(d2), indptr.ctypes.data, A.indices.ctypes.data, A.data.ctypes.data, out[0].ctypes.data, em.ctypes.data,
+            out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, out[4].ctypes.data, out[5].ctypes.data)
+    if rc != 0:
+        raise ValueError(L.lib.cnmfe_last_error().decode())
+    return em.astype(bool), out[1], out[2], out[3], out[4], out[5]
 
 
 def rows_of(A, lut, nloc, cols=None, span=None, cand=None):
@@ -1011,6 +1058,7 @@ class Sources2D:
                 from . import hostops
                 self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)
             self._update_b0_new()
+            self._prefetch_search_location()                               # the NEXT spatial update's masks depend on this A only
             return
         if whole_result is not None:
             A_ = whole_result
@@ -1033,6 +1081,7 @@ class Sources2D:
             from . import hostops
             self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)
         self._update_b0_new()                                                                        # :347-351
+        self._prefetch_search_location()
 
     def _post_process(self, A_):
         """obj.post_process_spatial() (:341) works on whole footprints, which only exist after the gather; sharded, every rank then takes the
@@ -1057,6 +1106,9 @@ class Sources2D:
         if getattr(self, "_pool", None) is None:
             self._pool = cf.ThreadPoolExecutor(max_workers=1)
         A = self.A
+        fut = getattr(self, "_ind_future", None)
+        if fut is not None and fut[0] is A:
+            return                                                         # (already on its way: requested at the end of the spatial update that made this A)
         self._ind_future = (A, self._pool.submit(lambda: self._as_mask_csc(self._search_location_owned(A))))
 
     @staticmethod

@@ -328,6 +328,21 @@ int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const fl
 int cnmfe_csc_drop_zeros(int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, const uint8_t *keep,
                          int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nnz_out);
 
+/* host helper: sum, centre of mass (utilities/com.m:20-28, clamped as :26-28) and second central moments (determine_search_location.m:73) of every footprint =
+ * column of the d x K CSC matrix A (pixels column-major in a d1 x d2 image); empty[k] = 1 where the values sum to 0 (:52).  K doubles per output.  The caller
+ * takes the 2 x 2 eigendecompositions (:74) and hands the result to cnmfe_search_ellipse.  No device involved. */
+int cnmfe_footprint_moments(int32_t K, int32_t d1, int32_t d2, const int64_t *colptr, const int32_t *rowidx, const float *val, double *s_out, uint8_t *empty,
+                            double *cmx, double *cmy, double *vxx, double *vxy, double *vyy);
+/* host helper: the 'ellipse' search masks IND = determine_search_location(A, 'ellipse', params) (utilities/determine_search_location.m:76-100, call site
+ * update_spatial_parallel.m:66) from the per-neuron quantities of :52-82 the caller has computed -- centre of mass (utilities/com.m:20-28), eigenvectors
+ * vk = (V11, V21, V12, V22) and eigenvalues clamped to [min_size^2, max_size^2] of the footprint's second moments: pixel (r, c) is in mask k iff
+ * sqrt(((r - cmx) V11 + (c - cmy) V21)^2 / d11 + ((r - cmx) V12 + (c - cmy) V22)^2 / d22) <= dist (:84), evaluated in exactly that order in double precision,
+ * within R pixels of (floor(cmx), floor(cmy)) and inside the d1 x d2 image; empty[k] != 0: no mask (:102-104).  Outputs: out_colptr[K + 1] (always),
+ * out_rowidx (0-based global pixels, ascending per neuron; written only when cap >= the total), *nnz_out = the total: call once with out_rowidx = NULL to size
+ * the buffer.  No device involved. */
+int cnmfe_search_ellipse(int32_t K, int32_t d1, int32_t d2, const double *cmx, const double *cmy, const double *vk, const double *d11, const double *d22,
+                         const uint8_t *empty, double dist, int32_t R, int64_t cap, int64_t *out_colptr, int32_t *out_rowidx, int64_t *nnz_out);
+
 /* host helper: the CSC matrix (nrow x ncol, rows ascending per column) of n (row, column, value) triplets in any order -- the gathered rows of A after the spatial
  * update (update_spatial_parallel.m:324-334: every patch writes its own disjoint rows of A_), assembled in one counting pass + a short sort per column instead of a
  * sort of the whole list.  Outputs: out_colptr[ncol + 1], out_rowidx[n], out_val[n].  CNMFE_EINVAL on an index out of range or a (row, column) given twice. */

@@ -46,12 +46,12 @@ def _fits(eng, r, seq, packed):
     return out
 
 
-@pytest.mark.parametrize("dims,T,r,K", [((40, 36), 600, 5, 5), ((64, 60), 300, 15, 8), ((40, 36), 9200, 5, 5), ((75, 66), 160, 18, 9), ((80, 72), 128, 24, 6),
+@pytest.mark.parametrize("dims,T,r,K", [((40, 36), 600, 5, 5), ((64, 60), 300, 15, 8), ((40, 36), 9200, 5, 5), ((75, 66), 160, 18, 9), ((80, 72), 128, 20, 6),
                                         ((70, 64), 200, 15, 40)])
 def test_packed_solve_equals_the_table_path(eng, dims, T, r, K):
     """A sequence of fits with changing A, C on one patch: first run (uniform W_old), footprints scaled, no footprints at all, a subset, the full set again;
     T = 9200 brings in the frame stride 2 of fit_ring_model.m:84-87 (a second packed copy); K = 40 on 70 x 64 puts 10-25 neurons around every ring
-    (more than the RSP_NS = 8 staged before the system is loaded: the later rounds); radii 18 / 24 are the 8-tile instantiations"""
+    (more than the RSP_NS = 8 staged before the system is loaded: the later rounds); radii 18 / 20 (120 / 124 offsets) are the 8-tile instantiations"""
     d1, d2 = dims
     f, Y, video = _video(eng, d1, d2, T, K, r, 11, min_sep=3 if K > 20 else 5)
     A = f.A_init.tocsc().astype(np.float32)

@@ -489,3 +489,37 @@ def test_csc_from_triplets_native_helper():
         _csc_from_triplets(np.array([1, 1]), np.array([0, 0]), np.array([1.0, 2.0]), (5, 2))
     with pytest.raises(ValueError):
         _csc_from_triplets(np.array([7]), np.array([0]), np.array([1.0]), (5, 2))
+
+
+def test_native_search_masks_equal_the_numpy_formulation():
+    """determine_search_location through the library's host helpers (cnmfe_footprint_moments, cnmfe_search_ellipse: one run of rows per image column, its ends
+    settled with the exact expression of determine_search_location.m:84) against the vectorised NumPy formulation it replaces -- identical index sets on empty
+    footprints, single pixels, elongated / rotated / thinned shapes, centres outside the image and every parameter set"""
+    from cnmf_e_amd.sources2d import determine_search_location
+    from cnmf_e_amd import _lib as L
+    try:
+        L.lib.cnmfe_search_ellipse
+    except (ImportError, OSError, AttributeError):
+        pytest.skip("library not built")
+    rng = np.random.default_rng(1)
+    for trial in range(120):
+        d1, d2, K = int(rng.integers(8, 90)), int(rng.integers(8, 90)), int(rng.integers(1, 10))
+        cols = []
+        for k in range(K):
+            m = np.zeros((d1, d2))
+            kind = rng.integers(0, 5)
+            if kind == 1:
+                m[rng.integers(0, d1), rng.integers(0, d2)] = rng.random() + 0.1
+            elif kind > 1:
+                r0, c0, sx, sy, th = rng.uniform(-2, d1 + 2), rng.uniform(-2, d2 + 2), rng.uniform(0.3, 12), rng.uniform(0.3, 12), rng.uniform(0, np.pi)
+                rr, cc = np.meshgrid(np.arange(d1), np.arange(d2), indexing="ij")
+                x = (rr - r0) * np.cos(th) + (cc - c0) * np.sin(th); y = -(rr - r0) * np.sin(th) + (cc - c0) * np.cos(th)
+                m = np.exp(-(x / sx) ** 2 - (y / sy) ** 2); m[m < 0.05] = 0
+                if kind == 4:
+                    m *= rng.random(m.shape) > 0.5
+            cols.append(sp.csc_matrix(m.reshape(-1, 1, order="F")))
+        A = sp.hstack(cols).tocsc().astype(np.float32); A.sort_indices()
+        mn, mx, ds = rng.choice([1.0, 3.0, 2.5]), rng.choice([8.0, 5.0, 12.5]), rng.choice([3.0, 2.0, 1.5, 4.2])
+        a = determine_search_location(A, d1, d2, mn, mx, ds).tocsc(); b = determine_search_location(A, d1, d2, mn, mx, ds, native=False).tocsc()
+        a.sort_indices(); b.sort_indices()
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), trial
