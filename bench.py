@@ -518,9 +518,12 @@ def main():
         fl = n_act * 2.0 * (n ** 3 / 3.0 + 2.0 * n * n)
         return {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / F64_MFMA_PEAK_TF, "traffic": None,
                 "kernel": "bg_ring_solve", "ms_per_launch": ms, "algorithmic_flops_per_launch": fl,
-                "note": "fp64 Cholesky + substitutions of %d independent %dx%d systems per launch (one per active pixel: 2(n^3/3 + 2n^2) flops each), priced against "
-                        "the fp64 peak (78.6 TFLOP/s, matrix and vector pipes alike).  One wave per pixel, the matrix in MFMA accumulator tiles "
-                        "(v_mfma_f64_16x16x4); the 16x16 diagonal steps, the table gather and the substitutions run on the vector pipe and bound the kernel -- DESIGN.md section 3"
+                "algorithmic_bytes_per_launch": n_act * 8.0 * ((((n - 1 + 15) // 16) * (((n - 1 + 15) // 16) + 1) // 2) * 256 + ((n - 1 + 15) // 16) * 16),
+                "note": "fp64 Cholesky + substitutions of %d independent %dx%d systems per launch (one per active pixel: 2(n^3/3 + 2n^2) flops each; the footprints' rank-2 "
+                        "corrections -- 4 n^2 flops per neuron around a pixel -- are NOT counted), priced against the fp64 peak (78.6 TFLOP/s, matrix and vector pipes alike).  "
+                        "One wave per pixel, the matrix in MFMA accumulator tiles (v_mfma_f64_16x16x4).  Since round 4 the systems are loaded from a per-pixel packed copy of the "
+                        "video's table (algorithmic_bytes_per_launch, coalesced: 1.9 ms at 6 TB/s, overlapped with other waves' arithmetic) and corrected in registers "
+                        "(option solve_packed); the 16x16 diagonal steps and the substitutions run on the vector pipe and bound the kernel -- DESIGN.md section 3"
                         % (int(n_act), n, n)}
     if dom.startswith("bg_gram"):
         roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else (BF16_MFMA_PEAK_TF if "bf16" in dom else F32_MFMA_PEAK_TF))
@@ -545,6 +548,9 @@ def main():
         roof["traffic"] = pmc_traffic("k_gram")
     if roof.get("kernel") == "bg_ring_solve":
         roof["traffic"] = pmc_traffic("k_ring_solve")
+        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_c3_pmc_FETCH_SIZE_v*.csv")))
+        roof["traffic_source"] = None if roof["traffic"] is None else ("NOT this run: 2 x FETCH_SIZE + WRITE_SIZE of %s (two rocprofv3 --pmc passes of this command, "
+                                                                        "scripts/profile_round.sh)" % os.path.relpath(pf[-1], ROOT).replace("FETCH_SIZE", "{FETCH,WRITE}_SIZE"))
     r1r = r1_roof()
     if r1r is not None:
         live = pmc_traffic_live()
