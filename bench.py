@@ -548,7 +548,8 @@ def main():
         roof["traffic"] = pmc_traffic("k_gram")
     if roof.get("kernel") == "bg_ring_solve":
         roof["traffic"] = pmc_traffic("k_ring_solve")
-        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_c3_pmc_FETCH_SIZE_v*.csv")))
+        import glob as _glob
+        pf = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_c3_pmc_FETCH_SIZE_v*.csv")))
         roof["traffic_source"] = None if roof["traffic"] is None else ("NOT this run: 2 x FETCH_SIZE + WRITE_SIZE of %s (two rocprofv3 --pmc passes of this command, "
                                                                         "scripts/profile_round.sh)" % os.path.relpath(pf[-1], ROOT).replace("FETCH_SIZE", "{FETCH,WRITE}_SIZE"))
     r1r = r1_roof()
