@@ -4,7 +4,7 @@ import argparse, os, sys, time, functools
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--patch", type=int, default=512, help="patch side (128: the 4 x 4 patches of BASELINE configs[3] on the 512 x 512 FOV)"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)")
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--patch", type=int, default=512, help="patch side (128: the 4 x 4 patches of BASELINE configs[3] on the 512 x 512 FOV)"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)"); ap.add_argument("--as-rank-of", type=int, default=0, help="N: only rank 0's patches of an N-rank run, no collectives (with --patch 128: one rank's share of c4, as scripts/rank_load.py)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -17,6 +17,8 @@ if world > 1:                                   # sharded run on ONE device (glo
     td.init_process_group(backend="gloo"); group = td.group.WORLD
     if a.patch == 512:
         a.npatch = world                        # weak: the FOV grows with the ranks; with --patch 128 the 4 x 4 patches of the fixed FOV are sharded (c4)
+if a.as_rank_of:
+    world, rank, group = a.as_rank_of, 0, None
 d1, d2, T, K, r, seed = 512, 512 * a.npatch, 10000, 500 * a.npatch, 15, 2
 f = synth.make_factors(d1, d2, T, K, seed)
 Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
