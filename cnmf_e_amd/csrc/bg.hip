@@ -1200,15 +1200,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         const int woff = (g.p_radius + 15) >> 4;            // window origins reach -ceil(p_radius / 16) blocks (1 for rings up to 16 pixels, 2 up to 32)
         const int nwin = (g.nbr + 2 * woff) * (g.nbc + 2 * woff);
         // ---- packed systems (ring_solve_packed.hpp): the video's table re-laid once per pixel in the solve's register-tile order; the fits then apply the
-        // footprints' corrections in registers and neither sweep the table (k_cov_correct) nor gather from it.  Conditions: the incremental table, at most
-        // RSP_CAP footprints over any pixel, the memory (43 KB per pixel at p = 96), one launch (no split solve)
+        // footprints' corrections in registers and neither sweep the table (k_cov_correct) nor gather from it.  Conditions: the incremental table,
+        // the memory (43 KB per pixel at p = 96), one launch (no split solve)
         bool packed = incr && ctx->opt("solve_packed", 1) != 0 && ctx->opt("solve_defer", 0) == 0 && (int64_t)nblk * std::max(1, K) < (int64_t)1 << 31 &&
                       (int64_t)lst_k.size() * BLKPX < (int64_t)1 << 31;
-        if (packed && has_a) {
-            int64_t mx = 0;
-            for (int64_t q = 0; q < P->d_b; ++q) mx = std::max<int64_t>(mx, csr.rowptr[q + 1] - csr.rowptr[q]);
-            if (mx > RSP_CAP) packed = false;
-        }
         const size_t sys_bytes = (size_t)P->d * ((size_t)(nt * (nt + 1) / 2) * 256 + 16 * nt) * sizeof(double);
         if (packed && !(P->sys_valid && P->sys.cap >= sys_bytes)) {
             if (P->sys.cap < sys_bytes) {

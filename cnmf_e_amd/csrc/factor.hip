@@ -510,18 +510,26 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
         return fail(CNMFE_EUNSUPPORTED, "maxN = %d; the NNLS kernel holds 1..%d passive variables", (int)param, NN_MAX);
     const std::vector<int32_t> &rptr = csr.rowptr;
     RET(to_dev(ctx, dColptr, IND_colptr, (size_t)K + 1));
+    ht.mark("u colptr");
     RET(to_dev(ctx, dErow, IND_rowidx, (size_t)nnz));
+    ht.mark("u erow");
     RET(to_dev(ctx, dEcol, ecol.data(), (size_t)nnz));
+    ht.mark("u ecol");
     RET(to_dev(ctx, dRptr, rptr.data(), rptr.size()));
+    ht.mark("u rptr");
     RET(to_dev(ctx, dRcol, csr.col.data(), csr.col.size()));
     RET(to_dev(ctx, dRsrc, csr.src.data(), csr.src.size()));
+    ht.mark("u rcol rsrc");
     RET(to_dev(ctx, dAval, aval.data(), aval.size()));
+    ht.mark("u aval");
     if (sn) RET(to_dev(ctx, dSn, sn, (size_t)d));
+    ht.mark("uploads");
     // S1
     const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(32, T / 256));
     const int64_t tchunk = ((T + nparts - 1) / nparts + 3) & ~int64_t(3);
     RET(dPart.ensure((size_t)nparts * nnz * sizeof(float)));
     RET(dU.ensure((size_t)nnz * sizeof(float)));
+    ht.mark("buffers");
     // a virtual residual (no sweep has run, resid.hip): U = P - W P out of the table P = Yc Cc' (vproj.hip); if that path cannot serve this update the sweep
     // runs now and Ysig is projected as before
     bool virt = P->ysig_virtual;
@@ -535,9 +543,10 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
            dErow.as<int>(), dEcol.as<int>(), nnz, dCc.as<float>(), ldc, tchunk, dPart.as<float>());
     LAUNCH(ctx, "reduce_parts", k_reduce_parts, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dPart.as<float>(), nnz, nparts, dU.as<float>());
     }
+    ht.mark("projection");
     // a footprint term pending beside Ysig (patches with halo neurons: the sweep ran without it) enters here: U += (W A_prev)(Cc_prev Cc')
     RET(residual_term_fold_spatial(ctx, P, K, nnz, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>(), S_[20]));
-    ht.mark("uploads + projection launch");
+    ht.mark("footprint term");
     // S2 on the co-occurrence pairs
     std::vector<char> include(K, 1);
     PairGraph g; build_graph(K, csr, d, include, g);

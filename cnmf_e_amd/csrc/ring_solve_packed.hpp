@@ -35,7 +35,7 @@ struct PackArgs {                                   // what the corrections read
     const int *lst_ptr, *lst_k; const short *slot_of; int K;   // per 16x16 block: its list of traces, slot of trace k in block b = slot_of[b * K + k]
     const double *Ut;                               // U~[(lst_ptr[b] + slot) * 256 + local pixel]
 };
-constexpr int RSP_CAP = 4;                          // footprints over one pixel (host check: denser populations take the table path)
+constexpr int RSP_CAP = 4;                          // footprints over one pixel whose (trace, value) entries are cached in LDS; longer rows are read where they lie
 constexpr int RSP_CH = 4;                           // neurons per staging round
 constexpr int RSP_NS = 8;                           // neurons staged before the system is loaded (two rounds)
 
@@ -76,6 +76,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     __shared__ int s_bk[N + 1];                                         // block * K
     __shared__ int s_ulp[N + 1];                                        // lst_ptr[block] * 256 + local pixel
     __shared__ int s_en[N + 1];
+    __shared__ int s_e0[N + 1];
     __shared__ int s_ec[N + 1][RSP_CAP];
     __shared__ float s_ev[N + 1][RSP_CAP];
     __shared__ unsigned s_mask[2];
@@ -102,7 +103,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     int bad = 0;
 #pragma unroll 1
     for (int a = lane; a <= N; a += 64) {
-        int q = -1, rs = 0, bk = 0, ulp = 0, en = 0;
+        int q = -1, rs = 0, bk = 0, ulp = 0, en = 0, e0s = 0;
         if (a < p || a == N) {
             const int rb = a < p ? rbm + dr[a] : rbm, cb = a < p ? cbm + dc[a] : cbm;
             const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
@@ -113,8 +114,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
                 if (corr) {
                     bk = blk * pa.K; ulp = pa.lst_ptr[blk] * 256 + lp;
                     const int e0 = pa.arow[q];
-                    en = pa.arow[q + 1] - e0;
-                    bad |= en > RSP_CAP;
+                    en = pa.arow[q + 1] - e0; e0s = e0;
 #pragma unroll
                     for (int j = 0; j < RSP_CAP; ++j)
                         if (j < en) {
@@ -123,10 +123,14 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
                             const int sl = pa.slot_of[(int64_t)blkm * pa.K + col];
                             if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
                         }
+                    for (int j = RSP_CAP; j < en; ++j) {               // (a pixel under more footprints than the cache holds: rare)
+                        const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0 + j]];
+                        if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
+                    }
                 }
             }
         }
-        s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en < RSP_CAP ? en : RSP_CAP;
+        s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en; s_e0[a] = e0s;
     }
     __syncthreads();
     // ---- border vectors u (row sums of Bf: corrected by k_rowsum_correct), g (the video's, corrected below) and the scalar s ----
@@ -171,6 +175,10 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
                 float av = 0.f;
 #pragma unroll
                 for (int j = 0; j < RSP_CAP; ++j) if (j < en && s_ec[a][j] == ks[i]) av = s_ev[a][j];
+                if (en > RSP_CAP && ks[i] >= 0) {
+                    const int e0 = s_e0[a];
+                    for (int j = RSP_CAP; j < en; ++j) if (pa.acol[e0 + j] == ks[i]) av = pa.aval[e0 + j];
+                }
                 s_u[slot0 + i][a] = uu[i]; s_a[slot0 + i][a] = av;
             }
         }
