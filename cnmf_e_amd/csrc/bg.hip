@@ -838,6 +838,16 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
     RET(ctx->bf.ensure((size_t)nblk * Tpad * BLKPX * sizeof(float)));
     const int nsg = nblk >= 512 ? std::max(1, std::min(8, (2048 + nblk - 1) / nblk)) : std::max(1, std::min(16, (4096 + nblk - 1) / std::max(1, nblk)));
     RET(ctx->inc[6].ensure((size_t)nsg * nblk * WIN_NLB * WIN_NLB * sizeof(double)));
+    // the packed systems of the ring solve (ring_solve_packed.hpp), under the same conditions as the fit applies
+    const int nt = (P->p + 15) / 16;
+    if (ctx->opt("solve_packed", 1) != 0 && nt >= 1 && nt <= 8) {
+        const size_t sys_bytes = (size_t)P->d * ((size_t)(nt * (nt + 1) / 2) * 256 + 16 * nt) * sizeof(double);
+        if (P->sys.cap < sys_bytes) {
+            size_t fr = 0, tot = 0;
+            CK(hipMemGetInfo(&fr, &tot));
+            if (fr >= sys_bytes + ((size_t)8 << 30)) { P->sys_valid = false; RET(P->sys.ensure(sys_bytes)); }
+        }
+    }
     return 0;
 }
 
