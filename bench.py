@@ -233,6 +233,9 @@ def main():
     if one_dev:
         local = 0
     dry = os.environ.get("CNMFE_BENCH_DRY", "0") == "1"
+    # torch's CPU kernels are not on this path, and an OpenMP team over every core of the host (one per rank), spinning behind any stray CPU tensor operation, is
+    # what throttled a CPU-quota'd container for 40 ms of every 100 (profiles/r04/forced_collectives.txt)
+    torch.set_num_threads(1)
     if not dry:
         torch.cuda.set_device(local)
     group = None
@@ -252,6 +255,14 @@ def main():
                 print(json.dumps({"dry": True, "rccl_ranks": td.get_world_size(group), "backend": td.get_backend(group), "sum": float(t_.item())}))
             td.destroy_process_group()
             return
+    # test hook for a 1-GPU box: the sharded code path -- every collective branch of the three methods -- on a real RCCL group of ONE rank
+    # (CNMFE_BENCH_FORCE_COLLECTIVES=1 python bench.py --config c4): what the collectives' host side costs per iteration, without a second GPU
+    force_coll = world == 1 and os.environ.get("CNMFE_BENCH_FORCE_COLLECTIVES", "0") == "1" and not dry
+    if force_coll:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        td.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        group = td.group.WORLD
     comm = {"rccl_ranks": 1, "backend": None}
     if group is not None:
         import torch.distributed as td
@@ -291,6 +302,9 @@ def main():
     torch.cuda.empty_cache()
     s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=5, deconv_flag=a.deconv, bg_ssub=a.bg_ssub),
                   f.A_init, f.C_init, f.sn, dist_group=group)
+    if force_coll:
+        s.force_collectives = True
+        comm["forced_collectives"] = True
     eng.profile(True)
 
     last = {}

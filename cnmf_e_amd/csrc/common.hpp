@@ -90,9 +90,14 @@ struct Profiler {
 // launch wrapper: LAUNCH(ctx, "name", kernel, grid, block, shmem, args...)
 #define LAUNCH(ctx, name, kern, grid, block, shmem, ...) do { \
     cnmfe::Profiler::Rec pr_; bool pon_ = (ctx)->prof.on && (ctx)->prof.want(name); \
+    const bool ltr_ = (ctx)->opt("host_trace", 0) >= 2; \
+    const auto lt0_ = ltr_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); \
     hipStream_t lst_ = (ctx)->st(); \
     if (pon_) (ctx)->prof.begin(name, lst_, pr_); \
+    const auto lt1_ = ltr_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); \
     hipLaunchKernelGGL(kern, grid, block, shmem, lst_, __VA_ARGS__); \
+    if (ltr_) { const auto lt2_ = std::chrono::steady_clock::now(); const double la_ = std::chrono::duration<double, std::milli>(lt1_ - lt0_).count(), lb_ = std::chrono::duration<double, std::milli>(lt2_ - lt1_).count(); \
+        if (la_ + lb_ > 2.0) fprintf(stderr, "[host_trace] launch %s: flush of held-back uploads %.2f ms, launch call %.2f ms\n", name, la_, lb_); } \
     if (pon_) (ctx)->prof.end(lst_, pr_); \
     hipError_t le_ = hipGetLastError(); \
     if (le_ != hipSuccess) return cnmfe::fail(CNMFE_EHIP, "launch %s failed: %s", name, hipGetErrorString(le_)); \

@@ -9,6 +9,7 @@ All arrays cross the boundary as plain pointers; sparse matrices are scipy CSC
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -626,13 +627,20 @@ class Engine:
 
         class _View:                                                    # zero-copy torch view of the engine's accumulator
             __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (C.cast(ptr, C.c_void_p).value, False), "version": 2}
+        # ONE tensor per (address, length), kept: a tensor over a Python object's memory is released through that object's deleter, which needs the GIL -- and the
+        # process group's watchdog thread, which drops the last reference of a finished collective's operands, then took the GIL for ~50 ms at a time, every
+        # ~100 ms, wherever the main thread happened to be (profiles/r04/forced_collectives.txt: c4 on one rank of RCCL 26 -> 50-58 ms per iteration)
+        key = (C.cast(ptr, C.c_void_p).value, n)
+        cached = getattr(self, "_stitch_view", None)
+        if cached is None or cached[0] != key:
+            cached = self._stitch_view = (key, torch.as_tensor(_View(), device="cuda"))
+        t = cached[1]
         if nccl:
             ext = torch.cuda.ExternalStream(int(sp_.value), device=torch.device("cuda", torch.cuda.current_device()))
             with torch.cuda.stream(ext):
-                t = torch.as_tensor(_View(), device="cuda")
-                td.all_reduce(t, group=group)
+                if os.environ.get("CNMFE_SKIP_STITCH_ALLREDUCE") != "1":     # (test hook of the one-rank measurements)
+                    td.all_reduce(t, group=group)
             return
-        t = torch.as_tensor(_View(), device="cuda")
         h = t.cpu(); td.all_reduce(h, group=group); t.copy_(h)
         torch.cuda.current_stream().synchronize()                       # the engine continues on its own stream
 

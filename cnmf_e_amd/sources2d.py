@@ -1165,6 +1165,11 @@ class Sources2D:
             return A_
         import torch
         import torch.distributed as td
+        import os as _os, time as _time
+        _tr = _os.environ.get("CNMFE_TRACE_GATHER") == "1"; _t = [_time.perf_counter()]
+        def _mk(what):
+            if _tr:
+                _t.append(_time.perf_counter()); print("[gather] %-18s %.2f ms" % (what, 1e3 * (_t[-1] - _t[-2])), flush=True)
         coo = A_.tocoo()
         nccl = td.get_backend(self.dist) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
@@ -1172,17 +1177,28 @@ class Sources2D:
         # two tensor collectives (sizes, then one padded int32 [3, nmax] block per rank: row, col, value bits) instead of pickled objects
         n = torch.tensor([coo.nnz], dtype=torch.int64, device=dev)
         sizes = [torch.zeros_like(n) for _ in range(W)]
+        _mk("prep")
         td.all_gather(sizes, n, group=self.dist)
+        _mk("all_gather sizes")
         sizes = [int(x.item()) for x in sizes]
+        _mk("item")
         nmax = max(1, max(sizes))
-        buf = torch.zeros((3, nmax), dtype=torch.int32)
-        buf[0, :coo.nnz] = torch.from_numpy(coo.row.astype(np.int32))
-        buf[1, :coo.nnz] = torch.from_numpy(coo.col.astype(np.int32))
-        buf[2, :coo.nnz] = torch.from_numpy(np.ascontiguousarray(coo.data, dtype=np.float32).view(np.int32))
-        buf = buf.to(dev)
+        # the padded block is put together by NumPy, not by torch CPU kernels: a torch fill / copy of this size opens an OpenMP region over every core of
+        # the host, whose threads then spin -- inside a CPU-quota'd container that throttled the whole process for ~40 ms of every 100-ms scheduler period
+        # (one rank of RCCL at c4: 26 -> 50-58 ms per iteration; OMP_NUM_THREADS=1 made it vanish: profiles/r04/forced_collectives.txt)
+        buf_np = np.zeros((3, nmax), dtype=np.int32)
+        buf_np[0, :coo.nnz] = coo.row
+        buf_np[1, :coo.nnz] = coo.col
+        buf_np[2, :coo.nnz] = np.ascontiguousarray(coo.data, dtype=np.float32).view(np.int32)
+        _mk("host buffer")
+        buf = torch.from_numpy(buf_np).to(dev)
+        _mk("to device")
         out = [torch.empty_like(buf) for _ in range(W)]
+        _mk("empty_like")
         td.all_gather(out, buf, group=self.dist)
+        _mk("all_gather")
         out = [o.cpu().numpy() for o in out]
+        _mk("to host")
         r = np.concatenate([o[0, :m] for o, m in zip(out, sizes)])            # int32 row / column indices: the CSC build is index-bound
         c = np.concatenate([o[1, :m] for o, m in zip(out, sizes)])
         d_ = np.concatenate([np.ascontiguousarray(o[2, :m]).view(np.float32) for o, m in zip(out, sizes)])

@@ -4,7 +4,7 @@ import argparse, os, sys, time, functools
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--patch", type=int, default=512, help="patch side (128: the 4 x 4 patches of BASELINE configs[3] on the 512 x 512 FOV)"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)"); ap.add_argument("--as-rank-of", type=int, default=0, help="N: only rank 0's patches of an N-rank run, no collectives (with --patch 128: one rank's share of c4, as scripts/rank_load.py)")
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=3); ap.add_argument("--bg-ssub", type=int, default=1); ap.add_argument("--cprofile", action="store_true"); ap.add_argument("--deconv", action="store_true"); ap.add_argument("--patch", type=int, default=512, help="patch side (128: the 4 x 4 patches of BASELINE configs[3] on the 512 x 512 FOV)"); ap.add_argument("--npatch", type=int, default=1, help="patches side by side on this one rank (FOV 512 x 512*npatch, K = 500*npatch)"); ap.add_argument("--force-collectives", action="store_true", help="one-rank nccl group + force_collectives: the collective branches' host side"); ap.add_argument("--as-rank-of", type=int, default=0, help="N: only rank 0's patches of an N-rank run, no collectives (with --patch 128: one rank's share of c4, as scripts/rank_load.py)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -19,6 +19,18 @@ if world > 1:                                   # sharded run on ONE device (glo
         a.npatch = world                        # weak: the FOV grows with the ranks; with --patch 128 the 4 x 4 patches of the fixed FOV are sharded (c4)
 if a.as_rank_of:
     world, rank, group = a.as_rank_of, 0, None
+if a.force_collectives:
+    import torch.distributed as td
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534"); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    print("affinity before init:", len(os.sched_getaffinity(0)), "cpus")
+    td.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0)); group = td.group.WORLD
+    _t = torch.ones(1, device="cuda"); td.all_reduce(_t); torch.cuda.synchronize()
+    print("affinity after init + first collective:", len(os.sched_getaffinity(0)), "cpus", sorted(os.sched_getaffinity(0))[:8])
+    import threading
+    print("threads:", threading.active_count(), "os threads:", len(os.listdir("/proc/self/task")))
+    if os.environ.get("RESET_AFFINITY") == "1":
+        os.sched_setaffinity(0, range(os.cpu_count())); print("affinity reset:", len(os.sched_getaffinity(0)))
 d1, d2, T, K, r, seed = 512, 512 * a.npatch, 10000, 500 * a.npatch, 15, 2
 f = synth.make_factors(d1, d2, T, K, seed)
 Yd = synth.make_video_device(f, "cuda:0"); torch.cuda.synchronize()
@@ -45,7 +57,25 @@ for name in dir(Engine):
             log.append((name, t0, t1, threading.get_ident() == main)); return r_
         return w
     setattr(Engine, name, wrap(fn, name))
+if os.environ.get("TRACE_SLOW_PY") == "1":               # which Python-side helper a long gap between two engine calls sits in (printed when > 3 ms)
+    import cnmf_e_amd.sources2d as _s2
+    def _wrap_slow(obj, name):
+        fn = getattr(obj, name)
+        static = isinstance(getattr(obj, "__dict__", {}).get(name), staticmethod)
+        @functools.wraps(fn)
+        def w(*x, **k):
+            t0 = time.perf_counter(); r_ = fn(*x, **k); dt_ = time.perf_counter() - t0
+            if dt_ > 3e-3: print("      [slow python] %s %.1f ms" % (name, dt_ * 1e3), flush=True)
+            return r_
+        setattr(obj, name, staticmethod(w) if static else w)
+    for nm in ("_slice", "_rows", "_prev_block_of", "_residual", "_temporal_residual_done", "_temporal_residual_early", "_gather_sparse", "_allreduce", "_post_process", "_first_run",
+               "_search_location_csc", "_update_b0_new", "ymean_full", "_prefetch_search_location"):
+        if hasattr(Sources2D, nm): _wrap_slow(Sources2D, nm)
+    for nm in ("rows_of", "_select_rows_native", "_csc_from_triplets", "determine_search_location"):
+        if hasattr(_s2, nm): _wrap_slow(_s2, nm)
 s = Sources2D(video, Options(ring_radius=r, bg_ssub=a.bg_ssub, deconv_flag=a.deconv), f.A_init, f.C_init, f.sn, dist_group=group)
+if a.force_collectives:
+    s.force_collectives = True
 if rank != 0:
     sys.stdout = open(os.devnull, 'w')
 marks = []
