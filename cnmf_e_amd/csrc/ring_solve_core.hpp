@@ -68,13 +68,20 @@ template <int J, int C> __device__ __forceinline__ void rs_chol_col(double (&a)[
 template <int J, int CC> __device__ __forceinline__ void rs_inv_row(double (&a)[16], const double &lij) {   // E(i, cc) -= lij E(J, cc) for cc = CC .. J-1
     if constexpr (CC < J) { rs_fmac_bc_self<J, CC == 0>(a[CC], lij); rs_inv_row<J, CC + 1>(a, lij); }
 }
-template <int J> __device__ __forceinline__ void rs_chol(double (&a)[16], double &mydinv, int i) {
+// `inv` = 1 / sqrt(pivot J), handed in by the previous column: the NEXT pivot is final as soon as column J's first update (C = J + 1) has landed, so its
+// broadcast and reciprocal square root (v_rsq_f64 + two Newton steps: a ~70-clock dependent chain) are started there and run under the remaining 14 - J updates
+// of column J instead of in front of column J + 1.  Same operations on the same values: bit-identical factors.
+template <int J> __device__ __forceinline__ void rs_chol(double (&a)[16], double &mydinv, int i, double inv) {
     if constexpr (J < 16) {
-        const double inv = rs_rsqrt(rs_bc<J>(a[J]));
         a[J] *= inv;                                        // L(i, J), i >= J
         mydinv = i == J ? inv : mydinv;
-        rs_chol_col<J, J + 1>(a);
-        rs_chol<J + 1>(a, mydinv, i);
+        double inv_next = 0.0;
+        if constexpr (J + 1 < 16) {
+            rs_fmac_bc<J + 1, true>(a[J + 1], a[J], a[J]);
+            inv_next = rs_rsqrt(rs_bc<J + 1>(a[J + 1]));
+            rs_chol_col<J, J + 2>(a);
+        }
+        rs_chol<J + 1>(a, mydinv, i, inv_next);
     }
 }
 // in place: E(i, c) = -sum_{j = c .. i-1} L(i, j) Y(j, c),  Y(j, c) = E(j, c) / L(j, j),  Y(j, j) = 1 / L(j, j)
@@ -96,7 +103,7 @@ __device__ __forceinline__ void rs_diag_block(double *sb, int lane) {
 #pragma unroll
     for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2 *>(sb + i * RS_DS + c); a[c] = v.x; a[c + 1] = v.y; }
     double mydinv = 0.0;
-    rs_chol<0>(a, mydinv, i);
+    rs_chol<0>(a, mydinv, i, rs_rsqrt(rs_bc<0>(a[0])));
     rs_inv<0>(a, mydinv, i);
     __syncthreads();                                        // every lane has read its row
     if (lane < 16) {
