@@ -20,6 +20,7 @@ python bench.py $X --warmup 0 --steps 5 > $o/bench_c3_warmup0_$ver.json 2>/dev/n
 python bench.py $X --demo-sequence > $o/bench_c3_demo_sequence_$ver.json 2>/dev/null
 CNMFE_OPTS=r1_virtual=0 python bench.py $X > $o/bench_c3_swept_$ver.json 2>/dev/null
 python scripts/rank_load.py > $o/rank_load_$ver.txt 2>&1
+CNMFE_BENCH_FORCE_COLLECTIVES=1 python bench.py $X --config c4 --steps 10 --warmup 4 > $o/bench_c4_forced_collectives_$ver.json 2>/dev/null
 unset CNMFE_BENCH_R1
 bash scripts/profile_round.sh r04$ver > /dev/null 2>&1
 for f in $o/bench_*_$ver.json; do python - "$f" <<'PY'
