@@ -518,6 +518,14 @@ def main():
                 return None
             tot += mult * 1024.0 * sum(float(r_["value_per_launch_KiB"]) for r_ in rows) / len(rows)
         return tot
+    def with_pmc(pr):
+        # fabric traffic of the two video passes from the round's PMC passes of this command (NOT this run, like the solve's): both equal their algorithmic bytes
+        if pr:
+            for name, sub in (("temporal_proj_B", "k_vp_proj_b"), ("bg_win_proj", "k_win_proj")):
+                if name in pr:
+                    pr[name]["traffic"] = pmc_traffic(sub)
+                    pr[name]["traffic_source"] = None if pr[name]["traffic"] is None else "NOT this run: 2 x FETCH_SIZE + WRITE_SIZE of the newest profiles/r*/bench_c3_pmc_{FETCH,WRITE}_SIZE_v*.csv"
+        return pr
     def solve_roof():
         # per active pixel: gather the (p+1)x(p+1) Gram + RHS from the table, ridge, Cholesky, two triangular solves -- all fp64
         if "bg_ring_solve" not in kern:
@@ -608,7 +616,7 @@ def main():
         "roofline_r1": r1r,
         "roofline_solve": solve_roof(),
         "roofline_r1_delta": dlr,
-        "roofline_projections": proj_roofs(),
+        "roofline_projections": with_pmc(proj_roofs()),
         **comm,
         "first_iteration": {"ms": warm_steps_ms[0] if warm_steps_ms else None, "warmup_steps_ms": [round(x, 3) for x in warm_steps_ms],
                             "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},

@@ -90,7 +90,7 @@ struct Profiler {
 // launch wrapper: LAUNCH(ctx, "name", kernel, grid, block, shmem, args...)
 #define LAUNCH(ctx, name, kern, grid, block, shmem, ...) do { \
     cnmfe::Profiler::Rec pr_; bool pon_ = (ctx)->prof.on && (ctx)->prof.want(name); \
-    const bool ltr_ = (ctx)->opt("host_trace", 0) >= 2; \
+    const bool ltr_ = (ctx)->trace_level >= 2; \
     const auto lt0_ = ltr_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); \
     hipStream_t lst_ = (ctx)->st(); \
     if (pon_) (ctx)->prof.begin(name, lst_, pr_); \
@@ -308,6 +308,7 @@ struct cnmfe_ctx {
     void *rccl_comm = nullptr; int rccl_rank = 0, rccl_n = 0;          // single-process multi-GPU stitch (cnmfe_stitch_temporal)
     cnmfe::DevBuf errflag;    // one int, set by kernels that meet a state the host-side set-up should have excluded (checked at the next sync)
     std::map<std::string, int64_t> opts;
+    int trace_level = 0;                                   // opts["host_trace"], read by every LAUNCH
     int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }
     ~cnmfe_ctx();
 };
