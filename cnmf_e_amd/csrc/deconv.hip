@@ -93,19 +93,45 @@ __device__ void select_pair(const float *y, int T, int k, int *hist /* 260 ints 
 // in-place radix-2 FFT of n complex points in LDS (re, im), 256 threads; the input is already in bit-reversed order and
 // tw[k] = exp(-2 pi i k / n), k < n/4, is a table (a sincospif per butterfly was most of the transform's time); the second quarter
 // of the circle is -i times the first
+// In-place radix-2 decimation-in-time FFT on bit-reversed input, TWO stages per pass: a thread takes the four elements i0 + {0, h, 2h, 3h} that stages s and s + 1
+// combine among themselves, runs both butterflies in registers and writes them back -- the same operations with the same twiddles as two single-stage passes (bit-
+// identical results), at half the barriers and 0.6x the LDS traffic (8 reads + 8 writes + 3 twiddles per 4 points instead of 2 x (8 + 8 + 4)).  The per-pixel GetSn
+// is four 4096-point transforms per pixel, 262144 pixels: 54 ms at the headline size with one stage per pass.
+__device__ __forceinline__ float2 fft_tw(const float2 *tw, int tk, int n) {
+    float2 w = tw[tk & (n / 4 - 1)];
+    if (tk >= n / 4) w = make_float2(w.y, -w.x);
+    return w;
+}
 __device__ void fft_lds(float *re, float *im, const float2 *tw, int n, int logn) {
     const int tid = threadIdx.x;
-    for (int s = 1; s <= logn; ++s) {
-        const int half = 1 << (s - 1), tstep = n >> s;
+    int s = 1;
+    if (logn & 1) {                                          // an odd number of stages: the first one (twiddle 1) on its own
         for (int b = tid; b < n / 2; b += 256) {
-            const int pos = b & (half - 1);
-            const int i0 = ((b >> (s - 1)) << s) + pos, i1 = i0 + half;
-            const int tk = pos * tstep;
-            float2 w = tw[tk & (n / 4 - 1)];
-            if (tk >= n / 4) w = make_float2(w.y, -w.x);
-            const float xr = re[i1] * w.x - im[i1] * w.y, xi = re[i1] * w.y + im[i1] * w.x;
-            const float ur = re[i0], ui = im[i0];
+            const int i0 = 2 * b, i1 = i0 + 1;
+            const float ur = re[i0], ui = im[i0], xr = re[i1], xi = im[i1];
             re[i0] = ur + xr; im[i0] = ui + xi; re[i1] = ur - xr; im[i1] = ui - xi;
+        }
+        __syncthreads();
+        s = 2;
+    }
+    for (; s < logn; s += 2) {
+        const int h = 1 << (s - 1), t1 = n >> s, t2 = n >> (s + 1);
+        for (int q = tid; q < n / 4; q += 256) {
+            const int pos = q & (h - 1);
+            const int i0 = ((q >> (s - 1)) << (s + 1)) + pos, i1 = i0 + h, i2 = i0 + 2 * h, i3 = i0 + 3 * h;
+            const float2 w1 = fft_tw(tw, pos * t1, n), wa = fft_tw(tw, pos * t2, n), wb = fft_tw(tw, (pos + h) * t2, n);
+            // stage s: (i0, i1) and (i2, i3), both with w1
+            float xr = re[i1] * w1.x - im[i1] * w1.y, xi = re[i1] * w1.y + im[i1] * w1.x;
+            float ur = re[i0], ui = im[i0];
+            const float a0r = ur + xr, a0i = ui + xi, a1r = ur - xr, a1i = ui - xi;
+            xr = re[i3] * w1.x - im[i3] * w1.y; xi = re[i3] * w1.y + im[i3] * w1.x;
+            ur = re[i2]; ui = im[i2];
+            const float a2r = ur + xr, a2i = ui + xi, a3r = ur - xr, a3i = ui - xi;
+            // stage s + 1: (i0, i2) with wa, (i1, i3) with wb
+            xr = a2r * wa.x - a2i * wa.y; xi = a2r * wa.y + a2i * wa.x;
+            re[i0] = a0r + xr; im[i0] = a0i + xi; re[i2] = a0r - xr; im[i2] = a0i - xi;
+            xr = a3r * wb.x - a3i * wb.y; xi = a3r * wb.y + a3i * wb.x;
+            re[i1] = a1r + xr; im[i1] = a1i + xi; re[i3] = a1r - xr; im[i3] = a1i - xi;
         }
         __syncthreads();
     }
