@@ -933,9 +933,17 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         pairs_b.clear(); pairs_k.clear();
         for (int k = 0; k < K && has_a; ++k) {
             mark.clear();
-            for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
-                const int q = A_rowidx[e], b_ = ((q / P->nr_b) >> 4) * g.nbr + ((q % P->nr_b) >> 4);
-                if (own[b_] != k) { own[b_] = k; mark.push_back(b_); }
+            // (the entries of a column ascend with the pixel index: one step per run of an image column of the block region, not per entry -- this list
+            //  building sits in front of the window projection's launch)
+            for (int64_t e = A_colptr[k]; e < A_colptr[k + 1];) {
+                const int q0 = A_rowidx[e], cb = q0 / P->nr_b, col_end = (cb + 1) * P->nr_b;
+                int qlast = q0;
+                ++e;
+                while (e < A_colptr[k + 1] && A_rowidx[e] < col_end && A_rowidx[e] >= qlast) { qlast = A_rowidx[e]; ++e; }
+                for (int bi = (q0 - cb * P->nr_b) >> 4; bi <= (qlast - cb * P->nr_b) >> 4; ++bi) {
+                    const int b_ = (cb >> 4) * g.nbr + bi;
+                    if (own[b_] != k) { own[b_] = k; mark.push_back(b_); }
+                }
             }
             for (int b_ : mark)
                 for (int dj = -maxd; dj <= maxd; ++dj)

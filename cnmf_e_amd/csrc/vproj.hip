@@ -87,15 +87,25 @@ __global__ void __launch_bounds__(256) k_vp_spatial(const int *__restrict__ erow
 // (exact for masks whose image columns are runs; a superset otherwise).  Appends (block) to `out`.
 static void reach_blocks(const Patch *P, const BgGeom &g, int R, const int32_t *rowidx, int64_t e0, int64_t e1, std::vector<int> &lo, std::vector<int> &hi, std::vector<int> &out) {
     int bjmin = INT_MAX, bjmax = -1;
-    for (int64_t e = e0; e < e1; ++e) {
-        const int m = rowidx[e];
-        const int rb = m % P->nr + P->roff, cb = m / P->nr + P->coff;
-        const int bi0 = std::max(0, rb - R) >> 4, bi1 = std::min(P->nr_b - 1, rb + R) >> 4;
+    // the entries of a CSC column ascend with the pixel index, i.e. image column by image column: one update per IMAGE COLUMN (its first and last stored row)
+    // instead of one per entry -- this list building sat in front of the temporal projection's first launch with the GPU idle (0.45 ms at 500 neurons)
+    auto flush = [&](int cb, int rfirst, int rlast) {
+        const int bi0 = std::max(0, rfirst - R) >> 4, bi1 = std::min(P->nr_b - 1, rlast + R) >> 4;
         const int bj0 = std::max(0, cb - R) >> 4, bj1 = std::min(P->nc_b - 1, cb + R) >> 4;
         for (int bj = bj0; bj <= bj1; ++bj) {
             if (hi[bj] < 0) { lo[bj] = bi0; hi[bj] = bi1; } else { lo[bj] = std::min(lo[bj], bi0); hi[bj] = std::max(hi[bj], bi1); }
         }
         bjmin = std::min(bjmin, bj0); bjmax = std::max(bjmax, bj1);
+    };
+    int64_t e = e0;
+    while (e < e1) {
+        const int m0 = rowidx[e];
+        const int c = m0 / P->nr;                                            // image column of this run (patch coordinates)
+        const int col_end = (c + 1) * P->nr;
+        int mlast = m0;
+        ++e;
+        while (e < e1 && rowidx[e] < col_end && rowidx[e] >= mlast) { mlast = rowidx[e]; ++e; }   // (an unsorted column just starts a new run: still a superset)
+        flush(c + P->coff, m0 - c * P->nr + P->roff, mlast - c * P->nr + P->roff);
     }
     for (int bj = bjmin; bj <= bjmax; ++bj) {
         if (hi[bj] < 0) continue;
