@@ -523,3 +523,30 @@ def test_native_search_masks_equal_the_numpy_formulation():
         a = determine_search_location(A, d1, d2, mn, mx, ds).tocsc(); b = determine_search_location(A, d1, d2, mn, mx, ds, native=False).tocsc()
         a.sort_indices(); b.sort_indices()
         assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), trial
+
+
+def test_native_search_helpers_refuse_bad_arguments_and_size_their_output():
+    """cnmfe_search_ellipse: out_colptr and the total always, the indices only into a buffer that holds them (the sizing call of include/cnmfe.h);
+    null arguments are CNMFE_EINVAL with a message, never a crash"""
+    from cnmf_e_amd import _lib as L
+    try:
+        fn, fm = L.lib.cnmfe_search_ellipse, L.lib.cnmfe_footprint_moments
+    except (ImportError, OSError, AttributeError):
+        pytest.skip("library not built")
+    K, d1, d2, R = 2, 20, 18, 6
+    cx = np.array([7.3, 12.9]); cy = np.array([6.1, 9.5]); vk = np.array([1.0, 0.0, 0.0, 1.0] * K); a11 = np.array([4.0, 9.0]); a22 = np.array([9.0, 9.0])
+    em = np.zeros(K, np.uint8); optr = np.empty(K + 1, np.int64); nn = np.zeros(1, np.int64)
+    args = (K, d1, d2, cx.ctypes.data, cy.ctypes.data, vk.ctypes.data, a11.ctypes.data, a22.ctypes.data, em.ctypes.data, 2.0, R)
+    assert fn(*args, 0, optr.ctypes.data, None, nn.ctypes.data) == 0                     # sizing call
+    n = int(nn[0]); assert n > 0 and optr[0] == 0 and optr[K] == n
+    small = np.full(max(1, n - 1), -7, np.int32)
+    assert fn(*args, n - 1, optr.ctypes.data, small.ctypes.data, nn.ctypes.data) == 0 and np.all(small == -7)      # too small: nothing written
+    rows = np.empty(n, np.int32)
+    assert fn(*args, n, optr.ctypes.data, rows.ctypes.data, nn.ctypes.data) == 0
+    assert rows.min() >= 0 and rows.max() < d1 * d2
+    for k in range(K):
+        assert np.all(np.diff(rows[optr[k]:optr[k + 1]]) > 0)
+    assert fn(K, d1, d2, None, cy.ctypes.data, vk.ctypes.data, a11.ctypes.data, a22.ctypes.data, em.ctypes.data, 2.0, R, 0, optr.ctypes.data, None, nn.ctypes.data) != 0
+    assert b"null" in L.lib.cnmfe_last_error()
+    out = np.empty((6, K)); e8 = np.empty(K, np.uint8)
+    assert fm(K, d1, d2, None, None, None, out[0].ctypes.data, e8.ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, out[4].ctypes.data, out[5].ctypes.data) != 0
