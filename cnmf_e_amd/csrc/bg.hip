@@ -1281,10 +1281,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
             int *dErrS = nullptr;
             RET(ctx_errflag(ctx, &dErrS));
-#define RS6_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr); break;
+            const int svar = (int)ctx->opt("solve_variant", 0);
+#define RS6_LAUNCH(NT_, V_) LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_, V_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr)
+#define RS6_CASE(NT_) case NT_: if (svar == 2) RS6_LAUNCH(NT_, 2); else if (svar == 1) RS6_LAUNCH(NT_, 1); else RS6_LAUNCH(NT_, 0); break;
             switch (nt) { RS6_CASE(1) RS6_CASE(2) RS6_CASE(3) RS6_CASE(4) RS6_CASE(5) RS6_CASE(6) RS6_CASE(7) RS6_CASE(8) default: break; }
 #undef RS6_CASE
+#undef RS6_LAUNCH
         } else {
         RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
         LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());

@@ -66,7 +66,10 @@ __device__ __forceinline__ void rsp_rank2(double4_t (&T)[(NT * (NT + 1)) / 2], c
     }
 }
 
-template <int NT>
+// VAR (option "solve_variant", round 5): 0 = round 4's kernel; 1 = the system's cache lines touched at the top (they stream into L2 under the index set-up
+// instead of behind it), the set-up and staging loops unrolled (their two rounds' dependent gathers in flight together) and the fused diagonal step
+// (rs_cholinv); 2 = 1 + the look-ahead factorisation (rs_factor_la_step).  All three compute the same bits.
+template <int NT, int VAR>
 __global__ void __launch_bounds__(64, (NT <= 2 ? 4 : (NT <= 3 ? 3 : (NT <= 6 ? 2 : 1))))
 k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc, const double *__restrict__ rowsum,
               const unsigned char *__restrict__ active, float *__restrict__ W, int *__restrict__ errflag, int probe, const int *__restrict__ pix) {
@@ -99,47 +102,135 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     const int blkm = (cbm >> 4) * g.nbr + (rbm >> 4);
     const bool corr = pa.arow != nullptr && !(probe & 8);
     if (lane < 2) s_mask[lane] = 0;
+    // VAR >= 1: one dword of every 128-byte line of the system, requested now and retired (long arrived) in front of the tile loads
+    constexpr int NTOUCH = VAR >= 1 ? ((NTILE * 256 + N) * 8 + 64 * 128 - 1) / (64 * 128) : 0;
+    int touch[NTOUCH > 0 ? NTOUCH : 1];
+    if constexpr (VAR >= 1) {
+        constexpr int LAST = ((NTILE * 256 + N) * 8 - 4) / 128;         // last line of the pixel's record
+#pragma unroll
+        for (int i = 0; i < NTOUCH; ++i) {
+            const int line = i * 64 + lane;
+            touch[i] = reinterpret_cast<const int *>(sp)[(line < LAST ? line : LAST) * 32];
+        }
+    }
     __syncthreads();
     int bad = 0;
-#pragma unroll 1
-    for (int a = lane; a <= N; a += 64) {
-        int q = -1, rs = 0, bk = 0, ulp = 0, en = 0, e0s = 0;
-        if (a < p || a == N) {
-            const int rb = a < p ? rbm + dr[a] : rbm, cb = a < p ? cbm + dc[a] : cbm;
-            const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-            if (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) {
-                q = cb * g.nr_b + rb;
-                const int blk = (cb >> 4) * g.nbr + (rb >> 4), lp = lp_of(rb & 15, cb & 15);
-                rs = blk * 256 + lp;
-                if (corr) {
-                    bk = blk * pa.K; ulp = pa.lst_ptr[blk] * 256 + lp;
-                    const int e0 = pa.arow[q];
-                    en = pa.arow[q + 1] - e0; e0s = e0;
+    double sc;
+    if constexpr (VAR >= 1) {
+        // Branch-free, every round of 64 lanes at once: the loads of a phase (ring offsets -> CSR row bounds, row sums, border vector -> cached entries ->
+        // their slots in the centre block's list) are in flight together, five dependent phases in all.  Round 4's loop took a branch and a full wait per load
+        // (two rounds x up to twelve dependent loads).  Indices of absent neighbours / entries are clamped to 0, their results discarded by selects.
+        constexpr int R = (N + 64) / 64;
+        int drv[R], dcv[R];
 #pragma unroll
-                    for (int j = 0; j < RSP_CAP; ++j)
-                        if (j < en) {
-                            const int col = pa.acol[e0 + j];
-                            s_ec[a][j] = col; s_ev[a][j] = pa.aval[e0 + j];
-                            const int sl = pa.slot_of[(int64_t)blkm * pa.K + col];
-                            if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
-                        }
-                    for (int j = RSP_CAP; j < en; ++j) {               // (a pixel under more footprints than the cache holds: rare)
-                        const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0 + j]];
+        for (int rr = 0; rr < R; ++rr) { const int a = lane + 64 * rr, ai = a < p ? a : 0; drv[rr] = dr[ai]; dcv[rr] = dc[ai]; }
+        int qv[R], blkv[R], lpv[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int a = lane + 64 * rr;
+            const bool ring = a < p;
+            const int rb = ring ? rbm + drv[rr] : rbm, cb = ring ? cbm + dcv[rr] : cbm;
+            const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
+            const bool ex = (ring || a == N) && ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2;
+            qv[rr] = ex ? cb * g.nr_b + rb : -1;
+            blkv[rr] = ex ? (cb >> 4) * g.nbr + (rb >> 4) : 0;
+            lpv[rr] = lp_of(rb & 15, cb & 15);
+        }
+        double rsum[R], gvec[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int a = lane + 64 * rr;
+            rsum[rr] = rowsum[blkv[rr] * 256 + lpv[rr]];
+            gvec[rr] = sp[NTILE * 256 + (a < N ? a : N - 1)];
+        }
+        sc = rowsum[blkm * 256 + lp_of(rbm & 15, cbm & 15)];
+        int e0v[R], env[R], lptv[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) { e0v[rr] = 0; env[rr] = 0; lptv[rr] = 0; }
+        if (corr) {
+            int e1v[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) { const int qq = qv[rr] >= 0 ? qv[rr] : 0; e0v[rr] = pa.arow[qq]; e1v[rr] = pa.arow[qq + 1]; lptv[rr] = pa.lst_ptr[blkv[rr]]; }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) env[rr] = qv[rr] >= 0 ? e1v[rr] - e0v[rr] : 0;
+            int colv[R][RSP_CAP]; float valv[R][RSP_CAP];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int j = 0; j < RSP_CAP; ++j) { const int idx = j < env[rr] ? e0v[rr] + j : 0; colv[rr][j] = pa.acol[idx]; valv[rr][j] = pa.aval[idx]; }
+            int slv[R][RSP_CAP];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int j = 0; j < RSP_CAP; ++j) slv[rr][j] = pa.slot_of[(int64_t)blkm * pa.K + colv[rr][j]];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int a = lane + 64 * rr;
+                if (a <= N) {
+#pragma unroll
+                    for (int j = 0; j < RSP_CAP; ++j) {
+                        s_ec[a][j] = colv[rr][j]; s_ev[a][j] = valv[rr][j];
+                        if (j < env[rr]) { if (slv[rr][j] < 0) bad = 1; else atomicOr(&s_mask[slv[rr][j] >> 5], 1u << (slv[rr][j] & 31)); }
+                    }
+                    for (int j = RSP_CAP; j < env[rr]; ++j) {          // (a pixel under more footprints than the cache holds: rare)
+                        const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0v[rr] + j]];
                         if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
                     }
                 }
             }
         }
-        s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en; s_e0[a] = e0s;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int a = lane + 64 * rr;
+            if (a <= N) {
+                const bool ex = qv[rr] >= 0;
+                s_q[a] = qv[rr]; s_rs[a] = ex ? blkv[rr] * 256 + lpv[rr] : 0; s_bk[a] = (ex && corr) ? blkv[rr] * pa.K : 0;
+                s_ulp[a] = (ex && corr) ? lptv[rr] * 256 + lpv[rr] : 0; s_en[a] = env[rr]; s_e0[a] = e0v[rr];
+                if (a < N) { s_vec[0][a] = ex ? rsum[rr] : 0.0; s_vec[1][a] = ex ? gvec[rr] : 0.0; }
+            }
+        }
+        __syncthreads();
+    } else {
+#pragma unroll 1
+        for (int a = lane; a <= N; a += 64) {
+            int q = -1, rs = 0, bk = 0, ulp = 0, en = 0, e0s = 0;
+            if (a < p || a == N) {
+                const int rb = a < p ? rbm + dr[a] : rbm, cb = a < p ? cbm + dc[a] : cbm;
+                const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
+                if (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) {
+                    q = cb * g.nr_b + rb;
+                    const int blk = (cb >> 4) * g.nbr + (rb >> 4), lp = lp_of(rb & 15, cb & 15);
+                    rs = blk * 256 + lp;
+                    if (corr) {
+                        bk = blk * pa.K; ulp = pa.lst_ptr[blk] * 256 + lp;
+                        const int e0 = pa.arow[q];
+                        en = pa.arow[q + 1] - e0; e0s = e0;
+#pragma unroll
+                        for (int j = 0; j < RSP_CAP; ++j)
+                            if (j < en) {
+                                const int col = pa.acol[e0 + j];
+                                s_ec[a][j] = col; s_ev[a][j] = pa.aval[e0 + j];
+                                const int sl = pa.slot_of[(int64_t)blkm * pa.K + col];
+                                if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
+                            }
+                        for (int j = RSP_CAP; j < en; ++j) {               // (a pixel under more footprints than the cache holds: rare)
+                            const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0 + j]];
+                            if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
+                        }
+                    }
+                }
+            }
+            s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en; s_e0[a] = e0s;
+        }
+        __syncthreads();
+        // ---- border vectors u (row sums of Bf: corrected by k_rowsum_correct), g (the video's, corrected below) and the scalar s ----
+        for (int a = lane; a < N; a += 64) {
+            const bool ex = s_q[a] >= 0;
+            s_vec[0][a] = ex ? rowsum[s_rs[a]] : 0.0;
+            s_vec[1][a] = ex ? sp[NTILE * 256 + a] : 0.0;
+        }
+        sc = rowsum[s_rs[N]];
     }
-    __syncthreads();
-    // ---- border vectors u (row sums of Bf: corrected by k_rowsum_correct), g (the video's, corrected below) and the scalar s ----
-    for (int a = lane; a < N; a += 64) {
-        const bool ex = s_q[a] >= 0;
-        s_vec[0][a] = ex ? rowsum[s_rs[a]] : 0.0;
-        s_vec[1][a] = ex ? sp[NTILE * 256 + a] : 0.0;
-    }
-    const double sc = rowsum[s_rs[N]];
     // ---- the footprints' corrections: one symmetric rank-2 update per neuron with a pixel on the ring or under the centre.  A round stages U~ and A of up to
     // RSP_CH neurons for every ring pixel in LDS (two dependent gathers: slot, value); the FIRST round runs before the system is loaded -- with the 168 tile
     // registers live the compiler spilled a third of them around this phase --, later rounds (more than RSP_CH neurons on one ring: rare) run under them
@@ -157,6 +248,51 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
             ks[i] = -1;
             if (mask) { const int s = __builtin_ctzll(mask); mask &= mask - 1; ks[i] = pa.lst_k[lbm + s]; ++nst; }
         }
+        if constexpr (VAR >= 1) {
+            // both gathers (slot of trace ks[i] in the pixel's block list -> U~ of that slot) for every round of lanes at once, clamped addresses + selects
+            constexpr int R = (N + 64) / 64;
+            int qs[R], sl[R][RSP_CH];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int a = lane + 64 * rr, al = a <= N ? a : N;
+                qs[rr] = a <= N ? s_q[al] : -1;
+                const int bk = s_bk[al];
+#pragma unroll
+                for (int i = 0; i < RSP_CH; ++i) sl[rr][i] = (int)pa.slot_of[(qs[rr] >= 0 && ks[i] >= 0) ? (int64_t)bk + ks[i] : 0];
+            }
+            double uu[R][RSP_CH];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int a = lane + 64 * rr, al = a <= N ? a : N;
+                const int ulp = s_ulp[al];
+#pragma unroll
+                for (int i = 0; i < RSP_CH; ++i) {
+                    const bool use = qs[rr] >= 0 && ks[i] >= 0;
+                    bad |= use && sl[rr][i] == -1;
+                    const bool ok = use && sl[rr][i] >= 0;
+                    const double v = pa.Ut[ok ? (int64_t)ulp + (int64_t)sl[rr][i] * 256 : 0];
+                    uu[rr][i] = ok ? v : 0.0;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int a = lane + 64 * rr;
+                if (a <= N) {
+                    const int en = s_en[a];
+#pragma unroll
+                    for (int i = 0; i < RSP_CH; ++i) {
+                        float av = 0.f;
+#pragma unroll
+                        for (int j = 0; j < RSP_CAP; ++j) if (j < en && s_ec[a][j] == ks[i]) av = s_ev[a][j];
+                        if (en > RSP_CAP && ks[i] >= 0) {
+                            const int e0 = s_e0[a];
+                            for (int j = RSP_CAP; j < en; ++j) if (pa.acol[e0 + j] == ks[i]) av = pa.aval[e0 + j];
+                        }
+                        s_u[slot0 + i][a] = uu[rr][i]; s_a[slot0 + i][a] = av;
+                    }
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int a = lane; a <= N; a += 64) {
             const int q = s_q[a];
@@ -182,6 +318,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
                 s_u[slot0 + i][a] = uu[i]; s_a[slot0 + i][a] = av;
             }
         }
+        }
     };
     auto apply = [&](double4_t (&T)[NTILE]) {
         __syncthreads();
@@ -194,6 +331,12 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     };
     if (mask) stage(0);
     if (mask) stage(RSP_CH);
+    if constexpr (VAR >= 1) {
+        int tacc = 0;
+#pragma unroll
+        for (int i = 0; i < NTOUCH; ++i) tacc |= touch[i];
+        asm volatile("" :: "v"(tacc));
+    }
     // ---- the system: 2 NTILE coalesced 16-byte loads, all in flight at once ----
     double4_t T[NTILE];
 #pragma unroll
@@ -225,7 +368,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     if (bad) atomicOr(errflag, 1);
     __syncthreads();
     double wc[NT];
-    rs_solve_core<NT>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
+    rs_solve_core<NT, VAR>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
     if (rq == 0) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) {

@@ -1,12 +1,13 @@
 """Phase probes of the ring-regression solve kernel on one patch: python scripts/solve_ab.py --cfg c3 [--probes 0,1,3,7]
-(solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions).  Every run fits the same first-run problem (ring
-re-initialised before each fit).  The --modes argument only repeats the runs: the alternative solve kernels were removed in round 3."""
+(solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions, 8 no footprint corrections).  Every run fits the same
+first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_variant (ring_solve_packed.hpp: 0 round 4's kernel,
+1 prefetch + branch-free set-up + fused diagonal step, 2 = 1 + look-ahead factorisation); the weights of every mode are compared with the first's bit for bit."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="5"); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0)
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="0"); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0)
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -25,14 +26,18 @@ Ws = {}
 for mode in [int(x) for x in a.modes.split(",")]:
     for probe in [int(x) for x in a.probes.split(",")]:
         eng.ring_init(0, r)
-        eng.set_option("solve_probe", probe); eng.profile_reset()
-        _, info = eng.fit_ring_model(0, f.A_init.astype(np.float32), f.C_init)
-        eng.synchronize()
-        tab = eng.profile_table()
-        print("solve_mode %d probe %d: bg_ring_solve %.3f ms   (%s)" % (mode, probe, tab["bg_ring_solve"]["total_ms"] / tab["bg_ring_solve"]["calls"], info), flush=True)
+        eng.set_option("solve_probe", probe); eng.set_option("solve_variant", mode)
+        ts = []
+        for rep in range(a.reps):
+            eng.ring_init(0, r); eng.profile_reset()
+            _, info = eng.fit_ring_model(0, f.A_init.astype(np.float32), f.C_init)
+            eng.synchronize()
+            tab = eng.profile_table()
+            ts.append(tab["bg_ring_solve"]["total_ms"] / tab["bg_ring_solve"]["calls"])
+        print("solve_variant %d probe %d: bg_ring_solve %s ms   (%s)" % (mode, probe, " ".join("%.3f" % t for t in ts), info), flush=True)
         if probe == 0:
             Ws[mode] = eng.ring_csr(0).data.copy()
 ks = list(Ws)
 for k in ks[1:]:
     dW = np.abs(Ws[k] - Ws[ks[0]])
-    print("max |W_%d - W_%d| / max|W| = %.3e   (rms %.3e, nan %d)" % (k, ks[0], dW.max() / np.abs(Ws[ks[0]]).max(), np.sqrt((dW ** 2).mean()), int(np.isnan(Ws[k]).sum())))
+    print("max |W_%d - W_%d| / max|W| = %.3e   (rms %.3e, nan %d, entries that differ in any bit %d of %d)" % (k, ks[0], dW.max() / np.abs(Ws[ks[0]]).max(), np.sqrt((dW ** 2).mean()), int(np.isnan(Ws[k]).sum()), int((Ws[k].view(np.uint32) != Ws[ks[0]].view(np.uint32)).sum()), Ws[k].size))
