@@ -339,13 +339,8 @@ int ctx_errflag(cnmfe_ctx *ctx, int **dflag) {
     *dflag = ctx->errflag.as<int>();
     return 0;
 }
-// waits for the stream and reports what its kernels raised since the last call
-int ctx_check_errflag(cnmfe_ctx *ctx) {
-    if (!ctx->errflag.p) { CK(hipStreamSynchronize(ctx->st())); return 0; }
-    int h = 0;
-    CK(hipMemcpyAsync(&h, ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
-    CK(hipStreamSynchronize(ctx->st()));
-    if (!h) return 0;
+// what a raised error word means: clears it, drops every table a later call would trust, and reports
+static int errflag_raise(cnmfe_ctx *ctx, int h) {
     CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
     // whatever raised the flag left truncated or inconsistent tables behind (the footprint terms beside a residual, a P table): nothing kept with the patches may
     // be trusted by a later call -- the next residual sweeps again, the next spatial update builds its own table
@@ -354,6 +349,15 @@ int ctx_check_errflag(cnmfe_ctx *ctx) {
     if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 32 footprints of A_prev (flag %d)", h);
     if (h & 4) return fail(CNMFE_EUNSUPPORTED, "bg_ssub > 1: a pixel's interpolation window meets more than 64 footprints of A_prev (flag %d)", h);
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
+}
+// waits for the stream and reports what its kernels raised since the last call
+int ctx_check_errflag(cnmfe_ctx *ctx) {
+    if (!ctx->errflag.p) { CK(hipStreamSynchronize(ctx->st())); return 0; }
+    int h = 0;
+    CK(hipMemcpyAsync(&h, ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
+    if (!h) return 0;
+    return errflag_raise(ctx, h);
 }
 
 // ---- T5: stitch accumulator (update_temporal_parallel.m:264-280) ------------------------------------------------------------------
@@ -472,6 +476,7 @@ cnmfe_ctx::~cnmfe_ctx() {
     cnmfe::pin_register(this, false);
     for (auto *j : tjobs) delete j;
     for (auto e : tickets) (void)hipEventDestroy(e);
+    if (ticket_flags) (void)hipHostFree(ticket_flags);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -872,22 +877,34 @@ int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
     return spatial_fetch(ctx, A_out, nnz);
 }
 
-int cnmfe_update_spatial_fetch_async(cnmfe_ctx *ctx, float *A_out_pinned, int64_t nnz, int64_t *ticket) {
-    if (!ctx || !ticket) return fail(CNMFE_EINVAL, "null context / ticket");
-    if (!A_out_pinned && nnz) return fail(CNMFE_EINVAL, "null A_out");
-    CK(hipSetDevice(ctx->device));
-    if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
-    if (nnz) CK(hipMemcpyAsync(A_out_pinned, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+// A ticket = an event behind the work queued so far.  The device error word travels with it: a caller that waits for its ticket only -- not for the
+// stream, cnmfe_synchronize -- still hears what the kernels in front of the ticket had to report (a ring over too many footprints, an inconsistent table)
+// before it uses what they computed.
+static int ticket_record(cnmfe_ctx *ctx, int64_t *ticket) {
     size_t t = 0;
     while (t < ctx->tickets.size() && ctx->ticket_busy[t]) ++t;
     if (t == ctx->tickets.size()) {
         hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->tickets.push_back(e); ctx->ticket_busy.push_back(0);
     }
+    if (ctx->errflag.p && t < cnmfe_ctx::TICKET_FLAGS) {
+        if (!ctx->ticket_flags) { CK(hipHostMalloc((void **)&ctx->ticket_flags, cnmfe_ctx::TICKET_FLAGS * sizeof(int), hipHostMallocDefault)); memset(ctx->ticket_flags, 0, cnmfe_ctx::TICKET_FLAGS * sizeof(int)); }
+        ctx->ticket_flags[t] = 0;
+        CK(hipMemcpyAsync(&ctx->ticket_flags[t], ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+    }
     CK(hipEventRecord(ctx->tickets[t], ctx->st()));
     ctx->ticket_busy[t] = 1;
     *ticket = (int64_t)t;
     return 0;
+}
+
+int cnmfe_update_spatial_fetch_async(cnmfe_ctx *ctx, float *A_out_pinned, int64_t nnz, int64_t *ticket) {
+    if (!ctx || !ticket) return fail(CNMFE_EINVAL, "null context / ticket");
+    if (!A_out_pinned && nnz) return fail(CNMFE_EINVAL, "null A_out");
+    CK(hipSetDevice(ctx->device));
+    if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
+    if (nnz) CK(hipMemcpyAsync(A_out_pinned, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
+    return ticket_record(ctx, ticket);
 }
 
 int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket) {
@@ -896,6 +913,11 @@ int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket) {
     CK(hipSetDevice(ctx->device));
     CK(hipEventSynchronize(ctx->tickets[ticket]));
     ctx->ticket_busy[ticket] = 0;
+    if (ctx->ticket_flags && (size_t)ticket < cnmfe_ctx::TICKET_FLAGS && ctx->ticket_flags[ticket]) {
+        const int h = ctx->ticket_flags[ticket];
+        ctx->ticket_flags[ticket] = 0;
+        return errflag_raise(ctx, h);
+    }
     return 0;
 }
 
@@ -907,19 +929,6 @@ int cnmfe_update_spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2,
     if (IND_colptr[K] && (!A_out || !keep_out)) return fail(CNMFE_EINVAL, "null A_out / keep_out");
     CK(hipSetDevice(ctx->device));
     return spatial_fetch_connected(ctx, d1, d2, K, IND_colptr, IND_rowidx, A_out, keep_out);
-}
-
-static int ticket_record(cnmfe_ctx *ctx, int64_t *ticket) {
-    size_t t = 0;
-    while (t < ctx->tickets.size() && ctx->ticket_busy[t]) ++t;
-    if (t == ctx->tickets.size()) {
-        hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->tickets.push_back(e); ctx->ticket_busy.push_back(0);
-    }
-    CK(hipEventRecord(ctx->tickets[t], ctx->st()));
-    ctx->ticket_busy[t] = 1;
-    *ticket = (int64_t)t;
-    return 0;
 }
 
 int cnmfe_update_spatial_fetch_connected_async(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K, const int64_t *IND_colptr, const int32_t *IND_rowidx,

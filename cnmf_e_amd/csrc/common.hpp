@@ -270,6 +270,8 @@ struct cnmfe_ctx {
     int64_t copy_gen = 0; std::vector<std::pair<int64_t, hipEvent_t>> copy_gens; std::vector<hipEvent_t> copy_ev_pool;
     int copy_batch_mark();                                 // api.hip: after the last enqueue of a batch on copy_stream
     std::vector<hipEvent_t> tickets; std::vector<char> ticket_busy;   // cnmfe_update_spatial_fetch_async / cnmfe_ticket_wait
+    int *ticket_flags = nullptr;                           // pinned, TICKET_FLAGS words: the device error word as it stood when ticket t was recorded (copied behind the ticket's work)
+    static constexpr size_t TICKET_FLAGS = 1024;
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;
     // scratch shared by all patches of this context (sized for the largest)

@@ -91,6 +91,7 @@ template <int J> __device__ __forceinline__ void rs_inv(double (&a)[16], const d
         const double lij = i > J ? a[J] * dj : 0.0;
         rs_inv_row<J, 0>(a, lij);
         a[J] = i > J ? -lij : a[J];
+        asm volatile("s_nop 0" : "+v"(a[J]));                // (round 5, scripts/isa_stats.py: the scheduler may sink this select to right in front of the DPP read of a[J] in step J + 1)
         rs_inv<J + 1>(a, mydinv, i);
     }
 }
@@ -140,6 +141,9 @@ template <int J, class Hook> __device__ __forceinline__ void rs_cholinv(double (
         hk.template at<2 * J + 1>();
         if constexpr (J < 15) rs_inv_row<J, 0>(a, lij);     // (J = 15: lij = 0 in every lane)
         a[J] = i > J ? -lij : a[J];
+        // a[J] is next read THROUGH DPP (rs_inv_row<J + 1, J>, no wait states of its own) a whole column later: without this pin the scheduler sank the select to
+        // right in front of that read (found in the ISA of the NT = 6 instantiation by scripts/isa_stats.py: lane J + 1's read returned the old a[J])
+        asm volatile("s_nop 0" : "+v"(a[J]));
         rs_cholinv<J + 1>(a, mydinv, i, inv_next, hk);
     }
 }
@@ -235,15 +239,14 @@ template <int NT, int K> struct RsLook {
         constexpr int t = Q / 4, r = Q % 4;
         if constexpr (t < NTRSM) {                                          // P_iK = X1' C_iK', rows K + 2 ..
             constexpr int i = K + 2 + t;
-            if constexpr (r == 0) tmp = (double4_t){0.0, 0.0, 0.0, 0.0};
-            rs_pin(tmp);
+            if constexpr (r == 0) { tmp = (double4_t){0.0, 0.0, 0.0, 0.0}; rs_pin(tmp); }     // (the pin behind call r is the pin in front of call r + 1)
             tmp = __builtin_amdgcn_mfma_f64_16x16x4f64(X1[r], T[rs_tix(i, K)][r], tmp, 0, 0, 0);
             rs_pin(tmp);
             if constexpr (r == 3) T[rs_tix(i, K)] = tmp;
         } else {
             constexpr RsIJ e = rs_upd_ij<NT, K>(t - NTRSM);
             if constexpr (r == 0 && e.first) nP = -T[rs_tix(e.j, K)];
-            rs_pin(T[rs_tix(e.i, e.j)]);
+            if constexpr (r == 0) rs_pin(T[rs_tix(e.i, e.j)]);
             T[rs_tix(e.i, e.j)] = __builtin_amdgcn_mfma_f64_16x16x4f64(nP[r], T[rs_tix(e.i, K)][r], T[rs_tix(e.i, e.j)], 0, 0, 0);
             rs_pin(T[rs_tix(e.i, e.j)]);
         }

@@ -66,9 +66,46 @@ __device__ __forceinline__ void rsp_rank2(double4_t (&T)[(NT * (NT + 1)) / 2], c
     }
 }
 
-// VAR (option "solve_variant", round 5): 0 = round 4's kernel; 1 = the system's cache lines touched at the top (they stream into L2 under the index set-up
-// instead of behind it), the set-up and staging loops unrolled (their two rounds' dependent gathers in flight together) and the fused diagonal step
-// (rs_cholinv); 2 = 1 + the look-ahead factorisation (rs_factor_la_step).  All three compute the same bits.
+// The same corrections on the MATRIX pipe (round 5).  The solve is bound by its vector instructions (6082 per pixel against 189 MFMAs, profiles/r04/pmc_pipes_v4.txt);
+// rsp_rank2 above spends ~250 of them per neuron.  Up to 8 staged neurons are one rank-16 update  G(a, b) -= sum_k P(k, a) Q(k, b)  with the 16 rows
+// k = (u_0..u_3 | u_4..u_7 | a_0..a_3 | a_4..a_7) of P paired with (a_0..a_3 | a_4..a_7 | u_0..u_3 | u_4..u_7) of Q: lane (c, rq) of the MFMA operands holds row
+// k = rq + 4 r' of call r', i.e. for ring pixel 16 X + c the FOUR values u_rq, u_rq+4, a_rq, a_rq+4 -- in this order (negated) as the A operand of block column J, in
+// the order a, a, u, u as the B operand of block row I.  Tile (I, J) holds G(16 I + c, 16 J + rq + 4 r) = D(rq + 4 r, c): A carries the J side.  84 fp64 MFMAs
+// (42 when at most four neurons are staged: calls 0 and 2) instead of 168 FMAs + 48 LDS reads per neuron.  Exact products, fp64 sums: the order of the sum over
+// the neurons differs from rsp_rank2 (1e-16 relative).
+template <int NT>
+__device__ __forceinline__ void rsp_rank2_mfma(double4_t (&T)[(NT * (NT + 1)) / 2], const double (*su)[16 * NT + 2], const float (*sa)[16 * NT + 2], int c, int rq, bool two) {
+    auto load4 = [&](int X, double &u0, double &u1, double &a0, double &a1) {
+        u0 = su[rq][16 * X + c]; a0 = (double)sa[rq][16 * X + c];
+        u1 = two ? su[rq + 4][16 * X + c] : 0.0; a1 = two ? (double)sa[rq + 4][16 * X + c] : 0.0;
+    };
+#pragma unroll
+    for (int J = 0; J < NT; ++J) {
+        double pu0, pu1, pa0, pa1;
+        load4(J, pu0, pu1, pa0, pa1);
+        pu0 = -pu0; pu1 = -pu1; pa0 = -pa0; pa1 = -pa1;
+#pragma unroll
+        for (int I = J; I < NT; ++I) {
+            double qu0, qu1, qa0, qa1;
+            if (I == J) { qu0 = -pu0; qu1 = -pu1; qa0 = -pa0; qa1 = -pa1; }
+            else load4(I, qu0, qu1, qa0, qa1);
+            double4_t t = T[rs_tix(I, J)];
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(pu0, qa0, t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(pa0, qu0, t, 0, 0, 0);
+            if (two) {
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(pu1, qa1, t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1, qu1, t, 0, 0, 0);
+            }
+            T[rs_tix(I, J)] = t;
+        }
+    }
+}
+
+// VAR (option "solve_variant", round 5) is a set of bits: RSV_FUSED = the fused diagonal step (rs_cholinv), RSV_LA = the look-ahead factorisation
+// (rs_factor_la_step; implies RSV_FUSED), RSV_MFMA2 = the footprints' rank-2 corrections on the matrix pipe (rsp_rank2_mfma).  0 = round 4's kernel.
+// Measured and dropped (profiles/r05/solve_variants.txt): a branch-free index set-up / staging with the gathers of a phase in flight together (+1600 vector
+// instructions of selects and clamped addresses in a kernel that is bound by them) and one touched dword per line of the system at the top (+6 gather instructions).
+constexpr int RSV_FUSED = 1, RSV_LA = 2, RSV_MFMA2 = 16;
 template <int NT, int VAR>
 __global__ void __launch_bounds__(64, (NT <= 2 ? 4 : (NT <= 3 ? 3 : (NT <= 6 ? 2 : 1))))
 k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc, const double *__restrict__ rowsum,
@@ -102,135 +139,47 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     const int blkm = (cbm >> 4) * g.nbr + (rbm >> 4);
     const bool corr = pa.arow != nullptr && !(probe & 8);
     if (lane < 2) s_mask[lane] = 0;
-    // VAR >= 1: one dword of every 128-byte line of the system, requested now and retired (long arrived) in front of the tile loads
-    constexpr int NTOUCH = VAR >= 1 ? ((NTILE * 256 + N) * 8 + 64 * 128 - 1) / (64 * 128) : 0;
-    int touch[NTOUCH > 0 ? NTOUCH : 1];
-    if constexpr (VAR >= 1) {
-        constexpr int LAST = ((NTILE * 256 + N) * 8 - 4) / 128;         // last line of the pixel's record
-#pragma unroll
-        for (int i = 0; i < NTOUCH; ++i) {
-            const int line = i * 64 + lane;
-            touch[i] = reinterpret_cast<const int *>(sp)[(line < LAST ? line : LAST) * 32];
-        }
-    }
     __syncthreads();
     int bad = 0;
-    double sc;
-    if constexpr (VAR >= 1) {
-        // Branch-free, every round of 64 lanes at once: the loads of a phase (ring offsets -> CSR row bounds, row sums, border vector -> cached entries ->
-        // their slots in the centre block's list) are in flight together, five dependent phases in all.  Round 4's loop took a branch and a full wait per load
-        // (two rounds x up to twelve dependent loads).  Indices of absent neighbours / entries are clamped to 0, their results discarded by selects.
-        constexpr int R = (N + 64) / 64;
-        int drv[R], dcv[R];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) { const int a = lane + 64 * rr, ai = a < p ? a : 0; drv[rr] = dr[ai]; dcv[rr] = dc[ai]; }
-        int qv[R], blkv[R], lpv[R];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int a = lane + 64 * rr;
-            const bool ring = a < p;
-            const int rb = ring ? rbm + drv[rr] : rbm, cb = ring ? cbm + dcv[rr] : cbm;
+#pragma unroll 1
+    for (int a = lane; a <= N; a += 64) {
+        int q = -1, rs = 0, bk = 0, ulp = 0, en = 0, e0s = 0;
+        if (a < p || a == N) {
+            const int rb = a < p ? rbm + dr[a] : rbm, cb = a < p ? cbm + dc[a] : cbm;
             const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-            const bool ex = (ring || a == N) && ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2;
-            qv[rr] = ex ? cb * g.nr_b + rb : -1;
-            blkv[rr] = ex ? (cb >> 4) * g.nbr + (rb >> 4) : 0;
-            lpv[rr] = lp_of(rb & 15, cb & 15);
-        }
-        double rsum[R], gvec[R];
+            if (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) {
+                q = cb * g.nr_b + rb;
+                const int blk = (cb >> 4) * g.nbr + (rb >> 4), lp = lp_of(rb & 15, cb & 15);
+                rs = blk * 256 + lp;
+                if (corr) {
+                    bk = blk * pa.K; ulp = pa.lst_ptr[blk] * 256 + lp;
+                    const int e0 = pa.arow[q];
+                    en = pa.arow[q + 1] - e0; e0s = e0;
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int a = lane + 64 * rr;
-            rsum[rr] = rowsum[blkv[rr] * 256 + lpv[rr]];
-            gvec[rr] = sp[NTILE * 256 + (a < N ? a : N - 1)];
-        }
-        sc = rowsum[blkm * 256 + lp_of(rbm & 15, cbm & 15)];
-        int e0v[R], env[R], lptv[R];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) { e0v[rr] = 0; env[rr] = 0; lptv[rr] = 0; }
-        if (corr) {
-            int e1v[R];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) { const int qq = qv[rr] >= 0 ? qv[rr] : 0; e0v[rr] = pa.arow[qq]; e1v[rr] = pa.arow[qq + 1]; lptv[rr] = pa.lst_ptr[blkv[rr]]; }
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) env[rr] = qv[rr] >= 0 ? e1v[rr] - e0v[rr] : 0;
-            int colv[R][RSP_CAP]; float valv[R][RSP_CAP];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-                for (int j = 0; j < RSP_CAP; ++j) { const int idx = j < env[rr] ? e0v[rr] + j : 0; colv[rr][j] = pa.acol[idx]; valv[rr][j] = pa.aval[idx]; }
-            int slv[R][RSP_CAP];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-                for (int j = 0; j < RSP_CAP; ++j) slv[rr][j] = pa.slot_of[(int64_t)blkm * pa.K + colv[rr][j]];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-                const int a = lane + 64 * rr;
-                if (a <= N) {
-#pragma unroll
-                    for (int j = 0; j < RSP_CAP; ++j) {
-                        s_ec[a][j] = colv[rr][j]; s_ev[a][j] = valv[rr][j];
-                        if (j < env[rr]) { if (slv[rr][j] < 0) bad = 1; else atomicOr(&s_mask[slv[rr][j] >> 5], 1u << (slv[rr][j] & 31)); }
-                    }
-                    for (int j = RSP_CAP; j < env[rr]; ++j) {          // (a pixel under more footprints than the cache holds: rare)
-                        const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0v[rr] + j]];
+                    for (int j = 0; j < RSP_CAP; ++j)
+                        if (j < en) {
+                            const int col = pa.acol[e0 + j];
+                            s_ec[a][j] = col; s_ev[a][j] = pa.aval[e0 + j];
+                            const int sl = pa.slot_of[(int64_t)blkm * pa.K + col];
+                            if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
+                        }
+                    for (int j = RSP_CAP; j < en; ++j) {               // (a pixel under more footprints than the cache holds: rare)
+                        const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0 + j]];
                         if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
                     }
                 }
             }
         }
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int a = lane + 64 * rr;
-            if (a <= N) {
-                const bool ex = qv[rr] >= 0;
-                s_q[a] = qv[rr]; s_rs[a] = ex ? blkv[rr] * 256 + lpv[rr] : 0; s_bk[a] = (ex && corr) ? blkv[rr] * pa.K : 0;
-                s_ulp[a] = (ex && corr) ? lptv[rr] * 256 + lpv[rr] : 0; s_en[a] = env[rr]; s_e0[a] = e0v[rr];
-                if (a < N) { s_vec[0][a] = ex ? rsum[rr] : 0.0; s_vec[1][a] = ex ? gvec[rr] : 0.0; }
-            }
-        }
-        __syncthreads();
-    } else {
-#pragma unroll 1
-        for (int a = lane; a <= N; a += 64) {
-            int q = -1, rs = 0, bk = 0, ulp = 0, en = 0, e0s = 0;
-            if (a < p || a == N) {
-                const int rb = a < p ? rbm + dr[a] : rbm, cb = a < p ? cbm + dc[a] : cbm;
-                const int ra = g.r0_abs + rb, ca = g.c0_abs + cb;
-                if (ra >= 1 && ra <= g.d1 && ca >= 1 && ca <= g.d2) {
-                    q = cb * g.nr_b + rb;
-                    const int blk = (cb >> 4) * g.nbr + (rb >> 4), lp = lp_of(rb & 15, cb & 15);
-                    rs = blk * 256 + lp;
-                    if (corr) {
-                        bk = blk * pa.K; ulp = pa.lst_ptr[blk] * 256 + lp;
-                        const int e0 = pa.arow[q];
-                        en = pa.arow[q + 1] - e0; e0s = e0;
-#pragma unroll
-                        for (int j = 0; j < RSP_CAP; ++j)
-                            if (j < en) {
-                                const int col = pa.acol[e0 + j];
-                                s_ec[a][j] = col; s_ev[a][j] = pa.aval[e0 + j];
-                                const int sl = pa.slot_of[(int64_t)blkm * pa.K + col];
-                                if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
-                            }
-                        for (int j = RSP_CAP; j < en; ++j) {               // (a pixel under more footprints than the cache holds: rare)
-                            const int sl = pa.slot_of[(int64_t)blkm * pa.K + pa.acol[e0 + j]];
-                            if (sl < 0) bad = 1; else atomicOr(&s_mask[sl >> 5], 1u << (sl & 31));
-                        }
-                    }
-                }
-            }
-            s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en; s_e0[a] = e0s;
-        }
-        __syncthreads();
-        // ---- border vectors u (row sums of Bf: corrected by k_rowsum_correct), g (the video's, corrected below) and the scalar s ----
-        for (int a = lane; a < N; a += 64) {
-            const bool ex = s_q[a] >= 0;
-            s_vec[0][a] = ex ? rowsum[s_rs[a]] : 0.0;
-            s_vec[1][a] = ex ? sp[NTILE * 256 + a] : 0.0;
-        }
-        sc = rowsum[s_rs[N]];
+        s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en; s_e0[a] = e0s;
     }
+    __syncthreads();
+    // ---- border vectors u (row sums of Bf: corrected by k_rowsum_correct), g (the video's, corrected below) and the scalar s ----
+    for (int a = lane; a < N; a += 64) {
+        const bool ex = s_q[a] >= 0;
+        s_vec[0][a] = ex ? rowsum[s_rs[a]] : 0.0;
+        s_vec[1][a] = ex ? sp[NTILE * 256 + a] : 0.0;
+    }
+    const double sc = rowsum[s_rs[N]];
     // ---- the footprints' corrections: one symmetric rank-2 update per neuron with a pixel on the ring or under the centre.  A round stages U~ and A of up to
     // RSP_CH neurons for every ring pixel in LDS (two dependent gathers: slot, value); the FIRST round runs before the system is loaded -- with the 168 tile
     // registers live the compiler spilled a third of them around this phase --, later rounds (more than RSP_CH neurons on one ring: rare) run under them
@@ -248,51 +197,6 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
             ks[i] = -1;
             if (mask) { const int s = __builtin_ctzll(mask); mask &= mask - 1; ks[i] = pa.lst_k[lbm + s]; ++nst; }
         }
-        if constexpr (VAR >= 1) {
-            // both gathers (slot of trace ks[i] in the pixel's block list -> U~ of that slot) for every round of lanes at once, clamped addresses + selects
-            constexpr int R = (N + 64) / 64;
-            int qs[R], sl[R][RSP_CH];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-                const int a = lane + 64 * rr, al = a <= N ? a : N;
-                qs[rr] = a <= N ? s_q[al] : -1;
-                const int bk = s_bk[al];
-#pragma unroll
-                for (int i = 0; i < RSP_CH; ++i) sl[rr][i] = (int)pa.slot_of[(qs[rr] >= 0 && ks[i] >= 0) ? (int64_t)bk + ks[i] : 0];
-            }
-            double uu[R][RSP_CH];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-                const int a = lane + 64 * rr, al = a <= N ? a : N;
-                const int ulp = s_ulp[al];
-#pragma unroll
-                for (int i = 0; i < RSP_CH; ++i) {
-                    const bool use = qs[rr] >= 0 && ks[i] >= 0;
-                    bad |= use && sl[rr][i] == -1;
-                    const bool ok = use && sl[rr][i] >= 0;
-                    const double v = pa.Ut[ok ? (int64_t)ulp + (int64_t)sl[rr][i] * 256 : 0];
-                    uu[rr][i] = ok ? v : 0.0;
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-                const int a = lane + 64 * rr;
-                if (a <= N) {
-                    const int en = s_en[a];
-#pragma unroll
-                    for (int i = 0; i < RSP_CH; ++i) {
-                        float av = 0.f;
-#pragma unroll
-                        for (int j = 0; j < RSP_CAP; ++j) if (j < en && s_ec[a][j] == ks[i]) av = s_ev[a][j];
-                        if (en > RSP_CAP && ks[i] >= 0) {
-                            const int e0 = s_e0[a];
-                            for (int j = RSP_CAP; j < en; ++j) if (pa.acol[e0 + j] == ks[i]) av = pa.aval[e0 + j];
-                        }
-                        s_u[slot0 + i][a] = uu[rr][i]; s_a[slot0 + i][a] = av;
-                    }
-                }
-            }
-        } else {
 #pragma unroll 1
         for (int a = lane; a <= N; a += 64) {
             const int q = s_q[a];
@@ -318,12 +222,12 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
                 s_u[slot0 + i][a] = uu[i]; s_a[slot0 + i][a] = av;
             }
         }
-        }
     };
     auto apply = [&](double4_t (&T)[NTILE]) {
         __syncthreads();
+        if constexpr ((VAR & RSV_MFMA2) != 0) rsp_rank2_mfma<NT>(T, s_u, s_a, c, rq, nst > RSP_CH);
         for (int i = 0; i < nst; ++i) {
-            rsp_rank2<NT>(T, s_u[i], s_a[i], c, rq);
+            if constexpr ((VAR & RSV_MFMA2) == 0) rsp_rank2<NT>(T, s_u[i], s_a[i], c, rq);
             const double uN = s_u[i][N], aN = (double)s_a[i][N];
             for (int a = lane; a < N; a += 64) s_vec[1][a] -= fma(s_u[i][a], aN, (double)s_a[i][a] * uN);
         }
@@ -331,12 +235,6 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     };
     if (mask) stage(0);
     if (mask) stage(RSP_CH);
-    if constexpr (VAR >= 1) {
-        int tacc = 0;
-#pragma unroll
-        for (int i = 0; i < NTOUCH; ++i) tacc |= touch[i];
-        asm volatile("" :: "v"(tacc));
-    }
     // ---- the system: 2 NTILE coalesced 16-byte loads, all in flight at once ----
     double4_t T[NTILE];
 #pragma unroll
@@ -368,7 +266,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     if (bad) atomicOr(errflag, 1);
     __syncthreads();
     double wc[NT];
-    rs_solve_core<NT, VAR>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
+    rs_solve_core<NT, ((VAR & RSV_LA) ? 2 : ((VAR & RSV_FUSED) ? 1 : 0))>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
     if (rq == 0) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) {

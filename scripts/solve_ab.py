@@ -1,7 +1,7 @@
 """Phase probes of the ring-regression solve kernel on one patch: python scripts/solve_ab.py --cfg c3 [--probes 0,1,3,7]
 (solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions, 8 no footprint corrections).  Every run fits the same
-first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_variant (ring_solve_packed.hpp: 0 round 4's kernel,
-1 prefetch + branch-free set-up + fused diagonal step, 2 = 1 + look-ahead factorisation); the weights of every mode are compared with the first's bit for bit."""
+first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_variant (bg.hip: 0 round 4's kernel, 1 fused diagonal step,
+2 = 1 + look-ahead factorisation, 3 rank-2 corrections on the matrix pipe, 4 = 2 + 3, 5 = 1 + 3); the weights of every mode are compared with the first's."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,4 +40,4 @@ for mode in [int(x) for x in a.modes.split(",")]:
 ks = list(Ws)
 for k in ks[1:]:
     dW = np.abs(Ws[k] - Ws[ks[0]])
-    print("max |W_%d - W_%d| / max|W| = %.3e   (rms %.3e, nan %d, entries that differ in any bit %d of %d)" % (k, ks[0], dW.max() / np.abs(Ws[ks[0]]).max(), np.sqrt((dW ** 2).mean()), int(np.isnan(Ws[k]).sum()), int((Ws[k].view(np.uint32) != Ws[ks[0]].view(np.uint32)).sum()), Ws[k].size))
+    print("max |W_%d - W_%d| / max|W| = %.3e   (rms %.3e, nan %d, entries that differ in any bit %d of %d)" % (k, ks[0], np.nanmax(dW) / np.abs(Ws[ks[0]]).max(), np.sqrt(np.nanmean(dW ** 2)), int(np.isnan(Ws[k]).sum()), int((Ws[k].view(np.uint32) != Ws[ks[0]].view(np.uint32)).sum()), Ws[k].size))
