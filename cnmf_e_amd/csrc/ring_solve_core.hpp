@@ -27,6 +27,13 @@ __device__ __forceinline__ double rs_rsqrt(double x) {
     return y;
 }
 
+// A workgroup of ONE wave exchanges through LDS behind __syncthreads() (no barrier instruction is emitted for it); the four waves of a shared-diagonal workgroup
+// (round 5, rs_factor4_step) exchange per wave: LDS operations of one wave execute in order, so only the COMPILER must be kept from moving them across the point.
+template <int WG> __device__ __forceinline__ void rs_sync() {
+    if constexpr (WG == 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+}
+
 constexpr int RS_DS = 18;                 // row stride (doubles) of the 16x16 LDS exchange tile: conflict-free b128 row reads
 
 __host__ __device__ constexpr int rs_tix(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
@@ -255,6 +262,7 @@ template <int NT, int K> struct RsLook {
         if constexpr (Q < QE) { op<Q>(); run<Q + 1, QE>(); }
     }
     template <int H> __device__ __forceinline__ void at() { run<(H * NOPS) / NHOOK, ((H + 1) * NOPS) / NHOOK>(); }
+    __device__ __forceinline__ void run_all() { run<0, NOPS>(); }
 };
 template <int NT, int K>
 __device__ __forceinline__ void rs_factor_la_step(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq, const double4_t &X1) {
@@ -293,6 +301,76 @@ __device__ __forceinline__ void rs_factor_fused(double4_t (&T)[(NT * (NT + 1)) /
         rs_factor_fused<NT, K + 1>(T, s_blk, lane, c, rq, X1n);
     }
 }
+// ---- round 5: SHARED diagonal steps.  The diagonal step works in 16-lane DPP rows and a one-wave workgroup runs it four times in replica -- 3300 of the solve's
+// 6082 vector instructions per pixel, on the pipe that bounds it (profiles/r04/pmc_pipes_v4.txt: vector pipe 50 % busy, matrix pipe 24 %).  A workgroup of FOUR
+// waves = four pixels hands the four diagonal tiles of a block column to ONE wave, DPP row pp = pixel pp: the same instruction stream factors and inverts four
+// different tiles.  The duty rotates (wave K mod 4 takes column K: the waves sit on different SIMDs), two workgroup barriers per block column; with the look-ahead
+// the other three waves issue their column's remaining MFMAs meanwhile.  sb4 + w * stride = the exchange tile of wave w.
+template <class Hook> __device__ __forceinline__ void rs_diag_block4(double *sb4, int stride, int lane, Hook &hk) {
+    const int i = lane & 15;
+    double *sb = sb4 + (lane >> 4) * stride;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2 *>(sb + i * RS_DS + c); a[c] = v.x; a[c + 1] = v.y; }
+    double mydinv = 0.0;
+    rs_cholinv<0>(a, mydinv, i, rs_rsqrt(rs_bc<0>(a[0])), hk);
+    rs_sync<4>();                                           // every lane of this wave has read its row
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        double2 v;
+        v.x = i > c ? a[c] * mydinv : (i == c ? mydinv : 0.0);
+        v.y = i > c + 1 ? a[c + 1] * mydinv : (i == c + 1 ? mydinv : 0.0);
+        *reinterpret_cast<double2 *>(sb + i * RS_DS + c) = v;
+    }
+}
+// block column K is factored (X1 = inv(L_KK)' of this wave's pixel): its panel and trailing update, then the shared diagonal step of column K + 1
+template <int NT, int K, bool LA>
+__device__ __forceinline__ void rs_factor4_step(double4_t (&T)[(NT * (NT + 1)) / 2], double *sb4, int stride, int w, int lane, int c, int rq, const double4_t &X1) {
+    if constexpr (K + 1 < NT) {
+        double *s_blk = sb4 + w * stride;
+        if constexpr (LA) {
+            T[rs_tix(K + 1, K)] = rs_mfma4(X1, T[rs_tix(K + 1, K)], (double4_t){0.0, 0.0, 0.0, 0.0});
+            const double4_t nP = -T[rs_tix(K + 1, K)];
+            T[rs_tix(K + 1, K + 1)] = rs_mfma4(nP, T[rs_tix(K + 1, K)], T[rs_tix(K + 1, K + 1)]);
+        } else {
+            rs_step<NT, K>(T, X1);
+        }
+        rs_put_diag(T[rs_tix(K + 1, K + 1)], s_blk, c, rq);
+        __syncthreads();                                    // the four tiles of column K + 1 are in LDS
+        if constexpr (LA) {
+            RsLook<NT, K> hk(T, X1);
+            if (w == ((K + 1) & 3)) rs_diag_block4(sb4, stride, lane, hk);
+            else hk.run_all();
+        } else {
+            RsNoHook nh;
+            if (w == ((K + 1) & 3)) rs_diag_block4(sb4, stride, lane, nh);
+        }
+        __syncthreads();                                    // ... and hold inv(L)
+        double4_t X1n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X1n[r] = s_blk[c * RS_DS + rq + 4 * r];
+        rs_sync<4>();
+        if constexpr (LA) T[rs_tix(K, K)] = X1;
+        rs_factor4_step<NT, K + 1, LA>(T, sb4, stride, w, lane, c, rq, X1n);
+    } else {
+        if constexpr (LA) T[rs_tix(K, K)] = X1;
+        else rs_step<NT, K>(T, X1);
+    }
+}
+template <int NT, bool LA>
+__device__ __forceinline__ void rs_factor4(double4_t (&T)[(NT * (NT + 1)) / 2], double *sb4, int stride, int w, int lane, int c, int rq) {
+    double *s_blk = sb4 + w * stride;
+    rs_put_diag(T[0], s_blk, c, rq);
+    __syncthreads();
+    RsNoHook nh;
+    if (w == 0) rs_diag_block4(sb4, stride, lane, nh);
+    __syncthreads();
+    double4_t X1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X1[r] = s_blk[c * RS_DS + rq + 4 * r];
+    rs_sync<4>();
+    rs_factor4_step<NT, 0, LA>(T, sb4, stride, w, lane, c, rq, X1);
+}
 // VAR 0: rs_factor as it was; 1: the fused diagonal step; 2: fused + look-ahead
 template <int NT, int VAR>
 __device__ __forceinline__ void rs_factor_var(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq) {
@@ -317,13 +395,17 @@ __device__ __forceinline__ void rs_factor_var(double4_t (&T)[(NT * (NT + 1)) / 2
 //   s_blk   : [16 * RS_DS] LDS, s_part : [4][64] LDS
 //   sc, lam, Tp : s, the ridge, the number of frames (the ones row's own Gram entry)
 //   wc[k]   : on return, w(16 k + c) in every lane with l & 15 == c
-template <int NT, int VAR = 0>
+//   WG = 4 (shared diagonal steps): s_blk = this wave's exchange tile, the tile of wave v at s_blk + (v - w) * stride
+template <int NT, int VAR = 0, int WG = 1>
 __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2], double (*s_vec)[16 * NT], double *s_blk, double (*s_part)[64],
-                                              double sc, double lam, double Tp, int lane, int probe, double (&wc)[NT]) {
+                                              double sc, double lam, double Tp, int lane, int probe, double (&wc)[NT], int w = 0, int stride = 0) {
     constexpr int N = 16 * NT;
     const int c = lane & 15, rq = lane >> 4;
     // ---- block Cholesky ----
-    if (!(probe & 2)) rs_factor_var<NT, VAR>(T, s_blk, lane, c, rq);
+    if (!(probe & 2)) {
+        if constexpr (WG == 4) rs_factor4<NT, VAR == 2>(T, s_blk - w * stride, stride, w, lane, c, rq);
+        else rs_factor_var<NT, VAR>(T, s_blk, lane, c, rq);
+    }
     if (probe & 4) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) wc[k] = T[rs_tix(k, k)][0];
@@ -339,7 +421,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
         const double4_t Mkk = T[rs_tix(k, k)];
 #pragma unroll
         for (int v = 0; v < 2; ++v) s_part[v][c * 4 + rq] = (rq == 0 ? s_vec[v][16 * k + c] : 0.0) - pb[v][k];
-        __syncthreads();
+        rs_sync<WG>();
         double p2[2];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -354,7 +436,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
         }
 #pragma unroll
         for (int v = 0; v < 2; ++v) s_part[2 + v][c * 4 + rq] = p2[v];
-        __syncthreads();
+        rs_sync<WG>();
         double zq[2][4];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -379,7 +461,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
                 for (int r = 0; r < 4; ++r) acc = fma(T[rs_tix(i, k)][r], zq[v][r], acc);
                 pb[v][i] = acc;
             }
-        __syncthreads();
+        rs_sync<WG>();
     }
     // ---- Schur complement of the ones row: w0, then y = z_g - w0 z_u ----
     double zuu = 0.0, zug = 0.0;
@@ -387,7 +469,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
     zuu = rs_wave_sum(zuu); zug = rs_wave_sum(zug);
     const double w0 = (sc - zug) / (Tp + lam - zuu);
     for (int a = lane; a < N; a += 64) s_vec[2][a] = s_vec[1][a] - w0 * s_vec[0][a];
-    __syncthreads();
+    rs_sync<WG>();
     // ---- back substitution L' w = y: w_k = inv(L_kk)' (y_k - sum_{i>k} L_ik' w_i); both products contract over the lane index c ----
 #pragma unroll
     for (int k = NT - 1; k >= 0; --k) {
@@ -400,21 +482,21 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
                 for (int r = 0; r < 4; ++r) acc[r] = fma(T[rs_tix(i, k)][r], wc[i], acc[r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = acc[r];
-            __syncthreads();
+            rs_sync<WG>();
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 16; cc += 2) { const double2 v = *reinterpret_cast<const double2 *>(s_blk + c * RS_DS + cc); s0 += v.x; s1 += v.y; }
             yk -= s0 + s1;
-            __syncthreads();
+            rs_sync<WG>();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = T[rs_tix(k, k)][r] * yk;
-        __syncthreads();
+        rs_sync<WG>();
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < 16; cc += 2) { const double2 v = *reinterpret_cast<const double2 *>(s_blk + c * RS_DS + cc); s0 += v.x; s1 += v.y; }
         wc[k] = s0 + s1;
-        __syncthreads();
+        rs_sync<WG>();
     }
 }
 
