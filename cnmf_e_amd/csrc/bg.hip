@@ -1281,33 +1281,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
             int *dErrS = nullptr;
             RET(ctx_errflag(ctx, &dErrS));
-            // option solve_variant: an index into the measured combinations of ring_solve_packed.hpp's RSV_* bits
-            const int svar = (int)ctx->opt("solve_variant", 0);
-#define RS6_LAUNCH(NT_, V_) LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_, V_, 1>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr)
-#define RS6_LAUNCH4(NT_, V_) LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_, V_, 4>), dim3((unsigned)((P->d + 3) / 4)), dim3(256), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr)
-            // (7 and 8 tiles keep a third of their system in accumulation registers: the look-ahead's pins would copy those tiles to vector registers and back)
-#define RS6_CASE(NT_) case NT_: if (svar == 4) RS6_LAUNCH(NT_, (NT_ <= 6 ? RSV_FUSED | RSV_LA | RSV_MFMA2 : RSV_FUSED | RSV_MFMA2)); \
-                                else if (svar == 6) RS6_LAUNCH4(NT_, RSV_FUSED); else RS6_LAUNCH(NT_, 0); break;
-            if (nt == 6) {
-                switch (svar) {
-                case 1: RS6_LAUNCH(6, RSV_FUSED); break;
-                case 2: RS6_LAUNCH(6, RSV_FUSED | RSV_LA); break;
-                case 3: RS6_LAUNCH(6, RSV_MFMA2); break;
-                case 4: RS6_LAUNCH(6, RSV_FUSED | RSV_LA | RSV_MFMA2); break;
-                case 5: RS6_LAUNCH(6, RSV_FUSED | RSV_MFMA2); break;
-                case 6: RS6_LAUNCH4(6, RSV_FUSED); break;
-                case 7: RS6_LAUNCH4(6, RSV_FUSED | RSV_LA); break;
-                case 8: RS6_LAUNCH4(6, RSV_FUSED | RSV_LA | RSV_MFMA2); break;
-                case 9: RS6_LAUNCH4(6, RSV_FUSED | RSV_MFMA2); break;
-                default: RS6_LAUNCH(6, 0); break;
-                }
-            } else
-            switch (nt) { RS6_CASE(1) RS6_CASE(2) RS6_CASE(3) RS6_CASE(4) RS6_CASE(5) RS6_CASE(7) RS6_CASE(8) default: break; }
+#define RS6_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr); break;
+            switch (nt) { RS6_CASE(1) RS6_CASE(2) RS6_CASE(3) RS6_CASE(4) RS6_CASE(5) RS6_CASE(6) RS6_CASE(7) RS6_CASE(8) default: break; }
 #undef RS6_CASE
-#undef RS6_LAUNCH4
-#undef RS6_LAUNCH
         } else {
         RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
         LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());

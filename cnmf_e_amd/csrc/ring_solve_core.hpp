@@ -27,13 +27,6 @@ __device__ __forceinline__ double rs_rsqrt(double x) {
     return y;
 }
 
-// A workgroup of ONE wave exchanges through LDS behind __syncthreads() (no barrier instruction is emitted for it); the four waves of a shared-diagonal workgroup
-// (round 5, rs_factor4_step) exchange per wave: LDS operations of one wave execute in order, so only the COMPILER must be kept from moving them across the point.
-template <int WG> __device__ __forceinline__ void rs_sync() {
-    if constexpr (WG == 1) __syncthreads();
-    else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
-}
-
 constexpr int RS_DS = 18;                 // row stride (doubles) of the 16x16 LDS exchange tile: conflict-free b128 row reads
 
 __host__ __device__ constexpr int rs_tix(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
@@ -98,7 +91,11 @@ template <int J> __device__ __forceinline__ void rs_inv(double (&a)[16], const d
         const double lij = i > J ? a[J] * dj : 0.0;
         rs_inv_row<J, 0>(a, lij);
         a[J] = i > J ? -lij : a[J];
-        asm volatile("s_nop 0" : "+v"(a[J]));                // (round 5, scripts/isa_stats.py: the scheduler may sink this select to right in front of the DPP read of a[J] in step J + 1)
+        // Round 5: a[J] is next read THROUGH DPP -- rs_inv_row<J + 1, J>, an asm statement without wait states of its own -- and the scheduler is free to sink
+        // this select to right in front of that read (VALU write -> DPP read needs two wait states; the compiler's hazard recogniser does not look into asm).
+        // scripts/isa_stats.py found exactly that in the NT = 4, 5, 7, 8 instantiations (at J = 15, where the stale value is multiplied by lij = 0: harmless by
+        // luck) and, in this round's fused variant of the step, at J = 14 (wrong weights).  The pin keeps the select in front of the next step's asm sequence.
+        asm volatile("s_nop 0" : "+v"(a[J]));
         rs_inv<J + 1>(a, mydinv, i);
     }
 }
@@ -113,54 +110,6 @@ __device__ __forceinline__ void rs_diag_block(double *sb, int lane) {
     double mydinv = 0.0;
     rs_chol<0>(a, mydinv, i, rs_rsqrt(rs_bc<0>(a[0])));
     rs_inv<0>(a, mydinv, i);
-    __syncthreads();                                        // every lane has read its row
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c += 2) {
-            double2 v;
-            v.x = i > c ? a[c] * mydinv : (i == c ? mydinv : 0.0);
-            v.y = i > c + 1 ? a[c + 1] * mydinv : (i == c + 1 ? mydinv : 0.0);
-            *reinterpret_cast<double2 *>(sb + i * RS_DS + c) = v;
-        }
-    }
-    __syncthreads();
-}
-
-// ---- round 5: the diagonal step with the inversion UNDER the pivot chain ----
-// rs_chol is a chain of 16 pivots (update -> broadcast -> v_rsq_f64 + two Newton steps -> scale: ~100 clocks each, of which the 15 - J updates of column J fill
-// less and less), and rs_inv behind it a second chain of 16 steps whose J-th needs only column J of L and the rows of the inverse above J.  Fused, step J of the
-// inversion (J updates on a[0 .. J-1]) runs in the shadow of pivot J + 1's reciprocal square root, where column J's own updates (14 - J of them, on a[J+2 ..])
-// run out: every column issues ~17 updates whatever J is.  Same operations on the same values in the same per-register order: bit-identical to rs_chol + rs_inv.
-// `hk.at<H>()`, H = 0 .. 31, is called twice per column: the look-ahead factorisation below issues the previous block column's trailing MFMAs there.
-struct RsNoHook { template <int H> __device__ __forceinline__ void at() {} };
-template <int J, class Hook> __device__ __forceinline__ void rs_cholinv(double (&a)[16], double &mydinv, int i, double inv, Hook &hk) {
-    if constexpr (J < 16) {
-        a[J] *= inv;                                        // L(i, J), i >= J
-        mydinv = i == J ? inv : mydinv;
-        double inv_next = 0.0;
-        if constexpr (J + 1 < 16) {
-            rs_fmac_bc<J + 1, true>(a[J + 1], a[J], a[J]);
-            inv_next = rs_rsqrt(rs_bc<J + 1>(a[J + 1]));
-        }
-        hk.template at<2 * J>();
-        if constexpr (J + 1 < 16) rs_chol_col<J, J + 2>(a);
-        const double lij = i > J ? a[J] * inv : 0.0;        // (inv == the broadcast of lane J's mydinv that rs_inv takes)
-        hk.template at<2 * J + 1>();
-        if constexpr (J < 15) rs_inv_row<J, 0>(a, lij);     // (J = 15: lij = 0 in every lane)
-        a[J] = i > J ? -lij : a[J];
-        // a[J] is next read THROUGH DPP (rs_inv_row<J + 1, J>, no wait states of its own) a whole column later: without this pin the scheduler sank the select to
-        // right in front of that read (found in the ISA of the NT = 6 instantiation by scripts/isa_stats.py: lane J + 1's read returned the old a[J])
-        asm volatile("s_nop 0" : "+v"(a[J]));
-        rs_cholinv<J + 1>(a, mydinv, i, inv_next, hk);
-    }
-}
-template <class Hook> __device__ __forceinline__ void rs_diag_block2(double *sb, int lane, Hook &hk) {
-    const int i = lane & 15;
-    double a[16];
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2 *>(sb + i * RS_DS + c); a[c] = v.x; a[c + 1] = v.y; }
-    double mydinv = 0.0;
-    rs_cholinv<0>(a, mydinv, i, rs_rsqrt(rs_bc<0>(a[0])), hk);
     __syncthreads();                                        // every lane has read its row
     if (lane < 16) {
 #pragma unroll
@@ -215,197 +164,19 @@ __device__ __forceinline__ void rs_factor(double4_t (&T)[(NT * (NT + 1)) / 2], d
 }
 
 
-// ---- round 5: look-ahead.  Diagonal step K + 1 needs ONE tile of block column K's trailing update -- (K+1, K+1) -- and is a ~2200-clock chain on the vector
-// pipe; the other TRSMs and rank-16 updates of column K (72 / 48 / 28 / 12 MFMAs of 64 clocks at NT = 6) do not depend on it.  An in-order wave overlaps the two
-// only if they alternate in program order, so the diagonal step calls a hook twice per column (rs_cholinv) and the hook issues the next MFMAs of the column's
-// remainder there.  Every MFMA is pinned between two `s_nop 0` asm statements on its accumulator (volatile asm keeps its order against the DPP statements of the
-// diagonal step; a NON-empty pin because the hazard recogniser counts an asm statement as one wait state whatever it holds).  Same products, same accumulation
-// order per tile: bit-identical to rs_factor.
-struct RsIJ { int i, j; bool first; };
-template <int NT, int K> __host__ __device__ constexpr RsIJ rs_upd_ij(int u) {          // u-th trailing tile of block column K in rs_step's order, (K+1, K+1) left out
-    int idx = 0;
-    for (int j = K + 1; j < NT; ++j) {
-        bool first = true;
-        for (int i = j; i < NT; ++i) {
-            if (i == K + 1 && j == K + 1) continue;
-            if (idx == u) return RsIJ{i, j, first};
-            first = false; ++idx;
-        }
-    }
-    return RsIJ{-1, -1, false};
-}
-__device__ __forceinline__ void rs_pin(double4_t &x) { asm volatile("s_nop 0" : "+v"(x)); }
-template <int NT, int K> struct RsLook {
-    static constexpr int n = NT - K - 1;                                    // tiles of the panel below the diagonal
-    static constexpr int NTRSM = n - 1, NUPD = (n * (n + 1)) / 2 - 1, NOPS = 4 * (NTRSM + NUPD), NHOOK = 32;
-    double4_t (&T)[(NT * (NT + 1)) / 2];
-    const double4_t &X1;
-    double4_t tmp, nP;
-    __device__ __forceinline__ RsLook(double4_t (&T_)[(NT * (NT + 1)) / 2], const double4_t &X1_) : T(T_), X1(X1_) {}
-    template <int Q> __device__ __forceinline__ void op() {
-        constexpr int t = Q / 4, r = Q % 4;
-        if constexpr (t < NTRSM) {                                          // P_iK = X1' C_iK', rows K + 2 ..
-            constexpr int i = K + 2 + t;
-            if constexpr (r == 0) { tmp = (double4_t){0.0, 0.0, 0.0, 0.0}; rs_pin(tmp); }     // (the pin behind call r is the pin in front of call r + 1)
-            tmp = __builtin_amdgcn_mfma_f64_16x16x4f64(X1[r], T[rs_tix(i, K)][r], tmp, 0, 0, 0);
-            rs_pin(tmp);
-            if constexpr (r == 3) T[rs_tix(i, K)] = tmp;
-        } else {
-            constexpr RsIJ e = rs_upd_ij<NT, K>(t - NTRSM);
-            if constexpr (r == 0 && e.first) nP = -T[rs_tix(e.j, K)];
-            if constexpr (r == 0) rs_pin(T[rs_tix(e.i, e.j)]);
-            T[rs_tix(e.i, e.j)] = __builtin_amdgcn_mfma_f64_16x16x4f64(nP[r], T[rs_tix(e.i, K)][r], T[rs_tix(e.i, e.j)], 0, 0, 0);
-            rs_pin(T[rs_tix(e.i, e.j)]);
-        }
-    }
-    template <int Q, int QE> __device__ __forceinline__ void run() {
-        if constexpr (Q < QE) { op<Q>(); run<Q + 1, QE>(); }
-    }
-    template <int H> __device__ __forceinline__ void at() { run<(H * NOPS) / NHOOK, ((H + 1) * NOPS) / NHOOK>(); }
-    __device__ __forceinline__ void run_all() { run<0, NOPS>(); }
-};
-template <int NT, int K>
-__device__ __forceinline__ void rs_factor_la_step(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq, const double4_t &X1) {
-    if constexpr (K + 1 < NT) {
-        T[rs_tix(K + 1, K)] = rs_mfma4(X1, T[rs_tix(K + 1, K)], (double4_t){0.0, 0.0, 0.0, 0.0});
-        {
-            const double4_t nP = -T[rs_tix(K + 1, K)];
-            T[rs_tix(K + 1, K + 1)] = rs_mfma4(nP, T[rs_tix(K + 1, K)], T[rs_tix(K + 1, K + 1)]);
-        }
-        rs_put_diag(T[rs_tix(K + 1, K + 1)], s_blk, c, rq);
-        __syncthreads();
-        RsLook<NT, K> hk(T, X1);
-        rs_diag_block2(s_blk, lane, hk);
-        double4_t X1n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X1n[r] = s_blk[c * RS_DS + rq + 4 * r];
-        __syncthreads();
-        T[rs_tix(K, K)] = X1;
-        rs_factor_la_step<NT, K + 1>(T, s_blk, lane, c, rq, X1n);
-    } else {
-        T[rs_tix(K, K)] = X1;
-    }
-}
-template <int NT, int K>
-__device__ __forceinline__ void rs_factor_fused(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq, const double4_t &X1) {
-    rs_step<NT, K>(T, X1);
-    if constexpr (K + 1 < NT) {
-        rs_put_diag(T[rs_tix(K + 1, K + 1)], s_blk, c, rq);
-        __syncthreads();
-        RsNoHook nh;
-        rs_diag_block2(s_blk, lane, nh);
-        double4_t X1n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X1n[r] = s_blk[c * RS_DS + rq + 4 * r];
-        __syncthreads();
-        rs_factor_fused<NT, K + 1>(T, s_blk, lane, c, rq, X1n);
-    }
-}
-// ---- round 5: SHARED diagonal steps.  The diagonal step works in 16-lane DPP rows and a one-wave workgroup runs it four times in replica -- 3300 of the solve's
-// 6082 vector instructions per pixel, on the pipe that bounds it (profiles/r04/pmc_pipes_v4.txt: vector pipe 50 % busy, matrix pipe 24 %).  A workgroup of FOUR
-// waves = four pixels hands the four diagonal tiles of a block column to ONE wave, DPP row pp = pixel pp: the same instruction stream factors and inverts four
-// different tiles.  The duty rotates (wave K mod 4 takes column K: the waves sit on different SIMDs), two workgroup barriers per block column; with the look-ahead
-// the other three waves issue their column's remaining MFMAs meanwhile.  sb4 + w * stride = the exchange tile of wave w.
-template <class Hook> __device__ __forceinline__ void rs_diag_block4(double *sb4, int stride, int lane, Hook &hk) {
-    const int i = lane & 15;
-    double *sb = sb4 + (lane >> 4) * stride;
-    double a[16];
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2 *>(sb + i * RS_DS + c); a[c] = v.x; a[c + 1] = v.y; }
-    double mydinv = 0.0;
-    rs_cholinv<0>(a, mydinv, i, rs_rsqrt(rs_bc<0>(a[0])), hk);
-    rs_sync<4>();                                           // every lane of this wave has read its row
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        double2 v;
-        v.x = i > c ? a[c] * mydinv : (i == c ? mydinv : 0.0);
-        v.y = i > c + 1 ? a[c + 1] * mydinv : (i == c + 1 ? mydinv : 0.0);
-        *reinterpret_cast<double2 *>(sb + i * RS_DS + c) = v;
-    }
-}
-// block column K is factored (X1 = inv(L_KK)' of this wave's pixel): its panel and trailing update, then the shared diagonal step of column K + 1
-template <int NT, int K, bool LA>
-__device__ __forceinline__ void rs_factor4_step(double4_t (&T)[(NT * (NT + 1)) / 2], double *sb4, int stride, int w, int lane, int c, int rq, const double4_t &X1) {
-    if constexpr (K + 1 < NT) {
-        double *s_blk = sb4 + w * stride;
-        if constexpr (LA) {
-            T[rs_tix(K + 1, K)] = rs_mfma4(X1, T[rs_tix(K + 1, K)], (double4_t){0.0, 0.0, 0.0, 0.0});
-            const double4_t nP = -T[rs_tix(K + 1, K)];
-            T[rs_tix(K + 1, K + 1)] = rs_mfma4(nP, T[rs_tix(K + 1, K)], T[rs_tix(K + 1, K + 1)]);
-        } else {
-            rs_step<NT, K>(T, X1);
-        }
-        rs_put_diag(T[rs_tix(K + 1, K + 1)], s_blk, c, rq);
-        __syncthreads();                                    // the four tiles of column K + 1 are in LDS
-        if constexpr (LA) {
-            RsLook<NT, K> hk(T, X1);
-            if (w == ((K + 1) & 3)) rs_diag_block4(sb4, stride, lane, hk);
-            else hk.run_all();
-        } else {
-            RsNoHook nh;
-            if (w == ((K + 1) & 3)) rs_diag_block4(sb4, stride, lane, nh);
-        }
-        __syncthreads();                                    // ... and hold inv(L)
-        double4_t X1n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X1n[r] = s_blk[c * RS_DS + rq + 4 * r];
-        rs_sync<4>();
-        if constexpr (LA) T[rs_tix(K, K)] = X1;
-        rs_factor4_step<NT, K + 1, LA>(T, sb4, stride, w, lane, c, rq, X1n);
-    } else {
-        if constexpr (LA) T[rs_tix(K, K)] = X1;
-        else rs_step<NT, K>(T, X1);
-    }
-}
-template <int NT, bool LA>
-__device__ __forceinline__ void rs_factor4(double4_t (&T)[(NT * (NT + 1)) / 2], double *sb4, int stride, int w, int lane, int c, int rq) {
-    double *s_blk = sb4 + w * stride;
-    rs_put_diag(T[0], s_blk, c, rq);
-    __syncthreads();
-    RsNoHook nh;
-    if (w == 0) rs_diag_block4(sb4, stride, lane, nh);
-    __syncthreads();
-    double4_t X1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) X1[r] = s_blk[c * RS_DS + rq + 4 * r];
-    rs_sync<4>();
-    rs_factor4_step<NT, 0, LA>(T, sb4, stride, w, lane, c, rq, X1);
-}
-// VAR 0: rs_factor as it was; 1: the fused diagonal step; 2: fused + look-ahead
-template <int NT, int VAR>
-__device__ __forceinline__ void rs_factor_var(double4_t (&T)[(NT * (NT + 1)) / 2], double *s_blk, int lane, int c, int rq) {
-    if constexpr (VAR == 0) rs_factor<NT>(T, s_blk, lane, c, rq);
-    else {
-        rs_put_diag(T[0], s_blk, c, rq);
-        __syncthreads();
-        RsNoHook nh;
-        rs_diag_block2(s_blk, lane, nh);
-        double4_t X1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X1[r] = s_blk[c * RS_DS + rq + 4 * r];
-        __syncthreads();
-        if constexpr (VAR == 2) rs_factor_la_step<NT, 0>(T, s_blk, lane, c, rq, X1);
-        else rs_factor_fused<NT, 0>(T, s_blk, lane, c, rq, X1);
-    }
-}
-
 // Everything behind the gather: factorisation, the two forward substitutions, Schur complement of the ones row, back substitution.
 //   T       : the tiles of G + lam I (see the header comment), consumed
 //   s_vec   : [3][16 NT] LDS; on entry s_vec[0] = u, s_vec[1] = g (zeros on missing / padding rows)
 //   s_blk   : [16 * RS_DS] LDS, s_part : [4][64] LDS
 //   sc, lam, Tp : s, the ridge, the number of frames (the ones row's own Gram entry)
 //   wc[k]   : on return, w(16 k + c) in every lane with l & 15 == c
-//   WG = 4 (shared diagonal steps): s_blk = this wave's exchange tile, the tile of wave v at s_blk + (v - w) * stride
-template <int NT, int VAR = 0, int WG = 1>
+template <int NT>
 __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2], double (*s_vec)[16 * NT], double *s_blk, double (*s_part)[64],
-                                              double sc, double lam, double Tp, int lane, int probe, double (&wc)[NT], int w = 0, int stride = 0) {
+                                              double sc, double lam, double Tp, int lane, int probe, double (&wc)[NT]) {
     constexpr int N = 16 * NT;
     const int c = lane & 15, rq = lane >> 4;
     // ---- block Cholesky ----
-    if (!(probe & 2)) {
-        if constexpr (WG == 4) rs_factor4<NT, VAR == 2>(T, s_blk - w * stride, stride, w, lane, c, rq);
-        else rs_factor_var<NT, VAR>(T, s_blk, lane, c, rq);
-    }
+    if (!(probe & 2)) rs_factor<NT>(T, s_blk, lane, c, rq);
     if (probe & 4) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) wc[k] = T[rs_tix(k, k)][0];
@@ -421,7 +192,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
         const double4_t Mkk = T[rs_tix(k, k)];
 #pragma unroll
         for (int v = 0; v < 2; ++v) s_part[v][c * 4 + rq] = (rq == 0 ? s_vec[v][16 * k + c] : 0.0) - pb[v][k];
-        rs_sync<WG>();
+        __syncthreads();
         double p2[2];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -436,7 +207,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
         }
 #pragma unroll
         for (int v = 0; v < 2; ++v) s_part[2 + v][c * 4 + rq] = p2[v];
-        rs_sync<WG>();
+        __syncthreads();
         double zq[2][4];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -461,7 +232,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
                 for (int r = 0; r < 4; ++r) acc = fma(T[rs_tix(i, k)][r], zq[v][r], acc);
                 pb[v][i] = acc;
             }
-        rs_sync<WG>();
+        __syncthreads();
     }
     // ---- Schur complement of the ones row: w0, then y = z_g - w0 z_u ----
     double zuu = 0.0, zug = 0.0;
@@ -469,7 +240,7 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
     zuu = rs_wave_sum(zuu); zug = rs_wave_sum(zug);
     const double w0 = (sc - zug) / (Tp + lam - zuu);
     for (int a = lane; a < N; a += 64) s_vec[2][a] = s_vec[1][a] - w0 * s_vec[0][a];
-    rs_sync<WG>();
+    __syncthreads();
     // ---- back substitution L' w = y: w_k = inv(L_kk)' (y_k - sum_{i>k} L_ik' w_i); both products contract over the lane index c ----
 #pragma unroll
     for (int k = NT - 1; k >= 0; --k) {
@@ -482,21 +253,21 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
                 for (int r = 0; r < 4; ++r) acc[r] = fma(T[rs_tix(i, k)][r], wc[i], acc[r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = acc[r];
-            rs_sync<WG>();
+            __syncthreads();
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 16; cc += 2) { const double2 v = *reinterpret_cast<const double2 *>(s_blk + c * RS_DS + cc); s0 += v.x; s1 += v.y; }
             yk -= s0 + s1;
-            rs_sync<WG>();
+            __syncthreads();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = T[rs_tix(k, k)][r] * yk;
-        rs_sync<WG>();
+        __syncthreads();
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < 16; cc += 2) { const double2 v = *reinterpret_cast<const double2 *>(s_blk + c * RS_DS + cc); s0 += v.x; s1 += v.y; }
         wc[k] = s0 + s1;
-        rs_sync<WG>();
+        __syncthreads();
     }
 }
 

@@ -66,100 +66,32 @@ __device__ __forceinline__ void rsp_rank2(double4_t (&T)[(NT * (NT + 1)) / 2], c
     }
 }
 
-// The same corrections on the MATRIX pipe (round 5).  The solve is bound by its vector instructions (6082 per pixel against 189 MFMAs, profiles/r04/pmc_pipes_v4.txt);
-// rsp_rank2 above spends ~250 of them per neuron.  Up to 8 staged neurons are one rank-16 update  G(a, b) -= sum_k P(k, a) Q(k, b)  with the 16 rows
-// k = (u_0..u_3 | u_4..u_7 | a_0..a_3 | a_4..a_7) of P paired with (a_0..a_3 | a_4..a_7 | u_0..u_3 | u_4..u_7) of Q: lane (c, rq) of the MFMA operands holds row
-// k = rq + 4 r' of call r', i.e. for ring pixel 16 X + c the FOUR values u_rq, u_rq+4, a_rq, a_rq+4 -- in this order (negated) as the A operand of block column J, in
-// the order a, a, u, u as the B operand of block row I.  Tile (I, J) holds G(16 I + c, 16 J + rq + 4 r) = D(rq + 4 r, c): A carries the J side.  84 fp64 MFMAs
-// (42 when at most four neurons are staged: calls 0 and 2) instead of 168 FMAs + 48 LDS reads per neuron.  Exact products, fp64 sums: the order of the sum over
-// the neurons differs from rsp_rank2 (1e-16 relative).
 template <int NT>
-__device__ __forceinline__ void rsp_rank2_mfma(double4_t (&T)[(NT * (NT + 1)) / 2], const double (*su)[16 * NT + 2], const float (*sa)[16 * NT + 2], int c, int rq, bool two) {
-    auto load4 = [&](int X, double &u0, double &u1, double &a0, double &a1) {
-        u0 = su[rq][16 * X + c]; a0 = (double)sa[rq][16 * X + c];
-        u1 = two ? su[rq + 4][16 * X + c] : 0.0; a1 = two ? (double)sa[rq + 4][16 * X + c] : 0.0;
-    };
-#pragma unroll
-    for (int J = 0; J < NT; ++J) {
-        double pu0, pu1, pa0, pa1;
-        load4(J, pu0, pu1, pa0, pa1);
-        pu0 = -pu0; pu1 = -pu1; pa0 = -pa0; pa1 = -pa1;
-#pragma unroll
-        for (int I = J; I < NT; ++I) {
-            double qu0, qu1, qa0, qa1;
-            if (I == J) { qu0 = -pu0; qu1 = -pu1; qa0 = -pa0; qa1 = -pa1; }
-            else load4(I, qu0, qu1, qa0, qa1);
-            double4_t t = T[rs_tix(I, J)];
-            t = __builtin_amdgcn_mfma_f64_16x16x4f64(pu0, qa0, t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f64_16x16x4f64(pa0, qu0, t, 0, 0, 0);
-            if (two) {
-                t = __builtin_amdgcn_mfma_f64_16x16x4f64(pu1, qa1, t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1, qu1, t, 0, 0, 0);
-            }
-            T[rs_tix(I, J)] = t;
-        }
-    }
-}
-
-// VAR (option "solve_variant", round 5) is a set of bits: RSV_FUSED = the fused diagonal step (rs_cholinv), RSV_LA = the look-ahead factorisation
-// (rs_factor_la_step; implies RSV_FUSED), RSV_MFMA2 = the footprints' rank-2 corrections on the matrix pipe (rsp_rank2_mfma).  0 = round 4's kernel.
-// Measured and dropped (profiles/r05/solve_variants.txt): a branch-free index set-up / staging with the gathers of a phase in flight together (+1600 vector
-// instructions of selects and clamped addresses in a kernel that is bound by them) and one touched dword per line of the system at the top (+6 gather instructions).
-constexpr int RSV_FUSED = 1, RSV_LA = 2, RSV_MFMA2 = 16;
-// WG = 4 (round 5): four waves = four consecutive pixels per workgroup, the diagonal steps shared (ring_solve_core.hpp, rs_factor4_step); everything else is per
-// wave, in its own slice of LDS (2 x 4 x 18.4 KB per CU).  A pixel that is not fitted (inactive, or behind the patch's last) is solved like the others and not stored:
-// every wave of a workgroup meets the same workgroup barriers; a workgroup without any fitted pixel leaves at once.
-template <int NT> struct RspLds {
-    static constexpr int N = 16 * NT;
-    int q[N + 1];                                           // block-region pixel of ring neighbour a ([N]: the centre), -1: outside the field of view
-    int rs[N + 1];                                          // block * 256 + local pixel (row sums)
-    int bk[N + 1];                                          // block * K
-    int ulp[N + 1];                                         // lst_ptr[block] * 256 + local pixel
-    int en[N + 1];
-    int e0[N + 1];
-    int ec[N + 1][RSP_CAP];
-    float ev[N + 1][RSP_CAP];
-    unsigned mask[4];
-    __attribute__((aligned(16))) double u[RSP_NS][N + 2];
-    __attribute__((aligned(16))) double vec[3][N];
-    // the staged A values share their memory with the factorisation's exchange buffers (used only behind the corrections; barriers in between):
-    // eight waves per CU must fit 160 KB
-    __attribute__((aligned(16))) double core[16 * RS_DS + 4 * 64];
-};
-template <int NT, int VAR, int WG>
-__global__ void __launch_bounds__(64 * WG, (WG == 4 ? (NT <= 6 ? 2 : 1) : (NT <= 2 ? 4 : (NT <= 3 ? 3 : (NT <= 6 ? 2 : 1)))))
+__global__ void __launch_bounds__(64, (NT <= 2 ? 4 : (NT <= 3 ? 3 : (NT <= 6 ? 2 : 1))))
 k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc, const double *__restrict__ rowsum,
               const unsigned char *__restrict__ active, float *__restrict__ W, int *__restrict__ errflag, int probe, const int *__restrict__ pix) {
     constexpr int N = 16 * NT, NTILE = (NT * (NT + 1)) / 2;
-    static_assert(WG == 1 || WG == 4, "one wave per pixel, one or four pixels per workgroup");
-    static_assert(sizeof(RspLds<NT>) % 16 == 0, "the waves' LDS slices keep the 16-byte alignment");
-    __shared__ RspLds<NT> lds[WG];
-    const int w = WG == 1 ? 0 : (int)(threadIdx.x >> 6);
-    RspLds<NT> &L = lds[w];
-    int (&s_q)[N + 1] = L.q; int (&s_rs)[N + 1] = L.rs; int (&s_bk)[N + 1] = L.bk; int (&s_ulp)[N + 1] = L.ulp; int (&s_en)[N + 1] = L.en; int (&s_e0)[N + 1] = L.e0;
-    int (&s_ec)[N + 1][RSP_CAP] = L.ec; float (&s_ev)[N + 1][RSP_CAP] = L.ev; unsigned (&s_mask)[4] = L.mask;
-    double (&s_u)[RSP_NS][N + 2] = L.u; double (&s_vec)[3][N] = L.vec;
-    double *s_core = L.core;
+    __shared__ int s_q[N + 1];                                          // block-region pixel of ring neighbour a ([N]: the centre), -1: outside the field of view
+    __shared__ int s_rs[N + 1];                                         // block * 256 + local pixel (row sums)
+    __shared__ int s_bk[N + 1];                                         // block * K
+    __shared__ int s_ulp[N + 1];                                        // lst_ptr[block] * 256 + local pixel
+    __shared__ int s_en[N + 1];
+    __shared__ int s_e0[N + 1];
+    __shared__ int s_ec[N + 1][RSP_CAP];
+    __shared__ float s_ev[N + 1][RSP_CAP];
+    __shared__ unsigned s_mask[2];
+    __shared__ __attribute__((aligned(16))) double s_u[RSP_NS][N + 2];
+    __shared__ __attribute__((aligned(16))) double s_vec[3][N];
+    // the staged A values share their memory with the factorisation's exchange buffers (used only behind the corrections; barriers in between):
+    // eight one-wave workgroups per CU must fit 160 KB
+    __shared__ __attribute__((aligned(16))) double s_core[16 * RS_DS + 4 * 64];
     double *s_blk = s_core;
     double (*s_part)[64] = reinterpret_cast<double (*)[64]>(s_core + 16 * RS_DS);
     float (*s_a)[N + 2] = reinterpret_cast<float (*)[N + 2]>(s_core);
     static_assert(sizeof(float) * RSP_NS * (N + 2) <= sizeof(double) * (16 * RS_DS + 4 * 64), "staged A values do not fit the exchange buffers");
-    int64_t m;
-    bool store;
-    if constexpr (WG == 1) {
-        m = pix ? pix[blockIdx.x] : (int)blockIdx.x;
-        if (active && !active[m]) return;
-        store = true;
-    } else {
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < WG; ++j) { const int64_t mj = (int64_t)blockIdx.x * WG + j; any |= mj < g.d && (!active || active[mj]); }
-        if (!any) return;
-        const int64_t mw = (int64_t)blockIdx.x * WG + w;
-        store = mw < g.d && (!active || active[mw]);
-        m = mw < g.d ? mw : g.d - 1;
-    }
-    const int lane = threadIdx.x & 63, c = lane & 15, rq = lane >> 4;
+    const int64_t m = pix ? pix[blockIdx.x] : (int)blockIdx.x;
+    if (active && !active[m]) return;
+    const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
     const int p = g.p;
     const double *sp = sys + m * (int64_t)(NTILE * 256 + N);
     const int mi = (int)m;
@@ -167,7 +99,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     const int blkm = (cbm >> 4) * g.nbr + (rbm >> 4);
     const bool corr = pa.arow != nullptr && !(probe & 8);
     if (lane < 2) s_mask[lane] = 0;
-    rs_sync<WG>();
+    __syncthreads();
     int bad = 0;
 #pragma unroll 1
     for (int a = lane; a <= N; a += 64) {
@@ -200,7 +132,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
         }
         s_q[a] = q; s_rs[a] = rs; s_bk[a] = bk; s_ulp[a] = ulp; s_en[a] = en; s_e0[a] = e0s;
     }
-    rs_sync<WG>();
+    __syncthreads();
     // ---- border vectors u (row sums of Bf: corrected by k_rowsum_correct), g (the video's, corrected below) and the scalar s ----
     for (int a = lane; a < N; a += 64) {
         const bool ex = s_q[a] >= 0;
@@ -252,14 +184,13 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
         }
     };
     auto apply = [&](double4_t (&T)[NTILE]) {
-        rs_sync<WG>();
-        if constexpr ((VAR & RSV_MFMA2) != 0) rsp_rank2_mfma<NT>(T, s_u, s_a, c, rq, nst > RSP_CH);
+        __syncthreads();
         for (int i = 0; i < nst; ++i) {
-            if constexpr ((VAR & RSV_MFMA2) == 0) rsp_rank2<NT>(T, s_u[i], s_a[i], c, rq);
+            rsp_rank2<NT>(T, s_u[i], s_a[i], c, rq);
             const double uN = s_u[i][N], aN = (double)s_a[i][N];
             for (int a = lane; a < N; a += 64) s_vec[1][a] -= fma(s_u[i][a], aN, (double)s_a[i][a] * uN);
         }
-        rs_sync<WG>();
+        __syncthreads();
     };
     if (mask) stage(0);
     if (mask) stage(RSP_CH);
@@ -292,10 +223,10 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (c == rq + 4 * r && rowex[I]) T[rs_tix(I, I)][r] += lam;
     if (bad) atomicOr(errflag, 1);
-    rs_sync<WG>();
+    __syncthreads();
     double wc[NT];
-    rs_solve_core<NT, ((VAR & RSV_LA) ? 2 : ((VAR & RSV_FUSED) ? 1 : 0)), WG>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc, w, (int)(sizeof(RspLds<NT>) / sizeof(double)));
-    if (rq == 0 && store) {
+    rs_solve_core<NT>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
+    if (rq == 0) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int a = 16 * k + c;

@@ -1,7 +1,7 @@
 """Phase probes of the ring-regression solve kernel on one patch: python scripts/solve_ab.py --cfg c3 [--probes 0,1,3,7]
 (solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions, 8 no footprint corrections).  Every run fits the same
-first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_variant (bg.hip: 0 round 4's kernel, 1 fused diagonal step,
-2 = 1 + look-ahead factorisation, 3 rank-2 corrections on the matrix pipe, 4 = 2 + 3, 5 = 1 + 3); the weights of every mode are compared with the first's."""
+first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_variant of round 5's experiment (scripts/probes/solve_r5/: the
+patch, what the variants are, what they measured); without the patch the runs only repeat.  The weights of every mode are compared with the first's."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +26,9 @@ Ws = {}
 for mode in [int(x) for x in a.modes.split(",")]:
     for probe in [int(x) for x in a.probes.split(",")]:
         eng.ring_init(0, r)
-        eng.set_option("solve_probe", probe); eng.set_option("solve_variant", mode)
+        eng.set_option("solve_probe", probe)
+        try: eng.set_option("solve_variant", mode)          # (only builds with scripts/probes/solve_r5/variants.patch applied know the option)
+        except Exception: pass
         ts = []
         for rep in range(a.reps):
             eng.ring_init(0, r); eng.profile_reset()
