@@ -503,15 +503,18 @@ cnmfe_ctx *cnmfe_create(int device) {
     // CNMFE_OPTS="name=value,name=value": tunables of cnmfe_set_option preset for every context of the process (A/B runs of the test suite and the bench
     // without touching their code); names this build does not know are ignored -- the same environment serves builds with different option sets
     if (const char *env = getenv("CNMFE_OPTS")) {
-        std::string s(env);
+        std::string s(env), applied, ignored;
         size_t pos = 0;
         while (pos < s.size()) {
             size_t end = s.find(',', pos); if (end == std::string::npos) end = s.size();
             const std::string kv = s.substr(pos, end - pos); pos = end + 1;
             const size_t eq = kv.find('=');
             if (eq == std::string::npos || eq == 0) continue;
-            (void)cnmfe_set_option(ctx, kv.substr(0, eq).c_str(), strtoll(kv.c_str() + eq + 1, nullptr, 10));
+            const int rc_ = cnmfe_set_option(ctx, kv.substr(0, eq).c_str(), strtoll(kv.c_str() + eq + 1, nullptr, 10));
+            (rc_ == 0 ? applied : ignored) += (rc_ == 0 ? (applied.empty() ? "" : ",") : (ignored.empty() ? "" : ",")) + kv;
         }
+        static bool said = false;                              // once per process: a preset that silently changes every context is worth one line
+        if (!said) { said = true; fprintf(stderr, "[cnmfe] CNMFE_OPTS applied to every context: %s%s%s\n", applied.empty() ? "(none)" : applied.c_str(), ignored.empty() ? "" : "; not known to this build, ignored: ", ignored.c_str()); }
     }
     return ctx;
 }
@@ -1127,13 +1130,25 @@ int cnmfe_csc_from_triplets(int64_t n, const int32_t *rows, const int32_t *cols,
     for (int32_t k = 0; k < ncol; ++k) out_colptr[k + 1] += out_colptr[k];
     std::vector<int64_t> cur(out_colptr, out_colptr + ncol);
     for (int64_t e = 0; e < n; ++e) { const int64_t at = cur[cols[e]]++; out_rowidx[at] = rows[e]; out_val[at] = vals[e]; }
-    for (int32_t k = 0; k < ncol; ++k) {                    // (a rank's part arrives sorted within the column: the insertion sort mostly merges a few runs)
+    std::vector<std::pair<int32_t, float>> tmp;
+    for (int32_t k = 0; k < ncol; ++k) {                    // rows ascending within the column
         const int64_t a = out_colptr[k], b = out_colptr[k + 1];
-        for (int64_t i = a + 1; i < b; ++i) {
-            const int32_t r = out_rowidx[i]; const float v = out_val[i];
-            int64_t j = i;
-            while (j > a && out_rowidx[j - 1] > r) { out_rowidx[j] = out_rowidx[j - 1]; out_val[j] = out_val[j - 1]; --j; }
-            out_rowidx[j] = r; out_val[j] = v;
+        bool sorted = true;
+        for (int64_t i = a + 1; i < b && sorted; ++i) sorted = out_rowidx[i - 1] <= out_rowidx[i];
+        if (!sorted) {
+            if (b - a <= 32) {                              // (a rank's part arrives sorted within the column: a few runs to merge)
+                for (int64_t i = a + 1; i < b; ++i) {
+                    const int32_t r = out_rowidx[i]; const float v = out_val[i];
+                    int64_t j = i;
+                    while (j > a && out_rowidx[j - 1] > r) { out_rowidx[j] = out_rowidx[j - 1]; out_val[j] = out_val[j - 1]; --j; }
+                    out_rowidx[j] = r; out_val[j] = v;
+                }
+            } else {                                        // (a long unsorted column must not cost n^2)
+                tmp.resize((size_t)(b - a));
+                for (int64_t i = a; i < b; ++i) tmp[(size_t)(i - a)] = {out_rowidx[i], out_val[i]};
+                std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, float> &x, const std::pair<int32_t, float> &y) { return x.first < y.first; });
+                for (int64_t i = a; i < b; ++i) { out_rowidx[i] = tmp[(size_t)(i - a)].first; out_val[i] = tmp[(size_t)(i - a)].second; }
+            }
         }
         for (int64_t i = a + 1; i < b; ++i) if (out_rowidx[i] == out_rowidx[i - 1]) return fail(CNMFE_EINVAL, "cnmfe_csc_from_triplets: entry (%d, %d) given twice", out_rowidx[i], k);
     }

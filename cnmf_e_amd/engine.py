@@ -237,6 +237,7 @@ class Engine:
         return _p(a, L.f32p), L.ROWMAJOR, a
 
     def __init__(self, device: int = 0):
+        self._opts_set = {}
         self._ctx = L.lib.cnmfe_create(int(device))
         if not self._ctx:
             raise L.CnmfeError("cnmfe_create failed: " + L.lib.cnmfe_last_error().decode())
@@ -638,7 +639,8 @@ class Engine:
         if nccl:
             ext = torch.cuda.ExternalStream(int(sp_.value), device=torch.device("cuda", torch.cuda.current_device()))
             with torch.cuda.stream(ext):
-                if os.environ.get("CNMFE_SKIP_STITCH_ALLREDUCE") != "1":     # (test hook of the one-rank measurements)
+                # (test hook of the one-rank measurements: honoured on a ONE-rank group only -- with more ranks skipping the reduction would silently return wrong traces)
+                if not (os.environ.get("CNMFE_SKIP_STITCH_ALLREDUCE") == "1" and td.get_world_size(group) == 1):
                     td.all_reduce(t, group=group)
             return
         h = t.cpu(); td.all_reduce(h, group=group); t.copy_(h)
@@ -754,3 +756,17 @@ class Engine:
 
     def set_option(self, name, value):
         L.check(L.lib.cnmfe_set_option(self._ctx, name.encode(), int(value)))
+        self._opts_set[name] = int(value)
+
+    def get_option(self, name, default):
+        """the value this engine's option has: what set_option gave it last, else what CNMFE_OPTS preset at cnmfe_create, else `default` (the library's own)"""
+        if name in self._opts_set:
+            return self._opts_set[name]
+        for kv in os.environ.get("CNMFE_OPTS", "").split(","):
+            k, _, v = kv.partition("=")
+            if k == name and v:
+                try:
+                    return int(v)
+                except ValueError:
+                    pass
+        return default

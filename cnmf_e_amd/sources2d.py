@@ -249,17 +249,20 @@ def rows_of(A, lut, nloc, cols=None, span=None, cand=None):
 
 
 def _csc_from_triplets(r, c, v, shape):
-    """the CSC matrix of disjoint (row, column, value) triplets: one counting pass in the library's host helper (cnmfe_csc_from_triplets) -- scipy's COO -> CSC
-    conversion sorts the whole list, and every rank of a sharded run assembles the WHOLE gathered A; falls back to scipy without the library"""
+    """the CSC matrix of DISJOINT (row, column, value) triplets (ValueError on a pair given twice): one counting pass in the library's host helper
+    (cnmfe_csc_from_triplets) -- scipy's COO -> CSC conversion sorts the whole list, and every rank of a sharded run assembles the WHOLE gathered A; falls back
+    to scipy without the library"""
     r = np.ascontiguousarray(r, dtype=np.int32); c = np.ascontiguousarray(c, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.float32)
     try:
         fn = L.lib.cnmfe_csc_from_triplets
-    except (ImportError, OSError):
+    except (ImportError, OSError, AttributeError):                # (no library, or a CNMFE_LIB build without the helper)
         return sp.csc_matrix((v, (r, c)), shape=shape)
     n = int(r.size)
     optr = np.empty(shape[1] + 1, dtype=np.int64); orow = np.empty(max(n, 1), dtype=np.int32); oval = np.empty(max(n, 1), dtype=np.float32)
     rc = fn(n, r.ctypes.data, c.ctypes.data, v.ctypes.data, int(shape[1]), int(shape[0]), optr.ctypes.data, orow.ctypes.data, oval.ctypes.data)
     if rc != 0:
+        # PRECONDITION: disjoint triplets (the patches' rows are, update_spatial_parallel.m:324-334).  A pair given twice -- which scipy's conversion would sum
+        # silently -- or an index out of range is an error of the caller, reported as such
         raise ValueError(L.lib.cnmfe_last_error().decode())
     M = sp.csc_matrix((oval[:n], orow[:n], optr), shape=shape)
     M.has_sorted_indices = True
@@ -803,10 +806,22 @@ class Sources2D:
 
     def delete(self, ind):
         """obj.delete(ind)  (@Sources2D/Sources2D.m:762-811): columns of A, rows of C / C_raw / S and of P.kernel_pars go; A_prev, C_prev stay"""
-        ind = np.atleast_1d(np.asarray(ind, dtype=np.int64))
+        K = self.A.shape[1]
+        ind = np.atleast_1d(np.asarray(ind))
+        if ind.dtype == np.bool_:                                                 # obj.delete(mask): MATLAB's usual calling style (obj.A(:, ind) = [])
+            if ind.size != K:
+                raise ValueError("delete: a logical index of %d entries for %d neurons" % (ind.size, K))
+            ind = np.flatnonzero(ind)
+        ind = ind.astype(np.int64)
         if ind.size == 0:
             return                                                                # :764-766
-        keep = np.setdiff1d(np.arange(self.A.shape[1]), ind)
+        if ind.min() < 0 or ind.max() >= K:
+            raise IndexError("delete: neuron index out of range (0 .. %d)" % (K - 1))
+        keep = np.setdiff1d(np.arange(K), ind)
+        for name in ("ids", "tags"):                                              # :791-797 (the reference drops them with the neurons)
+            val = getattr(self, name, None)
+            if val is not None and len(val) == K:
+                setattr(self, name, np.asarray(val)[keep])
         C_raw = np.asarray(self.C_raw)[keep] if self.C_raw is not None and np.asarray(self.C_raw).shape[0] == self.A.shape[1] else None
         if getattr(self, "S", None) is not None and np.asarray(self.S).shape[0] == self.A.shape[1]:
             self.S = np.asarray(self.S)[keep]                                     # :801-803
