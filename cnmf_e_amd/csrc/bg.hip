@@ -678,6 +678,7 @@ __global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_
 }  // namespace cnmfe
 #include "ring_solve.hpp"
 #include "ring_solve_packed.hpp"
+#include "gram_i8.hpp"
 namespace cnmfe {
 
 // ind_active = abs(W_old)*sum(A,2) > 0  (fit_ring_model.m:28)
@@ -982,7 +983,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     if (build_base) P->sys_valid = false;
     ht.mark("footprint block lists");
     g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16
-    g.Tpad = g.bf4 == 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages
+    // round 5 (gram_i8.hpp): the VIDEO's table on the int8 matrix pipe, exact up to a 32-bit quantisation of the data (option gram_i8, default 1; int32 range: <= 24576 frames)
+    const bool use_i8 = build_base && !outl && ctx->opt("gram_i8", 1) != 0 && g.Tp <= 24576;
+    if (use_i8) g.bf4 = 3;
+    g.Tpad = g.bf4 >= 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages; int8: steps of four
     const int nblk = g.nbr * g.nbc;
 
     // ---- the window projection first: it needs the footprint lists and the traces, nothing else, and takes 5 ms at the headline size -- the host
@@ -1153,7 +1157,14 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 7) & ~int64_t(7));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
         RET(rsT.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        if (g.bf4 == 2) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->st()));
+        if (g.bf4 >= 2) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->st()));
+        if (use_i8) {
+            RET(ctx->dig_scale.ensure((size_t)nblk * BLKPX * sizeof(double)));
+            const int tchunk16 = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 15) & ~int64_t(15));
+            LAUNCH(ctx, "bg_dig_scale", k_dig_scale, dim3(nblk), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, ctx->dig_scale.as<double>());
+            LAUNCH(ctx, "bg_build_dig", k_build_dig, dim3(nblk, (unsigned)((g.Tpad + tchunk16 - 1) / tchunk16)), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
+                   ctx->dig_scale.as<double>(), ctx->bf.as<uint4>(), tchunk16, rsT.as<double>());
+        } else
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());
         if (outl) {
@@ -1183,7 +1194,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                    ctx->bf2.as<float>(), Tpad_src, ctx->bf.as<float>(), g.Tpad, ctx->outl_sel.as<int>(), g.Tp);
             CK(hipStreamSynchronize(ctx->st()));                           // `sel` is staged from this scope
         }
-        if (g.bf4 != 2)
+        if (g.bf4 < 2)
             LAUNCH(ctx, "bg_rowsum", k_rowsum, dim3(nblk), dim3(256), 0, ctx->bf.as<float>(), g.Tpad, rsT.as<double>(), g.bf4);
 
         {
@@ -1196,7 +1207,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 attr4 = true;
             }
             const int flushw = (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16);
-            if (g.bf4 == 2)
+            if (use_i8) {
+                static bool attr8 = false;
+                if (!attr8) { CK(hipFuncSetAttribute((const void *)k_gram_i8, hipFuncAttributeMaxDynamicSharedMemorySize, GI_NBUF * GI_STAGE_B)); attr8 = true; }
+                LAUNCH(ctx, "bg_gram_i8", k_gram_i8, dim3(nwg), dim3(512), (size_t)GI_NBUF * GI_STAGE_B, ctx->bf.as<uint4>(), g.Tpad >> 4, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), ctx->dig_scale.as<double>(), covT.as<double>());
+            } else if (g.bf4 == 2)
                 LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
             else if (f32s)

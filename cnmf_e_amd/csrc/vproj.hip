@@ -323,10 +323,14 @@ __global__ void __launch_bounds__(256) k_vp_proj_b(const float4 *__restrict__ Y4
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const double a = Bl[(t * BLKPX + px) * 16 + n];
+#ifdef CNMFE_PROBE_NOMFMA                                       // timing probe (scripts/build_variant.py): the loads stay, the matrix work goes -- results are garbage
+                    acc[0][t][0] = fma(a, b0, acc[0][t][0]); acc[1][t][0] = fma(a, b1, acc[1][t][0]); acc[2][t][0] = fma(a, b2, acc[2][t][0]); acc[3][t][0] = fma(a, b3, acc[3][t][0]);
+#else
                     acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[0][t], 0, 0, 0);
                     acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[1][t], 0, 0, 0);
                     acc[2][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[2][t], 0, 0, 0);
                     acc[3][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[3][t], 0, 0, 0);
+#endif
                 }
             }
             asm volatile("" ::: "memory");

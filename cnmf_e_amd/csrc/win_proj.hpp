@@ -84,7 +84,11 @@ __device__ __forceinline__ void win_body4(const float4 *__restrict__ Y4, const B
             for (int a = 0; a < 4; ++a) {
                 const double av = (double)comp(f.y[a], m);
 #pragma unroll
+#ifdef CNMFE_PROBE_NOMFMA                                       // timing probe (scripts/build_variant.py): the loads stay, the matrix work goes -- results are garbage
+                for (int b = 0; b < NT; ++b) acc[a][b][0] = fma(av, bv[b], acc[a][b][0]);
+#else
                 for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[b], acc[a][b], 0, 0, 0);
+#endif
             }
             if (gw) {
                 double gv = bv[0];
