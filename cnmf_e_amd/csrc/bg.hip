@@ -553,7 +553,8 @@ __global__ void __launch_bounds__(256) k_win_proj(const float4 *__restrict__ Y4,
 constexpr int WF_S = 4;
 __global__ void __launch_bounds__(256) k_win_fix(BgGeom g, int K, const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
                                                  const int *__restrict__ lst_ptr, const short *__restrict__ slot_of, const int *__restrict__ blk_list, int nseg,
-                                                 double *__restrict__ Ut, int64_t ut_stride, const double *__restrict__ Gb, int64_t gb_stride, double *__restrict__ Praw) {
+                                                 double *__restrict__ Ut, int64_t ut_stride, const double *__restrict__ Gb, int64_t gb_stride, double *__restrict__ Praw,
+                                                 const double *__restrict__ GK, const int *__restrict__ lst_k) {
     __shared__ double G[WIN_NLB * WF_S];                     // G[r][j]: column s0 + j of the block's list Gram matrix
     const int blk = blk_list[blockIdx.x];
     const int l0 = lst_ptr[blk], nl = lst_ptr[blk + 1] - l0;
@@ -564,7 +565,9 @@ __global__ void __launch_bounds__(256) k_win_fix(BgGeom g, int K, const int *__r
     {
         const int r = lp / WF_S, c = s0 + lp % WF_S;         // WIN_NLB * WF_S == 256: one entry per thread
         double v = 0.0;
-        if (r < nlp && c < nlp) {
+        if (GK) {                                            // (win_proj_i8.hpp: one K x K Gram matrix of the centred traces per fit instead of per-block, per-segment copies)
+            if (r < nl && c < nl) v = GK[(int64_t)lst_k[l0 + r] * K + lst_k[l0 + c]];
+        } else if (r < nlp && c < nlp) {
             const double *gp = Gb + (int64_t)blk * WIN_NLB * WIN_NLB + r * WIN_NLB + c;
 #pragma unroll 4
             for (int sg = 0; sg < nseg; ++sg) v += gp[sg * gb_stride];
@@ -679,6 +682,7 @@ __global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_
 #include "ring_solve.hpp"
 #include "ring_solve_packed.hpp"
 #include "gram_i8.hpp"
+#include "win_proj_i8.hpp"
 namespace cnmfe {
 
 // ind_active = abs(W_old)*sum(A,2) > 0  (fit_ring_model.m:28)
@@ -999,6 +1003,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     std::vector<int> blall;
     int nsg = 1; int64_t ut_stride = 0, gb_stride = 0;
     bool proj_queued = false;
+    bool win_i8 = false;                                       // the window projection ran on the int8 pipe: k_win_fix takes G from the K x K matrix
     auto queue_projection = [&]() -> int {
         for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());      // longest lists first
         RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
@@ -1012,7 +1017,26 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ut_stride = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX; gb_stride = (int64_t)nblk * WIN_NLB * WIN_NLB;
         RET(dUt.ensure((size_t)nsg * ut_stride * sizeof(double)));
         RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
-        if (g.kstride == 1 || g.kstride == 2 || g.kstride == 4) {
+        if (P->dig_valid && g.kstride == 1 && g.Tp <= 24576 && ctx->opt("win_i8", 1) != 0 && K > 0) {
+            // round 5 (win_proj_i8.hpp): the same sums on the int8 matrix pipe out of the resident digit planes; G = Cc Cc' once, K x K
+            const int64_t T16 = P->dig_T16;
+            RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
+            RET(ctx->tscale.ensure((size_t)K * sizeof(double)));
+            RET(ctx->gk.ensure((size_t)K * K * sizeof(double)));
+            LAUNCH(ctx, "bg_trace_dig", k_trace_dig, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, (int64_t)T, T16, ctx->tdig.as<uint4>(), ctx->tscale.as<double>());
+            const int ntk = ((int)K + 15) >> 4;
+            LAUNCH(ctx, "bg_trace_gram", k_trace_gram, dim3((unsigned)(ntk * (ntk + 1) / 2)), dim3(64 * TG_W), 0, dCc.as<float>(), ldc, (int64_t)T, (int)K, ctx->gk.as<double>());
+            std::vector<int> items;
+            for (int b_ : blall) {
+                const int ntl = (lst_ptr[b_ + 1] - lst_ptr[b_] + 15) >> 4;
+                for (int gq = 0; gq < (ntl + 1) / 2; ++gq) items.push_back(b_ | (gq << 24));
+            }
+            RET(to_dev(ctx, ctx->win_items, items.data(), items.size()));
+            if (!items.empty())
+                LAUNCH(ctx, "bg_win_proj", k_win_proj_i8, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
+                       ctx->tscale.as<double>(), dLp.as<int>(), dLk.as<int>(), ctx->win_items.as<int>(), nsg, dUt.as<double>(), ut_stride);
+            win_i8 = true;
+        } else if (g.kstride == 1 || g.kstride == 2 || g.kstride == 4) {
             const int nbig = (int)blk_nt[3].size();              // blall starts with the longest lists
             if (nbig)
                 LAUNCH(ctx, "bg_win_proj", k_win_proj4<true>, dim3((unsigned)(nbig * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc.as<float>(), ldc, dLp.as<int>(), dLk.as<int>(),
@@ -1158,12 +1182,29 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
         RET(rsT.ensure((size_t)nblk * BLKPX * sizeof(double)));
         if (g.bf4 >= 2) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->st()));
+        uint4 *digp = nullptr; double *digs = nullptr;          // where the digit planes of this build live
         if (use_i8) {
-            RET(ctx->dig_scale.ensure((size_t)nblk * BLKPX * sizeof(double)));
+            // resident with the patch (the fits' window projection reads them, win_proj_i8.hpp) when one more video's worth of memory leaves 8 GB free and the
+            // stride is 1; otherwise in the context's scratch like Bf
+            const size_t dbytes = (size_t)nblk * g.Tpad * BLKPX * sizeof(float);
+            bool resident = kstride == 1 && !P->derived && ctx->opt("win_i8", 1) != 0;
+            if (resident && P->dig.cap < dbytes) {
+                size_t fr = 0, tot = 0;
+                CK(hipMemGetInfo(&fr, &tot));
+                if (fr < dbytes + ((size_t)8 << 30)) resident = false;
+            }
+            if (resident) {
+                RET(P->dig.ensure(dbytes)); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double)));
+                digp = P->dig.as<uint4>(); digs = P->dig_sc.as<double>();
+                P->dig_T16 = g.Tpad >> 4; P->dig_valid = true;
+            } else {
+                RET(ctx->dig_scale.ensure((size_t)nblk * BLKPX * sizeof(double)));
+                digp = ctx->bf.as<uint4>(); digs = ctx->dig_scale.as<double>();
+            }
             const int tchunk16 = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 15) & ~int64_t(15));
-            LAUNCH(ctx, "bg_dig_scale", k_dig_scale, dim3(nblk), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, ctx->dig_scale.as<double>());
+            LAUNCH(ctx, "bg_dig_scale", k_dig_scale, dim3(nblk), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, digs);
             LAUNCH(ctx, "bg_build_dig", k_build_dig, dim3(nblk, (unsigned)((g.Tpad + tchunk16 - 1) / tchunk16)), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
-                   ctx->dig_scale.as<double>(), ctx->bf.as<uint4>(), tchunk16, rsT.as<double>());
+                   digs, digp, tchunk16, rsT.as<double>());
         } else
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());
@@ -1210,8 +1251,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             if (use_i8) {
                 static bool attr8 = false;
                 if (!attr8) { CK(hipFuncSetAttribute((const void *)k_gram_i8, hipFuncAttributeMaxDynamicSharedMemorySize, GI_NBUF * GI_STAGE_B)); attr8 = true; }
-                LAUNCH(ctx, "bg_gram_i8", k_gram_i8, dim3(nwg), dim3(512), (size_t)GI_NBUF * GI_STAGE_B, ctx->bf.as<uint4>(), g.Tpad >> 4, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), ctx->dig_scale.as<double>(), covT.as<double>());
+                LAUNCH(ctx, "bg_gram_i8", k_gram_i8, dim3(nwg), dim3(512), (size_t)GI_NBUF * GI_STAGE_B, digp, g.Tpad >> 4, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), digs, covT.as<double>());
             } else if (g.bf4 == 2)
                 LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
@@ -1267,7 +1308,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 RET(to_dev(ctx, dSlot, slot_of.data(), slot_of.size()));
                 if (keep_pt) RET(P->pt_tab.ensure(std::max<size_t>(1, lst_k.size()) * BLKPX * sizeof(double)));
                 LAUNCH(ctx, "bg_win_fix", k_win_fix, dim3((unsigned)blall.size(), WIN_NLB / WF_S), dim3(256), 0, g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(),
-                       dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride, keep_pt ? P->pt_tab.as<double>() : nullptr);
+                       dSlot.as<short>(), dBl.as<int>(), nsg, dUt.as<double>(), ut_stride, dGb.as<double>(), gb_stride, keep_pt ? P->pt_tab.as<double>() : nullptr,
+                       win_i8 ? ctx->gk.as<double>() : (const double *)nullptr, dLk.as<int>());
                 if (keep_pt) {
                     P->pt_K = K; P->pt_lp_h = lst_ptr; P->pt_slot_h = slot_of;
                     P->pt_gen = bound_rows_of(ctx, C, c_order, K, P->pt_rows) ? ctx->bound_gen : -1;

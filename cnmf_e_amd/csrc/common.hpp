@@ -180,6 +180,9 @@ struct Patch {
     // the video's normal equations per patch pixel, packed in the ring solve's register-tile order (ring_solve_packed.hpp): gathered once from cov_base
     // (and once more for a second frame stride), 43 KB per pixel at p = 96
     DevBuf sys, sys_alt; bool sys_valid = false, sys_alt_valid = false;
+    // the centred video as 32-bit fixed-point digit planes [blk][frame/16][plane][256 px] x 16 B + per-pixel scales (gram_i8.hpp), kept for the fits' window projection
+    // (win_proj_i8.hpp) when the memory allows: frame stride 1 only
+    DevBuf dig, dig_sc; int64_t dig_T16 = 0; bool dig_valid = false;
     // The ring solve in two halves (round 4): the fit solves the pixels near footprints (mask E: what the spatial update's masks can reach) and leaves the rest
     // -- pixels whose weights nobody reads before the spatial update's result has gone to the host -- PENDING; w_finish() (bg.hip) launches that second half in
     // front of the first reader of W that may touch it, in practice right behind the spatial update's download: the host's turnaround between the spatial and
@@ -287,6 +290,7 @@ struct cnmfe_ctx {
     int bgs_patch = -1, bgs_d1s = 0; int64_t bgs_dF = 0;   // the patch bgs_b belongs to (cnmfe_background_ssub)
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
     cnmfe::DevBuf dig_scale;  // gram_i8.hpp: per block-region pixel the scale of its 32-bit fixed-point trace (the int8-digit table build)
+    cnmfe::DevBuf tdig, tscale, gk, win_items;   // win_proj_i8.hpp: digit planes / scales of the centred traces, their K x K Gram matrix, the (block, trace group) work items
     cnmfe::DevBuf bf2, outl_cnt, outl_sel;   // outlier branch of the ring fit: clipped copy of bf, outliers per frame, kept frames
     cnmfe::DevBuf cov;        // block-pair covariances [pair][256][256] (fp64)
     cnmfe::DevBuf rowsum;     // [blk][256] double
