@@ -183,6 +183,7 @@ struct Patch {
     // the centred video as 32-bit fixed-point digit planes [blk][frame/16][plane][256 px] x 16 B + per-pixel scales (gram_i8.hpp), kept for the fits' window projection
     // (win_proj_i8.hpp) when the memory allows: frame stride 1 only
     DevBuf dig, dig_sc; int64_t dig_T16 = 0; bool dig_valid = false;
+    DevBuf yt4; bool yt4_valid = false;                   // vproj.hip: the centred video tiled by 16 x 16 block (k_tile_video), for the temporal projection
     // The ring solve in two halves (round 4): the fit solves the pixels near footprints (mask E: what the spatial update's masks can reach) and leaves the rest
     // -- pixels whose weights nobody reads before the spatial update's result has gone to the host -- PENDING; w_finish() (bg.hip) launches that second half in
     // front of the first reader of W that may touch it, in practice right behind the spatial update's download: the host's turnaround between the spatial and

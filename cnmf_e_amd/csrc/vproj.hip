@@ -272,7 +272,24 @@ __global__ void __launch_bounds__(256) k_vp_const(const int64_t *__restrict__ co
 //   64 steps of 4 pixels; a wave load moves 16 chunks x 4 consecutive pixels x 16 B (64-byte runs, every byte used).
 // D: lane holds rows (lane >> 4) + 4 r = list slots, column lane & 15 = its chunk: the four components are four consecutive frames -> one 32-byte store per
 // (slot, chunk) into the partial buffer part[(l0 + slot) * ldp + 4 chunk ..].
-template <int NT>
+// the centred video once more, in the ORDER the projection below reads it: Yt4[((blk * ncg + cg) * 64 + st) * 64 + lane] = chunk 16 cg + (lane & 15) of pixel
+// 4 st + (lane >> 4) of the block (row + 16 column inside the block; 0 outside the block region or behind the last chunk).  A wave instruction of the projection
+// wants 4 consecutive pixels of 16 chunks: 16 segments of 64 bytes, 4 MB apart in the frame-major video -- here ONE kilobyte of consecutive addresses
+// (round 5; + one video's worth of HBM, kept only when that leaves 8 GB free)
+__global__ void __launch_bounds__(256) k_tile_video(const float4 *__restrict__ Y4, BgGeom g, int64_t Tc, int64_t ncg, float4 *__restrict__ Yt4) {
+    const int blk = blockIdx.x, bi = blk % g.nbr, bj = blk / g.nbr;
+    const int64_t cg = blockIdx.y;
+    const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+    const int64_t cl = cg * 16 + n;
+    float4 *o = Yt4 + ((int64_t)blk * ncg + cg) * 64 * 64 + lane;
+    for (int st = threadIdx.x >> 6; st < 64; st += 4) {
+        const int px = 4 * st + kq, rb = bi * 16 + (px & 15), cb = bj * 16 + (px >> 4);
+        const bool in = rb < g.nr_b && cb < g.nc_b && cl < Tc;
+        o[st * 64] = in ? Y4[cl * g.d_b + (int64_t)cb * g.nr_b + rb] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NT, bool TILED>
 __global__ void __launch_bounds__(256) k_vp_proj_b(const float4 *__restrict__ Y4, BgGeom g, int64_t Tc, const int *__restrict__ blk_list, const int *__restrict__ lst_ptr,
                                                    const int *__restrict__ g16, const double *__restrict__ Bt, int nseg, double *__restrict__ part, int64_t ldp) {
     extern __shared__ __attribute__((aligned(16))) double Bl[];        // [NT][256][16]
@@ -292,7 +309,7 @@ __global__ void __launch_bounds__(256) k_vp_proj_b(const float4 *__restrict__ Y4
     const int64_t cgs = (ncg + nseg - 1) / nseg, cg0 = seg * cgs, cg1 = cg0 + cgs < ncg ? cg0 + cgs : ncg;
     for (int64_t cg = cg0 + wave; cg < cg1; cg += 4) {
         const int64_t cl = cg * 16 + n, clc = cl < Tc ? cl : Tc - 1;
-        const float4 *yb = Y4 + clc * g.d_b;
+        const float4 *yb = TILED ? Y4 + (((int64_t)blk * ncg + cg) * 64) * 64 + lane : Y4 + clc * g.d_b;
         double4_t acc[4][NT];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -300,6 +317,7 @@ __global__ void __launch_bounds__(256) k_vp_proj_b(const float4 *__restrict__ Y4
             for (int t = 0; t < NT; ++t) acc[j][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
         auto qof = [&](int st) -> int64_t {
             const int px = 4 * st + kq;
+            if constexpr (TILED) return (int64_t)st * 64;
             int rb = rb0 + (px & 15), cb = cb0 + (px >> 4);
             rb = rb < g.nr_b ? rb : g.nr_b - 1; cb = cb < g.nc_b ? cb : g.nc_b - 1;
             return (int64_t)cb * g.nr_b + rb;
@@ -415,6 +433,22 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
     if (nent > 0)
         LAUNCH(ctx, "temporal_build_B", k_vp_build_b, dim3((unsigned)nent), dim3(256), 0, dEb.as<int>(), dEk.as<int>(), dEs.as<int>(), dG16.as<int>(), g, R, dColptr, dErow, dAval,
                P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->W.as<float>(), dBt.as<double>());
+    // the block-tiled copy of the centred video (k_tile_video), built at the first projection of a patch when the memory allows
+    bool tiled = false;
+    if (!P->derived && ctx->opt("proj_tiled", 1) != 0) {
+        const int64_t ncg_t = (P->Tc + 15) >> 4;
+        const size_t ybytes = (size_t)nblk * ncg_t * 64 * 64 * sizeof(float4);
+        if (!P->yt4_valid) {
+            bool ok = true;
+            if (P->yt4.cap < ybytes) { size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot)); ok = fr >= ybytes + ((size_t)8 << 30); }
+            if (ok) {
+                RET(P->yt4.ensure(ybytes));
+                LAUNCH(ctx, "temporal_tile_video", k_tile_video, dim3((unsigned)nblk, (unsigned)ncg_t), dim3(256), 0, P->Yc4.as<float4>(), g, P->Tc, ncg_t, P->yt4.as<float4>());
+                P->yt4_valid = true;
+            }
+        }
+        tiled = P->yt4_valid;
+    }
     LAUNCH(ctx, "temporal_const", k_vp_const, dim3((unsigned)K), dim3(256), 0, dColptr, dErow, dAval, g, P->ymean_d.as<double>(), P->b0.as<double>(), dCst.as<double>());
     int off = 0;
     for (int t = 3; t >= 0; --t) {
@@ -425,8 +459,11 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
         const int64_t ncg = ((P->Tc + 15) >> 4);
         int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((ncg + 7) / 8, (VP_WG_TARGET + total - 1) / std::max(1, total)));
         const size_t shmem = (size_t)(t + 1) * BLKPX * 16 * sizeof(double);
-#define VP_GO(NT_) do { if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-            LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->Yc4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \
+#define VP_GO(NT_) do { if (shmem > 64 * 1024) { CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+                                                     CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); } \
+            if (tiled) LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_, true>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->yt4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \
+                   dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); \
+            else LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_, false>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->Yc4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \
                    dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); } while (0)
         if (t == 0) VP_GO(1); else if (t == 1) VP_GO(2); else if (t == 2) VP_GO(3); else VP_GO(4);
 #undef VP_GO
