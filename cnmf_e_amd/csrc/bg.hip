@@ -871,8 +871,21 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     const bool a_empty = K == 0;
     int64_t ldc = 4;
     HostCSR csr;
+    bool trace_i8_done = false;                                // the int8 window projection's trace digits and K x K Gram are already queued
     if (has_a) {
         RET(upload_centered(ctx, dC, C, K, T, c_order, dCc, dCm, &ldc));
+        // win_proj_i8.hpp: what depends on the traces alone goes out NOW -- the host's footprint block lists (0.2 ms at the headline size) are built underneath it
+        // instead of in front of an idle GPU (a fit that turns out to use a frame stride > 1 has queued 0.1 ms for nothing)
+        if (P->dig_valid && !outl && T <= 24576 && ctx->opt("win_i8", 1) != 0 && ctx->opt("gram_incremental", 1) != 0) {
+            const int64_t T16 = P->dig_T16;
+            RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
+            RET(ctx->tscale.ensure((size_t)K * sizeof(double)));
+            RET(ctx->gk.ensure((size_t)K * K * sizeof(double)));
+            LAUNCH(ctx, "bg_trace_dig", k_trace_dig, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, (int64_t)T, T16, ctx->tdig.as<uint4>(), ctx->tscale.as<double>());
+            const int ntk = ((int)K + 15) >> 4;
+            LAUNCH(ctx, "bg_trace_gram", k_trace_gram, dim3((unsigned)(ntk * (ntk + 1) / 2)), dim3(64 * TG_W), 0, dCc.as<float>(), ldc, (int64_t)T, (int)K, ctx->gk.as<double>());
+            trace_i8_done = true;
+        }
     }
     // the CSR rows of A (b0, ind_active, the table corrections): built AFTER the window projection is queued when that can go first (below)
     auto upload_csr = [&]() -> int {
@@ -1020,12 +1033,14 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         if (P->dig_valid && g.kstride == 1 && g.Tp <= 24576 && ctx->opt("win_i8", 1) != 0 && K > 0) {
             // round 5 (win_proj_i8.hpp): the same sums on the int8 matrix pipe out of the resident digit planes; G = Cc Cc' once, K x K
             const int64_t T16 = P->dig_T16;
-            RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
-            RET(ctx->tscale.ensure((size_t)K * sizeof(double)));
-            RET(ctx->gk.ensure((size_t)K * K * sizeof(double)));
-            LAUNCH(ctx, "bg_trace_dig", k_trace_dig, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, (int64_t)T, T16, ctx->tdig.as<uint4>(), ctx->tscale.as<double>());
-            const int ntk = ((int)K + 15) >> 4;
-            LAUNCH(ctx, "bg_trace_gram", k_trace_gram, dim3((unsigned)(ntk * (ntk + 1) / 2)), dim3(64 * TG_W), 0, dCc.as<float>(), ldc, (int64_t)T, (int)K, ctx->gk.as<double>());
+            if (!trace_i8_done) {                                // (the first fit of a patch: the digit planes did not exist when the traces went up)
+                RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
+                RET(ctx->tscale.ensure((size_t)K * sizeof(double)));
+                RET(ctx->gk.ensure((size_t)K * K * sizeof(double)));
+                LAUNCH(ctx, "bg_trace_dig", k_trace_dig, dim3(K), dim3(256), 0, dCc.as<float>(), ldc, (int64_t)T, T16, ctx->tdig.as<uint4>(), ctx->tscale.as<double>());
+                const int ntk = ((int)K + 15) >> 4;
+                LAUNCH(ctx, "bg_trace_gram", k_trace_gram, dim3((unsigned)(ntk * (ntk + 1) / 2)), dim3(64 * TG_W), 0, dCc.as<float>(), ldc, (int64_t)T, (int)K, ctx->gk.as<double>());
+            }
             std::vector<int> items;
             for (int b_ : blall) {
                 const int ntl = (lst_ptr[b_ + 1] - lst_ptr[b_] + 15) >> 4;
