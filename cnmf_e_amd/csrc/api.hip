@@ -321,7 +321,6 @@ int ring_stats_enqueue(cnmfe_ctx *ctx, Patch *P) {
     return 0;
 }
 int ring_stats_get(cnmfe_ctx *ctx, Patch *P, int *pmax, bool *first) {
-    RET(w_finish(ctx, P));                                    // (a pending half of the ring solve enqueues the statistics itself)
     if (!P->stat_valid) RET(ring_stats_enqueue(ctx, P));      // W came from somewhere else (ring_init, cnmfe_ring_set_csr): evaluate now
     CK(hipEventSynchronize(P->stat_ev));
     if (pmax) *pmax = *reinterpret_cast<const int *>(P->stat_host);
@@ -535,9 +534,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual", "prealloc", "solve_defer", "solve_packed", "gram_i8", "win_i8", "proj_tiled",
+    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "gram_mode", "gram_flush", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual", "prealloc", "solve_packed", "gram_i8", "win_i8", "proj_tiled",
                                   /* retired experiment switches (rounds 2-3): still accepted, ignored -- scripts/r1_probe.py, r1_duo.py, solve_ab.py name them */
-                                  "r1_arc_d", "r1_arc_bias", "r1_duo_ord", "solve_mode", "gram_kernel", "solve_gfill", nullptr};
+                                  "r1_arc_d", "r1_arc_bias", "r1_duo_ord", "solve_mode", "gram_kernel", "solve_gfill", "solve_defer", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; if (!strcmp(name, "host_trace")) ctx->trace_level = (int)value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -576,7 +575,6 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     size_t esz = dtype == CNMFE_F32 ? 4 : dtype == CNMFE_F64 ? 8 : dtype == CNMFE_U16 ? 2 : dtype == CNMFE_U8 ? 1 : dtype == CNMFE_F16 ? 2 : 0;
     if (!esz) return fail(CNMFE_EINVAL, "unknown dtype %d", dtype);
     if (memspace != CNMFE_HOST && memspace != CNMFE_DEVICE) return fail(CNMFE_EINVAL, "unknown memspace %d", memspace);
-    RET(w_finish(ctx, P));                           // (a deferred half of the last fit belongs to the video that was fitted)
     if (!P->Y.p) {                                   // a re-upload after the block was finalised: start over with a zeroed staging copy
         RET(P->Y.ensure((size_t)P->d_b * P->T * sizeof(float)));
         CK(hipMemsetAsync(P->Y.p, 0, (size_t)P->d_b * P->T * sizeof(float), ctx->st()));
@@ -647,7 +645,6 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
         (P->prect[2] - P->brect[2] < std::min(h, P->prect[2] - 1)) || (P->brect[3] - P->prect[3] < std::min(h, P->d2 - P->prect[3])))
         return fail(CNMFE_EINVAL, "block halo is narrower than the ring radius %d", radius);
     P->ring_ready = false;                                  // from here on a failure leaves "no ring", never a mismatched one
-    P->w_pending = false;                                   // (a deferred half of a ring solve: its W is being replaced)
     P->dr.swap(ndr); P->dc.swap(ndc); P->p = np_; P->radius = radius;
     RET(to_dev(ctx, P->ring_dr, P->dr.data(), P->dr.size()));
     RET(to_dev(ctx, P->ring_dc, P->dc.data(), P->dc.size()));
@@ -688,7 +685,6 @@ int cnmfe_ring_get_csr(cnmfe_ctx *ctx, int patch_id, int64_t *rowptr, int32_t *c
     Patch *P = get_patch(ctx, patch_id);
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
     CK(hipSetDevice(ctx->device));
-    RET(w_finish(ctx, P));
     std::vector<float> W((size_t)P->p * P->d);
     CK(hipMemcpyAsync(W.data(), P->W.p, W.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     CK(hipStreamSynchronize(ctx->st()));
@@ -713,7 +709,6 @@ int cnmfe_ring_set_values(cnmfe_ctx *ctx, int patch_id, const float *val) {
     Patch *P = get_patch(ctx, patch_id);
     if (!P || !P->ring_ready) return fail(CNMFE_ESTATE, "ring of patch %d not initialised", patch_id);
     CK(hipSetDevice(ctx->device));
-    RET(w_finish(ctx, P));
     std::vector<float> W((size_t)P->p * P->d, 0.f);
     int64_t e = 0;
     for (int64_t m = 0; m < P->d; ++m) {

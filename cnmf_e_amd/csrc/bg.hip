@@ -783,10 +783,9 @@ static double matlab_quantile(std::vector<int> x, double q) {
     return x[lo - 1] + (r - (double)lo) * (double)(x[lo] - x[lo - 1]);
 }
 
-static int solve_launch(cnmfe_ctx *ctx, Patch *P, const CovTab &tab, const BgGeom &g, const double *rowsum, const unsigned char *act, int nt, int probe, const double *fill,
-                        const int *pix = nullptr, int64_t npix = -1) {
-    if (npix == 0) return 0;
-    const unsigned ngrid = (unsigned)(pix ? npix : P->d);
+static int solve_launch(cnmfe_ctx *ctx, Patch *P, const CovTab &tab, const BgGeom &g, const double *rowsum, const unsigned char *act, int nt, int probe, const double *fill) {
+    const unsigned ngrid = (unsigned)P->d;
+    const int *pix = nullptr;
     int *dErr = nullptr;
     RET(ctx_errflag(ctx, &dErr));
     // one wave per pixel, the matrix in MFMA accumulator tiles (ring_solve.hpp).  Measured and removed (profiles/r02/solve_ab_c3.txt): the
@@ -798,26 +797,11 @@ static int solve_launch(cnmfe_ctx *ctx, Patch *P, const CovTab &tab, const BgGeo
     return 0;
 }
 
-struct WArgs { CovTab tab; BgGeom g; const double *rowsum, *fill; const unsigned char *act; int nt, probe; int64_t nE, nL; };
-int w_finish(cnmfe_ctx *ctx, Patch *P) {
-    if (!P->w_pending) return 0;
-    P->w_pending = false;
-    if (P->w_blob.size() != sizeof(WArgs)) return fail(CNMFE_ESTATE, "pending ring solve without its arguments");
-    WArgs a; memcpy(&a, P->w_blob.data(), sizeof(a));
-    RET(solve_launch(ctx, P, a.tab, a.g, a.rowsum, a.act, a.nt, a.probe, a.fill, P->w_maskL.as<int>(), a.nL));
-    return ring_stats_enqueue(ctx, P);                       // what the NEXT fit of this patch asks of the (now complete) W
-}
-int w_finish_all(cnmfe_ctx *ctx) {
-    for (auto &kv : ctx->patches) RET(w_finish(ctx, kv.second));
-    return 0;
-}
-
 // The large buffers of the ring fit, allocated when the ring is set (cnmfe_ring_init: once per patch, after the upload) instead of inside the first fit: the
 // video's covariance table, the context's working table, the tiled Bf and the window projection's partial sums -- 18 GB at the headline size.  A fit then
 // queues its kernels without a hipMalloc in between (tens of milliseconds of the first iteration, and on some boxes the dispatch behind a fresh multi-GB
 // allocation stalled for 0.5-0.8 s, profiles/r03/README.md).  Sizes follow the geometry only; a buffer that is already large enough is left alone.
 int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
-    RET(w_finish_all(ctx));                                  // (a pending half solve reads the context's tables: they may be re-allocated below)
     if (ctx->opt("gram_incremental", 1) == 0 || P->p <= 0) return 0;
     int p_radius = 0;
     for (int i = 0; i < P->p; ++i) p_radius = std::max(p_radius, std::max(std::abs(P->dr[i]), std::abs(P->dc[i])));
@@ -859,7 +843,6 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only, double thresh_outlier) {
     HostTrace ht(ctx, "fit_ring");
-    RET(w_finish_all(ctx));                                  // a half solve still pending (of this or another patch) reads the tables this fit rewrites, and W_old must be complete
     const bool outl = thresh_outlier == thresh_outlier;      // ~isnan(thresh_outlier), :50
     if (outl && !P->sn_ready && !(b0_only & 1)) return fail(CNMFE_ESTATE, "fit_ring_model with thresh_outlier needs the noise levels of the block (cnmfe_set_noise)");
     const int64_t T = P->T;
@@ -1292,7 +1275,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         // ---- packed systems (ring_solve_packed.hpp): the video's table re-laid once per pixel in the solve's register-tile order; the fits then apply the
         // footprints' corrections in registers and neither sweep the table (k_cov_correct) nor gather from it.  Conditions: the incremental table,
         // the memory (43 KB per pixel at p = 96), one launch (no split solve)
-        bool packed = incr && ctx->opt("solve_packed", 1) != 0 && ctx->opt("solve_defer", 0) == 0 && (int64_t)nblk * std::max(1, K) < (int64_t)1 << 31 &&
+        bool packed = incr && ctx->opt("solve_packed", 1) != 0 && (int64_t)nblk * std::max(1, K) < (int64_t)1 << 31 &&
                       (int64_t)lst_k.size() * BLKPX < (int64_t)1 << 31;
         const size_t sys_bytes = (size_t)P->d * ((size_t)(nt * (nt + 1) / 2) * 256 + 16 * nt) * sizeof(double);
         if (packed && !(P->sys_valid && P->sys.cap >= sys_bytes)) {
@@ -1362,63 +1345,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
         LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());
         tab.wcodes = dWcodes.as<int>(); tab.woff = woff;
-        // ---- the solve in two halves: E = the pixels within SOLVE_DE of a footprint's bounding box (what the next spatial update's masks read) now, the others
-        // when the first reader of the whole W comes along (w_finish) -- the one fitted full-resolution patch of a context only: the tables are the context's
-        bool split = false;
-        int64_t nE = -1, nL = 0;
-        // MEASURED, NOT THE DEFAULT (option "solve_defer", profiles/r04/solve_defer_ab.txt): at the headline size the host's work in front of the spatial kernels
-        // (search masks, slices, the mask's CSR, the need lists: 5 ms) hides behind the 7.6 ms of the one-launch solve -- with the first half alone (4.1 ms) in front
-        // of it that work is exposed instead of the turnaround behind it: 17.7-19.3 ms against 17.9-18.1, and 6.4-6.7 against 6.2-6.3 at 256 x 256.
-        if (has_a && !P->derived && !b0_out && ctx->opt("solve_defer", 0) != 0) {
-            int nfit = 0;
-            for (auto &kv : ctx->patches) nfit += kv.second->ring_ready && !kv.second->derived;
-            if (nfit == 1) {
-                // E: per footprint the disc around its bounding box' centre that reaches SOLVE_DE pixels beyond the box -- the 'ellipse' search masks of
-                // determine_search_location.m:57-89 (semi-axes 9..24 pixels about the centre of mass) of compact footprints stay inside; a mask that does not
-                // (checked on the host against this very map, vproj.hip) simply triggers the second half early
-                constexpr int SOLVE_DE = 4;
-                std::vector<uint8_t> &E = P->w_emask_h;
-                E.assign((size_t)P->d, 0);
-                for (int k = 0; k < K; ++k) {
-                    if (A_colptr[k + 1] == A_colptr[k]) continue;
-                    int r0 = 1 << 30, r1 = -1, c0 = 1 << 30, c1 = -1;
-                    for (int64_t e = A_colptr[k]; e < A_colptr[k + 1]; ++e) {
-                        const int q = A_rowidx[e], rb = q % P->nr_b, cb = q / P->nr_b;
-                        r0 = std::min(r0, rb); r1 = std::max(r1, rb); c0 = std::min(c0, cb); c1 = std::max(c1, cb);
-                    }
-                    const double cr = 0.5 * (r0 + r1) - P->roff, cc = 0.5 * (c0 + c1) - P->coff, rad = 0.5 * std::max(r1 - r0, c1 - c0) + SOLVE_DE + 0.5;
-                    const int pc0 = std::max(0, (int)std::ceil(cc - rad)), pc1 = std::min(P->nc - 1, (int)std::floor(cc + rad));
-                    for (int c = pc0; c <= pc1; ++c) {
-                        const double hh = std::sqrt(std::max(0.0, rad * rad - (c - cc) * (c - cc)));
-                        const int pr0 = std::max(0, (int)std::ceil(cr - hh)), pr1 = std::min(P->nr - 1, (int)std::floor(cr + hh));
-                        if (pr1 >= pr0) memset(&E[(size_t)c * P->nr + pr0], 1, (size_t)(pr1 - pr0 + 1));
-                    }
-                }
-                static thread_local std::vector<int> lE, lL;
-                lE.clear(); lL.clear();
-                for (int64_t m = 0; m < P->d; ++m) (E[(size_t)m] ? lE : lL).push_back((int)m);
-                nE = (int64_t)lE.size(); nL = (int64_t)lL.size();
-                split = nE > 0 && nL >= P->d / 8;                  // (a field of view covered by footprints: nothing worth deferring)
-                if (split) {                                         // the two halves as pixel lists (w_maskE / w_maskL: int lists despite the name of the first version)
-                    RET(to_dev(ctx, P->w_maskE, lE.data(), lE.size()));
-                    RET(to_dev(ctx, P->w_maskL, lL.data(), lL.size()));
-                    if (act) {                                       // the active flags must outlive the context's scratch (tmp[8]) until the second half runs
-                        RET(ctx->vp[12].ensure((size_t)P->d));
-                        CK(hipMemcpyAsync(ctx->vp[12].p, act, (size_t)P->d, hipMemcpyDeviceToDevice, ctx->st()));
-                        act = ctx->vp[12].as<unsigned char>();
-                    }
-                }
-            }
-        }
-        RET(solve_launch(ctx, P, tab, g, ctx->rowsum.as<double>(), act, nt, probe, dFill.as<double>(), split ? P->w_maskE.as<int>() : nullptr, nE));
-        if (split) {
-            WArgs a; a.tab = tab; a.g = g; a.rowsum = ctx->rowsum.as<double>(); a.fill = dFill.as<double>(); a.act = act; a.nt = nt; a.probe = probe; a.nE = nE; a.nL = nL;
-            P->w_blob.resize(sizeof(WArgs)); memcpy(P->w_blob.data(), &a, sizeof(a));
-            P->w_pending = true; P->stat_valid = false;
-        }
+        RET(solve_launch(ctx, P, tab, g, ctx->rowsum.as<double>(), act, nt, probe, dFill.as<double>()));
         }
     }
-    if (!P->w_pending)
     RET(ring_stats_enqueue(ctx, P));                         // what the NEXT fit of this patch asks of the W being written now
     ht.mark("solve launch");
     if (b0_out) {

@@ -184,14 +184,6 @@ struct Patch {
     // (win_proj_i8.hpp) when the memory allows: frame stride 1 only
     DevBuf dig, dig_sc; int64_t dig_T16 = 0; bool dig_valid = false;
     DevBuf yt4; bool yt4_valid = false;                   // vproj.hip: the centred video tiled by 16 x 16 block (k_tile_video), for the temporal projection
-    // The ring solve in two halves (round 4): the fit solves the pixels near footprints (mask E: what the spatial update's masks can reach) and leaves the rest
-    // -- pixels whose weights nobody reads before the spatial update's result has gone to the host -- PENDING; w_finish() (bg.hip) launches that second half in
-    // front of the first reader of W that may touch it, in practice right behind the spatial update's download: the host's turnaround between the spatial and
-    // the temporal update (a millisecond of GPU idle at the headline size) then runs under it.  Same arithmetic per pixel, so the same W.
-    bool w_pending = false;
-    DevBuf w_maskE, w_maskL;           // d bytes each: active & E, active & ~E
-    std::vector<uint8_t> w_emask_h;    // E on the host (does a search mask stay inside it?)
-    std::vector<uint8_t> w_blob;       // the launch arguments of the pending half (bg.hip: WArgs)
     // what the next fit asks of W before it can queue anything (pmax of fit_ring_model.m:60, row 1 for the first-run test of :25), copied to
     // pinned memory behind the fit that produced W: the next fit reads it without draining the stream (ring_stats_*, api.hip)
     DevBuf stat_dev; void *stat_host = nullptr; hipEvent_t stat_ev = nullptr; bool stat_valid = false;
@@ -360,8 +352,6 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only = 0, double thresh_outlier = NAN);
 int tu_warm_resid(); int tu_warm_bg(); int tu_warm_factor(); int tu_warm_deconv(); int tu_warm_ssub(); int tu_warm_vproj();   // one per translation unit: load its code object (cnmfe_create)
-int w_finish(cnmfe_ctx *ctx, Patch *P);                   // bg.hip: the deferred half of the ring solve, if one is pending (every reader of W outside the mask E calls it first)
-int w_finish_all(cnmfe_ctx *ctx);                         // ... of every patch of the context (before the shared tables are rewritten or freed)
 int bg_reserve(cnmfe_ctx *ctx, Patch *P);                 // bg.hip: the ring fit's large buffers, sized by the geometry, allocated ahead of the first fit
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr, int tables_only = 0);

@@ -939,7 +939,6 @@ __global__ void __launch_bounds__(256) k_rss(const float4 *__restrict__ ysig4, i
 int rss_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
             const float *b0_block, const float *b0_new, double *rss_out) {
     RET(residual_materialize(ctx, P));
-    RET(w_finish(ctx, P));                                   // (k_rss_const reads every row of W)
     const int64_t T = P->T, d = P->d;
     DevBuf &dC = ctx->tmp[0], &dCnt = ctx->tmp[3], &dK = ctx->tmp[4], &dV = ctx->tmp[5], &dB0b = ctx->tmp[6], &dB0n = ctx->tmp[7], &dKap = ctx->tmp[12], &dPart = ctx->tmp[13];
     const bool has_a = K > 0 && A_colptr[K] > 0;
@@ -994,7 +993,6 @@ __global__ void __launch_bounds__(256) k_bg_out(const float4 *__restrict__ yc4, 
 
 int bg_reconstruct_run(cnmfe_ctx *ctx, Patch *P, const float *b0_block, const float *b0_new, int64_t frame0, int64_t nframes, float *out, int out_memspace) {
     RET(residual_materialize(ctx, P));
-    RET(w_finish(ctx, P));
     const int64_t d = P->d;
     DevBuf &dB0b = ctx->tmp[6], &dB0n = ctx->tmp[7], &dKap = ctx->tmp[12];
     RET(to_dev(ctx, dB0b, b0_block, (size_t)P->d_b)); RET(to_dev(ctx, dB0n, b0_new, (size_t)d));
@@ -1101,7 +1099,6 @@ static int r1_sweep(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, bool has_ac, int64_t
 int residual_realize(cnmfe_ctx *ctx, Patch *P) {
     if (!P->ysig_virtual) return 0;
     if (!P->ysig_valid) { P->ysig_virtual = false; return 0; }
-    RET(w_finish(ctx, P));
     RET(P->ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
     RET(r1_sweep(ctx, P, P->ysig, false, 4, false, nullptr));
     P->ysig_virtual = false;
@@ -1119,9 +1116,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
     int64_t ldc = 4;
     bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
     // everything below reads W (the ELL rows of W A_prev, a sweep) -- except a request without footprints that is only recorded: then a pending half of the
-    // ring solve (bg.hip, w_finish) stays pending
-    if (has_ac || Ysig_out || outbuf || tables_only || ctx->opt("r1_virtual", 1) == 0 || ctx->opt("r1_lazy", 1) == 0 || ctx->opt("r1_delta", 1) == 0) RET(w_finish(ctx, P));
-    if (has_ac) {
+    if (has_ac || Ysig_out || outbuf || tables_only || ctx->opt("r1_virtual", 1) == 0 || ctx->opt("r1_lazy", 1) == 0 || ctx->opt("r1_delta", 1) == 0)    if (has_ac) {
         RET(upload_centered(ctx, dC, C, Ksel, T, c_order, dCc, dCm, &ldc));
         HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
         RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));

@@ -192,11 +192,6 @@ int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_ord
         ht.mark("table built");
     }
     if (nnz == 0) return 0;
-    if (P->w_pending) {                                      // the fit solved the pixels of its mask E only so far: does every mask pixel lie inside?
-        bool inside = P->w_emask_h.size() == (size_t)P->d;
-        for (int64_t e = 0; e < nnz && inside; ++e) inside = P->w_emask_h[(size_t)IND_rowidx[e]] != 0;
-        if (!inside) RET(w_finish(ctx, P));
-    }
     DevBuf &dKmap = ctx->vp[0];
     RET(to_dev(ctx, dKmap, kmap.data(), kmap.size()));
     int *dErr = nullptr;
@@ -385,7 +380,6 @@ __global__ void __launch_bounds__(256) k_vp_reduce(const double *__restrict__ pa
 int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                    const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu) {
     HostTrace ht(ctx, "vproj_temporal");
-    RET(w_finish(ctx, P));                                   // B = A - W'A reads the rows of W under the footprints: the whole W is wanted by now anyway
     const BgGeom g = vp_geom(P);
     const int nblk = g.nbr * g.nbc, R = g.p_radius;
     if (16 + 2 * R > VP_WS) return 1;

@@ -197,59 +197,3 @@ def test_virtual_spatial_update_with_changed_traces_builds_its_own_table(eng):
     finally:
         eng.set_option("r1_virtual", 1)
         eng.bind_traces(None)
-
-
-@pytest.mark.parametrize("dims,r", [((96, 80), 15), ((110, 90), 5)])
-def test_deferred_half_of_the_ring_solve(dims, r):
-    """the ring solve in two halves (bg.hip, w_finish): the fit solves the pixels near footprints, the others when the first reader of the whole W comes along --
-    the same W bit for bit as the one-launch solve, whoever that reader is (a CSR export, the next fit, a residual with footprints, the temporal projection), and
-    a spatial update whose masks stay inside the solved pixels does not trigger it"""
-    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
-    from cnmf_e_amd.engine import Engine
-    eng = Engine(0)                                           # (a context with ONE fitted patch: the halves share the context's tables)
-    d1, d2 = dims
-    T, K = 200, 4
-    f, Y, video = _setup(eng, d1, d2, T, K, r, 81)
-    A = f.A_init.tocsc().astype(np.float32)
-    Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
-    IND = _dilated_mask(A, d1, d2)
-    solves = lambda t: _calls(t, "bg_ring_solve")
-    try:
-        ref = {}
-        for defer in (0, 1):
-            eng.set_option("solve_defer", defer)
-            eng.ring_init(0, r)
-            eng.bind_traces(Cm)
-            out = []
-            for fit in range(2):                                  # the first-run fit (every pixel) and a later one (ind_active)
-                eng.profile(True); eng.profile_reset()
-                eng.fit_ring_model(0, A, Cm, want_b0=False)
-                n_fit = solves(eng.profile_table())
-                eng.residual(0, None, None)                       # recorded only: W is not read
-                a_new = eng.update_spatial(0, "hals", A, Cm, IND)
-                n_sp = solves(eng.profile_table())
-                eng.residual(0, A, Cm)                            # the W A_prev tables read every row of W
-                n_res = solves(eng.profile_table())
-                c = eng.hals_temporal(0, a_new, Cm, 2)
-                eng.profile(False)
-                out.append((eng.ring_csr(0).data.copy(), a_new.toarray(), c[0], (n_fit, n_sp, n_res)))
-            ref[defer] = out
-        for fit in range(2):
-            w0, a0, c0, n0 = ref[0][fit]; w1, a1, c1, n1 = ref[1][fit]
-            assert n0 == (1, 1, 1), n0
-            assert n1 == (1, 1, 2), n1                            # the second half ran in front of the residual with footprints, not before
-            assert np.array_equal(w0, w1) and np.array_equal(a0, a1) and np.array_equal(c0, c1)
-        # other first readers of the whole W: a CSR export, the next fit
-        eng.ring_init(0, r); eng.fit_ring_model(0, A, Cm, want_b0=False); eng.fit_ring_model(0, A, Cm, want_b0=False)
-        eng.set_option("solve_defer", 1)
-        eng.fit_ring_model(0, A, Cm, want_b0=False)
-        w_csr = eng.ring_csr(0).data.copy()
-        eng.set_option("solve_defer", 0)
-        eng.ring_init(0, r); eng.fit_ring_model(0, A, Cm, want_b0=False); eng.fit_ring_model(0, A, Cm, want_b0=False); eng.fit_ring_model(0, A, Cm, want_b0=False)
-        w_ref3 = eng.ring_csr(0).data.copy()
-        eng.set_option("solve_defer", 1)
-        eng.ring_init(0, r); eng.fit_ring_model(0, A, Cm, want_b0=False); eng.fit_ring_model(0, A, Cm, want_b0=False); eng.fit_ring_model(0, A, Cm, want_b0=False)
-        assert np.array_equal(eng.ring_csr(0).data, w_ref3)
-        assert np.array_equal(w_csr, w_ref3)                      # (the third fit of the same inputs, read through the CSR export while its second half was pending)
-    finally:
-        eng.close()
