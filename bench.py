@@ -46,7 +46,7 @@ SHARD_OF = {"c5shard": 8}    # configurations that run one rank's patches of an 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (157.3 TF), spec
 F32_MFMA_PEAK_TF = 157.3
-BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); the split-bf16 Gram issues 4 bf16 products per fp32-equivalent product
+I8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA, spec (MI355X_MICROARCH.md measures >= 3944 TOPS on 16x16x64); the int8 Gram issues 13 digit-pair products per fp32-equivalent product
 
 
 def _blas_info():
@@ -570,13 +570,15 @@ def main():
                         "video's table (algorithmic_bytes_per_launch, coalesced: 1.9 ms at 6 TB/s, overlapped with other waves' arithmetic) and corrected in registers "
                         "(option solve_packed); the 16x16 diagonal steps and the substitutions run on the vector pipe and bound the kernel -- DESIGN.md section 3"
                         % (int(n_act), n, n)}
-    if dom.startswith("bg_gram"):
-        roof = gram_roof(dom, F64_MFMA_PEAK_TF if "f64" in dom else (BF16_MFMA_PEAK_TF if "bf16" in dom else F32_MFMA_PEAK_TF))
-        if "bf16" in dom:
-            roof["achieved"] *= 4.0; roof["frac"] *= 4.0; roof["algorithmic_flops_per_launch"] *= 4.0
-            roof["note"] = ("every needed covariance once (block-sparse SYRK, 9.57 TFLOP fp32-equivalent at the headline size) as 4 bf16 MFMA products each "
-                            "(38.3 TFLOP on the bf16 pipe, peak = dense bf16); the kernel is bound by the chip's power budget (effective clock 1.5-1.75 GHz "
-                            "under 385 GB of fabric traffic per launch), not by the matrix pipe -- see DESIGN.md")
+    if dom.startswith("bg_gram"):                                # (only with --warmup 0: the table of the video is built once per recording)
+        if dom == "bg_gram_i8":                                  # 13 int8 digit-pair products per fp32-equivalent product (gram_i8.hpp), priced against the int8 matrix peak
+            roof = gram_roof(dom, I8_MFMA_PEAK_TOPS)
+            roof["achieved"] *= 13.0; roof["frac"] *= 13.0; roof["algorithmic_flops_per_launch"] *= 13.0; roof["unit"] = "TOP/s"
+            roof["note"] = ("every needed covariance once (block-sparse SYRK, 9.57 T fp32-equivalent multiply-adds x 2 at the headline size) as 13 int8 digit-pair products "
+                            "with exact int32 accumulation; the kernel is bound by its operand traffic (the split-bf16 mode of rounds 2-4 moved the same bytes in 50 ms), "
+                            "not by the matrix pipe -- DESIGN.md")
+        else:
+            roof = gram_roof(dom, F64_MFMA_PEAK_TF)
     elif dom == "residual_r1":
         roof = r1_roof()
     elif dom == "ssub_up_fused":                                 # bg_ssub > 1: read Y' + W*(..) at low resolution (two arrays), write Ysig
@@ -637,7 +639,7 @@ def main():
         "roofline_projections": with_pmc(proj_roofs()),
         **comm,
         "first_iteration": {"ms": warm_steps_ms[0] if warm_steps_ms else None, "warmup_steps_ms": [round(x, 3) for x in warm_steps_ms],
-                            "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_f64", "bg_build_bf", "bg_rowsum") and v["calls"]},
+                            "one_off_kernels_ms": {k: round(v["total_ms"], 3) for k, v in warm_tab.items() if k in ("bg_gram_i8", "bg_gram_f64", "bg_build_dig", "bg_dig_scale", "bg_build_bf", "bg_rowsum", "bg_sys_pack") and v["calls"]},
                             "kernels_ms": None if first_tab is None else {k: round(v["total_ms"], 3) for k, v in sorted(first_tab.items(), key=lambda kv: -kv[1]["total_ms"])[:14] if v["calls"]},
                             "kernel_sum_ms": None if first_tab is None else round(sum(v["total_ms"] for v in first_tab.values()), 3),
                             "note": "the FIRST step after the upload (timed on its own): its background fit also builds the block-pair covariance table of the video on "

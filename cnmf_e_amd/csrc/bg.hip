@@ -22,10 +22,6 @@ namespace cnmfe {
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // ---- B1 ------------------------------------------------------------------------------------------
-// fp32 -> (hi, lo) bf16 pair, round-to-nearest-even: x = hi + lo + O(2^-17 |x|)
-__device__ __forceinline__ unsigned bf16_rne(float x) { const unsigned u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }
-__device__ __forceinline__ void bf16_split(float x, unsigned &hi, unsigned &lo) { hi = bf16_rne(x); lo = bf16_rne(x - __uint_as_float(hi << 16)); }
-
 __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g,
                                                   const int *__restrict__ arow, const int *__restrict__ acol, const float *__restrict__ aval,
                                                   const float *__restrict__ Cc, int64_t ldc, float *__restrict__ bf, int tchunk, double *__restrict__ rs) {
@@ -41,30 +37,7 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
     const int64_t tp0 = (int64_t)blockIdx.y * tchunk;          // tchunk is a multiple of 4
     const int64_t tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
     float *out = bf + ((int64_t)blk * g.Tpad) * BLKPX + lp;
-    double rsum = 0.0;                                   // bf4 == 2: the ones-row of X from the exact fp32 values (the split loses 2^-17)
-    if (g.kstride == 1 && g.bf4 == 2) {            // split-bf16 operands: 8 frames per iteration -> one 16-byte store per plane
-        for (int64_t tp = tp0; tp < tp1; tp += 8) {
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            const int64_t c = tp >> 2;
-            if (in) {
-                if (c < Tc) v0 = Y4[c * g.d_b + q];
-                if (c + 1 < Tc) v1 = Y4[(c + 1) * g.d_b + q];
-                for (int e = e0; e < e1; ++e) {
-                    const float av = aval[e];
-                    const float *cr = Cc + (int64_t)acol[e] * ldc + tp;
-                    if (c < Tc) { const float4 c4 = *reinterpret_cast<const float4 *>(cr); v0.x -= av * c4.x; v0.y -= av * c4.y; v0.z -= av * c4.z; v0.w -= av * c4.w; }
-                    if (c + 1 < Tc) { const float4 c4 = *reinterpret_cast<const float4 *>(cr + 4); v1.x -= av * c4.x; v1.y -= av * c4.y; v1.z -= av * c4.z; v1.w -= av * c4.w; }
-                }
-            }
-            unsigned h[8], l[8];
-            bf16_split(v0.x, h[0], l[0]); bf16_split(v0.y, h[1], l[1]); bf16_split(v0.z, h[2], l[2]); bf16_split(v0.w, h[3], l[3]);
-            bf16_split(v1.x, h[4], l[4]); bf16_split(v1.y, h[5], l[5]); bf16_split(v1.z, h[6], l[6]); bf16_split(v1.w, h[7], l[7]);
-            uint4 *o16 = reinterpret_cast<uint4 *>(bf) + (((int64_t)blk * (g.Tpad >> 3) + (tp >> 3)) * 2) * BLKPX + lp;    // [blk][frame/8][hi | lo][256 px]
-            o16[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-            o16[BLKPX] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-            rsum += (((double)v0.x + (double)v0.y) + ((double)v0.z + (double)v0.w)) + (((double)v1.x + (double)v1.y) + ((double)v1.z + (double)v1.w));
-        }
-    } else if (g.kstride == 1) {                   // the video is resident centred: Bf = Yc - A*(C - Cmean), 4 frames per load
+    if (g.kstride == 1) {                          // the video is resident centred: Bf = Yc - A*(C - Cmean), 4 frames per load
         for (int64_t tp = tp0; tp < tp1; tp += 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int64_t c = tp >> 2;
@@ -88,16 +61,10 @@ __global__ void __launch_bounds__(256) k_build_bf(const float4 *__restrict__ Y4,
                 v = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)];
                 for (int e = e0; e < e1; ++e) v -= aval[e] * Cc[(int64_t)acol[e] * ldc + t];
             }
-            if (g.bf4 == 2) {
-                unsigned h, l; bf16_split(v, h, l);
-                unsigned short *e = reinterpret_cast<unsigned short *>(bf) + ((((int64_t)blk * (g.Tpad >> 3) + (tp >> 3)) * 2) * BLKPX + lp) * 8 + (tp & 7);
-                e[0] = (unsigned short)h; e[(int64_t)BLKPX * 8] = (unsigned short)l;
-                rsum += (double)v;
-            } else if (g.bf4) bf[(((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 4 + (tp & 3)] = v;
+            if (g.bf4) bf[(((int64_t)blk * (g.Tpad >> 2) + (tp >> 2)) * BLKPX + lp) * 4 + (tp & 3)] = v;
             else out[tp * BLKPX] = v;
         }
     }
-    if (g.bf4 == 2 && rs) atomicAdd(&rs[(int64_t)blk * BLKPX + lp], rsum);
 }
 
 // row sums of Bf over the used frames (the "ones" row of X, fit_ring_model.m:101)
@@ -136,17 +103,19 @@ constexpr int G4_NBUF = 4, G4_STAGE_F = 2 * GK * 128;
 
 struct G4Wave {                       // per-wave constants of a work item (all wave-uniform except lbase, vo0, vo1)
     const float *gA, *gB;
-    unsigned vo0, vo1, vo2, dA0;
-    int lbase, lbaseB, nst, flush_every, ns, lane;
+    unsigned vo0, vo1, dA0;
+    int lbase, nst, probe, ns, lane;
     double *out;                      // cov + pair*256*256 + (ih*128)*256 + jh*128
 };
 
 // the whole stage loop for a wave that owns NS slots (the last one only if `ns == NS`): instantiated per NS and
 // selected ONCE per workgroup, so the loop body is branch-free straight-line code with its own register allocation
-// (a switch inside the loop made hipcc keep the fp64 shadows in scratch: 456 spilled VGPRs)
-// MODE 0: fp64 MFMA; 1: fp32 MFMA; 2: split bf16 (4 products hi*hi + hi*lo + lo*hi + lo*lo on the bf16 pipe, 16x the fp32 MFMA rate:
-// W error like MODE 1 -- emulation in DESIGN.md -- at a quarter of its matrix-pipe time).  MODE >= 1 folds into fp64 shadows.
-template <int MODE, int NS>
+// (a switch inside the loop made hipcc keep the accumulators in scratch: 456 spilled VGPRs).
+// fp64 MFMAs: exact products of the fp32 operands, fp64 sums.  Rounds 1-4 also carried an fp32-MFMA mode with fp64 shadow accumulation (89 ms at H, W error 2e-4)
+// and a split-bf16 mode (4 bf16 products per fp32 product, 50 ms, 9e-5) for the direct Gram: both retired in round 5, when the int8 digit Gram (gram_i8.hpp: 64 ms,
+// EXACT up to a 32-bit quantisation, 1e-8 of W) took over every use that fits its int32 range -- this kernel remains for the outlier branch (a clipped, frame-selected
+// Bf) and for recordings beyond 24576 used frames.
+template <int NS>
 __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, const int *__restrict__ tlw) {
     int ao[NS], bo[NS], ti[NS], tj[NS];
 #pragma unroll
@@ -158,21 +127,19 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
     const bool last = w.ns == NS;
     auto issue = [&](int st) {
         int sc = st < w.nst ? st : w.nst - 1;                            // clamp: keeps the vmcnt arithmetic uniform
-        if ((w.flush_every >> 16) & 1) sc = 0;                           // A/B probe (gram_probe bit 0): every stage re-reads stage 0 -> no fabric traffic
+        if (w.probe & 1) sc = 0;                                         // A/B probe (gram_probe bit 0): every stage re-reads stage 0 -> no fabric traffic
         const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
         const unsigned d = w.dA0 + (unsigned)(st & (G4_NBUF - 1)) * (G4_STAGE_F * 4u);
         glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
         glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
     };
     double4_t acc[NS];
-    float4_t facc[NS];
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) { acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
+    for (int sl = 0; sl < NS; ++sl) acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s0 = 0; s0 < G4_NBUF - 1; ++s0) issue(s0);
-    int since = 0;
     for (int st = 0; st < w.nst; ++st) {
-        if (!((w.flush_every >> 16) & 2)) {                                           // (gram_probe bit 1: timing experiment without the stage sync)
+        if (!(w.probe & 2)) {                                                         // (gram_probe bit 1: timing experiment without the stage sync)
         asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * (G4_NBUF - 2)) : "memory");    // this wave's part of stage st has landed
         __builtin_amdgcn_s_barrier();                                                // ... and everybody else's; buffer st-1 is free
         }
@@ -202,48 +169,16 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
             const bool on0 = true, on1 = (base + 1 < NS - 1) || (base + 1 == NS - 1 && last);
             const bool only0_last = (base == NS - 1);                   // odd NS: the last slot stands alone
             const bool do0 = only0_last ? last : on0;
-            if (MODE == 2) {
-                typedef short short4_t __attribute__((ext_vector_type(4)));
-                union U { float2 f; short4_t s; };
-                U ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    ah[u].f = make_float2(fa[cur][u].x, fa[cur][u].y); al[u].f = make_float2(fa[cur][u].z, fa[cur][u].w);
-                    bh[u].f = make_float2(fb[cur][u].x, fb[cur][u].y); bl[u].f = make_float2(fb[cur][u].z, fb[cur][u].w);
+                    if (base + u >= NS) continue;
+                    if (u == 0 ? !do0 : !on1) continue;
+                    const float av = kq == 0 ? fa[cur][u].x : kq == 1 ? fa[cur][u].y : kq == 2 ? fa[cur][u].z : fa[cur][u].w;
+                    const float bv = kq == 0 ? fb[cur][u].x : kq == 1 ? fb[cur][u].y : kq == 2 ? fb[cur][u].z : fb[cur][u].w;
+                    acc[base + u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)bv, acc[base + u], 0, 0, 0);
                 }
-#pragma unroll
-                for (int term = 0; term < 4; ++term) {                  // smallest products first: lo*lo, hi*lo, lo*hi, hi*hi
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (base + u >= NS) continue;
-                        if (u == 0 ? !do0 : !on1) continue;
-                        const short4_t av = (term == 0 || term == 2) ? al[u].s : ah[u].s;
-                        const short4_t bv = (term == 0 || term == 1) ? bl[u].s : bh[u].s;
-                        facc[base + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, facc[base + u], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (base + u >= NS) continue;
-                        if (u == 0 ? !do0 : !on1) continue;
-                        const float av = kq == 0 ? fa[cur][u].x : kq == 1 ? fa[cur][u].y : kq == 2 ? fa[cur][u].z : fa[cur][u].w;
-                        const float bv = kq == 0 ? fb[cur][u].x : kq == 1 ? fb[cur][u].y : kq == 2 ? fb[cur][u].z : fb[cur][u].w;
-                        if (MODE == 1) facc[base + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, facc[base + u], 0, 0, 0);
-                        else acc[base + u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)bv, acc[base + u], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (MODE >= 1 && (++since == (w.flush_every & 0xffff) || st + 1 == w.nst)) {     // fold the fp32 partial sums into the fp64 shadows
-            since = 0;
-#pragma unroll
-            for (int sl = 0; sl < NS; ++sl) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[sl][r] += (double)facc[sl][r];
-                facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f};
             }
         }
         asm volatile("" ::: "memory");
@@ -255,127 +190,15 @@ __device__ __forceinline__ void gram4_run(const G4Wave &w, const float *smem, co
         if (sl < NS - 1 || last) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // D layouts: fp32 16x16 -> row = (lane>>4)*4 + r ; fp64 16x16 -> row = (lane>>4) + 4*r
-                const int rr = MODE >= 1 ? ((w.lane >> 4) * 4 + r) : ((w.lane >> 4) + 4 * r);
+                const int rr = (w.lane >> 4) + 4 * r;                    // D layout (fp64 16x16): row = (lane >> 4) + 4 r
                 w.out[(int64_t)(ti[sl] * 16 + rr) * BLKPX + tj[sl] * 16 + fl] = acc[sl][r];
             }
         }
 }
 
-// split-bf16 on the K=32 instruction: v_mfma_f32_16x16x32_bf16 is the full-rate bf16 MFMA of gfx950 (16 clk for 16384 flop; the
-// K=16 form used by gram4_run<2> takes the same 16 clk for half the work).  One compute step = two 16-frame stages: lane group
-// l>>4 takes quad-row l>>4 of BOTH stages (8 frames); A and B fragments are built identically, so the pairing of frames inside
-// the instruction's k index is irrelevant.  4 ds_read_b128 + 4 MFMAs per tile and 32 frames.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-struct G4Frag { float4 ah, al, bh, bl; };                             // hi / lo planes of the A and B fragments of one tile (4 x ds_read_b128)
-// LDS stage geometry (floats) and the DMA of one 16-frame stage of the split-bf16 mode:
-// G4Quad: 4 waves, item = (block pair, 128x128 quadrant): stage = [A half: e(2) x plane(2) x 128 px][B half: same] x 16 B = 16 KB
-struct G4Quad {
-    static constexpr int STAGE_F = G4_STAGE_F, APL = 512, BPL = 512, WAVES = 4, LIST = 64, NBUF = 4, DEPTH = 1, NDMA = 4;   // DEPTH steps in flight
-    static __device__ __forceinline__ void issue(const G4Wave &w, int sc, unsigned d) {
-        const float *sa = w.gA + (int64_t)sc * GK * BLKPX, *sb = w.gB + (int64_t)sc * GK * BLKPX;
-        glds16(sa, w.vo0, d); glds16(sa, w.vo1, d + 4096u);
-        glds16(sb, w.vo0, d + 8192u); glds16(sb, w.vo1, d + 12288u);
-    }
-};
-template <class CFG, int NS>
-__device__ __forceinline__ void gram4_run_k32(const G4Wave &w, const float *smem, const int *__restrict__ tlw) {
-    // The non-MFMA VALU work per MFMA decides this loop (PMC: 2.9 VALU instructions per MFMA saturated the issue port at 40 % matrix-pipe
-    // utilisation), so the body is branch-free straight-line code: every slot loads its own four fragments into one of two NAMED register sets
-    // (compile-time ping-pong, no copies), slots past `ns` of the last wave recompute tile 0 and are never stored (the workgroup waits for its
-    // busiest wave anyway), and steps go in pairs: the first product of a pair starts from the inline constant 0 and the pair's sum is folded
-    // into the fp64 shadows (cvt + add, nothing to clear).  64 frames per fold: W error vs the fp64 mode 9e-5 (128 frames: 2e-4).
-    int ao[NS], bo[NS], ti[NS], tj[NS];
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl) {
-        const int code = __builtin_amdgcn_readfirstlane(tlw[sl < w.ns ? sl : 0]);   // this wave owns a CONTIGUOUS run of the (row-major) tile list
-        ti[sl] = code & 7; tj[sl] = code >> 4;
-        ao[sl] = ti[sl] * 64; bo[sl] = tj[sl] * 64;
-    }
-    const bool probe_nomem = (w.flush_every >> 16) & 1;
-    int ib = 0, cb = 0;                                             // stage buffer (even) the next issue fills / the current step reads: both rotate 0, 2, .. NBUF-2
-    auto issue2 = [&](int step) {                                   // stages 2*step, 2*step+1 -> buffers ib, ib+1
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int st = 2 * step + h;
-            int sc = st < w.nst ? st : w.nst - 1;
-            if (probe_nomem) sc = 0;
-            CFG::issue(w, sc, w.dA0 + (unsigned)(ib + h) * (CFG::STAGE_F * 4u));
-        }
-        ib = ib + 2 == CFG::NBUF ? 0 : ib + 2;
-    };
-    double4_t acc[NS];
-    float4_t facc[NS];
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl) { acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0}; facc[sl] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
-    const int nstep = w.nst >> 1;                                   // Tpad is a multiple of 64 in this mode: nstep is even
-    auto ld = [&](const float *lpa, const float *lpb, int sl) {
-        G4Frag f;
-        f.ah = *reinterpret_cast<const float4 *>(lpa + ao[sl]); f.al = *reinterpret_cast<const float4 *>(lpa + ao[sl] + CFG::APL);
-        f.bh = *reinterpret_cast<const float4 *>(lpb + bo[sl]); f.bl = *reinterpret_cast<const float4 *>(lpb + bo[sl] + CFG::BPL);
-        return f;
-    };
-    auto mm = [&](const G4Frag &f, float4_t c0, auto first) {
-        union U { float4 v; bf16x8_t h; } ah, al, bh, bl;
-        ah.v = f.ah; al.v = f.al; bh.v = f.bh; bl.v = f.bl;
-        float4_t c;
-        if constexpr (decltype(first)::value) c = (float4_t){0.f, 0.f, 0.f, 0.f}; else c = c0;
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bl.h, c, 0, 0, 0);      // smallest products first (without lo*lo: 47 vs 51 ms, W error 6.6e-4 vs 9.4e-5)
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bl.h, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.h, bh.h, c, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.h, bh.h, c, 0, 0, 0);
-    };
-    auto body = [&](int step, auto first) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * CFG::NDMA * (CFG::DEPTH - 1)) : "memory");   // this wave's part of both stages has landed (younger steps may still fly)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue2(step + CFG::DEPTH);
-        int lb = w.lbase, lbB = w.lbaseB;
-        asm volatile("" : "+v"(lb), "+v"(lbB));
-        // the two stages of a step sit in adjacent buffers ((2*step)&3 is 0 or 2); lane group l>>4 owns one of their four 8-frame
-        // rows, whose hi and lo planes ARE the K=32 operands: every fragment is one ds_read_b128, no register shuffling
-        const float *lp = smem + cb * CFG::STAGE_F + lb, *lpb = smem + cb * CFG::STAGE_F + lbB;
-        cb = cb + 2 == CFG::NBUF ? 0 : cb + 2;
-        G4Frag x = ld(lp, lpb, 0), y = x;
-#pragma unroll
-        for (int sl = 0; sl < NS; sl += 2) {
-            if (sl + 1 < NS) y = ld(lp, lpb, sl + 1);
-            asm volatile("" ::: "memory");
-            facc[sl] = mm(x, facc[sl], first);
-            if (sl + 2 < NS) x = ld(lp, lpb, sl + 2);
-            asm volatile("" ::: "memory");
-            if (sl + 1 < NS) facc[sl + 1] = mm(y, facc[sl + 1], first);
-        }
-        asm volatile("" ::: "memory");
-    };
-#pragma unroll
-    for (int s0 = 0; s0 < CFG::DEPTH; ++s0) issue2(s0);
-    for (int step = 0; step < nstep; step += 2) {
-        body(step, std::true_type{});
-        body(step + 1, std::false_type{});
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {                           // fold the 64-frame fp32 sums into the fp64 shadows
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[sl][r] += (double)facc[sl][r];
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int fl = w.lane & 15;
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-        if (sl < w.ns) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = (w.lane >> 4) * 4 + r;
-                w.out[(int64_t)(ti[sl] * 16 + rr) * BLKPX + tj[sl] * 16 + fl] = acc[sl][r];
-            }
-        }
-}
-
-template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, int64_t Tpad, const int4 *__restrict__ pairs,
                                                   const int *__restrict__ work, int nwork, const int *__restrict__ tl_cnt,
-                                                  const int *__restrict__ tl, int flush_every, double *__restrict__ cov) {
+                                                  const int *__restrict__ tl, int probe, double *__restrict__ cov) {
     extern __shared__ __attribute__((aligned(16))) float smem[];       // the ONLY LDS object (a second one de-pipelines the DMA)
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -398,23 +221,12 @@ __global__ void __launch_bounds__(256, 2) k_gram4(const float *__restrict__ bf, 
     w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
     w.dA0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem + (unsigned)wave * 1024u;
     w.lbase = (lane >> 4) * 512 + (lane & 15) * 4;                     // quad-row l>>4, pixel l&15 of the tile, 4 frames
-    if (MODE >= 2) {
-        // split-bf16 layout: a 16-frame stage of a half is [8-frame row e][plane hi/lo][128 px] x 16 B = 8 instructions of 1 KB;
-        // wave w moves instruction w (row 0: plane (w>>1)&1, pixels (w&1)*64..) and w+4 (row 1).  Lane group l>>4 reads 8-frame row
-        // (l>>4)&1 of stage (l>>4)>>1 of the step.
-        w.vo0 = (unsigned)((((((wave >> 1) & 1) * BLKPX) + (wave & 1) * 64 + lane) * 4) * 4);
-        w.vo1 = w.vo0 + 2u * BLKPX * 4u * 4u;
-        w.lbase = (lane >> 5) * G4_STAGE_F + ((lane >> 4) & 1) * 1024 + (lane & 15) * 4;
-        w.lbaseB = w.lbase + GK * 128;
-    }
-    w.nst = (int)(Tpad / GK); w.flush_every = flush_every; w.lane = lane;
-    const int nsmax = (cnt + 3) >> 2;
-    if (MODE >= 2) { const int lo_ = wave * nsmax; w.ns = cnt > lo_ ? (cnt - lo_ < nsmax ? cnt - lo_ : nsmax) : 0; }   // tiles [wave*nsmax, ...): a contiguous run
-    else w.ns = cnt > wave ? (cnt - wave + 3) >> 2 : 0;                // tiles wave, wave+4, ...
+    w.nst = (int)(Tpad / GK); w.probe = probe; w.lane = lane;
+    w.ns = cnt > wave ? (cnt - wave + 3) >> 2 : 0;                     // tiles wave, wave+4, ...
     w.out = cov + (int64_t)pair * BLKPX * BLKPX + (int64_t)(ih * 128) * BLKPX + jh * 128;
-    const int *tlw = MODE >= 2 ? tl + lidx * 64 + wave * nsmax : tl + lidx * 64 + wave;
+    const int *tlw = tl + lidx * 64 + wave;
     switch ((cnt + 3) >> 2) {                                          // slots of the busiest wave; the others skip the last one
-#define G4_CASE(N) case N: if (MODE == 2) gram4_run_k32<G4Quad, N>(w, smem, tlw); else gram4_run<MODE >= 2 ? 1 : MODE, N>(w, smem, tlw); break;
+#define G4_CASE(N) case N: gram4_run<N>(w, smem, tlw); break;
         G4_CASE(1) G4_CASE(2) G4_CASE(3) G4_CASE(4) G4_CASE(5) G4_CASE(6) G4_CASE(7) G4_CASE(8)
         G4_CASE(9) G4_CASE(10) G4_CASE(11) G4_CASE(12) G4_CASE(13) G4_CASE(14) G4_CASE(15) G4_CASE(16)
 #undef G4_CASE
@@ -982,11 +794,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
     if (build_base) P->sys_valid = false;
     ht.mark("footprint block lists");
-    g.bf4 = incr || outl ? 1 : (ctx->opt("gram_mode", 3) >= 3 ? 2 : 1);   // gram_mode 3: split bf16
-    // round 5 (gram_i8.hpp): the VIDEO's table on the int8 matrix pipe, exact up to a 32-bit quantisation of the data (option gram_i8, default 1; int32 range: <= 24576 frames)
-    const bool use_i8 = build_base && !outl && ctx->opt("gram_i8", 1) != 0 && g.Tp <= 24576;
+    g.bf4 = 1;
+    // round 5 (gram_i8.hpp): the Gram -- the VIDEO's table of the incremental path, or the direct Gram of Bf where that path does not apply -- on the int8 matrix
+    // pipe, exact up to a 32-bit quantisation of the data (option gram_i8, default 1; int32 range: <= 24576 used frames).  The outlier branch (a clipped,
+    // frame-selected Bf) keeps the fp64 kernel.
+    const bool use_i8 = (build_base || !incr) && !outl && ctx->opt("gram_i8", 1) != 0 && g.Tp <= 24576;
     if (use_i8) g.bf4 = 3;
-    g.Tpad = g.bf4 >= 2 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // split-bf16: pairs of steps of two stages; int8: steps of four
+    g.Tpad = g.bf4 == 3 ? (g.Tp + 4 * GK - 1) / (4 * GK) * (4 * GK) : (g.Tp + GK - 1) / GK * GK;   // int8: steps of four 16-frame stages
     const int nblk = g.nbr * g.nbc;
 
     // ---- the window projection first: it needs the footprint lists and the traces, nothing else, and takes 5 ms at the headline size -- the host
@@ -1167,7 +981,6 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         ht.mark("tile lists + uploads (sync)");
         // incremental: the table of the video alone is built once (fp64 pipe) and kept with the patch; later fits skip B1 / B2a entirely
         DevBuf &covT = incr ? P->cov_base : ctx->cov, &rsT = incr ? P->rowsum_base : ctx->rowsum;
-        const bool f32s = !incr && !outl && ctx->opt("gram_mode", 3) >= 2;     // outlier branch: exact fp64 products of the fp32 Bf
         const bool has_a_bf = has_a && !incr;
         if (incr) {
             RET(P->cov_base.ensure((size_t)npairs * BLKPX * BLKPX * sizeof(double)));
@@ -1179,13 +992,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 7) & ~int64_t(7));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
         RET(rsT.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        if (g.bf4 >= 2) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->st()));
+        if (g.bf4 == 3) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->st()));
         uint4 *digp = nullptr; double *digs = nullptr;          // where the digit planes of this build live
         if (use_i8) {
-            // resident with the patch (the fits' window projection reads them, win_proj_i8.hpp) when one more video's worth of memory leaves 8 GB free and the
-            // stride is 1; otherwise in the context's scratch like Bf
+            // the VIDEO's planes stay resident with the patch (the fits' window projection reads them, win_proj_i8.hpp) when one more video's worth of memory
+            // leaves 8 GB free and the stride is 1; otherwise, and for the direct Gram of Bf, in the context's scratch
             const size_t dbytes = (size_t)nblk * g.Tpad * BLKPX * sizeof(float);
-            bool resident = kstride == 1 && !P->derived && ctx->opt("win_i8", 1) != 0;
+            bool resident = incr && kstride == 1 && !P->derived && ctx->opt("win_i8", 1) != 0;
             if (resident && P->dig.cap < dbytes) {
                 size_t fr = 0, tot = 0;
                 CK(hipMemGetInfo(&fr, &tot));
@@ -1199,10 +1012,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 RET(ctx->dig_scale.ensure((size_t)nblk * BLKPX * sizeof(double)));
                 digp = ctx->bf.as<uint4>(); digs = ctx->dig_scale.as<double>();
             }
+            RET(ctx->dig_smax.ensure((size_t)nblk * BLKPX * sizeof(unsigned)));
+            CK(hipMemsetAsync(ctx->dig_smax.p, 0, (size_t)nblk * BLKPX * sizeof(unsigned), ctx->st()));
+            DigA da{has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc};
             const int tchunk16 = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 15) & ~int64_t(15));
-            LAUNCH(ctx, "bg_dig_scale", k_dig_scale, dim3(nblk), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, digs);
-            LAUNCH(ctx, "bg_build_dig", k_build_dig, dim3(nblk, (unsigned)((g.Tpad + tchunk16 - 1) / tchunk16)), dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
-                   digs, digp, tchunk16, rsT.as<double>());
+            const dim3 gd(nblk, (unsigned)((g.Tpad + tchunk16 - 1) / tchunk16));
+            LAUNCH(ctx, "bg_dig_scale", k_dig_scale, gd, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, da, tchunk16, ctx->dig_smax.as<unsigned>());
+            LAUNCH(ctx, "bg_build_dig", k_build_dig, gd, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, da, ctx->dig_smax.as<unsigned>(), digs, digp, tchunk16, rsT.as<double>());
         } else
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());
@@ -1240,26 +1056,17 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             const size_t shmem = (size_t)G4_NBUF * G4_STAGE_F * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
-                CK(hipFuncSetAttribute((const void *)k_gram4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                CK(hipFuncSetAttribute((const void *)k_gram4<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                CK(hipFuncSetAttribute((const void *)k_gram4<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                CK(hipFuncSetAttribute((const void *)k_gram4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                 attr4 = true;
             }
-            const int flushw = (int)ctx->opt("gram_flush", 4) | ((int)ctx->opt("gram_probe", 0) << 16);
             if (use_i8) {
                 static bool attr8 = false;
                 if (!attr8) { CK(hipFuncSetAttribute((const void *)k_gram_i8, hipFuncAttributeMaxDynamicSharedMemorySize, GI_NBUF * GI_STAGE_B)); attr8 = true; }
                 LAUNCH(ctx, "bg_gram_i8", k_gram_i8, dim3(nwg), dim3(512), (size_t)GI_NBUF * GI_STAGE_B, digp, g.Tpad >> 4, dPairs.as<int4>(), dWork.as<int>(), nwork,
                        dTcnt.as<int>(), dTl.as<int>(), digs, covT.as<double>());
-            } else if (g.bf4 == 2)
-                LAUNCH(ctx, "bg_gram_bf16x4", k_gram4<2>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
-            else if (f32s)
-                LAUNCH(ctx, "bg_gram_f32s", k_gram4<1>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), flushw, covT.as<double>());
-            else
-                LAUNCH(ctx, "bg_gram_f64", k_gram4<0>, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), 0, covT.as<double>());
+            } else
+                LAUNCH(ctx, "bg_gram_f64", k_gram4, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
+                       dTcnt.as<int>(), dTl.as<int>(), (int)ctx->opt("gram_probe", 0), covT.as<double>());
         }
         if (incr) { P->base_valid = true; P->base_kstride = kstride; }
         }

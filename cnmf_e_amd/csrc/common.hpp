@@ -282,6 +282,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf bgs_r, bgs_b, bgs_upr, bgs_upc;   // bg_ssub > 1, reconstruct_background / compute_RSS: R_low, W*R_low, replication maps
     int bgs_patch = -1, bgs_d1s = 0; int64_t bgs_dF = 0;   // the patch bgs_b belongs to (cnmfe_background_ssub)
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
+    cnmfe::DevBuf dig_smax;   // gram_i8.hpp: per block-region pixel max |Bf| (float bits) of the build in flight
     cnmfe::DevBuf dig_scale;  // gram_i8.hpp: per block-region pixel the scale of its 32-bit fixed-point trace (the int8-digit table build)
     cnmfe::DevBuf tdig, tscale, gk, win_items;   // win_proj_i8.hpp: digit planes / scales of the centred traces, their K x K Gram matrix, the (block, trace group) work items
     cnmfe::DevBuf bf2, outl_cnt, outl_sel;   // outlier branch of the ring fit: clipped copy of bf, outliers per frame, kept frames

@@ -1,4 +1,4 @@
-// B2a, round 5: the covariance table of the VIDEO on the int8 matrix pipe -- exactly.
+// B2a, round 5: the covariance table of the VIDEO (and the direct Gram of Bf, the fallback) on the int8 matrix pipe -- exactly.
 //
 // The table  cov(a, b) = sum_t Yc_a(t) Yc_b(t)  is built once per recording (and frame stride) and was the cold path's largest item: 172 ms of fp64 MFMAs at
 // 512 x 512 x 10000 (k_gram4<0>, 0.7 of the fp64 matrix peak).  Its consumers need ~1e-10 relative accuracy (the ridge systems have condition numbers of 1e4-1e5:
@@ -20,70 +20,85 @@ namespace cnmfe {
 
 typedef int int4v_t __attribute__((ext_vector_type(4)));
 
-// scale[blk * 256 + lp] = max over the used frames of |Yc| / (2^31 - 2^24)   (1 for an all-zero or out-of-region pixel)
-__global__ void __launch_bounds__(256) k_dig_scale(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, double *__restrict__ scale) {
+// 16 consecutive used frames tp .. tp + 15 of Bf = Yc - A (C - mean C) for block-region pixel q (arow == nullptr: the centred video itself); zero outside the block
+// region and behind the last used frame.  Same fp32 arithmetic as k_build_bf (bg.hip).
+struct DigA { const int *arow, *acol; const float *aval, *Cc; int64_t ldc; };
+__device__ __forceinline__ void dig_frames16(const float4 *__restrict__ Y4, int64_t Tc, const BgGeom &g, bool in, int64_t q, int64_t tp, int e0, int e1, const DigA &A, float (&x)[16]) {
+    if (g.kstride == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = (tp >> 2) + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in && c < Tc) {
+                v = Y4[c * g.d_b + q];
+                for (int e = e0; e < e1; ++e) {
+                    const float av = A.aval[e];
+                    const float4 c4 = *reinterpret_cast<const float4 *>(A.Cc + (int64_t)A.acol[e] * A.ldc + 4 * c);
+                    v.x -= av * c4.x; v.y -= av * c4.y; v.z -= av * c4.z; v.w -= av * c4.w;
+                }
+            }
+            const int64_t t0 = tp + 4 * j;                         // (frames behind the last used one count as 0 whatever the chunk's padding holds)
+            x[4 * j] = t0 < g.Tp ? v.x : 0.f; x[4 * j + 1] = t0 + 1 < g.Tp ? v.y : 0.f; x[4 * j + 2] = t0 + 2 < g.Tp ? v.z : 0.f; x[4 * j + 3] = t0 + 3 < g.Tp ? v.w : 0.f;
+        }
+    } else {
+        const float *Ys = reinterpret_cast<const float *>(Y4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = 0.f;
+            if (in && tp + j < g.Tp) {
+                const int64_t t = (tp + j) * g.kstride;            // frame subsampling Bf(:, 1:k:end)  (fit_ring_model.m:87)
+                v = Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)];
+                for (int e = e0; e < e1; ++e) v -= A.aval[e] * A.Cc[(int64_t)A.acol[e] * A.ldc + t];
+            }
+            x[j] = v;
+        }
+    }
+}
+
+// smax[blk * 256 + lp] = max over the used frames of |Bf| (as the bits of a non-negative float: atomicMax over the frame chunks of the grid; zeroed by the caller)
+__global__ void __launch_bounds__(256) k_dig_scale(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, DigA A, int tchunk, unsigned *__restrict__ smax) {
     const int blk = blockIdx.x, bi = blk % g.nbr, bj = blk / g.nbr, lp = threadIdx.x;
     const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
     const int rb = bi * BLK + lr, cb = bj * BLK + lc;
+    const bool in = rb < g.nr_b && cb < g.nc_b;
+    if (!in) return;
+    const int64_t q = (int64_t)cb * g.nr_b + rb;
+    int e0 = 0, e1 = 0;
+    if (A.arow) { e0 = A.arow[q]; e1 = A.arow[q + 1]; }
+    const int64_t tp0 = (int64_t)blockIdx.y * tchunk, tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
     float m = 0.f;
-    if (rb < g.nr_b && cb < g.nc_b) {
-        const int64_t q = (int64_t)cb * g.nr_b + rb;
-        if (g.kstride == 1) {
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-            int64_t c = 0;
-            for (; c + 4 < Tc; c += 4) {
-                const float4 v0 = Y4[c * g.d_b + q], v1 = Y4[(c + 1) * g.d_b + q], v2 = Y4[(c + 2) * g.d_b + q], v3 = Y4[(c + 3) * g.d_b + q];
-                m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
-                m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
-                m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))));
-                m3 = fmaxf(m3, fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w))));
-            }
-            for (; c < Tc; ++c) {
-                const float4 v = Y4[c * g.d_b + q];
-                const int64_t t0 = 4 * c;                               // (the last chunk: only the used frames)
-                m0 = fmaxf(m0, fmaxf(fmaxf(t0 < g.Tp ? fabsf(v.x) : 0.f, t0 + 1 < g.Tp ? fabsf(v.y) : 0.f), fmaxf(t0 + 2 < g.Tp ? fabsf(v.z) : 0.f, t0 + 3 < g.Tp ? fabsf(v.w) : 0.f)));
-            }
-            m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        } else {
-            const float *Ys = reinterpret_cast<const float *>(Y4);
-            for (int64_t tp = 0; tp < g.Tp; ++tp) { const int64_t t = tp * g.kstride; m = fmaxf(m, fabsf(Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)])); }
-        }
+    for (int64_t tp = tp0; tp < tp1; tp += 16) {
+        float x[16];
+        dig_frames16(Y4, Tc, g, in, q, tp, e0, e1, A, x);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(x[j]));
     }
-    scale[(int64_t)blk * BLKPX + lp] = m > 0.f ? (double)m / 2130706432.0 : 1.0;       // 2^31 - 2^24
+    atomicMax(&smax[(int64_t)blk * BLKPX + lp], __float_as_uint(m));
 }
 
-// digit planes dig[((blk * T16 + s) * 4 + plane) * 256 + lp] (16 bytes = the digits of frames 16 s .. 16 s + 15, zero behind the used frames); rs += the exact
-// row sums of the fp32 values (the ones row of the regression: not quantised)
-__global__ void __launch_bounds__(256) k_build_dig(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, const double *__restrict__ scale, uint4 *__restrict__ dig,
-                                                   int tchunk, double *__restrict__ rs) {
+// digit planes dig[((blk * T16 + s) * 4 + plane) * 256 + lp] (16 bytes = the digits of frames 16 s .. 16 s + 15, zero behind the used frames); scale = the pixel's
+// smax / (2^31 - 2^24) (1 for an all-zero or out-of-region pixel), written by the first frame chunk; rs += the exact row sums of the fp32 values (the ones row of
+// the regression: not quantised)
+__global__ void __launch_bounds__(256) k_build_dig(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, DigA A, const unsigned *__restrict__ smax, double *__restrict__ scale,
+                                                   uint4 *__restrict__ dig, int tchunk, double *__restrict__ rs) {
     const int blk = blockIdx.x, bi = blk % g.nbr, bj = blk / g.nbr, lp = threadIdx.x;
     const int lr = ((lp >> 4) & 3) * 4 + (lp & 3), lc = (lp >> 6) * 4 + ((lp >> 2) & 3);
     const int rb = bi * BLK + lr, cb = bj * BLK + lc;
     const bool in = rb < g.nr_b && cb < g.nc_b;
     const int64_t q = in ? (int64_t)cb * g.nr_b + rb : 0;
-    const double inv = 1.0 / scale[(int64_t)blk * BLKPX + lp];
+    int e0 = 0, e1 = 0;
+    if (in && A.arow) { e0 = A.arow[q]; e1 = A.arow[q + 1]; }
+    const float mx = __uint_as_float(smax[(int64_t)blk * BLKPX + lp]);
+    const double sc = mx > 0.f ? (double)mx / 2130706432.0 : 1.0;          // 2^31 - 2^24
+    if (blockIdx.y == 0) scale[(int64_t)blk * BLKPX + lp] = sc;
+    const double inv = 1.0 / sc;
     const int64_t tp0 = (int64_t)blockIdx.y * tchunk;          // tchunk is a multiple of 16
     const int64_t tp1 = tp0 + tchunk < g.Tpad ? tp0 + tchunk : g.Tpad;
     const int64_t T16 = g.Tpad >> 4;
-    const float *Ys = reinterpret_cast<const float *>(Y4);
     double rsum = 0.0;
     for (int64_t tp = tp0; tp < tp1; tp += 16) {
         float x[16];
-        if (g.kstride == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t c = (tp >> 2) + j;
-                const float4 v = (in && c < Tc) ? Y4[c * g.d_b + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int64_t t0 = tp + 4 * j;                         // (frames behind the last used one count as 0 whatever the chunk's padding holds)
-                x[4 * j] = t0 < g.Tp ? v.x : 0.f; x[4 * j + 1] = t0 + 1 < g.Tp ? v.y : 0.f; x[4 * j + 2] = t0 + 2 < g.Tp ? v.z : 0.f; x[4 * j + 3] = t0 + 3 < g.Tp ? v.w : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int64_t t = (tp + j) * g.kstride;
-                x[j] = (in && tp + j < g.Tp) ? Ys[((t >> 2) * g.d_b + q) * 4 + (t & 3)] : 0.f;
-            }
-        }
+        dig_frames16(Y4, Tc, g, in, q, tp, e0, e1, A, x);
         unsigned pl[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)

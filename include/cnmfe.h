@@ -394,13 +394,18 @@ int cnmfe_profile_count(cnmfe_ctx *ctx);
 int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *calls);
 int cnmfe_synchronize(cnmfe_ctx *ctx);
 /* tunables for A/B runs; unknown names -> CNMFE_EINVAL.  r1_variant (R1 kernel), r1_delta / r1_lazy / r1_defer (incremental residual, see
- * cnmfe_residual), gram_incremental (see cnmfe_fit_ring_model), gram_mode 1 | 2 | 3 = fp64 | fp32 | split-bf16 matrix pipe for the direct
- * Gram, gram_flush, tile_order, debug (1: NaN-poison never-computed table entries), *_probe (timing experiments); round 4: r1_virtual (default 1: a
- * cnmfe_residual without an output buffer records its request and the two updates project the centred video instead of a swept Ysig; 0 restores the sweep),
- * solve_packed (default 1: the ring solve reads per-pixel packed copies of the video's normal equations -- 43 KB per patch pixel at 96 ring offsets, allocated
- * when that much + 8 GB is free -- and applies the footprints' corrections in registers; 0: the block-pair table is swept and gathered from, as before),
- * solve_defer (1: the ring solve in two halves, measured slower: off), prealloc, host_trace (1: host-side phase times of every call on stderr, 2: + slow launch
- * calls).  Every option can be preset for a process with CNMFE_OPTS="name=value,...". */
+ * cnmfe_residual), gram_incremental (see cnmfe_fit_ring_model), tile_order, debug (1: NaN-poison never-computed table entries), *_probe (timing experiments);
+ * round 4: r1_virtual (default 1: a cnmfe_residual without an output buffer records its request and the two updates project the centred video instead of a swept
+ * Ysig; 0 restores the sweep), solve_packed (default 1: the ring solve reads per-pixel packed copies of the video's normal equations -- 43 KB per patch pixel at 96
+ * ring offsets, allocated when that much + 8 GB is free -- and applies the footprints' corrections in registers; 0: the block-pair table is swept and gathered
+ * from, as before), prealloc, host_trace (1: host-side phase times of every call on stderr, 2: + slow launch calls);
+ * round 5: gram_i8 (default 1: the covariance table of the video -- and the direct Gram of the fallback -- on the int8 matrix pipe from 32-bit fixed-point digit
+ * planes, exact int32 accumulation, up to 24576 used frames; 0: the fp64 matrix pipe), win_i8 (default 1: the digit planes stay resident -- one more video's worth
+ * of memory, taken only when that leaves 8 GB free -- and every fit's window projection runs on the int8 pipe; 0: the fp64 kernel on the centred video),
+ * proj_tiled (default 1: the temporal projection reads a copy of the centred video in its own read order -- again one video's worth, same rule; 0: the frame-major
+ * video).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
+ * accepted and ignored: gram_mode, gram_flush, solve_defer and the experiment switches of rounds 2-3.
+ * Every option can be preset for a process with CNMFE_OPTS="name=value,..." (logged once on stderr). */
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

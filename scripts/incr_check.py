@@ -19,7 +19,7 @@ A0 = f.A_init.astype(np.float32)
 rng = np.random.default_rng(0)
 cases = [(A0, f.C_init), (A0 * 0.9, (f.C_init * 1.1).astype(np.float32)), (A0[:, :300].tocsc(), np.ascontiguousarray(f.C_init[:300]))]
 res = {}
-for name, opts in (("direct fp64", dict(gram_incremental=0, gram_mode=1)), ("direct bf16x4", dict(gram_incremental=0, gram_mode=3)), ("incremental", dict(gram_incremental=1, gram_mode=3))):
+for name, opts in (("direct fp64", dict(gram_incremental=0, gram_i8=0)), ("direct int8 digits", dict(gram_incremental=0, gram_i8=1)), ("incremental", dict(gram_incremental=1, gram_i8=1))):
     for k, v in opts.items(): eng.set_option(k, v)
     eng.ring_init(0, r)
     out = []

@@ -286,7 +286,7 @@ def test_incremental_gram_equals_direct_fp64(eng, T, r):
     Cm = np.ascontiguousarray(f.C_init, dtype=np.float32)
     seq = [(A, Cm), (A * 0.8, Cm * 1.2), (None, None), (A[:, :2].tocsc(), Cm[:2]), (A, Cm)]
     def run(incr):
-        eng.set_option("gram_incremental", incr); eng.set_option("gram_mode", 3 if incr else 1)
+        eng.set_option("gram_incremental", incr); eng.set_option("gram_i8", 1 if incr else 0)      # (the reference: the direct Gram on the fp64 pipe)
         eng.ring_init(0, r)
         out = []
         for Ai, Ci in seq:
@@ -304,7 +304,7 @@ def test_incremental_gram_equals_direct_fp64(eng, T, r):
         if T > 9000:
             assert max(k for _, _, k in inc) == 2
     finally:
-        eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
+        eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_i8", 1)
 
 
 def test_bound_rows_equal_uploaded_rows(eng):
@@ -408,7 +408,7 @@ def test_ring_change_rebuilds_the_kept_table(eng):
     try:
         out = {}
         for incr in (0, 1):
-            eng.set_option("gram_incremental", incr); eng.set_option("gram_mode", 3 if incr else 1)
+            eng.set_option("gram_incremental", incr); eng.set_option("gram_i8", 1 if incr else 0)      # (the reference: the direct Gram on the fp64 pipe)
             res = []
             for r_, nn in ((5, None), (8, None), (8, 20), (5, None)):
                 eng.ring_init(0, r_, nn) if nn else eng.ring_init(0, r_)
@@ -420,7 +420,7 @@ def test_ring_change_rebuilds_the_kept_table(eng):
         for a, b in zip(out[0], out[1]):
             assert a.shape == b.shape and np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
     finally:
-        eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
+        eng.set_option("debug", 0); eng.set_option("gram_incremental", 1); eng.set_option("gram_i8", 1)
 
 
 def _ar1_traces(K, T, g=0.95, sn=0.3, seed=5, rate=0.01, amp=1.5):
@@ -882,7 +882,7 @@ def test_two_frame_strides_keep_their_tables(eng):
     out = {}
     try:
         for incr in (0, 1):
-            eng.set_option("gram_incremental", incr); eng.set_option("gram_mode", 3 if incr else 1)
+            eng.set_option("gram_incremental", incr); eng.set_option("gram_i8", 1 if incr else 0)      # (the reference: the direct Gram on the fp64 pipe)
             eng.profile(True); eng.profile_reset()
             res = []
             for npos, stride in ((6, 2), (12, 1), (6, 2)):
@@ -898,7 +898,7 @@ def test_two_frame_strides_keep_their_tables(eng):
         for a, b in zip(out[0], out[1]):
             assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
     finally:
-        eng.set_option("gram_incremental", 1); eng.set_option("gram_mode", 3)
+        eng.set_option("gram_incremental", 1); eng.set_option("gram_i8", 1)
 
 
 @pytest.mark.parametrize("deconv", [False, True])

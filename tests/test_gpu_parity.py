@@ -285,13 +285,14 @@ def test_method_level_iteration_parity(eng, alg):
         assert np.allclose(s.b0_new, o.b0_new, rtol=1e-6, atol=2e-4)
 
 
-@pytest.mark.parametrize("gram_mode", [1, 2, 3, 0])
-def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
-    """gram_mode 1 = fp64 matrix pipe, 2 = fp32 pipe with fp64 shadow accumulation, 3 = split bf16 (all three: the direct Gram of Bf,
-    gram_incremental = 0); 0 here = the default incremental path (table of the video + footprint corrections).  debug=1 NaN-poisons the
-    covariance table so that a lookup into a pruned (never computed) sub-tile cannot go unnoticed."""
+@pytest.mark.parametrize("incr,i8", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_fit_ring_gram_modes_and_pruning(eng, incr, i8):
+    """the Gram behind the regression: gram_incremental = 0 -> the direct Gram of Bf, 1 (default) -> the table of the video + footprint corrections; gram_i8 = 0 ->
+    the fp64 matrix pipe, 1 (default) -> the int8 pipe on 32-bit fixed-point digits (gram_i8.hpp).  All four against the float64 oracle under ONE tolerance
+    (the fp32 / split-bf16 modes of rounds 1-4, 2e-4, are retired).  debug=1 NaN-poisons the covariance table so that a lookup into a pruned (never computed)
+    sub-tile cannot go unnoticed."""
     c = Case(eng, 70, 66, 160, 5, 15, 19, [35, 33])
-    eng.set_option("debug", 1); eng.set_option("gram_mode", gram_mode or 3); eng.set_option("gram_incremental", 0 if gram_mode else 1)
+    eng.set_option("debug", 1); eng.set_option("gram_i8", i8); eng.set_option("gram_incremental", incr)
     try:
         for idx in c.video.owned:
             pid = c.video.pid[idx]
@@ -304,9 +305,9 @@ def test_fit_ring_gram_modes_and_pruning(eng, gram_mode):
             W = eng.ring_csr(pid)
             assert np.all(np.isfinite(W.data))
             Wref = Wref.tocsr(); Wref.sort_indices()
-            assert rel(W.data, Wref.data) <= (2e-6 if gram_mode <= 1 else 2e-4), rel(W.data, Wref.data)
+            assert rel(W.data, Wref.data) <= 2e-6, rel(W.data, Wref.data)
     finally:
-        eng.set_option("debug", 0); eng.set_option("gram_mode", 3); eng.set_option("gram_incremental", 1)
+        eng.set_option("debug", 0); eng.set_option("gram_i8", 1); eng.set_option("gram_incremental", 1)
 
 
 def _deconv_case(eng, T=1500, K=5):
