@@ -30,7 +30,7 @@ for name, opts in (("direct fp64", dict(gram_incremental=0, gram_i8=0)), ("direc
         out.append(eng.ring_csr(0).data.astype(np.float64))
         print("%-14s fit %d: %s  %s" % (name, ci, {k: round(v["total_ms"], 2) for k, v in tab.items() if k.startswith("bg_") and v["total_ms"] > 0.05}, info), flush=True)
     res[name] = out
-for name in ("direct bf16x4", "incremental"):
+for name in ("direct int8 digits", "incremental"):
     for ci in range(len(cases)):
         a, b = res[name][ci], res["direct fp64"][ci]
         print("%-14s fit %d vs direct fp64: rel %.3e  max abs %.3e" % (name, ci, np.linalg.norm(a - b) / np.linalg.norm(b), np.abs(a - b).max()))
