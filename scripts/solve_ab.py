@@ -28,7 +28,7 @@ for mode in [int(x) for x in a.modes.split(",")]:
         eng.ring_init(0, r)
         eng.set_option("solve_probe", probe)
         try: eng.set_option("solve_variant", mode)          # (only builds with scripts/probes/solve_r5/variants.patch applied know the option)
-        except Exception: pass
+        except Exception: eng.set_option("solve_pair", mode)  # the shipped build: 0 one pixel per wave (k_ring_solve6), 1 two (k_ring_solve_pair)
         ts = []
         for rep in range(a.reps):
             eng.ring_init(0, r); eng.profile_reset()
@@ -36,7 +36,7 @@ for mode in [int(x) for x in a.modes.split(",")]:
             eng.synchronize()
             tab = eng.profile_table()
             ts.append(tab["bg_ring_solve"]["total_ms"] / tab["bg_ring_solve"]["calls"])
-        print("solve_variant %d probe %d: bg_ring_solve %s ms   (%s)" % (mode, probe, " ".join("%.3f" % t for t in ts), info), flush=True)
+        print("mode %d probe %d: bg_ring_solve %s ms   (%s)" % (mode, probe, " ".join("%.3f" % t for t in ts), info), flush=True)
         if probe == 0:
             Ws[mode] = eng.ring_csr(0).data.copy()
 ks = list(Ws)
