@@ -16,6 +16,15 @@
 
 namespace cnmfe {
 
+// a 16-byte load of data that is read ONCE per pass (the digit planes of the video in k_win_proj_i8): non-temporal, so the stream does not evict the trace planes every
+// workgroup re-reads (1.97 -> 1.94 ms at H, three runs each on one lease; the fp32 stream of k_vp_proj_b showed no difference and keeps plain loads)
+typedef unsigned nt_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
+    const nt_u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+
 extern thread_local char g_err[1024];
 inline int fail(int code, const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);

@@ -127,7 +127,7 @@ __device__ __forceinline__ void win_body_i8(const uint4 *__restrict__ dig, int64
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { const uint4 u = vp[a][(s16 * 4 + p) * BLKPX]; f.v[a][p] = (int4v_t){(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+            for (int p = 0; p < 4; ++p) { const uint4 u = ld_stream(vp[a] + (s16 * 4 + p) * BLKPX); f.v[a][p] = (int4v_t){(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
 #pragma unroll
         for (int b = 0; b < NTG; ++b)
 #pragma unroll
