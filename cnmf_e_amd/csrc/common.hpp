@@ -193,6 +193,15 @@ struct Patch {
     // (win_proj_i8.hpp) when the memory allows: frame stride 1 only
     DevBuf dig, dig_sc; int64_t dig_T16 = 0; bool dig_valid = false;
     DevBuf yt4; bool yt4_valid = false;                   // vproj.hip: the centred video tiled by 16 x 16 block (k_tile_video), for the temporal projection
+    // bg_ssub > 1 (ssub.hip, round 5: the sweep-free residual of res_kind 2): the low-resolution residual patch and the factor of the last cnmfe_residual_ssub, and
+    // imresize's bicubic UPSAMPLING taps of the block region's rows / columns (low-resolution index + weight, ss_Pr / ss_Pc per row / column) on the host and the
+    // device, their ranges per row / column (made monotone: ss_rlo[r] <= every tap index of the rows >= r, ss_rhi[r] >= those of the rows <= r), and the
+    // TRANSPOSED taps (per low-resolution row / column the block-region rows / columns it feeds, CSR) for up' A of the temporal projection
+    int ss_res = -1, ss_ssub = 0, ss_Pr = 0, ss_Pc = 0, ss_d1s = 0, ss_d2s = 0;
+    bool ss_taps = false;
+    std::vector<int> ss_tr_idx, ss_tc_idx, ss_rlo, ss_rhi, ss_clo, ss_chi, ss_trp_h, ss_tri_h, ss_tcp_h, ss_tci_h;
+    std::vector<float> ss_tr_w, ss_tc_w;
+    DevBuf ss_ir, ss_wr, ss_ic, ss_wc, ss_trp, ss_tri, ss_trw, ss_tcp, ss_tci, ss_tcw, ss_dlt;
     // what the next fit asks of W before it can queue anything (pmax of fit_ring_model.m:60, row 1 for the first-run test of :25), copied to
     // pinned memory behind the fit that produced W: the next fit reads it without draining the stream (ring_stats_*, api.hip)
     DevBuf stat_dev; void *stat_host = nullptr; hipEvent_t stat_ev = nullptr; bool stat_valid = false;
@@ -283,8 +292,8 @@ struct cnmfe_ctx {
     cnmfe::DevBuf bound;      // trace matrix bound with cnmfe_traces_bind (K x ldc fp32), passed as c_order = CNMFE_BOUND
     int32_t bound_K = 0; int64_t bound_T = 0; int bound_order = 1; bool bound_valid = false;
     int64_t bound_gen = 0;    // counts the changes of the bound matrix' CONTENT (cnmfe_traces_bind, the stitch, deconvTemporal on it): what a table derived from its rows is valid for
-    cnmfe::DevBuf vp[16];     // scratch of the sweep-free projections (vproj.hip)
-    size_t hw_vp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    cnmfe::DevBuf vp[32];     // scratch of the sweep-free projections (vproj.hip; [16..]: the bg_ssub > 1 forms)
+    size_t hw_vp[32] = {};
     int64_t last_ldc = 0;     // row stride of the centred traces the last residual_run left in tmp[1]
     cnmfe::DevBuf ysig_low;   // bg_ssub > 1: residual sweep of the low-resolution patch
     cnmfe::DevBuf up_tmp;     // bg_ssub > 1: column-upsampled W*(...) (low rows x block columns)
@@ -374,10 +383,18 @@ int residual_realize(cnmfe_ctx *ctx, Patch *P);           // a virtual residual 
 // rows of the bound trace matrix a (C, c_order) argument names: false when it is some other matrix
 bool bound_rows_of(const cnmfe_ctx *ctx, const float *C, int c_order, int32_t K, std::vector<int32_t> &rows);
 // vproj.hip -- the projections of a virtual residual.  Return 1 when they cannot serve the request (the caller realizes the residual and projects Ysig).
+// (dQ != nullptr: instead of U, the ring sums sum_i W(m,i) P(m + o_i, k) of the mask's entries in fp64 -- what the bg_ssub form upsamples)
 int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
-                  const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU);
+                  const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU, double *dQ = nullptr);
 int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                    const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu);
+// the same for a residual of cnmfe_residual_ssub (res_kind 2): through the resampling maps, DESIGN.md section 3 bg_ssub
+int vproj_spatial_ssub(cnmfe_ctx *ctx, Patch *M, int32_t K, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                       const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU);
+int vproj_temporal_ssub(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                        const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu);
+int ssub_taps(cnmfe_ctx *ctx, Patch *M, const Patch *R);  // ssub.hip: the upsampling taps of M's block region from R's grid, host + device (once per patch)
+int ssub_realize(cnmfe_ctx *ctx, Patch *M);               // ssub.hip: the low-resolution sweep + upsample behind a virtual residual of res_kind 2
 int residual_term_project(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu, int *dOverflow);   // 1: cannot be applied, materialise instead; *dOverflow set on the device if a footprint meets > 512 traces
 bool residual_term_foldable_spatial(const Patch *P, int32_t K, int64_t ldc);   // the pending term can enter the spatial update through its projection (no pass over Ysig)
 int residual_term_fold_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, int64_t nnz, const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU, DevBuf &dG);

@@ -534,7 +534,8 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
     // runs now and Ysig is projected as before
     bool virt = P->ysig_virtual;
     if (virt) {
-        const int rcv = vproj_spatial(ctx, P, K, C, c_order, IND_colptr, IND_rowidx, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>());
+        const int rcv = P->res_kind == 2 ? vproj_spatial_ssub(ctx, P, K, C, c_order, IND_colptr, IND_rowidx, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>())
+                                         : vproj_spatial(ctx, P, K, C, c_order, IND_colptr, IND_rowidx, dErow.as<int>(), dEcol.as<int>(), dCc.as<float>(), ldc, dU.as<float>());
         if (rcv < 0) return rcv;
         if (rcv > 0) { RET(residual_realize(ctx, P)); virt = false; }
     }
@@ -691,7 +692,8 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         // a virtual residual: A' Ysig = B' Yc + A' (Ymean - b0), B = A - W'A, one block-tiled pass over the centred video (vproj.hip)
         bool virt = P->ysig_virtual;
         if (virt) {
-            const int rcv = vproj_temporal(ctx, P, K, A_colptr, A_rowidx, A_val, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(), dU.as<float>(), ldc);
+            const int rcv = P->res_kind == 2 ? vproj_temporal_ssub(ctx, P, K, A_colptr, A_rowidx, A_val, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(), dU.as<float>(), ldc)
+                                             : vproj_temporal(ctx, P, K, A_colptr, A_rowidx, A_val, dColptr.as<int64_t>(), dErow.as<int>(), dAval.as<float>(), dU.as<float>(), ldc);
             if (rcv < 0) return rcv;
             if (rcv > 0) { RET(residual_realize(ctx, P)); virt = false; }
         }

@@ -1099,6 +1099,7 @@ static int r1_sweep(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, bool has_ac, int64_t
 int residual_realize(cnmfe_ctx *ctx, Patch *P) {
     if (!P->ysig_virtual) return 0;
     if (!P->ysig_valid) { P->ysig_virtual = false; return 0; }
+    if (P->res_kind == 2) return ssub_realize(ctx, P);      // bg_ssub > 1: the low-resolution sweep and its upsample (ssub.hip)
     RET(P->ysig.ensure((size_t)P->d * P->Tc * sizeof(float4)));
     RET(r1_sweep(ctx, P, P->ysig, false, 4, false, nullptr));
     P->ysig_virtual = false;

@@ -15,6 +15,7 @@
 // downsample kernel (set-up time) and a two-pass separable upsample fused with the final combination (per call).
 #include "common.hpp"
 #include <cmath>
+#include <climits>
 
 namespace cnmfe {
 
@@ -378,68 +379,63 @@ __global__ void __launch_bounds__(UP_NT) k_wa_upsample(int64_t d, int nr, int nr
     for (int s_ = 0; s_ < n; ++s_) { kk[(int64_t)s_ * d + m] = tk[s_][t]; vv[(int64_t)s_ * d + m] = tv[s_][t]; }
 }
 
-int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int ssub, int32_t K, const int64_t *cp, const int32_t *ri,
-                  const float *va, const float *C, int c_order, float *Ysig_out, int out_memspace) {
-    int d1s, d2s; low_dims(M, ssub, d1s, d2s);
-    if (R->d1 != d1s || R->d2 != d2s || R->T != M->T) return fail(CNMFE_ESTATE, "patch %d is not the low-resolution residual patch of patch %d", res_id, pid);
-    std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
-    const bool has_a = K > 0 && cp[K] > 0;
-    if (has_a) a_low(M, ssub, false, K, cp, ri, va, ocp, ori, ova);
-    // Ysig = [Y' + (Ymean - b0) - up(W down(Y'))] + up(W down(A_prev)) (C - mean C): while the video, W (of the residual patch) and b0 are
-    // unchanged a further call only changes the second bracket, exactly as in cnmfe_residual -- its full-resolution ELL form (k_wa_upsample)
-    // goes through the same pending-term / streaming-delta machinery (resid.hip), so the iteration does ONE low-resolution sweep + upsample.
-    const bool reuse = M->ysig_valid && M->res_kind == 2 && M->ysig.p && ctx->opt("r1_delta", 1) != 0;
-    RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, reuse ? 1 : 0));
-    const int64_t ldc_t = ctx->last_ldc;
-    // the centred traces of this call move to the patch (pendCc / resCc) and the buffer the patch held before comes back as tmp[1]: a swap
-    // both ways, no hipMalloc / hipFree per call (the guard hands the leftover buffer back on every exit path)
-    struct GiveBack { DevBuf b; DevBuf &home; ~GiveBack() { if (b.p && !home.p) b.swap(home); } } gb{DevBuf(), ctx->tmp[1]};
-    DevBuf &tCc = gb.b;
-    if (has_a) tCc.swap(ctx->tmp[1]);
+// imresize's bicubic upsampling taps of M's block region from R's grid: host copies, their (monotone) ranges, their transposes, and the device arrays -- once per patch
+int ssub_taps(cnmfe_ctx *ctx, Patch *M, const Patch *R) {
+    const int d1s = R->d1, d2s = R->d2;
+    if (M->ss_taps && M->ss_d1s == d1s && M->ss_d2s == d2s) return 0;
+    M->ss_taps = false;
     Taps tr = make_taps(d1s, M->nr_b, (double)M->nr_b / d1s, false), tc = make_taps(d2s, M->nc_b, (double)M->nc_b / d2s, false);
-    DevBuf &dIr = ctx->tmp[0], &dWr = ctx->scr[21], &dIc = ctx->tmp[2], &dWc = ctx->tmp[3], &dDlt = ctx->tmp[7];
-    RET(to_dev(ctx, dIr, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, dWr, tr.w.data(), tr.w.size()));
-    RET(to_dev(ctx, dIc, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, dWc, tc.w.data(), tc.w.size()));
-    // the footprint term of this call at full resolution: into the pending (reuse) or the applied slot of the main patch.  A pixel whose interpolation
-    // window meets more than UP_CAP footprints raises the context's error flag (reported by the next call that waits, like the low-resolution ring's own
-    // limit in k_ring_wa): reading a flag back here cost a drain of the stream in each of the iteration's two residual calls
-    {
-        DevBuf &tCnt = reuse ? M->pendCnt : M->resCnt, &tK = reuse ? M->pendK : M->resK, &tV = reuse ? M->pendV : M->resV;
-        if (has_a) {
-            int *dErr = nullptr;
-            RET(ctx_errflag(ctx, &dErr));
-            RET(tCnt.ensure((size_t)M->d * sizeof(int))); RET(tK.ensure((size_t)UP_CAP * M->d * sizeof(int))); RET(tV.ensure((size_t)UP_CAP * M->d * sizeof(float)));
-            LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + UP_NT - 1) / UP_NT)), dim3(UP_NT), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
-                   dIr.as<int>(), dWr.as<float>(), tr.P, dIc.as<int>(), dWc.as<float>(), tc.P, ctx->tmp[8].as<int>(), ctx->tmp[9].as<int>(), ctx->tmp[10].as<float>(),
-                   tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dErr);
-            (reuse ? M->pendCc : M->resCc).swap(tCc);
-        }
-        if (reuse) {
-            M->pend = true; M->pend_ac = has_a; M->pend_ldc = ldc_t; M->pend_K = K;
-            if (ctx->opt("r1_lazy", 1) == 0 || Ysig_out) RET(residual_materialize(ctx, M));
-            if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
-            return 0;
-        }
-        M->res_ac = has_a; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
-        M->res_kind = 2; M->ysig_virtual = false;
-    }
+    auto ranges = [](const Taps &t, std::vector<int> &lo, std::vector<int> &hi) {
+        lo.assign((size_t)t.n_out, INT_MAX); hi.assign((size_t)t.n_out, -1);
+        for (int o = 0; o < t.n_out; ++o)
+            for (int i = 0; i < t.P; ++i) if (t.w[(size_t)o * t.P + i] != 0.f) { lo[o] = std::min(lo[o], t.idx[(size_t)o * t.P + i]); hi[o] = std::max(hi[o], t.idx[(size_t)o * t.P + i]); }
+        for (int o = t.n_out - 2; o >= 0; --o) lo[o] = std::min(lo[o], lo[o + 1]);        // monotone: a run of rows [a, b] reaches [lo[a], hi[b]]
+        for (int o = 1; o < t.n_out; ++o) hi[o] = std::max(hi[o], hi[o - 1]);
+    };
+    auto transpose = [](const Taps &t, std::vector<int> &ptr, std::vector<int> &idx, std::vector<float> &w) {
+        ptr.assign((size_t)t.n_in + 1, 0);
+        for (int o = 0; o < t.n_out; ++o) for (int i = 0; i < t.P; ++i) if (t.w[(size_t)o * t.P + i] != 0.f) ++ptr[t.idx[(size_t)o * t.P + i] + 1];
+        for (int j = 0; j < t.n_in; ++j) ptr[j + 1] += ptr[j];
+        idx.resize((size_t)ptr[t.n_in]); w.resize((size_t)ptr[t.n_in]);
+        std::vector<int> cur(ptr.begin(), ptr.end() - 1);
+        for (int o = 0; o < t.n_out; ++o)                    // ascending output index, tap order: a fixed order of every transposed sum
+            for (int i = 0; i < t.P; ++i) { const float v = t.w[(size_t)o * t.P + i]; if (v != 0.f) { const int q = cur[t.idx[(size_t)o * t.P + i]]++; idx[q] = o; w[q] = v; } }
+    };
+    ranges(tr, M->ss_rlo, M->ss_rhi); ranges(tc, M->ss_clo, M->ss_chi);
+    std::vector<float> trw, tcw;
+    transpose(tr, M->ss_trp_h, M->ss_tri_h, trw); transpose(tc, M->ss_tcp_h, M->ss_tci_h, tcw);
+    RET(to_dev(ctx, M->ss_ir, tr.idx.data(), tr.idx.size())); RET(to_dev(ctx, M->ss_wr, tr.w.data(), tr.w.size()));
+    RET(to_dev(ctx, M->ss_ic, tc.idx.data(), tc.idx.size())); RET(to_dev(ctx, M->ss_wc, tc.w.data(), tc.w.size()));
+    RET(to_dev(ctx, M->ss_trp, M->ss_trp_h.data(), M->ss_trp_h.size())); RET(to_dev(ctx, M->ss_tri, M->ss_tri_h.data(), M->ss_tri_h.size())); RET(to_dev(ctx, M->ss_trw, trw.data(), trw.size()));
+    RET(to_dev(ctx, M->ss_tcp, M->ss_tcp_h.data(), M->ss_tcp_h.size())); RET(to_dev(ctx, M->ss_tci, M->ss_tci_h.data(), M->ss_tci_h.size())); RET(to_dev(ctx, M->ss_tcw, tcw.data(), tcw.size()));
+    M->ss_Pr = tr.P; M->ss_Pc = tc.P; M->ss_d1s = d1s; M->ss_d2s = d2s;
+    M->ss_tr_idx.swap(tr.idx); M->ss_tr_w.swap(tr.w); M->ss_tc_idx.swap(tc.idx); M->ss_tc_w.swap(tc.w);
+    M->ss_taps = true;
+    return 0;
+}
+
+// Ysig = Y' + (Ymean - b0) - up(W down(Y')): the upsample of the low-resolution sweep in ctx->ysig_low, combined with the video
+static int ssub_upsample(cnmfe_ctx *ctx, Patch *M, Patch *R) {
+    const int d1s = M->ss_d1s;
+    const int Pr = M->ss_Pr, Pc = M->ss_Pc;
+    DevBuf &dIr = M->ss_ir, &dWr = M->ss_wr, &dIc = M->ss_ic, &dWc = M->ss_wc, &dDlt = M->ss_dlt;
+    const std::vector<int> &tri = M->ss_tr_idx, &tci = M->ss_tc_idx;
     const int64_t ntmp = (int64_t)d1s * M->nc_b;
-    RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));
     RET(M->ysig.ensure((size_t)M->d * M->Tc * sizeof(float4)));
     RET(dDlt.ensure(M->d * sizeof(float)));
     LAUNCH(ctx, "r1_dlt", k_dlt2, dim3((unsigned)((M->d + 255) / 256)), dim3(256), 0, M->ymean_f.as<float>(), M->b0.as<double>(), dDlt.as<float>(),
            M->d, M->nr, M->nr_b, M->roff, M->coff);
     // the fused kernel needs 6-tap (upsampling) tables and a low-resolution window per 64 x 16 tile that fits its LDS tiles
-    bool fused = tr.P == 6 && tc.P == 6;
+    bool fused = Pr == 6 && Pc == 6;
     if (fused) {
         for (int r0 = M->roff; r0 < M->roff + M->nr && fused; r0 += UF_TR) {
             int lo = 1 << 30, hi = -1;
-            for (int q = r0 * 6; q < std::min(r0 + UF_TR, M->roff + M->nr) * 6; ++q) { lo = std::min(lo, tr.idx[q]); hi = std::max(hi, tr.idx[q]); }
+            for (int q = r0 * 6; q < std::min(r0 + UF_TR, M->roff + M->nr) * 6; ++q) { lo = std::min(lo, tri[q]); hi = std::max(hi, tri[q]); }
             if (hi - lo + 1 > UF_NLR) fused = false;
         }
         for (int c0 = M->coff; c0 < M->coff + M->nc && fused; c0 += UF_TC) {
             int lo = 1 << 30, hi = -1;
-            for (int q = c0 * 6; q < std::min(c0 + UF_TC, M->coff + M->nc) * 6; ++q) { lo = std::min(lo, tc.idx[q]); hi = std::max(hi, tc.idx[q]); }
+            for (int q = c0 * 6; q < std::min(c0 + UF_TC, M->coff + M->nc) * 6; ++q) { lo = std::min(lo, tci[q]); hi = std::max(hi, tci[q]); }
             if (hi - lo + 1 > UF_NLC) fused = false;
         }
     }
@@ -452,15 +448,82 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
         LAUNCH(ctx, "ssub_up_fused", k_up_fused, dim3((unsigned)ntile, (unsigned)nseg), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(), d1s, R->d_b,
                M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->nc, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(),
                dIc.as<int>(), dWc.as<float>(), ntr, M->Tc, cseg, M->ysig.as<float4>());
-        M->ysig_valid = true;
-        if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
         return 0;
     }
+    RET(ctx->up_tmp.ensure((size_t)ntmp * M->Tc * sizeof(float4)));
     LAUNCH(ctx, "ssub_up_cols", k_up_cols, dim3((unsigned)((ntmp + 255) / 256), (unsigned)M->Tc), dim3(256), 0, R->Yc4.as<float4>(), ctx->ysig_low.as<float4>(),
-           d1s, R->d_b, ctx->up_tmp.as<float4>(), M->nc_b, dIc.as<int>(), dWc.as<float>(), tc.P);
+           d1s, R->d_b, ctx->up_tmp.as<float4>(), M->nc_b, dIc.as<int>(), dWc.as<float>(), Pc);
     LAUNCH(ctx, "ssub_up_rows_combine", k_up_rows_combine, dim3((unsigned)((M->d + 255) / 256), (unsigned)M->Tc), dim3(256), 0, ctx->up_tmp.as<float4>(), d1s,
-           M->nc_b, M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(), tr.P,
+           M->nc_b, M->Yc4.as<float4>(), M->d_b, M->nr_b, M->nr, M->roff, M->coff, M->d, dDlt.as<float>(), dIr.as<int>(), dWr.as<float>(), Pr,
            M->ysig.as<float4>());
+    return 0;
+}
+
+// a virtual residual of cnmfe_residual_ssub becomes a resident one: the low-resolution sweep (no footprint term: the term, if any, pends beside Ysig at full
+// resolution either way) and its upsample run now
+int ssub_realize(cnmfe_ctx *ctx, Patch *M) {
+    Patch *R = get_patch(ctx, M->ss_res);
+    if (!R) return fail(CNMFE_ESTATE, "the low-resolution residual patch %d of a recorded residual is gone", M->ss_res);
+    RET(ssub_taps(ctx, M, R));
+    RET(residual_run(ctx, R, M->ss_res, 0, nullptr, nullptr, nullptr, nullptr, CNMFE_BOUND, nullptr, CNMFE_HOST, &ctx->ysig_low, 0));
+    RET(ssub_upsample(ctx, M, R));
+    M->ysig_virtual = false;
+    return 0;
+}
+
+int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int ssub, int32_t K, const int64_t *cp, const int32_t *ri,
+                  const float *va, const float *C, int c_order, float *Ysig_out, int out_memspace) {
+    int d1s, d2s; low_dims(M, ssub, d1s, d2s);
+    if (R->d1 != d1s || R->d2 != d2s || R->T != M->T) return fail(CNMFE_ESTATE, "patch %d is not the low-resolution residual patch of patch %d", res_id, pid);
+    std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
+    const bool has_a = K > 0 && cp[K] > 0;
+    if (has_a) a_low(M, ssub, false, K, cp, ri, va, ocp, ori, ova);
+    RET(ssub_taps(ctx, M, R));
+    M->ss_res = res_id; M->ss_ssub = ssub;
+    // Ysig = [Y' + (Ymean - b0) - up(W down(Y'))] + up(W down(A_prev)) (C - mean C): while the video, W (of the residual patch) and b0 are
+    // unchanged a further call only changes the second bracket, exactly as in cnmfe_residual -- its full-resolution ELL form (k_wa_upsample)
+    // goes through the same pending-term / streaming-delta machinery (resid.hip), so the iteration does at most ONE low-resolution sweep + upsample.
+    // Round 5: and usually none -- a request nobody asks the output of is only RECORDED (ysig_virtual, as cnmfe_residual does since round 4): the spatial and
+    // the temporal update take their projections through the resampling maps (vproj.hip, vproj_*_ssub), every other consumer realises it (ssub_realize).
+    const bool lazy = ctx->opt("r1_delta", 1) != 0;
+    const bool reuse = M->ysig_valid && M->res_kind == 2 && (M->ysig.p || M->ysig_virtual) && lazy;
+    const bool virt_new = !reuse && !Ysig_out && lazy && ctx->opt("ssub_virtual", 1) != 0 && ctx->opt("r1_virtual", 1) != 0 && ctx->opt("r1_lazy", 1) != 0;
+    const bool tables = reuse || virt_new;
+    RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, tables ? 1 : 0));
+    const int64_t ldc_t = ctx->last_ldc;
+    // the centred traces of this call move to the patch (pendCc / resCc) and the buffer the patch held before comes back as tmp[1]: a swap
+    // both ways, no hipMalloc / hipFree per call (the guard hands the leftover buffer back on every exit path)
+    struct GiveBack { DevBuf b; DevBuf &home; ~GiveBack() { if (b.p && !home.p) b.swap(home); } } gb{DevBuf(), ctx->tmp[1]};
+    DevBuf &tCc = gb.b;
+    if (has_a) tCc.swap(ctx->tmp[1]);
+    // the footprint term of this call at full resolution: into the pending (recorded / reused residual) or the applied slot of the main patch.  A pixel whose
+    // interpolation window meets more than UP_CAP footprints raises the context's error flag (reported by the next call that waits, like the low-resolution ring's own
+    // limit in k_ring_wa): reading a flag back here cost a drain of the stream in each of the iteration's two residual calls
+    {
+        DevBuf &tCnt = tables ? M->pendCnt : M->resCnt, &tK = tables ? M->pendK : M->resK, &tV = tables ? M->pendV : M->resV;
+        if (has_a) {
+            int *dErr = nullptr;
+            RET(ctx_errflag(ctx, &dErr));
+            RET(tCnt.ensure((size_t)M->d * sizeof(int))); RET(tK.ensure((size_t)UP_CAP * M->d * sizeof(int))); RET(tV.ensure((size_t)UP_CAP * M->d * sizeof(float)));
+            LAUNCH(ctx, "ssub_wa_upsample", k_wa_upsample, dim3((unsigned)((M->d + UP_NT - 1) / UP_NT)), dim3(UP_NT), 0, M->d, M->nr, M->nr_b, M->roff, M->coff, d1s, R->d,
+                   M->ss_ir.as<int>(), M->ss_wr.as<float>(), M->ss_Pr, M->ss_ic.as<int>(), M->ss_wc.as<float>(), M->ss_Pc, ctx->tmp[8].as<int>(), ctx->tmp[9].as<int>(),
+                   ctx->tmp[10].as<float>(), tCnt.as<int>(), tK.as<int>(), tV.as<float>(), dErr);
+            (tables ? M->pendCc : M->resCc).swap(tCc);
+        }
+        if (tables) {
+            if (virt_new) {
+                M->res_ac = false; M->res_ldc = ldc_t; M->res_K = 0; M->res_kind = 2;
+                M->ysig_valid = true; M->ysig_virtual = true;
+            }
+            M->pend = reuse ? true : has_a; M->pend_ac = has_a; M->pend_ldc = ldc_t; M->pend_K = K;
+            if (ctx->opt("r1_lazy", 1) == 0 || Ysig_out) RET(residual_materialize(ctx, M));
+            if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
+            return 0;
+        }
+        M->res_ac = has_a; M->res_ldc = ldc_t; M->res_K = K; M->pend = false;
+        M->res_kind = 2; M->ysig_virtual = false;
+    }
+    RET(ssub_upsample(ctx, M, R));
     M->ysig_valid = true;
     if (Ysig_out) RET(ysig_export(ctx, M, M->ysig, Ysig_out, out_memspace));
     return 0;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_vp_segsum(const double *__restrict__ Ut
 __global__ void __launch_bounds__(256) k_vp_spatial(const int *__restrict__ erow, const int *__restrict__ ecol, int64_t nnz, BgGeom g, const int *__restrict__ dr,
                                                     const int *__restrict__ dc, const float *__restrict__ W, const double *__restrict__ tab,
                                                     const int *__restrict__ lp, const short *__restrict__ slot_of, int Kt, const int *__restrict__ kmap,
-                                                    float *__restrict__ U, int *__restrict__ err) {
+                                                    float *__restrict__ U, double *__restrict__ Q, int *__restrict__ err) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= nnz) return;
     const int m = erow[e], kt = kmap[ecol[e]];
@@ -77,9 +77,12 @@ __global__ void __launch_bounds__(256) k_vp_spatial(const int *__restrict__ erow
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (w8[u] != 0.f) acc += (double)w8[u] * p8[u];
     }
-    const int64_t i0 = at(rbm, cbm);
-    if (i0 < 0) bad = true;
-    U[e] = (float)((i0 < 0 ? 0.0 : tab[i0]) - acc);
+    if (Q) Q[e] = acc;                                      // (bg_ssub: the ring sum alone, fp64 -- upsampled by k_vp_ssub_combine)
+    else {
+        const int64_t i0 = at(rbm, cbm);
+        if (i0 < 0) bad = true;
+        U[e] = (float)((i0 < 0 ? 0.0 : tab[i0]) - acc);
+    }
     if (bad) atomicOr(err, 1);                             // (the host checked the coverage: an inconsistent table, reported by the next wait)
 }
 
@@ -115,7 +118,7 @@ static void reach_blocks(const Patch *P, const BgGeom &g, int R, const int32_t *
 }
 
 int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
-                  const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU) {
+                  const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU, double *dQ) {
     HostTrace ht(ctx, "vproj_spatial");
     const BgGeom g = vp_geom(P);
     const int nblk = g.nbr * g.nbc, R = g.p_radius;
@@ -197,7 +200,7 @@ int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_ord
     int *dErr = nullptr;
     RET(ctx_errflag(ctx, &dErr));
     LAUNCH(ctx, "spatial_from_ptab", k_vp_spatial, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dErow, dEcol, nnz, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(),
-           P->W.as<float>(), P->pt_tab.as<double>(), P->pt_lp.as<int>(), P->pt_slot.as<short>(), (int)P->pt_K, dKmap.as<int>(), dU, dErr);
+           P->W.as<float>(), P->pt_tab.as<double>(), P->pt_lp.as<int>(), P->pt_slot.as<short>(), (int)P->pt_K, dKmap.as<int>(), dU, dQ, dErr);
     return 0;
 }
 
@@ -377,6 +380,81 @@ __global__ void __launch_bounds__(256) k_vp_reduce(const double *__restrict__ pa
     U[(int64_t)k * ldu + t] = t < T ? (float)s : 0.f;
 }
 
+// ---- the host side of a block-tiled projection, shared by the full-resolution form and bg_ssub's low-resolution one ----
+struct VpLists {
+    int64_t nent = 0;
+    std::vector<int> lst_ptr, g16, ent_blk, ent_k, ent_slot, kent, kptr, blk_nt[4], blall;
+};
+// need[need_ptr[k] .. need_ptr[k + 1]): the blocks neuron k's B column meets.  Entries in (block, slot) order; per neuron its entries in ascending block order
+// (the order of the final sum), followed by `extra_row0 + k` when extra_row0 >= 0 (a partial row of its own per neuron, bg_ssub).  1: a block meets more than
+// WIN_NLB neurons
+static int vp_make_lists(const std::vector<int> &need_ptr, const std::vector<int> &need, int nblk, int32_t K, bool extra, VpLists &L) {
+    L.nent = (int64_t)need.size();
+    std::vector<int> cnt((size_t)nblk + 1, 0);
+    for (int b : need) ++cnt[b + 1];
+    L.lst_ptr.assign((size_t)nblk + 1, 0); L.g16.assign((size_t)nblk + 1, 0);
+    for (int b = 0; b < nblk; ++b) {
+        if (cnt[b + 1] > WIN_NLB) return 1;                // more than 64 neurons over one block: the sweep serves this update
+        L.lst_ptr[b + 1] = L.lst_ptr[b] + cnt[b + 1];
+        L.g16[b + 1] = L.g16[b] + ((cnt[b + 1] + 15) >> 4);
+    }
+    L.ent_blk.resize((size_t)L.nent); L.ent_k.resize((size_t)L.nent); L.ent_slot.resize((size_t)L.nent);
+    std::vector<int> fill((size_t)nblk, 0), kent((size_t)L.nent);
+    for (int32_t k = 0; k < K; ++k)
+        for (int i = need_ptr[k]; i < need_ptr[k + 1]; ++i) {
+            const int b = need[i], s_ = fill[b]++, e = L.lst_ptr[b] + s_;
+            L.ent_blk[e] = b; L.ent_k[e] = k; L.ent_slot[e] = s_; kent[i] = e;
+        }
+    for (int32_t k = 0; k < K; ++k) std::sort(kent.begin() + need_ptr[k], kent.begin() + need_ptr[k + 1]);     // (entry index ascends with the block)
+    if (!extra) { L.kent.swap(kent); L.kptr = need_ptr; }
+    else {
+        L.kent.clear(); L.kent.reserve(kent.size() + K); L.kptr.assign((size_t)K + 1, 0);
+        for (int32_t k = 0; k < K; ++k) {
+            L.kent.insert(L.kent.end(), kent.begin() + need_ptr[k], kent.begin() + need_ptr[k + 1]);
+            L.kent.push_back((int)L.nent + k);
+            L.kptr[k + 1] = (int)L.kent.size();
+        }
+    }
+    for (int t = 0; t < 4; ++t) L.blk_nt[t].clear();
+    for (int b = 0; b < nblk; ++b) { const int n = L.lst_ptr[b + 1] - L.lst_ptr[b]; if (n) L.blk_nt[(n - 1) >> 4].push_back(b); }
+    L.blall.clear();
+    for (int t = 3; t >= 0; --t) L.blall.insert(L.blall.end(), L.blk_nt[t].begin(), L.blk_nt[t].end());
+    return 0;
+}
+static int vp_upload_lists(cnmfe_ctx *ctx, const VpLists &L) {
+    DevBuf *V = ctx->vp;
+    RET(to_dev(ctx, V[1], L.ent_blk.data(), L.ent_blk.size())); RET(to_dev(ctx, V[2], L.ent_k.data(), L.ent_k.size())); RET(to_dev(ctx, V[3], L.ent_slot.data(), L.ent_slot.size()));
+    RET(to_dev(ctx, V[4], L.g16.data(), L.g16.size())); RET(to_dev(ctx, V[5], L.lst_ptr.data(), L.lst_ptr.size()));
+    RET(to_dev(ctx, V[9], L.kptr.data(), L.kptr.size())); RET(to_dev(ctx, V[10], L.kent.data(), L.kent.size()));
+    RET(to_dev(ctx, V[11], L.blall.data(), L.blall.size()));
+    return 0;
+}
+// the projection launches: the video of patch V (its centred frames, or its read-order copy when `tiled`) against the B panels in ctx->vp[6], partial rows into ctx->vp[8]
+static int vp_launch_proj(cnmfe_ctx *ctx, Patch *V, const BgGeom &g, const VpLists &L, bool tiled, int64_t ldp) {
+    DevBuf *B = ctx->vp;
+    DevBuf &dG16 = B[4], &dLp = B[5], &dBt = B[6], &dPart = B[8], &dBl = B[11];
+    int off = 0;
+    for (int t = 3; t >= 0; --t) {
+        const int nb_ = (int)L.blk_nt[t].size();
+        if (!nb_) continue;
+        const int total = (int)L.blall.size();
+        // frame segments: enough workgroups to fill the chip a few times over, each at least a few chunk groups per wave
+        const int64_t ncg = ((V->Tc + 15) >> 4);
+        int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((ncg + 7) / 8, (VP_WG_TARGET + total - 1) / std::max(1, total)));
+        const size_t shmem = (size_t)(t + 1) * BLKPX * 16 * sizeof(double);
+#define VP_GO(NT_) do { if (shmem > 64 * 1024) { CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+                                                     CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); } \
+            if (tiled) LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_, true>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, V->yt4.as<float4>(), g, V->Tc, dBl.as<int>() + off, dLp.as<int>(), \
+                   dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); \
+            else LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_, false>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, V->Yc4.as<float4>(), g, V->Tc, dBl.as<int>() + off, dLp.as<int>(), \
+                   dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); } while (0)
+        if (t == 0) VP_GO(1); else if (t == 1) VP_GO(2); else if (t == 2) VP_GO(3); else VP_GO(4);
+#undef VP_GO
+        off += nb_;
+    }
+    return 0;
+}
+
 int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                    const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu) {
     HostTrace ht(ctx, "vproj_temporal");
@@ -391,35 +469,16 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
         reach_blocks(P, g, R, A_rowidx, A_colptr[k], A_colptr[k + 1], lo, hi, need);
         need_ptr[k + 1] = (int)need.size();
     }
-    const int64_t nent = (int64_t)need.size();
-    std::vector<int> cnt((size_t)nblk + 1, 0);
-    for (int b : need) ++cnt[b + 1];
-    std::vector<int> lst_ptr((size_t)nblk + 1, 0), g16((size_t)nblk + 1, 0);
-    for (int b = 0; b < nblk; ++b) {
-        if (cnt[b + 1] > WIN_NLB) return 1;                // more than 64 neurons over one block: the sweep serves this update
-        lst_ptr[b + 1] = lst_ptr[b] + cnt[b + 1];
-        g16[b + 1] = g16[b] + ((cnt[b + 1] + 15) >> 4);
-    }
+    VpLists L;
+    if (vp_make_lists(need_ptr, need, nblk, K, false, L)) return 1;
+    const int64_t nent = L.nent;
     const int64_t ldp = ldu;                               // partial sums: one row of ldu doubles per entry
     if (nent * ldp * 8 > (int64_t(24) << 30)) return 1;    // (a partial buffer beyond 24 GB: not what this path is for)
-    // entries in (block, slot) order; per neuron its entries in ascending block order (the order of the final sum)
-    std::vector<int> ent_blk((size_t)nent), ent_k((size_t)nent), ent_slot((size_t)nent), fill((size_t)nblk, 0), kent((size_t)nent), blk_nt[4], blall;
-    for (int32_t k = 0; k < K; ++k)
-        for (int i = need_ptr[k]; i < need_ptr[k + 1]; ++i) {
-            const int b = need[i], s_ = fill[b]++, e = lst_ptr[b] + s_;
-            ent_blk[e] = b; ent_k[e] = k; ent_slot[e] = s_; kent[i] = e;
-        }
-    for (int32_t k = 0; k < K; ++k) std::sort(kent.begin() + need_ptr[k], kent.begin() + need_ptr[k + 1]);     // (entry index ascends with the block)
-    for (int b = 0; b < nblk; ++b) { const int n = lst_ptr[b + 1] - lst_ptr[b]; if (n) blk_nt[(n - 1) >> 4].push_back(b); }
     ht.mark("lists");
     DevBuf *V = ctx->vp;
-    DevBuf &dEb = V[1], &dEk = V[2], &dEs = V[3], &dG16 = V[4], &dLp = V[5], &dBt = V[6], &dCst = V[7], &dPart = V[8], &dNptr = V[9], &dNent = V[10], &dBl = V[11];
-    RET(to_dev(ctx, dEb, ent_blk.data(), ent_blk.size())); RET(to_dev(ctx, dEk, ent_k.data(), ent_k.size())); RET(to_dev(ctx, dEs, ent_slot.data(), ent_slot.size()));
-    RET(to_dev(ctx, dG16, g16.data(), g16.size())); RET(to_dev(ctx, dLp, lst_ptr.data(), lst_ptr.size()));
-    RET(to_dev(ctx, dNptr, need_ptr.data(), need_ptr.size())); RET(to_dev(ctx, dNent, kent.data(), kent.size()));
-    for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());
-    RET(to_dev(ctx, dBl, blall.data(), blall.size()));
-    const size_t bt_bytes = (size_t)std::max(1, g16[nblk]) * BLKPX * 16 * sizeof(double);
+    DevBuf &dEb = V[1], &dEk = V[2], &dEs = V[3], &dG16 = V[4], &dBt = V[6], &dCst = V[7], &dPart = V[8], &dNptr = V[9], &dNent = V[10];
+    RET(vp_upload_lists(ctx, L));
+    const size_t bt_bytes = (size_t)std::max(1, L.g16[nblk]) * BLKPX * 16 * sizeof(double);
     RET(dBt.ensure_hw(bt_bytes, ctx->hw_vp[6]));
     RET(dCst.ensure_hw((size_t)K * sizeof(double), ctx->hw_vp[7]));
     RET(dPart.ensure_hw((size_t)std::max<int64_t>(1, nent) * ldp * sizeof(double), ctx->hw_vp[8]));
@@ -444,27 +503,328 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
         tiled = P->yt4_valid;
     }
     LAUNCH(ctx, "temporal_const", k_vp_const, dim3((unsigned)K), dim3(256), 0, dColptr, dErow, dAval, g, P->ymean_d.as<double>(), P->b0.as<double>(), dCst.as<double>());
-    int off = 0;
-    for (int t = 3; t >= 0; --t) {
-        const int nb_ = (int)blk_nt[t].size();
-        if (!nb_) continue;
-        const int total = (int)blall.size();
-        // frame segments: enough workgroups to fill the chip a few times over, each at least a few chunk groups per wave
-        const int64_t ncg = ((P->Tc + 15) >> 4);
-        int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((ncg + 7) / 8, (VP_WG_TARGET + total - 1) / std::max(1, total)));
-        const size_t shmem = (size_t)(t + 1) * BLKPX * 16 * sizeof(double);
-#define VP_GO(NT_) do { if (shmem > 64 * 1024) { CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-                                                     CK(hipFuncSetAttribute((const void *)k_vp_proj_b<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); } \
-            if (tiled) LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_, true>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->yt4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \
-                   dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); \
-            else LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_b<NT_, false>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->Yc4.as<float4>(), g, P->Tc, dBl.as<int>() + off, dLp.as<int>(), \
-                   dG16.as<int>(), dBt.as<double>(), nsg, dPart.as<double>(), ldp); } while (0)
-        if (t == 0) VP_GO(1); else if (t == 1) VP_GO(2); else if (t == 2) VP_GO(3); else VP_GO(4);
-#undef VP_GO
-        off += nb_;
-    }
+    RET(vp_launch_proj(ctx, P, g, L, tiled, ldp));
     LAUNCH(ctx, "temporal_reduce_B", k_vp_reduce, dim3((unsigned)((ldu + 255) / 256), (unsigned)K), dim3(256), 0, dPart.as<double>(), ldp, dNptr.as<int>(), dNent.as<int>(),
            dCst.as<double>(), P->T, dU, ldu);
+    ht.mark("launches");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// bg_ssub > 1 (round 5): the same two projections THROUGH the resampling maps.  With D = imresize(., 1/s) (bicubic, antialiased: the low-resolution residual
+// patch R holds D Yc as its resident video), Up = imresize(., [nr_b nc_b]) (bicubic) and W_L the ring weights on the low-resolution grid,
+//     Ysig = Yc(patch) + dlt - Up W_L D Yc + [footprint term: full-resolution ELL rows of up(W_L down(A_prev)), pending as before]
+//     (update_spatial_parallel.m:167-178 == update_temporal_parallel.m:153-165)
+// * spatial:   U(m,k) = P_F(m,k) - sum_{l in taps(m)} up(m,l) Q_L(l,k),   P_F = Yc Cc' on the mask's entries (one read of the video rows under the masks, fp64 sums),
+//                                                                        Q_L(l,k) = sum_i W_L(l,i) P_L(l + o_i, k),  P_L = (D Yc) Cc': vproj_spatial's table of R
+//   Q_L on the low-resolution bounding box of every mask's taps (dense per neuron: the upsampling looks its 4 x 4 taps up by position)
+// * temporal:  A' Ysig = A' Yc + A' dlt 1' - B_L' (D Yc),   B_L = W_L' (Up' A): the block-tiled projection of R's video with panels built from up' A, plus the
+//   footprint rows' own fp64 projection of the full-resolution video as one more partial row per neuron
+// Both replace the low-resolution sweep, its upsample (a 10.5 GB read + a 10.5 GB write at H) and the projections of the realised Ysig.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vp_rows_block(const int *__restrict__ erow, int64_t nnz, int nr, int nr_b, int roff, int coff, int *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const int m = erow[e];
+    out[e] = (m / nr + coff) * nr_b + (m % nr + roff);
+}
+// P_F(e) = sum_t Yc(q_e, t) Cc(k_e, t): k_proj_spatial (factor.hip) on the centred VIDEO with fp64 sums -- the background these sums still contain is removed by the
+// upsampled ring term afterwards, so the cancellation must not cost digits
+__global__ void __launch_bounds__(256) k_vp_rows_spatial(const float4 *__restrict__ Y4, int64_t d_b, int64_t T, const int *__restrict__ erq, const int *__restrict__ ecol, int64_t nnz,
+                                                         const float *__restrict__ Cc, int64_t ldc, int64_t tchunk, double *__restrict__ part) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const int64_t t0 = (int64_t)blockIdx.y * tchunk, t1 = t0 + tchunk < T ? t0 + tchunk : T;      // tchunk is a multiple of 4
+    const float4 *y = Y4 + erq[e];
+    const float *c = Cc + (int64_t)ecol[e] * ldc;            // centred traces are 0 beyond T
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int64_t t = t0; t < t1; t += 4) {
+        const float4 yv = y[(t >> 2) * d_b];
+        const float4 cv = *reinterpret_cast<const float4 *>(c + t);
+        a0 = fma((double)yv.x, (double)cv.x, a0); a1 = fma((double)yv.y, (double)cv.y, a1); a2 = fma((double)yv.z, (double)cv.z, a2); a3 = fma((double)yv.w, (double)cv.w, a3);
+    }
+    part[(int64_t)blockIdx.y * nnz + e] = (a0 + a1) + (a2 + a3);
+}
+// U(e) = sum of the frame parts of P_F(e), in order, - sum over the upsampling taps of pixel m_e of w_c w_r Q_L(tap, k_e);  bb[k] = (first low row, first low column,
+// rows, offset) of neuron k's dense low-resolution box in Q
+__global__ void __launch_bounds__(256) k_vp_ssub_combine(const int *__restrict__ erow, const int *__restrict__ ecol, int64_t nnz, int nr, int roff, int coff,
+                                                         const double *__restrict__ part, int nparts, const int *__restrict__ ir, const float *__restrict__ wr, int Pr,
+                                                         const int *__restrict__ ic, const float *__restrict__ wc, int Pc, const int4 *__restrict__ bb,
+                                                         const double *__restrict__ Q, float *__restrict__ U) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const int m = erow[e], k = ecol[e];
+    const int rb = m % nr + roff, cb = m / nr + coff;
+    double pf = 0.0;
+    for (int j = 0; j < nparts; ++j) pf += part[(int64_t)j * nnz + e];
+    const int4 b = bb[k];
+    double acc = 0.0;
+    for (int u = 0; u < Pc; ++u) {
+        const float wcu = wc[cb * Pc + u];
+        if (wcu == 0.f) continue;
+        const int64_t cofs = (int64_t)b.w + (int64_t)(ic[cb * Pc + u] - b.y) * b.z - b.x;
+        for (int q = 0; q < Pr; ++q) {
+            const float w = wr[rb * Pr + q];
+            if (w == 0.f) continue;
+            acc = fma((double)wcu * (double)w, Q[cofs + ir[rb * Pr + q]], acc);
+        }
+    }
+    U[e] = (float)(pf - acc);
+}
+
+// every image-column run of a CSC column over patch rows (ascending): f(block-region column, first block-region row, last one)
+template <typename F>
+static void for_column_runs(const Patch *P, const int32_t *rowidx, int64_t e0, int64_t e1, F f) {
+    int64_t e = e0;
+    while (e < e1) {
+        const int m0 = rowidx[e];
+        const int c = m0 / P->nr, col_end = (c + 1) * P->nr;
+        int mlast = m0;
+        ++e;
+        while (e < e1 && rowidx[e] < col_end && rowidx[e] >= mlast) { mlast = rowidx[e]; ++e; }
+        f(c + P->coff, m0 - c * P->nr + P->roff, mlast - c * P->nr + P->roff);
+    }
+}
+// low-resolution bounding box [r0, r1] x [c0, c1] of the upsampling taps of a column's pixels (r1 < r0: the column is empty)
+static void low_box(const Patch *M, const int32_t *rowidx, int64_t e0, int64_t e1, int &r0, int &r1, int &c0, int &c1) {
+    r0 = c0 = INT_MAX; r1 = c1 = -1;
+    for_column_runs(M, rowidx, e0, e1, [&](int cb, int rf, int rl) {
+        r0 = std::min(r0, M->ss_rlo[rf]); r1 = std::max(r1, M->ss_rhi[rl]);
+        c0 = std::min(c0, M->ss_clo[cb]); c1 = std::max(c1, M->ss_chi[cb]);
+    });
+}
+
+int vproj_spatial_ssub(cnmfe_ctx *ctx, Patch *M, int32_t K, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
+                       const int *dErow, const int *dEcol, const float *dCc, int64_t ldc, float *dU) {
+    HostTrace ht(ctx, "vproj_spatial_ssub");
+    Patch *R = get_patch(ctx, M->ss_res);
+    if (!R || !R->ring_ready) return 1;
+    RET(ssub_taps(ctx, M, R));
+    const int64_t nnz = IND_colptr[K];
+    if (nnz == 0) return 0;
+    const int d1s = M->ss_d1s;
+    // the low-resolution mask: per neuron the dense box of its mask's taps
+    std::vector<int64_t> lcp((size_t)K + 1, 0);
+    std::vector<int> bb((size_t)K * 4, 0);
+    for (int32_t k = 0; k < K; ++k) {
+        int r0, r1, c0, c1;
+        low_box(M, IND_rowidx, IND_colptr[k], IND_colptr[k + 1], r0, r1, c0, c1);
+        const int h = r1 >= r0 ? r1 - r0 + 1 : 0, w = r1 >= r0 ? c1 - c0 + 1 : 0;
+        bb[(size_t)k * 4] = h ? r0 : 0; bb[(size_t)k * 4 + 1] = h ? c0 : 0; bb[(size_t)k * 4 + 2] = h; bb[(size_t)k * 4 + 3] = (int)lcp[k];
+        lcp[k + 1] = lcp[k] + (int64_t)h * w;
+    }
+    const int64_t nl = lcp[K];
+    if (nl >= (int64_t(1) << 31)) return 1;
+    std::vector<int32_t> lrow((size_t)nl), lcol((size_t)nl);
+    for (int32_t k = 0; k < K; ++k) {
+        const int r0 = bb[(size_t)k * 4], c0 = bb[(size_t)k * 4 + 1], h = bb[(size_t)k * 4 + 2];
+        int64_t o = lcp[k];
+        const int w = h ? (int)((lcp[k + 1] - lcp[k]) / h) : 0;
+        for (int c = 0; c < w; ++c)
+            for (int r = 0; r < h; ++r, ++o) { lrow[o] = (c0 + c) * d1s + (r0 + r); lcol[o] = k; }
+    }
+    ht.mark("low-resolution masks");
+    DevBuf *V = ctx->vp;
+    DevBuf &dLr = V[16], &dLc = V[17], &dQ = V[18], &dBB = V[19], &dPart = V[20], &dErq = V[21];
+    RET(to_dev(ctx, dLr, lrow.data(), lrow.size())); RET(to_dev(ctx, dLc, lcol.data(), lcol.size())); RET(to_dev(ctx, dBB, bb.data(), bb.size()));
+    RET(dQ.ensure_hw((size_t)nl * sizeof(double), ctx->hw_vp[18]));
+    // Q_L: the ring sums of R's table on the boxes (the table P_L = (D Yc) Cc' is built by vproj_spatial: one read of the low-resolution video)
+    const int rc = vproj_spatial(ctx, R, K, C, c_order, lcp.data(), lrow.data(), dLr.as<int>(), dLc.as<int>(), dCc, ldc, nullptr, dQ.as<double>());
+    if (rc) return rc;
+    // P_F: the rows of the centred video under the masks
+    const int64_t T = M->T;
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(32, T / 256));
+    const int64_t tchunk = ((T + nparts - 1) / nparts + 3) & ~int64_t(3);
+    RET(dPart.ensure_hw((size_t)nparts * nnz * sizeof(double), ctx->hw_vp[20]));
+    const int *erq = dErow;
+    if (M->nr != M->nr_b || M->roff || M->coff) {
+        RET(dErq.ensure_hw((size_t)nnz * sizeof(int), ctx->hw_vp[21]));
+        LAUNCH(ctx, "ssub_rows_block", k_vp_rows_block, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dErow, nnz, M->nr, M->nr_b, M->roff, M->coff, dErq.as<int>());
+        erq = dErq.as<int>();
+    }
+    LAUNCH(ctx, "spatial_proj_rows", k_vp_rows_spatial, dim3((unsigned)((nnz + 255) / 256), (unsigned)nparts), dim3(256), 0, M->Yc4.as<float4>(), M->d_b, T, erq, dEcol, nnz, dCc, ldc,
+           tchunk, dPart.as<double>());
+    LAUNCH(ctx, "spatial_ssub_combine", k_vp_ssub_combine, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dErow, dEcol, nnz, M->nr, M->roff, M->coff, dPart.as<double>(), nparts,
+           M->ss_ir.as<int>(), M->ss_wr.as<float>(), M->ss_Pr, M->ss_ic.as<int>(), M->ss_wc.as<float>(), M->ss_Pc, reinterpret_cast<const int4 *>(dBB.p), dQ.as<double>(), dU);
+    ht.mark("launches");
+    return 0;
+}
+
+// B_L of one (low-resolution block, neuron) entry: B_L = -W_L' (Up' A).  The footprint's entries around the block go into a dense full-resolution window, up' A on the
+// block's ring-grown low-resolution window is gathered from it through the TRANSPOSED taps -- rows first, then columns (separable; fixed order: bit-reproducible) --,
+// the transposed ring product as in k_vp_build_b.  span_r[2 bi], span_r[2 bi + 1] / span_c: the full-resolution rows / columns the window of block row bi / block column
+// bj reaches (host).  Dynamic LDS: winL[ws * ws] + mid[ws * fmax] doubles, winF[fmax * fmax] floats.
+__global__ void __launch_bounds__(256) k_vp_build_b_ssub(const int *__restrict__ ent_blk, const int *__restrict__ ent_k, const int *__restrict__ ent_slot, const int *__restrict__ g16,
+                                                         BgGeom g, int R, int fmax, const int *__restrict__ span_r, const int *__restrict__ span_c,
+                                                         const int64_t *__restrict__ colptr, const int *__restrict__ erq, const float *__restrict__ aval, int nr_bF,
+                                                         const int *__restrict__ trp, const int *__restrict__ tri, const float *__restrict__ trw,
+                                                         const int *__restrict__ tcp, const int *__restrict__ tci, const float *__restrict__ tcw,
+                                                         const int *__restrict__ dr, const int *__restrict__ dc, const float *__restrict__ W, double *__restrict__ Bt) {
+    extern __shared__ __attribute__((aligned(16))) double vb_lds[];
+    const int ws = 16 + 2 * R;
+    double *winL = vb_lds, *mid = vb_lds + ws * ws;
+    float *winF = reinterpret_cast<float *>(mid + ws * fmax);
+    const int b = ent_blk[blockIdx.x], k = ent_k[blockIdx.x], slot = ent_slot[blockIdx.x];
+    const int bi = b % g.nbr, bj = b / g.nbr;
+    const int wr0 = bi * 16 - R, wc0 = bj * 16 - R;
+    const int fr0 = span_r[2 * bi], fh = span_r[2 * bi + 1] - fr0 + 1, fc0 = span_c[2 * bj], fw = span_c[2 * bj + 1] - fc0 + 1;      // (<= fmax)
+    for (int i = threadIdx.x; i < fh * fw; i += 256) winF[i] = 0.f;
+    __syncthreads();
+    for (int64_t e = colptr[k] + threadIdx.x; e < colptr[k + 1]; e += 256) {
+        const int q = erq[e];
+        const int rw = q % nr_bF - fr0, cw = q / nr_bF - fc0;
+        if (rw >= 0 && rw < fh && cw >= 0 && cw < fw) winF[cw * fh + rw] = aval[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ws * fw; i += 256) {       // rows: mid[cF][jr] = sum over the rows low row jr feeds
+        const int jr = wr0 + i % ws, cF = i / ws;
+        double s = 0.0;
+        if (jr >= 0 && jr < g.nr_b) {
+            const float *col = winF + cF * fh - fr0;
+            for (int t = trp[jr]; t < trp[jr + 1]; ++t) s = fma((double)trw[t], (double)col[tri[t]], s);
+        }
+        mid[cF * ws + i % ws] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ws * ws; i += 256) {       // columns
+        const int jc = wc0 + i / ws;
+        double a = 0.0;
+        if (jc >= 0 && jc < g.nc_b)
+            for (int t = tcp[jc]; t < tcp[jc + 1]; ++t) a = fma((double)tcw[t], mid[(tci[t] - fc0) * ws + i % ws], a);
+        winL[i] = a;
+    }
+    __syncthreads();
+    const int px = threadIdx.x, rb = bi * 16 + (px & 15), cb = bj * 16 + (px >> 4);
+    double v = 0.0;
+    if (rb < g.nr_b && cb < g.nc_b) {
+        double acc = 0.0;
+        for (int i = 0; i < g.p; ++i) {
+            const int rm = rb - dr[i], cm = cb - dc[i];                     // the centre pixel whose i-th ring neighbour is this pixel
+            const double a = winL[(cm - wc0) * ws + (rm - wr0)];
+            if (a != 0.0) acc += (double)W[(int64_t)i * g.d + (int64_t)(cm - g.coff) * g.nr + (rm - g.roff)] * a;      // (a != 0: a pixel of the low-resolution grid)
+        }
+        v = -acc;
+    }
+    Bt[(((int64_t)g16[b] + (slot >> 4)) * BLKPX + px) * 16 + (slot & 15)] = v;
+}
+// the footprint rows' own projection, part[row0 + k][t] = sum_e A(e) Yc(q_e, t) in fp64: k_proj_temporal (factor.hip) on the centred video
+__global__ void __launch_bounds__(256) k_vp_rows_temporal(const float4 *__restrict__ Y4, int64_t d_b, int64_t T, const int64_t *__restrict__ colptr, const int *__restrict__ erq,
+                                                          const float *__restrict__ aval, int64_t cchunk, double *__restrict__ part, int64_t ldp) {
+    const int k = blockIdx.x;
+    const int64_t e0 = colptr[k], e1 = colptr[k + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t Tc = (T + 3) >> 2;
+    const int64_t c0 = (int64_t)blockIdx.y * cchunk, c1 = c0 + cchunk < Tc ? c0 + cchunk : Tc;
+    constexpr int NE = 6;
+    const int nit = (int)(e1 - e0 + 63 < (int64_t)64 * NE ? (e1 - e0 + 63) >> 6 : NE);
+    int rw[NE]; float av[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int64_t e = e0 + lane + 64 * i;
+        const bool in = i < nit && e < e1;
+        rw[i] = in ? erq[e] : 0; av[i] = in ? aval[e] : 0.f;
+    }
+    const int64_t et = e0 + (int64_t)64 * NE;
+    for (int64_t c = c0 + wave; c < c1; c += 4) {
+        const float4 *y = Y4 + c * d_b;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (i < nit) {
+                const float4 yv = y[rw[i]];
+                const double a = (double)av[i];
+                s0 = fma(a, (double)yv.x, s0); s1 = fma(a, (double)yv.y, s1); s2 = fma(a, (double)yv.z, s2); s3 = fma(a, (double)yv.w, s3);
+            }
+        for (int64_t e = et + lane; e < e1; e += 64) {
+            const double a = (double)aval[e]; const float4 yv = y[erq[e]];
+            s0 = fma(a, (double)yv.x, s0); s1 = fma(a, (double)yv.y, s1); s2 = fma(a, (double)yv.z, s2); s3 = fma(a, (double)yv.w, s3);
+        }
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o); }
+        if (lane == 0) {
+            double *u = part + (int64_t)k * ldp + 4 * c;     // ldp is a multiple of 4 >= T
+            u[0] = s0; u[1] = s1; u[2] = s2; u[3] = s3;
+        }
+    }
+}
+
+int vproj_temporal_ssub(cnmfe_ctx *ctx, Patch *M, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
+                        const int64_t *dColptr, const int *dErow, const float *dAval, float *dU, int64_t ldu) {
+    HostTrace ht(ctx, "vproj_temporal_ssub");
+    (void)A_val;
+    Patch *R = get_patch(ctx, M->ss_res);
+    if (!R || !R->ring_ready) return 1;
+    RET(ssub_taps(ctx, M, R));
+    const BgGeom g = vp_geom(R);
+    const BgGeom gM = vp_geom(M);
+    const int nblk = g.nbr * g.nbc, RL = g.p_radius, ws = 16 + 2 * RL;
+    if (ws > VP_WS) return 1;
+    const int d1s = M->ss_d1s, d2s = M->ss_d2s;
+    // the full-resolution rows / columns a ring-grown low-resolution block window reaches through the transposed taps, per block row / column
+    int fmax = 1;
+    std::vector<int> span_r((size_t)2 * g.nbr, 0), span_c((size_t)2 * g.nbc, 0);
+    auto span = [&](const std::vector<int> &ptr, const std::vector<int> &idx, int n_low, int nb, std::vector<int> &out) {
+        for (int bi = 0; bi < nb; ++bi) {
+            int a0 = INT_MAX, a1 = -1;
+            for (int j = std::max(0, bi * 16 - RL); j < bi * 16 - RL + ws && j < n_low; ++j) for (int t = ptr[j]; t < ptr[j + 1]; ++t) { a0 = std::min(a0, idx[t]); a1 = std::max(a1, idx[t]); }
+            if (a1 < a0) { a0 = 0; a1 = 0; }
+            out[(size_t)2 * bi] = a0; out[(size_t)2 * bi + 1] = a1;
+            fmax = std::max(fmax, a1 - a0 + 1);
+        }
+    };
+    span(M->ss_trp_h, M->ss_tri_h, d1s, g.nbr, span_r); span(M->ss_tcp_h, M->ss_tci_h, d2s, g.nbc, span_c);
+    const size_t shm_b = ((size_t)ws * ws + (size_t)ws * fmax) * sizeof(double) + (size_t)fmax * fmax * sizeof(float);
+    if (shm_b > 150 * 1024) return 1;
+    // the low-resolution blocks B_L(:, k) meets: the box of up' A's support grown by the ring
+    std::vector<int> need_ptr((size_t)K + 1, 0), need;
+    need.reserve((size_t)K * 8);
+    for (int32_t k = 0; k < K; ++k) {
+        int r0, r1, c0, c1;
+        low_box(M, A_rowidx, A_colptr[k], A_colptr[k + 1], r0, r1, c0, c1);
+        if (r1 >= r0) {
+            const int bi0 = std::max(0, r0 - RL) >> 4, bi1 = std::min(d1s - 1, r1 + RL) >> 4, bj0 = std::max(0, c0 - RL) >> 4, bj1 = std::min(d2s - 1, c1 + RL) >> 4;
+            for (int bj = bj0; bj <= bj1; ++bj) for (int bi = bi0; bi <= bi1; ++bi) need.push_back(bj * g.nbr + bi);
+        }
+        need_ptr[k + 1] = (int)need.size();
+    }
+    VpLists L;
+    if (vp_make_lists(need_ptr, need, nblk, K, true, L)) return 1;
+    const int64_t nent = L.nent, ldp = ldu;
+    if ((nent + K) * ldp * 8 > (int64_t(24) << 30)) return 1;
+    ht.mark("lists");
+    DevBuf *V = ctx->vp;
+    DevBuf &dEb = V[1], &dEk = V[2], &dEs = V[3], &dG16 = V[4], &dBt = V[6], &dCst = V[7], &dPart = V[8], &dNptr = V[9], &dNent = V[10], &dErq = V[21], &dSr = V[22], &dSc = V[23];
+    RET(vp_upload_lists(ctx, L));
+    RET(to_dev(ctx, dSr, span_r.data(), span_r.size())); RET(to_dev(ctx, dSc, span_c.data(), span_c.size()));
+    const size_t bt_bytes = (size_t)std::max(1, L.g16[nblk]) * BLKPX * 16 * sizeof(double);
+    RET(dBt.ensure_hw(bt_bytes, ctx->hw_vp[6]));
+    RET(dCst.ensure_hw((size_t)K * sizeof(double), ctx->hw_vp[7]));
+    RET(dPart.ensure_hw((size_t)(nent + K) * ldp * sizeof(double), ctx->hw_vp[8]));
+    CK(hipMemsetAsync(dBt.p, 0, bt_bytes, ctx->st()));
+    const int64_t nnz = A_colptr[K];
+    const int *erq = dErow;
+    if (M->nr != M->nr_b || M->roff || M->coff) {
+        RET(dErq.ensure_hw((size_t)std::max<int64_t>(1, nnz) * sizeof(int), ctx->hw_vp[21]));
+        if (nnz) LAUNCH(ctx, "ssub_rows_block", k_vp_rows_block, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, dErow, nnz, M->nr, M->nr_b, M->roff, M->coff, dErq.as<int>());
+        erq = dErq.as<int>();
+    }
+    if (nent > 0) {
+        if (shm_b > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_vp_build_b_ssub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_b));
+        LAUNCH(ctx, "temporal_build_B", k_vp_build_b_ssub, dim3((unsigned)nent), dim3(256), shm_b, dEb.as<int>(), dEk.as<int>(), dEs.as<int>(), dG16.as<int>(), g, RL, fmax, dSr.as<int>(), dSc.as<int>(),
+               dColptr, erq, dAval, M->nr_b, M->ss_trp.as<int>(), M->ss_tri.as<int>(), M->ss_trw.as<float>(), M->ss_tcp.as<int>(), M->ss_tci.as<int>(), M->ss_tcw.as<float>(),
+               R->ring_dr.as<int>(), R->ring_dc.as<int>(), R->W.as<float>(), dBt.as<double>());
+    }
+    LAUNCH(ctx, "temporal_const", k_vp_const, dim3((unsigned)K), dim3(256), 0, dColptr, dErow, dAval, gM, M->ymean_d.as<double>(), M->b0.as<double>(), dCst.as<double>());
+    {   // A' Yc of the footprint rows: partial rows nent .. nent + K - 1 (every frame group of a row is written: empty footprints write zeros through the loop bounds)
+        const int64_t Tc = M->Tc;
+        const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, Tc / 32));
+        const int64_t cchunk = (Tc + nchunk - 1) / nchunk;
+        CK(hipMemsetAsync((char *)dPart.p + (size_t)nent * ldp * sizeof(double), 0, (size_t)K * ldp * sizeof(double), ctx->st()));
+        LAUNCH(ctx, "temporal_proj_rows", k_vp_rows_temporal, dim3((unsigned)K, (unsigned)nchunk), dim3(256), 0, M->Yc4.as<float4>(), M->d_b, M->T, dColptr, erq, dAval, cchunk,
+               dPart.as<double>() + nent * ldp, ldp);
+    }
+    RET(vp_launch_proj(ctx, R, g, L, false, ldp));
+    LAUNCH(ctx, "temporal_reduce_B", k_vp_reduce, dim3((unsigned)((ldu + 255) / 256), (unsigned)K), dim3(256), 0, dPart.as<double>(), ldp, dNptr.as<int>(), dNent.as<int>(),
+           dCst.as<double>(), M->T, dU, ldu);
     ht.mark("launches");
     return 0;
 }
