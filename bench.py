@@ -439,7 +439,7 @@ def main():
         """the two projection kernels (north_star's "residual projections"): S1 U = Ysig*C' on the search mask (HALS_spatial.m:27-32) and T1
         U = A'*Ysig (HALS_temporal.m:48).  Algorithmic bytes = the rows of Ysig a launch needs, once (pixels under the mask / under a footprint,
         x T x 4) + the K x T traces read (S1) or written (T1) + the mask / footprint entries; whole-FOV single patch only."""
-        if world != 1 or len(video.owned) != 1 or a.bg_ssub != 1:
+        if world != 1 or len(video.owned) != 1:
             return None
         out = {}
         try:
@@ -447,8 +447,23 @@ def main():
             IND = s._search_location_owned(Acsc)
             npix = {"spatial_proj_U": int(np.unique(IND.indices).size), "temporal_proj_U": int(np.unique(Acsc.indices).size)}
             nnz = {"spatial_proj_U": int(IND.nnz), "temporal_proj_U": int(Acsc.nnz)}
+            npix["spatial_proj_rows"], npix["temporal_proj_rows"] = npix["spatial_proj_U"], npix["temporal_proj_U"]      # bg_ssub > 1, sweep-free: the same rows of the VIDEO
+            nnz["spatial_proj_rows"], nnz["temporal_proj_rows"] = nnz["spatial_proj_U"], nnz["temporal_proj_U"]
         except Exception:
             return None
+        if a.bg_ssub != 1:
+            # bg_ssub > 1 (round 5): the full-resolution rows under the masks / footprints (fp64 sums) and the low-resolution video twice (the table of the spatial
+            # update, the B_L panels of the temporal one); the fit's own window projection reads the low-resolution fit patch
+            low = 4.0 * (d_b / float(a.bg_ssub ** 2)) * T + 4.0 * K * T
+            for name, by in (("spatial_proj_rows", None), ("temporal_proj_rows", None), ("spatial_ptab_proj", low), ("temporal_proj_B", low), ("bg_win_proj", low)):
+                if name not in kern:
+                    continue
+                if by is None:
+                    by = 4.0 * npix[name] * T + 4.0 * K * T + 8.0 * nnz[name]
+                ms = kern[name]["ms_per_step"]
+                out[name] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": name, "ms_per_update": ms, "algorithmic_bytes_per_update": by}
+            return out or None
         # the sweep-free formulation's video passes: the temporal projection through B = A - W'A (one read of the centred block video + the K x T result;
         # its fp64 partial sums per (16x16 block, neuron) are traffic, not algorithmic bytes) and the fit's window projection P = Yc Cc' (one read + the traces)
         for name in ("temporal_proj_B", "bg_win_proj"):
@@ -588,6 +603,14 @@ def main():
                 "kernel": dom, "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     elif dom == "bg_ring_solve":
         roof = solve_roof()
+    elif dom in ("spatial_proj_rows", "temporal_proj_rows") and (proj_roofs() or {}).get(dom):
+        # bg_ssub > 1, sweep-free: the largest kernel is the fp64 projection of the video rows under the search masks (one read of those rows)
+        pr = proj_roofs()[dom]
+        roof = {"bound": "hbm", "achieved": pr["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pr["frac"], "traffic": None, "kernel": dom,
+                "ms_per_launch": pr["ms_per_update"], "algorithmic_bytes_per_launch": pr["algorithmic_bytes_per_update"],
+                "note": "bg_ssub = %d: no kernel dominates the sweep-free iteration (the low-resolution fit's solve and window projection, two reads of the low-resolution "
+                        "video and these rows of the full-resolution one are 0.7-1.1 ms each -- roofline_projections); this is the pass over the pixel rows under the search "
+                        "masks, strided 16-byte reads per entry, fp64 sums" % a.bg_ssub}
     else:
         roof = {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": dom,
                 "ms_per_launch": kern[dom]["ms_per_call"]}
@@ -622,10 +645,13 @@ def main():
                                ("%s (weak): %dx%dx%d fp32 video per GPU, K=%d per GPU, ring_radius=%d, 1 patch per GPU (%d patches), "
                                 "spatial=%s, deconv_flag=%s, bg_ssub=%d" % (a.config, d1, d2p, T, Kp, r, n_patches, a.alg, "true" if a.deconv else "false", a.bg_ssub)),
                    "iteration": "update_background_parallel + update_spatial_parallel + update_temporal_parallel",
-                   "formulation": ("sweep-free residual (option r1_virtual = 1, the default): the spatial update reads Ysig*C' = P - W*P out of the fit's table "
+                   "formulation": ("sweep-free residual through the resampling maps (option ssub_virtual = 1, the default): Ysig*C' = P_F - up(W_L*P_L) with P_F the video rows "
+                                   "under the masks and P_L the table of the low-resolution video, A'*Ysig = A'*Yc - B_L'*(down Yc), B_L = W_L'*up'*A; same values as the swept "
+                                   "residual (tests/test_gpu_ssub_virtual.py)" if a.bg_ssub != 1 and os.environ.get("CNMFE_OPTS", "").find("ssub_virtual=0") < 0 and os.environ.get("CNMFE_OPTS", "").find("r1_virtual=0") < 0 else
+                                  ("sweep-free residual (option r1_virtual = 1, the default): the spatial update reads Ysig*C' = P - W*P out of the fit's table "
                                    "P = Yc*Cc', the temporal update projects the centred video through B = A - W'*A; same values as the swept residual "
                                    "(tests/test_gpu_virtual.py); the ring sweep itself is timed separately for `roofline_r1`")
-                                  if os.environ.get("CNMFE_OPTS", "").find("r1_virtual=0") < 0 else "swept residual (r1_virtual = 0): one ring sweep per iteration",
+                                  if os.environ.get("CNMFE_OPTS", "").find("r1_virtual=0") < 0 and a.bg_ssub == 1 else "swept residual (r1_virtual = 0 / ssub_virtual = 0): one ring sweep per iteration"),
                    "parallelism": ("patches round-robin over %d rank(s)" % world) if not shard_of else
                                   ("rank 0 of %d: this rank's %d of the %d patches on ONE GPU, no collectives (a per-rank load figure, not a scaling point); "
                                    "the video is uploaded as fp16 and widened on the device" % (shard_of, len(video.owned), len(video.order))),

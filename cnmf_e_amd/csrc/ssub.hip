@@ -289,32 +289,69 @@ int ssub_derive(cnmfe_ctx *ctx, Patch *S, int dst_id, int ssub, int mode) {
     return 0;
 }
 
-// A restricted to the sampled pixels (nearest) or pushed through the bicubic downsample (linear map): d_low x K CSC
+// A restricted to the sampled pixels (nearest) or pushed through the bicubic downsample (linear map): d_low x K CSC.
+// Round 5: on the host's critical path once the sweep left the iteration (1.9 ms per call at H) -- 'nearest' is a filter through two look-up tables, the bicubic map
+// accumulates every column in the dense low-resolution box of its taps (flat transposed taps; the same sums in the same order as the first version's hash-and-sort).
 static void a_low(const Patch *S, int ssub, bool nearest, int32_t K, const int64_t *cp, const int32_t *ri, const float *va,
                   std::vector<int64_t> &ocp, std::vector<int32_t> &ori, std::vector<float> &ova) {
     int d1s, d2s; low_dims(S, ssub, d1s, d2s);
     Taps tr = make_taps(S->nr_b, d1s, 1.0 / ssub, nearest), tc = make_taps(S->nc_b, d2s, 1.0 / ssub, nearest);
-    // transposed taps: for every input index the (output, weight) pairs it feeds
-    std::vector<std::vector<std::pair<int, float>>> fr(S->nr_b), fc(S->nc_b);
-    for (int o = 0; o < d1s; ++o) for (int i = 0; i < tr.P; ++i) { const float w = tr.w[(size_t)o * tr.P + i]; if (w != 0.f) fr[tr.idx[(size_t)o * tr.P + i]].push_back({o, w}); }
-    for (int o = 0; o < d2s; ++o) for (int j = 0; j < tc.P; ++j) { const float w = tc.w[(size_t)o * tc.P + j]; if (w != 0.f) fc[tc.idx[(size_t)o * tc.P + j]].push_back({o, w}); }
-    const int64_t dl = (int64_t)d1s * d2s;
-    std::vector<double> acc((size_t)dl, 0.0);
-    std::vector<char> hit((size_t)dl, 0);
-    std::vector<int32_t> touched;
     ocp.assign(K + 1, 0); ori.clear(); ova.clear();
+    ori.reserve((size_t)cp[K] / (nearest ? 2 : 1) + 16); ova.reserve((size_t)cp[K] / (nearest ? 2 : 1) + 16);
+    if (nearest) {
+        // (the weight of the one kept tap is 1: rows normalised; an input index sampled by no output is dropped)
+        std::vector<int> rlow((size_t)S->nr_b, -1), clow((size_t)S->nc_b, -1);
+        bool simple = true;
+        auto fill = [&](const Taps &t, std::vector<int> &low) {
+            for (int o = 0; o < t.n_out; ++o)
+                for (int i = 0; i < t.P; ++i) if (t.w[(size_t)o * t.P + i] != 0.f) { int &l = low[t.idx[(size_t)o * t.P + i]]; if (l >= 0 || t.w[(size_t)o * t.P + i] != 1.f) simple = false; l = o; }
+        };
+        fill(tr, rlow); fill(tc, clow);
+        if (simple) {
+            for (int32_t k = 0; k < K; ++k) {
+                for (int64_t e = cp[k]; e < cp[k + 1]; ++e) {
+                    const int pr = rlow[ri[e] % S->nr_b], pc = clow[ri[e] / S->nr_b];
+                    if (pr >= 0 && pc >= 0 && va[e] != 0.f) { ori.push_back(pc * d1s + pr); ova.push_back(va[e]); }
+                }
+                ocp[k + 1] = (int64_t)ori.size();
+            }
+            return;
+        }
+    }
+    // transposed taps, flat: for every input index the (output, weight) pairs it feeds, outputs ascending
+    auto transpose = [](const Taps &t, std::vector<int> &ptr, std::vector<int> &out, std::vector<float> &w) {
+        ptr.assign((size_t)t.n_in + 1, 0);
+        for (int o = 0; o < t.n_out; ++o) for (int i = 0; i < t.P; ++i) if (t.w[(size_t)o * t.P + i] != 0.f) ++ptr[t.idx[(size_t)o * t.P + i] + 1];
+        for (int j = 0; j < t.n_in; ++j) ptr[j + 1] += ptr[j];
+        out.resize((size_t)ptr[t.n_in]); w.resize((size_t)ptr[t.n_in]);
+        std::vector<int> cur(ptr.begin(), ptr.end() - 1);
+        for (int o = 0; o < t.n_out; ++o) for (int i = 0; i < t.P; ++i) { const float v = t.w[(size_t)o * t.P + i]; if (v != 0.f) { const int q = cur[t.idx[(size_t)o * t.P + i]]++; out[q] = o; w[q] = v; } }
+    };
+    std::vector<int> rp, ro, cq, co; std::vector<float> rw, cw;
+    transpose(tr, rp, ro, rw); transpose(tc, cq, co, cw);
+    std::vector<double> box;
     for (int32_t k = 0; k < K; ++k) {
-        touched.clear();
+        int r0 = INT_MAX, r1 = -1, c0 = INT_MAX, c1 = -1;              // the low-resolution box of this column's taps
         for (int64_t e = cp[k]; e < cp[k + 1]; ++e) {
             const int r = ri[e] % S->nr_b, c = ri[e] / S->nr_b;
-            for (auto &pr : fr[r]) for (auto &pc : fc[c]) {
-                const int32_t q = pc.first * d1s + pr.first;
-                if (!hit[q]) { hit[q] = 1; touched.push_back(q); }
-                acc[q] += (double)pr.second * pc.second * va[e];
-            }
+            if (rp[r + 1] > rp[r]) { r0 = std::min(r0, ro[rp[r]]); r1 = std::max(r1, ro[rp[r + 1] - 1]); }
+            if (cq[c + 1] > cq[c]) { c0 = std::min(c0, co[cq[c]]); c1 = std::max(c1, co[cq[c + 1] - 1]); }
         }
-        std::sort(touched.begin(), touched.end());
-        for (int32_t q : touched) { if (acc[q] != 0.0) { ori.push_back(q); ova.push_back((float)acc[q]); } acc[q] = 0.0; hit[q] = 0; }
+        if (r1 >= r0 && c1 >= c0) {
+            const int h = r1 - r0 + 1, w = c1 - c0 + 1;
+            box.assign((size_t)h * w, 0.0);
+            for (int64_t e = cp[k]; e < cp[k + 1]; ++e) {
+                const int r = ri[e] % S->nr_b, c = ri[e] / S->nr_b;
+                const float v = va[e];
+                for (int a = rp[r]; a < rp[r + 1]; ++a) {
+                    const float wr_ = rw[a];
+                    double *col0 = box.data() + (ro[a] - r0);
+                    for (int b = cq[c]; b < cq[c + 1]; ++b) col0[(size_t)(co[b] - c0) * h] += (double)wr_ * cw[b] * v;
+                }
+            }
+            for (int c = 0; c < w; ++c)
+                for (int r = 0; r < h; ++r) { const double x = box[(size_t)c * h + r]; if (x != 0.0) { ori.push_back((c0 + c) * d1s + (r0 + r)); ova.push_back((float)x); } }
+        }
         ocp[k + 1] = (int64_t)ori.size();
     }
 }
@@ -323,9 +360,12 @@ int ssub_fit(cnmfe_ctx *ctx, Patch *M, Patch *F, Patch *R, int ssub, int32_t K, 
              const float *C, int c_order, int with_projection, int64_t info[4], double thresh_outlier) {
     std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
     ctx->bgs_patch = -1;                                   // W changes: a kept W*R_low (cnmfe_background_ssub) is stale
+    HostTrace ht(ctx, "fit_ssub");
     if (K > 0) a_low(M, ssub, true, K, cp, ri, va, ocp, ori, ova);
+    ht.mark("nearest(A)");
     // b0 = mean(Y - A*C, 2) on the patch pixels (:222-223) = Ymean - A*mean(C): independent of W, so it goes first (a short, synchronous call)
     RET(bg_fit_ring(ctx, M, K, cp, ri, va, C, c_order, with_projection, nullptr, nullptr, /*b0_only=*/1));
+    ht.mark("b0");
     // W: fit_ring_model(imresize(Y - A*C, 1/s, 'nearest'), [], [], W_old, ...)  (update_background_parallel.m:224-227).  The call returns with the
     // Gram / solve kernels in flight (its host staging has been consumed); the copy of W to the residual patch is ordered behind them.
     RET(bg_fit_ring(ctx, F, K, K > 0 ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, with_projection, nullptr, info, /*A = [] for ind_active*/ 2,
@@ -477,7 +517,9 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     if (R->d1 != d1s || R->d2 != d2s || R->T != M->T) return fail(CNMFE_ESTATE, "patch %d is not the low-resolution residual patch of patch %d", res_id, pid);
     std::vector<int64_t> ocp; std::vector<int32_t> ori; std::vector<float> ova;
     const bool has_a = K > 0 && cp[K] > 0;
+    HostTrace ht(ctx, "residual_ssub");
     if (has_a) a_low(M, ssub, false, K, cp, ri, va, ocp, ori, ova);
+    ht.mark("down(A_prev)");
     RET(ssub_taps(ctx, M, R));
     M->ss_res = res_id; M->ss_ssub = ssub;
     // Ysig = [Y' + (Ymean - b0) - up(W down(Y'))] + up(W down(A_prev)) (C - mean C): while the video, W (of the residual patch) and b0 are
@@ -491,6 +533,7 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     const bool tables = reuse || virt_new;
     RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, tables ? 1 : 0));
     const int64_t ldc_t = ctx->last_ldc;
+    ht.mark("low-resolution W*A tables");
     // the centred traces of this call move to the patch (pendCc / resCc) and the buffer the patch held before comes back as tmp[1]: a swap
     // both ways, no hipMalloc / hipFree per call (the guard hands the leftover buffer back on every exit path)
     struct GiveBack { DevBuf b; DevBuf &home; ~GiveBack() { if (b.p && !home.p) b.swap(home); } } gb{DevBuf(), ctx->tmp[1]};

@@ -155,7 +155,10 @@ int cnmfe_fit_ring_model_ssub(cnmfe_ctx *ctx, int patch_id, int fit_patch, int r
 
 /* update_spatial_parallel.m:167-178 == update_temporal_parallel.m:153-165:
  *   Ysig = Y(ind_patch,:) - imresize(W * imresize(R - mean(R,2), 1/s), [nr_block nc_block])(ind_patch,:) - b0,  R = Y - A_prev*C_prev.
- * The result stays resident as the Ysig of patch_id (for cnmfe_update_spatial / cnmfe_hals_temporal / cnmfe_get_sn). */
+ * The result stays resident as the Ysig of patch_id (for cnmfe_update_spatial / cnmfe_hals_temporal / cnmfe_get_sn).
+ * Round 5: with Ysig_out == NULL the request is only RECORDED (as cnmfe_residual does since round 4; option ssub_virtual): cnmfe_update_spatial and
+ * cnmfe_hals_temporal take Ysig*C' and A'*Ysig through the two resampling maps from the video rows under the masks / footprints and the low-resolution video of
+ * res_patch (fp64 sums); every other consumer runs the low-resolution sweep and its upsample first.  res_patch must stay alive until the next fit / upload. */
 int cnmfe_residual_ssub(cnmfe_ctx *ctx, int patch_id, int res_patch, int32_t ssub, int32_t Ksel, const int64_t *A_colptr,
                         const int32_t *A_rowidx, const float *A_val, const float *C, int c_order,
                         float *Ysig_out /* d x T or NULL */, int out_memspace);
@@ -403,7 +406,8 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  * planes, exact int32 accumulation, up to 24576 used frames; 0: the fp64 matrix pipe), win_i8 (default 1: the digit planes stay resident -- one more video's worth
  * of memory, taken only when that leaves 8 GB free -- and every fit's window projection runs on the int8 pipe; 0: the fp64 kernel on the centred video),
  * proj_tiled (default 1: the temporal projection reads a copy of the centred video in its own read order -- again one video's worth, same rule; 0: the frame-major
- * video).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
+ * video), ssub_virtual (default 1: cnmfe_residual_ssub without an output buffer records its request too, and the two updates project through the resampling maps --
+ * the rows of the video under the masks / footprints and the low-resolution video; 0: the low-resolution sweep + upsample of rounds 2-4).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
  * accepted and ignored: gram_mode, gram_flush, solve_defer and the experiment switches of rounds 2-3.
  * Every option can be preset for a process with CNMFE_OPTS="name=value,..." (logged once on stderr). */
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);
