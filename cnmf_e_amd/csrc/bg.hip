@@ -630,7 +630,8 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
                     const int i2 = i + dR, j2 = j + dC;
                     if (i2 >= pi0 && i2 <= pi1 && j2 >= pj0 && j2 <= pj1) ++npairs;
                 }
-    const int64_t Tpad = (P->T + GK - 1) / GK * GK;
+    const bool i8 = ctx->opt("gram_i8", 1) != 0 && P->T <= 24576;                   // (as bg_fit_ring decides for a stride-1 build: steps of four 16-frame stages)
+    const int64_t Tpad = i8 ? (P->T + 4 * GK - 1) / (4 * GK) * (4 * GK) : (P->T + GK - 1) / GK * GK;
     const size_t tab = (size_t)npairs * BLKPX * BLKPX * sizeof(double);
     RET(P->cov_base.ensure(tab));
     RET(P->rowsum_base.ensure((size_t)nblk * BLKPX * sizeof(double)));
@@ -648,6 +649,20 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
             CK(hipMemGetInfo(&fr, &tot));
             if (fr >= sys_bytes + ((size_t)8 << 30)) { P->sys_valid = false; RET(P->sys.ensure(sys_bytes)); }
         }
+    }
+    // round 5: the two further copies of the video (digit planes of the window projection, the temporal projection's read-order copy) under the rule their builders
+    // apply -- one more video's worth each, only if that leaves 8 GB free.  Allocated HERE, while the caller sets its patches up: a fresh 10 GB hipMalloc takes 0.3 ms
+    // on most leases and 1-3 SECONDS on some (profiles/r05/first_iteration_stall.txt: one run in five, inside the first iteration's temporal projection)
+    auto reserve = [&](DevBuf &b, size_t bytes) -> int {
+        if (b.cap >= bytes) return 0;
+        size_t fr = 0, tot = 0;
+        CK(hipMemGetInfo(&fr, &tot));
+        if (fr >= bytes + ((size_t)8 << 30)) RET(b.ensure(bytes));
+        return 0;
+    };
+    if (!P->derived) {
+        if (i8 && ctx->opt("win_i8", 1) != 0) { RET(reserve(P->dig, (size_t)nblk * Tpad * BLKPX * sizeof(float))); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double))); }
+        if (ctx->opt("proj_tiled", 1) != 0 && ctx->opt("r1_virtual", 1) != 0) RET(reserve(P->yt4, (size_t)nblk * ((P->Tc + 15) >> 4) * 64 * 64 * sizeof(float4)));
     }
     return 0;
 }

@@ -10,6 +10,7 @@ export CNMFE_BENCH_R1=0
 python bench.py $X --alg hals_thresh > $o/bench_c3_hals_thresh_$ver.json 2>/dev/null
 python bench.py $X --alg nnls > $o/bench_c3_nnls_$ver.json 2>/dev/null
 python bench.py $X --bg-ssub 2 > $o/bench_c3_bg_ssub2_$ver.json 2>/dev/null
+CNMFE_OPTS=ssub_virtual=0 python bench.py $X --bg-ssub 2 > $o/bench_c3_bg_ssub2_swept_$ver.json 2>/dev/null
 python bench.py $X --deconv > $o/bench_c3_deconv_$ver.json 2>/dev/null
 python bench.py $X --bg-ssub 2 --deconv --alg hals_thresh > $o/bench_c3_demo_defaults_$ver.json 2>/dev/null
 python bench.py $X --config c2 > $o/bench_c2_$ver.json 2>/dev/null
