@@ -653,11 +653,13 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
     // round 5: the two further copies of the video (digit planes of the window projection, the temporal projection's read-order copy) under the rule their builders
     // apply -- one more video's worth each, only if that leaves 8 GB free.  Allocated HERE, while the caller sets its patches up: a fresh 10 GB hipMalloc takes 0.3 ms
     // on most leases and 1-3 SECONDS on some (profiles/r05/first_iteration_stall.txt: one run in five, inside the first iteration's temporal projection)
+    // (AHEAD of time only while a quarter of the device stays free: the buffers every patch's fit and updates must have are allocated later, and 64 patches
+    //  reserving down to the builders' 8 GB left none for them -- tests/test_gpu_zconfigs.py::test_c5_whole_on_one_gpu; below that the builders decide as before)
     auto reserve = [&](DevBuf &b, size_t bytes) -> int {
         if (b.cap >= bytes) return 0;
         size_t fr = 0, tot = 0;
         CK(hipMemGetInfo(&fr, &tot));
-        if (fr >= bytes + ((size_t)8 << 30)) RET(b.ensure(bytes));
+        if (fr >= bytes + std::max((size_t)8 << 30, tot / 4)) RET(b.ensure(bytes));
         return 0;
     };
     if (!P->derived) {
