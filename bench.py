@@ -501,7 +501,7 @@ def main():
         if a.no_extras or a.config != "c3" or world != 1 or a.bg_ssub != 1 or a.deconv or os.environ.get("CNMFE_BENCH_PMC", "1") == "0" or not shutil.which("rocprofv3"):
             return None
         import csv, glob
-        keys = ("k_ring_solve", "k_vp_proj_b", "k_win_proj", "k_residual_duo")
+        keys = ("k_ring_solve", "k_vp_proj_", "k_win_proj", "k_residual_duo")
         res = {k: {} for k in keys}
         for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
             tmp = tempfile.mkdtemp(prefix="cnmfe_pmc_", dir="/tmp")
@@ -559,7 +559,7 @@ def main():
     def with_pmc(pr):
         # fabric traffic of the two video passes: from this run's PMC passes, else from the committed ones (said so)
         if pr:
-            for name, sub in (("temporal_proj_B", "k_vp_proj_b"), ("bg_win_proj", "k_win_proj")):
+            for name, sub in (("temporal_proj_B", "k_vp_proj_"), ("bg_win_proj", "k_win_proj")):
                 if name in pr and not live_traffic(pr[name], sub):
                     pr[name]["traffic"] = pmc_traffic(sub)
                     pr[name]["traffic_source"] = None if pr[name]["traffic"] is None else "NOT this run: 2 x FETCH_SIZE + WRITE_SIZE of the newest profiles/r*/bench_c3_pmc_{FETCH,WRITE}_SIZE_v*.csv"

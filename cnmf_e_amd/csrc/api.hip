@@ -534,7 +534,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual", "prealloc", "solve_packed", "gram_i8", "win_i8", "proj_tiled", "ssub_virtual",
+    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual", "prealloc", "solve_packed", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "ssub_virtual",
                                   /* retired experiment switches (rounds 2-3): still accepted, ignored -- scripts/r1_probe.py, r1_duo.py, solve_ab.py name them */
                                   "r1_arc_d", "r1_arc_bias", "r1_duo_ord", "solve_mode", "gram_kernel", "solve_gfill", "solve_defer", "gram_mode", "gram_flush", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; if (!strcmp(name, "host_trace")) ctx->trace_level = (int)value; return 0; }
@@ -611,7 +611,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     CK(hipStreamSynchronize(ctx->st()));
     std::fill(P->frame_seen.begin() + t0, P->frame_seen.begin() + t0 + nt, (uint8_t)1);
     P->frames_uploaded += nt;
-    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->sys_valid = false; P->sys_alt_valid = false; P->pt_valid = false; P->dig_valid = false; P->yt4_valid = false;
+    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->sys_valid = false; P->sys_alt_valid = false; P->pt_valid = false; P->dig_valid = false; P->digp_valid = false; P->yt4_valid = false;
     return 0;
 }
 

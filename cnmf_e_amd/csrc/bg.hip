@@ -664,7 +664,9 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
     };
     if (!P->derived) {
         if (i8 && ctx->opt("win_i8", 1) != 0) { RET(reserve(P->dig, (size_t)nblk * Tpad * BLKPX * sizeof(float))); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double))); }
-        if (ctx->opt("proj_tiled", 1) != 0 && ctx->opt("r1_virtual", 1) != 0) RET(reserve(P->yt4, (size_t)nblk * ((P->Tc + 15) >> 4) * 64 * 64 * sizeof(float4)));
+        const bool pi8 = i8 && ctx->opt("win_i8", 1) != 0 && ctx->opt("proj_i8", 1) != 0;      // the temporal projection on the int8 pipe reads pixel-major planes instead
+        if (pi8 && ctx->opt("r1_virtual", 1) != 0) RET(reserve(P->digp, (size_t)nblk * Tpad * BLKPX * sizeof(float)));
+        else if (ctx->opt("proj_tiled", 1) != 0 && ctx->opt("r1_virtual", 1) != 0) RET(reserve(P->yt4, (size_t)nblk * ((P->Tc + 15) >> 4) * 64 * 64 * sizeof(float4)));
     }
     return 0;
 }
@@ -1024,7 +1026,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             if (resident) {
                 RET(P->dig.ensure(dbytes)); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double)));
                 digp = P->dig.as<uint4>(); digs = P->dig_sc.as<double>();
-                P->dig_T16 = g.Tpad >> 4; P->dig_valid = true;
+                P->dig_T16 = g.Tpad >> 4; P->dig_valid = true; P->digp_valid = false;
             } else {
                 RET(ctx->dig_scale.ensure((size_t)nblk * BLKPX * sizeof(double)));
                 digp = ctx->bf.as<uint4>(); digs = ctx->dig_scale.as<double>();

@@ -193,6 +193,7 @@ struct Patch {
     // (win_proj_i8.hpp) when the memory allows: frame stride 1 only
     DevBuf dig, dig_sc; int64_t dig_T16 = 0; bool dig_valid = false;
     DevBuf yt4; bool yt4_valid = false;                   // vproj.hip: the centred video tiled by 16 x 16 block (k_tile_video), for the temporal projection
+    DevBuf digp; bool digp_valid = false;                 // vproj_i8.hpp: the digit planes once more, pixel-major (k_dig_pixmajor), for the temporal projection on the int8 pipe
     // bg_ssub > 1 (ssub.hip, round 5: the sweep-free residual of res_kind 2): the low-resolution residual patch and the factor of the last cnmfe_residual_ssub, and
     // imresize's bicubic UPSAMPLING taps of the block region's rows / columns (low-resolution index + weight, ss_Pr / ss_Pc per row / column) on the host and the
     // device, their ranges per row / column (made monotone: ss_rlo[r] <= every tap index of the rows >= r, ss_rhi[r] >= those of the rows <= r), and the

@@ -15,6 +15,7 @@
 // The pending footprint term enters both updates through their projections as before (residual_term_fold_spatial / residual_term_project, resid.hip).
 #include "common.hpp"
 #include "win_proj.hpp"
+#include "vproj_i8.hpp"
 #include <climits>
 
 namespace cnmfe {
@@ -486,6 +487,42 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
     if (nent > 0)
         LAUNCH(ctx, "temporal_build_B", k_vp_build_b, dim3((unsigned)nent), dim3(256), 0, dEb.as<int>(), dEk.as<int>(), dEs.as<int>(), dG16.as<int>(), g, R, dColptr, dErow, dAval,
                P->ring_dr.as<int>(), P->ring_dc.as<int>(), P->W.as<float>(), dBt.as<double>());
+    // round 5 (late): on the int8 pipe out of the video's digit planes when the fit left them resident (vproj_i8.hpp) -- their pixel-major copy is made once per upload
+    bool i8 = !P->derived && P->dig_valid && ctx->opt("proj_i8", 1) != 0 && nent > 0 && P->dig_T16 * 16 >= ldu;
+    if (i8 && !P->digp_valid) {
+        const size_t dbytes = (size_t)nblk * P->dig_T16 * 16 * 64 * sizeof(uint4);
+        if (P->digp.cap < dbytes) { size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot)); i8 = fr >= dbytes + ((size_t)8 << 30); }
+        if (i8) {
+            RET(P->digp.ensure(dbytes));
+            LAUNCH(ctx, "temporal_dig_pixmajor", k_dig_pixmajor, dim3((unsigned)nblk, (unsigned)P->dig_T16), dim3(256), 0, P->dig.as<uint4>(), P->dig_T16, P->digp.as<uint4>());
+            P->digp_valid = true;
+        }
+    }
+    LAUNCH(ctx, "temporal_const", k_vp_const, dim3((unsigned)K), dim3(256), 0, dColptr, dErow, dAval, g, P->ymean_d.as<double>(), P->b0.as<double>(), dCst.as<double>());
+    if (i8) {
+        const int ngrp = L.g16[nblk];
+        std::vector<int> grp_blk((size_t)std::max(1, ngrp), 0);
+        for (int b = 0; b < nblk; ++b) for (int q = L.g16[b]; q < L.g16[b + 1]; ++q) grp_blk[q] = b;
+        DevBuf &dGb = V[24], &dBd = V[25], &dBs = V[26];
+        RET(to_dev(ctx, dGb, grp_blk.data(), grp_blk.size()));
+        RET(dBd.ensure_hw((size_t)std::max(1, ngrp) * 1024 * sizeof(uint4), ctx->hw_vp[25]));
+        RET(dBs.ensure_hw((size_t)std::max(1, ngrp) * 16 * sizeof(double), ctx->hw_vp[26]));
+        LAUNCH(ctx, "temporal_panel_dig", k_vp_bdig, dim3((unsigned)ngrp), dim3(256), 0, dBt.as<double>(), dGb.as<int>(), P->dig_sc.as<double>(), dBd.as<uint4>(), dBs.as<double>());
+        const int64_t T16 = P->dig_T16;
+        int off = 0;
+        for (int t = 3; t >= 0; --t) {
+            const int nb_ = (int)L.blk_nt[t].size();
+            if (!nb_) continue;
+            const int total = (int)L.blall.size();
+            const int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((T16 + 7) / 8, (VP_WG_TARGET + total - 1) / std::max(1, total)));
+            const size_t shmem = (size_t)(t + 1) * 1024 * sizeof(uint4);
+#define VP_GO8(NT_) LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_i8<NT_>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->digp.as<uint4>(), T16, ctx->vp[11].as<int>() + off, \
+                           ctx->vp[5].as<int>(), ctx->vp[4].as<int>(), dBd.as<uint4>(), dBs.as<double>(), nsg, dPart.as<double>(), ldp)
+            if (t == 0) VP_GO8(1); else if (t == 1) VP_GO8(2); else if (t == 2) VP_GO8(3); else VP_GO8(4);
+#undef VP_GO8
+            off += nb_;
+        }
+    } else {
     // the block-tiled copy of the centred video (k_tile_video), built at the first projection of a patch when the memory allows
     bool tiled = false;
     if (!P->derived && ctx->opt("proj_tiled", 1) != 0) {
@@ -502,8 +539,8 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
         }
         tiled = P->yt4_valid;
     }
-    LAUNCH(ctx, "temporal_const", k_vp_const, dim3((unsigned)K), dim3(256), 0, dColptr, dErow, dAval, g, P->ymean_d.as<double>(), P->b0.as<double>(), dCst.as<double>());
     RET(vp_launch_proj(ctx, P, g, L, tiled, ldp));
+    }
     LAUNCH(ctx, "temporal_reduce_B", k_vp_reduce, dim3((unsigned)((ldu + 255) / 256), (unsigned)K), dim3(256), 0, dPart.as<double>(), ldp, dNptr.as<int>(), dNent.as<int>(),
            dCst.as<double>(), P->T, dU, ldu);
     ht.mark("launches");

@@ -406,7 +406,8 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  * planes, exact int32 accumulation, up to 24576 used frames; 0: the fp64 matrix pipe), win_i8 (default 1: the digit planes stay resident -- one more video's worth
  * of memory, taken only when that leaves 8 GB free -- and every fit's window projection runs on the int8 pipe; 0: the fp64 kernel on the centred video),
  * proj_tiled (default 1: the temporal projection reads a copy of the centred video in its own read order -- again one video's worth, same rule; 0: the frame-major
- * video), ssub_virtual (default 1: cnmfe_residual_ssub without an output buffer records its request too, and the two updates project through the resampling maps --
+ * video), proj_i8 (default 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes -- instead of the read-order copy, same size, same
+ * rule; needs win_i8; 0: the fp64 matrix pipe), ssub_virtual (default 1: cnmfe_residual_ssub without an output buffer records its request too, and the two updates project through the resampling maps --
  * the rows of the video under the masks / footprints and the low-resolution video; 0: the low-resolution sweep + upsample of rounds 2-4).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
  * accepted and ignored: gram_mode, gram_flush, solve_defer and the experiment switches of rounds 2-3.
  * Every option can be preset for a process with CNMFE_OPTS="name=value,..." (logged once on stderr). */

@@ -1,5 +1,6 @@
 """Round 5's int8 matrix-pipe paths (cnmf_e_amd/csrc/gram_i8.hpp, win_proj_i8.hpp) and the temporal projection's read-order copy (vproj.hip, k_tile_video)
-against the fp64 kernels they replace, on one engine and the same uploads: options gram_i8 / win_i8 / proj_tiled 1 (defaults) vs 0.
+against the fp64 kernels they replace, on one engine and the same uploads: options gram_i8 / win_i8 / proj_i8 (vproj_i8.hpp: the temporal projection on the int8 pipe) 1
+(defaults) vs 0; and the read-order copy of the fp64 temporal projection (proj_tiled, what runs when proj_i8 is off) against the frame-major video.
 
 The int8 paths accumulate EXACTLY (int32) over a 32-bit fixed-point quantisation of the data, so they differ from the fp64 kernels only by that quantisation:
 1e-8 of W in the CPU emulation (scripts/probes/gram_i8_emulation.py), a last-bit flip of the fp32 weights on the GPU.  Through the default settings of every other
@@ -54,14 +55,18 @@ def test_int8_paths_equal_the_fp64_kernels(dims, T, r, K, pdims):
     d1, d2 = dims
     f, Y = _case(d1, d2, T, K, r, 23, min_sep=3 if K > 20 else 5)
     W1, A1, C1, n1 = _run({}, f, Y, d1, d2, T, r, pdims)
-    W0, A0, C0, n0 = _run({"gram_i8": 0, "win_i8": 0, "proj_tiled": 0}, f, Y, d1, d2, T, r, pdims)
-    assert "bg_gram_i8" in n1 and "bg_trace_gram" in n1 and "temporal_tile_video" in n1, n1      # the new paths really ran ...
-    assert "bg_gram_f64" in n0 and "bg_gram_i8" not in n0 and "bg_trace_gram" not in n0 and "temporal_tile_video" not in n0, n0      # ... and really did not
+    W0, A0, C0, n0 = _run({"gram_i8": 0, "win_i8": 0, "proj_i8": 0, "proj_tiled": 0}, f, Y, d1, d2, T, r, pdims)
+    assert "bg_gram_i8" in n1 and "bg_trace_gram" in n1 and "temporal_dig_pixmajor" in n1 and "temporal_panel_dig" in n1, n1      # the new paths really ran ...
+    assert "bg_gram_f64" in n0 and "bg_gram_i8" not in n0 and "bg_trace_gram" not in n0 and "temporal_tile_video" not in n0 and "temporal_panel_dig" not in n0, n0      # ... and really did not
     for a, b in zip(W1, W0):
         assert np.all(np.isfinite(a))
         assert rel(a, b) <= 5e-7, rel(a, b)                      # observed 2e-8 .. 9e-8 (last-bit flips of the fp32 weights)
     assert np.array_equal(A1 != 0, A0 != 0)
     assert rel(A1, A0) <= 2e-6 and rel(C1, C0) <= 2e-6, (rel(A1, A0), rel(C1, C0))
+    # the fp64 temporal projection on its read-order copy of the video (what a patch without resident digit planes runs)
+    W2, A2, C2, n2 = _run({"proj_i8": 0}, f, Y, d1, d2, T, r, pdims)
+    assert "temporal_tile_video" in n2 and "temporal_panel_dig" not in n2, n2
+    assert rel(A2, A0) <= 2e-6 and rel(C2, C0) <= 2e-6, (rel(A2, A0), rel(C2, C0))
 
 
 def test_int8_table_of_a_strided_fit_and_without_footprints():
