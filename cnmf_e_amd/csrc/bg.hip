@@ -662,11 +662,16 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
         if (fr >= bytes + std::max((size_t)8 << 30, tot / 4)) RET(b.ensure(bytes));
         return 0;
     };
+    // (only a recording whose fits use every frame keeps digit planes: the stride floor(T / min(T, 100 pmax)) of fit_ring_model.m:84-87 starts at pmax = p and only grows)
+    const bool stride1 = P->T / std::max<int64_t>(1, std::min<int64_t>(P->T, (int64_t)P->p * 100)) <= 1;
     if (!P->derived) {
-        if (i8 && ctx->opt("win_i8", 1) != 0) { RET(reserve(P->dig, (size_t)nblk * Tpad * BLKPX * sizeof(float))); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double))); }
-        const bool pi8 = i8 && ctx->opt("win_i8", 1) != 0 && ctx->opt("proj_i8", 1) != 0;      // the temporal projection on the int8 pipe reads pixel-major planes instead
-        if (pi8 && ctx->opt("r1_virtual", 1) != 0) RET(reserve(P->digp, (size_t)nblk * Tpad * BLKPX * sizeof(float)));
-        else if (ctx->opt("proj_tiled", 1) != 0 && ctx->opt("r1_virtual", 1) != 0) RET(reserve(P->yt4, (size_t)nblk * ((P->Tc + 15) >> 4) * 64 * 64 * sizeof(float4)));
+        const bool planes = i8 && stride1 && ctx->opt("win_i8", 1) != 0;
+        const bool pi8 = planes && ctx->opt("proj_i8", 1) != 0;      // the temporal projection on the int8 pipe reads pixel-major planes instead of the read-order copy
+        if (planes) { RET(reserve(P->dig, (size_t)nblk * Tpad * BLKPX * sizeof(float))); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double))); }
+        if (ctx->opt("r1_virtual", 1) != 0) {
+            if (pi8) RET(reserve(P->digp, (size_t)nblk * Tpad * BLKPX * sizeof(float)));
+            else if (ctx->opt("proj_tiled", 1) != 0) RET(reserve(P->yt4, (size_t)nblk * ((P->Tc + 15) >> 4) * 64 * 64 * sizeof(float4)));
+        }
     }
     return 0;
 }
