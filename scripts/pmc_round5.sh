@@ -10,7 +10,7 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_
   timeout 200 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pm_r5 -o x -- $cmd > /dev/null 2> /tmp/pm_r5.err
   python - <<'PY' >> $O/summary.txt
 import csv, collections, glob
-names = {"k_ring_solve6": "bg_ring_solve (k_ring_solve6<6>)", "k_vp_proj_b": "temporal_proj_B (k_vp_proj_b<1, true>)", "k_win_proj_i8": "bg_win_proj (k_win_proj_i8)"}
+names = {"k_ring_solve6": "bg_ring_solve (k_ring_solve6<6>)", "k_vp_proj_i8": "temporal_proj_B (k_vp_proj_i8<1>)", "k_vp_proj_b": "temporal_proj_B (k_vp_proj_b<1, true>, proj_i8 = 0)", "k_win_proj_i8": "bg_win_proj (k_win_proj_i8)"}
 fs = glob.glob("/tmp/pm_r5/**/*counter_collection.csv", recursive=True)
 if not fs: print("no counters:", open("/tmp/pm_r5.err").read()[-400:])
 for f in fs:
