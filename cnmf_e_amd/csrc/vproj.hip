@@ -12,6 +12,8 @@
 //   a block-tiled projection of the centred video on the fp64 matrix pipe: per 16x16 block of pixels the neurons whose B meets it (<= 64), contraction over
 //   the block's 256 pixels, partial sums per (block, neuron) added in a fixed order (bit-reproducible).  One read of the video.
 // Everything is accumulated in fp64 from exact fp32 products, so the cancellation between the A and W'A parts of B (the background they remove) costs nothing.
+// Round 5: with the video's digit planes resident the same contraction runs on the int8 matrix pipe (vproj_i8.hpp: exact int32 sums of 32-bit fixed-point operands,
+// the partial sums still fp64); the fp64 kernel below serves the patches without planes.
 // The pending footprint term enters both updates through their projections as before (residual_term_fold_spatial / residual_term_project, resid.hip).
 #include "common.hpp"
 #include "win_proj.hpp"
