@@ -1,13 +1,14 @@
 """Phase probes of the ring-regression solve kernel on one patch: python scripts/solve_ab.py --cfg c3 [--probes 0,1,3,7]
-(solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions, 8 no footprint corrections).  Every run fits the same
-first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_variant of round 5's experiment (scripts/probes/solve_r5/: the
-patch, what the variants are, what they measured); without the patch the runs only repeat.  The weights of every mode are compared with the first's."""
+(solve_probe bits: 1 no table loads, 2 no factorisation, 4 return before the substitutions, 8 no footprint corrections, 16 no refinement (fp32 solve only)).
+Every run fits the same first-run problem (ring re-initialised before each fit).  --modes = values of the option solve_f32 (0: k_ring_solve6, fp64 tiles; 1:
+k_ring_solve7, fp32 factorisation + fp64 refinement: round 6's experiment, scripts/probes/solve_r6/ -- without the patch the runs only repeat).  The weights of every mode are compared with the first's.  --refit: a second fit with the footprints in
+(not a first run: only the active pixels are solved, the corrections apply)."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="0"); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0)
+ap.add_argument("--cfg", default="c3"); ap.add_argument("--modes", default="0"); ap.add_argument("--reps", type=int, default=1); ap.add_argument("--probes", default="0"); ap.add_argument("--radius", type=int, default=0); ap.add_argument("--refit", type=int, default=0)
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -27,8 +28,8 @@ for mode in [int(x) for x in a.modes.split(",")]:
     for probe in [int(x) for x in a.probes.split(",")]:
         eng.ring_init(0, r)
         eng.set_option("solve_probe", probe)
-        try: eng.set_option("solve_variant", mode)          # (only builds with scripts/probes/solve_r5/variants.patch applied know the option)
-        except Exception: eng.set_option("solve_pair", mode)  # the shipped build: 0 one pixel per wave (k_ring_solve6), 1 two (k_ring_solve_pair)
+        try: eng.set_option("solve_f32", mode)              # (only builds with scripts/probes/solve_r6/f32_refine.patch applied know the option)
+        except Exception: print("(this build has no option solve_f32: mode %d only repeats the shipped kernel)" % mode, flush=True)
         ts = []
         for rep in range(a.reps):
             eng.ring_init(0, r); eng.profile_reset()
@@ -39,6 +40,12 @@ for mode in [int(x) for x in a.modes.split(",")]:
         print("mode %d probe %d: bg_ring_solve %s ms   (%s)" % (mode, probe, " ".join("%.3f" % t for t in ts), info), flush=True)
         if probe == 0:
             Ws[mode] = eng.ring_csr(0).data.copy()
+        if probe & 256:                                     # k_ring_solve7's diagnostic rows: W(0, :) = refinement steps taken, W(1, :) = |d_1| / |x|
+            Wd = eng.ring_csr(0)
+            full = np.flatnonzero(np.diff(Wd.indptr) == info["pmax"])
+            nit = Wd.data[Wd.indptr[full]]; eta = Wd.data[Wd.indptr[full] + 1]
+            print("  refinement steps (pixels with a whole ring: %d): %s;  |d_1|/|x| quantiles 10/50/90/99/100%%: %s" % (
+                full.size, dict(zip(*np.unique(nit, return_counts=True))), " ".join("%.2e" % q for q in np.quantile(eta, [0.1, 0.5, 0.9, 0.99, 1.0]))), flush=True)
 ks = list(Ws)
 for k in ks[1:]:
     dW = np.abs(Ws[k] - Ws[ks[0]])
