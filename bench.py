@@ -575,16 +575,24 @@ def main():
         acts = [int(i_.get("n_active", -1)) for i_ in infos]
         n_act = (sum(acts) / float(len(acts))) if acts and min(acts) >= 0 else d / float(max(1, len(video.owned)))
         ms = kern["bg_ring_solve"]["ms_per_call"]
-        fl = n_act * 2.0 * (n ** 3 / 3.0 + 2.0 * n * n)
-        return {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / F64_MFMA_PEAK_TF, "traffic": None,
-                "kernel": "bg_ring_solve", "ms_per_launch": ms, "algorithmic_flops_per_launch": fl,
-                "algorithmic_bytes_per_launch": n_act * 8.0 * ((((n - 1 + 15) // 16) * (((n - 1 + 15) // 16) + 1) // 2) * 256 + ((n - 1 + 15) // 16) * 16),
-                "note": "fp64 Cholesky + substitutions of %d independent %dx%d systems per launch (one per active pixel: 2(n^3/3 + 2n^2) flops each; the footprints' rank-2 "
-                        "corrections -- 4 n^2 flops per neuron around a pixel -- are NOT counted), priced against the fp64 peak (78.6 TFLOP/s, matrix and vector pipes alike).  "
-                        "One wave per pixel, the matrix in MFMA accumulator tiles (v_mfma_f64_16x16x4).  Since round 4 the systems are loaded from a per-pixel packed copy of the "
-                        "video's table (algorithmic_bytes_per_launch, coalesced: 1.9 ms at 6 TB/s, overlapped with other waves' arithmetic) and corrected in registers "
-                        "(option solve_packed); the 16x16 diagonal steps and the substitutions run on the vector pipe and bound the kernel -- DESIGN.md section 3"
-                        % (int(n_act), n, n)}
+        # a Cholesky is n^3 / 3 flops, the two substitutions 2 n^2 (round 5 priced twice that: multiply-adds counted as two)
+        fl = n_act * (n ** 3 / 3.0 + 2.0 * n * n)
+        nt_ = (n - 1 + 15) // 16
+        by = n_act * 8.0 * ((nt_ * (nt_ + 1) // 2) * 256 + nt_ * 16)
+        # both bounds: the packed systems take longer to stream at the HBM peak than the flops take at the fp64 peak -- the bytes are the roofline of this kernel
+        t_fl, t_by = fl / (F64_MFMA_PEAK_TF * 1e12), by / (HBM_PEAK_GBS * 1e9)
+        bytes_bound = t_by >= t_fl
+        return {"bound": "hbm" if bytes_bound else "mfma",
+                "achieved": by / ms / 1e6 if bytes_bound else fl / ms / 1e9, "peak": HBM_PEAK_GBS if bytes_bound else F64_MFMA_PEAK_TF, "unit": "GB/s" if bytes_bound else "TFLOP/s",
+                "frac": (by / ms / 1e6 / HBM_PEAK_GBS) if bytes_bound else (fl / ms / 1e9 / F64_MFMA_PEAK_TF), "traffic": None,
+                "kernel": "bg_ring_solve", "ms_per_launch": ms, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                "frac_of_hbm_peak": by / ms / 1e6 / HBM_PEAK_GBS, "frac_of_fp64_peak": fl / ms / 1e9 / F64_MFMA_PEAK_TF,
+                "note": "fp64 Cholesky + substitutions of %d independent %dx%d systems per launch (one per active pixel: n^3/3 + 2n^2 flops each, SURVEY.md 8(d); the footprints' "
+                        "rank-2 corrections -- 4 n^2 flops per neuron around a pixel -- are NOT counted), loaded from a per-pixel packed copy of the video's table (43 KB per pixel at "
+                        "p = 96, coalesced) and corrected in registers.  Priced against both bounds (frac_of_hbm_peak, frac_of_fp64_peak); the bytes are the binding one.  One wave per "
+                        "pixel, the matrix in MFMA accumulator tiles (v_mfma_f64_16x16x4); what holds the kernel at this fraction is neither pipe but the LATENCY of its dependent "
+                        "chains at two waves per SIMD (four dependent gathers of the set-up, 6 x 240 DPP FMAs of the diagonal steps, the substitutions' LDS round trips) -- "
+                        "DESIGN.md section 3, scripts/probes/solve_r5 and solve_r6 (fp32 + refinement: measured slower)" % (int(n_act), n, n)}
     if dom.startswith("bg_gram"):                                # (only with --warmup 0: the table of the video is built once per recording)
         if dom == "bg_gram_i8":                                  # 13 int8 digit-pair products per fp32-equivalent product (gram_i8.hpp), priced against the int8 matrix peak
             roof = gram_roof(dom, I8_MFMA_PEAK_TOPS)

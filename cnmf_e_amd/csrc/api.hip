@@ -339,8 +339,10 @@ int ctx_errflag(cnmfe_ctx *ctx, int **dflag) {
     return 0;
 }
 // what a raised error word means: clears it, drops every table a later call would trust, and reports
-static int errflag_raise(cnmfe_ctx *ctx, int h) {
-    CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
+// `taken`: the device word was already read AND cleared at the point of the stream the flag `h` stands for (a ticket's k_flag_take) -- clearing it again here
+// would wipe what kernels queued behind that point have raised since
+static int errflag_raise(cnmfe_ctx *ctx, int h, bool taken = false) {
+    if (!taken) CK(hipMemsetAsync(ctx->errflag.p, 0, sizeof(int), ctx->st()));
     // whatever raised the flag left truncated or inconsistent tables behind (the footprint terms beside a residual, a P table): nothing kept with the patches may
     // be trusted by a later call -- the next residual sweeps again, the next spatial update builds its own table
     for (auto &kv : ctx->patches) { Patch *q = kv.second; q->ysig_valid = false; q->ysig_virtual = false; q->pend = false; q->res_ac = false; q->res_kind = 0; q->pt_valid = false; }
@@ -358,6 +360,10 @@ int ctx_check_errflag(cnmfe_ctx *ctx) {
     if (!h) return 0;
     return errflag_raise(ctx, h);
 }
+// a ticket's share of the error word: what the kernels in front of it raised since the last take, read and cleared in ONE step at the ticket's place in the stream.
+// (A plain copy at record time + a clear at wait time reported one fault once per outstanding ticket -- every raise invalidating state the caller had rebuilt in
+//  between -- and the clear wiped faults raised behind the ticket.)
+__global__ void k_flag_take(int *__restrict__ flag, int *__restrict__ out) { *out = atomicExch(flag, 0); }
 
 // ---- T5: stitch accumulator (update_temporal_parallel.m:264-280) ------------------------------------------------------------------
 // acc[row][t] += aa_m(j) * C_raw_m(j, t), row = ind_m[j]; the weight sum lives in column ld - 4 of the same row
@@ -887,8 +893,10 @@ static int ticket_record(cnmfe_ctx *ctx, int64_t *ticket) {
     }
     if (ctx->errflag.p && t < cnmfe_ctx::TICKET_FLAGS) {
         if (!ctx->ticket_flags) { CK(hipHostMalloc((void **)&ctx->ticket_flags, cnmfe_ctx::TICKET_FLAGS * sizeof(int), hipHostMallocDefault)); memset(ctx->ticket_flags, 0, cnmfe_ctx::TICKET_FLAGS * sizeof(int)); }
+        RET(ctx->ticket_dev.ensure(cnmfe_ctx::TICKET_FLAGS * sizeof(int)));
         ctx->ticket_flags[t] = 0;
-        CK(hipMemcpyAsync(&ctx->ticket_flags[t], ctx->errflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
+        hipLaunchKernelGGL(k_flag_take, dim3(1), dim3(1), 0, ctx->st(), ctx->errflag.as<int>(), ctx->ticket_dev.as<int>() + t);
+        CK(hipMemcpyAsync(&ctx->ticket_flags[t], ctx->ticket_dev.as<int>() + t, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
     }
     CK(hipEventRecord(ctx->tickets[t], ctx->st()));
     ctx->ticket_busy[t] = 1;
@@ -911,10 +919,11 @@ int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket) {
     CK(hipSetDevice(ctx->device));
     CK(hipEventSynchronize(ctx->tickets[ticket]));
     ctx->ticket_busy[ticket] = 0;
-    if (ctx->ticket_flags && (size_t)ticket < cnmfe_ctx::TICKET_FLAGS && ctx->ticket_flags[ticket]) {
+    if ((size_t)ticket >= cnmfe_ctx::TICKET_FLAGS) return ctx_check_errflag(ctx);          // (more tickets outstanding than flag slots: the whole stream's word, at the price of a drain)
+    if (ctx->ticket_flags && ctx->ticket_flags[ticket]) {
         const int h = ctx->ticket_flags[ticket];
         ctx->ticket_flags[ticket] = 0;
-        return errflag_raise(ctx, h);
+        return errflag_raise(ctx, h, true);
     }
     return 0;
 }

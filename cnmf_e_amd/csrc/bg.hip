@@ -1016,7 +1016,6 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         const int tchunk = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 7) & ~int64_t(7));
         dim3 gb(nblk, (unsigned)((g.Tpad + tchunk - 1) / tchunk));
         RET(rsT.ensure((size_t)nblk * BLKPX * sizeof(double)));
-        if (g.bf4 == 3) CK(hipMemsetAsync(rsT.p, 0, (size_t)nblk * BLKPX * sizeof(double), ctx->st()));
         uint4 *digp = nullptr; double *digs = nullptr;          // where the digit planes of this build live
         if (use_i8) {
             // the VIDEO's planes stay resident with the patch (the fits' window projection reads them, win_proj_i8.hpp) when one more video's worth of memory
@@ -1042,7 +1041,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             const int tchunk16 = (int)((std::max<int64_t>(64, (g.Tpad + 15) / 16) + 15) & ~int64_t(15));
             const dim3 gd(nblk, (unsigned)((g.Tpad + tchunk16 - 1) / tchunk16));
             LAUNCH(ctx, "bg_dig_scale", k_dig_scale, gd, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, da, tchunk16, ctx->dig_smax.as<unsigned>());
-            LAUNCH(ctx, "bg_build_dig", k_build_dig, gd, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, da, ctx->dig_smax.as<unsigned>(), digs, digp, tchunk16, rsT.as<double>());
+            RET(ctx->dig_rspart.ensure((size_t)gd.y * nblk * BLKPX * sizeof(double)));
+            LAUNCH(ctx, "bg_build_dig", k_build_dig, gd, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, da, ctx->dig_smax.as<unsigned>(), digs, digp, tchunk16, ctx->dig_rspart.as<double>());
+            LAUNCH(ctx, "bg_rs_reduce", k_rs_reduce, dim3((unsigned)nblk), dim3(256), 0, ctx->dig_rspart.as<double>(), (int)gd.y, (int64_t)nblk * BLKPX, rsT.as<double>());
         } else
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());

@@ -285,7 +285,8 @@ struct cnmfe_ctx {
     int64_t copy_gen = 0; std::vector<std::pair<int64_t, hipEvent_t>> copy_gens; std::vector<hipEvent_t> copy_ev_pool;
     int copy_batch_mark();                                 // api.hip: after the last enqueue of a batch on copy_stream
     std::vector<hipEvent_t> tickets; std::vector<char> ticket_busy;   // cnmfe_update_spatial_fetch_async / cnmfe_ticket_wait
-    int *ticket_flags = nullptr;                           // pinned, TICKET_FLAGS words: the device error word as it stood when ticket t was recorded (copied behind the ticket's work)
+    int *ticket_flags = nullptr;                           // pinned, TICKET_FLAGS words: what the kernels in front of ticket t raised since the previous take (k_flag_take: read and cleared at the ticket's place in the stream)
+    cnmfe::DevBuf ticket_dev;                              // the device side of those words
     static constexpr size_t TICKET_FLAGS = 1024;
     cnmfe::Profiler prof;
     std::map<int, cnmfe::Patch *> patches;
@@ -302,6 +303,7 @@ struct cnmfe_ctx {
     int bgs_patch = -1, bgs_d1s = 0; int64_t bgs_dF = 0;   // the patch bgs_b belongs to (cnmfe_background_ssub)
     cnmfe::DevBuf bf;         // tiled centred background residual  [blk][t'][256] fp32
     cnmfe::DevBuf dig_smax;   // gram_i8.hpp: per block-region pixel max |Bf| (float bits) of the build in flight
+    cnmfe::DevBuf dig_rspart; // gram_i8.hpp: per frame chunk the row sums of the build in flight (reduced in a fixed order by k_rs_reduce)
     cnmfe::DevBuf dig_scale;  // gram_i8.hpp: per block-region pixel the scale of its 32-bit fixed-point trace (the int8-digit table build)
     cnmfe::DevBuf tdig, tscale, gk, win_items;   // win_proj_i8.hpp: digit planes / scales of the centred traces, their K x K Gram matrix, the (block, trace group) work items
     cnmfe::DevBuf bf2, outl_cnt, outl_sel;   // outlier branch of the ring fit: clipped copy of bf, outliers per frame, kept frames

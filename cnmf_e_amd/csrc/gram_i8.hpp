@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(256) k_dig_scale(const float4 *__restrict__ Y4
 }
 
 // digit planes dig[((blk * T16 + s) * 4 + plane) * 256 + lp] (16 bytes = the digits of frames 16 s .. 16 s + 15, zero behind the used frames); scale = the pixel's
-// smax / (2^31 - 2^24) (1 for an all-zero or out-of-region pixel), written by the first frame chunk; rs += the exact row sums of the fp32 values (the ones row of
-// the regression: not quantised)
+// smax / (2^31 - 2^24) (1 for an all-zero or out-of-region pixel), written by the first frame chunk; rs[chunk][blk][lp] = this frame chunk's row sums of the fp32
+// values (the ones row of the regression: not quantised)
 __global__ void __launch_bounds__(256) k_build_dig(const float4 *__restrict__ Y4, int64_t Tc, BgGeom g, DigA A, const unsigned *__restrict__ smax, double *__restrict__ scale,
                                                    uint4 *__restrict__ dig, int tchunk, double *__restrict__ rs) {
     const int blk = blockIdx.x, bi = blk % g.nbr, bj = blk / g.nbr, lp = threadIdx.x;
@@ -119,7 +119,15 @@ __global__ void __launch_bounds__(256) k_build_dig(const float4 *__restrict__ Y4
 #pragma unroll
         for (int p = 0; p < 4; ++p) o[p * BLKPX] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
     }
-    if (rs) atomicAdd(&rs[(int64_t)blk * BLKPX + lp], rsum);
+    if (rs) rs[((int64_t)blockIdx.y * gridDim.x + blk) * BLKPX + lp] = rsum;       // per frame chunk: k_rs_reduce adds the chunks in a fixed order (an fp64 atomicAdd here made
+}                                                                                   // the row sums -- and through them W -- differ in the last bits from run to run)
+
+__global__ void __launch_bounds__(256) k_rs_reduce(const double *__restrict__ part, int nchunk, int64_t n, double *__restrict__ rs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[(int64_t)c * n + i];
+    rs[i] = s;
 }
 
 constexpr int GI_STAGE_B = 16384;            // a 16-frame stage in LDS: [A half: plane(4) x 128 px x 16 B][B half: the same]

@@ -1116,8 +1116,7 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
            &dWaCnt = ctx->tmp[8], &dWaK = ctx->tmp[9], &dWaV = ctx->tmp[10];
     int64_t ldc = 4;
     bool has_ac = Ksel > 0 && A_colptr[Ksel] > 0;
-    // everything below reads W (the ELL rows of W A_prev, a sweep) -- except a request without footprints that is only recorded: then a pending half of the
-    if (has_ac || Ysig_out || outbuf || tables_only || ctx->opt("r1_virtual", 1) == 0 || ctx->opt("r1_lazy", 1) == 0 || ctx->opt("r1_delta", 1) == 0)    if (has_ac) {
+    if (has_ac) {
         RET(upload_centered(ctx, dC, C, Ksel, T, c_order, dCc, dCm, &ldc));
         HostCSR csr; csc_to_csr(P->d_b, Ksel, A_colptr, A_rowidx, A_val, csr);
         RET(to_dev(ctx, dArow, csr.rowptr.data(), csr.rowptr.size()));

@@ -529,7 +529,11 @@ int ssub_residual(cnmfe_ctx *ctx, Patch *M, int pid, Patch *R, int res_id, int s
     // the temporal update take their projections through the resampling maps (vproj.hip, vproj_*_ssub), every other consumer realises it (ssub_realize).
     const bool lazy = ctx->opt("r1_delta", 1) != 0;
     const bool reuse = M->ysig_valid && M->res_kind == 2 && (M->ysig.p || M->ysig_virtual) && lazy;
-    const bool virt_new = !reuse && !Ysig_out && lazy && ctx->opt("ssub_virtual", 1) != 0 && ctx->opt("r1_virtual", 1) != 0 && ctx->opt("r1_lazy", 1) != 0;
+    // (ssub_virtual 1, the default: only where it pays -- profiles/r05/ssub_virtual_check.txt: the sweep-free form wins at 512 x 512 x 10000 (8.2 against 13.9 ms per
+    //  iteration) and loses on patches of 256 x 256 x 3000 and below (5.8 against 4.6 ms: its list building, k_vp_build_b_ssub and two extra passes over the
+    //  low-resolution video outweigh a sweep that small); 2: always)
+    const int64_t sv = ctx->opt("ssub_virtual", 1);
+    const bool virt_new = !reuse && !Ysig_out && lazy && (sv >= 2 || (sv == 1 && (double)M->d_b * (double)M->T >= 5e8)) && ctx->opt("r1_virtual", 1) != 0 && ctx->opt("r1_lazy", 1) != 0;
     const bool tables = reuse || virt_new;
     RET(residual_run(ctx, R, res_id, has_a ? K : 0, has_a ? ocp.data() : nullptr, ori.data(), ova.data(), C, c_order, nullptr, CNMFE_HOST, &ctx->ysig_low, tables ? 1 : 0));
     const int64_t ldc_t = ctx->last_ldc;

@@ -407,8 +407,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  * of memory, taken only when that leaves 8 GB free -- and every fit's window projection runs on the int8 pipe; 0: the fp64 kernel on the centred video),
  * proj_tiled (default 1: the temporal projection reads a copy of the centred video in its own read order -- again one video's worth, same rule; 0: the frame-major
  * video), proj_i8 (default 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes -- instead of the read-order copy, same size, same
- * rule; needs win_i8; 0: the fp64 matrix pipe), ssub_virtual (default 1: cnmfe_residual_ssub without an output buffer records its request too, and the two updates project through the resampling maps --
- * the rows of the video under the masks / footprints and the low-resolution video; 0: the low-resolution sweep + upsample of rounds 2-4).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
+ * rule; needs win_i8; 0: the fp64 matrix pipe), ssub_virtual (cnmfe_residual_ssub without an output buffer records its request too, and the two updates project through the resampling maps --
+ * the rows of the video under the masks / footprints and the low-resolution video: 2 always, 1 (default) on patches of at least 5e8 samples -- below that the low-resolution
+ * sweep is the faster form, profiles/r05/ssub_virtual_check.txt --, 0: the low-resolution sweep + upsample of rounds 2-4).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
  * accepted and ignored: gram_mode, gram_flush, solve_defer and the experiment switches of rounds 2-3.
  * Every option can be preset for a process with CNMFE_OPTS="name=value,..." (logged once on stderr). */
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);

@@ -1,4 +1,4 @@
-"""bg_ssub > 1, sweep-free (option ssub_virtual = 1, vproj_*_ssub) against the swept residual (0) on one engine build: A, C, W after full iterations, and which kernels ran.
+"""bg_ssub > 1, sweep-free (option ssub_virtual = 2: forced; 1, the default, decides by patch size; vproj_*_ssub) against the swept residual (0) on one engine build: A, C, W after full iterations, and which kernels ran.
     python scripts/ssub_virtual_check.py [--cfg small|mid|c3] [--ssub 2] [--iters 2] [--pdims 64,64]"""
 import argparse, os, sys, time
 import numpy as np
@@ -19,7 +19,7 @@ pd = [int(x) for x in a.pdims.split(",")] if a.pdims else [d1, d2]
 res = {}
 for virt in (1, 0):
     eng = Engine(0)
-    eng.set_option("ssub_virtual", virt)
+    eng.set_option("ssub_virtual", 2 if virt else 0)
     video = PatchedVideo(d1, d2, T, pd, r, eng)
     video.upload_from_full(Y)
     s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=a.alg, maxIter=3, bg_ssub=a.ssub), f.A_init, f.C_init, f.sn)

@@ -1,4 +1,4 @@
-"""bg_ssub > 1 without the sweep (round 5: option ssub_virtual, default 1; cnmf_e_amd/csrc/vproj.hip vproj_spatial_ssub / vproj_temporal_ssub, ssub.hip ssub_realize):
+"""bg_ssub > 1 without the sweep (round 5: option ssub_virtual: 2 always, 1 -- the default -- on patches of 5e8 samples and more; cnmf_e_amd/csrc/vproj.hip vproj_spatial_ssub / vproj_temporal_ssub, ssub.hip ssub_realize):
 cnmfe_residual_ssub only RECORDS the request, the spatial and the temporal update take Ysig C' and A' Ysig through the resampling maps
 (update_spatial_parallel.m:167-178, update_temporal_parallel.m:153-165), every other consumer realises the residual (low-resolution sweep + upsample) first.
 
@@ -26,7 +26,7 @@ def _run(virt, f, Y, d1, d2, T, r, pdims, ssub, alg="hals", iters=2, update_sn=F
     from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
     eng = Engine(0)
     try:
-        eng.set_option("ssub_virtual", virt)
+        eng.set_option("ssub_virtual", 2 if virt else 0)      # (1, the default, takes the sweep-free form only on patches large enough for it to pay)
         video = PatchedVideo(d1, d2, T, pdims or [d1, d2], r, eng)
         video.upload_from_full(Y)
         s = Sources2D(video, Options(ring_radius=r, spatial_algorithm=alg, maxIter=3, bg_ssub=ssub), f.A_init, f.C_init, f.sn)
