@@ -45,6 +45,7 @@ PATCHES = {"c4": [128, 128], "c4tiny": [48, 48], "c5shard": [128, 128]}
 SHARD_OF = {"c5shard": 8}    # configurations that run one rank's patches of an N-rank decomposition without the collectives (a per-rank load figure, not a scaling point)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (157.3 TF), spec
+F32_VECTOR_PEAK_TF = 157.3   # fp32 vector (= fp32 matrix) peak, spec
 F32_MFMA_PEAK_TF = 157.3
 I8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA, spec (MI355X_MICROARCH.md measures >= 3944 TOPS on 16x16x64); the int8 Gram issues 13 digit-pair products per fp32-equivalent product
 
@@ -431,10 +432,15 @@ def main():
             return None
         bytes_r1 = 4.0 * d_b * T + 4.0 * d * T + 8.0 * d * p + 4.0 * (Kp if not sharded_fov else Kp * d_b / float(d1 * d2)) * T       # read Y + write Ysig + W + C
         ms = src["ms_per_call"]
+        # the sweep is a per-pixel weighted sum of p neighbours per frame (every pixel its own p weights: no shared operand, no matrix form): 2 p d T flops on the
+        # fp32 VECTOR pipe.  At p = 96 those take longer at the vector peak (157.3 TFLOP/s) than the bytes take at the HBM peak: both fractions are reported
+        flops_r1 = 2.0 * p * d * T
         return {"bound": "hbm", "achieved": bytes_r1 / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_r1 / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "residual_r1", "ms_per_launch": ms,
-                "algorithmic_bytes_per_launch": bytes_r1, "timed": src["from"],
-                "in_iteration": "residual_r1" in kern}
+                "algorithmic_bytes_per_launch": bytes_r1, "algorithmic_flops_per_launch": flops_r1,
+                "frac_of_fp32_vector_peak": flops_r1 / ms / 1e9 / F32_VECTOR_PEAK_TF,
+                "min_ms_at_hbm_peak": bytes_r1 / (HBM_PEAK_GBS * 1e6), "min_ms_at_vector_peak": flops_r1 / (F32_VECTOR_PEAK_TF * 1e9),
+                "timed": src["from"], "in_iteration": "residual_r1" in kern}
     def proj_roofs():
         """the two projection kernels (north_star's "residual projections"): S1 U = Ysig*C' on the search mask (HALS_spatial.m:27-32) and T1
         U = A'*Ysig (HALS_temporal.m:48).  Algorithmic bytes = the rows of Ysig a launch needs, once (pixels under the mask / under a footprint,
@@ -691,8 +697,8 @@ def main():
     # the driver's record keeps `roofline`, `config` and `cpu_baseline` whole and only the NAMES of the other keys: the iteration's other large kernels, the share of
     # the step the kernels fill and the cold figure ride along inside `roofline` (verdict r4 #8)
     if out["roofline"] is not None:
-        top = sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
-        out["roofline"]["top3_kernels_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in top}
+        top = sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])[:5]
+        out["roofline"]["top5_kernels_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in top}
         out["roofline"]["kernel_sum_over_step"] = round(out["kernel_sum_ms_per_step"] / out["ms_per_step"], 4)
         out["roofline"]["ms_per_step_incl_cold"] = None if out["ms_per_step_incl_cold"] is None else round(out["ms_per_step_incl_cold"], 2)
         out["roofline"]["first_iteration_ms"] = None if not warm_steps_ms else round(warm_steps_ms[0], 2)
@@ -702,6 +708,7 @@ def main():
                                            for k, v in pr_.items() if k in ("temporal_proj_B", "bg_win_proj")} or None
         if out.get("roofline_r1"):
             out["roofline"]["r1_sweep_not_in_iteration"] = {"ms": round(out["roofline_r1"]["ms_per_launch"], 3), "frac_of_hbm": round(out["roofline_r1"]["frac"], 3),
+                                                            "frac_of_fp32_vector_peak": round(out["roofline_r1"]["frac_of_fp32_vector_peak"], 3),
                                                             "traffic_over_algorithmic": None if not out["roofline_r1"].get("traffic") else
                                                             round(out["roofline_r1"]["traffic"] / out["roofline_r1"]["algorithmic_bytes_per_launch"], 3)}
     eng.close()

@@ -347,7 +347,7 @@ static int errflag_raise(cnmfe_ctx *ctx, int h, bool taken = false) {
     // be trusted by a later call -- the next residual sweeps again, the next spatial update builds its own table
     for (auto &kv : ctx->patches) { Patch *q = kv.second; q->ysig_valid = false; q->ysig_virtual = false; q->pend = false; q->res_ac = false; q->res_kind = 0; q->pt_valid = false; }
     ctx->bgs_patch = -1;
-    if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 32 footprints of A_prev (flag %d)", h);
+    if (h & 2) return fail(CNMFE_EUNSUPPORTED, "a pixel's ring touches more than 256 footprints of A_prev (flag %d)", h);
     if (h & 4) return fail(CNMFE_EUNSUPPORTED, "bg_ssub > 1: a pixel's interpolation window meets more than 64 footprints of A_prev (flag %d)", h);
     return fail(CNMFE_ESTATE, "a kernel met an inconsistent table (flag %d): the ring regression needed a block pair the covariance table does not hold", h);
 }

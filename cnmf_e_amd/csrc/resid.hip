@@ -101,8 +101,11 @@ __global__ void k_dlt(const float *__restrict__ ymean_f, const double *__restric
 }
 
 // W*A_prev per patch pixel (ELL rows): wa(m,k) = sum_i W(m,i) * A_prev(m + o_i, k), accumulated in ring order.
-// One thread per pixel; its <= WA_CAP (k, value) slots live in LDS ([slot][thread], conflict-free).
+// One thread per pixel; its first WA_CAP (k, value) slots live in registers (4) and LDS ([slot][thread], conflict-free), slots beyond that -- a ring over more than
+// 32 footprints: rare -- where the table itself lies (round 6: `cap` rows are allocated, max(32, min(K, WA_CAP_MAX)); the reference has no such limit,
+// fit_ring_model.m:28 / update_spatial_parallel.m:162-166; only a ring over more than WA_CAP_MAX footprints still raises the error flag).
 constexpr int WA_CAP_ = 32;
+constexpr int WA_CAP_MAX = 256;
 // STAGE: the (column, value) arrays of the block's CSR are copied to LDS first (dynamic, 8 B per entry) and the per-entry loop reads them there.  A pixel
 // whose ring crosses footprints walks tens of entries one dependent load after the other; out of L2 that walk made the kernel's duration (70-130 us for
 // a 128 x 128 patch, as much as for the 512 x 512 frame) -- what a small patch's footprints need fits the LDS many times over.
@@ -110,7 +113,7 @@ template <bool STAGE>
 __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, int64_t d, int nr, int nr_b, int nc_b, int roff, int coff, int p,
                                                  const int *__restrict__ dr, const int *__restrict__ dc, const int *__restrict__ arow,
                                                  const int *__restrict__ acol_g, const float *__restrict__ aval_g, int nnz,
-                                                 int *__restrict__ wa_cnt, int *__restrict__ wa_k, float *__restrict__ wa_v, int *__restrict__ overflow) {
+                                                 int *__restrict__ wa_cnt, int *__restrict__ wa_k, float *__restrict__ wa_v, int *__restrict__ overflow, int cap) {
     __shared__ int tk[WA_CAP_][128];
     __shared__ float tv[WA_CAP_][128];
     extern __shared__ __attribute__((aligned(16))) char wa_dyn[];
@@ -160,12 +163,15 @@ __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, in
                     ++n;
                 } else {
                     int s = 4;
-                    while (s < n && tk[s][t] != k) ++s;
+                    while (s < n && s < WA_CAP_ && tk[s][t] != k) ++s;
+                    if (s == WA_CAP_) while (s < n && wa_k[(int64_t)s * d + m] != k) ++s;          // (beyond the LDS slots: the table's own rows, this thread's column)
                     if (s == n) {
-                        if (n == WA_CAP_) { atomicOr(overflow, 2); continue; }     // (bit 1 of the context's error flag: reported at the next wait)
-                        tk[s][t] = k; tv[s][t] = 0.f; ++n;
+                        if (n == cap) { atomicOr(overflow, 2); continue; }         // (bit 1 of the context's error flag: reported at the next wait)
+                        if (s < WA_CAP_) { tk[s][t] = k; tv[s][t] = 0.f; } else { wa_k[(int64_t)s * d + m] = k; wa_v[(int64_t)s * d + m] = 0.f; }
+                        ++n;
                     }
-                    tv[s][t] = fmaf(w, a, tv[s][t]);
+                    if (s < WA_CAP_) tv[s][t] = fmaf(w, a, tv[s][t]);
+                    else wa_v[(int64_t)s * d + m] = fmaf(w, a, wa_v[(int64_t)s * d + m]);
                 }
             }
     }
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(128) k_ring_wa(const float *__restrict__ W, in
     if (n > 1) { wa_k[d + m] = rk1; wa_v[d + m] = rv1; }
     if (n > 2) { wa_k[2 * d + m] = rk2; wa_v[2 * d + m] = rv2; }
     if (n > 3) { wa_k[3 * d + m] = rk3; wa_v[3 * d + m] = rv3; }
-    for (int s = 4; s < n; ++s) { wa_k[(int64_t)s * d + m] = tk[s][t]; wa_v[(int64_t)s * d + m] = tv[s][t]; }
+    for (int s = 4; s < n && s < WA_CAP_; ++s) { wa_k[(int64_t)s * d + m] = tk[s][t]; wa_v[(int64_t)s * d + m] = tv[s][t]; }
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1123,9 +1129,10 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
         RET(to_dev(ctx, dAcol, csr.col.data(), csr.col.size()));
         RET(to_dev(ctx, dAval, csr.val.data(), csr.val.size()));
         RET(dWaCnt.ensure_hw(P->d * sizeof(int), ctx->hw_wa[0]));
-        RET(dWaK.ensure_hw((size_t)WA_CAP * P->d * sizeof(int), ctx->hw_wa[1]));
-        RET(dWaV.ensure_hw((size_t)WA_CAP * P->d * sizeof(float), ctx->hw_wa[2]));
-        // a ring that touches more than WA_CAP footprints raises the context's error flag (ctx_check_errflag at the next wait of this call chain: the
+        const int wa_cap = std::max(WA_CAP, std::min((int)Ksel, WA_CAP_MAX));        // a ring cannot touch more footprints than there are
+        RET(dWaK.ensure_hw((size_t)wa_cap * P->d * sizeof(int), ctx->hw_wa[1]));
+        RET(dWaV.ensure_hw((size_t)wa_cap * P->d * sizeof(float), ctx->hw_wa[2]));
+        // a ring that touches more than WA_CAP_MAX footprints raises the context's error flag (ctx_check_errflag at the next wait of this call chain: the
         // spatial / temporal update's own download) instead of costing a drain of the stream here -- with several patches per context that drain
         // was what kept the host from setting up patch m + 1 under patch m's kernels
         int *dErrWa = nullptr;
@@ -1137,11 +1144,11 @@ int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t 
                 CK(hipFuncSetAttribute((const void *)k_ring_wa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             LAUNCH(ctx, "r1_ring_wa", k_ring_wa<true>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), wa_stage, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
                    P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
-                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
+                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa, wa_cap);
         } else
             LAUNCH(ctx, "r1_ring_wa", k_ring_wa<false>, dim3((unsigned)((P->d + 127) / 128)), dim3(128), 0, P->W.as<float>(), P->d, P->nr, P->nr_b, P->nc_b,
                    P->roff, P->coff, P->p, P->ring_dr.as<int>(), P->ring_dc.as<int>(), dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), nnzA,
-                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa);
+                   dWaCnt.as<int>(), dWaK.as<int>(), dWaV.as<float>(), dErrWa, wa_cap);
     }
     if (tables_only) { ctx->last_ldc = ldc; return 0; }       // bg_ssub: the caller only wants (W*A) and the centred traces (tmp[8..10], tmp[1])
     // the footprint term this call leaves applied is kept beside Ysig (the scratch buffers above change hands with the patch's)

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-6 record: bench lines of every configuration DESIGN.md section 4 quotes + the rocprofv3 kernel statistics and PMC passes of the bench command.
+# On the GPU box: bash scripts/gpu_r5_profiles.sh <ver>   -> gpurun_out/r06/*_<ver>.json, gpurun_out/prof_r06<ver>/
+cd "$GRAFT_REPO_ROOT" || exit 1
+ver=${1:-v1}; o=gpurun_out/r06; mkdir -p $o
+export PYTHONUNBUFFERED=1
+python bench.py > $o/bench_c3_$ver.json 2> $o/bench_c3_$ver.err
+X="--no-extras --no-cpu-baseline"
+export CNMFE_BENCH_R1=0
+python bench.py $X --alg hals_thresh > $o/bench_c3_hals_thresh_$ver.json 2>/dev/null
+python bench.py $X --alg nnls > $o/bench_c3_nnls_$ver.json 2>/dev/null
+python bench.py $X --bg-ssub 2 > $o/bench_c3_bg_ssub2_$ver.json 2>/dev/null
+CNMFE_OPTS=ssub_virtual=0 python bench.py $X --bg-ssub 2 > $o/bench_c3_bg_ssub2_swept_$ver.json 2>/dev/null
+python bench.py $X --deconv > $o/bench_c3_deconv_$ver.json 2>/dev/null
+python bench.py $X --bg-ssub 2 --deconv --alg hals_thresh > $o/bench_c3_demo_defaults_$ver.json 2>/dev/null
+python bench.py $X --config c2 > $o/bench_c2_$ver.json 2>/dev/null
+python bench.py $X --config c4 --steps 5 > $o/bench_c4_n1_$ver.json 2>/dev/null
+python bench.py $X --config c5shard --steps 5 > $o/bench_c5shard_$ver.json 2>/dev/null
+python bench.py $X --config c5shard --steps 5 --deconv > $o/bench_c5shard_deconv_$ver.json 2>/dev/null
+python bench.py $X --warmup 0 --steps 5 > $o/bench_c3_warmup0_$ver.json 2>/dev/null
+python bench.py $X --demo-sequence > $o/bench_c3_demo_sequence_$ver.json 2>/dev/null
+CNMFE_OPTS=r1_virtual=0 python bench.py $X > $o/bench_c3_swept_$ver.json 2>/dev/null
+python scripts/rank_load.py > $o/rank_load_$ver.txt 2>&1
+CNMFE_BENCH_FORCE_COLLECTIVES=1 python bench.py $X --config c4 --steps 10 --warmup 4 > $o/bench_c4_forced_collectives_$ver.json 2>/dev/null
+unset CNMFE_BENCH_R1
+bash scripts/profile_round.sh r06$ver > /dev/null 2>&1
+for f in $o/bench_*_$ver.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-48s %8.3f %-22s ms/step %s  kernel sum %s" % (sys.argv[1].split("/")[-1], d["value"], d["unit"], d.get("ms_per_step"), d.get("kernel_sum_ms_per_step")))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done | tee $o/record_$ver.txt
+bash scripts/pmc_round5.sh > /dev/null 2>&1; cp gpurun_out/pmc_r05/summary.txt $o/pmc_pipes_$ver.txt 2>/dev/null
+tail -5 $o/rank_load_$ver.txt

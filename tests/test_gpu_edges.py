@@ -728,10 +728,11 @@ def test_lazy_traces_keep_their_iteration(eng):
         eng2.close()
 
 
-def test_more_footprints_on_a_ring_than_the_engine_holds(eng):
-    """A pixel whose ring touches more than 32 footprints of A_prev: CNMFE_EUNSUPPORTED.  The check rides on the context's error flag, so it is
-    reported by the first call of the chain that waits for the device -- here the export of the residual -- and the context stays usable."""
-    from cnmf_e_amd import _lib as L
+def test_more_footprints_on_a_ring_than_the_lds_slots_hold(eng):
+    """A pixel whose ring touches more than 32 footprints of A_prev (update_spatial_parallel.m:162-166 knows no such limit): until round 5 CNMFE_EUNSUPPORTED,
+    now the (W * A_prev) row of such a pixel continues where the table lies (k_ring_wa: 32 slots in registers / LDS, the rest in the table's own rows, as
+    many rows as there are footprints, up to 256) and the sweep's per-pixel fallback reads it from there.  Checked against the oracle's residual."""
+    import cnmfe_oracle as orc
     d1, d2, T, r = 48, 48, 64, 5
     f, Y, video = _video(eng, d1, d2, T, 3, r, 7)
     eng.ring_init(0, r)
@@ -741,10 +742,20 @@ def test_more_footprints_on_a_ring_than_the_engine_holds(eng):
     rows = [(24 + int(cs[i % rs.size]) + (i // rs.size)) * d1 + 24 + int(rs[i % rs.size]) for i in range(K)]
     A = sp.csc_matrix((np.ones(K, np.float32), (rows, np.arange(K))), shape=(d1 * d2, K))
     Cm = np.random.default_rng(0).random((K, T)).astype(np.float32)
-    with pytest.raises(L.CnmfeError, match="more than 32 footprints"):
-        eng.residual(0, A, Cm, want=True)
-    out = eng.residual(0, A[:, :20], Cm[:20], want=True)         # fine again with fewer
-    assert np.isfinite(out).all()
+    W = eng.ring_csr(0).astype(np.float64)
+    assert int(np.max(np.diff((abs(W) @ abs(A)).tocsr().indptr))) > 32          # (some ring does meet more than 32 of them)
+    b0f = Y.astype(np.float64).mean(axis=0).astype(np.float32)   # b0 = the pixels' means, as fp32 (what set_b0 takes): the constant term Ymean - b0 the sweep adds in
+    eng.set_b0(0, b0f)                                           # fp32 then stays small (at b0 = 0 it is ~1000 and its rounding, 3e-5, would hide what is checked here)
+    b0 = b0f.astype(np.float64)
+    Yb = Y.T.astype(np.float64)                                  # d x T: one patch = the field of view
+    for Ksel in (K, 20, K):                                      # with more, with fewer, with more again (the table's rows grow and are reused)
+        out = eng.residual(0, A[:, :Ksel], Cm[:Ksel], want=True)
+        ref = orc.residual_ysig(Yb, A[:, :Ksel].astype(np.float64), Cm[:Ksel], W, b0, np.ones(d1 * d2, dtype=bool))
+        # in units of the VIDEO (~1300 here: the sweep's fp32 arithmetic on the centred video leaves up to 2.3e-7 of that, whatever K -- scripts/dbg_cap.py); a footprint
+        # term lost beyond slot 32 would be ~4e-6 of it, on the crowded pixels
+        e = np.abs(out.T - ref).max(axis=1) / np.abs(Y).max()
+        crowded = np.diff((abs(W) @ abs(A[:, :Ksel])).tocsr().indptr) > 32
+        assert e.max() <= 5e-7 and (not crowded.any() or e[crowded].max() <= 1e-7), (Ksel, e.max(), e[crowded].max() if crowded.any() else None)
 
 
 def orc_nhood(r):
