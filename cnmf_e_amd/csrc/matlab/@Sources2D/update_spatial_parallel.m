@@ -26,6 +26,7 @@ function update_spatial_parallel(obj, use_parallel, update_sn)
     K = size(obj.A, 2);
     ii = cell(np, 1);  jj = cell(np, 1);  vv = cell(np, 1);
     sn_all = obj.P.sn(:);
+    pending = {};
     for m = 1:np
         h = eng.h(eng.owner(m));
         pix_p = local_pixels(eng.patch_pos{m}, d1);
@@ -49,10 +50,17 @@ function update_spatial_parallel(obj, use_parallel, update_sn)
         end
         if isempty(ind), continue; end
         if same_C, Carg = int32(ind(:)); else, Carg = obj.C(ind, :); end
-        Anew = cnmfe_mex('spatial', h, eng.pid(m), alg, obj.A(pix_p, ind), Carg, IND(pix_p, ind), sn_p, param);
-        [r, c, v] = find(Anew);
-        ii{m} = pix_p(r);  jj{m} = reshape(ind(c), [], 1);  vv{m} = v;
+        % the update is QUEUED (sweeps + the copy of the result into pinned memory) and collected two patches late: the host cuts the next patch's
+        % slices and assembles the previous patch's triplets while the device works (a blocking 'spatial' per patch drained the stream np times)
+        pending{end + 1} = {h, cnmfe_mex('spatial_queue', h, eng.pid(m), alg, obj.A(pix_p, ind), Carg, IND(pix_p, ind), sn_p, param), m, pix_p, ind}; %#ok<AGROW>
+        while numel(pending) > 2
+            [ii, jj, vv] = collect_one(pending{1}, ii, jj, vv);  pending(1) = [];
+        end
     end
+    while ~isempty(pending)
+        [ii, jj, vv] = collect_one(pending{1}, ii, jj, vv);  pending(1) = [];
+    end
+    for g = 1:numel(eng.h), cnmfe_mex('synchronize', eng.h(g)); end      % what the kernels had to report is heard before obj.A is replaced
     A_new = sparse(cell2mat(ii), cell2mat(jj), cell2mat(vv), d1 * d2, K);
     if update_sn, obj.P.sn = reshape(sn_all, size(obj.P.sn)); end
 
@@ -73,6 +81,13 @@ function update_spatial_parallel(obj, use_parallel, update_sn)
     obj.A = A_new;
     Ymean = cell2mat(obj.P.Ymean);
     obj.b0_new = Ymean - obj.reshape(obj.A * mean(obj.C, 2), 2);
+end
+
+function [ii, jj, vv] = collect_one(p, ii, jj, vv)
+    Anew = cnmfe_mex('spatial_collect', p{1}, p{2});
+    [r, c, v] = find(Anew);
+    m = p{3};  pix_p = p{4};  ind = p{5};
+    ii{m} = pix_p(r);  jj{m} = reshape(ind(c), [], 1);  vv{m} = v;
 end
 
 function pix = local_pixels(rect, d1)

@@ -31,6 +31,7 @@ function update_temporal_parallel(obj, use_parallel, use_c_hat)
         cnmfe_mex('bind_traces', eng.h(g), obj.C_prev);
         cnmfe_mex('stitch_begin', eng.h(g), K, T);
     end
+    jobs = {};
     for m = 1:np
         h = eng.h(eng.owner(m));
         pix_p = local_pixels(eng.patch_pos{m}, d1);
@@ -46,14 +47,21 @@ function update_temporal_parallel(obj, use_parallel, use_c_hat)
         A_pp = obj.A(pix_p, ind);
         if ~use_c_hat
             cnmfe_mex('fast_temporal', h, eng.pid(m), A_pp, T);
+            cnmfe_mex('stitch_add', h, ind);
         elseif deconv
             [~, ~, ~, pars] = cnmfe_mex('temporal_deconv', h, eng.pid(m), A_pp, obj.C(ind, :), opt.maxIter, dopt.smin, dopt.max_tau, pars_all(ind));
             pars_all(ind) = pars;
+            cnmfe_mex('stitch_add', h, ind);
         else
+            % the patches are independent (the reference's loop is a parfor, :112-186): every patch's projections are queued as a JOB and the
+            % Gauss-Seidel levels of all jobs of a context run together below -- a level of one patch is a handful of workgroups
             if same_C, Carg = int32(ind(:)); else, Carg = obj.C(ind, :); end
-            cnmfe_mex('temporal', h, eng.pid(m), A_pp, Carg, opt.maxIter);
+            jobs{end + 1} = {h, cnmfe_mex('temporal_job', h, eng.pid(m), A_pp, Carg, opt.maxIter), ind}; %#ok<AGROW>
         end
-        cnmfe_mex('stitch_add', h, ind);
+    end
+    if ~isempty(jobs)
+        for g = 1:numel(eng.h), cnmfe_mex('temporal_jobs_sweep', eng.h(g)); end
+        for j = 1:numel(jobs), cnmfe_mex('stitch_add_job', jobs{j}{1}, jobs{j}{2}, jobs{j}{3}); end
     end
     C_raw = double(cnmfe_mex('stitch_temporal', eng.h, ~deconv, K, T));
     if deconv

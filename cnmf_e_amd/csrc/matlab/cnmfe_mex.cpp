@@ -35,6 +35,14 @@
 //   rss = cnmfe_mex('compute_rss', h, pid, A_patch, C_or_rows, b0_block, b0_new_patch)
 //   Ybg = cnmfe_mex('reconstruct_background', h, pid, b0_block, b0_new_patch, frame0, nframes)
 //   keep = cnmfe_mex('postprocess', h, A, d1, d2)                          post_process_spatial.m:19-32 (connected)
+// Round 6 -- the calls the measured host (cnmf_e_amd/sources2d.py, bench.py) makes and this gateway lacked; the .m twins use them:
+//   cnmfe_mex('set_option', h, name, value)                                cnmfe_set_option (the tunables of include/cnmfe.h; the defaults ARE the fast path)
+//   cnmfe_mex('synchronize', h)                                            wait for the context's stream; reports what its kernels raised
+//   q = cnmfe_mex('spatial_queue', h, pid, alg, A_patch, C_or_rows, IND_patch, sn, param)   the update is QUEUED (sweeps + the copy of the result into pinned
+//   A = cnmfe_mex('spatial_collect', h, q)                                 memory) and collected later: patch m + 1 is set up and queued while patch m runs
+//   job = cnmfe_mex('temporal_job', h, pid, A_patch, C_or_rows, maxIter)   everything of 'temporal' up to the Gauss-Seidel sweeps; 'temporal_jobs_sweep' then runs
+//   cnmfe_mex('temporal_jobs_sweep', h)                                    level l of EVERY job in one launch; cnmfe_mex('stitch_add_job', h, job, ind) adds a job
+//   cnmfe_mex('stitch_finish_async', h, subtract_min, K, T)                :279-286 + bind on one context without waiting; C_raw = cnmfe_mex('stitch_collect', h)
 #include "mex.h"
 #include "matrix.h"
 #include <string.h>
@@ -44,7 +52,19 @@
 #define MAX_CTX 64
 static cnmfe_ctx *g_ctx[MAX_CTX];
 static int g_nctx = 0;
-static void at_exit(void) { for (int i = 0; i < g_nctx; ++i) if (g_ctx[i]) { cnmfe_destroy(g_ctx[i]); g_ctx[i] = NULL; } g_nctx = 0; }
+// queued spatial updates ('spatial_queue' ... 'spatial_collect'): the ticket of the copy into pinned memory and a persistent copy of the mask whose pattern the result has
+#define MAX_PEND 1024
+typedef struct { int used; cnmfe_ctx *c; int64_t ticket; float *pinned; int64_t nnz; mxArray *ind; } Pending;
+static Pending g_pend[MAX_PEND];
+// the asynchronous stitch of a context ('stitch_finish_async' ... 'stitch_collect'): K x T floats, row-major, pinned
+typedef struct { float *pinned; size_t K, T; } StitchOut;
+static StitchOut g_stitch[MAX_CTX];
+static void at_exit(void) {
+    for (int i = 0; i < MAX_PEND; ++i) if (g_pend[i].used) { if (g_pend[i].pinned) cnmfe_host_free(g_pend[i].pinned); if (g_pend[i].ind) mxDestroyArray(g_pend[i].ind); g_pend[i].used = 0; }
+    for (int i = 0; i < MAX_CTX; ++i) if (g_stitch[i].pinned) { cnmfe_host_free(g_stitch[i].pinned); g_stitch[i].pinned = NULL; }
+    for (int i = 0; i < g_nctx; ++i) if (g_ctx[i]) { cnmfe_destroy(g_ctx[i]); g_ctx[i] = NULL; }
+    g_nctx = 0;
+}
 #define FAIL(...) mexErrMsgIdAndTxt("cnmfe_mex:error", __VA_ARGS__)
 #define CHECK(rc) do { if ((rc) != 0) FAIL("%s", cnmfe_last_error()); } while (0)
 
@@ -196,6 +216,75 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         for (int64_t i = 0; i < A.nnz; ++i) k[i] = keep[i] != 0;
         return;
     }
+    if (!strcmp(cmd, "set_option")) {                           // cnmfe_mex('set_option', h, name, value)
+        if (nin != 4) FAIL("set_option: 4 inputs required (h, name, value)");
+        char name[48];
+        if (!mxIsChar(pin[2]) || mxGetString(pin[2], name, sizeof(name))) FAIL("set_option: bad option name");
+        CHECK(cnmfe_set_option(c, name, (int64_t)mxGetScalar(pin[3])));
+        return;
+    }
+    if (!strcmp(cmd, "synchronize")) {
+        if (nin != 2) FAIL("synchronize: 2 inputs required");
+        CHECK(cnmfe_synchronize(c));
+        return;
+    }
+    if (!strcmp(cmd, "temporal_jobs_sweep")) {                  // the Gauss-Seidel levels of every queued job, one launch per level (update_temporal_parallel.m:112-186 is a parfor)
+        if (nin != 2) FAIL("temporal_jobs_sweep: 2 inputs required");
+        CHECK(cnmfe_temporal_jobs_sweep(c));
+        return;
+    }
+    if (!strcmp(cmd, "stitch_add_job")) {                       // cnmfe_mex('stitch_add_job', h, job, ind): ind 1-based rows (double or int32)
+        if (nin != 4) FAIL("stitch_add_job: 4 inputs required (h, job, ind)");
+        const int32_t n = (int32_t)mxGetNumberOfElements(pin[3]);
+        int32_t *ind = (int32_t *)mxMalloc(((size_t)n + 1) * sizeof(int32_t));
+        if (mxIsInt32(pin[3])) { const int32_t *src = (const int32_t *)mxGetData(pin[3]); for (int32_t i = 0; i < n; ++i) ind[i] = src[i] - 1; }
+        else if (mxIsDouble(pin[3])) { const double *src = mxGetPr(pin[3]); for (int32_t i = 0; i < n; ++i) ind[i] = (int32_t)src[i] - 1; }
+        else FAIL("stitch_add_job: ind must be double or int32");
+        CHECK(cnmfe_stitch_add_job(c, (int32_t)mxGetScalar(pin[2]), n, ind));
+        return;
+    }
+    if (!strcmp(cmd, "stitch_finish_async")) {                  // cnmfe_mex('stitch_finish_async', h, subtract_min, K, T)
+        if (nin != 5) FAIL("stitch_finish_async: 5 inputs required (h, subtract_min, K, T)");
+        const int hi = (int)mxGetScalar(pin[1]) - 1;
+        const size_t K = (size_t)mxGetScalar(pin[3]), T = (size_t)mxGetScalar(pin[4]);
+        if (g_stitch[hi].pinned) { cnmfe_host_free(g_stitch[hi].pinned); g_stitch[hi].pinned = NULL; }
+        g_stitch[hi].pinned = (float *)cnmfe_host_alloc((K * T + 1) * sizeof(float));
+        if (!g_stitch[hi].pinned) FAIL("%s", cnmfe_last_error());
+        g_stitch[hi].K = K; g_stitch[hi].T = T;
+        CHECK(cnmfe_stitch_finish_async(c, mxGetScalar(pin[2]) != 0, g_stitch[hi].pinned));
+        return;
+    }
+    if (!strcmp(cmd, "stitch_collect")) {                       // C_raw = cnmfe_mex('stitch_collect', h)   (single, K x T)
+        if (nin != 2) FAIL("stitch_collect: 2 inputs required");
+        const int hi = (int)mxGetScalar(pin[1]) - 1;
+        if (!g_stitch[hi].pinned) FAIL("stitch_collect: no stitch_finish_async outstanding on this context");
+        CHECK(cnmfe_stitch_wait(c));
+        const size_t K = g_stitch[hi].K, T = g_stitch[hi].T;
+        pout[0] = mxCreateNumericMatrix(K, T, mxSINGLE_CLASS, mxREAL);
+        float *dst = (float *)mxGetData(pout[0]);
+        const float *src = g_stitch[hi].pinned;                 // row-major K x T -> MATLAB's column-major
+        for (size_t k = 0; k < K; ++k) for (size_t t = 0; t < T; ++t) dst[t * K + k] = src[k * T + t];
+        cnmfe_host_free(g_stitch[hi].pinned); g_stitch[hi].pinned = NULL;
+        return;
+    }
+    if (!strcmp(cmd, "spatial_collect")) {                      // A = cnmfe_mex('spatial_collect', h, q)
+        if (nin != 3) FAIL("spatial_collect: 3 inputs required (h, q)");
+        const int q = (int)mxGetScalar(pin[2]) - 1;
+        if (q < 0 || q >= MAX_PEND || !g_pend[q].used || g_pend[q].c != c) FAIL("spatial_collect: no such queued update on this context");
+        Pending *P = &g_pend[q];
+        const int rc = cnmfe_ticket_wait(c, P->ticket);
+        const mxArray *IND = P->ind;
+        const size_t K = mxGetN(IND);
+        if (rc == 0) {
+            pout[0] = mxCreateSparse(mxGetM(IND), K, P->nnz > 0 ? (size_t)P->nnz : 1, mxREAL);           // same pattern as IND
+            memcpy(mxGetJc(pout[0]), mxGetJc(IND), (K + 1) * sizeof(mwIndex));
+            memcpy(mxGetIr(pout[0]), mxGetIr(IND), (size_t)P->nnz * sizeof(mwIndex));
+            for (int64_t i = 0; i < P->nnz; ++i) mxGetPr(pout[0])[i] = P->pinned[i];
+        }
+        cnmfe_host_free(P->pinned); mxDestroyArray(P->ind); P->pinned = NULL; P->ind = NULL; P->used = 0;
+        CHECK(rc);
+        return;
+    }
     if (nin < 3) FAIL("missing patch id");
     const int pid = (int)mxGetScalar(pin[2]);
     if (!strcmp(cmd, "patch")) {
@@ -259,6 +348,36 @@ void mexFunction(int nout, mxArray *pout[], int nin, const mxArray *pin[]) {
         if (nout > 0) pout[0] = to_double(Co, K, T);
         if (nout > 1) pout[1] = to_double(Cr, K, T);
         if (nout > 2) pout[2] = to_double(aa, K, 1);
+    } else if (!strcmp(cmd, "temporal_job")) {                 // job = cnmfe_mex('temporal_job', h, pid, A_patch, C_or_rows, maxIter)
+        if (nin != 6) FAIL("temporal_job: 6 inputs required");
+        Csc A = csc_of(pin[3]);
+        Traces Cm = traces_of(pin[4], A.K);
+        int32_t job = -1;
+        CHECK(cnmfe_hals_temporal_job(c, pid, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, (int32_t)mxGetScalar(pin[5]), NULL, NULL, &job));
+        pout[0] = mxCreateDoubleScalar((double)job);
+    } else if (!strcmp(cmd, "spatial_queue")) {                // q = cnmfe_mex('spatial_queue', h, pid, alg, A_patch, C_or_rows, IND_patch, sn, param)
+        if (nin != 9) FAIL("spatial_queue: 9 inputs required");
+        char alg[16];
+        if (mxGetString(pin[3], alg, sizeof(alg))) FAIL("spatial_queue: bad algorithm name");
+        const int a = !strcmp(alg, "hals") ? CNMFE_SPATIAL_HALS : !strcmp(alg, "hals_thresh") ? CNMFE_SPATIAL_HALS_THRESH : !strcmp(alg, "nnls") ? CNMFE_SPATIAL_NNLS : -1;
+        if (a < 0) FAIL("spatial_queue: unknown algorithm '%s'", alg);
+        if (!mxIsSparse(pin[6])) FAIL("spatial_queue: IND must be sparse");
+        int q = 0;
+        while (q < MAX_PEND && g_pend[q].used) ++q;
+        if (q == MAX_PEND) FAIL("spatial_queue: too many updates queued and not collected");
+        Csc A = csc_of(pin[4]), IND = csc_of(pin[6]);
+        Traces Cm = traces_of(pin[5], A.K);
+        float *sn = mxIsEmpty(pin[7]) ? NULL : f32_of(pin[7], NULL);
+        CHECK(cnmfe_update_spatial(c, pid, a, A.K, A.cp, A.ri, A.v, Cm.ptr, Cm.order, IND.cp, IND.ri, sn, (int32_t)mxGetScalar(pin[8]), NULL));   // A_out == NULL: deferred
+        Pending *P = &g_pend[q];
+        P->pinned = (float *)cnmfe_host_alloc(((size_t)IND.nnz + 1) * sizeof(float));
+        if (!P->pinned) FAIL("%s", cnmfe_last_error());
+        const int rc = cnmfe_update_spatial_fetch_async(c, P->pinned, IND.nnz, &P->ticket);
+        if (rc != 0) { cnmfe_host_free(P->pinned); P->pinned = NULL; CHECK(rc); }
+        P->ind = mxDuplicateArray(pin[6]);
+        mexMakeArrayPersistent(P->ind);
+        P->c = c; P->nnz = IND.nnz; P->used = 1;
+        pout[0] = mxCreateDoubleScalar((double)(q + 1));
     } else if (!strcmp(cmd, "temporal_deconv")) {
         if (nin != 9) FAIL("temporal_deconv: 9 inputs required (h, pid, A, C, maxIter, smin, max_tau, pars)");
         Csc A = csc_of(pin[3]);

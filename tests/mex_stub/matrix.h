@@ -33,6 +33,7 @@ mxArray *mxCreateLogicalScalar(bool);
 mxArray *mxCreateNumericMatrix(mwSize, mwSize, mxClassID, mxComplexity);
 mxArray *mxCreateSparse(mwSize, mwSize, mwSize, mxComplexity);
 void mxDestroyArray(mxArray *);
+mxArray *mxDuplicateArray(const mxArray *);
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ extern "C" {
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...) __attribute__((noreturn));
 int mexCallMATLAB(int nlhs, mxArray *plhs[], int nrhs, mxArray *prhs[], const char *name);
 int mexAtExit(void (*fn)(void));
+void mexMakeArrayPersistent(mxArray *);
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
 #ifdef __cplusplus
 }
