@@ -540,9 +540,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
-    static const char *known[] = {"r1_variant", "tile_order", "gram_probe", "solve_probe", "r1_delta", "r1_lazy", "r1_defer", "r1_probe", "r1_nseg", "gram_incremental", "debug", "host_trace", "deconv_trace", "r1_virtual", "prealloc", "solve_packed", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "ssub_virtual",
-                                  /* retired experiment switches (rounds 2-3): still accepted, ignored -- scripts/r1_probe.py, r1_duo.py, solve_ab.py name them */
-                                  "r1_arc_d", "r1_arc_bias", "r1_duo_ord", "solve_mode", "gram_kernel", "solve_gfill", "solve_defer", "gram_mode", "gram_flush", nullptr};
+    // behaviour switches (include/cnmfe.h) and, behind them, the probes of scripts/ (diagnostics: solve_probe, r1_probe, deconv_trace, host_trace, debug)
+    static const char *known[] = {"r1_variant", "r1_delta", "r1_lazy", "r1_defer", "r1_virtual", "gram_incremental", "prealloc", "solve_packed", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "ssub_virtual",
+                                  "solve_probe", "r1_probe", "deconv_trace", "host_trace", "debug", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; if (!strcmp(name, "host_trace")) ctx->trace_level = (int)value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }

@@ -1091,7 +1091,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                        dTcnt.as<int>(), dTl.as<int>(), digs, covT.as<double>());
             } else
                 LAUNCH(ctx, "bg_gram_f64", k_gram4, dim3(nwg), dim3(256), shmem, ctx->bf.as<float>(), g.Tpad, dPairs.as<int4>(), dWork.as<int>(), nwork,
-                       dTcnt.as<int>(), dTl.as<int>(), (int)ctx->opt("gram_probe", 0), covT.as<double>());
+                       dTcnt.as<int>(), dTl.as<int>(), 0, covT.as<double>());
         }
         if (incr) { P->base_valid = true; P->base_kstride = kstride; }
         }

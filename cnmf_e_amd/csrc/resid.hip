@@ -1064,13 +1064,12 @@ static int r1_sweep(cnmfe_ctx *ctx, Patch *P, DevBuf &ysig, bool has_ac, int64_t
     // enough workgroups to fill 256 CUs several times over; segments are a multiple of 4 frames
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((T + 255) / 256, (4096 + ntiles - 1) / ntiles));
     if (variant == 14) nseg = std::max<int64_t>(1, std::min<int64_t>((T + 255) / 256, (512 + ntiles - 1) / ntiles));   // 1024-pixel tiles: two rounds of the chip; every segment re-reads W
-    if (ctx->opt("r1_nseg", 0) > 0) nseg = std::min<int64_t>(ctx->opt("r1_nseg", 0), (T + 3) / 4);      // (experiments: force the number of frame segments)
     int64_t tseg = ((T + nseg - 1) / nseg + 3) & ~int64_t(3);
     nseg = (T + tseg - 1) / tseg;
     a.tseg = tseg;
     int rc;
     if (special) {
-        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, (int)ctx->opt("tile_order", 1)));
+        RET(build_tile_map(ctx, dOffs, a.ntile_r, ntile_c, TR, TC, h, 1));
         a.tile_map = dOffs.as<int>();
         const dim3 gridd((unsigned)((int64_t)a.ntile_r * ntile_c), (unsigned)nseg);
         if (h == 15) rc = launch_r1_v<15>(ctx, variant, a, sweep_ac, ntile_c, nseg);

@@ -396,21 +396,29 @@ int cnmfe_profile_reset(cnmfe_ctx *ctx);
 int cnmfe_profile_count(cnmfe_ctx *ctx);
 int cnmfe_profile_get(cnmfe_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *calls);
 int cnmfe_synchronize(cnmfe_ctx *ctx);
-/* tunables for A/B runs; unknown names -> CNMFE_EINVAL.  r1_variant (R1 kernel), r1_delta / r1_lazy / r1_defer (incremental residual, see
- * cnmfe_residual), gram_incremental (see cnmfe_fit_ring_model), tile_order, debug (1: NaN-poison never-computed table entries), *_probe (timing experiments);
- * round 4: r1_virtual (default 1: a cnmfe_residual without an output buffer records its request and the two updates project the centred video instead of a swept
- * Ysig; 0 restores the sweep), solve_packed (default 1: the ring solve reads per-pixel packed copies of the video's normal equations -- 43 KB per patch pixel at 96
- * ring offsets, allocated when that much + 8 GB is free -- and applies the footprints' corrections in registers; 0: the block-pair table is swept and gathered
- * from, as before), prealloc, host_trace (1: host-side phase times of every call on stderr, 2: + slow launch calls);
- * round 5: gram_i8 (default 1: the covariance table of the video -- and the direct Gram of the fallback -- on the int8 matrix pipe from 32-bit fixed-point digit
- * planes, exact int32 accumulation, up to 24576 used frames; 0: the fp64 matrix pipe), win_i8 (default 1: the digit planes stay resident -- one more video's worth
- * of memory, taken only when that leaves 8 GB free -- and every fit's window projection runs on the int8 pipe; 0: the fp64 kernel on the centred video),
- * proj_tiled (default 1: the temporal projection reads a copy of the centred video in its own read order -- again one video's worth, same rule; 0: the frame-major
- * video), proj_i8 (default 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes -- instead of the read-order copy, same size, same
- * rule; needs win_i8; 0: the fp64 matrix pipe), ssub_virtual (cnmfe_residual_ssub without an output buffer records its request too, and the two updates project through the resampling maps --
- * the rows of the video under the masks / footprints and the low-resolution video: 2 always, 1 (default) on patches of at least 5e8 samples -- below that the low-resolution
- * sweep is the faster form, profiles/r05/ssub_virtual_check.txt --, 0: the low-resolution sweep + upsample of rounds 2-4).  A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.  Retired, still
- * accepted and ignored: gram_mode, gram_flush, solve_defer and the experiment switches of rounds 2-3.
+/* Tunables; unknown names -> CNMFE_EINVAL.  Thirteen behaviour switches, every default = the measured path, every other value parity-tested against it:
+ *   r1_variant        R1 sweep kernel (14: duo-role LDS-DMA kernel, the default where it applies; -1: the generic kernel)
+ *   r1_delta, r1_lazy, r1_defer    incremental residual (see cnmfe_residual): fold a footprint-term difference into the resident Ysig / only record a request nobody
+ *                     reads / sweep without the term and keep it pending.  Default 1 each.
+ *   r1_virtual        default 1: a cnmfe_residual without an output buffer records its request and the two updates project the centred video instead of a swept
+ *                     Ysig; 0 restores the sweep
+ *   ssub_virtual      the same for cnmfe_residual_ssub (through the resampling maps): 2 always, 1 (default) on patches of at least 5e8 samples -- below that the
+ *                     low-resolution sweep is the faster form, profiles/r05/ssub_virtual_check.txt --, 0: the low-resolution sweep + upsample
+ *   gram_incremental  default 1: the covariance table of the VIDEO is kept and corrected per fit (see cnmfe_fit_ring_model); 0: the direct Gram of Bf every fit
+ *   solve_packed      default 1: the ring solve reads per-pixel packed copies of the video's normal equations (43 KB per patch pixel at 96 ring offsets, allocated
+ *                     when that much + 8 GB is free) and applies the footprints' corrections in registers; 0: the block-pair table is swept and gathered from
+ *   gram_i8           default 1: the table (and the direct Gram of the fallback) on the int8 matrix pipe from 32-bit fixed-point digit planes, exact int32
+ *                     accumulation, up to 24576 used frames; 0: the fp64 matrix pipe
+ *   win_i8            default 1: the digit planes stay resident (one more video's worth of memory, taken only when that leaves 8 GB free) and every fit's window
+ *                     projection runs on the int8 pipe; 0: the fp64 kernel on the centred video
+ *   proj_tiled / proj_i8   default 1 / 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes (needs win_i8), else out of a copy of
+ *                     the centred video in its own read order (one video's worth either, same rule); 0 / 0: the frame-major video on the fp64 pipe
+ *   prealloc          default 1: cnmfe_fit_reserve may allocate the fit's large buffers ahead of the first fit
+ * A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.
+ * Diagnostics (scripts/): solve_probe, r1_probe (phase probes: results are NOT the product's), deconv_trace, host_trace (1: host-side phase times of every call on
+ * stderr, 2: + slow launch calls), debug (1: NaN-poison never-computed table entries).
+ * Round 6 removed the retired names rounds 2-5 still accepted and ignored (gram_mode, gram_flush, solve_defer, solve_mode, solve_gfill, gram_kernel, r1_arc_d,
+ * r1_arc_bias, r1_duo_ord) and the experiment switches tile_order, gram_probe, r1_nseg.
  * Every option can be preset for a process with CNMFE_OPTS="name=value,..." (logged once on stderr). */
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value);
 

@@ -19,7 +19,7 @@ eng = Engine(0)
 video = PatchedVideo(d1, d2, T, [d1, d2], r, eng)
 video.upload_block_device((0, 0), Yd.data_ptr()); del Yd; torch.cuda.empty_cache()
 eng.ring_init(0, r)
-eng.set_option("r1_variant", a.variant); eng.set_option("tile_order", a.order); eng.set_option("r1_delta", 1 if a.delta else 0); eng.set_option("r1_probe", a.probe)
+eng.set_option("r1_variant", a.variant); eng.set_option("r1_delta", 1 if a.delta else 0); eng.set_option("r1_probe", a.probe)
 eng.profile(True)
 A_b = f.A_init.astype(np.float32) if a.ac else None
 if a.delta:
