@@ -41,13 +41,15 @@ struct DeconvIO {
     float *tbuf = nullptr;             // ylong == 2 (nfft = 16384): the Welch twiddle / window tables, 2 nfft floats per trace slot
 };
 
+// (red: one double per wave of the workgroup -- 4 for the 256-thread kernels, 8 for k_deconv's 512)
 __device__ __forceinline__ double block_sum(double v, double *red) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nw = (int)(blockDim.x >> 6);
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const double r = (red[0] + red[1]) + (red[2] + red[3]);
+    double r = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int w = 4; w < nw; w += 4) r += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
     __syncthreads();
     return r;
 }
@@ -60,13 +62,13 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 __device__ __forceinline__ unsigned fkey(float x) { const unsigned u = __float_as_uint(x); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 __device__ void select_pair(const float *y, int T, int k, int *hist /* 260 ints of LDS */, float &vk, float &vk1) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NTH = (int)blockDim.x;
     unsigned prefix = 0, known = 0;
     int kk = k, cnt_eq = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int t = tid; t < T; t += 256) { const unsigned key = fkey(y[t]); if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1); }
+        for (int t = tid; t < T; t += NTH) { const unsigned key = fkey(y[t]); if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1); }
         __syncthreads();
         if (tid == 0) {
             int acc = 0, b = 0;
@@ -80,12 +82,12 @@ __device__ void select_pair(const float *y, int T, int k, int *hist /* 260 ints 
     vk = fkey_inv(prefix);
     if (kk + 1 < cnt_eq) { vk1 = vk; return; }
     unsigned mn = 0xffffffffu;
-    for (int t = tid; t < T; t += 256) { const unsigned key = fkey(y[t]); if (key > prefix && key < mn) mn = key; }
+    for (int t = tid; t < T; t += NTH) { const unsigned key = fkey(y[t]); if (key > prefix && key < mn) mn = key; }
     for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mn, o); mn = other < mn ? other : mn; }
     if ((tid & 63) == 0) hist[tid >> 6] = (int)mn;
     __syncthreads();
     unsigned r = (unsigned)hist[0];
-    for (int w = 1; w < 4; ++w) r = (unsigned)hist[w] < r ? (unsigned)hist[w] : r;
+    for (int w = 1; w < (NTH >> 6); ++w) r = (unsigned)hist[w] < r ? (unsigned)hist[w] : r;
     __syncthreads();
     vk1 = r == 0xffffffffu ? vk : fkey_inv(r);
 }
@@ -103,10 +105,10 @@ __device__ __forceinline__ float2 fft_tw(const float2 *tw, int tk, int n) {
     return w;
 }
 __device__ void fft_lds(float *re, float *im, const float2 *tw, int n, int logn) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NTH = (int)blockDim.x;
     int s = 1;
     if (logn & 1) {                                          // an odd number of stages: the first one (twiddle 1) on its own
-        for (int b = tid; b < n / 2; b += 256) {
+        for (int b = tid; b < n / 2; b += NTH) {
             const int i0 = 2 * b, i1 = i0 + 1;
             const float ur = re[i0], ui = im[i0], xr = re[i1], xi = im[i1];
             re[i0] = ur + xr; im[i0] = ui + xi; re[i1] = ur - xr; im[i1] = ui - xi;
@@ -116,7 +118,7 @@ __device__ void fft_lds(float *re, float *im, const float2 *tw, int n, int logn)
     }
     for (; s < logn; s += 2) {
         const int h = 1 << (s - 1), t1 = n >> s, t2 = n >> (s + 1);
-        for (int q = tid; q < n / 4; q += 256) {
+        for (int q = tid; q < n / 4; q += NTH) {
             const int pos = q & (h - 1);
             const int i0 = ((q >> (s - 1)) << (s + 1)) + pos, i1 = i0 + h, i2 = i0 + 2 * h, i3 = i0 + 3 * h;
             const float2 w1 = fft_tw(tw, pos * t1, n), wa = fft_tw(tw, pos * t2, n), wb = fft_tw(tw, (pos + h) * t2, n);
@@ -151,7 +153,7 @@ struct Ysig4Acc {                                    // frame t of one pixel of 
 // transform (nfft = 16384: T > 36868) leaves no room for them in the 160 KB of LDS.
 template <class YT>
 __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *red, bool wintab, float *tabs = nullptr) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NTH = (int)blockDim.x;
     const int nfft = c.nfft, L = c.L, step = c.L - c.nov;
     float *tb = tabs ? tabs : scr + 2 * nfft;
     float *re = scr, *im = scr + nfft, *win = tb + nfft / 2;
@@ -164,13 +166,13 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) acc[i] = 0.f;
     double w2 = 0;
-    for (int i = tid; i < L; i += 256) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; if (wintab) win[i] = (float)w; }
-    for (int k = tid; k < nfft / 4; k += 256) { float sn_, cs_; sincospif(-(float)k / (float)(nfft / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
+    for (int i = tid; i < L; i += NTH) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; if (wintab) win[i] = (float)w; }
+    for (int k = tid; k < nfft / 4; k += NTH) { float sn_, cs_; sincospif(-(float)k / (float)(nfft / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
     if (tabs) __threadfence_block();                 // (tables in global memory: written and read by this workgroup alone; block_sum's barriers order them)
     w2 = block_sum(w2, red);
     for (int sg = 0; sg < c.nseg; sg += 2) {
         const bool two = sg + 1 < c.nseg;
-        for (int i = tid; i < nfft; i += 256) {
+        for (int i = tid; i < nfft; i += NTH) {
             float va = 0.f, vb = 0.f;
             if (i < L) { const float w = wintab ? win[i] : (float)(0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1))); va = y[sg * step + i] * w; if (two) vb = y[(sg + 1) * step + i] * w; }
             const int j = (int)(__brev((unsigned)i) >> (32 - logn));
@@ -180,7 +182,7 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
         fft_lds(re, im, tw, nfft, logn);
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
-            const int k = k0 + tid + i * 256;
+            const int k = k0 + tid + i * NTH;
             if (k <= k1) acc[i] += 0.5f * ((re[k] * re[k] + im[k] * im[k]) + (re[nfft - k] * re[nfft - k] + im[nfft - k] * im[nfft - k]));
         }
         __syncthreads();
@@ -188,7 +190,7 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
     double ls = 0;
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
-        const int k = k0 + tid + i * 256;
+        const int k = k0 + tid + i * NTH;
         if (k <= k1) {
             double psd = (double)acc[i] / ((double)c.nseg * w2);
             if (k != nfft / 2) psd *= 2.0;                     // one-sided: Nyquist bin is not doubled
@@ -201,14 +203,14 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
 
 // estimate_time_constant(y, 1, sn): returns g, or a negative flag (-2) when |g| > 1
 __device__ __forceinline__ double est_g(const float *y, double shift, int T, double sn, double *red) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NTH = (int)blockDim.x;
     double m = 0;
-    for (int t = tid; t < T; t += 256) m += (double)y[t] - shift;
+    for (int t = tid; t < T; t += NTH) m += (double)y[t] - shift;
     m = block_sum(m, red) / T;
     double xc[7];
     for (int k = 0; k <= 6; ++k) {
         double s = 0;
-        for (int t = tid; t + k < T; t += 256) s += ((double)y[t + k] - shift - m) * ((double)y[t] - shift - m);
+        for (int t = tid; t + k < T; t += NTH) s += ((double)y[t + k] - shift - m) * ((double)y[t] - shift - m);
         xc[k] = block_sum(s, red) / T;
     }
     double num = 0, den = 0;
@@ -469,7 +471,10 @@ __device__ __forceinline__ void oasis_first(const float *y, double bsub, int T, 
     P.n = __shfl(P.n, 0);
 }
 
-// split the pools into tasks of <= 64 samples: wave 0, 64 pools per round, task slots from a wave prefix sum of the per-pool counts
+// round 6: a task is DTK = 31 samples (an ODD number; 64 until round 6) -- the tasks of a long pool start 63 words apart in the LDS copy of the trace, so the lanes of a wave that walk
+// their tasks in step read different banks (64 apart they all read the SAME bank), and there are about as many tasks as k_deconv has threads (512).
+constexpr int DTK = 31;
+// split the pools into tasks of <= DTK samples: wave 0, 64 pools per round, task slots from a wave prefix sum of the per-pool counts
 // (one lane walking the pool list paid a dependent global load per pool: 65 us for 115 pools)
 __device__ __forceinline__ int build_tasks(const Pools &P, const DeconvIO &io, int64_t base2) {
     const int lane = threadIdx.x;                                           // called by tid < 64 with P.n uniform
@@ -478,12 +483,12 @@ __device__ __forceinline__ int build_tasks(const Pools &P, const DeconvIO &io, i
     for (int p0 = 0; p0 < P.n; p0 += 64) {
         const int p = p0 + lane;
         const int l = p < P.n ? P.l[p] : 0;
-        const int k = (l + 63) >> 6;
+        const int k = (l + DTK - 1) / DTK;
         int inc = k;
         for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
         int at = nt + inc - k;
-        for (int off = 0; off < l; off += 64, ++at) {
-            io.tk_pool[base2 + at] = p; io.tk_off[base2 + at] = off; io.tk_len[base2 + at] = l - off < 64 ? l - off : 64;
+        for (int off = 0; off < l; off += DTK, ++at) {
+            io.tk_pool[base2 + at] = p; io.tk_off[base2 + at] = off; io.tk_len[base2 + at] = l - off < DTK ? l - off : DTK;
         }
         nt += __shfl(inc, 63);
     }
@@ -494,25 +499,63 @@ __device__ __forceinline__ int build_tasks(const Pools &P, const DeconvIO &io, i
 // given -- the denominators hh_p = sum_{j<l_p} g^2j = cumsum(h.*h)(l_p) of foopsi_oasisAR1.m:166-174 from the same sweep.  tkv (2 doubles per
 // task), num and hh are flat pointers: k_deconv places them in LDS when the pool list is short enough (a Brent step is then not three
 // global-memory round trips long), else in the global scratch.
+__device__ __forceinline__ double ipow(double x, int n) { double r = 1.0; for (; n; n >>= 1) { if (n & 1) r *= x; x *= x; } return r; }
+
+// td (round 6): the tasks' descriptors staged in LDS by k_deconv after every build_tasks -- {first sample, len | (off / 64) << 8, pool, tasks of the pool if this is
+// its first task else 0}.  An evaluation of Brent's objective used to start with three dependent global loads per task (task -> pool -> pool start) and its
+// per-pool sum with two more: ~5 us per evaluation, 28 evaluations per trace, almost all of it load latency.  nullptr: the global arrays (pool lists too long for LDS).
 __device__ __forceinline__ void pool_numerators(const float *y, double bsub, double lam, double g, const Pools &P, const DeconvIO &io, int64_t base2,
-                                int ntask, double *tkv, double *num, double *hh) {
-    const int tid = threadIdx.x;
-    double g64 = g; for (int i = 0; i < 6; ++i) g64 *= g64;       // g^64: a task starts at a multiple of 64 samples into its pool
-    for (int k = tid; k < ntask; k += 256) {
-        const int p = io.tk_pool[base2 + k], off = io.tk_off[base2 + k], len = io.tk_len[base2 + k];
-        const int t0 = P.t[p] - 1 + off;
-        double gj = 1.0, s = 0, h2 = 0;
-        { double bs = g64; for (int e = off >> 6; e; e >>= 1) { if (e & 1) gj *= bs; bs *= bs; } }
-        for (int j = 0; j < len; ++j) { s += (((double)y[t0 + j] - bsub) - lam * (1 - g)) * gj; h2 = fma(gj, gj, h2); gj *= g; }
+                                int ntask, double *tkv, double *num, double *hh, const int4 *td = nullptr) {
+    const int tid = threadIdx.x, NTH = (int)blockDim.x;
+    double g64;                                                  // g^DTK: a task starts at a multiple of DTK samples into its pool
+    const double g2 = g * g;
+    const double g4 = g2 * g2;
+    { const double g8 = g4 * g4, g16 = g8 * g8; g64 = (((g16 * g8) * g4) * g2) * g; static_assert(DTK == 31, "g^DTK is spelled out for 31"); }
+    const double S63 = g2 < 1.0 ? (1.0 - g64 * g64) / (1.0 - g2) : (double)DTK;      // sum_{j < DTK} g^2j
+    const double shift = bsub + lam * (1 - g);
+    for (int k = tid; k < ntask; k += NTH) {
+        int t0, len, o64;
+        if (td) { const int4 d = td[k]; t0 = d.x; len = d.y & 255; o64 = d.y >> 8; }
+        else { const int p = io.tk_pool[base2 + k], off = io.tk_off[base2 + k]; len = io.tk_len[base2 + k]; t0 = P.t[p] - 1 + off; o64 = off / DTK; }
+        // g^off by squaring; the task's sum in Horner form, s = g^off (x_0 + g (x_1 + g (x_2 + ...))), x_j = yp(t0 + j) (as four chains, below) -- one fma per sample instead of a product, a
+        // running power and two accumulations (round 6: an evaluation of Brent's objective was 3.7 us of vector-pipe issue on ONE wave per SIMD, 28 evaluations per
+        // trace) -- and the squares' sum in closed form, sum_{j < len} g^(2 (off + j)) = g^(2 off) (1 - g^(2 len)) / (1 - g^2), S63 = the factor of a whole task
+        double goff = 1.0;
+        { double bs = g64; for (int e = o64; e; e >>= 1) { if (e & 1) goff *= bs; bs *= bs; } }
+        // FOUR interleaved Horner chains in g^4 (samples j = r mod 4): a dependent fp64 fma every ~30 clocks was what an evaluation waited for, 63 in a row
+        double H0 = 0.0, H1 = 0.0, H2 = 0.0, H3 = 0.0;
+        for (int m1 = (len + 3) >> 2; m1 > 0; m1 -= 2) {         // two groups of four per batch of reads, last group first; samples behind the task's end count as 0
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = 4 * (m1 - 1 - (u >> 2)) + (u & 3); v[u] = y[t0 + (j >= 0 && j < len ? j : 0)]; }
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = 4 * (m1 - 1 - (u >> 2)) + (u & 3); x[u] = j < len ? (double)v[u] - shift : 0.0; }
+            H0 = fma(H0, g4, x[0]); H1 = fma(H1, g4, x[1]); H2 = fma(H2, g4, x[2]); H3 = fma(H3, g4, x[3]);
+            if (m1 >= 2) { H0 = fma(H0, g4, x[4]); H1 = fma(H1, g4, x[5]); H2 = fma(H2, g4, x[6]); H3 = fma(H3, g4, x[7]); }
+        }
+        const double H = (H0 + g * H1) + g2 * (H2 + g * H3);
+        const double s = goff * H;
+        const double h2 = goff * goff * (len == DTK ? S63 : (g2 < 1.0 ? (1.0 - ipow(g2, len)) / (1.0 - g2) : (double)len));
         tkv[2 * k] = s; tkv[2 * k + 1] = h2;
     }
     __syncthreads();
-    for (int k = tid; k < ntask; k += 256) {
-        if (io.tk_off[base2 + k] != 0) continue;                 // first task of its pool sums the pool's tasks in order
-        const int p = io.tk_pool[base2 + k];
-        const int nk = (P.l[p] + 63) >> 6;                       // (its task count from the pool length: no load-dependent loop exit)
+    for (int k = tid; k < ntask; k += NTH) {
+        int p, nk;
+        if (td) { const int4 d = td[k]; if (d.w == 0) continue; p = d.z; nk = d.w; }
+        else {
+            if (io.tk_off[base2 + k] != 0) continue;             // first task of its pool sums the pool's tasks in order
+            p = io.tk_pool[base2 + k];
+            nk = (P.l[p] + DTK - 1) / DTK;                       // (its task count from the pool length: no load-dependent loop exit)
+        }
         double s = 0, h2 = 0;
-        for (int q = 0; q < nk; ++q) { s += tkv[2 * (k + q)]; h2 += tkv[2 * (k + q) + 1]; }
+        for (int q0 = 0; q0 < nk; q0 += 8) {                     // (eight partials read at a time, added in order: a long pool -- a silent stretch of the trace -- has
+            double2 pv[8];                                       //  tens of tasks, and a read per addition made its first task's thread the evaluation's critical path)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const double2 *>(tkv + 2 * (k + (q0 + u < nk ? q0 + u : nk - 1)));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (q0 + u < nk) { s += pv[u].x; h2 += pv[u].y; }
+        }
         num[p] = s;
         if (hh) hh[p] = h2;
     }
@@ -529,13 +572,19 @@ __device__ __forceinline__ double hh_of(double g, int l) {       // cumsum(h.*h)
 // LONG: the trace does not fit LDS beside the Welch transform (T > 18436) -- it and the output staging live in a per-slot global buffer
 // (L2-resident: a few hundred KB per workgroup) and LDS only holds the scratch.  Same code; every access to y goes through a pointer whose
 // address space the compiler infers per instantiation.
+// round 6: 512 threads per trace (256 until then).  Every parallel phase of the kernel is a short dependent chain per thread (fp64 latency, LDS round trips), and a
+// workgroup has a CU to itself -- 20 to 100 traces per level on 256 CUs: with ONE wave per SIMD nothing hides those latencies (a 31-sample task of Brent's objective
+// took 3 us).  Two waves per SIMD and tasks half as long; the register budget (256) stays.
+constexpr int DECONV_NT = 512;
 template <bool LONG>
-__global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
+__global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ double red[8];
+    __shared__ double red[DECONV_NT / 64];
     __shared__ int sh_i[4];
-    const int tid = threadIdx.x, T = c.T;
+    const int tid = threadIdx.x, T = c.T, NTH = DECONV_NT;
     const int slot = blockIdx.x;
+    const long long tc0 = wall_clock64();                    // (option deconv_trace: thread 0 of the traced trace prints where its time goes, 100 MHz ticks)
+    long long tcl = tc0;
     int k;
     if (io.jobs) {                                         // several jobs in one launch: this workgroup's trace belongs to job e.x
         const int2 e = io.jlist[slot];
@@ -558,12 +607,19 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     double *tkv = io.tk_val + 2 * base2, *num = io.pnum + base, *hhs = nullptr;          // (tk_val: 4 T doubles per slot, two per task)
     bool in_lds = false;
     int ntask = 0;
-    auto place = [&]() {                            // after every build_tasks: P.n and ntask changed
-        in_lds = (size_t)48 * P.n + (size_t)16 * ntask <= scr_bytes;
+    int4 *td = nullptr;                             // the tasks' descriptors in LDS (pool_numerators)
+    auto place = [&]() {                            // after every build_tasks: P.n and ntask changed.  Called by every thread, behind a barrier
+        in_lds = (size_t)48 * P.n + (size_t)32 * ntask + 16 <= scr_bytes;
         if (in_lds) {
             double *end = reinterpret_cast<double *>(reinterpret_cast<char *>(scr) + scr_bytes);
             tkv = end - 2 * ntask; num = tkv - P.n; hhs = num - P.n;
-        } else { tkv = io.tk_val + 2 * base2; num = io.pnum + base; hhs = nullptr; }
+            td = reinterpret_cast<int4 *>((reinterpret_cast<uintptr_t>(hhs) - (size_t)16 * ntask) & ~(uintptr_t)15);
+            for (int q = tid; q < ntask; q += NTH) {
+                const int p = io.tk_pool[base2 + q], off = io.tk_off[base2 + q], len = io.tk_len[base2 + q];
+                td[q] = make_int4(P.t[p] - 1 + off, len | ((off / DTK) << 8), p, off == 0 ? (P.l[p] + DTK - 1) / DTK : 0);
+            }
+            __syncthreads();
+        } else { tkv = io.tk_val + 2 * base2; num = io.pnum + base; hhs = nullptr; td = nullptr; }
     };
 
     // ---- raw trace into LDS; HALS: ck_raw = C(k,:) + (U(k,:) - V(k,:)*C)/aa(k)  (HALS_temporal.m:62) ----
@@ -571,22 +627,31 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     if (c.hals) {
         const float a = io.aa[k];
         const int n0 = io.nptr[k], n1 = io.nptr[k + 1];
-        for (int t = tid; t < T; t += 256) {
+        for (int t = tid; t < T; t += NTH) {
             float vc = 0.f;
             for (int j = n0; j < n1; ++j) vc = fmaf(io.nval[j], io.C[(int64_t)io.nidx[j] * io.ldc + t], vc);
             y[t] = ck[t] + (io.U[(int64_t)k * io.ldc + t] - vc) / a;
         }
     } else {
         const float *src = io.Craw + (int64_t)k * io.ldc;
-        for (int t = tid; t < T; t += 256) y[t] = src[t];
+        for (int t = tid; t < T; t += NTH) y[t] = src[t];
     }
     __syncthreads();
+    // deconv_trace = 1000000 + k + 1: TIMING of trace k only (no 'DT' lines: a device printf costs tens of microseconds) -- the laps are kept and printed at the end
+    const bool timing = c.trace == 1000000 + k + 1 && tid == 0;
+    // (phase ids, named by scripts/deconv_phases.py: 0 row update + load, 1 quantile + median, 2 GetSn, 3 time constant, 4 cold OASIS pass + tasks,
+    //  5 b + Brent over g, 6 warm-started pass + tasks, 7 solution + outputs, 20 = evaluations of Brent's objective in the search that follows)
+    int lap_id[24]; float lap_us[24]; int nlap = 0;
+    auto lap = [&](int what) {
+        if (timing && nlap < 24) { const long long t = wall_clock64(); lap_id[nlap] = what; lap_us[nlap] = (float)(t - tcl) * 0.01f; ++nlap; tcl = t; }
+    };
+    lap(0);
     // NaN guard of deconvTemporal.m:37-40
     int bad = 0;
-    for (int t = tid; t < T; t += 256) bad |= !(y[t] == y[t]);
+    for (int t = tid; t < T; t += NTH) bad |= !(y[t] == y[t]);
     bad = __syncthreads_or(bad);
     if (bad) {
-        for (int t = tid; t < T; t += 256) { ck[t] = 0.f; io.S[(int64_t)k * io.ldc + t] = 0.f; if (io.Craw) io.Craw[(int64_t)k * io.ldc + t] = 0.f; }
+        for (int t = tid; t < T; t += NTH) { ck[t] = 0.f; io.S[(int64_t)k * io.ldc + t] = 0.f; if (io.Craw) io.Craw[(int64_t)k * io.ldc + t] = 0.f; }
         return;
     }
     // ---- median (HALS_temporal.m:78) and 15 % quantile (foopsi_oasisAR1.m:93) of the raw trace ----
@@ -604,19 +669,21 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         select_pair(y, T, (T - 1) / 2, reinterpret_cast<int *>(scr), m0, m1);
         const float med = 0.5f * (m0 + ((T & 1) ? m0 : m1));
         double s = 0, n = 0;
-        for (int t = tid; t < T; t += 256) if (y[t] < med) { s += y[t]; n += 1; }
+        for (int t = tid; t < T; t += NTH) if (y[t] < med) { s += y[t]; n += 1; }
         s = block_sum(s, red); n = block_sum(n, red);
         bsub = s / n;                                // b = mean(ck_raw(ck_raw < median(ck_raw)))
     }
     __syncthreads();
+    lap(1);
     // ---- noise level (GetSn on the raw trace: HALS_temporal.m:79, deconvTemporal.m:45) ----
     const double sn = get_sn(y, c, scr, red, true, tabs);
+    lap(2);
     // ---- time constant (deconvolveCa.m:73-89) ----
     double g = (double)io.pars[k];
     if (g == 0.0) {
         g = est_g(y, bsub, T, sn, red);
         if (g < -1.0) {                              // no stable AR(1): c = s = 0, pars = 0
-            for (int t = tid; t < T; t += 256) {
+            for (int t = tid; t < T; t += NTH) {
                 const float raw = (float)((double)y[t] - bsub);
                 ck[t] = raw;                         // "if sum(abs(ck))==0, ck = ck_raw" (HALS_temporal.m:95-97, deconvTemporal.m:53-55)
                 if (!c.hals || c.last) { io.S[(int64_t)k * io.ldc + t] = 0.f; io.Craw[(int64_t)k * io.ldc + t] = raw; }
@@ -625,10 +692,11 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
             return;
         }
     }
+    lap(3);
     const double smin = c.smin_opt < 0 ? -c.smin_opt * sn : c.smin_opt;       // deconvolveCa.m:116-118
     const double lam = c.lam;
     double mean_y = 0;
-    for (int t = tid; t < T; t += 256) mean_y += (double)y[t] - bsub;
+    for (int t = tid; t < T; t += NTH) mean_y += (double)y[t] - bsub;
     mean_y = block_sum(mean_y, red) / T;
 
     // ---- foopsi_oasisAR1.m:82-117 ----
@@ -637,13 +705,14 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
     __syncthreads();
     P.n = sh_i[0]; ntask = sh_i[1]; place();
+    lap(4);
     const bool trc = c.trace == k + 1 && tid == 0;
     if (trc) printf("DT first sn %.17g g %.17g b %.17g bsub %.17g smin %.17g pools %d\n", sn, g, b, bsub, smin, P.n);
     const int niter = c.optimize_b ? c.maxIter : (optimize_g ? 1 : 0);
     for (int it = 0; it < niter; ++it) {
         // sum of the current solution: c(t) = max(0, v/w) g^j on each pool
         double ssol = 0;
-        for (int q = tid; q < ntask; q += 256) {
+        for (int q = tid; q < ntask; q += NTH) {
             const int p = io.tk_pool[base2 + q], off = io.tk_off[base2 + q], len = io.tk_len[base2 + q];
             const double r = P.v[p] / P.w[p];
             double gj = pow(g, (double)off) * (r > 0 ? r : 0.0);
@@ -665,13 +734,15 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         }
         // ---- update_g (:122-180): Brent's fminbnd of rss(g) on [0,1] ----
         double sumy2 = 0;
-        for (int t = tid; t < T; t += 256) { const double v = (double)y[t] - (bsub + b); sumy2 += v * v; }
+        for (int t = tid; t < T; t += NTH) { const double v = (double)y[t] - (bsub + b); sumy2 += v * v; }
         sumy2 = block_sum(sumy2, red);
+        int nev = 0;
         auto rss = [&](double gg) -> double {
-            pool_numerators(y, bsub + b, lam, gg, P, io, base2, ntask, tkv, num, hhs);
+            pool_numerators(y, bsub + b, lam, gg, P, io, base2, ntask, tkv, num, hhs, td);
             double s = 0;
-            for (int p = tid; p < P.n; p += 256) { const double nm = num[p]; if (nm > 0) s += nm * nm / (hhs ? hhs[p] : hh_of(gg, P.l[p])); }
+            for (int p = tid; p < P.n; p += NTH) { const double nm = num[p]; if (nm > 0) s += nm * nm / (hhs ? hhs[p] : hh_of(gg, P.l[p])); }
             s = block_sum(s, red);
+            ++nev;
             return sumy2 - s;                        // ||y - c||^2 with c = max(num/hh, 0) h on every pool (lam = 0 form)
         };
         double xf, glast;
@@ -720,12 +791,14 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
             }
         }
         g = xf;
+        if (timing && nlap < 24) { lap_id[nlap] = 20; lap_us[nlap] = (float)nev; ++nlap; }      // (id 20: evaluations of the objective in this Brent search)
+        lap(5);
         // warm-started pools: v = yp' * h(g), w = cumsum(h_last.^2)(l) with h_last from the LAST rss_g call (:155-161, sic)
-        pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, tkv, num, nullptr);       // (hhs keeps the LAST rss_g call's sums)
+        pool_numerators(y, bsub + b, lam, g, P, io, base2, ntask, tkv, num, nullptr, td);   // (hhs keeps the LAST rss_g call's sums)
         const bool staged = in_lds;
         double *sv = reinterpret_cast<double *>(scr), *sw = sv + P.n, *sg = sw + P.n;
         int *st = reinterpret_cast<int *>(sg + P.n), *sl = st + P.n;
-        for (int p = tid; p < P.n; p += 256) {
+        for (int p = tid; p < P.n; p += NTH) {
             const int l = P.l[p];
             const double v = num[p], w = hhs ? hhs[p] : hh_of(glast, l);
             P.v[p] = v; P.w[p] = w;
@@ -740,6 +813,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
         }
         __syncthreads();
         P.n = sh_i[0]; ntask = sh_i[1]; place();
+        lap(6);
         if (trc) printf("DT updated g %.17g glast %.17g pools %d\n", g, glast, P.n);
         if (fabs(g - g0) / g0 < 1e-3) optimize_g = 0;            // :110-112
         if (!c.optimize_b) break;
@@ -748,7 +822,7 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     float *so = io.S + (int64_t)k * io.ldc;
     const bool wr = !c.hals || c.last;
     double sabs = 0;
-    for (int q = tid; q < ntask; q += 256) {
+    for (int q = tid; q < ntask; q += NTH) {
         const int p = io.tk_pool[base2 + q], off = io.tk_off[base2 + q], len = io.tk_len[base2 + q];
         const double r = P.v[p] / P.w[p];
         double gj = pow(g, (double)off) * (r > 0 ? r : 0.0);
@@ -758,18 +832,24 @@ __global__ void __launch_bounds__(256) k_deconv(DeconvCfg c, DeconvIO io) {
     sabs = block_sum(sabs, red);
     __syncthreads();
     const double btot = bsub + b;                     // HALS: ck_raw - b - tmp_options.b ; deconvTemporal: ck_raw - options.b
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += NTH) {
         const float raw = (float)((double)y[t] - btot);
         ck[t] = sabs == 0.0 ? raw : ostage[t];
         if (wr) { so[t] = 0.f; io.Craw[(int64_t)k * io.ldc + t] = raw; }
     }
     __syncthreads();
     if (wr)
-        for (int p = 1 + tid; p < P.n; p += 256) {    // s(t_p) = c(t_p) - g c(t_p - 1) at pool starts
+        for (int p = 1 + tid; p < P.n; p += NTH) {    // s(t_p) = c(t_p) - g c(t_p - 1) at pool starts
             const int t0 = P.t[p] - 1;
             so[t0] = (float)((double)ostage[t0] - g * (double)ostage[t0 - 1]);
         }
     if (tid == 0) { io.pars[k] = (float)g; io.sn_out[k] = (float)sn; io.b_out[k] = (float)b; }
+    lap(7);
+    if (timing) {
+        const double tot = (double)(wall_clock64() - tc0) * 0.01;
+        for (int i = 0; i < nlap; ++i) printf("DTT %d %d %.2f\n", k, lap_id[i], (double)lap_us[i]);
+        printf("DTT %d 99 %.2f\n", k, tot);
+    }
 }
 
 // ---- S5: per-pixel noise of the resident residual, sn = GetSn(Ysig)  (update_spatial_parallel.m:191-194) -------
@@ -941,11 +1021,11 @@ int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const
         io.ybuf = s.ybuf.as<float>(); io.obuf = s.obuf.as<float>();
         if (c.ylong == 2) { RET(s.tbuf.ensure((size_t)n * 2 * c.nfft * 4)); io.tbuf = s.tbuf.as<float>(); }
         if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<true>, dim3(n), dim3(256), shmem, c, io);
+        LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<true>, dim3(n), dim3(DECONV_NT), shmem, c, io);
         return 0;
     }
     if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<false>, dim3(n), dim3(256), shmem, c, io);
+    LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<false>, dim3(n), dim3(DECONV_NT), shmem, c, io);
     return 0;
 }
 
