@@ -695,7 +695,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(upload_centered(ctx, dC, C, K, T, c_order, dCc, dCm, &ldc));
         // win_proj_i8.hpp: what depends on the traces alone goes out NOW -- the host's footprint block lists (0.2 ms at the headline size) are built underneath it
         // instead of in front of an idle GPU (a fit that turns out to use a frame stride > 1 has queued 0.1 ms for nothing)
-        if (P->dig_valid && !outl && T <= 24576 && ctx->opt("win_i8", 1) != 0 && ctx->opt("gram_incremental", 1) != 0) {
+        if (P->dig_valid && !outl && T <= 24576 && ctx->opt("win_i8", 1) != 0 && ctx->opt("gram_incremental", 1) != 0 && !(P->base_valid && P->base_kstride > 1)) {      // (a strided fit keeps the fp64 window kernel)
             const int64_t T16 = P->dig_T16;
             RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
             RET(ctx->tscale.ensure((size_t)K * sizeof(double)));
@@ -853,6 +853,8 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         RET(dGb.ensure((size_t)nsg * gb_stride * sizeof(double)));
         if (P->dig_valid && g.kstride == 1 && g.Tp <= 24576 && ctx->opt("win_i8", 1) != 0 && K > 0) {
             // round 5 (win_proj_i8.hpp): the same sums on the int8 matrix pipe out of the resident digit planes; G = Cc Cc' once, K x K
+            // (round 6 ran a strided fit here too -- planes of every frame, trace digits zeroed on the skipped frames: correct, and no faster than the fp64 kernel on
+            //  patches of 128 x 128, which reads its 2 GB at 5.5 TB/s already, while the K x K trace Gram became a kernel of its own: profiles/r06/c5shard_i8.txt)
             const int64_t T16 = P->dig_T16;
             if (!trace_i8_done) {                                // (the first fit of a patch: the digit planes did not exist when the traces went up)
                 RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
@@ -1044,6 +1046,27 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             RET(ctx->dig_rspart.ensure((size_t)gd.y * nblk * BLKPX * sizeof(double)));
             LAUNCH(ctx, "bg_build_dig", k_build_dig, gd, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g, da, ctx->dig_smax.as<unsigned>(), digs, digp, tchunk16, ctx->dig_rspart.as<double>());
             LAUNCH(ctx, "bg_rs_reduce", k_rs_reduce, dim3((unsigned)nblk), dim3(256), 0, ctx->dig_rspart.as<double>(), (int)gd.y, (int64_t)nblk * BLKPX, rsT.as<double>());
+            // round 6: a fit on every kstride-th frame (T > 100 pmax: BASELINE configs[4], T = 20000) built the planes of ITS frames above, in the scratch, for the table.
+            // The planes the spatial update's table and the temporal projection read hold EVERY frame and are built here, once per recording, under the same memory
+            // rule (until round 5 a strided recording ran both on the fp64 pipe: 2.9-3.0 ms each for a rank's share of configs[4], profiles/r05/bench_c5shard_v3.json;
+            // 2.5-2.6 ms now -- at that patch size all three video passes move their bytes at 5.5 TB/s whatever the pipe)
+            if (incr && kstride > 1 && !resident && !P->derived && !has_a_bf && T <= 24576 && ctx->opt("win_i8", 1) != 0) {
+                BgGeom g1 = g; g1.kstride = 1; g1.Tp = T; g1.Tpad = (T + 4 * GK - 1) / (4 * GK) * (4 * GK);
+                const size_t d1bytes = (size_t)nblk * g1.Tpad * BLKPX * sizeof(float);
+                bool ok = true;
+                if (P->dig.cap < d1bytes) { size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot)); if (fr < d1bytes + ((size_t)8 << 30)) ok = false; }
+                if (ok) {
+                    RET(P->dig.ensure(d1bytes)); RET(P->dig_sc.ensure((size_t)nblk * BLKPX * sizeof(double)));
+                    CK(hipMemsetAsync(ctx->dig_smax.p, 0, (size_t)nblk * BLKPX * sizeof(unsigned), ctx->st()));
+                    const int tch1 = (int)((std::max<int64_t>(64, (g1.Tpad + 15) / 16) + 15) & ~int64_t(15));
+                    const dim3 gd1(nblk, (unsigned)((g1.Tpad + tch1 - 1) / tch1));
+                    DigA dv{nullptr, nullptr, nullptr, nullptr, 0};
+                    LAUNCH(ctx, "bg_dig_scale", k_dig_scale, gd1, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g1, dv, tch1, ctx->dig_smax.as<unsigned>());
+                    LAUNCH(ctx, "bg_build_dig", k_build_dig, gd1, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g1, dv, ctx->dig_smax.as<unsigned>(), P->dig_sc.as<double>(), P->dig.as<uint4>(), tch1,
+                           (double *)nullptr);
+                    P->dig_T16 = g1.Tpad >> 4; P->dig_valid = true; P->digp_valid = false;
+                }
+            }
         } else
         LAUNCH(ctx, "bg_build_bf", k_build_bf, gb, dim3(256), 0, P->Yc4.as<float4>(), P->Tc, g,
                has_a_bf ? dArow.as<int>() : nullptr, dAcol.as<int>(), dAval.as<float>(), dCc.as<float>(), ldc, ctx->bf.as<float>(), tchunk, rsT.as<double>());
@@ -1192,6 +1215,27 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     // without b0_out the call returns with the fit in flight (every later engine call is stream-ordered behind it)
     if (info) { info[0] = first_run ? 1 : 0; info[1] = kstride; info[2] = nactive; info[3] = pmax; }
     P->ysig_valid = false;
+    return 0;
+}
+
+// the window projection of ALL frames on the int8 pipe out of a patch's resident digit planes, for callers outside this file (vproj.hip: the spatial update's table):
+// digits of the centred traces dCc (K rows, ldc apart), the (block, trace-group pair) items of the lists lst_ptr / blall, one launch; Ut[seg * ut_stride + ...] as
+// k_win_proj_i8 leaves it (per-segment partial sums in real units)
+int win_i8_table(cnmfe_ctx *ctx, Patch *P, const char *name_dig, const char *name_proj, int K, const float *dCc, int64_t ldc, const std::vector<int> &lst_ptr, const std::vector<int> &blall,
+                 const int *dLp, const int *dLk, int nsg, double *dUt, int64_t ut_stride) {
+    const int64_t T16 = P->dig_T16;
+    RET(ctx->tdig.ensure((size_t)K * T16 * 4 * sizeof(uint4)));
+    RET(ctx->tscale.ensure((size_t)K * sizeof(double)));
+    LAUNCH(ctx, name_dig, k_trace_dig, dim3(K), dim3(256), 0, dCc, ldc, (int64_t)P->T, T16, ctx->tdig.as<uint4>(), ctx->tscale.as<double>());
+    std::vector<int> items;
+    for (int b_ : blall) {
+        const int ntl = (lst_ptr[b_ + 1] - lst_ptr[b_] + 15) >> 4;
+        for (int gq = 0; gq < (ntl + 1) / 2; ++gq) items.push_back(b_ | (gq << 24));
+    }
+    RET(to_dev(ctx, ctx->win_items, items.data(), items.size()));
+    if (!items.empty())
+        LAUNCH(ctx, name_proj, k_win_proj_i8, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
+               ctx->tscale.as<double>(), dLp, dLk, ctx->win_items.as<int>(), nsg, dUt, ut_stride);
     return 0;
 }
 

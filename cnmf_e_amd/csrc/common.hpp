@@ -373,7 +373,10 @@ int download_traces(cnmfe_ctx *ctx, const float *dC, int64_t ldc, float *C, int3
 // implemented in the kernel translation units
 int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx, const float *A_val,
                 const float *C, int c_order, int with_projection, float *b0_out, int64_t info[4], int b0_only = 0, double thresh_outlier = NAN);
-int tu_warm_resid(); int tu_warm_bg(); int tu_warm_factor(); int tu_warm_deconv(); int tu_warm_ssub(); int tu_warm_vproj();   // one per translation unit: load its code object (cnmfe_create)
+int tu_warm_resid(); int tu_warm_bg();
+int win_i8_table(cnmfe_ctx *ctx, Patch *P, const char *name_dig, const char *name_proj, int K, const float *dCc, int64_t ldc, const std::vector<int> &lst_ptr, const std::vector<int> &blall,
+                 const int *dLp, const int *dLk, int nsg, double *dUt, int64_t ut_stride);   // bg.hip: the int8 window projection of all frames (the spatial update's table, vproj.hip)
+int tu_warm_factor(); int tu_warm_deconv(); int tu_warm_ssub(); int tu_warm_vproj();   // one per translation unit: load its code object (cnmfe_create)
 int bg_reserve(cnmfe_ctx *ctx, Patch *P);                 // bg.hip: the ring fit's large buffers, sized by the geometry, allocated ahead of the first fit
 int residual_run(cnmfe_ctx *ctx, Patch *P, int pid, int32_t Ksel, const int64_t *A_colptr, const int32_t *A_rowidx,
                  const float *A_val, const float *C, int c_order, float *Ysig_out, int out_memspace, DevBuf *outbuf = nullptr, int tables_only = 0);

@@ -183,12 +183,18 @@ int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_ord
             const int nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
             RET(dUt.ensure((size_t)nsg * nent * sizeof(double)));
             const int nbig = (int)blk_nt[3].size();
+            if (!P->derived && P->dig_valid && P->T <= 24576 && ctx->opt("win_i8", 1) != 0) {
+                // round 6: the table on the int8 pipe out of the resident digit planes, by the fit's own kernel (win_proj_i8.hpp) -- what a recording whose fit runs on
+                // every other frame needs every iteration (the fit's table covers ITS frames only: BASELINE configs[4]), and any patch whose fit left no table
+                RET(win_i8_table(ctx, P, "spatial_trace_dig", "spatial_ptab_proj", K, dCc, ldc, lst_ptr, blall, P->pt_lp.as<int>(), dLk.as<int>(), nsg, dUt.as<double>(), nent));
+            } else {
             if (nbig)
                 LAUNCH(ctx, "spatial_ptab_proj", k_win_proj4<true>, dim3((unsigned)(nbig * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc, ldc, P->pt_lp.as<int>(), dLk.as<int>(),
                        dBl.as<int>(), nsg, dUt.as<double>(), nent, (double *)nullptr, (int64_t)0);
             if (nb_ > nbig)
                 LAUNCH(ctx, "spatial_ptab_proj", k_win_proj4<false>, dim3((unsigned)((nb_ - nbig) * nsg)), dim3(256), 0, P->Yc4.as<float4>(), g, dCc, ldc, P->pt_lp.as<int>(),
                        dLk.as<int>(), dBl.as<int>() + nbig, nsg, dUt.as<double>(), nent, (double *)nullptr, (int64_t)0);
+            }
             LAUNCH(ctx, "spatial_ptab_sum", k_vp_segsum, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, dUt.as<double>(), nent, nsg, nent, P->pt_tab.as<double>());
         }
         P->pt_K = K; P->pt_lp_h.swap(lst_ptr); P->pt_slot_h.swap(slot_of);
