@@ -440,6 +440,12 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_r1, "algorithmic_flops_per_launch": flops_r1,
                 "frac_of_fp32_vector_peak": flops_r1 / ms / 1e9 / F32_VECTOR_PEAK_TF,
                 "min_ms_at_hbm_peak": bytes_r1 / (HBM_PEAK_GBS * 1e6), "min_ms_at_vector_peak": flops_r1 / (F32_VECTOR_PEAK_TF * 1e9),
+                # every product takes one operand from the LDS halo tile; the duo-role kernel's four centres per thread halve that (resid_duo.hpp: 0.5 reads of 4 B per
+                # product), against ~150 TB/s of aggregate ds_read_b128 bandwidth (MI355X_MICROARCH.md, LDS)
+                "lds_bytes_per_launch": 0.5 * 4.0 * p * d * T, "frac_of_lds_peak": 0.5 * 4.0 * p * d * T / ms / 1e9 / 150e3,
+                "note": "a per-pixel weighted sum of p ring neighbours per frame, every pixel with its own weights: three resources at once -- 0.28 of the HBM peak for its "
+                        "bytes, ~0.34 of the fp32 vector peak for its 2 p d T flops, ~0.35 of the LDS read bandwidth for its operands -- none of them the roofline by itself; the "
+                        "kernel is not in the iteration since round 4 (r1_virtual)",
                 "timed": src["from"], "in_iteration": "residual_r1" in kern}
     def proj_roofs():
         """the two projection kernels (north_star's "residual projections"): S1 U = Ysig*C' on the search mask (HALS_spatial.m:27-32) and T1
