@@ -61,6 +61,7 @@ PROTOTYPES = {
     "cnmfe_upload_block": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "cnmfe_get_ymean": (C.c_int, [c_ctx, C.c_int, f64p]),
     "cnmfe_ring_init": (C.c_int, [c_ctx, C.c_int, C.c_int32, C.c_int32]),
+    "cnmfe_ring_solve_stats": (C.c_int, [c_ctx, C.c_int, i64p]),
     "cnmfe_fit_reserve": (C.c_int, [c_ctx, C.c_int]),
     "cnmfe_ring_nnz": (C.c_int, [c_ctx, C.c_int, i64p, i32p]),
     "cnmfe_ring_get_csr": (C.c_int, [c_ctx, C.c_int, i64p, i32p, f32p]),

@@ -541,7 +541,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
     // behaviour switches (include/cnmfe.h) and, behind them, the probes of scripts/ (diagnostics: solve_probe, r1_probe, deconv_trace, host_trace, debug)
-    static const char *known[] = {"r1_variant", "r1_delta", "r1_lazy", "r1_defer", "r1_virtual", "gram_incremental", "prealloc", "solve_packed", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "ssub_virtual",
+    static const char *known[] = {"r1_variant", "r1_delta", "r1_lazy", "r1_defer", "r1_virtual", "gram_incremental", "prealloc", "solve_packed", "solve_inv", "solve_inv_terms", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "ssub_virtual",
                                   "solve_probe", "r1_probe", "deconv_trace", "host_trace", "debug", nullptr};
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; if (!strcmp(name, "host_trace")) ctx->trace_level = (int)value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
@@ -617,7 +617,7 @@ int cnmfe_upload_block(cnmfe_ctx *ctx, int patch_id, const void *Y, int dtype, i
     CK(hipStreamSynchronize(ctx->st()));
     std::fill(P->frame_seen.begin() + t0, P->frame_seen.begin() + t0 + nt, (uint8_t)1);
     P->frames_uploaded += nt;
-    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->sys_valid = false; P->sys_alt_valid = false; P->pt_valid = false; P->dig_valid = false; P->digp_valid = false; P->yt4_valid = false;
+    P->ymean_valid = false; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->sys_valid = false; P->sys_alt_valid = false; P->kinv_valid = false; P->kinv_lam_valid = false; P->kinv_fits = 0; P->pt_valid = false; P->dig_valid = false; P->digp_valid = false; P->yt4_valid = false;
     return 0;
 }
 
@@ -662,7 +662,7 @@ int cnmfe_ring_init(cnmfe_ctx *ctx, int patch_id, int32_t radius, int32_t num_ne
     CK(hipStreamSynchronize(ctx->st()));
     P->stat_valid = false;
     if (P->stat_host) { (void)hipHostFree(P->stat_host); P->stat_host = nullptr; }      // sized by the number of ring offsets
-    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->sys_valid = false; P->sys_alt_valid = false; P->pt_valid = false;   // (the kept covariance tables cover the sub-tiles THIS ring needs)
+    P->ring_ready = true; P->ysig_valid = false; P->base_valid = false; P->base_alt_valid = false; P->sys_valid = false; P->sys_alt_valid = false; P->kinv_valid = false; P->kinv_lam_valid = false; P->kinv_fits = 0; P->pt_valid = false;   // (the kept covariance tables cover the sub-tiles THIS ring needs)
     return 0;
 }
 
@@ -784,6 +784,20 @@ static int check_csc(const char *what, int32_t K, int64_t nrow, const int64_t *c
     return 0;
 }
 extern "C++" { namespace cnmfe { int check_csc_pub(const char *what, int32_t ncol, int64_t nrow, const int64_t *colptr, const int32_t *rowidx) { return check_csc(what, ncol, nrow, colptr, rowidx); } } }
+
+int cnmfe_ring_solve_stats(cnmfe_ctx *ctx, int patch_id, int64_t out[4]) {
+    if (!ctx || !out) return fail(CNMFE_EINVAL, "null argument");
+    Patch *P = get_patch(ctx, patch_id);
+    if (!P) return fail(CNMFE_EINVAL, "no patch %d", patch_id);
+    out[0] = out[1] = out[2] = out[3] = -1;
+    if (!P->kinv_valid || !P->kinv_list.p) return 0;
+    CK(hipSetDevice(ctx->device));
+    int h[4];
+    CK(hipMemcpyAsync(h, P->kinv_list.as<int>() + 2 * P->d, sizeof(h), hipMemcpyDeviceToHost, ctx->st()));
+    CK(hipStreamSynchronize(ctx->st()));
+    for (int i = 0; i < 4; ++i) out[i] = h[i];
+    return 0;
+}
 
 int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                          const float *A_val, const float *C, int c_order, double thresh_outlier, int with_projection,

@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_
 }  // namespace cnmfe
 #include "ring_solve.hpp"
 #include "ring_solve_packed.hpp"
+#include "ring_solve_inv.hpp"
 #include "gram_i8.hpp"
 #include "win_proj_i8.hpp"
 namespace cnmfe {
@@ -647,7 +648,7 @@ int bg_reserve(cnmfe_ctx *ctx, Patch *P) {
         if (P->sys.cap < sys_bytes) {
             size_t fr = 0, tot = 0;
             CK(hipMemGetInfo(&fr, &tot));
-            if (fr >= sys_bytes + ((size_t)8 << 30)) { P->sys_valid = false; RET(P->sys.ensure(sys_bytes)); }
+            if (fr >= sys_bytes + ((size_t)8 << 30)) { P->sys_valid = false; P->kinv_valid = false; P->kinv_lam_valid = false; P->kinv_fits = 0; RET(P->sys.ensure(sys_bytes)); }
         }
     }
     // round 5: the two further copies of the video (digit planes of the window projection, the temporal projection's read-order copy) under the rule their builders
@@ -814,9 +815,10 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
         P->cov_base.swap(P->cov_base_alt); P->rowsum_base.swap(P->rowsum_base_alt);
         std::swap(P->base_valid, P->base_alt_valid); std::swap(P->base_kstride, P->base_alt_kstride);
         P->sys.swap(P->sys_alt); std::swap(P->sys_valid, P->sys_alt_valid);          // (the packed systems belong to their table)
+        P->kinv_valid = false; P->kinv_lam_valid = false; P->kinv_fits = 0;          // (and the inverses to the packed systems)
     }
     const bool build_base = incr && !(P->base_valid && P->base_kstride == kstride);
-    if (build_base) P->sys_valid = false;
+    if (build_base) { P->sys_valid = false; P->kinv_valid = false; P->kinv_lam_valid = false; P->kinv_fits = 0; }
     ht.mark("footprint block lists");
     g.bf4 = 1;
     // round 5 (gram_i8.hpp): the Gram -- the VIDEO's table of the incremental path, or the direct Gram of Bf where that path does not apply -- on the int8 matrix
@@ -1150,7 +1152,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                                         P->rowsum_base.as<double>(), (const unsigned char *)nullptr, (float *)nullptr, dErrP, 0, (const int *)nullptr, dFill.as<double>(), P->sys.as<double>()); break;
                 switch (nt) { RSP_CASE(1) RSP_CASE(2) RSP_CASE(3) RSP_CASE(4) RSP_CASE(5) RSP_CASE(6) RSP_CASE(7) RSP_CASE(8) default: break; }
 #undef RSP_CASE
-                P->sys_valid = true;
+                P->sys_valid = true; P->kinv_valid = false; P->kinv_lam_valid = false; P->kinv_fits = 0;
             }
         }
         if (incr) {
@@ -1192,10 +1194,54 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
             int *dErrS = nullptr;
             RET(ctx_errflag(ctx, &dErrS));
+            // ---- round 6 (ring_solve_inv.hpp): the fit out of the cached explicit inverses.  solve_inv: 0 off; 1 (default) the inverses are built in front of a
+            // patch's SECOND fit with footprints (a recording fitted once never pays the build) at the ridge its first fit left; 2 in front of the first ----
+            const int inv_mode = (int)ctx->opt("solve_inv", 0);
+            const size_t kinv_bytes = (size_t)P->d * (size_t)ri_stride(nt) * sizeof(double);
+            bool inv_ok = inv_mode != 0 && has_a && nt <= 6 && !(probe & 7);
+            if (inv_ok && P->kinv.cap < kinv_bytes) {
+                size_t fr = 0, tot = 0;
+                CK(hipMemGetInfo(&fr, &tot));
+                if (fr < kinv_bytes + ((size_t)8 << 30)) inv_ok = false;
+            }
+            double *lam_arr = nullptr;
+            if (inv_ok) {
+                if (P->kinv_lam.cap < (size_t)P->d * sizeof(double)) { RET(P->kinv_lam.ensure((size_t)P->d * sizeof(double))); P->kinv_lam_valid = false; }
+                RET(P->kinv_list.ensure(((size_t)2 * P->d + 4) * sizeof(int)));
+                if (!P->kinv_lam_valid) { CK(hipMemsetAsync(P->kinv_lam.p, 0, (size_t)P->d * sizeof(double), ctx->st())); P->kinv_lam_valid = true; }
+                lam_arr = P->kinv_lam.as<double>();
+                if (!P->kinv_valid && (P->kinv_fits >= 1 || inv_mode >= 2)) {
+                    RET(P->kinv.ensure(kinv_bytes));
+#define RI_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_inverse", (k_ring_inverse<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), P->rowsum_base.as<double>(), (const double *)lam_arr, P->kinv.as<double>()); break;
+                    switch (nt) { RI_CASE(1) RI_CASE(2) RI_CASE(3) RI_CASE(4) RI_CASE(5) RI_CASE(6) default: break; }
+#undef RI_CASE
+                    P->kinv_valid = true;
+                }
+                ++P->kinv_fits;
+            }
+            if (inv_ok && P->kinv_valid) {
+                int *flist = P->kinv_list.as<int>(), *rlist = flist + P->d, *fcnt = flist + 2 * P->d;
+                CK(hipMemsetAsync(fcnt, 0, 4 * sizeof(int), ctx->st()));
+                InvArgs ia{};
+                ia.kp = P->kinv.as<double>(); ia.sys = P->sys.as<double>(); ia.csum = dCsum.as<double>(); ia.lam_out = lam_arr;
+                ia.flist = flist; ia.rlist = rlist; ia.fcnt = fcnt; ia.maxit = (int)ctx->opt("solve_inv_terms", 5);
+                const unsigned nlist = (unsigned)std::min<int64_t>(P->d, 2048);
+#define RA_CASE(NT_) case NT_: \
+                LAUNCH(ctx, "bg_ring_solve", (k_ring_apply<NT_>), dim3((unsigned)P->d), dim3(64), 0, ia, pa, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(), ctx->rowsum.as<double>(), \
+                       act, P->W.as<float>(), dErrS, probe, (const int *)nullptr); \
+                LAUNCH(ctx, "bg_ring_solve_rest", (k_ring_solve6<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), P->ring_dc.as<int>(), \
+                       ctx->rowsum.as<double>(), (const unsigned char *)nullptr, P->W.as<float>(), dErrS, probe, (const int *)flist, (const int *)fcnt, lam_arr); \
+                LAUNCH(ctx, "bg_ring_inverse_rest", (k_ring_inverse_list<NT_>), dim3(nlist), dim3(64), 0, P->sys.as<double>(), g, P->ring_dr.as<int>(), P->ring_dc.as<int>(), \
+                       P->rowsum_base.as<double>(), (const double *)lam_arr, P->kinv.as<double>(), (const int *)rlist, (const int *)(fcnt + 3)); break;
+                switch (nt) { RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) default: break; }
+#undef RA_CASE
+            } else {
 #define RS6_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
-                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr); break;
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr, (const int *)nullptr, lam_arr); break;
             switch (nt) { RS6_CASE(1) RS6_CASE(2) RS6_CASE(3) RS6_CASE(4) RS6_CASE(5) RS6_CASE(6) RS6_CASE(7) RS6_CASE(8) default: break; }
 #undef RS6_CASE
+            }
         } else {
         RET(dWcodes.ensure((size_t)nwin * 256 * sizeof(int)));
         LAUNCH(ctx, "bg_win_codes", k_win_codes, dim3((unsigned)nwin), dim3(256), 0, dPairOf.as<int>(), g.nbr, g.nbc, woff, maxd, nrel, dWcodes.as<int>());

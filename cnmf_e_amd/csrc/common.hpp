@@ -189,6 +189,10 @@ struct Patch {
     // the video's normal equations per patch pixel, packed in the ring solve's register-tile order (ring_solve_packed.hpp): gathered once from cov_base
     // (and once more for a second frame stride), 43 KB per pixel at p = 96
     DevBuf sys, sys_alt; bool sys_valid = false, sys_alt_valid = false;
+    // round 6 (ring_solve_inv.hpp): the explicit inverses of those systems at a ridge lam0 per pixel (k_ring_inverse: built behind the patch's first packed fit,
+    // the bytes of `sys` once more), the ridge every fit leaves per pixel, and the list of pixels a fit's fast path (k_ring_apply) left to k_ring_solve6
+    // (kinv_list: [d] pixels, then 4 counters).  They belong to `sys`: invalid whenever it is
+    DevBuf kinv, kinv_lam, kinv_list; bool kinv_valid = false, kinv_lam_valid = false; int kinv_fits = 0;
     // the centred video as 32-bit fixed-point digit planes [blk][frame/16][plane][256 px] x 16 B + per-pixel scales (gram_i8.hpp), kept for the fits' window projection
     // (win_proj_i8.hpp) when the memory allows: frame stride 1 only
     DevBuf dig, dig_sc; int64_t dig_T16 = 0; bool dig_valid = false;

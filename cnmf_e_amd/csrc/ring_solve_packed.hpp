@@ -69,7 +69,8 @@ __device__ __forceinline__ void rsp_rank2(double4_t (&T)[(NT * (NT + 1)) / 2], c
 template <int NT>
 __global__ void __launch_bounds__(64, (NT <= 2 ? 4 : (NT <= 3 ? 3 : (NT <= 6 ? 2 : 1))))
 k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *__restrict__ dr, const int *__restrict__ dc, const double *__restrict__ rowsum,
-              const unsigned char *__restrict__ active, float *__restrict__ W, int *__restrict__ errflag, int probe, const int *__restrict__ pix) {
+              const unsigned char *__restrict__ active, float *__restrict__ W, int *__restrict__ errflag, int probe, const int *__restrict__ pix, const int *__restrict__ npix,
+              double *__restrict__ lam_out) {
     constexpr int N = 16 * NT, NTILE = (NT * (NT + 1)) / 2;
     __shared__ int s_q[N + 1];                                          // block-region pixel of ring neighbour a ([N]: the centre), -1: outside the field of view
     __shared__ int s_rs[N + 1];                                         // block * 256 + local pixel (row sums)
@@ -89,6 +90,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     double (*s_part)[64] = reinterpret_cast<double (*)[64]>(s_core + 16 * RS_DS);
     float (*s_a)[N + 2] = reinterpret_cast<float (*)[N + 2]>(s_core);
     static_assert(sizeof(float) * RSP_NS * (N + 2) <= sizeof(double) * (16 * RS_DS + 4 * 64), "staged A values do not fit the exchange buffers");
+    if (npix && (int)blockIdx.x >= *npix) return;                       // (a device-side list: ring_solve_inv.hpp -- what its fast path left over; the grid covers the list's capacity)
     const int64_t m = pix ? pix[blockIdx.x] : (int)blockIdx.x;
     if (active && !active[m]) return;
     const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
@@ -223,6 +225,7 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (c == rq + 4 * r && rowex[I]) T[rs_tix(I, I)][r] += lam;
     if (bad) atomicOr(errflag, 1);
+    if (lam_out && lane == 0) lam_out[m] = lam;                         // (the ridge of this fit: the lam0 of an inverse built later, ring_solve_inv.hpp)
     __syncthreads();
     double wc[NT];
     rs_solve_core<NT>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);

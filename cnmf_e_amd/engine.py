@@ -350,6 +350,13 @@ class Engine:
                                            cord, float(thresh_outlier), int(bool(with_projection)), _p(b0, L.f32p), _p(inf, L.i64p)))
         return b0, dict(first_run=bool(inf[0]), frame_stride=int(inf[1]), n_active=int(inf[2]), pmax=int(inf[3]))
 
+    def ring_solve_stats(self, pid):
+        """diagnostics of the last fit's ring solve out of the cached inverses (cnmfe_ring_solve_stats): pixels left to the factorising kernel, ridge-series terms,
+        pixels with at least one term, inverses rebuilt; all -1 without inverses"""
+        out = np.zeros(4, dtype=np.int64)
+        L.check(L.lib.cnmfe_ring_solve_stats(self._ctx, pid, _p(out, L.i64p)))
+        return dict(left_over=int(out[0]), series_terms=int(out[1]), pixels_with_terms=int(out[2]), rebuilt=int(out[3]))
+
     # -- bg_ssub > 1 ---------------------------------------------------------------------------------------------
     def patch_derive(self, src_pid, new_pid, ssub, mode):
         """low-resolution patch of src_pid (mode 'nearest' | 'bicubic'); its FOV is the ceil(nr_b/s) x ceil(nc_b/s) grid"""

@@ -120,6 +120,12 @@ int cnmfe_fit_ring_model(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64_t 
                          double thresh_outlier, int with_projection,
                          float *b0_out /* d or NULL */, int64_t info[4]);
 
+/* Diagnostics of the last fit's ring solve when it ran out of the cached inverses (option solve_inv, ring_solve_inv.hpp; replaces nothing in the reference --
+ * fit_ring_model.m:106 solves every pixel from scratch): out[0] pixels the fast path left to the factorising kernel (more than 8 neurons around the ring, a
+ * ridge series that did not converge), out[3] those among them whose inverse was rebuilt; with solve_probe bit 512 also out[1] ridge-series terms taken over
+ * all pixels, out[2] pixels that took at least one.  All -1 when the patch has no inverses.  Synchronises the context's stream. */
+int cnmfe_ring_solve_stats(cnmfe_ctx *ctx, int patch_id, int64_t out[4]);
+
 /* Optional, once per patch that will be FITTED (after cnmfe_ring_init; with bg_ssub > 1 that is the low-resolution fit patch): allocate the ring fit's large
  * device buffers now -- the block-pair covariance tables, the tiled residual, the window projection's partial sums (18 GB for 512 x 512 x 10000, radius 15) --
  * so that the first cnmfe_fit_ring_model queues its kernels without a hipMalloc in between.  Sizes follow the geometry only; nothing is computed.  The host
@@ -405,6 +411,10 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  *   ssub_virtual      the same for cnmfe_residual_ssub (through the resampling maps): 2 always, 1 (default) on patches of at least 5e8 samples -- below that the
  *                     low-resolution sweep is the faster form, profiles/r05/ssub_virtual_check.txt --, 0: the low-resolution sweep + upsample
  *   gram_incremental  default 1: the covariance table of the VIDEO is kept and corrected per fit (see cnmfe_fit_ring_model); 0: the direct Gram of Bf every fit
+ *   solve_inv         default 1: fits of a patch from its second one with footprints on solve their pixels out of explicit inverses of the VIDEO's normal equations
+ *                     (built once in front of that fit, the bytes of solve_packed's systems once more; the footprints enter by the Woodbury identity, the ridge's
+ *                     drift by a short series: ring_solve_inv.hpp); 2: built in front of the first such fit; 0: every fit factors every pixel's system
+ *   solve_inv_terms   default 5: terms of the ridge series before a pixel is left to the factorising kernel and its inverse rebuilt
  *   solve_packed      default 1: the ring solve reads per-pixel packed copies of the video's normal equations (43 KB per patch pixel at 96 ring offsets, allocated
  *                     when that much + 8 GB is free) and applies the footprints' corrections in registers; 0: the block-pair table is swept and gathered from
  *   gram_i8           default 1: the table (and the direct Gram of the fallback) on the int8 matrix pipe from 32-bit fixed-point digit planes, exact int32
