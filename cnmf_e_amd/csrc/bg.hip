@@ -494,6 +494,7 @@ __global__ void __launch_bounds__(256) k_win_codes(const int *__restrict__ pair_
 #include "ring_solve.hpp"
 #include "ring_solve_packed.hpp"
 #include "ring_solve_inv.hpp"
+#include "ring_solve_staged.hpp"
 #include "gram_i8.hpp"
 #include "win_proj_i8.hpp"
 namespace cnmfe {
@@ -763,14 +764,17 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     bool incr = !outl && ctx->opt("gram_incremental", 1) != 0 && K < 32768;   // the clipped Bf is not linear in the video: direct Gram   // (derived low-resolution patches of bg_ssub included: their video is built once)
     std::vector<int> lst_ptr, lst_k, blk_nt[4];
     std::vector<short> slot_of;
+    static thread_local std::vector<int> nbox;               // 4 per neuron: first / last row, first / last column of its footprint in the block region
     if (incr) {
         // (flat arrays, two passes: a vector of vectors cost 0.4 ms of allocator churn per fit at the headline size, in front of the window projection)
         const int nblk_ = g.nbr * g.nbc;
         static thread_local std::vector<int> own, seen, cnt, pairs_b, pairs_k, mark;
         own.assign(nblk_, -1); seen.assign(nblk_, -1); cnt.assign(nblk_ + 1, 0);
         pairs_b.clear(); pairs_k.clear();
+        nbox.assign((size_t)4 * std::max(1, K), 0);
         for (int k = 0; k < K && has_a; ++k) {
             mark.clear();
+            int bx[4] = {1 << 30, -1, 1 << 30, -1};                                 // the footprint's bounding box in the block region: rows, columns
             // (the entries of a column ascend with the pixel index: one step per run of an image column of the block region, not per entry -- this list
             //  building sits in front of the window projection's launch)
             for (int64_t e = A_colptr[k]; e < A_colptr[k + 1];) {
@@ -778,11 +782,13 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                 int qlast = q0;
                 ++e;
                 while (e < A_colptr[k + 1] && A_rowidx[e] < col_end && A_rowidx[e] >= qlast) { qlast = A_rowidx[e]; ++e; }
+                bx[0] = std::min(bx[0], q0 - cb * P->nr_b); bx[1] = std::max(bx[1], qlast - cb * P->nr_b); bx[2] = std::min(bx[2], cb); bx[3] = std::max(bx[3], cb);
                 for (int bi = (q0 - cb * P->nr_b) >> 4; bi <= (qlast - cb * P->nr_b) >> 4; ++bi) {
                     const int b_ = (cb >> 4) * g.nbr + bi;
                     if (own[b_] != k) { own[b_] = k; mark.push_back(b_); }
                 }
             }
+            for (int i = 0; i < 4; ++i) nbox[(size_t)4 * k + i] = bx[i];
             for (int b_ : mark)
                 for (int dj = -maxd; dj <= maxd; ++dj)
                     for (int di = -maxd; di <= maxd; ++di) {
@@ -839,6 +845,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
     std::vector<int> blall;
     int nsg = 1; int64_t ut_stride = 0, gb_stride = 0;
     bool proj_queued = false;
+    bool stage_ok = false;                                     // ring_solve_staged.hpp: this fit's neuron windows are built
     bool win_i8 = false;                                       // the window projection ran on the int8 pipe: k_win_fix takes G from the K x K matrix
     auto queue_projection = [&]() -> int {
         for (int t = 3; t >= 0; --t) blall.insert(blall.end(), blk_nt[t].begin(), blk_nt[t].end());      // longest lists first
@@ -1176,6 +1183,43 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                        dNeed.as<unsigned short>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dLp.as<int>(), dSlot.as<short>(), dUt.as<double>());
                 LAUNCH(ctx, "bg_rowsum_correct", k_rowsum_correct, dim3(nblk), dim3(256), 0, P->rowsum_base.as<double>(), ctx->rowsum.as<double>(), g,
                        dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(), dCsum.as<double>());
+                // ---- round 6 (ring_solve_staged.hpp): U~ and A of every neuron as dense images over its footprint's bounding box dilated by the ring radius,
+                // and per list position the neuron's window: the solve samples them with index arithmetic instead of walking CSR rows and slot tables ----
+                if (packed && ctx->opt("solve_staged", 1) != 0 && P->nr_b < 32768 && P->nc_b < 32768) {
+                    std::vector<int> nmeta((size_t)8 * K, 0), lmeta((size_t)8 * std::max<size_t>(1, lst_k.size()), 0);
+                    int64_t tot = 0;
+                    stage_ok = true;
+                    for (int k = 0; k < K; ++k) {
+                        int *mk = &nmeta[(size_t)8 * k];
+                        if (nbox[(size_t)4 * k + 1] < 0) continue;                   // (an empty footprint: on no list)
+                        // a centre whose ring reaches the footprint lies within one radius of its bounding box (the candidate test), and that ring's pixels within
+                        // two: U~ = Yc Cc' - ... is non-zero wherever the video is, and the correction pairs it with A on ANOTHER ring pixel
+                        const int R2 = 2 * g.p_radius;
+                        const int r0 = std::max(0, nbox[(size_t)4 * k] - R2), r1 = std::min(P->nr_b - 1, nbox[(size_t)4 * k + 1] + R2);
+                        const int c0 = std::max(0, nbox[(size_t)4 * k + 2] - R2), c1 = std::min(P->nc_b - 1, nbox[(size_t)4 * k + 3] + R2);
+                        mk[5] = std::max(0, nbox[(size_t)4 * k] - g.p_radius) | (std::min(P->nr_b - 1, nbox[(size_t)4 * k + 1] + g.p_radius) << 16);
+                        mk[6] = std::max(0, nbox[(size_t)4 * k + 2] - g.p_radius) | (std::min(P->nc_b - 1, nbox[(size_t)4 * k + 3] + g.p_radius) << 16);
+                        const int64_t n = (int64_t)(r1 - r0 + 1) * (c1 - c0 + 1);
+                        if (n > NWIN_MAX || tot + n > ((int64_t)1 << 30)) { stage_ok = false; break; }
+                        mk[0] = r0; mk[1] = c0; mk[2] = r1 - r0 + 1; mk[3] = c1 - c0 + 1; mk[4] = (int)tot;
+                        tot += n;
+                    }
+                    if (stage_ok) {
+                        for (size_t i = 0; i < lst_k.size(); ++i) {
+                            const int *mk = &nmeta[(size_t)8 * lst_k[i]];
+                            int *ml = &lmeta[8 * i];
+                            ml[0] = lst_k[i]; ml[1] = mk[0]; ml[2] = mk[1]; ml[3] = mk[2]; ml[4] = mk[3]; ml[5] = mk[4]; ml[6] = mk[5]; ml[7] = mk[6];
+                        }
+                        RET(to_dev(ctx, ctx->stg[0], nmeta.data(), nmeta.size()));
+                        RET(to_dev(ctx, ctx->stg[1], lmeta.data(), lmeta.size()));
+                        RET(ctx->stg[2].ensure((size_t)std::max<int64_t>(1, tot) * sizeof(double)));
+                        RET(ctx->stg[3].ensure((size_t)std::max<int64_t>(1, tot) * sizeof(float)));
+                        int *dErrW = nullptr;
+                        RET(ctx_errflag(ctx, &dErrW));
+                        LAUNCH(ctx, "bg_neuron_windows", k_nwin_build, dim3((unsigned)K), dim3(256), 0, ctx->stg[0].as<int>(), g, (int)K, dArow.as<int>(), dAcol.as<int>(), dAval.as<float>(),
+                               dLp.as<int>(), dSlot.as<short>(), dUt.as<double>(), ctx->stg[2].as<double>(), ctx->stg[3].as<float>(), dErrW);
+                    }
+                }
             } else {                                                   // no footprints: Bf is the centred video itself
                 if (!packed)
                 CK(hipMemcpyAsync(ctx->cov.p, P->cov_base.p, (size_t)npairs * BLKPX * BLKPX * sizeof(double), hipMemcpyDeviceToDevice, ctx->st()));
@@ -1196,7 +1240,7 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             RET(ctx_errflag(ctx, &dErrS));
             // ---- round 6 (ring_solve_inv.hpp): the fit out of the cached explicit inverses.  solve_inv: 0 off; 1 (default) the inverses are built in front of a
             // patch's SECOND fit with footprints (a recording fitted once never pays the build) at the ridge its first fit left; 2 in front of the first ----
-            const int inv_mode = (int)ctx->opt("solve_inv", 0);
+            const int inv_mode = (int)ctx->opt("solve_inv", 0);             // (off by default: in the steady-state iteration the ridge drifts every fit, the series takes 1-2 terms per pixel and the fit is no faster than the factorising kernel -- DESIGN.md)
             const size_t kinv_bytes = (size_t)P->d * (size_t)ri_stride(nt) * sizeof(double);
             bool inv_ok = inv_mode != 0 && has_a && nt <= 6 && !(probe & 7);
             if (inv_ok && P->kinv.cap < kinv_bytes) {
@@ -1236,6 +1280,12 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
                        P->rowsum_base.as<double>(), (const double *)lam_arr, P->kinv.as<double>(), (const int *)rlist, (const int *)(fcnt + 3)); break;
                 switch (nt) { RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) default: break; }
 #undef RA_CASE
+            } else if (has_a && stage_ok && nt <= 6) {
+                StageArgs sg{dLp.as<int>(), ctx->stg[1].as<int>(), ctx->stg[2].as<double>(), ctx->stg[3].as<float>()};
+#define RS8_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve8<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), sg, g, P->ring_dr.as<int>(), \
+                                        P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr, lam_arr); break;
+                switch (nt) { RS8_CASE(1) RS8_CASE(2) RS8_CASE(3) RS8_CASE(4) RS8_CASE(5) RS8_CASE(6) default: break; }
+#undef RS8_CASE
             } else {
 #define RS6_CASE(NT_) case NT_: LAUNCH(ctx, "bg_ring_solve", (k_ring_solve6<NT_>), dim3((unsigned)P->d), dim3(64), 0, P->sys.as<double>(), pa, g, P->ring_dr.as<int>(), \
                                         P->ring_dc.as<int>(), ctx->rowsum.as<double>(), act, P->W.as<float>(), dErrS, probe, (const int *)nullptr, (const int *)nullptr, lam_arr); break;

@@ -316,6 +316,7 @@ struct cnmfe_ctx {
     cnmfe::DevBuf tmp[16];    // small scratch
     size_t hw_cc = 0, hw_cm = 0, hw_wa[3] = {0, 0, 0};     // high-water sizes of the buffers that rotate through tmp[1], tmp[2], tmp[8..10] (DevBuf::ensure_hw)
     cnmfe::DevBuf inc[7];     // incremental ring regression: block footprint lists, U~, trace sums
+    cnmfe::DevBuf stg[4];     // ring_solve_staged.hpp: per-neuron window metadata, per-list-position metadata, the windows of U~ and of A
     cnmfe::DevBuf wcodes, solve_fill;   // ring solve: the block-pair codes per window origin (k_win_codes); the fill values {0, 1} in global memory (ring_solve.hpp)
     cnmfe::DevBuf stage;      // upload staging
     // per-call device scratch of the factor updates (factor.hip, deconv.hip): grown on demand, NEVER freed between calls -- a hipMalloc /

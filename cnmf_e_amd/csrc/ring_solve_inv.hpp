@@ -88,40 +88,56 @@ __device__ __forceinline__ double4_t ri_transpose(const double4_t &X, double *s_
 __device__ __forceinline__ int ri_perm(int a) { return (a & ~15) + ((a & 3) << 2) + ((a >> 2) & 3); }      // element rq + 4 r of a block -> 4 rq + r
 
 // y = K v on the vector pipe.  Tiles: T[rs_tix(I, J)] (I >= J), lane (c, rq), register r = K[16 I + rq + 4 r][16 J + c].  v in LDS twice: sv[a] and
-// svp[ri_perm(a)] (a lane's four rows of a block are 32 consecutive bytes).  y goes out the same way (so, sop); every lane returns nothing -- callers read LDS.
+// svp[ri_perm(a)] (a lane's four rows of a block are 32 consecutive bytes).  A tile serves two products: (K_IJ v_J)[rho] contracts over the 16 lanes of a DPP
+// row -- summed by a DPP butterfly, no LDS round trip --, (K_IJ' v_I)[gam] over registers and the four row groups -- the four partial sums of every block row go
+// to their own slice of `part` (6 x 64 doubles), so that ONE barrier separates all products from all sums.  The lane-contraction sums land in `so` (row group rq
+// writes rows rq + 4 r), then every lane adds the row-group partials of the elements it owns (a0 = lane, a1 = lane + 64) and returns them; `sop` (optional)
+// receives the result in the permuted order.
 template <int NT>
 __device__ __forceinline__ void ri_matvec(const double4_t (&T)[(NT * (NT + 1)) / 2], const double *sv, const double *svp, double *so, double *sop,
-                                          double *s_blk, double *s_red, int c, int rq) {
+                                          double *part, int c, int rq, double &y0, double &y1) {
+    constexpr int N = 16 * NT;
+    const int lane = rq * 16 + c;
 #pragma unroll
     for (int I = 0; I < NT; ++I) {
         double4_t an = {0.0, 0.0, 0.0, 0.0};
         double at = 0.0;
 #pragma unroll
-        for (int J = 0; J <= I; ++J) {                      // (K_IJ v_J)[rho] = sum_gam tile[rho][gam] v[16 J + gam]: contracts over the lanes of a DPP row
+        for (int J = 0; J <= I; ++J) {
             const double vc = sv[16 * J + c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) an[r] = fma(T[rs_tix(I, J)][r], vc, an[r]);
         }
 #pragma unroll
-        for (int J = I + 1; J < NT; ++J) {                  // (K_JI' v_J)[gam] = sum_rho tile[rho][gam] v[16 J + rho]: contracts over registers and row groups
+        for (int J = I + 1; J < NT; ++J) {
             const double2 v01 = *reinterpret_cast<const double2 *>(svp + 16 * J + 4 * rq), v23 = *reinterpret_cast<const double2 *>(svp + 16 * J + 4 * rq + 2);
             at = fma(T[rs_tix(J, I)][0], v01.x, at); at = fma(T[rs_tix(J, I)][1], v01.y, at);
             at = fma(T[rs_tix(J, I)][2], v23.x, at); at = fma(T[rs_tix(J, I)][3], v23.y, at);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_blk[(rq + 4 * r) * RS_DS + c] = an[r];
-        s_red[c * 4 + rq] = at;
-        __syncthreads();
-        double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 16; cc += 2) { const double2 v = *reinterpret_cast<const double2 *>(s_blk + c * RS_DS + cc); y0 += v.x; y1 += v.y; }
-        const double2 r01 = *reinterpret_cast<const double2 *>(s_red + c * 4), r23 = *reinterpret_cast<const double2 *>(s_red + c * 4 + 2);
-        const double y = (y0 + y1) + ((r01.x + r01.y) + (r23.x + r23.y));
-        if (rq == 0) { so[16 * I + c] = y; sop[16 * I + ((c & 3) << 2) + (c >> 2)] = y; }
-        __syncthreads();
+        for (int r = 0; r < 4; ++r) an[r] = ri_row_sum(an[r]);
+        const double mine = c == 0 ? an[0] : (c == 1 ? an[1] : (c == 2 ? an[2] : an[3]));
+        if (c < 4) so[16 * I + rq + 4 * c] = mine;
+        part[I * 64 + c * 4 + rq] = at;
         asm volatile("" ::: "memory");                     // (v is re-read per block row: kept in registers across the rows it costs 60 beside the tiles)
         __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+    const int a0 = lane, a1 = lane + 64;
+    y0 = 0.0; y1 = 0.0;
+    if (a0 < N) {
+        const double2 r01 = *reinterpret_cast<const double2 *>(part + (a0 >> 4) * 64 + (a0 & 15) * 4), r23 = *reinterpret_cast<const double2 *>(part + (a0 >> 4) * 64 + (a0 & 15) * 4 + 2);
+        y0 = so[a0] + ((r01.x + r01.y) + (r23.x + r23.y));
+    }
+    if (a1 < N) {
+        const double2 r01 = *reinterpret_cast<const double2 *>(part + (a1 >> 4) * 64 + (a1 & 15) * 4), r23 = *reinterpret_cast<const double2 *>(part + (a1 >> 4) * 64 + (a1 & 15) * 4 + 2);
+        y1 = so[a1] + ((r01.x + r01.y) + (r23.x + r23.y));
+    }
+    if (sop) {
+        if (a0 < N) sop[ri_perm(a0)] = y0;
+        if (a1 < N) sop[ri_perm(a1)] = y1;
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
@@ -136,9 +152,9 @@ __device__ __forceinline__ void ri_inverse_pixel(const int64_t m, const double *
                                                  const double *__restrict__ rowsum_base, const double *__restrict__ lam_in, double *__restrict__ kp) {
     constexpr int N = 16 * NT, NTILE = (NT * (NT + 1)) / 2;
     __shared__ int s_rs[N];                                             // block * 256 + local pixel of ring neighbour a, -1: none
-    __shared__ __attribute__((aligned(16))) double s_vec[6][N];         // g0, g0 permuted, u0, u0 permuted, a product, the product permuted
+    __shared__ __attribute__((aligned(16))) double s_vec[5][N];         // g0, g0 permuted, u0, u0 permuted, a product
     __shared__ __attribute__((aligned(16))) double s_blk[16 * RS_DS];
-    __shared__ __attribute__((aligned(16))) double s_red[64];
+    __shared__ __attribute__((aligned(16))) double s_part[NT * 64];
     const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
     const int p = g.p, mi = (int)m;
     const int rbm = mi % g.nr + g.roff, cbm = mi / g.nr + g.coff;
@@ -213,11 +229,13 @@ __device__ __forceinline__ void ri_inverse_pixel(const int64_t m, const double *
         reinterpret_cast<double2 *>(kq)[(t * 2 + 1) * 64 + lane] = make_double2(T[t][2], T[t][3]);
     }
     // ---- k_g = K g0, k_u = K u0 ----
-    ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[4], s_vec[5], s_blk, s_red, c, rq);
-    for (int a = lane; a < N; a += 64) kq[NTILE * 256 + a] = s_vec[4][a];
-    __syncthreads();
-    ri_matvec<NT>(T, s_vec[2], s_vec[3], s_vec[4], s_vec[5], s_blk, s_red, c, rq);
-    for (int a = lane; a < N; a += 64) kq[NTILE * 256 + N + a] = s_vec[4][a];
+    double y0, y1;
+    ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[4], nullptr, s_part, c, rq, y0, y1);
+    if (lane < N) kq[NTILE * 256 + lane] = y0;
+    if (lane + 64 < N) kq[NTILE * 256 + lane + 64] = y1;
+    ri_matvec<NT>(T, s_vec[2], s_vec[3], s_vec[4], nullptr, s_part, c, rq, y0, y1);
+    if (lane < N) kq[NTILE * 256 + N + lane] = y0;
+    if (lane + 64 < N) kq[NTILE * 256 + N + lane + 64] = y1;
     if (lane == 0) { kq[NTILE * 256 + 2 * N] = lam0; kq[NTILE * 256 + 2 * N + 1] = tr; }
 }
 template <int NT>
@@ -283,6 +301,7 @@ k_ring_apply(InvArgs ia, PackArgs pa, BgGeom g, const int *__restrict__ dr, cons
     float (*s_ev)[RSP_CAP] = reinterpret_cast<float (*)[RSP_CAP]>(s_e0 + (N + 1) + RSP_CAP * (N + 1));
     unsigned *s_mask = reinterpret_cast<unsigned *>(s_e0 + (N + 1) + 2 * RSP_CAP * (N + 1));
     double *s_blk = reinterpret_cast<double *>(s_x), *s_red = s_blk + 16 * RS_DS, *s_H = s_red + 128;
+    static_assert(16 * RS_DS + 128 >= NT * 64, "ri_matvec's partial sums take s_blk and s_red");
     double (*s_vec)[N] = reinterpret_cast<double (*)[N]>(s_H + 256);    // [0] v, [1] v permuted, [2] t, [3] t permuted
     const int64_t m = pix ? pix[blockIdx.x] : (int)blockIdx.x;
     if (active && !active[m]) return;
@@ -582,8 +601,8 @@ k_ring_apply(InvArgs ia, PackArgs pa, BgGeom g, const int *__restrict__ dr, cons
     double b0, b1;
     minus_V((h0 ? s_gu[1][a0] : 0.0) - w0 * (h0 ? s_gu[0][a0] : 0.0), (h1 ? s_gu[1][a1] : 0.0) - w0 * (h1 ? s_gu[0][a1] : 0.0), b0, b1);
     put_v(b0, b1);
-    ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], s_vec[3], s_blk, s_red, c, rq);
-    double xa = h0 ? s_vec[2][a0] : 0.0, xb = h1 ? s_vec[2][a1] : 0.0;
+    double xa, xb;
+    ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], nullptr, s_blk, c, rq, xa, xb);
     if (h0) s_gu[1][a0] = xa;                                           // x0 (the slot of g, dead behind the right-hand side)
     if (h1) s_gu[1][a1] = xb;
     int terms = 0;
@@ -597,8 +616,7 @@ k_ring_apply(InvArgs ia, PackArgs pa, BgGeom g, const int *__restrict__ dr, cons
             __syncthreads();
             minus_V(h0 ? s_gu[0][a0] : 0.0, h1 ? s_gu[0][a1] : 0.0, b0, b1);
             put_v(b0, b1);
-            ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], s_vec[3], s_blk, s_red, c, rq);
-            cu0 = h0 ? s_vec[2][a0] : 0.0; cu1 = h1 ? s_vec[2][a1] : 0.0;
+            ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], nullptr, s_blk, c, rq, cu0, cu1);
         }
         double rprev = 1.0;
         fail_ = true;
@@ -606,7 +624,8 @@ k_ring_apply(InvArgs ia, PackArgs pa, BgGeom g, const int *__restrict__ dr, cons
         for (int it = 0; it < ia.maxit; ++it) {
             __syncthreads();
             put_v(xa, xb);
-            ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], s_vec[3], s_blk, s_red, c, rq);         // t = K x
+            double t0_, t1_;
+            ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], s_vec[3], s_blk, c, rq, t0_, t1_);             // t = K x (wanted in the permuted order: s_vec[3])
             double sp_ = 0.0;                                                                              // s = V' t
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
@@ -633,8 +652,8 @@ k_ring_apply(InvArgs ia, PackArgs pa, BgGeom g, const int *__restrict__ dr, cons
             __syncthreads();
             minus_V(xa, xb, b0, b1);                                                                       // x - V capinv V' K x
             put_v(b0, b1);
-            ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], s_vec[3], s_blk, s_red, c, rq);         // C x
-            const double cv0 = h0 ? s_vec[2][a0] : 0.0, cv1 = h1 ? s_vec[2][a1] : 0.0;
+            double cv0, cv1;
+            ri_matvec<NT>(T, s_vec[0], s_vec[1], s_vec[2], nullptr, s_blk, c, rq, cv0, cv1);              // C x
             double w0p = 0.0;
             if (border) w0p = -ri_wave_sum(fma(h0 ? s_gu[0][a0] : 0.0, cv0, (h1 ? s_gu[0][a1] : 0.0) * cv1)) / (tau - uCu);
             const double n0 = (h0 ? s_gu[1][a0] : 0.0) - delta * (cv0 - w0p * cu0), n1 = (h1 ? s_gu[1][a1] : 0.0) - delta * (cv1 - w0p * cu1);

@@ -196,6 +196,13 @@ k_ring_solve6(const double *__restrict__ sys, PackArgs pa, BgGeom g, const int *
     };
     if (mask) stage(0);
     if (mask) stage(RSP_CH);
+#ifdef RSP_DEBUG
+    if (probe & 4096) {                                     // (diagnostic: the staged U~ summed over the neurons, per ring pixel)
+        __syncthreads();
+        for (int a = lane; a < p; a += 64) { double v = 0.0; for (int i = 0; i < nst; ++i) v += s_u[i][a]; W[(int64_t)a * g.d + m] = (float)v; }
+        return;
+    }
+#endif
     // ---- the system: 2 NTILE coalesced 16-byte loads, all in flight at once ----
     double4_t T[NTILE];
 #pragma unroll
