@@ -82,6 +82,13 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
         }
         cmask = __ballot(cand);
     }
+    // ---- the system: 2 NTILE coalesced 16-byte loads, all in flight at once -- issued FIRST: the set-up below (lists, geometry, the windows' samples) runs under their latency ----
+    double4_t T[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        const double2 v0 = reinterpret_cast<const double2 *>(sp)[(t * 2) * 64 + lane], v1 = reinterpret_cast<const double2 *>(sp)[(t * 2 + 1) * 64 + lane];
+        T[t] = (double4_t){v0.x, v0.y, v1.x, v1.y};
+    }
     // ---- geometry ----
 #pragma unroll 1
     for (int a = lane; a <= N; a += 64) {
@@ -165,13 +172,6 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
             W[(int64_t)a * g.d + m] = v;
         }
         return;
-    }
-    // ---- the system: 2 NTILE coalesced 16-byte loads, all in flight at once ----
-    double4_t T[NTILE];
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-        const double2 v0 = reinterpret_cast<const double2 *>(sp)[(t * 2) * 64 + lane], v1 = reinterpret_cast<const double2 *>(sp)[(t * 2 + 1) * 64 + lane];
-        T[t] = (double4_t){v0.x, v0.y, v1.x, v1.y};
     }
     if (nst) apply(T);
     while (cmask) {                                         // more than RSP_NS candidates around one pixel: further rounds under the live tiles (rare)

@@ -524,9 +524,10 @@ int vproj_temporal(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr,
             const int total = (int)L.blall.size();
             const int nsg = (int)std::max<int64_t>(1, std::min<int64_t>((T16 + 7) / 8, (VP_WG_TARGET + total - 1) / std::max(1, total)));
             const size_t shmem = (size_t)(t + 1) * 1024 * sizeof(uint4);
-#define VP_GO8(NT_) LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_i8<NT_>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->digp.as<uint4>(), T16, ctx->vp[11].as<int>() + off, \
+#define VP_GO8(NT_, V0_) LAUNCH(ctx, "temporal_proj_B", (k_vp_proj_i8<NT_, V0_>), dim3((unsigned)(nb_ * nsg)), dim3(256), shmem, P->digp.as<uint4>(), T16, ctx->vp[11].as<int>() + off, \
                            ctx->vp[5].as<int>(), ctx->vp[4].as<int>(), dBd.as<uint4>(), dBs.as<double>(), nsg, dPart.as<double>(), ldp)
-            if (t == 0) VP_GO8(1); else if (t == 1) VP_GO8(2); else if (t == 2) VP_GO8(3); else VP_GO8(4);
+            if (ctx->opt("proj_i8_planes", 3) >= 4) { if (t == 0) VP_GO8(1, 0); else if (t == 1) VP_GO8(2, 0); else if (t == 2) VP_GO8(3, 0); else VP_GO8(4, 0); }
+            else { if (t == 0) VP_GO8(1, 1); else if (t == 1) VP_GO8(2, 1); else if (t == 2) VP_GO8(3, 1); else VP_GO8(4, 1); }
 #undef VP_GO8
             off += nb_;
         }

@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(256) k_vp_bdig(const double *__restrict__ Bt, 
 // The projection.  Workgroup = (block, frame segment), 4 waves; a wave takes 16-frame groups.  Per group: 16 fragment loads of the video (4 pixel groups x 4 planes), the
 // panel's fragments from LDS (one ds_read_b128 each), 52 MFMAs per slot group into 5 class accumulators, and the D tile (row = list slot (lane >> 4) * 4 + r, column =
 // frame lane & 15) scaled into the partial rows part[(l0 + slot) * ldp + 16 fg + f] (a wave instruction writes 16 consecutive frames of four slots)
-template <int NT>
+// V0 = 1 (round 6, option proj_i8_planes = 3, the default): the video's lowest digit plane is neither loaded nor multiplied -- 24-bit samples (the rounding of a
+// pixel's centred trace to 2^-23 of its largest value, the precision its fp32 samples have around a mean of that size anyway), 3/4 of the bytes, 11 of the 13 MFMAs.
+// The regression's window projection (win_proj_i8.hpp) keeps all four planes: its sums go through systems of condition 1e5.
+template <int NT, int V0>
 __global__ void __launch_bounds__(256) k_vp_proj_i8(const uint4 *__restrict__ digp, int64_t T16, const int *__restrict__ blk_list, const int *__restrict__ lst_ptr,
                                                     const int *__restrict__ g16, const uint4 *__restrict__ bdig, const double *__restrict__ bscale, int nseg,
                                                     double *__restrict__ part, int64_t ldp) {
@@ -116,14 +119,14 @@ __global__ void __launch_bounds__(256) k_vp_proj_i8(const uint4 *__restrict__ di
         for (int r = 0; r < 4; ++r) ts[b][r] = bscale[((int64_t)g16[blk] + b) * 16 + kq * 4 + r];
     const int64_t gseg = (T16 + nseg - 1) / nseg, fg0 = seg * gseg, fg1 = fg0 + gseg < T16 ? fg0 + gseg : T16;
     const uint4 *vb = digp + ((int64_t)blk * T16 * 16) * 64 + lane;
-    auto load = [&](int64_t fg, int4v_t (&x)[4][4]) {
+    auto load = [&](int64_t fg, int4v_t (&x)[4][4 - V0]) {
         const uint4 *p = vb + (fg < fg1 ? fg : fg1 - 1) * 16 * 64;  // (the group behind the segment re-reads its last one: no branch, never used)
 #pragma unroll
         for (int pg = 0; pg < 4; ++pg)
 #pragma unroll
-            for (int pl = 0; pl < 4; ++pl) { const uint4 u = ld_stream(p + (pg * 4 + pl) * 64); x[pg][pl] = (int4v_t){(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+            for (int pl = V0; pl < 4; ++pl) { const uint4 u = ld_stream(p + (pg * 4 + pl) * 64); x[pg][pl - V0] = (int4v_t){(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
     };
-    auto compute = [&](int64_t fg, const int4v_t (&x)[4][4]) {
+    auto compute = [&](int64_t fg, const int4v_t (&x)[4][4 - V0]) {
         const int64_t t = fg * 16 + f;
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
@@ -138,20 +141,20 @@ __global__ void __launch_bounds__(256) k_vp_proj_i8(const uint4 *__restrict__ di
                 int4v_t y[4];                                       // the panel's four planes of this pixel group (A operand: rows = slots)
 #pragma unroll
                 for (int pl = 0; pl < 4; ++pl) { const uint4 u = pan[((b * 4 + pg) * 4 + pl) * 64 + lane]; y[pl] = (int4v_t){(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
-                const int4v_t *v = x[pg];                           // class = (plane of B') + (plane of the video) - 2; consecutive MFMAs on different accumulators
-                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], v[0], c[1], 0, 0, 0);
-                c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], v[1], c[2], 0, 0, 0);
-                c[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], v[2], c[3], 0, 0, 0);
-                c[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], v[3], c[4], 0, 0, 0);
-                c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], v[0], c[0], 0, 0, 0);
-                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], v[1], c[1], 0, 0, 0);
-                c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], v[2], c[2], 0, 0, 0);
-                c[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], v[3], c[3], 0, 0, 0);
-                c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[1], v[1], c[0], 0, 0, 0);
-                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[1], v[2], c[1], 0, 0, 0);
-                c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[1], v[3], c[2], 0, 0, 0);
-                c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[0], v[2], c[0], 0, 0, 0);
-                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[0], v[3], c[1], 0, 0, 0);
+                // class = (plane of B') + (plane of the video) - 2; consecutive MFMAs on different accumulators
+                if constexpr (V0 == 0) c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], x[pg][0], c[1], 0, 0, 0);
+                c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], x[pg][1 - V0], c[2], 0, 0, 0);
+                c[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], x[pg][2 - V0], c[3], 0, 0, 0);
+                c[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[3], x[pg][3 - V0], c[4], 0, 0, 0);
+                if constexpr (V0 == 0) c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], x[pg][0], c[0], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], x[pg][1 - V0], c[1], 0, 0, 0);
+                c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], x[pg][2 - V0], c[2], 0, 0, 0);
+                c[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[2], x[pg][3 - V0], c[3], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[1], x[pg][1 - V0], c[0], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[1], x[pg][2 - V0], c[1], 0, 0, 0);
+                c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[1], x[pg][3 - V0], c[2], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[0], x[pg][2 - V0], c[0], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(y[0], x[pg][3 - V0], c[1], 0, 0, 0);
             }
             if (t < ldp) {
 #pragma unroll
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(256) k_vp_proj_i8(const uint4 *__restrict__ di
             }
         }
     };
-    int4v_t x0[4][4], x1[4][4];                                     // two named fragment sets: the next group's 16 loads go out before this group's MFMAs
+    int4v_t x0[4][4 - V0], x1[4][4 - V0];                           // two named fragment sets: the next group's 16 loads go out before this group's MFMAs
     if (fg0 + wave >= fg1) return;
     load(fg0 + wave, x0);
     for (int64_t fg = fg0 + wave; fg < fg1; fg += 8) {

@@ -411,7 +411,11 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  *   ssub_virtual      the same for cnmfe_residual_ssub (through the resampling maps): 2 always, 1 (default) on patches of at least 5e8 samples -- below that the
  *                     low-resolution sweep is the faster form, profiles/r05/ssub_virtual_check.txt --, 0: the low-resolution sweep + upsample
  *   gram_incremental  default 1: the covariance table of the VIDEO is kept and corrected per fit (see cnmfe_fit_ring_model); 0: the direct Gram of Bf every fit
- *   solve_inv         default 1: fits of a patch from its second one with footprints on solve their pixels out of explicit inverses of the VIDEO's normal equations
+ *   proj_i8_planes    default 3: the temporal projection on the int8 pipe reads the upper three of the video's four digit planes (24-bit samples: 3/4 of the bytes;
+ *                     A, C move by < 1e-7); 4: all of them
+ *   solve_staged      default 1: the ring solve samples the footprints' U~ and A out of per-neuron windows (ring_solve_staged.hpp; bit-identical weights); 0: it walks
+ *                     the CSR rows and slot tables
+ *   solve_inv         default 0; 1: fits of a patch from its second one with footprints on solve their pixels out of explicit inverses of the VIDEO's normal equations
  *                     (built once in front of that fit, the bytes of solve_packed's systems once more; the footprints enter by the Woodbury identity, the ridge's
  *                     drift by a short series: ring_solve_inv.hpp); 2: built in front of the first such fit; 0: every fit factors every pixel's system
  *   solve_inv_terms   default 5: terms of the ridge series before a pixel is left to the factorising kernel and its inverse rebuilt
