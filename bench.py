@@ -480,10 +480,15 @@ def main():
         # its fp64 partial sums per (16x16 block, neuron) are traffic, not algorithmic bytes) and the fit's window projection P = Yc Cc' (one read + the traces)
         for name in ("temporal_proj_B", "bg_win_proj"):
             if name in kern:
-                by = 4.0 * d_b * T + 4.0 * K * T
+                # bytes per sample the kernel is built to read: 4 (fp32, or four digit planes) -- the temporal projection on the int8 pipe reads three of the four
+                # planes since round 6 (option proj_i8_planes, default 3): its fraction is quoted for the 3 bytes it needs, not for the 4 of the fp32 video
+                planes = 4
+                if name == "temporal_proj_B" and eng.get_option("proj_i8", 1) and eng.get_option("proj_i8_planes", 3) < 4:
+                    planes = 3
+                by = float(planes) * d_b * T + 4.0 * K * T
                 ms = kern[name]["ms_per_step"]                  # (one projection per iteration, possibly split into launches by list length)
                 out[name] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": name, "ms_per_update": ms, "algorithmic_bytes_per_update": by}
+                             "kernel": name, "ms_per_update": ms, "algorithmic_bytes_per_update": by, "bytes_per_video_sample": planes}
         for name in ("spatial_proj_U", "temporal_proj_U"):
             if name not in kern:
                 continue

@@ -20,6 +20,11 @@ python bench.py $X --config c5shard --steps 5 --deconv > $o/bench_c5shard_deconv
 python bench.py $X --warmup 0 --steps 5 > $o/bench_c3_warmup0_$ver.json 2>/dev/null
 python bench.py $X --demo-sequence > $o/bench_c3_demo_sequence_$ver.json 2>/dev/null
 CNMFE_OPTS=r1_virtual=0 python bench.py $X > $o/bench_c3_swept_$ver.json 2>/dev/null
+# round 6's switches, one at a time against the default line: the staged ring solve, the temporal projection's digit planes, the ring solve out of cached inverses
+CNMFE_OPTS=solve_staged=0 python bench.py $X > $o/bench_c3_ab_solve_staged_off_$ver.json 2>/dev/null
+CNMFE_OPTS=proj_i8_planes=4 python bench.py $X > $o/bench_c3_ab_proj_planes4_$ver.json 2>/dev/null
+CNMFE_OPTS=solve_inv=1 python bench.py $X > $o/bench_c3_ab_solve_inv_on_$ver.json 2>/dev/null
+python scripts/probes/solve_inv/bench_loop.py --cfg c3 --steps 12 --mode 1 2>&1 | grep -v amdgpu.ids > $o/solve_inv_bench_loop_$ver.txt
 python scripts/rank_load.py > $o/rank_load_$ver.txt 2>&1
 CNMFE_BENCH_FORCE_COLLECTIVES=1 python bench.py $X --config c4 --steps 10 --warmup 4 > $o/bench_c4_forced_collectives_$ver.json 2>/dev/null
 unset CNMFE_BENCH_R1
