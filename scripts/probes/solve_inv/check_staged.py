@@ -24,7 +24,7 @@ A0, A1 = f.A_init.astype(np.float32), f.A_true.astype(np.float32)
 seq = [(A0, f.C_init), ((0.7 * A0 + 0.3 * A1).tocsc().astype(np.float32), (0.7 * f.C_init + 0.3 * f.C_true).astype(np.float32)), (A1, f.C_true)]
 Ws = {}
 eng.set_option("solve_inv", 0); eng.set_option("solve_probe", a.probe)
-for mode in (0, 1):
+for mode in [int(x) for x in os.environ.get("STAGED_MODES", "0,1").split(",")]:
     eng.set_option("solve_staged", mode)
     eng.ring_init(0, r)
     Ws[mode] = []
@@ -36,10 +36,11 @@ for mode in (0, 1):
         ts = {k: round(v["total_ms"] / v["calls"], 3) for k, v in tab.items() if (k.startswith("bg_ring") or k.startswith("bg_neuron")) and v["calls"]}
         Wc = eng.ring_csr(0); Ws[mode].append(Wc.data.copy())
         print("solve_staged %d fit %d: %s  active %d" % (mode, i, ts, info["n_active"]), flush=True)
+MA = max(Ws)
 for i in range(len(seq)):
-    d = Ws[1][i].view(np.uint32) != Ws[0][i].view(np.uint32)
-    print("fit %d: weights that differ in any bit: %d of %d;  max |dW| / max |W| = %.2e" % (i, int(d.sum()), d.size, np.abs(Ws[1][i] - Ws[0][i]).max() / np.abs(Ws[0][i]).max()), flush=True)
-    nan = np.isnan(Ws[1][i]); dd = np.abs(Ws[1][i] - Ws[0][i]); dd[nan] = 0
+    d = Ws[MA][i].view(np.uint32) != Ws[0][i].view(np.uint32)
+    print("fit %d: weights that differ in any bit: %d of %d;  max |dW| / max |W| = %.2e" % (i, int(d.sum()), d.size, np.abs(Ws[MA][i] - Ws[0][i]).max() / np.abs(Ws[0][i]).max()), flush=True)
+    nan = np.isnan(Ws[MA][i]); dd = np.abs(Ws[MA][i] - Ws[0][i]); dd[nan] = 0
     rows = np.repeat(np.arange(Wc.shape[0]), np.diff(Wc.indptr))
     print("   NaN weights %d in %d pixels; without them max |dW| / max |W| = %.2e; pixels with a difference > 1e-6: %d; first NaN pixels %s" % (
         int(nan.sum()), np.unique(rows[nan]).size, dd.max() / np.abs(Ws[0][i]).max(), np.unique(rows[dd > 1e-6 * np.abs(Ws[0][i]).max()]).size, np.unique(rows[nan])[:8].tolist()), flush=True)
