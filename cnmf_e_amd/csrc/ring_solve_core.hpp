@@ -43,6 +43,34 @@ __device__ __forceinline__ double rs_wave_sum(double v) {
     return v;
 }
 
+// a wave-uniform double into scalar registers (values loaded through the vector memory path stay in VGPRs otherwise -- and this kernel has none to spare)
+__device__ __forceinline__ double ri_uni(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int SRC> __device__ __forceinline__ double ri_readlane(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+// reductions without the LDS crossbar (a __shfl_xor is a ds_bpermute: six dependent ~100-clock steps per wave sum, and this kernel takes a dozen of them):
+// a butterfly inside each 16-lane DPP row -- quad_perm [1 0 3 2], [2 3 0 1], row_half_mirror, row_mirror on the two halves of the double -- leaves the row's
+// total in all its lanes; the four row totals meet through readlanes
+template <int CTRL> __device__ __forceinline__ double ri_dpp(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ri_row_sum(double v) {                // over the 16 lanes of a DPP row, in all of them
+    v += ri_dpp<0xB1>(v); v += ri_dpp<0x4E>(v); v += ri_dpp<0x141>(v); v += ri_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double ri_wave_sum(double v) {               // over the wave, uniform
+    v = ri_row_sum(v);
+    return (ri_readlane<0>(v) + ri_readlane<16>(v)) + (ri_readlane<32>(v) + ri_readlane<48>(v));
+}
+__device__ __forceinline__ double ri_wave_max(double v) {
+    v = fmax(v, ri_dpp<0xB1>(v)); v = fmax(v, ri_dpp<0x4E>(v)); v = fmax(v, ri_dpp<0x141>(v)); v = fmax(v, ri_dpp<0x140>(v));
+    return fmax(fmax(ri_readlane<0>(v), ri_readlane<16>(v)), fmax(ri_readlane<32>(v), ri_readlane<48>(v)));
+}
 // fp64 row broadcast inside each 16-lane DPP row: lane N of the row -> all 16 lanes (the only DPP control 64-bit operands take)
 // (inline asm like the FMAs below, with its own wait states: the source may have been written by one of THEIR asm statements one or two
 // instructions earlier, which the compiler's DPP hazard check does not see)
@@ -270,5 +298,6 @@ __device__ __forceinline__ void rs_solve_core(double4_t (&T)[(NT * (NT + 1)) / 2
         __syncthreads();
     }
 }
+
 
 }  // namespace cnmfe

@@ -68,6 +68,14 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
     const int rbm = mi % g.nr + g.roff, cbm = mi / g.nr + g.coff;
     const int blkm = (cbm >> 4) * g.nbr + (rbm >> 4);
     const bool corr = sa_.lmeta != nullptr && !(probe & 8);
+    // (in-kernel laps of one wave, scripts/probes/solve_r6/laps.py: a build with -DRSP_DEBUG and solve_probe = 16384)
+#ifdef RSP_DEBUG
+    long long lap[8]; int nlap = 0;
+#define RSP_LAP() do { lap[nlap++] = wall_clock64(); } while (0)
+    RSP_LAP();
+#else
+#define RSP_LAP() do {} while (0)
+#endif
     // ---- the centre block's list: one position per lane; the candidates are the neurons whose window holds the centre ----
     unsigned long long cmask = 0;
     int mr0 = 0, mc0 = 0, mh = 0, mw = 0, moff = 0;
@@ -108,6 +116,7 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
         s_vec[1][a] = q >= 0 ? sp[NTILE * 256 + a] : 0.0;
     }
     const double sc = rowsum[blkm * 256 + lp_of(rbm & 15, cbm & 15)];
+    RSP_LAP();                                              // 1: list, geometry, border vectors issued
     // ---- staging: up to RSP_NS candidates per round, every sample of the round in flight at once; `live`: the slots with a non-zero A on ring or centre ----
     unsigned live = 0;
     int nst = 0;
@@ -156,6 +165,7 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
         __syncthreads();
     };
     if (cmask) stage();
+    RSP_LAP();                                              // 2: staged
 #ifdef RSP_DEBUG
     if (probe & 4096) {
         __syncthreads();
@@ -174,6 +184,7 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
         return;
     }
     if (nst) apply(T);
+    RSP_LAP();                                              // 3: the system has arrived, corrections applied
     while (cmask) {                                         // more than RSP_NS candidates around one pixel: further rounds under the live tiles (rare)
         stage();
         apply(T);
@@ -196,7 +207,18 @@ k_ring_solve8(const double *__restrict__ sys, StageArgs sa_, BgGeom g, const int
     if (lam_out && lane == 0) lam_out[m] = lam;
     __syncthreads();
     double wc[NT];
-    rs_solve_core<NT>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe, wc);
+    RSP_LAP();                                              // 4: trace, ridge
+    if (!(probe & 2)) rs_factor<NT>(T, s_blk, lane, c, rq);
+    __syncthreads();
+    RSP_LAP();                                              // 5: factorisation
+    rs_solve_core<NT>(T, s_vec, s_blk, s_part, sc, lam, (double)g.Tp, lane, probe | 2, wc);
+    RSP_LAP();                                              // 6: substitutions
+#ifdef RSP_DEBUG
+    if ((probe & 16384) && (m % 509) == 7) {
+        if (lane == 0) for (int i = 1; i < nlap; ++i) W[(int64_t)(i - 1) * g.d + m] = (float)(lap[i] - lap[i - 1]);
+        return;
+    }
+#endif
     if (rq == 0) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
