@@ -248,6 +248,19 @@ def rows_of(A, lut, nloc, cols=None, span=None, cand=None):
     return _select_rows_numpy(A, lut, nloc, cand, cols is not None)
 
 
+def _csc_fast(data, indices, indptr, shape):
+    """a scipy CSC matrix around arrays that ARE a valid CSC structure with ascending row indices inside every column (what the library's host helpers return):
+    the constructor's format checks and the later has_sorted_indices scans cost 50-100 us per matrix, and a rank of a sharded run builds ~10 small ones per patch
+    and iteration (scripts/host_python_profile.py: 3.1 ms of Python per iteration for two 128 x 128 patches, a third of it here)"""
+    M = sp.csc_matrix.__new__(sp.csc_matrix)
+    M._shape = (int(shape[0]), int(shape[1])); M.maxprint = 50
+    if indptr.dtype != indices.dtype:                          # (scipy's kernels want one index type: the column pointers follow the row indices, as its constructor does)
+        indptr = indptr.astype(indices.dtype)
+    M.data, M.indices, M.indptr = data, indices, indptr
+    M.has_sorted_indices = True
+    return M
+
+
 def _csc_from_triplets(r, c, v, shape):
     """the CSC matrix of DISJOINT (row, column, value) triplets (ValueError on a pair given twice): one counting pass in the library's host helper
     (cnmfe_csc_from_triplets) -- scipy's COO -> CSC conversion sorts the whole list, and every rank of a sharded run assembles the WHOLE gathered A; falls back
@@ -264,9 +277,7 @@ def _csc_from_triplets(r, c, v, shape):
         # PRECONDITION: disjoint triplets (the patches' rows are, update_spatial_parallel.m:324-334).  A pair given twice -- which scipy's conversion would sum
         # silently -- or an index out of range is an error of the caller, reported as such
         raise ValueError(L.lib.cnmfe_last_error().decode())
-    M = sp.csc_matrix((oval[:n], orow[:n], optr), shape=shape)
-    M.has_sorted_indices = True
-    return M
+    return _csc_fast(oval[:n], orow[:n], optr, shape)
 
 
 def _select_rows_native(A, lut, nloc, cand, keep_all):
@@ -292,7 +303,7 @@ def _select_rows_native(A, lut, nloc, cand, keep_all):
         raise ValueError(L.lib.cnmfe_last_error().decode())
     nk = nk.value
     n = int(optr[nk])
-    return ind[:nk], sp.csc_matrix((oval[:n], orow[:n], optr[:nk + 1]), shape=(nloc, nk))
+    return ind[:nk], _csc_fast(oval[:n], orow[:n], optr[:nk + 1], (nloc, nk))
 
 
 def _select_rows_numpy(A, lut, nloc, cand, keep_all):
