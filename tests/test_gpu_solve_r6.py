@@ -129,3 +129,19 @@ def test_cached_inverses_with_footprints_that_meet_the_ring_in_one_pixel(eng):
     for wa, wb in zip(a, b):
         assert np.all(np.isfinite(wb))
         assert np.abs(wb - wa).max() <= 5e-7 * np.abs(wa).max()
+
+
+def test_staged_solve_falls_back_for_a_footprint_larger_than_a_window(eng):
+    """a footprint whose bounding box, dilated by two ring radii, has more entries than a neuron's window holds (two pixels in opposite corners of a 200 x 180
+    field of view): the fit must take k_ring_solve6 for this call -- and give the same weights"""
+    d1, d2, T, r = 200, 180, 120, 15
+    f, Y, video = _video(eng, d1, d2, T, 6, r, 9)
+    A = f.A_init.tocsc().astype(np.float32).tolil()
+    A[3 * d1 + 4, 0] = 0.5; A[(d2 - 5) * d1 + (d1 - 6), 0] = 0.4
+    A = A.tocsc().astype(np.float32)
+    C = np.ascontiguousarray(f.C_init, dtype=np.float32)
+    seq = [(A, C), ((A * 0.9).tocsc().astype(np.float32), C)]
+    a = _fits(eng, 0, r, seq, solve_staged=0, solve_inv=0)
+    b = _fits(eng, 0, r, seq, solve_staged=1, solve_inv=0)
+    for wa, wb in zip(a, b):
+        assert np.all(np.isfinite(wb)) and np.array_equal(wa.view(np.uint32), wb.view(np.uint32))
