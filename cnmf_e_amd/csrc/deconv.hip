@@ -14,8 +14,11 @@
 
 namespace cnmfe {
 
+// the longest trace the Welch estimator takes: pwelch's segment length floor(T / 4.5) <= 32768 = the largest transform built (two 16384-point halves in LDS)
+constexpr int WELCH_TMAX = 147456;
 struct DeconvCfg {
     int T, P2, nfft, L, nov, nseg;     // trace length, pow2 >= T, Welch geometry
+    int split;                         // round 6: nfft = 32768 (73728 < T <= 147456) as two 16384-point transforms (even / odd samples) + one butterfly, LDS = re | im of one of them
     int ylong;                         // 1: the trace lives in global memory (k_deconv<true>); 2: and so do the Welch tables (T > 36868: nfft = 16384)
     int maxIter;                       // foopsi iterations (20 inside HALS_temporal, 10 in deconvTemporal)
     int optimize_b, optimize_g;
@@ -38,7 +41,7 @@ struct DeconvIO {
     double *tk_val;
     double *pnum;                      // per-pool numerators, T per trace slot
     float *ybuf, *obuf;                // long traces only: the raw trace and the output staging, Tal floats per trace slot each
-    float *tbuf = nullptr;             // ylong == 2 (nfft = 16384): the Welch twiddle / window tables, 2 nfft floats per trace slot
+    float *tbuf = nullptr;             // ylong == 2 (nfft >= 16384): the Welch twiddle / window tables (+ the even samples' transform when the transform is split), 3 nfft floats per trace slot
 };
 
 // (red: one double per wave of the workgroup -- 4 for the 256-thread kernels, 8 for k_deconv's 512)
@@ -155,21 +158,60 @@ template <class YT>
 __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *red, bool wintab, float *tabs = nullptr) {
     const int tid = threadIdx.x, NTH = (int)blockDim.x;
     const int nfft = c.nfft, L = c.L, step = c.L - c.nov;
+    const int nh = c.split ? nfft / 2 : nfft;                  // the transform that runs in LDS
     float *tb = tabs ? tabs : scr + 2 * nfft;
-    float *re = scr, *im = scr + nfft, *win = tb + nfft / 2;
+    float *re = scr, *im = scr + nh, *win = tb + nfft / 2;
+    float *ebuf = tb + nfft / 2 + nfft;                        // (split: the even samples' transform, 2 nh floats, in the tables' global slot)
     float2 *tw = reinterpret_cast<float2 *>(tb);
-    int logn = 0; while ((1 << logn) < nfft) ++logn;
+    int logn = 0; while ((1 << logn) < nh) ++logn;
     const int k0 = (nfft + 3) / 4, k1 = nfft / 2;              // bins with 0.25 <= k/nfft <= 0.5
     const int nb = k1 - k0 + 1;
-    constexpr int MAXB = 17;                                   // bins per thread: nfft / 4 + 1 bins over 256 threads (nfft <= 16384: 4097 bins)
+    constexpr int MAXB = 33;                                   // bins per thread: nfft / 4 + 1 bins over 256 threads (nfft <= 32768: 8193 bins)
     float acc[MAXB];
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) acc[i] = 0.f;
     double w2 = 0;
     for (int i = tid; i < L; i += NTH) { const double w = 0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1)); w2 += w * w; if (wintab) win[i] = (float)w; }
-    for (int k = tid; k < nfft / 4; k += NTH) { float sn_, cs_; sincospif(-(float)k / (float)(nfft / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
+    for (int k = tid; k < nh / 4; k += NTH) { float sn_, cs_; sincospif(-(float)k / (float)(nh / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
     if (tabs) __threadfence_block();                 // (tables in global memory: written and read by this workgroup alone; block_sum's barriers order them)
     w2 = block_sum(w2, red);
+    if (c.split) {
+        // X_k = E_k + w^k O_k (w = exp(-2 pi i / nfft)) with E, O the nh-point transforms of the even / odd samples of the windowed, zero-padded pair of segments:
+        // E goes to the global slot, O stays in LDS, and the band's bins k, nfft - k (k = nfft/4 .. nfft/2: indices k mod nh and nh - k) are combined from there
+        for (int sg = 0; sg < c.nseg; sg += 2) {
+            const bool two = sg + 1 < c.nseg;
+            for (int par = 0; par < 2; ++par) {
+                for (int j = tid; j < nh; j += NTH) {
+                    const int i = 2 * j + par;
+                    float va = 0.f, vb = 0.f;
+                    if (i < L) { const float w = wintab ? win[i] : (float)(0.54 - 0.46 * cospi(2.0 * i / (double)(L - 1))); va = y[sg * step + i] * w; if (two) vb = y[(sg + 1) * step + i] * w; }
+                    const int jr = (int)(__brev((unsigned)j) >> (32 - logn));
+                    re[jr] = va; im[jr] = vb;
+                }
+                __syncthreads();
+                fft_lds(re, im, tw, nh, logn);
+                if (par == 0) {
+                    for (int j = tid; j < nh; j += NTH) { ebuf[j] = re[j]; ebuf[nh + j] = im[j]; }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int k = k0 + tid + i * NTH;
+                if (k <= k1) {
+                    float sn_, cs_;
+                    sincospif(-2.0f * (float)k / (float)nfft, &sn_, &cs_);        // w^k; w^(nfft - k) is its conjugate
+                    const int i1 = k & (nh - 1), j2 = (nfft - k) & (nh - 1);                  // k mod nh, (nfft - k) mod nh
+                    const float o1r = re[i1], o1i = im[i1], o2r = re[j2], o2i = im[j2];
+                    const float z1r = ebuf[i1] + (cs_ * o1r - sn_ * o1i), z1i = ebuf[nh + i1] + (cs_ * o1i + sn_ * o1r);
+                    const float z2r = ebuf[j2] + (cs_ * o2r + sn_ * o2i), z2i = ebuf[nh + j2] + (cs_ * o2i - sn_ * o2r);
+                    acc[i] += 0.5f * ((z1r * z1r + z1i * z1i) + (z2r * z2r + z2i * z2i));
+                }
+            }
+            __syncthreads();
+        }
+    } else
     for (int sg = 0; sg < c.nseg; sg += 2) {
         const bool two = sg + 1 < c.nseg;
         for (int i = tid; i < nfft; i += NTH) {
@@ -596,8 +638,8 @@ __global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) 
     const int Tal = (T + 3) & ~3;
     float *y = LONG ? io.ybuf + (int64_t)blockIdx.x * Tal : sm;          // T raw samples (fp32), persistent
     float *scr = LONG ? sm : sm + Tal;               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
-    const size_t scr_bytes = (size_t)(LONG ? (c.ylong == 2 ? 2 : 4) * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
-    float *tabs = (LONG && c.ylong == 2) ? io.tbuf + (int64_t)blockIdx.x * 2 * c.nfft : nullptr;      // nfft = 16384: the Welch tables do not fit beside re | im
+    const size_t scr_bytes = (size_t)(LONG ? (c.ylong == 2 ? (c.split ? 1 : 2) : 4) * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
+    float *tabs = (LONG && c.ylong == 2) ? io.tbuf + (int64_t)blockIdx.x * 3 * c.nfft : nullptr;      // nfft >= 16384: the Welch tables do not fit beside re | im
     float *ostage = LONG ? io.obuf + (int64_t)blockIdx.x * Tal : scr;   // the solution c(t), before it is written out
     const int nc_pools = (int)(scr_bytes / 24);
     const int64_t base = (int64_t)slot * T, base2 = (int64_t)slot * 2 * T;
@@ -875,26 +917,27 @@ __global__ void __launch_bounds__(256) k_sn_pixels_long(DeconvCfg c, const float
     __shared__ double red[4];
     for (int64_t m = blockIdx.x; m < npix; m += gridDim.x) {
         Ysig4Acc y{v4 + m, npix, add ? add[m] : 0.f};
-        const double v = get_sn(y, c, lds, red, false, tabs ? tabs + (int64_t)blockIdx.x * c.nfft : nullptr);
+        const double v = get_sn(y, c, lds, red, false, tabs ? tabs + (int64_t)blockIdx.x * 3 * c.nfft : nullptr);
         if (threadIdx.x == 0) sn[m] = (float)v;
         __syncthreads();
     }
 }
 // the per-pixel GetSn of a video of `npix` pixels ([T/4][npix] float4), the first T frames: picks the LDS-resident or the long flavour
 static int sn_pixels_launch(cnmfe_ctx *ctx, const char *name, const float4 *v4, int64_t npix, int64_t T, const float *add_mean, float *dSn) {
-    if (T < 64 || T > 73728) return fail(CNMFE_EUNSUPPORTED, "GetSn on the device supports 64 <= T <= 73728 frames (got %lld)", (long long)T);
+    if (T < 64 || T > WELCH_TMAX) return fail(CNMFE_EUNSUPPORTED, "GetSn on the device supports 64 <= T <= %d frames (got %lld)", WELCH_TMAX, (long long)T);
     DeconvCfg c{};
     c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
     c.L = (int)(T / 4.5); c.nov = c.L / 2;                                   // pwelch defaults (MathWorks documentation)
     c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
     c.nseg = (int)((T - c.nov) / (c.L - c.nov));
+    c.split = c.nfft > 16384 ? 1 : 0;                                        // (73728 < T <= 147456: two 16384-point transforms per pair of segments)
     const size_t shmem = ((((size_t)T + 3) & ~size_t(3)) + 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
     if (shmem <= 160 * 1024 - 256) return 1;                                 // the LDS-resident kernels (the caller launches its own: raw video / Ysig differ in the load)
     const bool tab_global = (2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float) > 160 * 1024 - 256;
-    const size_t sh = (tab_global ? 2 * (size_t)c.nfft : 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
+    const size_t sh = (tab_global ? (c.split ? 1 : 2) * (size_t)c.nfft : 2 * (size_t)c.nfft + (size_t)c.nfft / 2) * sizeof(float);
     const unsigned nwg = (unsigned)std::min<int64_t>(npix, 1024);
     float *tabs = nullptr;
-    if (tab_global) { RET(ctx->dscr.tbuf.ensure((size_t)nwg * c.nfft * sizeof(float))); tabs = ctx->dscr.tbuf.as<float>(); }
+    if (tab_global) { RET(ctx->dscr.tbuf.ensure((size_t)nwg * 3 * c.nfft * sizeof(float))); tabs = ctx->dscr.tbuf.as<float>(); }
     if (sh > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels_long, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     LAUNCH(ctx, name, k_sn_pixels_long, dim3(nwg), dim3(256), sh, c, v4, npix, add_mean, tabs, dSn);
     return 0;
@@ -979,11 +1022,12 @@ int sn_video_run(cnmfe_ctx *ctx, Patch *P, int64_t nframes, float *sn_out) {
 int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg &c, size_t &shmem) {
     if (!o) return fail(CNMFE_EINVAL, "null deconvolution options");
     if (o->type != 1 || o->method != 1) return fail(CNMFE_EUNSUPPORTED, "only type 'ar1' / method 'foopsi' is built (demo_large_data_1p.m:38-43)");
-    if (T < 64 || T > 73728) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= 73728 frames (got %lld)", (long long)T);
+    if (T < 64 || T > WELCH_TMAX) return fail(CNMFE_EUNSUPPORTED, "deconvolution supports 64 <= T <= %d frames (got %lld)", WELCH_TMAX, (long long)T);
     c.T = (int)T; c.P2 = 1; while (c.P2 < T) c.P2 <<= 1;
     c.L = (int)(T / 4.5); c.nov = c.L / 2;
     c.nfft = 256; while (c.nfft < c.L) c.nfft <<= 1;
     c.nseg = (int)((T - c.nov) / (c.L - c.nov));
+    c.split = c.nfft > 16384 ? 1 : 0;
     c.maxIter = in_sweep ? 20 : (o->maxIter > 0 ? o->maxIter : 10);          // HALS_temporal.m:92 passes 'maxIter', 20
     c.optimize_b = o->optimize_b; c.optimize_g = o->optimize_pars;
     c.smin_opt = o->smin; c.lam = o->lambda; c.gmax = exp(-1.0 / (o->max_tau > 0 ? o->max_tau : 100.0));
@@ -997,9 +1041,9 @@ int deconv_setup(const cnmfe_deconv_opts *o, int64_t T, int in_sweep, DeconvCfg 
         shmem = 4 * (size_t)c.nfft * sizeof(float);
         if (shmem > 160 * 1024 - 256) {              // nfft = 16384 (36868 < T <= 73728): re | im alone in LDS (128 KB), the twiddle / window tables in global memory
             c.ylong = 2;
-            shmem = 2 * (size_t)c.nfft * sizeof(float);
+            shmem = (c.split ? 1 : 2) * (size_t)c.nfft * sizeof(float);
         }
-        if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames: the Welch transform (nfft = %d) does not fit the deconvolution kernel's LDS (T <= 73728)", (long long)T, c.nfft);
+        if (shmem > 160 * 1024 - 256) return fail(CNMFE_EUNSUPPORTED, "trace of %lld frames: the Welch transform (nfft = %d) does not fit the deconvolution kernel's LDS (T <= %d)", (long long)T, c.nfft, WELCH_TMAX);
     }
     return 0;
 }
@@ -1019,7 +1063,7 @@ int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const
         const size_t Tal = ((size_t)T + 3) & ~size_t(3);
         RET(s.ybuf.ensure((size_t)n * Tal * 4)); RET(s.obuf.ensure((size_t)n * Tal * 4));
         io.ybuf = s.ybuf.as<float>(); io.obuf = s.obuf.as<float>();
-        if (c.ylong == 2) { RET(s.tbuf.ensure((size_t)n * 2 * c.nfft * 4)); io.tbuf = s.tbuf.as<float>(); }
+        if (c.ylong == 2) { RET(s.tbuf.ensure((size_t)n * 3 * c.nfft * 4)); io.tbuf = s.tbuf.as<float>(); }
         if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<true>, dim3(n), dim3(DECONV_NT), shmem, c, io);
         return 0;

@@ -469,11 +469,12 @@ def test_deconv_without_the_optimisation_loops(eng):
         assert abs((Sg[k] > 0).sum() - (Sr[k] > 0).sum()) <= 1
 
 
-@pytest.mark.parametrize("T", [18000, 24000, 50000])
+@pytest.mark.parametrize("T", [18000, 24000, 50000, 100000])
 def test_deconv_long_traces(eng, T):
     """T = 18000: trace (72 KB) + scratch (72 KB) is the largest image k_deconv<false> keeps in LDS; T = 24000 runs k_deconv<true> (trace and
     output staging in global memory, LDS = the Welch transform's scratch); T = 50000 (round 4: nfft = 16384) also keeps the Welch twiddle / window tables in
-    global memory, LDS = re | im alone.  Beyond nfft = 16384 (T > 73728) the call is refused (deconvolveCa.m:61 / GetSn.m:33 take any T)."""
+    global memory, LDS = re | im alone; T = 100000 (round 6: nfft = 32768) splits the transform into the 16384-point transforms of the even and the odd samples,
+    one of them in LDS at a time.  Beyond nfft = 32768 (T > 147456) the call is refused (deconvolveCa.m:61 / GetSn.m:33 take any T)."""
     import oasis_oracle as oo
     from cnmf_e_amd._lib import CnmfeError
     Y = _ar1_traces(2, T, seed=21, rate=0.004)
@@ -486,13 +487,14 @@ def test_deconv_long_traces(eng, T):
     assert rel(Cg[0], Cr[0]) <= 2e-5 and rel(Crawg[0], Crawr[0]) <= 2e-5
     assert abs((Sg[0] > 0).sum() - (Sr[0] > 0).sum()) <= 1
     with pytest.raises(CnmfeError):
-        eng.deconv_temporal(np.zeros((1, 80000), np.float32), opts)
+        eng.deconv_temporal(np.zeros((1, 150000), np.float32), opts)
 
 
-@pytest.mark.parametrize("T", [24000, 50000])
+@pytest.mark.parametrize("T", [24000, 50000, 100000])
 def test_get_sn_of_long_recordings(eng, T):
     """per-pixel GetSn (update_spatial_parallel.m:191-194, Sources2D.m:328-379 -> GetSn.m:33-47) beyond the 20400 frames a trace + its Welch transform fit the
-    LDS with: the segments are read out of the interleaved video, the transform alone sits in LDS (T = 50000: nfft = 16384, twiddles in global memory).  Both
+    LDS with: the segments are read out of the interleaved video, the transform alone sits in LDS (T = 50000: nfft = 16384, twiddles in global memory; T = 100000:
+    nfft = 32768 as two 16384-point halves).  Both
     flavours -- the raw video (estimate_noise) and the background-subtracted one (update_sn) -- against the oracle's GetSn on the same rows."""
     import oasis_oracle as oo
     from cnmf_e_amd import synth
