@@ -154,11 +154,15 @@ struct Ysig4Acc {                                    // frame t of one pixel of 
 // `y` is anything indexable by the frame (a pointer into LDS or global memory, or an accessor of the 4-frame-interleaved video: Ysig4Acc below).
 // `tabs`: where the twiddle (nfft / 2 floats) and window (nfft floats) tables live -- nullptr: behind re | im in scr; a global buffer for recordings whose
 // transform (nfft = 16384: T > 36868) leaves no room for them in the 160 KB of LDS.
-template <class YT>
+// MAXB: band bins per thread -- nfft / 4 + 1 bins over the workgroup's threads: 17 covers nfft <= 16384 with 256 threads and nfft <= 32768 with 512 (k_deconv); the
+// 256-thread kernel of long recordings asks for 33
+// SPLIT: the instantiation that also knows the split transform (nfft = 32768) -- its own kernels: with the branch compiled into the common ones hipcc
+// allocated them 250-500 more spilled registers (k_deconv 71 -> 317, k_sn_pixels from 151 registers to 256)
+template <class YT, int MAXB = 17, bool SPLIT = false>
 __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *red, bool wintab, float *tabs = nullptr) {
     const int tid = threadIdx.x, NTH = (int)blockDim.x;
     const int nfft = c.nfft, L = c.L, step = c.L - c.nov;
-    const int nh = c.split ? nfft / 2 : nfft;                  // the transform that runs in LDS
+    const int nh = SPLIT ? nfft / 2 : nfft;                    // the transform that runs in LDS
     float *tb = tabs ? tabs : scr + 2 * nfft;
     float *re = scr, *im = scr + nh, *win = tb + nfft / 2;
     float *ebuf = tb + nfft / 2 + nfft;                        // (split: the even samples' transform, 2 nh floats, in the tables' global slot)
@@ -166,7 +170,6 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
     int logn = 0; while ((1 << logn) < nh) ++logn;
     const int k0 = (nfft + 3) / 4, k1 = nfft / 2;              // bins with 0.25 <= k/nfft <= 0.5
     const int nb = k1 - k0 + 1;
-    constexpr int MAXB = 33;                                   // bins per thread: nfft / 4 + 1 bins over 256 threads (nfft <= 32768: 8193 bins)
     float acc[MAXB];
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) acc[i] = 0.f;
@@ -175,7 +178,7 @@ __device__ double get_sn(const YT &y, const DeconvCfg &c, float *scr, double *re
     for (int k = tid; k < nh / 4; k += NTH) { float sn_, cs_; sincospif(-(float)k / (float)(nh / 2), &sn_, &cs_); tw[k] = make_float2(cs_, sn_); }
     if (tabs) __threadfence_block();                 // (tables in global memory: written and read by this workgroup alone; block_sum's barriers order them)
     w2 = block_sum(w2, red);
-    if (c.split) {
+    if constexpr (SPLIT) {
         // X_k = E_k + w^k O_k (w = exp(-2 pi i / nfft)) with E, O the nh-point transforms of the even / odd samples of the windowed, zero-padded pair of segments:
         // E goes to the global slot, O stays in LDS, and the band's bins k, nfft - k (k = nfft/4 .. nfft/2: indices k mod nh and nh - k) are combined from there
         for (int sg = 0; sg < c.nseg; sg += 2) {
@@ -618,7 +621,7 @@ __device__ __forceinline__ double hh_of(double g, int l) {       // cumsum(h.*h)
 // workgroup has a CU to itself -- 20 to 100 traces per level on 256 CUs: with ONE wave per SIMD nothing hides those latencies (a 31-sample task of Brent's objective
 // took 3 us).  Two waves per SIMD and tasks half as long; the register budget (256) stays.
 constexpr int DECONV_NT = 512;
-template <bool LONG>
+template <bool LONG, bool SPLIT = false>
 __global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double red[DECONV_NT / 64];
@@ -638,7 +641,7 @@ __global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) 
     const int Tal = (T + 3) & ~3;
     float *y = LONG ? io.ybuf + (int64_t)blockIdx.x * Tal : sm;          // T raw samples (fp32), persistent
     float *scr = LONG ? sm : sm + Tal;               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
-    const size_t scr_bytes = (size_t)(LONG ? (c.ylong == 2 ? (c.split ? 1 : 2) : 4) * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
+    const size_t scr_bytes = (size_t)(LONG ? (c.ylong == 2 ? (SPLIT ? 1 : 2) : 4) * c.nfft : max(4 * c.nfft, Tal)) * sizeof(float);
     float *tabs = (LONG && c.ylong == 2) ? io.tbuf + (int64_t)blockIdx.x * 3 * c.nfft : nullptr;      // nfft >= 16384: the Welch tables do not fit beside re | im
     float *ostage = LONG ? io.obuf + (int64_t)blockIdx.x * Tal : scr;   // the solution c(t), before it is written out
     const int nc_pools = (int)(scr_bytes / 24);
@@ -718,7 +721,7 @@ __global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) 
     __syncthreads();
     lap(1);
     // ---- noise level (GetSn on the raw trace: HALS_temporal.m:79, deconvTemporal.m:45) ----
-    const double sn = get_sn(y, c, scr, red, true, tabs);
+    const double sn = get_sn<decltype(y), 17, SPLIT>(y, c, scr, red, true, tabs);
     lap(2);
     // ---- time constant (deconvolveCa.m:73-89) ----
     double g = (double)io.pars[k];
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) 
         if (!optimize_g) break;                      // :113-115
         const double g0 = g;
         if (g > c.gmax) {                            // :104-108
-            const double sn2 = get_sn(y, c, scr, red, true, tabs);
+            const double sn2 = get_sn<decltype(y), 17, SPLIT>(y, c, scr, red, true, tabs);
             const double g2 = est_g(y, bsub, T, sn2, red);
             if (g2 >= -1.0) g = g2;
             if (tid < 64) { oasis_first(y, bsub + b, T, g, lam, smin, P, scr, nc_pools); const int nt = build_tasks(P, io, base2); if (tid == 0) { sh_i[0] = P.n; sh_i[1] = nt; } }
@@ -912,12 +915,13 @@ __global__ void __launch_bounds__(256) k_sn_pixels(DeconvCfg c, const float4 *__
 // Long recordings (trace + transform beyond 160 KB of LDS: T > 20400): the trace stays where it is -- the windowed segments are read out of the interleaved
 // video (every sample twice: the segments overlap by half) -- and LDS holds the transform alone; with nfft = 16384 (T > 36868) the twiddle table lives in a
 // per-workgroup slot of global memory.  `add`: the pixel mean for the RAW video (estimate_noise), nullptr / 0 for Ysig.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) k_sn_pixels_long(DeconvCfg c, const float4 *__restrict__ v4, int64_t npix, const float *__restrict__ add, float *__restrict__ tabs, float *__restrict__ sn) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red[4];
     for (int64_t m = blockIdx.x; m < npix; m += gridDim.x) {
         Ysig4Acc y{v4 + m, npix, add ? add[m] : 0.f};
-        const double v = get_sn(y, c, lds, red, false, tabs ? tabs + (int64_t)blockIdx.x * 3 * c.nfft : nullptr);
+        const double v = get_sn<Ysig4Acc, SPLIT ? 33 : 17, SPLIT>(y, c, lds, red, false, tabs ? tabs + (int64_t)blockIdx.x * 3 * c.nfft : nullptr);
         if (threadIdx.x == 0) sn[m] = (float)v;
         __syncthreads();
     }
@@ -938,8 +942,13 @@ static int sn_pixels_launch(cnmfe_ctx *ctx, const char *name, const float4 *v4, 
     const unsigned nwg = (unsigned)std::min<int64_t>(npix, 1024);
     float *tabs = nullptr;
     if (tab_global) { RET(ctx->dscr.tbuf.ensure((size_t)nwg * 3 * c.nfft * sizeof(float))); tabs = ctx->dscr.tbuf.as<float>(); }
-    if (sh > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels_long, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    LAUNCH(ctx, name, k_sn_pixels_long, dim3(nwg), dim3(256), sh, c, v4, npix, add_mean, tabs, dSn);
+    if (c.split) {
+        if (sh > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels_long<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        LAUNCH(ctx, name, k_sn_pixels_long<true>, dim3(nwg), dim3(256), sh, c, v4, npix, add_mean, tabs, dSn);
+        return 0;
+    }
+    if (sh > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_sn_pixels_long<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    LAUNCH(ctx, name, k_sn_pixels_long<false>, dim3(nwg), dim3(256), sh, c, v4, npix, add_mean, tabs, dSn);
     return 0;
 }
 
@@ -1064,6 +1073,11 @@ int deconv_launch(cnmfe_ctx *ctx, DeconvCfg &c, size_t shmem, DeconvIO io, const
         RET(s.ybuf.ensure((size_t)n * Tal * 4)); RET(s.obuf.ensure((size_t)n * Tal * 4));
         io.ybuf = s.ybuf.as<float>(); io.obuf = s.obuf.as<float>();
         if (c.ylong == 2) { RET(s.tbuf.ensure((size_t)n * 3 * c.nfft * 4)); io.tbuf = s.tbuf.as<float>(); }
+        if (c.split) {
+            if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", (k_deconv<true, true>), dim3(n), dim3(DECONV_NT), shmem, c, io);
+            return 0;
+        }
         if (shmem > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_deconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         LAUNCH(ctx, c.hals ? "temporal_hals_deconv_level" : "deconv_temporal", k_deconv<true>, dim3(n), dim3(DECONV_NT), shmem, c, io);
         return 0;
