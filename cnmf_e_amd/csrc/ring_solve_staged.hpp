@@ -9,7 +9,7 @@
 //   * the solve reads its centre block's list (one load per lane), keeps the neurons whose bounding box, dilated by one radius, contains the centre (the only ones whose footprint a ring
 //     of this radius can reach: ~4 of the ~18 on a block's list) and samples their two images at its ring pixels with plain index arithmetic: three dependent
 //     loads instead of six, all candidates' samples in flight at once.  A candidate whose samples are all zero on ring and centre is skipped.
-// Same neurons in the same (ascending) order as before, the same rank-2 corrections: the weights are bit-identical to k_ring_solve6's (tests/test_gpu_packed.py).
+// Same neurons in the same (ascending) order as before, the same rank-2 corrections: the weights are bit-identical to k_ring_solve6's (tests/test_gpu_solve_r6.py).
 #pragma once
 #include "ring_solve_packed.hpp"
 
