@@ -1,3 +1,8 @@
+"""De-phasing the two waves of a SIMD at the start of the ring solve (round 6): does the kernel lose time because the two waves of a SIMD load together and then
+compute together?  The experiment needs one line at the top of k_ring_solve8 (cnmf_e_amd/csrc/ring_solve_staged.hpp), not kept in the tree:
+    if ((probe & 8192) && (blockIdx.x & 1) && blockIdx.x < 4096) { for (int i = 0; i < (probe >> 16); ++i) __builtin_amdgcn_s_sleep(127); }
+Result at H (three first-run fits each): 5.995 / 5.996 / 6.033 ms without, 6.03 / 6.06 / 6.03 / 6.04 ms with 1 / 2 / 3 / 5 sleep units for every other workgroup of the first
+two rounds: no effect -- the waves de-phase by themselves."""
 import os, sys, numpy as np
 sys.path.insert(0, "/root/repo")
 import torch
