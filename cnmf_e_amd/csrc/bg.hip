@@ -1059,7 +1059,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             // The planes the spatial update's table and the temporal projection read hold EVERY frame and are built here, once per recording, under the same memory
             // rule (until round 5 a strided recording ran both on the fp64 pipe: 2.9-3.0 ms each for a rank's share of configs[4], profiles/r05/bench_c5shard_v3.json;
             // 2.5-2.6 ms now -- at that patch size all three video passes move their bytes at 5.5 TB/s whatever the pipe)
-            if (incr && kstride > 1 && !resident && !P->derived && !has_a_bf && T <= 24576 && ctx->opt("win_i8", 1) != 0) {
+            // (round 6, late: up to I8_SEG_FRAMES * 16 frames -- the projections that contract over FRAMES keep every int32 sum inside one frame segment of at most
+            //  I8_SEG_FRAMES frames, vproj.hip; the temporal projection contracts over pixels and has no such limit)
+            if (incr && kstride > 1 && !resident && !P->derived && !has_a_bf && T <= (int64_t)I8_SEG_FRAMES * 16 && ctx->opt("win_i8", 1) != 0) {
                 BgGeom g1 = g; g1.kstride = 1; g1.Tp = T; g1.Tpad = (T + 4 * GK - 1) / (4 * GK) * (4 * GK);
                 const size_t d1bytes = (size_t)nblk * g1.Tpad * BLKPX * sizeof(float);
                 bool ok = true;

@@ -271,6 +271,8 @@ namespace cnmfe {
 // lists and tables then cost one dispatch instead of one each (44 per patch and iteration in the 4 x 4-patch configuration: 700 dependent
 // 4-microsecond dispatches, 6 ms of GPU time line per iteration, profiles/r03/gap_analysis_c4.txt).
 constexpr int PIN_NSEG = 24;
+// int8 matrix pipe, sums over FRAMES (gram_i8.hpp, win_proj_i8.hpp): 4 digit pairs x 64 frames x 2^14 per accumulation step keep an int32 sum exact for this many frames
+constexpr int I8_SEG_FRAMES = 24576;
 struct PinSegs { const uint4 *src[PIN_NSEG]; uint4 *dst[PIN_NSEG]; unsigned n16[PIN_NSEG]; };
 }  // namespace cnmfe
 

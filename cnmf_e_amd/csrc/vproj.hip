@@ -180,10 +180,13 @@ int vproj_spatial(cnmfe_ctx *ctx, Patch *P, int32_t K, const float *C, int c_ord
         const int64_t nent = (int64_t)std::max<size_t>(1, lst_k.size()) * BLKPX;
         RET(P->pt_tab.ensure((size_t)nent * sizeof(double)));
         if (nb_ > 0) {
-            const int nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
+            int nsg = nb_ >= 512 ? std::max(1, std::min(8, (2048 + nb_ - 1) / nb_)) : std::max(1, std::min(16, (4096 + nb_ - 1) / std::max(1, nb_)));
+            // the int8 kernel sums a frame segment in int32 (4 digit pairs x 2^14 per frame): at most I8_SEG_FRAMES frames per segment -- a longer recording gets more segments
+            const bool i8_tab = !P->derived && P->dig_valid && P->T <= (int64_t)I8_SEG_FRAMES * 16 && ctx->opt("win_i8", 1) != 0;
+            if (i8_tab) nsg = std::max(nsg, (int)((P->T + I8_SEG_FRAMES - 1) / I8_SEG_FRAMES));
             RET(dUt.ensure((size_t)nsg * nent * sizeof(double)));
             const int nbig = (int)blk_nt[3].size();
-            if (!P->derived && P->dig_valid && P->T <= 24576 && ctx->opt("win_i8", 1) != 0) {
+            if (i8_tab) {
                 // round 6: the table on the int8 pipe out of the resident digit planes, by the fit's own kernel (win_proj_i8.hpp) -- what a recording whose fit runs on
                 // every other frame needs every iteration (the fit's table covers ITS frames only: BASELINE configs[4]), and any patch whose fit left no table
                 RET(win_i8_table(ctx, P, "spatial_trace_dig", "spatial_ptab_proj", K, dCc, ldc, lst_ptr, blall, P->pt_lp.as<int>(), dLk.as<int>(), nsg, dUt.as<double>(), nent));

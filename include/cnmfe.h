@@ -426,7 +426,8 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  *   win_i8            default 1: the digit planes stay resident (one more video's worth of memory, taken only when that leaves 8 GB free) and every fit's window
  *                     projection runs on the int8 pipe; 0: the fp64 kernel on the centred video
  *   proj_tiled / proj_i8   default 1 / 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes (needs win_i8), else out of a copy of
- *                     the centred video in its own read order (one video's worth either, same rule); 0 / 0: the frame-major video on the fp64 pipe
+ *                     the centred video in its own read order (one video's worth either, same rule); 0 / 0: the frame-major video on the fp64 pipe.  The tables over ALL frames
+ *                     (spatial update, temporal projection) sum inside frame segments of at most 24576 frames, recordings up to 16 x 24576 frames
  *   prealloc          default 1: cnmfe_fit_reserve may allocate the fit's large buffers ahead of the first fit
  * A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.
  * Diagnostics (scripts/): solve_probe, r1_probe (phase probes: results are NOT the product's), deconv_trace, host_trace (1: host-side phase times of every call on

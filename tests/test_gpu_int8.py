@@ -100,3 +100,19 @@ def test_int8_table_of_a_strided_fit_and_without_footprints():
             eng.close()
     for a, b in zip(res[1], res[0]):
         assert np.all(np.isfinite(a)) and rel(a, b) <= 5e-7, rel(a, b)
+
+
+def test_int8_projections_of_a_recording_longer_than_one_int32_segment():
+    """T = 26000 > 24576 frames, frame stride 9 in the fit (fit_ring_model.m:84-87): the digit planes of EVERY frame feed the spatial update's table -- its sums run
+    over frames and are kept inside frame segments of at most 24576 frames -- and the temporal projection (sums over pixels); both against the fp64 kernels on the
+    same upload"""
+    d1, d2, T, r, K = 36, 32, 26000, 5, 4
+    f, Y = _case(d1, d2, T, K, r, 29)
+    W1, A1, C1, n1 = _run({}, f, Y, d1, d2, T, r, None)
+    W0, A0, C0, n0 = _run({"win_i8": 0, "proj_i8": 0}, f, Y, d1, d2, T, r, None)
+    assert "temporal_panel_dig" in n1 and "spatial_trace_dig" in n1, n1          # the int8 table of the spatial update and the int8 temporal projection ran ...
+    assert "temporal_panel_dig" not in n0 and "spatial_trace_dig" not in n0, n0  # ... and did not
+    for a, b in zip(W1, W0):
+        assert np.all(np.isfinite(a)) and rel(a, b) <= 5e-7, rel(a, b)
+    assert np.array_equal(A1 != 0, A0 != 0)
+    assert rel(A1, A0) <= 2e-6 and rel(C1, C0) <= 2e-6, (rel(A1, A0), rel(C1, C0))
