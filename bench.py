@@ -199,6 +199,18 @@ def spawn_ranks(n, argv):
     print(lines[-1], flush=True)
 
 
+def emit(obj):
+    """the ONE JSON line, as the last thing on stdout: what C libraries still hold in stdio's buffer (RCCL's banner under NCCL_DEBUG=VERSION, written when the communicator
+    was made and otherwise flushed at exit, BEHIND the line) goes out first"""
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(obj), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -740,7 +752,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":

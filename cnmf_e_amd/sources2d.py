@@ -1110,18 +1110,12 @@ class Sources2D:
         self._prefetch_search_location()
 
     def _post_process(self, A_):
-        """obj.post_process_spatial() (:341) works on whole footprints, which only exist after the gather; sharded, every rank then takes the
-        columns k = rank mod world and the processed columns are gathered again (disjoint columns: the same all-gather of triplets)"""
+        """obj.post_process_spatial() (:341) works on whole footprints, which only exist after the gather.  Sharded, every rank holds the whole gathered A and
+        runs the (deterministic) connectivity kernel over ALL of its columns: one 35-us kernel more per rank instead of a second all-gather round of the processed
+        columns (rounds 2-5 split the columns k = rank mod world and gathered them again: two collectives + the host-side assembly of the whole A once more, on
+        the spatial -> temporal hand-over where the device idles)"""
         v = self.video
-        if self.dist is None or (v.world_size == 1 and not self.force_collectives):
-            return self.engine.post_process_spatial(A_, v.d1, v.d2)
-        K = A_.shape[1]
-        mine = np.arange(v.rank, K, v.world_size)
-        sub = self.engine.post_process_spatial(A_[:, mine], v.d1, v.d2).tocoo() if mine.size else sp.coo_matrix((A_.shape[0], 0), dtype=np.float32)
-        part = sp.csc_matrix((sub.data, (sub.row, mine[sub.col])), shape=A_.shape) if mine.size else sp.csc_matrix(A_.shape, dtype=np.float32)
-        out = self._gather_sparse(part)
-        out.sort_indices()
-        return out
+        return self.engine.post_process_spatial(A_, v.d1, v.d2)
 
     def _prefetch_search_location(self):
         """The search mask of the NEXT spatial update depends on A only, which the background update leaves alone: build it
@@ -1186,48 +1180,44 @@ class Sources2D:
         return IND
 
     def _gather_sparse(self, A_):
-        """all-gather of the per-rank rows of A (disjoint pixel sets, no reduction)."""
+        """all-gather of the per-rank rows of A (disjoint pixel sets, no reduction).  ONE tensor collective per call once the sizes are known: every
+        rank sends a padded int32 [3, cap + 1] block (row, column, value bits; the last column carries its count) with cap = the largest count of the previous
+        gather + a quarter; a rank that outgrew cap is seen by everybody in the gathered counts, and everybody repeats the round with the capacity those counts ask
+        for (the first call of a run costs two rounds: it starts from cap = 0)."""
         if self.dist is None or (self.video.world_size == 1 and not self.force_collectives):
             return A_
         import torch
         import torch.distributed as td
-        import os as _os, time as _time
-        _tr = _os.environ.get("CNMFE_TRACE_GATHER") == "1"; _t = [_time.perf_counter()]
-        def _mk(what):
-            if _tr:
-                _t.append(_time.perf_counter()); print("[gather] %-18s %.2f ms" % (what, 1e3 * (_t[-1] - _t[-2])), flush=True)
         coo = A_.tocoo()
         nccl = td.get_backend(self.dist) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-        W = self.video.world_size
-        # two tensor collectives (sizes, then one padded int32 [3, nmax] block per rank: row, col, value bits) instead of pickled objects
-        n = torch.tensor([coo.nnz], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(n) for _ in range(W)]
-        _mk("prep")
-        td.all_gather(sizes, n, group=self.dist)
-        _mk("all_gather sizes")
-        sizes = [int(x.item()) for x in sizes]
-        _mk("item")
-        nmax = max(1, max(sizes))
-        # the padded block is put together by NumPy, not by torch CPU kernels: a torch fill / copy of this size opens an OpenMP region over every core of
-        # the host, whose threads then spin -- inside a CPU-quota'd container that throttled the whole process for ~40 ms of every 100-ms scheduler period
-        # (one rank of RCCL at c4: 26 -> 50-58 ms per iteration; OMP_NUM_THREADS=1 made it vanish: profiles/r04/forced_collectives.txt)
-        buf_np = np.zeros((3, nmax), dtype=np.int32)
-        buf_np[0, :coo.nnz] = coo.row
-        buf_np[1, :coo.nnz] = coo.col
-        buf_np[2, :coo.nnz] = np.ascontiguousarray(coo.data, dtype=np.float32).view(np.int32)
-        _mk("host buffer")
-        buf = torch.from_numpy(buf_np).to(dev)
-        _mk("to device")
-        out = [torch.empty_like(buf) for _ in range(W)]
-        _mk("empty_like")
-        td.all_gather(out, buf, group=self.dist)
-        _mk("all_gather")
-        out = [o.cpu().numpy() for o in out]
-        _mk("to host")
-        r = np.concatenate([o[0, :m] for o, m in zip(out, sizes)])            # int32 row / column indices: the CSC build is index-bound
-        c = np.concatenate([o[1, :m] for o, m in zip(out, sizes)])
-        d_ = np.concatenate([np.ascontiguousarray(o[2, :m]).view(np.float32) for o, m in zip(out, sizes)])
+        W = td.get_world_size(self.dist)                                  # (= video.world_size in a run; scripts/rank_load.py times one rank's share behind a group of one)
+        n = int(coo.nnz)
+        cap = int(getattr(self, "_gather_cap", 0))
+        while True:
+            # the padded block is put together by NumPy, not by torch CPU kernels: a torch fill / copy of this size opens an OpenMP region over every core of
+            # the host, whose threads then spin -- inside a CPU-quota'd container that throttled the whole process for ~40 ms of every 100-ms scheduler period
+            # (one rank of RCCL at c4: 26 -> 50-58 ms per iteration; OMP_NUM_THREADS=1 made it vanish: profiles/r04/forced_collectives.txt)
+            buf_np = np.zeros((3, cap + 1), dtype=np.int32)
+            m = min(n, cap)
+            if n <= cap:
+                buf_np[0, :m] = coo.row
+                buf_np[1, :m] = coo.col
+                buf_np[2, :m] = np.ascontiguousarray(coo.data, dtype=np.float32).view(np.int32)
+            buf_np[0, cap] = n
+            buf = torch.from_numpy(buf_np).to(dev)
+            out = torch.empty((W, 3, cap + 1), dtype=torch.int32, device=dev)
+            td.all_gather_into_tensor(out, buf, group=self.dist) if nccl else td.all_gather(list(out.unbind(0)), buf, group=self.dist)
+            out = out.cpu().numpy()
+            sizes = [int(out[w, 0, cap]) for w in range(W)]
+            nmax = max(sizes)
+            if nmax <= cap:
+                break
+            cap = ((nmax + nmax // 4 + 255) // 256) * 256                     # (the same number on every rank: it comes from the gathered counts)
+        self._gather_cap = max(cap, ((nmax + nmax // 4 + 255) // 256) * 256) if nmax > (cap * 3) // 4 else cap      # (grown ahead of a matrix that fills up)
+        r = np.concatenate([out[w, 0, :m_] for w, m_ in zip(range(W), sizes)])            # int32 row / column indices: the CSC build is index-bound
+        c = np.concatenate([out[w, 1, :m_] for w, m_ in zip(range(W), sizes)])
+        d_ = np.concatenate([np.ascontiguousarray(out[w, 2, :m_]).view(np.float32) for w, m_ in zip(range(W), sizes)])
         return _csc_from_triplets(r, c, d_, A_.shape)
 
     # -- objective ----------------------------------------------------------------------

@@ -5,7 +5,7 @@ import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--steps", type=int, default=6)
+ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--steps", type=int, default=6); ap.add_argument("--prof", default=""); ap.add_argument("--force-collectives", action="store_true", help="every collective branch of the three methods behind an RCCL group of ONE rank (the host side of the collectives, no second GPU)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -18,7 +18,14 @@ video = PatchedVideo(d1, d2, T, [128, 128], r, eng, rank=a.rank, world_size=a.wo
 for idx in video.owned:
     Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()
     video.upload_block_device(idx, Yb.data_ptr()); del Yb
-s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=5), f.A_init, f.C_init, f.sn)
+group = None
+if a.force_collectives or os.environ.get("CNMFE_BENCH_FORCE_COLLECTIVES", "0") == "1":
+    import torch.distributed as td
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534"); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    td.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    group = td.group.WORLD
+s = Sources2D(video, Options(ring_radius=r, spatial_algorithm="hals", maxIter=5), f.A_init, f.C_init, f.sn, dist_group=group)
+s.force_collectives = group is not None
 def step():
     t0 = time.perf_counter(); s.update_background_parallel(); t1 = time.perf_counter(); s.update_spatial_parallel(); t2 = time.perf_counter(); s.update_temporal_parallel()
     return t1 - t0, t2 - t1, time.perf_counter() - t2
@@ -26,12 +33,19 @@ for _ in range(2):
     step()
 torch.cuda.synchronize()
 eng.profile(True); eng.profile_reset()
+if a.prof:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
 t0 = time.perf_counter(); parts = np.zeros(3)
 for _ in range(a.steps):
     parts += step()
+if a.prof:
+    pr.disable()
+    with open(a.prof, "w") as fh:
+        pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(90); pstats.Stats(pr, stream=fh).sort_stats("tottime").print_stats(60)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 tab = eng.profile_table()
-print("rank %d of %d (%d patches): %.2f ms / iteration; host time in calls: bg %.2f spatial %.2f temporal %.2f ms; kernel sum %.2f ms" % (
-    a.rank, a.world, len(video.owned), 1e3 * dt, *(1e3 * parts / a.steps), sum(v["total_ms"] for v in tab.values()) / a.steps))
+print("rank %d of %d (%d patches)%s: %.2f ms / iteration; host time in calls: bg %.2f spatial %.2f temporal %.2f ms; kernel sum %.2f ms" % (
+    a.rank, a.world, len(video.owned), " with the collectives of a group of one" if group is not None else "", 1e3 * dt, *(1e3 * parts / a.steps), sum(v["total_ms"] for v in tab.values()) / a.steps))
 print({k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["total_ms"])[:14]})

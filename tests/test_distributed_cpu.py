@@ -104,6 +104,55 @@ def test_two_rank_sharded_deconvolution_matches_single_process(tmp_path):
     assert (ref["S"] > 0).any()
 
 
+def _gather_run(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    import scipy.sparse as sp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from cnmf_e_amd import synth
+    from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
+    from fake_engine import FakeEngine
+    d1, d2, T, K, r = 30, 28, 40, 4, 5
+    f = synth.make_factors(d1, d2, T, K, 7, gSig=1.5, gSiz=7, min_sep=5)
+    video = PatchedVideo(d1, d2, T, [15, 14], r, FakeEngine(), rank=rank, world_size=world)
+    video.upload_from_full(synth.make_video(f, np.float32).astype(np.float64))
+    s = Sources2D(video, Options(ring_radius=r), f.A_init, f.C_init, f.sn, dist_group=td.group.WORLD)
+    d = d1 * d2
+    rng = np.random.default_rng(3)
+    caps, ok = [], True
+    # per call: how many entries each rank contributes (disjoint rows: rank 0 the even pixels, rank 1 the odd ones).  Growth beyond the remembered capacity on ONE
+    # rank only, an empty contribution, a shrinking one
+    for n0, n1 in [(5, 9), (1000, 3), (0, 0), (40, 1600), (7, 7), (0, 1680)]:
+        full = []
+        for rk, n in ((0, n0), (1, n1)):
+            rows = rng.choice(d // 2, size=min(n, d // 2), replace=False) * 2 + rk
+            cols = rng.integers(0, K, size=rows.size)
+            if n > d // 2:                                              # more entries than pixels of a parity: several columns per row
+                rows = np.repeat(np.arange(rk, d, 2), K)[:n]; cols = np.tile(np.arange(K), d // 2)[:n]
+            full.append((rows, cols, rng.random(rows.size).astype(np.float32) + 0.5))
+        mine = full[rank]
+        got = s._gather_sparse(sp.csc_matrix((mine[2], (mine[0], mine[1])), shape=(d, K)))
+        want = sp.csc_matrix((np.concatenate([x[2] for x in full]), (np.concatenate([x[0] for x in full]), np.concatenate([x[1] for x in full]))), shape=(d, K))
+        ok = ok and got.shape == want.shape and (got != want).nnz == 0
+        caps.append(int(s._gather_cap))
+    if rank == 0:
+        np.savez(out, ok=ok, caps=np.array(caps))
+    td.barrier(); td.destroy_process_group()
+
+
+def test_gather_of_footprint_rows_in_one_round_with_a_remembered_capacity(tmp_path):
+    """_gather_sparse sends one padded block per rank and call; the capacity follows the gathered counts (the same number on every rank), a rank that outgrew it
+    makes everybody repeat the round, empty contributions and shrinking ones pass"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "g.npz")
+    mp.spawn(_gather_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert bool(got["ok"])
+    caps = got["caps"].tolist()
+    assert caps == [256, 1280, 1280, 2048, 2048, 2304], caps
+
+
 def test_bench_spawns_its_own_ranks_and_refuses_without_gpus():
     """`python bench.py --gpus N` with no launcher in the environment starts N ranks itself (it used to run ONE rank silently).
     CNMFE_BENCH_DRY=1 stops after the rendezvous and one all-reduce (gloo here: no GPU), so this checks the env plumbing and the relayed line;
