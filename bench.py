@@ -296,6 +296,11 @@ def main():
     d2, K = (d2p, Kp) if sharded_fov else (d2p * world, Kp * world)
     f = synth.make_factors(d1, d2, T, K, seed)
     eng = Engine(local)
+    # several patches per rank: their calls alternate between two execution lanes (streams + scratch sets, cnmfe_set_option "lanes") -- small patches' kernels are
+    # a few workgroups each with a dispatch latency between two dependent ones; CNMFE_BENCH_LANES=1 gives the one-stream figure
+    lanes = int(os.environ.get("CNMFE_BENCH_LANES", "2" if sharded_fov else "1"))
+    if lanes > 1:
+        eng.set_option("lanes", lanes)
     shard_of = SHARD_OF.get(a.config, 0)
     if shard_of and world > 1:
         raise SystemExit("%s is one rank's share of a %d-rank run on ONE GPU" % (a.config, shard_of))
@@ -689,6 +694,7 @@ def main():
                                    "P = Yc*Cc', the temporal update projects the centred video through B = A - W'*A; same values as the swept residual "
                                    "(tests/test_gpu_virtual.py); the ring sweep itself is timed separately for `roofline_r1`")
                                   if os.environ.get("CNMFE_OPTS", "").find("r1_virtual=0") < 0 and a.bg_ssub == 1 else "swept residual (r1_virtual = 0 / ssub_virtual = 0): one ring sweep per iteration"),
+                   "lanes_per_rank": lanes,
                    "parallelism": ("patches round-robin over %d rank(s)" % world) if not shard_of else
                                   ("rank 0 of %d: this rank's %d of the %d patches on ONE GPU, no collectives (a per-rank load figure, not a scaling point); "
                                    "the video is uploaded as fp16 and widened on the device" % (shard_of, len(video.owned), len(video.order))),

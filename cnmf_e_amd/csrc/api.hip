@@ -414,6 +414,7 @@ static int stitch_finish_one(cnmfe_ctx *ctx, int subtract_min, float *C_raw_out,
     if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
     const int32_t K = ctx->stitch_K; const int64_t T = ctx->stitch_T, ldc = (T + 3) & ~int64_t(3);
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     RET(ctx->bound.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ldc) * sizeof(float)));
     if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->st(), ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // the last download still reads `bound`
     if (K > 0) LAUNCH(ctx, "stitch_finish", k_stitch_finish, dim3((unsigned)K), dim3(256), 0, ctx->stitch.as<float>(), ctx->stitch_ld, T, subtract_min, ctx->bound.as<float>(), ldc);
@@ -483,6 +484,82 @@ cnmfe_ctx::~cnmfe_ctx() {
     for (auto e : tickets) (void)hipEventDestroy(e);
     if (ticket_flags) (void)hipHostFree(ticket_flags);
     if (stream_) (void)hipStreamDestroy(stream_);
+    for (auto *L : lanes) delete L;                           // (the inactive lanes' streams, events and scratch)
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+}
+
+// ---- execution lanes (common.hpp, cnmfe_lane) ----
+void cnmfe_ctx::swap_lane(cnmfe_lane &L) {
+    std::swap(stream_, L.stream_); std::swap(pseg, L.pseg); std::swap(npseg, L.npseg); pin.swap(L.pin); std::swap(spatial_nnz, L.spatial_nnz);
+    for (int i = 0; i < 32; ++i) { vp[i].swap(L.vp[i]); std::swap(hw_vp[i], L.hw_vp[i]); }
+    std::swap(last_ldc, L.last_ldc);
+    ysig_low.swap(L.ysig_low); up_tmp.swap(L.up_tmp); bgs_r.swap(L.bgs_r); bgs_b.swap(L.bgs_b); bgs_upr.swap(L.bgs_upr); bgs_upc.swap(L.bgs_upc);
+    std::swap(bgs_patch, L.bgs_patch); std::swap(bgs_d1s, L.bgs_d1s); std::swap(bgs_dF, L.bgs_dF);
+    bf.swap(L.bf); dig_smax.swap(L.dig_smax); dig_rspart.swap(L.dig_rspart); dig_scale.swap(L.dig_scale); tdig.swap(L.tdig); tscale.swap(L.tscale); gk.swap(L.gk);
+    win_items.swap(L.win_items); bf2.swap(L.bf2); outl_cnt.swap(L.outl_cnt); outl_sel.swap(L.outl_sel); cov.swap(L.cov); rowsum.swap(L.rowsum);
+    for (int i = 0; i < 16; ++i) tmp[i].swap(L.tmp[i]);
+    std::swap(hw_cc, L.hw_cc); std::swap(hw_cm, L.hw_cm); for (int i = 0; i < 3; ++i) std::swap(hw_wa[i], L.hw_wa[i]);
+    for (int i = 0; i < 7; ++i) inc[i].swap(L.inc[i]);
+    for (int i = 0; i < 4; ++i) stg[i].swap(L.stg[i]);
+    wcodes.swap(L.wcodes); solve_fill.swap(L.solve_fill); stage.swap(L.stage);
+    for (int i = 0; i < 24; ++i) scr[i].swap(L.scr[i]);
+    dscr.swap(L.dscr);
+}
+int cnmfe_ctx::activate(int lane) {
+    if (lanes.empty() || lane == cur_lane) {
+        if (!lanes.empty() && lane != 0 && lanes[lane]->fork_seen != fork_gen) {      // (active, but a call on lane 0 has queued shared work since this lane last looked)
+            CK(hipStreamWaitEvent(stream_, ev_fork, 0)); lanes[lane]->fork_seen = fork_gen;
+        }
+        if (!lanes.empty() && lane != 0) lanes[lane]->dirty = true;
+        return 0;
+    }
+    if (lane < 0 || lane >= (int)lanes.size()) return fail(CNMFE_ESTATE, "lane %d of %d", lane, (int)lanes.size());
+    if (npseg) flush_copies();                               // an inactive lane holds no held-back uploads: whoever reads their targets from another lane finds them queued
+    swap_lane(*lanes[cur_lane]);                             // the active lane's members into its storage ...
+    swap_lane(*lanes[lane]);                                 // ... and this lane's out of its own
+    cur_lane = lane;
+    if (lane != 0) {
+        if (lanes[lane]->fork_seen != fork_gen) { CK(hipStreamWaitEvent(stream_, ev_fork, 0)); lanes[lane]->fork_seen = fork_gen; }
+        lanes[lane]->dirty = true;
+    }
+    return 0;
+}
+int cnmfe_ctx::join_lanes() {
+    if (lanes.empty()) return 0;
+    // the other lanes first say where they are (each on its own stream, its held-back uploads sent), then lane 0 waits for those points
+    for (int l = 1; l < (int)lanes.size(); ++l) {
+        if (!lanes[l]->dirty) continue;
+        RET(activate(l));
+        CK(hipEventRecord(lanes[l]->ev, st()));
+    }
+    RET(activate(0));
+    for (int l = 1; l < (int)lanes.size(); ++l)
+        if (lanes[l]->dirty) { CK(hipStreamWaitEvent(st(), lanes[l]->ev, 0)); lanes[l]->dirty = false; }
+    return 0;
+}
+int cnmfe_ctx::fork_mark() {
+    if (lanes.empty()) return 0;
+    RET(activate(0));
+    CK(hipEventRecord(ev_fork, st()));
+    ++fork_gen;
+    return 0;
+}
+static int lanes_set(cnmfe_ctx *ctx, int64_t n) {
+    if (n < 1 || n > 4) return fail(CNMFE_EINVAL, "option lanes = %lld: 1 .. 4", (long long)n);
+    if (!ctx->patches.empty() && (int)std::max<size_t>(1, ctx->lanes.size()) != n) return fail(CNMFE_ESTATE, "option lanes is set before the first patch is created");
+    if (n == 1 || (int)ctx->lanes.size() == n) return 0;
+    CK(hipSetDevice(ctx->device));
+    for (int l = 0; l < n; ++l) {
+        cnmfe_lane *L = new cnmfe_lane();
+        ctx->lanes.push_back(L);
+        CK(hipEventCreateWithFlags(&L->ev, hipEventDisableTiming));
+        if (l == 0) continue;                                // (lane 0 is the active one: its members are the context's own)
+        CK(hipStreamCreate(&L->stream_));
+        if (L->pin.init(size_t(64) << 20) != 0) return fail(CNMFE_EHIP, "pinned staging arena (64 MB) of lane %d could not be allocated", l);
+    }
+    CK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    CK(hipEventRecord(ctx->ev_fork, ctx->st()));
+    return 0;
 }
 
 extern "C" {
@@ -527,12 +604,14 @@ cnmfe_ctx *cnmfe_create(int device) {
 void cnmfe_destroy(cnmfe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)ctx->join_lanes();
     (void)hipStreamSynchronize(ctx->st());
     delete ctx;
 }
 
 int cnmfe_synchronize(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
+    RET(ctx->join_lanes());                                  // (every lane's work in front of lane 0's stream)
     CK(hipStreamSynchronize(ctx->st()));
     if (ctx->copy_stream) CK(hipStreamSynchronize(ctx->copy_stream));
     return ctx_check_errflag(ctx);
@@ -543,6 +622,7 @@ int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     // behaviour switches (include/cnmfe.h) and, behind them, the probes of scripts/ (diagnostics: solve_probe, r1_probe, deconv_trace, host_trace, debug)
     static const char *known[] = {"r1_variant", "r1_delta", "r1_lazy", "r1_defer", "r1_virtual", "gram_incremental", "prealloc", "solve_packed", "solve_staged", "solve_inv", "solve_inv_terms", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "proj_i8_planes", "ssub_virtual",
                                   "solve_probe", "r1_probe", "deconv_trace", "host_trace", "debug", nullptr};
+    if (!strcmp(name, "lanes")) { RET(lanes_set(ctx, value)); ctx->opts[name] = value; return 0; }
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; if (!strcmp(name, "host_trace")) ctx->trace_level = (int)value; return 0; }
     return fail(CNMFE_EINVAL, "unknown option '%s'", name);
 }
@@ -557,6 +637,7 @@ int cnmfe_patch_create(cnmfe_ctx *ctx, int patch_id, const int32_t pr[4], const 
     CK(hipSetDevice(ctx->device));
     if (ctx->patches.count(patch_id)) { delete ctx->patches[patch_id]; ctx->patches.erase(patch_id); }
     Patch *P = new Patch();
+    P->lane = ctx->lanes.empty() ? 0 : (ctx->patches_created++ % (int)ctx->lanes.size());
     memcpy(P->prect, pr, sizeof(P->prect)); memcpy(P->brect, br, sizeof(P->brect));
     P->d1 = d1; P->d2 = d2; P->T = T;
     P->nr = pr[1] - pr[0] + 1; P->nc = pr[3] - pr[2] + 1;
@@ -885,6 +966,7 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
     if (algorithm == CNMFE_SPATIAL_HALS_THRESH && !sn) return fail(CNMFE_EINVAL, "HALS_THRESH needs sn");
     if (param <= 0) return fail(CNMFE_EINVAL, "maxIter/maxN must be positive");
     CK(hipSetDevice(ctx->device));
+    ctx->spatial_lane = P->lane;                            // (the fetch calls carry no patch id: they look at this lane's scratch)
     return spatial_run(ctx, P, algorithm, K, A_colptr, A_rowidx, A_val, C, c_order, IND_colptr, IND_rowidx, sn, param, A_out);
 }
 
@@ -892,6 +974,7 @@ int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     if (!A_out && nnz) return fail(CNMFE_EINVAL, "null A_out");
     CK(hipSetDevice(ctx->device));
+    RET(ctx->activate(ctx->spatial_lane));
     return spatial_fetch(ctx, A_out, nnz);
 }
 
@@ -922,6 +1005,7 @@ int cnmfe_update_spatial_fetch_async(cnmfe_ctx *ctx, float *A_out_pinned, int64_
     if (!ctx || !ticket) return fail(CNMFE_EINVAL, "null context / ticket");
     if (!A_out_pinned && nnz) return fail(CNMFE_EINVAL, "null A_out");
     CK(hipSetDevice(ctx->device));
+    RET(ctx->activate(ctx->spatial_lane));
     if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
     if (nnz) CK(hipMemcpyAsync(A_out_pinned, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
     return ticket_record(ctx, ticket);
@@ -949,6 +1033,7 @@ int cnmfe_update_spatial_fetch_connected(cnmfe_ctx *ctx, int32_t d1, int32_t d2,
     RET(check_csc("IND", K, (int64_t)d1 * d2, IND_colptr, IND_rowidx));
     if (IND_colptr[K] && (!A_out || !keep_out)) return fail(CNMFE_EINVAL, "null A_out / keep_out");
     CK(hipSetDevice(ctx->device));
+    RET(ctx->activate(ctx->spatial_lane));
     return spatial_fetch_connected(ctx, d1, d2, K, IND_colptr, IND_rowidx, A_out, keep_out);
 }
 
@@ -959,6 +1044,7 @@ int cnmfe_update_spatial_fetch_connected_async(cnmfe_ctx *ctx, int32_t d1, int32
     RET(check_csc("IND", K, (int64_t)d1 * d2, IND_colptr, IND_rowidx));
     if (IND_colptr[K] && (!A_out_pinned || !keep_out_pinned)) return fail(CNMFE_EINVAL, "null A_out / keep_out");
     CK(hipSetDevice(ctx->device));
+    RET(ctx->activate(ctx->spatial_lane));
     RET(spatial_fetch_connected(ctx, d1, d2, K, IND_colptr, IND_rowidx, A_out_pinned, keep_out_pinned, false));
     return ticket_record(ctx, ticket);
 }
@@ -1040,6 +1126,7 @@ int cnmfe_stitch_begin(cnmfe_ctx *ctx, int32_t K, int64_t T) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     if (K < 0 || T <= 0) return fail(CNMFE_EINVAL, "bad K / T");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     const int64_t ld = ((T + 3) & ~int64_t(3)) + 4;
     RET(ctx->stitch.ensure((size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float)));
     CK(hipMemsetAsync(ctx->stitch.p, 0, (size_t)std::max<int64_t>(1, (int64_t)K * ld) * sizeof(float), ctx->st()));
@@ -1071,6 +1158,7 @@ int cnmfe_hals_temporal_job(cnmfe_ctx *ctx, int patch_id, int32_t K, const int64
 int cnmfe_temporal_jobs_sweep(cnmfe_ctx *ctx) {
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     return temporal_sweep_jobs(ctx);
 }
 int cnmfe_stitch_add_job(cnmfe_ctx *ctx, int32_t job_id, int32_t K_m, const int32_t *ind_m) {
@@ -1087,6 +1175,7 @@ int cnmfe_stitch_add_job(cnmfe_ctx *ctx, int32_t job_id, int32_t K_m, const int3
         seen[ind_m[j]] = 1;
     }
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     RET(to_dev(ctx, ctx->scr[23], ind_m, (size_t)K_m));
     LAUNCH(ctx, "stitch_add", k_stitch_add, dim3((unsigned)((ctx->stitch_T + 255) / 256), (unsigned)K_m), dim3(256), 0, job->dCraw.as<float>(), job->ldc,
            job->dAa.as<float>(), ctx->scr[23].as<int>(), ctx->stitch.as<float>(), ctx->stitch_ld, ctx->stitch_T);
@@ -1107,6 +1196,7 @@ int cnmfe_stitch_add(cnmfe_ctx *ctx, int32_t K_m, const int32_t *ind_m) {
         seen[ind_m[j]] = 1;
     }
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     RET(to_dev(ctx, ctx->scr[23], ind_m, (size_t)K_m));
     LAUNCH(ctx, "stitch_add", k_stitch_add, dim3((unsigned)((ctx->stitch_T + 255) / 256), (unsigned)K_m), dim3(256), 0, ctx->last_craw.as<float>(), ctx->last_t_ldc,
            ctx->last_aa.as<float>(), ctx->scr[23].as<int>(), ctx->stitch.as<float>(), ctx->stitch_ld, ctx->stitch_T);
@@ -1119,6 +1209,7 @@ int cnmfe_stitch_buffer(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld) {
     if (!ctx || !dev_acc || !ld) return fail(CNMFE_EINVAL, "null argument");
     if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     CK(hipStreamSynchronize(ctx->st()));                 // the caller's collective runs on ITS stream: everything added so far must have landed
     *dev_acc = ctx->stitch.as<float>(); *ld = ctx->stitch_ld;
     return 0;
@@ -1130,6 +1221,7 @@ int cnmfe_stitch_buffer_stream(cnmfe_ctx *ctx, float **dev_acc, int64_t *ld, voi
     if (!ctx || !dev_acc || !ld || !hip_stream) return fail(CNMFE_EINVAL, "null argument");
     if (!ctx->stitch_open) return fail(CNMFE_ESTATE, "cnmfe_stitch_begin has not been called");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     *dev_acc = ctx->stitch.as<float>(); *ld = ctx->stitch_ld; *hip_stream = (void *)ctx->st();      // (st(): the held-back small uploads go out first)
     return 0;
 }
@@ -1419,6 +1511,7 @@ int cnmfe_traces_bind(cnmfe_ctx *ctx, int32_t K, int64_t T, const float *C, int 
     if (K < 0 || T <= 0) return fail(CNMFE_EINVAL, "bad K / T");
     if (c_order != CNMFE_ROWMAJOR && c_order != CNMFE_COLMAJOR) return fail(CNMFE_EINVAL, "bad c_order");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     int64_t ldc;
     if (ctx->copy_pending) { CK(hipStreamWaitEvent(ctx->st(), ctx->ev_copy_done, 0)); ctx->copy_pending = false; }   // a lazy download may still read `bound` (as stitch_finish_one)
     RET(upload_traces(ctx, ctx->bound, C, K, T, c_order, &ldc));
@@ -1434,6 +1527,7 @@ int cnmfe_deconv_temporal(cnmfe_ctx *ctx, int32_t K, int64_t T, float *C_raw, in
     if (K == 0) return 0;
     if (!C_raw || !opts || !C_out) return fail(CNMFE_EINVAL, "null C_raw / opts / C_out");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     return deconv_all_run(ctx, K, T, C_raw, c_order, opts, C_out, S_out, kernel_pars_out, sn_out);
 }
 
@@ -1441,6 +1535,7 @@ int cnmfe_deconv_temporal_bound(cnmfe_ctx *ctx, const cnmfe_deconv_opts *opts, f
     if (!ctx) return fail(CNMFE_EINVAL, "null context");
     if (!opts) return fail(CNMFE_EINVAL, "null deconvolution options");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     return deconv_bound_run(ctx, opts, C_out, C_raw_out, S_out, kernel_pars_out, sn_out);
 }
 
@@ -1452,6 +1547,7 @@ int cnmfe_post_process_spatial(cnmfe_ctx *ctx, int32_t d1, int32_t d2, int32_t K
     if (K == 0) return 0;
     if ((!A_val && A_colptr[K] > 0) || !keep) return fail(CNMFE_EINVAL, "null A_val / keep");
     CK(hipSetDevice(ctx->device));
+    GlobalScope gs_(ctx); if (gs_.rc) return gs_.rc;          // (lanes: lane 0, behind the other lanes; they wait for what this queues)
     return postproc_run(ctx, d1, d2, K, A_colptr, A_rowidx, A_val, keep);
 }
 

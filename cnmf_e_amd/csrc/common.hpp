@@ -210,11 +210,14 @@ struct Patch {
     // what the next fit asks of W before it can queue anything (pmax of fit_ring_model.m:60, row 1 for the first-run test of :25), copied to
     // pinned memory behind the fit that produced W: the next fit reads it without draining the stream (ring_stats_*, api.hip)
     DevBuf stat_dev; void *stat_host = nullptr; hipEvent_t stat_ev = nullptr; bool stat_valid = false;
+    int lane = 0;                                          // the execution lane (stream + scratch set) of this patch's calls: cnmfe_ctx::activate, option "lanes"
     ~Patch() { if (stat_host) (void)hipHostFree(stat_host); if (stat_ev) (void)hipEventDestroy(stat_ev); }
 };
 
 // device scratch of the OASIS kernels (deconv.hip): pool / task tables, grown on demand and kept with the context
-struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf, tbuf; };
+struct DeconvScratch { DevBuf pv, pw, pt, pl, tkp, tko, tkl, tkv, pnum, list, ybuf, obuf, tbuf;
+    void swap(DeconvScratch &o) { DevBuf *a[] = {&pv, &pw, &pt, &pl, &tkp, &tko, &tkl, &tkv, &pnum, &list, &ybuf, &obuf, &tbuf}, *b[] = {&o.pv, &o.pw, &o.pt, &o.pl, &o.tkp, &o.tko, &o.tkl, &o.tkv, &o.pnum, &o.list, &o.ybuf, &o.obuf, &o.tbuf};
+        for (int i = 0; i < 13; ++i) a[i]->swap(*b[i]); } };
 
 // One patch's temporal update set up but not swept (cnmfe_hals_temporal_job): its projections, A'A lists and traces in buffers of its own, its
 // Gauss-Seidel level schedule on the host.  cnmfe_temporal_jobs_sweep then runs level l of EVERY job of the context in one launch -- the patches of a
@@ -261,6 +264,7 @@ struct PinArena {
         }
         void *r = p + off; off += n; return r;
     }
+    void swap(PinArena &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(off, o.off); std::swap(half, o.half); for (int i = 0; i < 2; ++i) { std::swap(ev[i], o.ev[i]); std::swap(ev_set[i], o.ev_set[i]); } }
     ~PinArena() { if (p) (void)hipHostFree(p); for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]); }
 };
 }  // namespace cnmfe
@@ -275,6 +279,24 @@ constexpr int PIN_NSEG = 24;
 constexpr int I8_SEG_FRAMES = 24576;
 struct PinSegs { const uint4 *src[PIN_NSEG]; uint4 *dst[PIN_NSEG]; unsigned n16[PIN_NSEG]; };
 }  // namespace cnmfe
+
+// Execution lanes (option "lanes", round 6).  The patches of a rank are independent inside each of the three updates (the reference's parfor), and most of a small
+// patch's kernels are a few workgroups with 8-10 us of dispatch latency between two dependent ones: on ONE stream sixteen 128 x 128 patches leave the chip idle for a
+// sixth of the iteration.  A lane is a stream + a full set of the context's per-call scratch (+ its own pinned upload arena and held-back uploads); a patch belongs to
+// lane (creation order) mod lanes, every call with a patch id ACTIVATES the patch's lane first (get_patch), and the members below are swapped in and out of the
+// context, so that no code path knows about lanes.  Calls without a patch id that touch what all patches share (the bound traces, the stitch accumulator, the
+// temporal jobs' sweep, post-processing) run on lane 0 after lane 0 has been made to wait for the other lanes (join), and leave an event the other lanes wait for
+// at their next activation (fork) -- cnmfe::GlobalScope.  lanes = 1 (the default): none of this does anything.
+struct cnmfe_lane {
+    hipStream_t stream_ = nullptr; cnmfe::PinSegs pseg{}; int npseg = 0; cnmfe::PinArena pin; int64_t spatial_nnz = -1;
+    cnmfe::DevBuf vp[32]; size_t hw_vp[32] = {}; int64_t last_ldc = 0;
+    cnmfe::DevBuf ysig_low, up_tmp, bgs_r, bgs_b, bgs_upr, bgs_upc; int bgs_patch = -1, bgs_d1s = 0; int64_t bgs_dF = 0;
+    cnmfe::DevBuf bf, dig_smax, dig_rspart, dig_scale, tdig, tscale, gk, win_items, bf2, outl_cnt, outl_sel, cov, rowsum, tmp[16];
+    size_t hw_cc = 0, hw_cm = 0, hw_wa[3] = {0, 0, 0};
+    cnmfe::DevBuf inc[7], stg[4], wcodes, solve_fill, stage, scr[24]; cnmfe::DeconvScratch dscr;
+    hipEvent_t ev = nullptr; int64_t fork_seen = 0; bool dirty = false;      // (these three describe the lane itself and are never swapped)
+    ~cnmfe_lane() { if (stream_) (void)hipStreamDestroy(stream_); if (ev) (void)hipEventDestroy(ev); }
+};
 
 struct cnmfe_ctx {
     int device = 0;
@@ -339,6 +361,13 @@ struct cnmfe_ctx {
     std::map<std::string, int64_t> opts;
     int trace_level = 0;                                   // opts["host_trace"], read by every LAUNCH
     int64_t opt(const char *n, int64_t dflt) const { auto it = opts.find(n); return it == opts.end() ? dflt : it->second; }
+    // lanes (see cnmfe_lane): lanes[k] holds lane k's members while another lane is active; empty = one lane
+    std::vector<cnmfe_lane *> lanes; int cur_lane = 0, patches_created = 0, spatial_lane = 0;
+    hipEvent_t ev_fork = nullptr; int64_t fork_gen = 0;
+    void swap_lane(cnmfe_lane &L);                         // api.hip
+    int activate(int lane);                                // api.hip: make `lane` the active one (its stream behind st(), its scratch behind the members)
+    int join_lanes();                                      // api.hip: lane 0 active and waiting for everything the other lanes have been given
+    int fork_mark();                                       // api.hip: the other lanes wait for what lane 0 has been given up to here, at their next activation
     ~cnmfe_ctx();
 };
 
@@ -355,7 +384,20 @@ struct HostTrace {
         last = t;
     }
 };
-inline Patch *get_patch(cnmfe_ctx *ctx, int id) { auto it = ctx->patches.find(id); return it == ctx->patches.end() ? nullptr : it->second; }
+// (a call with a patch id runs on the patch's lane: its stream and its scratch are the context's from here on)
+inline Patch *get_patch(cnmfe_ctx *ctx, int id) {
+    auto it = ctx->patches.find(id);
+    if (it == ctx->patches.end()) return nullptr;
+    if (!ctx->lanes.empty() && ctx->activate(it->second->lane) != 0) return nullptr;
+    return it->second;
+}
+// a call WITHOUT a patch id that reads or writes what the patches share: lane 0, behind everything the other lanes were given; what it queues is waited for by
+// the other lanes' next calls
+struct GlobalScope {
+    cnmfe_ctx *ctx; int rc = 0;
+    explicit GlobalScope(cnmfe_ctx *c) : ctx(c) { if (ctx && !ctx->lanes.empty()) rc = ctx->join_lanes(); }
+    ~GlobalScope() { if (ctx && !ctx->lanes.empty()) (void)ctx->fork_mark(); }
+};
 int pinned_to_dev(cnmfe_ctx *ctx, void *dst, const void *src_pinned, size_t bytes);   // api.hip
 void pin_register(cnmfe_ctx *ctx, bool live);
 // upload a host vector to a DevBuf on the context stream

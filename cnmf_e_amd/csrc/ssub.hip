@@ -247,7 +247,7 @@ int ssub_derive(cnmfe_ctx *ctx, Patch *S, int dst_id, int ssub, int mode) {
     int d1s, d2s; low_dims(S, ssub, d1s, d2s);
     if (ctx->patches.count(dst_id)) { delete ctx->patches[dst_id]; ctx->patches.erase(dst_id); }
     Patch *P = new Patch();
-    P->derived = true;
+    P->derived = true; P->lane = S->lane;                   // (the low-resolution patches run on their source's lane: the calls that name two of them see one scratch set)
     const int32_t rect[4] = {1, d1s, 1, d2s};
     memcpy(P->prect, rect, sizeof(rect)); memcpy(P->brect, rect, sizeof(rect));
     P->d1 = d1s; P->d2 = d2s; P->T = S->T; P->Tc = S->Tc;

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=1); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--patch", type=int, default=512)
-ap.add_argument("--steps", type=int, default=4); ap.add_argument("--force-collectives", action="store_true"); ap.add_argument("--c5", action="store_true", help="configs[4]: 1024 x 1024 x 20000, K = 2000 (use with --world 8 --patch 128: 8 of 64 patches)")
+ap.add_argument("--lanes", type=int, default=1); ap.add_argument("--steps", type=int, default=4); ap.add_argument("--force-collectives", action="store_true"); ap.add_argument("--c5", action="store_true", help="configs[4]: 1024 x 1024 x 20000, K = 2000 (use with --world 8 --patch 128: 8 of 64 patches)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -15,6 +15,8 @@ from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
 d1, d2, T, K, r = (1024, 1024, 20000, 2000, 15) if a.c5 else (512, 512, 10000, 500, 15)
 f = synth.make_factors(d1, d2, T, K, 5 if a.c5 else 2)
 eng = Engine(0)
+if a.lanes > 1:
+    eng.set_option("lanes", a.lanes)
 video = PatchedVideo(d1, d2, T, [a.patch, a.patch], r, eng, rank=a.rank, world_size=a.world)
 for idx in video.owned:
     Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()

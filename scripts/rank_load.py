@@ -5,7 +5,7 @@ import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--steps", type=int, default=6); ap.add_argument("--prof", default=""); ap.add_argument("--force-collectives", action="store_true", help="every collective branch of the three methods behind an RCCL group of ONE rank (the host side of the collectives, no second GPU)")
+ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--lanes", type=int, default=1); ap.add_argument("--steps", type=int, default=6); ap.add_argument("--prof", default=""); ap.add_argument("--force-collectives", action="store_true", help="every collective branch of the three methods behind an RCCL group of ONE rank (the host side of the collectives, no second GPU)")
 a = ap.parse_args()
 import torch
 from cnmf_e_amd import synth
@@ -14,6 +14,8 @@ from cnmf_e_amd.sources2d import PatchedVideo, Sources2D, Options
 d1, d2, T, K, r = 512, 512, 10000, 500, 15
 f = synth.make_factors(d1, d2, T, K, 2)
 eng = Engine(0)
+if a.lanes > 1:
+    eng.set_option("lanes", a.lanes)
 video = PatchedVideo(d1, d2, T, [128, 128], r, eng, rank=a.rank, world_size=a.world)
 for idx in video.owned:
     Yb = synth.make_video_device(f, "cuda:0", pixels=video.block_pix[idx]); torch.cuda.synchronize()
