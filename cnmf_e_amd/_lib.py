@@ -92,6 +92,9 @@ PROTOTYPES = {
     "cnmfe_copy_wait": (C.c_int, [c_ctx, C.c_int64]),
     "cnmfe_csc_select_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "cnmfe_csc_select_block_patch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "cnmfe_csc_bbox": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "cnmfe_set_noise": (C.c_int, [c_ctx, C.c_int, f32p]),
     "cnmfe_patch_derive": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int32, C.c_int]),
     "cnmfe_fit_ring_model_ssub": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, i64p, i32p, f32p, f32p, C.c_int,

@@ -1468,6 +1468,51 @@ int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const fl
     return 0;
 }
 
+// rows_of twice in one pass (sources2d.py, update_temporal_parallel: `ind = find(sum(A(block, :), 1) > 0)`, A(block, ind) and A(patch, ind) of one patch): the columns
+// are the candidates whose BLOCK entries sum to > 0, the second matrix holds the same columns' PATCH entries (a patch's pixels are block pixels)
+int cnmfe_csc_select_block_patch(const int64_t *colptr, const int32_t *rowidx, const float *val, const int32_t *lut_block, const int32_t *lut_patch, int64_t ncand,
+                                 const int64_t *cand, int64_t cap, int64_t *out_ind, int64_t *blk_colptr, int32_t *blk_rowidx, float *blk_val,
+                                 int64_t *pat_colptr, int32_t *pat_rowidx, float *pat_val, int64_t *nkept) {
+    if (!colptr || !rowidx || !val || !lut_block || !lut_patch || (ncand > 0 && !cand) || !out_ind || !blk_colptr || !pat_colptr || !nkept ||
+        (cap > 0 && (!blk_rowidx || !blk_val || !pat_rowidx || !pat_val))) return fail(CNMFE_EINVAL, "cnmfe_csc_select_block_patch: null argument");
+    int64_t nb = 0, np_ = 0, nc = 0;
+    blk_colptr[0] = 0; pat_colptr[0] = 0;
+    for (int64_t j = 0; j < ncand; ++j) {
+        const int64_t k = cand[j];
+        if (j > 0 && k <= cand[j - 1]) return fail(CNMFE_EINVAL, "cnmfe_csc_select_block_patch: columns must be ascending");
+        const int64_t nb0 = nb, np0 = np_;
+        double s = 0.0;
+        for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
+            const int32_t lb = lut_block[rowidx[e]];
+            if (lb < 0) continue;
+            if (nb >= cap) return fail(CNMFE_EINVAL, "cnmfe_csc_select_block_patch: output capacity %lld exceeded", (long long)cap);
+            blk_rowidx[nb] = lb; blk_val[nb] = val[e]; s += (double)val[e]; ++nb;
+            const int32_t lp = lut_patch[rowidx[e]];
+            if (lp >= 0) { pat_rowidx[np_] = lp; pat_val[np_] = val[e]; ++np_; }
+        }
+        if (s > 0.0) { out_ind[nc] = k; ++nc; blk_colptr[nc] = nb; pat_colptr[nc] = np_; }
+        else { nb = nb0; np_ = np0; }
+    }
+    *nkept = nc;
+    return 0;
+}
+
+// per non-empty column of a sorted CSC footprint matrix over a d1-row image: its index and the bounding box of its entries (image rows / columns, 0-based)
+int cnmfe_csc_bbox(int32_t K, int32_t d1, const int64_t *colptr, const int32_t *rowidx, int64_t *nz, int32_t *rmin, int32_t *rmax, int32_t *cmin, int32_t *cmax, int64_t *nnz_cols) {
+    if (K < 0 || d1 <= 0 || !colptr || (colptr[K] > 0 && !rowidx) || !nnz_cols || (K > 0 && (!nz || !rmin || !rmax || !cmin || !cmax))) return fail(CNMFE_EINVAL, "cnmfe_csc_bbox: bad argument");
+    int64_t n = 0;
+    for (int32_t k = 0; k < K; ++k) {
+        const int64_t a = colptr[k], b = colptr[k + 1];
+        if (b <= a) continue;
+        int32_t lo = INT32_MAX, hi = -1;
+        for (int64_t e = a; e < b; ++e) { const int32_t r = rowidx[e] % d1; lo = std::min(lo, r); hi = std::max(hi, r); }
+        nz[n] = k; rmin[n] = lo; rmax[n] = hi; cmin[n] = rowidx[a] / d1; cmax[n] = rowidx[b - 1] / d1;      // (entries ascend in pixel index = image column major)
+        ++n;
+    }
+    *nnz_cols = n;
+    return 0;
+}
+
 int cnmfe_stitch_temporal(cnmfe_ctx *const *ctxs, int n, int subtract_min, float *C_raw_out, int c_order) {
     if (!ctxs || n <= 0) return fail(CNMFE_EINVAL, "no contexts");
     for (int i = 0; i < n; ++i) {

@@ -306,6 +306,51 @@ def _select_rows_native(A, lut, nloc, cand, keep_all):
     return ind[:nk], _csc_fast(oval[:n], orow[:n], optr[:nk + 1], (nloc, nk))
 
 
+def _select_block_patch_native(A, lut_b, nb, lut_p, npx, cand):
+    """(ind, A(block, ind), A(patch, ind)) in ONE pass of the library's host helper cnmfe_csc_select_block_patch -- what two rows_of calls give (the temporal update asks
+    for both per patch, update_temporal_parallel.m:83-91, on the spatial -> temporal hand-over where the device waits for the host); None when the helper cannot run"""
+    if A.indices.dtype != np.int32 or A.data.dtype != np.float32 or lut_b.dtype != np.int32 or lut_p.dtype != np.int32:
+        return None
+    try:
+        fn = L.lib.cnmfe_csc_select_block_patch
+    except (ImportError, OSError, AttributeError):
+        return None
+    indptr = A.indptr if A.indptr.dtype == np.int64 else A.indptr.astype(np.int64)
+    cand = np.ascontiguousarray(cand, dtype=np.int64)
+    nc = int(cand.size)
+    cap = int((indptr[cand + 1] - indptr[cand]).sum()) if nc else 0
+    ind = np.empty(nc, dtype=np.int64); bptr = np.empty(nc + 1, dtype=np.int64); pptr = np.empty(nc + 1, dtype=np.int64)
+    brow = np.empty(max(cap, 1), dtype=np.int32); bval = np.empty(max(cap, 1), dtype=np.float32)
+    prow = np.empty(max(cap, 1), dtype=np.int32); pval = np.empty(max(cap, 1), dtype=np.float32)
+    nk = ctypes.c_int64(0)
+    rc = fn(indptr.ctypes.data, A.indices.ctypes.data, A.data.ctypes.data, lut_b.ctypes.data, lut_p.ctypes.data, nc, cand.ctypes.data, cap,
+            ind.ctypes.data, bptr.ctypes.data, brow.ctypes.data, bval.ctypes.data, pptr.ctypes.data, prow.ctypes.data, pval.ctypes.data, ctypes.byref(nk))
+    if rc != 0:
+        raise ValueError(L.lib.cnmfe_last_error().decode())
+    nk = nk.value
+    n_b, n_p = int(bptr[nk]), int(pptr[nk])
+    return ind[:nk], _csc_fast(bval[:n_b], brow[:n_b], bptr[:nk + 1], (nb, nk)), _csc_fast(pval[:n_p], prow[:n_p], pptr[:nk + 1], (npx, nk))
+
+
+def _bbox_native(A, d1):
+    """(non-empty columns, first / last image row, first / last image column) of a sorted int32 CSC footprint matrix by cnmfe_csc_bbox; None when the helper cannot run"""
+    if A.indices.dtype != np.int32 or not A.has_sorted_indices:
+        return None
+    try:
+        fn = L.lib.cnmfe_csc_bbox
+    except (ImportError, OSError, AttributeError):
+        return None
+    K = A.shape[1]
+    indptr = A.indptr if A.indptr.dtype == np.int64 else A.indptr.astype(np.int64)
+    nz = np.empty(max(K, 1), dtype=np.int64); box = np.empty((4, max(K, 1)), dtype=np.int32)
+    n = ctypes.c_int64(0)
+    rc = fn(int(K), int(d1), indptr.ctypes.data, A.indices.ctypes.data, nz.ctypes.data, box[0].ctypes.data, box[1].ctypes.data, box[2].ctypes.data, box[3].ctypes.data, ctypes.byref(n))
+    if rc != 0:
+        raise ValueError(L.lib.cnmfe_last_error().decode())
+    n = n.value
+    return nz[:n], box[0, :n], box[1, :n], box[2, :n], box[3, :n]
+
+
 def _select_rows_numpy(A, lut, nloc, cand, keep_all):
     """the same selection with index arithmetic (a scipy column slice costs more than the data it moves here)"""
     K = A.shape[1]
@@ -636,14 +681,32 @@ class Sources2D:
                 cand = nz[(rmax >= r0) & (rmin <= r1) & (cmax >= c0) & (cmin <= c1)]
         return rows_of(A, t, n, cols=cols, span=span, cand=cand)
 
+    def _slice_block_patch(self, A, idx):
+        """(ind, A(block, ind), A(patch, ind)) = _slice(A, idx, "block") followed by _slice(A, idx, "patch", cols=ind), in one pass over the candidates"""
+        if sp.isspmatrix_csc(A) and A.has_sorted_indices:
+            bb = self._bbox_of(A)
+            if bb is not None:
+                v = self.video
+                tb, nb, _ = v.lut(idx, "block"); tp, npx, _ = v.lut(idx, "patch")
+                r0, r1, c0, c1 = [int(x) - 1 for x in v.block_pos[idx]]
+                nz, rmin, rmax, cmin, cmax = bb
+                got = _select_block_patch_native(A, tb, nb, tp, npx, nz[(rmax >= r0) & (rmin <= r1) & (cmax >= c0) & (cmin <= c1)])
+                if got is not None:
+                    return got
+        ind, A_blk = self._slice(A, idx, "block")
+        return ind, A_blk, (self._slice(A, idx, "patch", cols=ind)[1] if ind.size else None)
+
     def _bbox_of(self, A):
         """(non-empty columns, their first / last image row and column), cached for the last few matrices by identity"""
         cache = self.__dict__.setdefault("_bbox_cache", [])
         for M, bb in cache:
             if M is A:
                 return bb
-        nz = np.nonzero(np.diff(A.indptr) > 0)[0]
-        if nz.size == 0:
+        bb = _bbox_native(A, self.video.d1)
+        nz = np.nonzero(np.diff(A.indptr) > 0)[0] if bb is None else None
+        if bb is not None:
+            pass
+        elif nz.size == 0:
             bb = (nz, nz, nz, nz, nz)
         else:
             d1 = self.video.d1
@@ -1306,15 +1369,14 @@ class Sources2D:
                 A_pp = A_csc if ind.size == K else A_csc[:, ind]
                 self._cur_blocks[idx] = (ind, A_pp)
             else:
-                # (ind, A(block, ind)): also what the next background update fits against (update_background_parallel.m:128-130)
-                ind, A_blk = self._cur_blocks[idx] = self._slice(self.A, idx, "block")               # :83
+                # (ind, A(block, ind)): also what the next background update fits against (update_background_parallel.m:128-130); A(patch, ind) in the same pass
+                ind, A_blk, A_pp = self._slice_block_patch(self.A, idx)                              # :83, A_patch(ind_patch,:)
+                self._cur_blocks[idx] = (ind, A_blk)
             if ind.size == 0:
                 continue                                                                              # :123
             if not launched and not self._temporal_residual_done(idx):
                 self._residual(idx, A_prev_b if indp.size else None, C_prev_b)          # :149-152
             C_patch = self._rows(self.C, ind)                                                        # :86
-            if not whole:
-                A_pp = self._slice(self.A, idx, "patch", cols=ind)[1]                                  # A_patch(ind_patch,:)
             if not use_c_hat:                                                                         # :174-175
                 eng.fast_temporal(v.pid[idx], A_pp, want_raw=False)
             elif batch:

@@ -334,6 +334,14 @@ int cnmfe_csc_select_rows(const int64_t *colptr, const int32_t *rowidx, const fl
 /* host helper: the CSC matrix (ncol columns) without its stored zeros -- and, with keep != NULL, without the entries whose flag is 0 (the connectivity
  * flags of cnmfe_update_spatial_fetch_connected).  A spatial update returns values on the search mask's pattern, most of them zero; MATLAB's sparse
  * matrices drop them on assignment (update_spatial_parallel.m:324-334).  Outputs sized for nnz(in) always suffice; *nnz_out = entries written. */
+/* sources2d.py rows_of twice in one pass (update_temporal_parallel.m:83-91: ind = find(sum(A(block,:),1) > 0), A(block, ind), A(patch, ind)): the candidates whose
+ * BLOCK entries sum to > 0 as out_ind, their block entries (local rows lut_block) and their patch entries (lut_patch) as two CSC matrices over the same columns */
+int cnmfe_csc_select_block_patch(const int64_t *colptr, const int32_t *rowidx, const float *val, const int32_t *lut_block, const int32_t *lut_patch, int64_t ncand,
+                                 const int64_t *cand, int64_t cap, int64_t *out_ind, int64_t *blk_colptr, int32_t *blk_rowidx, float *blk_val,
+                                 int64_t *pat_colptr, int32_t *pat_rowidx, float *pat_val, int64_t *nkept);
+/* the non-empty columns of a sorted CSC footprint matrix over a d1-row image and the bounding boxes of their entries (0-based image rows / columns): the prefilter
+ * of the mask selections of update_*_parallel.m (a neuron whose box misses a patch's block cannot be selected there) */
+int cnmfe_csc_bbox(int32_t K, int32_t d1, const int64_t *colptr, const int32_t *rowidx, int64_t *nz, int32_t *rmin, int32_t *rmax, int32_t *cmin, int32_t *cmax, int64_t *nnz_cols);
 int cnmfe_csc_drop_zeros(int32_t ncol, const int64_t *colptr, const int32_t *rowidx, const float *val, const uint8_t *keep,
                          int64_t *out_colptr, int32_t *out_rowidx, float *out_val, int64_t *nnz_out);
 
@@ -428,6 +436,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  *   proj_tiled / proj_i8   default 1 / 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes (needs win_i8), else out of a copy of
  *                     the centred video in its own read order (one video's worth either, same rule); 0 / 0: the frame-major video on the fp64 pipe.  The tables over ALL frames
  *                     (spatial update, temporal projection) sum inside frame segments of at most 24576 frames, recordings up to 16 x 24576 frames
+ *   lanes             default 1; 2 .. 4 (set BEFORE the first patch is created): the patches alternate between that many execution lanes -- a HIP stream + a set of the
+ *                     context's scratch each -- so that the small kernels of independent patches overlap (update_*_parallel.m: parfor); calls on what the patches share
+ *                     (bound traces, stitch, the temporal jobs' sweep, post-processing) join the lanes.  Results are bit-equal to lanes = 1 (tests/test_gpu_lanes.py)
  *   prealloc          default 1: cnmfe_fit_reserve may allocate the fit's large buffers ahead of the first fit
  * A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.
  * Diagnostics (scripts/): solve_probe, r1_probe (phase probes: results are NOT the product's), deconv_trace, host_trace (1: host-side phase times of every call on

@@ -155,3 +155,45 @@ def test_native_drop_zeros_equals_eliminate_zeros():
         ref = sp.csc_matrix((v * (1 if kp is None else kp), iri.copy(), icp.copy()), shape=(d, K)); ref.eliminate_zeros()
         assert n.value == ref.nnz
         assert np.array_equal(optr, ref.indptr) and np.array_equal(orow[:n.value], ref.indices) and np.array_equal(oval[:n.value], ref.data)
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_fused_block_patch_selection_and_native_boxes(seed):
+    """cnmfe_csc_select_block_patch = rows_of(block) then rows_of(patch, cols=ind) (update_temporal_parallel.m:83-91); cnmfe_csc_bbox = the NumPy boxes of _bbox_of"""
+    from cnmf_e_amd import sources2d as S
+    rng = np.random.default_rng(seed)
+    d1, d2, K = 40, 36, 30
+    d = d1 * d2
+    rows, cols, vals = [], [], []
+    for k in range(K):
+        if k % 7 == 3:
+            continue
+        r0, c0 = rng.integers(0, d1 - 6), rng.integers(0, d2 - 6)
+        rr, cc = np.meshgrid(np.arange(r0, r0 + 6), np.arange(c0, c0 + 6), indexing="ij")
+        v = rng.standard_normal(36).astype(np.float32)
+        v[rng.random(36) < 0.3] = 0.0
+        if k % 5 == 0:
+            v = -np.abs(v)
+        rows.append((cc * d1 + rr).ravel()); cols.append(np.full(36, k)); vals.append(v)
+    A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(d, K), dtype=np.float32)
+    A.sort_indices()
+    def lut_of(r0, r1, c0, c1):
+        rr, cc = np.meshgrid(np.arange(r0, r1), np.arange(c0, c1), indexing="ij")
+        pix = np.sort((cc * d1 + rr).ravel())
+        t = np.full(d, -1, dtype=np.int32); t[pix] = np.arange(pix.size, dtype=np.int32)
+        return t, pix.size
+    (tb, nb), (tp, npx) = lut_of(5, 32, 4, 28), lut_of(10, 27, 9, 23)
+    every = np.nonzero(np.diff(A.indptr) > 0)[0]
+    for cand in (every, every[::2], np.zeros(0, dtype=np.int64)):
+        got = S._select_block_patch_native(A, tb, nb, tp, npx, cand)
+        assert got is not None
+        ind, Ab = S._select_rows_numpy(A, tb, nb, np.asarray(cand, dtype=np.int64), False)
+        _, Ap = S._select_rows_numpy(A, tp, npx, ind, True)
+        assert np.array_equal(got[0], ind)
+        for M, R in ((got[1], Ab), (got[2], Ap)):
+            assert M.shape == R.shape and np.array_equal(M.indptr, R.indptr) and np.array_equal(M.indices, R.indices) and np.array_equal(M.data, R.data)
+    nz, rmin, rmax, cmin, cmax = S._bbox_native(A, d1)
+    assert np.array_equal(nz, every)
+    for j, k in enumerate(every):
+        r = A.indices[A.indptr[k]:A.indptr[k + 1]]
+        assert (rmin[j], rmax[j], cmin[j], cmax[j]) == ((r % d1).min(), (r % d1).max(), (r // d1).min(), (r // d1).max())
