@@ -298,7 +298,8 @@ def main():
     eng = Engine(local)
     # several patches per rank: their calls alternate between two execution lanes (streams + scratch sets, cnmfe_set_option "lanes") -- small patches' kernels are
     # a few workgroups each with a dispatch latency between two dependent ones; CNMFE_BENCH_LANES=1 gives the one-stream figure
-    lanes = int(os.environ.get("CNMFE_BENCH_LANES", "2" if sharded_fov else "1"))
+    per_rank = 1 if not sharded_fov else -(-(-(-d1 // PATCHES[a.config][0]) * -(-d2 // PATCHES[a.config][1])) // (SHARD_OF.get(a.config, 0) or world))
+    lanes = int(os.environ.get("CNMFE_BENCH_LANES", str(max(1, min(3, per_rank)))))      # (three lanes measured best for 8 - 16 patches on one GPU, profiles/r06/lanes.txt)
     if lanes > 1:
         eng.set_option("lanes", lanes)
     shard_of = SHARD_OF.get(a.config, 0)

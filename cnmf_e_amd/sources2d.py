@@ -1170,7 +1170,9 @@ class Sources2D:
             from . import hostops
             self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)
         self._update_b0_new()                                                                        # :347-351
-        self._prefetch_search_location()
+        # (several patches: the mask thread is NOT started here -- its Python would share the GIL with the temporal update's set-up, on the hand-over where the device
+        # waits for the host (0.4 ms of a rank's 4.3 at c4); update_temporal_parallel starts it under its sweep call, update_background_parallel otherwise)
+        self._prefetch_wanted = True
 
     def _post_process(self, A_):
         """obj.post_process_spatial() (:341) works on whole footprints, which only exist after the gather.  Sharded, every rank holds the whole gathered A and
@@ -1388,6 +1390,9 @@ class Sources2D:
                 eng.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False, want_raw=False)  # :180-181
             eng.stitch_add(ind)                                                                       # :274-275
         if jobs:
+            if getattr(self, "_prefetch_wanted", False):
+                self._prefetch_wanted = False
+                self._prefetch_search_location()                           # host thread under the (GIL-free) sweep / stitch / fit calls that follow
             eng.temporal_jobs_sweep()
             for job, ind in jobs:
                 eng.stitch_add_job(job, ind)                                                          # :274-275

@@ -34,7 +34,8 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-eng.profile(True); eng.profile_reset()
+# timed WITHOUT per-launch events (a pair of events costs host and device time at every one of ~170 launches: what a run pays is the loop below); the kernel sums
+# come from extra steps with the events on
 if a.prof:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
@@ -47,7 +48,14 @@ if a.prof:
         pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(90); pstats.Stats(pr, stream=fh).sort_stats("tottime").print_stats(60)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
+eng.profile(True); eng.profile_reset()
+nprof = 6
+t1 = time.perf_counter()
+for _ in range(nprof):
+    step()
+torch.cuda.synchronize()
+dtp = (time.perf_counter() - t1) / nprof
 tab = eng.profile_table()
-print("rank %d of %d (%d patches)%s: %.2f ms / iteration; host time in calls: bg %.2f spatial %.2f temporal %.2f ms; kernel sum %.2f ms" % (
-    a.rank, a.world, len(video.owned), " with the collectives of a group of one" if group is not None else "", 1e3 * dt, *(1e3 * parts / a.steps), sum(v["total_ms"] for v in tab.values()) / a.steps))
-print({k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["total_ms"])[:14]})
+print("rank %d of %d (%d patches, %d lane(s))%s: %.2f ms / iteration (%.2f with events around every launch); host time in calls: bg %.2f spatial %.2f temporal %.2f ms; kernel sum %.2f ms" % (
+    a.rank, a.world, len(video.owned), a.lanes, " with the collectives of a group of one" if group is not None else "", 1e3 * dt, 1e3 * dtp, *(1e3 * parts / a.steps), sum(v["total_ms"] for v in tab.values()) / nprof))
+print({k: round(v["total_ms"] / nprof, 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["total_ms"])[:14]})
