@@ -748,7 +748,7 @@ def main():
     if world == 1 and a.config == "c3" and not a.no_extras and not a.weak and a.bg_ssub == 1 and not a.deconv and a.alg == "hals":
         # the N = 1 point of the strong-scaling curve (`--gpus N` runs configs[3] = this video in 4 x 4 patches): all 16 patches on this one GPU
         try:
-            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "6", "--warmup", "5", "--no-cpu-baseline", "--no-extras"],
                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
             c4 = json.loads(r_.stdout.decode().strip().splitlines()[-1])
             out["c4_n1"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "kernel_sum_ms_per_step")}

@@ -228,6 +228,7 @@ struct TemporalJob {
     DevBuf dC, dColptr, dErow, dAval, dU, dCraw, dNk, dNidx, dNval, dNptr, dAa, dOvf, dS, dPars, dSn, dB;
     std::vector<std::vector<int>> levels;
     bool swept = false;
+    bool dag = false;                                      // `levels` are the levels of the dependency graph over the items of all maxIter sweeps (factor.hip, dag_schedule)
     // A'A of the job comes back into pinned memory WITHOUT a wait in cnmfe_hals_temporal_job (the host goes on to the next patch); the sweep call waits once
     // for all jobs and finishes each: aa = diag(A'A) against the host-side column test, the projection again if a footprint term overflowed its list
     std::vector<int> diag; std::vector<char> upd; bool term_applied = false, finished = false; int nn = 0;

@@ -638,6 +638,10 @@ __global__ void __launch_bounds__(DECONV_NT) k_deconv(DeconvCfg c, DeconvIO io) 
         io.C = j.C; io.Craw = j.Craw; io.S = j.S; io.ldc = j.ldc; io.U = j.U; io.nptr = j.nptr; io.nidx = j.nidx; io.nval = j.nval; io.aa = j.aa;
         io.pars = j.pars; io.sn_out = j.sn_out; io.b_out = j.b_out;
     } else k = io.list[slot];
+    // bit 30 of a list entry: this item belongs to the LAST sweep of the update (HALS_temporal.m:99-102 keeps S and C_raw of that one) -- the sweeps of one update are
+    // scheduled as ONE dependency graph over (sweep, trace) items (factor.hip, dag_schedule), so a launch can hold items of different sweeps
+    c.last |= __builtin_amdgcn_readfirstlane(k >> 30) & 1;
+    k &= 0x3fffffff;
     const int Tal = (T + 3) & ~3;
     float *y = LONG ? io.ybuf + (int64_t)blockIdx.x * Tal : sm;          // T raw samples (fp32), persistent
     float *scr = LONG ? sm : sm + Tal;               // scratch: select histogram | FFT re, im, twiddles, window (4 nfft) | top of the OASIS pool stack
@@ -1097,8 +1101,9 @@ int temporal_deconv_sweeps(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, int64
     DeconvIO io;
     io.C = dC; io.Craw = dCraw; io.S = dS; io.ldc = ldc; io.U = dU; io.nptr = dNptr; io.nidx = dNidx; io.nval = dNval; io.aa = dAa;
     io.pars = dPars; io.sn_out = dSn; io.b_out = dB.as<float>();
-    for (int it = 0; it < maxIter; ++it) {
-        c.last = it == maxIter - 1;
+    // maxIter < 0: `levels` are the levels of the dependency graph over the items of ALL sweeps (factor.hip, dag_schedule): one pass, the last sweep's items carry bit 30
+    for (int it = 0; it < (maxIter < 0 ? 1 : maxIter); ++it) {
+        c.last = maxIter >= 0 && it == maxIter - 1;
         for (size_t l = 0; l < levels.size(); ++l)
             RET(deconv_launch(ctx, c, shmem, io, dLvl + off[l], (int)levels[l].size(), scr));
     }
@@ -1121,8 +1126,8 @@ int temporal_deconv_sweeps_jobs(cnmfe_ctx *ctx, const cnmfe_deconv_opts *dopts, 
     io.C = io.Craw = io.S = nullptr; io.ldc = 0; io.U = nullptr; io.nptr = io.nidx = nullptr; io.nval = io.aa = nullptr; io.pars = io.sn_out = io.b_out = nullptr;
     io.jobs = dTab.as<DeconvJobDev>();
     const size_t nlev = off.size() - 1;
-    for (int it = 0; it < maxIter; ++it) {
-        c.last = it == maxIter - 1;
+    for (int it = 0; it < (maxIter < 0 ? 1 : maxIter); ++it) {          // (maxIter < 0: the graph's levels over all sweeps, as temporal_deconv_sweeps)
+        c.last = maxIter >= 0 && it == maxIter - 1;
         for (size_t l = 0; l < nlev; ++l) {
             io.jlist = dList + off[l];
             RET(deconv_launch(ctx, c, shmem, io, nullptr, off[l + 1] - off[l], ctx->dscr));

@@ -478,6 +478,32 @@ static void build_graph(int K, const HostCSR &csr, int64_t nrow, const std::vect
     for (int k = 0; k < K; ++k) if (include[k]) g.levels[lvl[k]].push_back(k);
 }
 
+// The maxIter Gauss-Seidel sweeps of ONE update as one dependency graph over (sweep, neuron) items (option sweep_dag, default 1).  HALS_spatial.m:36-44 /
+// HALS_temporal.m:59-68 visit k = 1..K maxIter times; item (s, k) reads the rows of k's neighbours -- sweep s values of the lower-indexed ones, sweep s - 1 values of the
+// higher-indexed ones -- and writes row k.  Its predecessors are therefore (s, j) for neighbours j < k, (s - 1, j) for neighbours j > k and (s - 1, k); the
+// anti-dependencies are edges of the same kind ((s, k) -> (s, j) for j > k, (s, k) -> (s + 1, j) for j < k), so ANY order that respects the graph computes what the
+// sequential loops compute, bit for bit.  A level-synchronous schedule launches maxIter x (levels of a sweep) times; the graph's depth is less whenever the chains of
+// different sweeps do not line up (512 x 512, K = 500: 22 instead of 30) -- and a launch of the in-sweep deconvolution lasts as long as one trace's serial OASIS
+// whatever the number of traces in it.  flag_last: bit 30 marks the items of the last sweep (the deconvolution keeps S and C_raw of that one, k_deconv).
+static void dag_schedule(int K, const PairGraph &g, const std::vector<char> &include, int maxIter, bool flag_last, std::vector<std::vector<int>> &dag) {
+    std::vector<std::vector<int>> upper(K);
+    for (int k = 0; k < K; ++k) for (int a : g.lower[k]) upper[a].push_back(k);
+    std::vector<int> prev(K, 0), cur(K, 0);                  // depth (1-based) of (s - 1, .) and (s, .); 0: no such item
+    dag.clear();
+    for (int s = 0; s < maxIter; ++s) {
+        for (int k = 0; k < K; ++k) {
+            if (!include[k]) { cur[k] = 0; continue; }
+            int m = prev[k];
+            for (int a : g.lower[k]) if (include[a]) m = std::max(m, cur[a]);
+            for (int b : upper[k]) if (include[b]) m = std::max(m, prev[b]);
+            cur[k] = m + 1;
+            if ((int)dag.size() < cur[k]) dag.resize(cur[k]);
+            dag[cur[k] - 1].push_back(k | ((flag_last && s == maxIter - 1) ? (1 << 30) : 0));
+        }
+        prev.swap(cur);
+    }
+}
+
 int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_t *A_colptr, const int32_t *A_rowidx,
                 const float *A_val, const float *C, int c_order, const int64_t *IND_colptr, const int32_t *IND_rowidx,
                 const float *sn, int32_t param, float *A_out) {
@@ -575,9 +601,11 @@ int spatial_run(cnmfe_ctx *ctx, Patch *P, int algorithm, int32_t K, const int64_
 #undef NNLS_GO
     } else {
         std::vector<int> flat; std::vector<int> off;
+        const bool dag_on = ctx->opt("sweep_dag", 1) != 0 && param > 1;
+        if (dag_on) { std::vector<std::vector<int>> dag; dag_schedule(K, g, include, (int)param, false, dag); g.levels.swap(dag); }
         for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
         RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
-        for (int it = 0; it < param; ++it)
+        for (int it = 0; it < (dag_on ? 1 : param); ++it)
             for (size_t l = 0; l < g.levels.size(); ++l)
                 LAUNCH(ctx, "spatial_hals_level", k_hals_spatial, dim3((unsigned)g.levels[l].size()), dim3(128), 0, dLvl.as<int>() + off[l],
                        dColptr.as<int64_t>(), dErow.as<int>(), dRptr.as<int>(), dRcol.as<int>(), dRsrc.as<int>(), dU.as<float>(), dV.as<float>(), K,
@@ -735,6 +763,8 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         for (int64_t e = A_colptr[k]; e < A_colptr[k + 1] && !upd[k]; ++e) upd[k] = A_val[e] * A_val[e] > 0.f;
     if (upd != nonempty) build_graph(K, csr, d, upd, g);     // (almost always the same set: a stored column without a non-zero value is rare -- reuse the graph above)
     std::vector<int> flat, off;
+    const bool dag_on = ctx->opt("sweep_dag", 1) != 0 && maxIter > 1;
+    if (dag_on) { std::vector<std::vector<int>> dag; dag_schedule(K, g, upd, maxIter, dopts != nullptr, dag); g.levels.swap(dag); }
     for (auto &l : g.levels) { off.push_back((int)flat.size()); flat.insert(flat.end(), l.begin(), l.end()); }
     if (!job) RET(to_dev(ctx, dLvl, flat.data(), flat.size()));
     ht.mark("csr + graph + lists + levels");
@@ -752,7 +782,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         if (term_applied) CK(hipMemcpyAsync(job->pin + nn, dOvf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
         job->P = P; job->K = K; job->ldc = ldc; job->T = T; job->maxIter = maxIter; job->deconv = dopts != nullptr; job->swept = false; job->finished = false;
         job->diag = std::move(diag); job->upd = std::move(upd); job->term_applied = term_applied;
-        job->levels = std::move(g.levels);
+        job->levels = std::move(g.levels); job->dag = dag_on;
         if (dopts) {
             job->dopts = *dopts;
             RET(job->dS.ensure((size_t)K * ldc * sizeof(float)));
@@ -780,7 +810,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
     RET(to_dev(ctx, dAa, aa.data(), aa.size()));
     ht.mark("level schedule");
     if (!dopts) {
-        for (int it = 0; it < maxIter; ++it)
+        for (int it = 0; it < (dag_on ? 1 : maxIter); ++it)
             for (size_t l = 0; l < g.levels.size(); ++l)
                 LAUNCH(ctx, "temporal_hals_level", k_hals_temporal, dim3((unsigned)g.levels[l].size()), dim3(T >= 2048 ? 1024 : 256), 0, dLvl.as<int>() + off[l], dNptr.as<int>(),
                        dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dU.as<float>(), dC.as<float>(), dCraw.as<float>(), ldc, T);
@@ -791,7 +821,7 @@ int temporal_run(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, c
         RET(to_dev(ctx, dPars, kernel_pars, (size_t)K));
         RET(dSn.ensure((size_t)K * sizeof(float)));
         CK(hipMemsetAsync(dSn.p, 0, (size_t)K * sizeof(float), ctx->st()));
-        RET(temporal_deconv_sweeps(ctx, dopts, T, K, maxIter, g.levels, dLvl.as<int>(), off, dC.as<float>(), dCraw.as<float>(), dS.as<float>(), ldc,
+        RET(temporal_deconv_sweeps(ctx, dopts, T, K, dag_on ? -1 : maxIter, g.levels, dLvl.as<int>(), off, dC.as<float>(), dCraw.as<float>(), dS.as<float>(), ldc,
                                    dU.as<float>(), dNptr.as<int>(), dNidx.as<int>(), dNval.as<float>(), dAa.as<float>(), dPars.as<float>(), dSn.as<float>()));
         // nothing asked back (the sharded-free update_temporal_parallel keeps C_raw and aa on the device for the stitch and re-estimates the time constants
         // in deconvTemporal): kernel_pars is then input only and the call returns with the sweeps in flight
@@ -849,7 +879,7 @@ int temporal_sweep_jobs(cnmfe_ctx *ctx) {
     const TemporalJob *j0 = jobs[0];
     size_t lmax = 0;
     for (auto *j : jobs) {
-        if (j->T != j0->T || j->maxIter != j0->maxIter || j->deconv != j0->deconv || (j->deconv && memcmp(&j->dopts, &j0->dopts, sizeof(j->dopts)) != 0))
+        if (j->T != j0->T || j->maxIter != j0->maxIter || j->deconv != j0->deconv || j->dag != j0->dag || (j->deconv && memcmp(&j->dopts, &j0->dopts, sizeof(j->dopts)) != 0))
             return fail(CNMFE_ESTATE, "the temporal jobs of one sweep must share T, maxIter and the deconvolution options");
         lmax = std::max(lmax, j->levels.size());
     }
@@ -872,14 +902,14 @@ int temporal_sweep_jobs(cnmfe_ctx *ctx) {
                               (CNMFE_GPTR(float))j->dCraw.as<float>(), j->ldc};
         }
         RET(to_dev(ctx, dTab, tab.data(), tab.size()));
-        for (int it = 0; it < j0->maxIter; ++it)
+        for (int it = 0; it < (j0->dag ? 1 : j0->maxIter); ++it)          // (dag: the levels ARE the items of all sweeps, dag_schedule)
             for (size_t l = 0; l < lmax; ++l) {
                 const int n = off[l + 1] - off[l];
                 if (n > 0)
                     LAUNCH(ctx, "temporal_hals_level", k_hals_temporal_jobs, dim3((unsigned)n), dim3(j0->T >= 2048 ? 1024 : 256), 0, dTab.as<HJobDev>(), dList.as<int2>() + off[l], j0->T);
             }
     } else {
-        RET(temporal_deconv_sweeps_jobs(ctx, &j0->dopts, j0->T, j0->maxIter, jobs, dList.as<int2>(), off, dTab));
+        RET(temporal_deconv_sweeps_jobs(ctx, &j0->dopts, j0->T, j0->dag ? -1 : j0->maxIter, jobs, dList.as<int2>(), off, dTab));
     }
     for (auto *j : jobs) j->swept = true;
     ht.mark("launches");

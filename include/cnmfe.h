@@ -439,6 +439,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  *   lanes             default 1; 2 .. 4 (set BEFORE the first patch is created): the patches alternate between that many execution lanes -- a HIP stream + a set of the
  *                     context's scratch each -- so that the small kernels of independent patches overlap (update_*_parallel.m: parfor); calls on what the patches share
  *                     (bound traces, stitch, the temporal jobs' sweep, post-processing) join the lanes.  Results are bit-equal to lanes = 1 (tests/test_gpu_lanes.py)
+ *   sweep_dag         default 1: the maxIter Gauss-Seidel sweeps of a HALS update (HALS_spatial.m:36-44, HALS_temporal.m:59-68, with or without the in-sweep
+ *                     deconvolution) are launched level by level of ONE dependency graph over (sweep, neuron) items -- the same reads and writes per item, equal results,
+ *                     fewer and fuller launches (512 x 512, K = 500: 21 instead of 25); 0: sweep after sweep, level by level (rounds 1-5)
  *   prealloc          default 1: cnmfe_fit_reserve may allocate the fit's large buffers ahead of the first fit
  * A deployment short of HBM sets win_i8 = proj_tiled = 0 (and solve_packed = 0) or leaves it to the engine, which falls back by itself.
  * Diagnostics (scripts/): solve_probe, r1_probe (phase probes: results are NOT the product's), deconv_trace, host_trace (1: host-side phase times of every call on
