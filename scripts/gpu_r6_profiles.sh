@@ -14,9 +14,9 @@ CNMFE_OPTS=ssub_virtual=0 python bench.py $X --bg-ssub 2 > $o/bench_c3_bg_ssub2_
 python bench.py $X --deconv > $o/bench_c3_deconv_$ver.json 2>/dev/null
 python bench.py $X --bg-ssub 2 --deconv --alg hals_thresh > $o/bench_c3_demo_defaults_$ver.json 2>/dev/null
 python bench.py $X --config c2 > $o/bench_c2_$ver.json 2>/dev/null
-python bench.py $X --config c4 --steps 5 > $o/bench_c4_n1_$ver.json 2>/dev/null
-python bench.py $X --config c5shard --steps 5 > $o/bench_c5shard_$ver.json 2>/dev/null
-python bench.py $X --config c5shard --steps 5 --deconv > $o/bench_c5shard_deconv_$ver.json 2>/dev/null
+python bench.py $X --config c4 --steps 10 --warmup 5 > $o/bench_c4_n1_$ver.json 2>/dev/null
+python bench.py $X --config c5shard --steps 5 --warmup 5 > $o/bench_c5shard_$ver.json 2>/dev/null
+python bench.py $X --config c5shard --steps 5 --warmup 5 --deconv > $o/bench_c5shard_deconv_$ver.json 2>/dev/null
 python bench.py $X --warmup 0 --steps 5 > $o/bench_c3_warmup0_$ver.json 2>/dev/null
 python bench.py $X --demo-sequence > $o/bench_c3_demo_sequence_$ver.json 2>/dev/null
 CNMFE_OPTS=r1_virtual=0 python bench.py $X > $o/bench_c3_swept_$ver.json 2>/dev/null
@@ -25,7 +25,11 @@ CNMFE_OPTS=solve_staged=0 python bench.py $X > $o/bench_c3_ab_solve_staged_off_$
 CNMFE_OPTS=proj_i8_planes=4 python bench.py $X > $o/bench_c3_ab_proj_planes4_$ver.json 2>/dev/null
 CNMFE_OPTS=solve_inv=1 python bench.py $X > $o/bench_c3_ab_solve_inv_on_$ver.json 2>/dev/null
 python scripts/probes/solve_inv/bench_loop.py --cfg c3 --steps 12 --mode 1 2>&1 | grep -v amdgpu.ids > $o/solve_inv_bench_loop_$ver.txt
-python scripts/rank_load.py > $o/rank_load_$ver.txt 2>&1
+# the round's last switches: the sweeps as one dependency graph (sweep_dag), the execution lanes
+CNMFE_OPTS=sweep_dag=0 python bench.py $X --deconv > $o/bench_c3_ab_deconv_sweep_dag_off_$ver.json 2>/dev/null
+CNMFE_BENCH_LANES=1 python bench.py $X --config c4 --steps 10 --warmup 5 > $o/bench_c4_n1_ab_one_lane_$ver.json 2>/dev/null
+CNMFE_BENCH_LANES=1 python bench.py $X --config c5shard --steps 5 --warmup 5 > $o/bench_c5shard_ab_one_lane_$ver.json 2>/dev/null
+( for l in 1 2; do for fc in "" "--force-collectives"; do python scripts/rank_load.py --world 8 --steps 30 --lanes $l $fc 2>&1 | grep -a "^rank\|^{" | cut -c1-700; done; done ) > $o/rank_load_$ver.txt 2>&1
 CNMFE_BENCH_FORCE_COLLECTIVES=1 python bench.py $X --config c4 --steps 10 --warmup 4 > $o/bench_c4_forced_collectives_$ver.json 2>/dev/null
 unset CNMFE_BENCH_R1
 bash scripts/profile_round.sh r06$ver > /dev/null 2>&1
