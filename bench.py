@@ -374,14 +374,6 @@ def main():
         warm_steps_ms.append(1e3 * (time.perf_counter() - tw0))
         if first_tab is None:
             first_tab = eng.profile_table()
-    # lanes that rotate through more patches than there are lanes: the scratch sets of the lanes reach their sizes over the first four iterations (a buffer that grows is
-    # freed and re-allocated, which drains the device: 30-35 ms instead of 21 per iteration at c4 with three lanes).  Part of the set-up like the upload: untimed steps up
-    # to five in all, reported as `settle_steps`
-    settle = max(0, 5 - a.warmup) if (lanes > 1 and per_rank > lanes and a.warmup > 0) else 0
-    for _ in range(settle):
-        step()
-    if settle:
-        fence()
     warm_tab = eng.profile_table()
     # timed region: HIP events only around the kernels a roofline is quoted for (an event pair around EVERY launch costs host and device time per
     # launch -- 8 ms per iteration with the ~2000 small launches of c4, ~1 % at c3); the per-kernel breakdown comes from EXTRA steps after it
@@ -687,7 +679,7 @@ def main():
         dlr = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
                "traffic": pmc_traffic("k_residual_delta"), "kernel": "residual_delta", "ms_per_launch": ms, "algorithmic_bytes_per_launch": by}
     out = {
-        "metric": "cnmfe_iters_per_sec" if not shard_of else "cnmfe_rank_share_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps": settle,
+        "metric": "cnmfe_iters_per_sec" if not shard_of else "cnmfe_rank_share_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak" if a.weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("%s: %dx%dx%d fp32 video, K=%d, ring_radius=%d, %dx%d patches of distribute_data.m (%d resident blocks per GPU), "

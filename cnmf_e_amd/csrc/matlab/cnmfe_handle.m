@@ -21,6 +21,12 @@ function eng = cnmfe_handle(obj, gpus)
     eng = struct('h', zeros(1, numel(gpus)), 'gpus', gpus, 'dims', [d1 d2 T], 'ssub', opt.bg_ssub);
     for g = 1:numel(gpus), eng.h(g) = cnmfe_mex('create', gpus(g)); end
     np = numel(md.patch_pos);
+    % several patches per context: their calls alternate between execution lanes (a HIP stream + a scratch set each, include/cnmfe.h option 'lanes'; set before the
+    % first patch) -- the parfor over patches of the three update methods as concurrent streams, the same values bit for bit
+    per_ctx = ceil(np / numel(gpus));
+    if per_ctx > 1
+        for g = 1:numel(gpus), cnmfe_mex('set_option', eng.h(g), 'lanes', min(3, per_ctx)); end
+    end
     eng.patch_pos = md.patch_pos;  eng.block_pos = md.block_pos;
     eng.owner = mod((0:np-1), numel(gpus)) + 1;          % context index of patch m
     eng.pid = 0:np-1;                                    % ids of the full-resolution patches; 2 low-resolution companions per patch behind them

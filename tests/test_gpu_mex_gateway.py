@@ -143,6 +143,7 @@ def test_the_gateway_runs_the_twins_sequence_and_agrees_with_the_python_host():
     h = float(mex("create", 0, nout=1)[0, 0])
     try:
         mex("set_option", h, "prealloc", 0)
+        mex("set_option", h, "lanes", 3)                                 # cnmfe_handle.m: several patches per context -> execution lanes (the Python reference run uses one)
         with pytest.raises(RuntimeError, match="unknown option"):
             mex("set_option", h, "no_such_option", 1)
         pid = {idx: float(i + 1) for i, idx in enumerate(geo.order)}
