@@ -364,6 +364,14 @@ int ctx_check_errflag(cnmfe_ctx *ctx) {
 // (A plain copy at record time + a clear at wait time reported one fault once per outstanding ticket -- every raise invalidating state the caller had rebuilt in
 //  between -- and the clear wiped faults raised behind the ticket.)
 __global__ void k_flag_take(int *__restrict__ flag, int *__restrict__ out) { *out = atomicExch(flag, 0); }
+// a ticket's download as ONE kernel: n16 x 16 bytes from device memory into PINNED host memory (mapped into the device's address space like the upload arena that
+// k_pin_copy reads), and the error word taken into the ticket's pinned slot.  Rounds 4-6 (first half) queued hipMemcpyAsync(device -> pinned) + k_flag_take + a
+// 4-byte hipMemcpyAsync: in the second to fourth iteration after an upload those copy calls BLOCKED the host for 0.4-0.7 ms each (one rank of eight at c4: an
+// iteration of 10 ms instead of 3.3; sixteen patches: 30 instead of 18 -- scripts/gpu/r6_call28.sh), and they were three dispatches per patch
+__global__ void __launch_bounds__(256) k_fetch_take(const uint4 *__restrict__ src, uint4 *__restrict__ dst, unsigned n16, int *__restrict__ flag, int *__restrict__ flag_out) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+    if (flag && blockIdx.x == 0 && threadIdx.x == 0) *flag_out = atomicExch(flag, 0);
+}
 
 // ---- T5: stitch accumulator (update_temporal_parallel.m:264-280) ------------------------------------------------------------------
 // acc[row][t] += aa_m(j) * C_raw_m(j, t), row = ind_m[j]; the weight sum lives in column ld - 4 of the same row
@@ -491,14 +499,13 @@ cnmfe_ctx::~cnmfe_ctx() {
 // ---- execution lanes (common.hpp, cnmfe_lane) ----
 void cnmfe_ctx::swap_lane(cnmfe_lane &L) {
     std::swap(stream_, L.stream_); std::swap(pseg, L.pseg); std::swap(npseg, L.npseg); pin.swap(L.pin); std::swap(spatial_nnz, L.spatial_nnz);
-    for (int i = 0; i < 32; ++i) { vp[i].swap(L.vp[i]); std::swap(hw_vp[i], L.hw_vp[i]); }
+    for (int i = 0; i < 32; ++i) vp[i].swap(L.vp[i]);          // (the high-water sizes hw_* stay with the context: what one lane's patches needed, the other lanes' buffers get at once)
     std::swap(last_ldc, L.last_ldc);
     ysig_low.swap(L.ysig_low); up_tmp.swap(L.up_tmp); bgs_r.swap(L.bgs_r); bgs_b.swap(L.bgs_b); bgs_upr.swap(L.bgs_upr); bgs_upc.swap(L.bgs_upc);
     std::swap(bgs_patch, L.bgs_patch); std::swap(bgs_d1s, L.bgs_d1s); std::swap(bgs_dF, L.bgs_dF);
     bf.swap(L.bf); dig_smax.swap(L.dig_smax); dig_rspart.swap(L.dig_rspart); dig_scale.swap(L.dig_scale); tdig.swap(L.tdig); tscale.swap(L.tscale); gk.swap(L.gk);
     win_items.swap(L.win_items); bf2.swap(L.bf2); outl_cnt.swap(L.outl_cnt); outl_sel.swap(L.outl_sel); cov.swap(L.cov); rowsum.swap(L.rowsum);
     for (int i = 0; i < 16; ++i) tmp[i].swap(L.tmp[i]);
-    std::swap(hw_cc, L.hw_cc); std::swap(hw_cm, L.hw_cm); for (int i = 0; i < 3; ++i) std::swap(hw_wa[i], L.hw_wa[i]);
     for (int i = 0; i < 7; ++i) inc[i].swap(L.inc[i]);
     for (int i = 0; i < 4; ++i) stg[i].swap(L.stg[i]);
     wcodes.swap(L.wcodes); solve_fill.swap(L.solve_fill); stage.swap(L.stage);
@@ -981,17 +988,24 @@ int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz) {
 // A ticket = an event behind the work queued so far.  The device error word travels with it: a caller that waits for its ticket only -- not for the
 // stream, cnmfe_synchronize -- still hears what the kernels in front of the ticket had to report (a ring over too many footprints, an inconsistent table)
 // before it uses what they computed.
-static int ticket_record(cnmfe_ctx *ctx, int64_t *ticket) {
+static int ticket_record(cnmfe_ctx *ctx, int64_t *ticket, const void *src = nullptr, void *dst_pinned = nullptr, size_t bytes = 0) {
     size_t t = 0;
     while (t < ctx->tickets.size() && ctx->ticket_busy[t]) ++t;
     if (t == ctx->tickets.size()) {
         hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->tickets.push_back(e); ctx->ticket_busy.push_back(0);
     }
-    if (ctx->errflag.p && t < cnmfe_ctx::TICKET_FLAGS) {
+    const bool flagged = ctx->errflag.p && t < cnmfe_ctx::TICKET_FLAGS;
+    if (flagged) {
         if (!ctx->ticket_flags) { CK(hipHostMalloc((void **)&ctx->ticket_flags, cnmfe_ctx::TICKET_FLAGS * sizeof(int), hipHostMallocDefault)); memset(ctx->ticket_flags, 0, cnmfe_ctx::TICKET_FLAGS * sizeof(int)); }
-        RET(ctx->ticket_dev.ensure(cnmfe_ctx::TICKET_FLAGS * sizeof(int)));
         ctx->ticket_flags[t] = 0;
+    }
+    if (bytes) {                                             // the download and the flag in one kernel (k_fetch_take): both ends 16-byte granular with room (DevBuf: 256 B, the caller's block: a power of two)
+        const unsigned n16 = (unsigned)((bytes + 15) / 16), nb = std::min<unsigned>((n16 + 255) / 256, 64);
+        hipLaunchKernelGGL(k_fetch_take, dim3(nb), dim3(256), 0, ctx->st(), (const uint4 *)src, (uint4 *)dst_pinned, n16, flagged ? ctx->errflag.as<int>() : (int *)nullptr,
+                           flagged ? ctx->ticket_flags + t : (int *)nullptr);
+    } else if (flagged) {
+        RET(ctx->ticket_dev.ensure(cnmfe_ctx::TICKET_FLAGS * sizeof(int)));
         hipLaunchKernelGGL(k_flag_take, dim3(1), dim3(1), 0, ctx->st(), ctx->errflag.as<int>(), ctx->ticket_dev.as<int>() + t);
         CK(hipMemcpyAsync(&ctx->ticket_flags[t], ctx->ticket_dev.as<int>() + t, sizeof(int), hipMemcpyDeviceToHost, ctx->st()));
     }
@@ -1007,8 +1021,8 @@ int cnmfe_update_spatial_fetch_async(cnmfe_ctx *ctx, float *A_out_pinned, int64_
     CK(hipSetDevice(ctx->device));
     RET(ctx->activate(ctx->spatial_lane));
     if (ctx->spatial_nnz < 0 || nnz != ctx->spatial_nnz) return fail(CNMFE_ESTATE, "no deferred spatial update of %lld values (last one: %lld)", (long long)nnz, (long long)ctx->spatial_nnz);
-    if (nnz) CK(hipMemcpyAsync(A_out_pinned, ctx->scr[6].p, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->st()));
-    return ticket_record(ctx, ticket);
+    // A_out_pinned: PINNED host memory (cnmfe_host_alloc) of at least nnz floats rounded up to 16 bytes -- the copy is a kernel writing through the mapping
+    return ticket_record(ctx, ticket, ctx->scr[6].p, A_out_pinned, (size_t)nnz * sizeof(float));
 }
 
 int cnmfe_ticket_wait(cnmfe_ctx *ctx, int64_t ticket) {

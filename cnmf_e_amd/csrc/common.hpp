@@ -49,6 +49,8 @@ struct DevBuf {
         // a buffer that GROWS gets half as much again: index lists and value arrays follow nnz(A) / nnz(IND), which creep up over the first iterations, and every
         // hipFree drains the device -- 0.8-0.9 ms of the host blocked inside an upload while the fit's kernels ran (host_trace, one rank's share of c4)
         const size_t grown = (p && bytes < (size_t(64) << 20)) ? std::max(bytes, cap + cap / 2) : bytes;       // (small buffers only: a table or a video that grows is not over-allocated)
+        static const bool trace_alloc_ = getenv("CNMFE_TRACE_ALLOC") != nullptr;          // (diagnostic: every re-allocation of a grown buffer on stderr -- hipFree drains the device)
+        if (trace_alloc_ && p) fprintf(stderr, "[alloc] grow %zu -> %zu bytes (hipFree + hipMalloc)\n", cap, grown);
         if (p) { pin_flush_range(p, cap); (void)hipFree(p); p = nullptr; cap = 0; }     // (an upload into the old allocation may still be held back)
         size_t want = (grown + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&p, want);

@@ -209,7 +209,8 @@ int cnmfe_update_spatial(cnmfe_ctx *ctx, int patch_id, int algorithm, int32_t K,
                          const int64_t *IND_colptr, const int32_t *IND_rowidx,
                          const float *sn, int32_t param, float *A_out);
 int cnmfe_update_spatial_fetch(cnmfe_ctx *ctx, float *A_out, int64_t nnz);
-/* the same fetch without the wait: the copy into PINNED host memory (cnmfe_host_alloc) is queued behind the sweeps and *ticket names the point of the
+/* the same fetch without the wait: the copy into PINNED host memory (cnmfe_host_alloc; a kernel writes it through the mapping, in 16-byte units: room for nnz floats
+ * rounded up to 16 bytes) is queued behind the sweeps and *ticket names the point of the
  * stream where it is complete; cnmfe_ticket_wait(ctx, ticket) waits for exactly that point (not for what was queued after it) and releases the ticket.
  * With several patches per context the host mirror queues patch m + 1 before it collects patch m, so the device never waits for the host's assembly
  * of A (update_spatial_parallel.m:324-334).  A kernel-raised error is reported by the next waiting call of the context, not by the ticket. */
