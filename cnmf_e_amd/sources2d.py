@@ -20,6 +20,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 
 import ctypes
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -1147,7 +1148,12 @@ class Sources2D:
                 from . import hostops
                 self.A = hostops.circular_constraints_columns(self.A, v.d1, v.d2)
             self._update_b0_new()
-            self._prefetch_search_location()                               # the NEXT spatial update's masks depend on this A only
+            # the NEXT spatial update's masks depend on this A only: their thread starts under the temporal update's blocking (GIL-free) sweep call, not here, where its
+            # Python would share the GIL with the temporal set-up the device is waiting for (CNMFE_PREFETCH_EARLY=1: at once, as until round 6)
+            if os.environ.get("CNMFE_PREFETCH_EARLY", "0") == "1":
+                self._prefetch_search_location()
+            else:
+                self._prefetch_wanted = True
             return
         if whole_result is not None:
             A_ = whole_result
@@ -1181,6 +1187,11 @@ class Sources2D:
         the spatial -> temporal hand-over where the device idles)"""
         v = self.video
         return self.engine.post_process_spatial(A_, v.d1, v.d2)
+
+    def _start_wanted_prefetch(self):
+        if getattr(self, "_prefetch_wanted", False):
+            self._prefetch_wanted = False
+            self._prefetch_search_location()
 
     def _prefetch_search_location(self):
         """The search mask of the NEXT spatial update depends on A only, which the background update leaves alone: build it
@@ -1385,14 +1396,14 @@ class Sources2D:
                 jobs.append((eng.hals_temporal_job(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options if o.deconv_flag else None), ind))
                 continue
             elif o.deconv_flag:                                                                       # :106-110
+                self._start_wanted_prefetch()
                 eng.hals_temporal_deconv(v.pid[idx], A_pp, C_patch, o.maxIter, o.deconv_options, want_all=None)
             else:
+                self._start_wanted_prefetch()
                 eng.hals_temporal(v.pid[idx], A_pp, C_patch, o.maxIter, want_C=False, want_raw=False)  # :180-181
             eng.stitch_add(ind)                                                                       # :274-275
         if jobs:
-            if getattr(self, "_prefetch_wanted", False):
-                self._prefetch_wanted = False
-                self._prefetch_search_location()                           # host thread under the (GIL-free) sweep / stitch / fit calls that follow
+            self._start_wanted_prefetch()                                  # host thread under the (GIL-free) sweep / stitch / fit calls that follow
             eng.temporal_jobs_sweep()
             for job, ind in jobs:
                 eng.stitch_add_job(job, ind)                                                          # :274-275
