@@ -1,8 +1,12 @@
 #!/bin/bash
-# one rank's share with the collectives' host side: the round's gather (one collective, whole-A post-process) against the previous one (git stash of sources2d.py kept as sources2d_prev.py is NOT shipped: A/B by env)
-cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-timeout 250 python scripts/rank_load.py --world 8 --steps 20 --force-collectives 2>&1 | grep -a "^rank" | cut -c1-220
+# round 6, call 14: the matrix-vector product with DPP row sums and one barrier -- accuracy, then phase probes at c3
+mkdir -p gpurun_out/r06
+o=gpurun_out/r06/solve_inv_call14.txt
+for c in small c3; do
+  echo "== $c"; timeout 600 python scripts/probes/solve_inv/check_gpu.py --cfg $c --modes 0,2,1 2>&1 | grep -v amdgpu.ids | grep -v "^   pixel"
+done > $o 2>&1
+for pr in 544 576 640 528; do
+  echo "== c3 probe $pr (32: set-up + loads, 64: + matrix pipe, 128: + small inversion, 16: no ridge series; +512 statistics)" >> $o
+  timeout 600 python scripts/probes/solve_inv/check_gpu.py --cfg c3 --probe $pr --modes 2 2>&1 | grep -v amdgpu.ids | grep "mode 2 fit [01]" >> $o
 done
-timeout 250 python scripts/rank_load.py --world 8 --steps 20 2>&1 | grep -a "^rank" | cut -c1-220
-CNMFE_BENCH_FORCE_COLLECTIVES=1 timeout 280 python bench.py --config c4 --steps 10 --warmup 4 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c4 forced collectives', d['ms_per_step'])"
+cat $o

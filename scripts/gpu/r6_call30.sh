@@ -1,10 +1,8 @@
 #!/bin/bash
-# the search-mask thread at the end of the spatial update (CNMFE_PREFETCH_EARLY=1, rounds 3-6) against under the temporal sweep call: the headline, alternating
-cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do for e in 1 0; do
-CNMFE_PREFETCH_EARLY=$e timeout 200 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
-import sys,json
-for line in sys.stdin:
-    if line.startswith('{'):
-        d=json.loads(line); print('c3 prefetch early=$e:', round(d['ms_per_step'],3), 'kernel sum', d.get('kernel_sum_ms_per_step'))"
-done; done
+# round 6, call 30: kernel timeline of one rank's share of c4 (two patches) -- where the 2 ms between kernel sum and iteration time go
+export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/gp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o g -- python $GRAFT_REPO_ROOT/scripts/rank_load.py --steps 4 > /tmp/gp.out 2>/tmp/gp.err
+f=$(find /tmp/gp -name '*kernel_trace.csv' | head -1)
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r06
+python $GRAFT_REPO_ROOT/scripts/gap_analysis.py $f seq 2 > $GRAFT_REPO_ROOT/gpurun_out/r06/gap_rank_load.txt
+head -22 $GRAFT_REPO_ROOT/gpurun_out/r06/gap_rank_load.txt; tail -3 /tmp/gp.out
