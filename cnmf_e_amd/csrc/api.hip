@@ -583,11 +583,16 @@ cnmfe_ctx *cnmfe_create(int device) {
     cnmfe_ctx *ctx = new cnmfe_ctx();
     ctx->device = device;
     if (hipStreamCreate(&ctx->stream_) != hipSuccess) { fail(CNMFE_EHIP, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    // the download stream of the lazy traces and its events now, not inside the first temporal update (creating a stream is a new hardware queue: 20-25 ms of the first
+    // iteration after an upload went there, scripts/gpu/r6_call32.sh)
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_bound_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_copy_done, hipEventDisableTiming) != hipSuccess) { fail(CNMFE_EHIP, "copy stream / events could not be created"); delete ctx; return nullptr; }
     pin_register(ctx, true);
     if (ctx->pin.init(size_t(64) << 20) != 0) { fail(CNMFE_EHIP, "pinned staging arena (64 MB) could not be allocated"); delete ctx; return nullptr; }
     // every translation unit's code object is loaded now, not at the first launch of one of its kernels inside the first iteration (tens of milliseconds in all)
     hipLaunchKernelGGL(k_scratch_warm, dim3(1), dim3(64), 0, ctx->stream_, (int *)nullptr, 3);
-    (void)hipStreamSynchronize(ctx->stream_); (void)hipGetLastError();
+    hipLaunchKernelGGL(k_scratch_warm, dim3(1), dim3(64), 0, ctx->copy_stream, (int *)nullptr, 3);      // (a stream gets its hardware queue at its first use)
+    (void)hipStreamSynchronize(ctx->stream_); (void)hipStreamSynchronize(ctx->copy_stream); (void)hipGetLastError();
     (void)tu_warm_resid(); (void)tu_warm_bg(); (void)tu_warm_factor(); (void)tu_warm_deconv(); (void)tu_warm_ssub(); (void)tu_warm_vproj();
     // CNMFE_OPTS="name=value,name=value": tunables of cnmfe_set_option preset for every context of the process (A/B runs of the test suite and the bench
     // without touching their code); names this build does not know are ignored -- the same environment serves builds with different option sets
