@@ -562,6 +562,8 @@ static int lanes_set(cnmfe_ctx *ctx, int64_t n) {
         CK(hipEventCreateWithFlags(&L->ev, hipEventDisableTiming));
         if (l == 0) continue;                                // (lane 0 is the active one: its members are the context's own)
         CK(hipStreamCreate(&L->stream_));
+        hipLaunchKernelGGL(k_scratch_warm, dim3(1), dim3(64), 0, L->stream_, (int *)nullptr, 3);       // (its hardware queue now, not inside the first update)
+        CK(hipStreamSynchronize(L->stream_));
         if (L->pin.init(size_t(64) << 20) != 0) return fail(CNMFE_EHIP, "pinned staging arena (64 MB) of lane %d could not be allocated", l);
     }
     CK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
