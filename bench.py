@@ -503,6 +503,8 @@ def main():
                 planes = 4
                 if name == "temporal_proj_B" and eng.get_option("proj_i8", 1) and eng.get_option("proj_i8_planes", 3) < 4:
                     planes = 3
+                if name == "bg_win_proj" and eng.get_option("win_i8", 1) and eng.get_option("gram_i8", 1) and eng.get_option("win_i8_planes", 0) != 4 and T >= 2048:
+                    planes = 3                                  # (the fit's window projection too, since the end of round 6: option win_i8_planes, default 3)
                 by = float(planes) * d_b * T + 4.0 * K * T
                 ms = kern[name]["ms_per_step"]                  # (one projection per iteration, possibly split into launches by list length)
                 out[name] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,

@@ -634,7 +634,7 @@ int cnmfe_synchronize(cnmfe_ctx *ctx) {
 int cnmfe_set_option(cnmfe_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return fail(CNMFE_EINVAL, "null argument");
     // behaviour switches (include/cnmfe.h) and, behind them, the probes of scripts/ (diagnostics: solve_probe, r1_probe, deconv_trace, host_trace, debug)
-    static const char *known[] = {"r1_variant", "r1_delta", "r1_lazy", "r1_defer", "r1_virtual", "gram_incremental", "prealloc", "solve_packed", "sweep_dag", "solve_staged", "solve_inv", "solve_inv_terms", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "proj_i8_planes", "ssub_virtual",
+    static const char *known[] = {"r1_variant", "r1_delta", "r1_lazy", "r1_defer", "r1_virtual", "gram_incremental", "prealloc", "solve_packed", "sweep_dag", "win_i8_planes", "solve_staged", "solve_inv", "solve_inv_terms", "gram_i8", "win_i8", "proj_tiled", "proj_i8", "proj_i8_planes", "ssub_virtual",
                                   "solve_probe", "r1_probe", "deconv_trace", "host_trace", "debug", nullptr};
     if (!strcmp(name, "lanes")) { RET(lanes_set(ctx, value)); ctx->opts[name] = value; return 0; }
     for (int i = 0; known[i]; ++i) if (!strcmp(known[i], name)) { ctx->opts[name] = value; if (!strcmp(name, "host_trace")) ctx->trace_level = (int)value; return 0; }

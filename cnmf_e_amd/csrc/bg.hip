@@ -18,6 +18,14 @@
 #include <type_traits>
 
 namespace cnmfe {
+// option win_i8_planes: 0 (default) = three digit planes of the video in the window projection when the sums run over at least 2048 frames (the rounding of a sample to
+// 2^-23 of its pixel's largest value averages out with the number of frames: W 5e-7 .. 9e-7 of the oracle's at T = 3000 .. 20000), four for shorter recordings (T = 96:
+// A moved by 2.2e-6, above the tests' 2e-6 -- and a short recording's projection costs microseconds either way); 3 / 4 force the choice
+static inline bool win_planes3(cnmfe_ctx *ctx, int64_t T16) {
+    const int64_t o = ctx->opt("win_i8_planes", 0);
+    return o == 3 || (o != 4 && T16 * 16 >= 2048);
+}
+
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
@@ -880,8 +888,9 @@ int bg_fit_ring(cnmfe_ctx *ctx, Patch *P, int32_t K, const int64_t *A_colptr, co
             }
             RET(to_dev(ctx, ctx->win_items, items.data(), items.size()));
             if (!items.empty())
-                LAUNCH(ctx, "bg_win_proj", k_win_proj_i8, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
-                       ctx->tscale.as<double>(), dLp.as<int>(), dLk.as<int>(), ctx->win_items.as<int>(), nsg, dUt.as<double>(), ut_stride);
+                if (win_planes3(ctx, T16)) { LAUNCH(ctx, "bg_win_proj", k_win_proj_i8<1>, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
+                       ctx->tscale.as<double>(), dLp.as<int>(), dLk.as<int>(), ctx->win_items.as<int>(), nsg, dUt.as<double>(), ut_stride); } else { LAUNCH(ctx, "bg_win_proj", k_win_proj_i8<0>, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
+                       ctx->tscale.as<double>(), dLp.as<int>(), dLk.as<int>(), ctx->win_items.as<int>(), nsg, dUt.as<double>(), ut_stride); }
             win_i8 = true;
         } else if (g.kstride == 1 || g.kstride == 2 || g.kstride == 4) {
             const int nbig = (int)blk_nt[3].size();              // blall starts with the longest lists
@@ -1332,8 +1341,9 @@ int win_i8_table(cnmfe_ctx *ctx, Patch *P, const char *name_dig, const char *nam
     }
     RET(to_dev(ctx, ctx->win_items, items.data(), items.size()));
     if (!items.empty())
-        LAUNCH(ctx, name_proj, k_win_proj_i8, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
-               ctx->tscale.as<double>(), dLp, dLk, ctx->win_items.as<int>(), nsg, dUt, ut_stride);
+        if (win_planes3(ctx, T16)) { LAUNCH(ctx, name_proj, k_win_proj_i8<1>, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
+               ctx->tscale.as<double>(), dLp, dLk, ctx->win_items.as<int>(), nsg, dUt, ut_stride); } else { LAUNCH(ctx, name_proj, k_win_proj_i8<0>, dim3((unsigned)(items.size() * nsg)), dim3(512), 0, P->dig.as<uint4>(), T16, P->dig_sc.as<double>(), ctx->tdig.as<uint4>(),
+               ctx->tscale.as<double>(), dLp, dLk, ctx->win_items.as<int>(), nsg, dUt, ut_stride); }
     return 0;
 }
 

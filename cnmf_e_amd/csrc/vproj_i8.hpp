@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_vp_bdig(const double *__restrict__ Bt, 
 // frame lane & 15) scaled into the partial rows part[(l0 + slot) * ldp + 16 fg + f] (a wave instruction writes 16 consecutive frames of four slots)
 // V0 = 1 (round 6, option proj_i8_planes = 3, the default): the video's lowest digit plane is neither loaded nor multiplied -- 24-bit samples (the rounding of a
 // pixel's centred trace to 2^-23 of its largest value, the precision its fp32 samples have around a mean of that size anyway), 3/4 of the bytes, 11 of the 13 MFMAs.
-// The regression's window projection (win_proj_i8.hpp) keeps all four planes: its sums go through systems of condition 1e5.
+// The regression's window projection (win_proj_i8.hpp) reads three planes too since the end of round 6 (win_i8_planes): W stays within the tests' 2e-6 of the oracle.
 template <int NT, int V0>
 __global__ void __launch_bounds__(256) k_vp_proj_i8(const uint4 *__restrict__ digp, int64_t T16, const int *__restrict__ blk_list, const int *__restrict__ lst_ptr,
                                                     const int *__restrict__ g16, const uint4 *__restrict__ bdig, const double *__restrict__ bscale, int nseg,

@@ -434,6 +434,9 @@ int cnmfe_synchronize(cnmfe_ctx *ctx);
  *                     accumulation, up to 24576 used frames; 0: the fp64 matrix pipe
  *   win_i8            default 1: the digit planes stay resident (one more video's worth of memory, taken only when that leaves 8 GB free) and every fit's window
  *                     projection runs on the int8 pipe; 0: the fp64 kernel on the centred video
+ *   win_i8_planes     default 0 = 3 when the sums run over at least 2048 frames, else 4 (3 / 4 force it): the fit's window projection (and the all-frames table of a strided recording) reads the upper three digit planes of the video -- 24-bit
+ *                     samples, 3/4 of the bytes (1.93 -> 1.48 ms at 512 x 512 x 10000); W within 2e-6 of the float64 oracle's (observed 5e-7 .. 1.8e-6 of the largest
+ *                     weight; with all four planes, win_i8_planes = 4: 4e-8 .. 2e-7), A and C unchanged at ~1e-7
  *   proj_tiled / proj_i8   default 1 / 1: the temporal projection on the int8 pipe out of a pixel-major copy of the digit planes (needs win_i8), else out of a copy of
  *                     the centred video in its own read order (one video's worth either, same rule); 0 / 0: the frame-major video on the fp64 pipe.  The tables over ALL frames
  *                     (spatial update, temporal projection) sum inside frame segments of at most 24576 frames, recordings up to 16 x 24576 frames
